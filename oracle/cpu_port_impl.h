@@ -1,0 +1,259 @@
+/*
+ * cpu_port_impl.h -- TEST INFRASTRUCTURE ONLY.  Included twice by cpu_port.c with
+ * REAL = float / double and SUF = f32 / f64.
+ *
+ * O(N log N) CPU port of the same path dct_oracle.c states by definition: REDFT10/REDFT01
+ * (FFTW 3.3 manual definitions; reference call sites spec/spec.c:63, spec/ispec.c:165,
+ * scan/scan.c:292,359, motion/motion.c:535-552) through a mixed-radix complex FFT.
+ * Used (a) as the f64 checker at sizes where the O(N^2) definition is too slow, after being
+ * validated against it, and (b) as bench.py's `cpu_baseline` ("kind": "port").
+ */
+#define CAT2(a, b) a##_##b
+#define CAT(a, b) CAT2(a, b)
+#define FN(name) CAT(name, SUF)
+
+typedef struct { REAL re, im; } FN(cpx);
+#define CPX FN(cpx)
+
+typedef struct {
+	int n;            /* complex length */
+	int nfac, fac[40];
+	CPX *tw;          /* tw[k] = exp(-2 pi i k / n) */
+} FN(fftplan);
+#define FFTPLAN FN(fftplan)
+
+static void FN(fft_plan_init)(FFTPLAN *p, int n)
+{
+	p->n = n; p->nfac = 0;
+	int m = n;
+	while (m % 4 == 0) { p->fac[p->nfac++] = 4; m /= 4; }
+	while (m % 2 == 0) { p->fac[p->nfac++] = 2; m /= 2; }
+	for (int f = 3; m > 1; f += 2)
+		while (m % f == 0) { p->fac[p->nfac++] = f; m /= f; }
+	p->tw = malloc(sizeof(CPX) * (size_t)(n > 0 ? n : 1));
+	const long double tau = 6.283185307179586476925286766559005768L;
+	for (int k = 0; k < n; k++) {
+		p->tw[k].re = (REAL)cosl(tau * k / n);
+		p->tw[k].im = (REAL)-sinl(tau * k / n);
+	}
+}
+static void FN(fft_plan_free)(FFTPLAN *p) { free(p->tw); p->tw = NULL; }
+
+/* Decimation-in-time recursion: out[0..n) <- DFT of in[0], in[s], in[2s] ...; tws = n_total / n. */
+static void FN(fft_rec)(const FFTPLAN *P, const CPX *in, CPX *out, int n, int s, int level)
+{
+	if (n == 1) { *out = *in; return; }
+	const int p = P->fac[level], m = n / p;
+	for (int q = 0; q < p; q++)
+		FN(fft_rec)(P, in + (size_t)q * s, out + (size_t)q * m, m, s * p, level + 1);
+	const int tws = P->n / n;         /* twiddle stride: w_n^k = tw[k * tws] */
+	const CPX *tw = P->tw;
+	if (p == 2) {
+		for (int k = 0; k < m; k++) {
+			CPX a = out[k], b = out[k + m], w = tw[(size_t)k * tws];
+			REAL br = b.re * w.re - b.im * w.im, bi = b.re * w.im + b.im * w.re;
+			out[k].re = a.re + br; out[k].im = a.im + bi;
+			out[k + m].re = a.re - br; out[k + m].im = a.im - bi;
+		}
+	} else if (p == 4) {
+		for (int k = 0; k < m; k++) {
+			CPX a = out[k], b = out[k + m], c = out[k + 2 * m], d = out[k + 3 * m];
+			CPX w1 = tw[(size_t)k * tws], w2 = tw[(size_t)2 * k * tws], w3 = tw[(size_t)3 * k * tws];
+			REAL br = b.re * w1.re - b.im * w1.im, bi = b.re * w1.im + b.im * w1.re;
+			REAL cr = c.re * w2.re - c.im * w2.im, ci = c.re * w2.im + c.im * w2.re;
+			REAL dr = d.re * w3.re - d.im * w3.im, di = d.re * w3.im + d.im * w3.re;
+			REAL s0r = a.re + cr, s0i = a.im + ci, s1r = a.re - cr, s1i = a.im - ci;
+			REAL s2r = br + dr, s2i = bi + di, s3r = br - dr, s3i = bi - di;
+			out[k].re = s0r + s2r;         out[k].im = s0i + s2i;
+			out[k + m].re = s1r + s3i;     out[k + m].im = s1i - s3r;     /* -i * s3 */
+			out[k + 2 * m].re = s0r - s2r; out[k + 2 * m].im = s0i - s2i;
+			out[k + 3 * m].re = s1r - s3i; out[k + 3 * m].im = s1i + s3r;
+		}
+	} else {
+		/* generic odd radix: p-point DFT of the twiddled sub-results, O(p^2) */
+		CPX t[64];
+		CPX *tt = p <= 64 ? t : malloc(sizeof(CPX) * p);
+		for (int k = 0; k < m; k++) {
+			for (int q = 0; q < p; q++) {
+				CPX v = out[k + (size_t)q * m], w = tw[((size_t)q * k * tws) % P->n];
+				tt[q].re = v.re * w.re - v.im * w.im; tt[q].im = v.re * w.im + v.im * w.re;
+			}
+			for (int r = 0; r < p; r++) {
+				REAL ar = tt[0].re, ai = tt[0].im;
+				for (int q = 1; q < p; q++) {
+					CPX w = tw[((size_t)q * r * m * tws) % P->n];   /* w_p^{qr} = w_N^{qr N/p}, N/p = m*tws */
+					ar += tt[q].re * w.re - tt[q].im * w.im; ai += tt[q].re * w.im + tt[q].im * w.re;
+				}
+				out[k + (size_t)r * m].re = ar; out[k + (size_t)r * m].im = ai;
+			}
+		}
+		if (tt != t) free(tt);
+	}
+}
+
+/* Per-length DCT plan: half-length packing when N is even, full-length otherwise. */
+typedef struct {
+	int N, M;          /* M = complex FFT length (N/2 or N) */
+	int even;
+	FFTPLAN fft;
+	CPX *t4;           /* t4[k] = exp(-i pi k / 2N), k in [0, N] */
+	CPX *t1;           /* t1[k] = exp(-2 pi i k / N), k in [0, N/2] (even only) */
+	CPX *a, *b;        /* scratch, length M+1 */
+} FN(dctplan);
+#define DCTPLAN FN(dctplan)
+
+static void FN(dct_plan_init)(DCTPLAN *p, int N)
+{
+	p->N = N; p->even = (N % 2 == 0) && N >= 2; p->M = p->even ? N / 2 : N;
+	FN(fft_plan_init)(&p->fft, p->M);
+	const long double pi = 3.14159265358979323846264338327950288L;
+	p->t4 = malloc(sizeof(CPX) * (size_t)(N + 1));
+	for (int k = 0; k <= N; k++) { p->t4[k].re = (REAL)cosl(pi * k / (2.0L * N)); p->t4[k].im = (REAL)-sinl(pi * k / (2.0L * N)); }
+	p->t1 = malloc(sizeof(CPX) * (size_t)(N / 2 + 1));
+	for (int k = 0; k <= N / 2; k++) { p->t1[k].re = (REAL)cosl(2 * pi * k / N); p->t1[k].im = (REAL)-sinl(2 * pi * k / N); }
+	p->a = malloc(sizeof(CPX) * (size_t)(p->M + 1));
+	p->b = malloc(sizeof(CPX) * (size_t)(p->M + 1));
+}
+static void FN(dct_plan_free)(DCTPLAN *p) { FN(fft_plan_free)(&p->fft); free(p->t4); free(p->t1); free(p->a); free(p->b); }
+
+/* REDFT10 of x[0], x[xs], ... into y[0], y[ys], ... (in-place safe: x is fully read first). */
+static void FN(dct2_1d)(DCTPLAN *p, const REAL *x, ptrdiff_t xs, REAL *y, ptrdiff_t ys)
+{
+	const int N = p->N, M = p->M;
+	CPX *a = p->a, *b = p->b;
+	if (N == 1) { y[0] = 2 * x[0]; return; }
+	if (p->even) {
+		/* v[n]=x[2n], v[N-1-n]=x[2n+1]; z[m] = v[2m] + i v[2m+1] */
+		for (int m = 0; m < M; m++) {
+			int n0 = 2 * m, n1 = 2 * m + 1;
+			a[m].re = x[(ptrdiff_t)(n0 < M ? 2 * n0 : 2 * (N - 1 - n0) + 1) * xs];
+			a[m].im = x[(ptrdiff_t)(n1 < M ? 2 * n1 : 2 * (N - 1 - n1) + 1) * xs];
+		}
+		FN(fft_rec)(&p->fft, a, b, M, 1, 0);
+		b[M] = b[0];
+		for (int k = 0; k <= M / 2; k++) {
+			/* V[k] from Z[k], conj(Z[M-k]); then the quarter-sample twiddle */
+			for (int pass = 0; pass < 2; pass++) {
+				int kk = pass ? M - k : k;
+				if (pass && kk == k) break;
+				CPX zk = b[kk], zc = b[M - kk]; zc.im = -zc.im;
+				REAL er = (REAL)0.5 * (zk.re + zc.re), ei = (REAL)0.5 * (zk.im + zc.im);
+				REAL dr = (REAL)0.5 * (zk.re - zc.re), di = (REAL)0.5 * (zk.im - zc.im);
+				/* (d / i) = (di, -dr); times t1[kk] */
+				CPX w = p->t1[kk];
+				REAL orr = di * w.re + dr * w.im, oi = di * w.im - dr * w.re;
+				REAL vr = er + orr, vi = ei + oi;
+				CPX t = p->t4[kk];
+				REAL wr = vr * t.re - vi * t.im, wi = vr * t.im + vi * t.re;
+				y[(ptrdiff_t)kk * ys] = 2 * wr;
+				if (kk > 0) y[(ptrdiff_t)(N - kk) * ys] = -2 * wi;
+			}
+		}
+	} else {
+		const int h = (N + 1) / 2;
+		for (int n = 0; n < h; n++) { a[n].re = x[(ptrdiff_t)(2 * n) * xs]; a[n].im = 0; }
+		for (int n = 0; n < N / 2; n++) { a[N - 1 - n].re = x[(ptrdiff_t)(2 * n + 1) * xs]; a[N - 1 - n].im = 0; }
+		FN(fft_rec)(&p->fft, a, b, N, 1, 0);
+		for (int k = 0; k < N; k++) {
+			CPX t = p->t4[k];
+			y[(ptrdiff_t)k * ys] = 2 * (b[k].re * t.re - b[k].im * t.im);
+		}
+	}
+}
+
+/* REDFT01 */
+static void FN(dct3_1d)(DCTPLAN *p, const REAL *x, ptrdiff_t xs, REAL *y, ptrdiff_t ys)
+{
+	const int N = p->N, M = p->M;
+	CPX *a = p->a, *b = p->b;
+	if (N == 1) { y[0] = x[0]; return; }
+	if (p->even) {
+		/* V[k] = conj(t4[k]) (X[k] - i X[N-k]), k = 0..M, X[N] := 0 */
+		for (int k = 0; k <= M; k++) {
+			REAL xr = x[(ptrdiff_t)k * xs], xi = k ? -x[(ptrdiff_t)(N - k) * xs] : 0;
+			CPX t = p->t4[k];
+			b[k].re = xr * t.re + xi * t.im; b[k].im = xi * t.re - xr * t.im;
+		}
+		/* Z[k] = (V[k] + conj V[M-k]) + i conj(t1[k]) (V[k] - conj V[M-k]); z = conj(FFT(conj Z)) */
+		for (int k = 0; k < M; k++) {
+			CPX vk = b[k], vc = b[M - k]; vc.im = -vc.im;
+			REAL sr = vk.re + vc.re, si = vk.im + vc.im, dr = vk.re - vc.re, di = vk.im - vc.im;
+			CPX w = p->t1[k];
+			REAL wr = w.re, wi = -w.im;                       /* conj(t1[k]) = exp(+2 pi i k/N) */
+			REAL pr = dr * wr - di * wi, pi_ = dr * wi + di * wr;   /* (V - conjV) * e */
+			a[k].re = sr - pi_; a[k].im = -(si + pr);          /* conj( s + i p ) */
+		}
+		FN(fft_rec)(&p->fft, a, b, M, 1, 0);
+		for (int m = 0; m < M; m++) {
+			REAL v0 = b[m].re, v1 = -b[m].im;
+			int n0 = 2 * m, n1 = 2 * m + 1;
+			y[(ptrdiff_t)(n0 < M ? 2 * n0 : 2 * (N - 1 - n0) + 1) * ys] = v0;
+			y[(ptrdiff_t)(n1 < M ? 2 * n1 : 2 * (N - 1 - n1) + 1) * ys] = v1;
+		}
+	} else {
+		/* v[n] = Re sum_k V[k] e^{+2 pi i k n/N}, V hermitian; use forward FFT of conj */
+		for (int k = 0; k < N; k++) {
+			REAL xr = x[(ptrdiff_t)k * xs], xi = k ? -x[(ptrdiff_t)(N - k) * xs] : 0;
+			CPX t = p->t4[k];
+			a[k].re = xr * t.re + xi * t.im; a[k].im = -(xi * t.re - xr * t.im);
+		}
+		FN(fft_rec)(&p->fft, a, b, N, 1, 0);
+		const int h = (N + 1) / 2;
+		for (int n = 0; n < h; n++) y[(ptrdiff_t)(2 * n) * ys] = b[n].re;
+		for (int n = 0; n < N / 2; n++) y[(ptrdiff_t)(2 * n + 1) * ys] = b[N - 1 - n].re;
+	}
+}
+
+/*
+ * plan_many_r2r + execute semantics (see dct_oracle.c), threads = OpenMP threads to use.
+ * Works axis by axis in place on `out` after an initial strided copy in->out.
+ */
+int FN(cpu_port_r2r_many)(int rank, const int *n, int howmany,
+                          const REAL *in, const int *inembed, int istride, int idist,
+                          REAL *out, const int *onembed, int ostride, int odist,
+                          const int *kinds, int threads)
+{
+	if (rank < 1 || rank > 3) return -1;
+	int dims[3] = {1, 1, 1}, ie[3] = {1, 1, 1}, oe[3] = {1, 1, 1}, kd[3] = {0, 0, 0};
+	for (int a = 0; a < rank; a++) {
+		int s = 3 - rank + a;
+		dims[s] = n[a]; ie[s] = inembed ? inembed[a] : n[a]; oe[s] = onembed ? onembed[a] : n[a]; kd[s] = kinds[a];
+		if (kd[s] != 4 && kd[s] != 5) return -1;
+	}
+	if (threads < 1) threads = 1;
+	ptrdiff_t is[3] = {(ptrdiff_t)istride * ie[1] * ie[2], (ptrdiff_t)istride * ie[2], istride};
+	ptrdiff_t os[3] = {(ptrdiff_t)ostride * oe[1] * oe[2], (ptrdiff_t)ostride * oe[2], ostride};
+	int first = 1;
+	for (int ax = 2; ax >= 0; ax--) {
+		if (!kd[ax]) continue;
+		const int N = dims[ax], o1 = (ax + 1) % 3, o2 = (ax + 2) % 3;
+		const REAL *src = first ? in : out;
+		const ptrdiff_t *ss = first ? is : os;
+		const ptrdiff_t sdist = first ? idist : odist;
+		const long lines = (long)howmany * dims[o1] * dims[o2];
+		#pragma omp parallel num_threads(threads)
+		{
+			DCTPLAN P; FN(dct_plan_init)(&P, N);
+			REAL *tmp = malloc(sizeof(REAL) * (size_t)N);
+			#pragma omp for schedule(static)
+			for (long l = 0; l < lines; l++) {
+				long t = l / ((long)dims[o1] * dims[o2]), r = l % ((long)dims[o1] * dims[o2]);
+				long p = r / dims[o2], q = r % dims[o2];
+				const REAL *x = src + t * sdist + p * ss[o1] + q * ss[o2];
+				REAL *y = out + t * odist + p * os[o1] + q * os[o2];
+				if (kd[ax] == 5) FN(dct2_1d)(&P, x, ss[ax], tmp, 1); else FN(dct3_1d)(&P, x, ss[ax], tmp, 1);
+				for (int k = 0; k < N; k++) y[(ptrdiff_t)k * os[ax]] = tmp[k];
+			}
+			free(tmp); FN(dct_plan_free)(&P);
+		}
+		first = 0;
+	}
+	return 0;
+}
+
+#undef CPX
+#undef FFTPLAN
+#undef DCTPLAN
+#undef FN
+#undef CAT
+#undef CAT2
