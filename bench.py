@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark (BASELINE.json): Mpixels/s of the DCT-II + DCT-III roundtrip on
+3840x2160x3 f32 frames, device-resident, as a fraction of the MI355X HBM roofline.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ...`, one rank per GPU)
+
+A "step" = one roundtrip (2-D REDFT10 in place, then 2-D REDFT01 in place with the 1/(4wh) gain
+fused) over a batch of FRAMES independent frames per GPU -- the per-frame plan of spec/spec.c:63 +
+spec/ispec.c:165, and what motion's default `-b 0x0x1` runs per frame (motion/motion.c:174,613-753).
+Frames are independent units, so ranks shard them with no data-path collective (weak scaling).
+
+One JSON line on stdout (rank 0).  roofline.* describes the dominant kernel, timed with HIP events on
+the launch stream (torch's current stream -- the library launches on the stream handle it is given).
+cpu_baseline is the oracle's O(N log N) CPU port (oracle/cpu_port.c, "kind": "port"), timed on the
+host cores of the same box on a bounded sample; it is a reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W, C = 2160, 3840, 3
+ALG_BYTES_PER_PIXEL = 48.0        # 16 B/sample roundtrip = 48 B/pixel
+HBM_PEAK = 8.0e12                 # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy ceiling)
+SEED = 0xD5F0002
+
+
+def synth_frames(torch, nframes, device):
+    """splitmix64-seeded uniform [0,1) f32 (state advances once per sample,
+    f32 = (u >> 40) * 2^-24), generated on the host and copied to the device."""
+    import numpy as np
+    n = H * W * C
+    out = torch.empty((nframes, H, W, C), dtype=torch.float32, device=device)
+    idx = np.arange(1, n + 1, dtype=np.uint64)
+    for f in range(nframes):
+        with np.errstate(over="ignore"):
+            z = np.uint64(SEED + f) + idx * np.uint64(0x9E3779B97F4A7C15)
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z = z ^ (z >> np.uint64(31))
+        x = (z >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -24)
+        out[f] = torch.from_numpy(x.reshape(H, W, C)).to(device)
+    return out
+
+
+def cpu_baseline(max_seconds=30.0):
+    """Oracle CPU port (f32, all host cores) on one full 3840x2160x3 roundtrip, repeated while the
+    budget allows.  Only this leg of bench.py touches oracle/."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as ol
+    threads = max(1, min(ol.lib().cpu_port_max_threads(), os.cpu_count() or 1))
+    x = ol.synth_f32(SEED, H * W * C)
+    n, kinds2, kinds3 = [H, W], [ol.REDFT10] * 2, [ol.REDFT01] * 2
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        f = ol.r2r_many(x, n, kinds2, howmany=C, istride=C, idist=1, ostride=C, odist=1, impl="port", threads=threads)
+        b = ol.r2r_many(f, n, kinds3, howmany=C, istride=C, idist=1, ostride=C, odist=1, impl="port", threads=threads)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or el * (reps + 1) / reps > max_seconds or reps >= 8:
+            break
+    err = float(np.abs(b / np.float32(4.0 * W * H) - x).max())
+    return {"value": round(reps * H * W / 1e6 / el, 3), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} roundtrip(s) of one 3840x2160x3 f32 frame, oracle/cpu_port.c with {threads} OpenMP threads "
+                      f"(roundtrip max abs err {err:.1e})"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--frames", type=int, default=4, help="independent frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible", file=sys.stderr)
+        sys.exit(2)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from dspfun_amd import Plan, REDFT10, REDFT01
+    fwd = Plan.image(H, W, C, REDFT10)
+    inv = Plan.image(H, W, C, REDFT01).set_scale(1.0 / (4.0 * W * H))
+    frames = synth_frames(torch, args.frames, dev)
+    ref0 = frames[0].clone()
+    stream = torch.cuda.current_stream().cuda_stream
+    ptrs = [frames[f].data_ptr() for f in range(args.frames)]
+
+    def step():
+        for p in ptrs:
+            fwd.execute(p, stream=stream)
+            inv.execute(p, stream=stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # correctness of what was timed: after (warmup+steps) roundtrips the frame is still the input
+    drift = float((frames[0] - ref0).abs().max())
+
+    # per-kernel durations (HIP events on the launch stream), on rank 0
+    roof = None
+    if rank == 0:
+        names, times = [], []
+        reps = 22
+        for plan, tag in ((fwd, "redft10"), (inv, "redft01")):
+            desc = [ln for ln in plan.describe().splitlines() if ln.startswith("axis")]
+            for i in range(plan.num_passes):
+                ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+                for a, b in ev:
+                    a.record()
+                    plan.execute_pass(i, ptrs[0], stream=stream)
+                    b.record()
+                torch.cuda.synchronize()
+                ms = [a.elapsed_time(b) for a, b in ev][2:]                  # first two launches warm the caches
+                times.append(sum(ms) / len(ms))
+                names.append(f"{tag} {desc[i].split(':')[1].split()[0]} pass ({desc[i].strip()})")
+        frames[0].copy_(ref0)
+        k = max(range(len(times)), key=lambda i: times[i])
+        # algorithmic bytes of ONE launch: the 48 B/pixel roundtrip figure is 4 axis passes of 12 B/pixel each
+        alg = H * W * ALG_BYTES_PER_PIXEL / 4.0
+        achieved = alg / (times[k] * 1e-3)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("dominant_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
+                "kernel": names[k], "kernel_ms": round(times[k], 5),
+                "all_kernels_ms": {names[i]: round(times[i], 5) for i in range(len(times))},
+                "algorithmic_bytes_per_launch": alg}
+
+    if rank == 0:
+        pixels = args.steps * args.frames * world * H * W
+        value = pixels / 1e6 / elapsed
+        line = {
+            "metric": "Mpixels/s DCT-II+III roundtrip 3840x2160x3", "value": round(value, 2), "unit": "Mpixels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic (splitmix64 uniform [0,1), SURVEY.md 8d seed 0xD5F0002)",
+            "config": {"workload": "spec + ispec roundtrip on 3840x2160 RGB float32 (BASELINE configs[1])",
+                       "frames_per_gpu_per_step": args.frames, "layout": "interleaved HWC, in place, device-resident",
+                       "parallelism": f"frame-sharded x{world}, no collective"},
+            "roundtrip_frac_of_hbm_roofline": round(value * 1e6 * ALG_BYTES_PER_PIXEL / HBM_PEAK, 4),
+            "roundtrip_max_abs_drift": drift,
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,62 @@
+"""ctypes binding of the C ABI declared in include/dspfft.h.
+
+The product library is dspfun_amd/csrc/libdspfft_hip.so (hand-written HIP kernels for gfx950).
+There is no CPU fallback: if the library is missing, load() raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdspfft_hip.so")
+
+REDFT01, REDFT10 = 4, 5
+
+#: every symbol include/dspfft.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "dspfft_plan_many_r2r", "dspfft_plan_r2r_2d", "dspfft_plan_set_scale", "dspfft_plan_set_axis_scale0",
+    "dspfft_execute", "dspfft_plan_num_passes", "dspfft_execute_pass", "dspfft_destroy_plan", "dspfft_plan_describe", "dspfft_plan_algorithmic_bytes",
+    "dspfft_last_error", "dspfft_version",
+    "dspfft_scan_zigzag", "dspfft_scan_scatter", "dspfft_accumulate", "dspfft_broadcast_dc",
+    "dspfft_u8_to_f32", "dspfft_f32_to_u8",
+]
+
+_lib = None
+
+
+def bind(lib):
+    """Attach argtypes/restypes to an already opened CDLL exporting the dspfft_* ABI."""
+    ip = C.POINTER(C.c_int)
+    vp = C.c_void_p
+    lib.dspfft_plan_many_r2r.argtypes = [C.POINTER(vp), C.c_int, ip, C.c_int, ip, C.c_int, C.c_int, ip, C.c_int, C.c_int, ip]
+    lib.dspfft_plan_r2r_2d.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.dspfft_plan_set_scale.argtypes = [vp, C.c_float]
+    lib.dspfft_plan_set_axis_scale0.argtypes = [vp, C.c_int, C.c_float, C.c_float]
+    lib.dspfft_execute.argtypes = [vp, vp, vp, vp]
+    lib.dspfft_plan_num_passes.argtypes = [vp]
+    lib.dspfft_execute_pass.argtypes = [vp, C.c_int, vp, vp, vp]
+    lib.dspfft_destroy_plan.argtypes = [vp]
+    lib.dspfft_destroy_plan.restype = None
+    lib.dspfft_plan_describe.argtypes = [vp, C.c_char_p, C.c_size_t]
+    lib.dspfft_plan_algorithmic_bytes.argtypes = [vp]
+    lib.dspfft_plan_algorithmic_bytes.restype = C.c_size_t
+    lib.dspfft_last_error.restype = C.c_char_p
+    lib.dspfft_version.restype = C.c_char_p
+    lib.dspfft_scan_zigzag.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, vp]
+    lib.dspfft_scan_scatter.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_int, vp]
+    lib.dspfft_accumulate.argtypes = [vp, vp, C.c_uint64, vp]
+    lib.dspfft_broadcast_dc.argtypes = [vp, vp, C.c_uint64, C.c_int, vp]
+    lib.dspfft_u8_to_f32.argtypes = [vp, vp, C.c_uint64, vp]
+    lib.dspfft_f32_to_u8.argtypes = [vp, vp, C.c_double, C.c_uint64, vp]
+    return lib
+
+
+def load():
+    """The HIP product library.  Raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  dspfun_amd has no CPU fallback.")
+        _lib = bind(C.CDLL(LIB_PATH))
+    return _lib

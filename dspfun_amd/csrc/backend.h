@@ -1,0 +1,35 @@
+// backend.h -- what the plan/engine layer needs from the device side.  The product links
+// backend_hip.hip (HIP kernels on gfx950).  tests/emul links a CPU emulation of the SAME phase
+// functions for CPU-only unit tests of the planner and kernel logic; that build is never shipped.
+#pragma once
+#include <stddef.h>
+#include "dct_core.h"
+
+namespace dspfft {
+
+struct LaunchGeom {
+	int nwg;          // workgroups
+	int nthr;         // threads per workgroup
+	size_t lds_bytes; // dynamic LDS
+	size_t raw_bytes; // ROW: offset of buf[] inside LDS (raw[] comes first)
+};
+
+void *be_alloc(size_t bytes);
+void be_free(void *p);
+int be_upload(void *dst, const void *src, size_t bytes);   // host -> device table upload (synchronous)
+size_t be_max_lds();                                        // usable LDS bytes per workgroup
+const char *be_name();
+
+int be_launch_row(const PassArgs &a, const LaunchGeom &g, void *stream);
+int be_launch_col(const PassArgs &a, const LaunchGeom &g, void *stream);
+int be_launch_dense(const DenseArgs &a, const LaunchGeom &g, void *stream);
+
+// elementwise helpers (dspfft.h, "device-side helpers")
+int be_scan_zigzag(uint32_t *lin, uint32_t w, uint32_t h, uint64_t first, uint64_t count, void *stream);
+int be_scan_scatter(float *recon, const float *coeffs, const uint32_t *lin, uint64_t count, uint64_t npixels, int channels, void *stream);
+int be_accumulate(float *sum, const float *image, uint64_t len, void *stream);
+int be_broadcast_dc(float *sum, const float *coeffs, uint64_t npixels, int channels, void *stream);
+int be_u8_to_f32(float *dst, const uint8_t *src, uint64_t len, void *stream);
+int be_f32_to_u8(uint8_t *dst, const float *src, double mul, uint64_t len, void *stream);
+
+}  // namespace dspfft

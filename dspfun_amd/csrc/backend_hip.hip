@@ -1,0 +1,214 @@
+// backend_hip.hip -- gfx950 (MI355X / CDNA4) kernels and launches behind backend.h.
+//
+// Generic (runtime-geometry) kernels: one workgroup per line (ROW), per column tile (COL) or per
+// signal (DENSE); the whole signal set of the workgroup stays in LDS between global load and global
+// store, so each pass moves exactly one read + one write of the array through HBM.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+
+#include "backend.h"
+#include "elementwise_core.h"
+
+namespace dspfft {
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+// ---------------------------------------------------------------------------------------------
+template <int KIND>
+__global__ void __launch_bounds__(256) row_kernel(const PassArgs a, const unsigned raw_bytes)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+	float *raw = reinterpret_cast<float *>(lds);
+	cf *buf = reinterpret_cast<cf *>(lds + raw_bytes);
+	const int tid = threadIdx.x, nthr = blockDim.x, L = a.N / 2;
+	long long bin, bout;
+	row_base(a, blockIdx.x, bin, bout);
+	row_load(a, raw, bin, tid, nthr);
+	__syncthreads();
+	for (int c0 = 0; c0 < a.C; c0 += a.Bg) {
+		if (KIND == KIND_REDFT10) row_pack2(a, raw, buf, c0, tid, nthr);
+		else row_pre3(a, raw, buf, c0, tid, nthr);
+		__syncthreads();
+		for (int s = 0; s < a.fft.ns; s++) {
+			fft_stage(buf, L, a.fft.st[s], a.Bg, a.divB, a.W, tid, nthr);
+			__syncthreads();
+		}
+		if (KIND == KIND_REDFT10) row_post2(a, raw, buf, c0, tid, nthr);
+		else row_unpack3(a, raw, buf, c0, tid, nthr);
+		__syncthreads();
+	}
+	row_store(a, raw, bout, tid, nthr);
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(512) col_kernel(const PassArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+	cf *buf = reinterpret_cast<cf *>(lds);
+	const int tid = threadIdx.x, nthr = blockDim.x;
+	long long bin, bout; int valid;
+	col_base(a, blockIdx.x, bin, bout, valid);
+	if (KIND == KIND_REDFT10) col_load2(a, buf, bin, valid, tid, nthr);
+	else col_pre3(a, buf, bin, valid, tid, nthr);
+	__syncthreads();
+	for (int s = 0; s < a.fft.ns; s++) {
+		fft_stage(buf, a.N, a.fft.st[s], a.B, a.divB, a.W, tid, nthr);
+		__syncthreads();
+	}
+	if (KIND == KIND_REDFT10) col_post2(a, buf, bout, valid, tid, nthr);
+	else col_unpack3(a, buf, bout, valid, tid, nthr);
+}
+
+__global__ void __launch_bounds__(256) dense_kernel(const DenseArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+	float *x = reinterpret_cast<float *>(lds);
+	long long bin, bout;
+	dense_base(a, blockIdx.x, bin, bout);
+	dense_load(a, x, bin, threadIdx.x, blockDim.x);
+	__syncthreads();
+	dense_compute(a, x, bout, threadIdx.x, blockDim.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void zigzag_kernel(uint32_t *lin, uint32_t w, uint32_t h, uint64_t first, uint64_t count)
+{
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x)
+		lin[i] = zigzag_lin(w, h, first + i);
+}
+__global__ void scatter_kernel(float *recon, const float *coeffs, const uint32_t *lin, uint64_t count, int ch)
+{
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t p = lin[i];
+		if (p) for (int z = 0; z < ch; z++) recon[p * ch + z] = coeffs[p * ch + z];
+	}
+}
+__global__ void accumulate_kernel(float *sum, const float *img, uint64_t len)
+{
+	const uint64_t n4 = len / 4;
+	float4 *s4 = reinterpret_cast<float4 *>(sum);
+	const float4 *i4 = reinterpret_cast<const float4 *>(img);
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x, t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+	for (uint64_t i = t; i < n4; i += stride) {
+		float4 a = s4[i]; const float4 b = i4[i];
+		a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; s4[i] = a;
+	}
+	for (uint64_t i = n4 * 4 + t; i < len; i += stride) sum[i] += img[i];
+}
+__global__ void accumulate_scalar_kernel(float *sum, const float *img, uint64_t len)
+{
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < len; i += (uint64_t)gridDim.x * blockDim.x) sum[i] += img[i];
+}
+__global__ void broadcast_kernel(float *sum, const float *c, uint64_t npix, int ch)
+{
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < npix * ch; i += (uint64_t)gridDim.x * blockDim.x) sum[i] = c[i % ch];
+}
+__global__ void u8_to_f32_kernel(float *d, const uint8_t *s, uint64_t len)
+{
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < len; i += (uint64_t)gridDim.x * blockDim.x) d[i] = (float)s[i];
+}
+__global__ void f32_to_u8_kernel(uint8_t *d, const float *s, double mul, uint64_t len)
+{
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < len; i += (uint64_t)gridDim.x * blockDim.x) d[i] = quantise_u8((double)s[i] * mul);
+}
+
+// ---------------------------------------------------------------------------------------------
+void *be_alloc(size_t bytes) { void *p = nullptr; if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return nullptr; return p; }
+void be_free(void *p) { if (p) (void)hipFree(p); }
+int be_upload(void *dst, const void *src, size_t bytes) { HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return 0; }
+size_t be_max_lds() { return 160 * 1024; }
+const char *be_name() { return "hip-gfx950"; }
+
+template <class K>
+static int allow_lds(K kernel, size_t bytes)
+{
+	if (bytes > 64 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+	return 0;
+}
+
+int be_launch_row(const PassArgs &a, const LaunchGeom &g, void *stream)
+{
+	hipStream_t s = (hipStream_t)stream;
+	if (a.kind == KIND_REDFT10) {
+		if (int rc = allow_lds(row_kernel<KIND_REDFT10>, g.lds_bytes)) return rc;
+		hipLaunchKernelGGL(row_kernel<KIND_REDFT10>, dim3(g.nwg), dim3(g.nthr), g.lds_bytes, s, a, (unsigned)g.raw_bytes);
+	} else {
+		if (int rc = allow_lds(row_kernel<KIND_REDFT01>, g.lds_bytes)) return rc;
+		hipLaunchKernelGGL(row_kernel<KIND_REDFT01>, dim3(g.nwg), dim3(g.nthr), g.lds_bytes, s, a, (unsigned)g.raw_bytes);
+	}
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+int be_launch_col(const PassArgs &a, const LaunchGeom &g, void *stream)
+{
+	hipStream_t s = (hipStream_t)stream;
+	if (a.kind == KIND_REDFT10) {
+		if (int rc = allow_lds(col_kernel<KIND_REDFT10>, g.lds_bytes)) return rc;
+		hipLaunchKernelGGL(col_kernel<KIND_REDFT10>, dim3(g.nwg), dim3(g.nthr), g.lds_bytes, s, a);
+	} else {
+		if (int rc = allow_lds(col_kernel<KIND_REDFT01>, g.lds_bytes)) return rc;
+		hipLaunchKernelGGL(col_kernel<KIND_REDFT01>, dim3(g.nwg), dim3(g.nthr), g.lds_bytes, s, a);
+	}
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+int be_launch_dense(const DenseArgs &a, const LaunchGeom &g, void *stream)
+{
+	if (int rc = allow_lds(dense_kernel, g.lds_bytes)) return rc;
+	hipLaunchKernelGGL(dense_kernel, dim3(g.nwg), dim3(g.nthr), g.lds_bytes, (hipStream_t)stream, a);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+static inline int ew_grid(uint64_t n) { uint64_t b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b)); }
+
+int be_scan_zigzag(uint32_t *lin, uint32_t w, uint32_t h, uint64_t first, uint64_t count, void *stream)
+{
+	if (!count) return 0;
+	hipLaunchKernelGGL(zigzag_kernel, dim3(ew_grid(count)), dim3(256), 0, (hipStream_t)stream, lin, w, h, first, count);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+int be_scan_scatter(float *recon, const float *coeffs, const uint32_t *lin, uint64_t count, uint64_t npixels, int ch, void *stream)
+{
+	HIPCHK(hipMemsetAsync(recon, 0, sizeof(float) * npixels * ch, (hipStream_t)stream));
+	if (!count) return 0;
+	hipLaunchKernelGGL(scatter_kernel, dim3(ew_grid(count)), dim3(256), 0, (hipStream_t)stream, recon, coeffs, lin, count, ch);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+int be_accumulate(float *sum, const float *img, uint64_t len, void *stream)
+{
+	if (!len) return 0;
+	if ((((uintptr_t)sum | (uintptr_t)img) & 15) == 0)
+		hipLaunchKernelGGL(accumulate_kernel, dim3(ew_grid(len / 4 + 1)), dim3(256), 0, (hipStream_t)stream, sum, img, len);
+	else
+		hipLaunchKernelGGL(accumulate_scalar_kernel, dim3(ew_grid(len)), dim3(256), 0, (hipStream_t)stream, sum, img, len);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+int be_broadcast_dc(float *sum, const float *c, uint64_t npix, int ch, void *stream)
+{
+	if (!npix) return 0;
+	hipLaunchKernelGGL(broadcast_kernel, dim3(ew_grid(npix * ch)), dim3(256), 0, (hipStream_t)stream, sum, c, npix, ch);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+int be_u8_to_f32(float *d, const uint8_t *s, uint64_t len, void *stream)
+{
+	if (!len) return 0;
+	hipLaunchKernelGGL(u8_to_f32_kernel, dim3(ew_grid(len)), dim3(256), 0, (hipStream_t)stream, d, s, len);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+int be_f32_to_u8(uint8_t *d, const float *s, double mul, uint64_t len, void *stream)
+{
+	if (!len) return 0;
+	hipLaunchKernelGGL(f32_to_u8_kernel, dim3(ew_grid(len)), dim3(256), 0, (hipStream_t)stream, d, s, mul, len);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+}  // namespace dspfft

@@ -1,0 +1,432 @@
+// engine.cpp -- plan construction and execution behind include/dspfft.h.
+//
+// Mirrors the contract of the FFTW calls the reference makes through `fftw(call)`
+// (reference include/precision.h:115): plan_many_r2r captures geometry (spec/spec.c:63,
+// spec/ispec.c:165, zoom/zoom.c:263, scan/scan.c:292,359, motion/motion.c:535-552), execute runs
+// it any number of times (scan/scan.c:447 runs one plan per output frame).  A plan is a list of
+// 1-D axis passes over device memory; each pass is one kernel launch (see dct_core.h).
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/dspfft.h"
+#include "backend.h"
+
+using namespace dspfft;
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, ...)
+{
+	va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+	return code;
+}
+extern "C" const char *dspfft_last_error(void) { return g_err; }
+extern "C" const char *dspfft_version(void) { return "dspfft 0.1 (gfx950)"; }
+
+namespace {
+
+struct Dim { int n; long long is, os; };
+
+const int kRadices[] = {16, 15, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
+
+// Smallest number of stages, then smallest sum of radices (less butterfly work / registers).
+bool factor_search(int L, int depth, int maxdepth, std::vector<int> &cur, std::vector<int> &best, int &bestsum, int minr)
+{
+	if (L == 1) {
+		int s = 0; for (int r : cur) s += r;
+		if (best.empty() || cur.size() < best.size() || (cur.size() == best.size() && s < bestsum)) { best = cur; bestsum = s; }
+		return true;
+	}
+	if (depth == maxdepth) return false;
+	bool ok = false;
+	for (int r : kRadices) {
+		if (r > minr) continue;          // non-increasing order: each multiset visited once
+		if (L % r) continue;
+		cur.push_back(r);
+		ok |= factor_search(L / r, depth + 1, maxdepth, cur, best, bestsum, r);
+		cur.pop_back();
+	}
+	return ok;
+}
+
+bool factorize(int L, std::vector<int> &radices)
+{
+	radices.clear();
+	if (L == 1) return true;
+	for (int maxdepth = 1; maxdepth <= 8; maxdepth++) {
+		std::vector<int> cur, best; int bestsum = 0;
+		if (factor_search(L, 0, maxdepth, cur, best, bestsum, 16)) {
+			// largest radix last: the last stage needs no twiddles
+			std::sort(best.begin(), best.end());
+			radices = best;
+			return true;
+		}
+	}
+	return false;
+}
+
+FastDiv make_div(uint32_t d)
+{
+	FastDiv f; f.d = d; f.mul = d >= 2 ? (uint32_t)((((uint64_t)1 << 32) + d - 1) / d) : 0; return f;
+}
+
+struct Tables {
+	void *T = nullptr, *W = nullptr, *pos = nullptr, *cosTab = nullptr;
+	void release() { be_free(T); be_free(W); be_free(pos); be_free(cosTab); T = W = pos = cosTab = nullptr; }
+};
+
+bool build_fft(int L, FftDesc &F, std::vector<uint32_t> &pos)
+{
+	std::vector<int> rad;
+	if (!factorize(L, rad)) return false;
+	F.L = L; F.ns = (int)rad.size();
+	int Lc = L;
+	for (int i = 0; i < F.ns; i++) {
+		StageDesc &S = F.st[i];
+		S.R = rad[i]; S.Lc = Lc; S.M1 = Lc / rad[i]; S.twstep = L / Lc; S.divM1 = make_div((uint32_t)S.M1);
+		Lc = S.M1;
+	}
+	// digit reversal: slot p = sum d_i * (L / (R_1..R_i)) holds output k = d_1 + R_1 (d_2 + R_2 (...))
+	pos.assign(L, 0);
+	for (int p = 0; p < L; p++) {
+		int rem = p, k = 0, mult = 1, span = L;
+		for (int i = 0; i < F.ns; i++) {
+			span /= rad[i];
+			int d = rem / span; rem -= d * span;
+			k += d * mult; mult *= rad[i];
+		}
+		pos[k] = (uint32_t)p;
+	}
+	return true;
+}
+
+struct Pass {
+	enum Type { ROW, COL, DENSE } type;
+	int axis;
+	bool first;
+	PassArgs pa;
+	DenseArgs da;
+	LaunchGeom g;
+	std::vector<Dim> hostloop;
+	Tables tab;
+	std::string desc;
+};
+
+}  // namespace
+
+struct dspfft_plan_s {
+	int rank, howmany;
+	int n[3], kinds[3];
+	Dim axes[3], batch;
+	float scale, in0[3], out0[3];
+	std::vector<Pass> passes;
+	size_t alg_bytes;
+};
+
+namespace {
+
+void merge_dims(std::vector<Dim> &d)
+{
+	std::sort(d.begin(), d.end(), [](const Dim &a, const Dim &b) { return a.os < b.os; });
+	for (size_t i = 0; i + 1 < d.size();) {
+		if (d[i + 1].is == d[i].n * d[i].is && d[i + 1].os == d[i].n * d[i].os) {
+			d[i].n *= d[i + 1].n; d.erase(d.begin() + i + 1);
+		} else i++;
+	}
+}
+
+int upload_tables(Pass &P, int N, int L, const std::vector<uint32_t> &pos)
+{
+	const long double pi = 3.14159265358979323846264338327950288L;
+	std::vector<cf> T(N + 1), W(std::max(L, 1));
+	for (int j = 0; j <= N; j++) T[j] = cmk((float)cosl(pi * j / (2.0L * N)), (float)-sinl(pi * j / (2.0L * N)));
+	for (int t = 0; t < L; t++) W[t] = cmk((float)cosl(2 * pi * t / L), (float)-sinl(2 * pi * t / L));
+	P.tab.T = be_alloc(T.size() * sizeof(cf));
+	P.tab.W = be_alloc(W.size() * sizeof(cf));
+	P.tab.pos = be_alloc(pos.size() * sizeof(uint32_t));
+	if (!P.tab.T || !P.tab.W || !P.tab.pos) return -1;
+	if (be_upload(P.tab.T, T.data(), T.size() * sizeof(cf))) return -1;
+	if (be_upload(P.tab.W, W.data(), W.size() * sizeof(cf))) return -1;
+	if (be_upload(P.tab.pos, pos.data(), pos.size() * sizeof(uint32_t))) return -1;
+	P.pa.T = (const cf *)P.tab.T; P.pa.W = (const cf *)P.tab.W; P.pa.pos = (const uint32_t *)P.tab.pos;
+	return 0;
+}
+
+std::string radix_string(const FftDesc &F)
+{
+	std::string s;
+	for (int i = 0; i < F.ns; i++) { if (i) s += "x"; s += std::to_string(F.st[i].R); }
+	return s.empty() ? "1" : s;
+}
+
+// Build the pass along transformed axis `a`.  `first` => reads the user's input strides.
+int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
+{
+	memset(&P.pa, 0, sizeof P.pa); memset(&P.da, 0, sizeof P.da); memset(&P.g, 0, sizeof P.g);
+	P.axis = a; P.first = first;
+	const int N = pl->n[a];
+	const int kind = pl->kinds[a] == DSPFFT_REDFT10 ? KIND_REDFT10 : KIND_REDFT01;
+	auto eff = [&](const Dim &d) { Dim e = d; if (!first) e.is = d.os; return e; };
+	const Dim ax = eff(pl->axes[a]);
+	std::vector<Dim> others;
+	for (int b = 0; b < pl->rank; b++) if (b != a && pl->n[b] > 1) others.push_back(eff(pl->axes[b]));
+	if (pl->howmany > 1) others.push_back(eff(pl->batch));
+	const size_t maxlds = be_max_lds();
+	char buf[256];
+
+	// ---------------- ROW ----------------
+	{
+		bool ok = (N % 2 == 0) && ax.is == ax.os && ax.is >= 1 && ax.is <= 4;
+		int C = (int)ax.is, cdim = -1;
+		if (ok && C > 1) {
+			ok = false;
+			for (size_t i = 0; i < others.size(); i++)
+				if (others[i].is == 1 && others[i].os == 1 && others[i].n == C) { cdim = (int)i; ok = true; }
+		}
+		FftDesc F; std::vector<uint32_t> pos;
+		if (ok) ok = build_fft(N / 2, F, pos);
+		if (ok) {
+			const int L = N / 2;
+			size_t raw_bytes = (((size_t)N * C * 4) + 15) & ~(size_t)15;
+			int Bg = C;
+			if (raw_bytes + (size_t)L * Bg * 8 > maxlds) Bg = 1;
+			if (raw_bytes + (size_t)L * Bg * 8 > maxlds) ok = false;
+			if (ok) {
+				std::vector<Dim> lines;
+				for (size_t i = 0; i < others.size(); i++) if ((int)i != cdim) lines.push_back(others[i]);
+				merge_dims(lines);
+				PassArgs &pa = P.pa;
+				pa.N = N; pa.kind = kind; pa.C = C; pa.Bg = Bg; pa.fft = F; pa.divB = make_div((uint32_t)Bg);
+				pa.nb0 = lines.size() > 0 ? lines[0].n : 1; pa.sb0_in = lines.size() > 0 ? lines[0].is : 0; pa.sb0_out = lines.size() > 0 ? lines[0].os : 0;
+				pa.nb1 = lines.size() > 1 ? lines[1].n : 1; pa.sb1_in = lines.size() > 1 ? lines[1].is : 0; pa.sb1_out = lines.size() > 1 ? lines[1].os : 0;
+				for (size_t i = 2; i < lines.size(); i++) P.hostloop.push_back(lines[i]);
+				P.type = Pass::ROW;
+				P.g.nwg = pa.nb0 * pa.nb1; P.g.nthr = 256; P.g.raw_bytes = raw_bytes; P.g.lds_bytes = raw_bytes + (size_t)L * Bg * 8;
+				if (upload_tables(P, N, L, pos)) return fail(-3, "table upload failed");
+				snprintf(buf, sizeof buf, "axis %d: ROW  N=%d C=%d Bg=%d fft=%d(%s) lines=%d lds=%zu", a, N, C, Bg, L, radix_string(F).c_str(), P.g.nwg, P.g.lds_bytes);
+				P.desc = buf;
+				return 0;
+			}
+		}
+	}
+	// ---------------- COL ----------------
+	{
+		FftDesc F; std::vector<uint32_t> pos;
+		bool ok = build_fft(N, F, pos);
+		int idim = -1;
+		if (ok) {
+			for (size_t i = 0; i < others.size(); i++) if (others[i].is == 1 && others[i].os == 1) idim = (int)i;
+			ok = idim >= 0;
+		}
+		if (ok) {
+			// merge dims that continue the inner run contiguously (dense embeddings)
+			std::vector<Dim> rest;
+			Dim inner = others[idim];
+			for (size_t i = 0; i < others.size(); i++) if ((int)i != idim) rest.push_back(others[i]);
+			std::sort(rest.begin(), rest.end(), [](const Dim &x, const Dim &y) { return x.os < y.os; });
+			for (size_t i = 0; i < rest.size();) {
+				if (rest[i].is == inner.n && rest[i].os == inner.n && (long long)inner.n * rest[i].n < (1 << 30)) { inner.n *= rest[i].n; rest.erase(rest.begin() + i); i = 0; }
+				else i++;
+			}
+			merge_dims(rest);
+			int K = std::min(16, (inner.n + 1) & ~1);
+			while (K >= 2 && (size_t)N * (K / 2) * 8 > maxlds) K -= 2;
+			if (K >= 2) {
+				PassArgs &pa = P.pa;
+				pa.N = N; pa.kind = kind; pa.K = K; pa.B = K / 2; pa.ninner = inner.n; pa.ntiles = (inner.n + K - 1) / K;
+				pa.es_in = ax.is; pa.es_out = ax.os; pa.fft = F; pa.divB = make_div((uint32_t)pa.B);
+				pa.nb0 = rest.size() > 0 ? rest[0].n : 1; pa.sb0_in = rest.size() > 0 ? rest[0].is : 0; pa.sb0_out = rest.size() > 0 ? rest[0].os : 0;
+				pa.nb1 = rest.size() > 1 ? rest[1].n : 1; pa.sb1_in = rest.size() > 1 ? rest[1].is : 0; pa.sb1_out = rest.size() > 1 ? rest[1].os : 0;
+				for (size_t i = 2; i < rest.size(); i++) P.hostloop.push_back(rest[i]);
+				P.type = Pass::COL;
+				P.g.nwg = pa.ntiles * pa.nb0 * pa.nb1;
+				P.g.nthr = ((long long)N * pa.B >= 8192) ? 512 : 256;
+				P.g.lds_bytes = (size_t)N * pa.B * 8; P.g.raw_bytes = 0;
+				if (upload_tables(P, N, N, pos)) return fail(-3, "table upload failed");
+				snprintf(buf, sizeof buf, "axis %d: COL  N=%d K=%d inner=%d tiles=%d fft=%d(%s) wgs=%d lds=%zu", a, N, K, inner.n, pa.ntiles, N, radix_string(F).c_str(), P.g.nwg, P.g.lds_bytes);
+				P.desc = buf;
+				return 0;
+			}
+		}
+	}
+	// ---------------- DENSE ----------------
+	{
+		if ((size_t)N * 4 > maxlds) return fail(-2, "axis %d: length %d has a prime factor > 13 (or no usable layout) and exceeds the dense path's LDS limit", a, N);
+		merge_dims(others);
+		DenseArgs &da = P.da;
+		da.N = N; da.kind = kind; da.es_in = ax.is; da.es_out = ax.os;
+		da.nb0 = others.size() > 0 ? others[0].n : 1; da.sb0_in = others.size() > 0 ? others[0].is : 0; da.sb0_out = others.size() > 0 ? others[0].os : 0;
+		da.nb1 = others.size() > 1 ? others[1].n : 1; da.sb1_in = others.size() > 1 ? others[1].is : 0; da.sb1_out = others.size() > 1 ? others[1].os : 0;
+		da.nb2 = others.size() > 2 ? others[2].n : 1; da.sb2_in = others.size() > 2 ? others[2].is : 0; da.sb2_out = others.size() > 2 ? others[2].os : 0;
+		for (size_t i = 3; i < others.size(); i++) P.hostloop.push_back(others[i]);
+		const long double pi = 3.14159265358979323846264338327950288L;
+		std::vector<float> ct((size_t)4 * N);
+		for (int t = 0; t < 4 * N; t++) ct[t] = (float)cosl(pi * t / (2.0L * N));
+		P.tab.cosTab = be_alloc(ct.size() * 4);
+		if (!P.tab.cosTab || be_upload(P.tab.cosTab, ct.data(), ct.size() * 4)) return fail(-3, "table upload failed");
+		da.cosTab = (const float *)P.tab.cosTab;
+		P.type = Pass::DENSE;
+		long long lines = (long long)da.nb0 * da.nb1 * da.nb2;
+		if (lines > 0x7fffffff) return fail(-2, "too many lines for the dense path");
+		P.g.nwg = (int)lines; P.g.nthr = 256; P.g.lds_bytes = (size_t)N * 4;
+		snprintf(buf, sizeof buf, "axis %d: DENSE N=%d lines=%lld lds=%zu", a, N, lines, P.g.lds_bytes);
+		P.desc = buf;
+		return 0;
+	}
+}
+
+int run_pass(const dspfft_plan_s *pl, const Pass &P, const float *in, float *out, bool last, void *stream)
+{
+	const float scale = last ? pl->scale : 1.f;
+	// iterate the host-side batch dims (rare: more batch levels than a kernel takes)
+	std::vector<int> idx(P.hostloop.size(), 0);
+	for (;;) {
+		long long oin = 0, oout = 0;
+		for (size_t i = 0; i < idx.size(); i++) { oin += idx[i] * P.hostloop[i].is; oout += idx[i] * P.hostloop[i].os; }
+		int rc;
+		if (P.type == Pass::DENSE) {
+			DenseArgs a = P.da;
+			a.in = in + oin; a.out = out + oout; a.scale = scale; a.in_scale0 = pl->in0[P.axis]; a.out_scale0 = pl->out0[P.axis];
+			rc = be_launch_dense(a, P.g, stream);
+		} else {
+			PassArgs a = P.pa;
+			a.in = in + oin; a.out = out + oout; a.scale = scale; a.in_scale0 = pl->in0[P.axis]; a.out_scale0 = pl->out0[P.axis];
+			rc = P.type == Pass::ROW ? be_launch_row(a, P.g, stream) : be_launch_col(a, P.g, stream);
+		}
+		if (rc) return fail(-4, "kernel launch failed (%s): backend code %d", P.desc.c_str(), rc);
+		size_t i = 0;
+		for (; i < idx.size(); i++) { if (++idx[i] < P.hostloop[i].n) break; idx[i] = 0; }
+		if (i == idx.size()) break;
+	}
+	return 0;
+}
+
+}  // namespace
+
+extern "C" int dspfft_plan_many_r2r(dspfft_plan *plan, int rank, const int *n, int howmany,
+                                    const int *inembed, int istride, int idist,
+                                    const int *onembed, int ostride, int odist, const int *kinds)
+{
+	if (!plan) return fail(-1, "null plan pointer");
+	*plan = nullptr;
+	if (rank < 1 || rank > 3) return fail(-1, "rank %d unsupported (1..3)", rank);
+	if (howmany < 1 || istride < 1 || ostride < 1) return fail(-1, "howmany/stride must be >= 1");
+	for (int a = 0; a < rank; a++) {
+		if (n[a] < 1) return fail(-1, "n[%d] = %d", a, n[a]);
+		if (kinds[a] != DSPFFT_REDFT10 && kinds[a] != DSPFFT_REDFT01) return fail(-1, "kind %d unsupported (REDFT10/REDFT01 only)", kinds[a]);
+		if ((inembed && inembed[a] < n[a] && a > 0) || (onembed && onembed[a] < n[a] && a > 0)) return fail(-1, "embed smaller than n");
+	}
+	dspfft_plan_s *pl = new dspfft_plan_s();
+	pl->rank = rank; pl->howmany = howmany; pl->scale = 1.f;
+	long long is = istride, os = ostride;
+	for (int a = rank - 1; a >= 0; a--) {
+		pl->n[a] = n[a]; pl->kinds[a] = kinds[a]; pl->in0[a] = pl->out0[a] = 1.f;
+		pl->axes[a].n = n[a]; pl->axes[a].is = is; pl->axes[a].os = os;
+		is *= inembed ? inembed[a] : n[a]; os *= onembed ? onembed[a] : n[a];
+	}
+	pl->batch.n = howmany; pl->batch.is = idist; pl->batch.os = odist;
+	size_t samples = (size_t)howmany;
+	for (int a = 0; a < rank; a++) samples *= (size_t)n[a];
+	pl->alg_bytes = samples * 8;
+	bool first = true;
+	for (int a = rank - 1; a >= 0; a--) {
+		pl->passes.emplace_back();
+		int rc = build_pass(pl, a, first, pl->passes.back());
+		if (rc) { dspfft_destroy_plan(pl); return rc; }
+		first = false;
+	}
+	*plan = pl;
+	return 0;
+}
+
+extern "C" int dspfft_plan_r2r_2d(dspfft_plan *plan, int n0, int n1, int kind0, int kind1)
+{
+	int n[2] = {n0, n1}, k[2] = {kind0, kind1};
+	return dspfft_plan_many_r2r(plan, 2, n, 1, nullptr, 1, 0, nullptr, 1, 0, k);
+}
+
+extern "C" int dspfft_plan_set_scale(dspfft_plan pl, float scale)
+{
+	if (!pl) return fail(-1, "null plan");
+	pl->scale = scale; return 0;
+}
+extern "C" int dspfft_plan_set_axis_scale0(dspfft_plan pl, int axis, float in_scale0, float out_scale0)
+{
+	if (!pl || axis < 0 || axis >= pl->rank) return fail(-1, "bad plan/axis");
+	pl->in0[axis] = in_scale0; pl->out0[axis] = out_scale0; return 0;
+}
+
+extern "C" int dspfft_execute(dspfft_plan pl, const float *d_in, float *d_out, void *stream)
+{
+	if (!pl || !d_in || !d_out) return fail(-1, "null plan or buffer");
+	for (size_t i = 0; i < pl->passes.size(); i++) {
+		const Pass &P = pl->passes[i];
+		int rc = run_pass(pl, P, P.first ? d_in : d_out, d_out, i + 1 == pl->passes.size(), stream);
+		if (rc) return rc;
+	}
+	return 0;
+}
+
+extern "C" int dspfft_plan_num_passes(dspfft_plan pl) { return pl ? (int)pl->passes.size() : 0; }
+
+extern "C" int dspfft_execute_pass(dspfft_plan pl, int index, const float *d_in, float *d_out, void *stream)
+{
+	if (!pl || !d_in || !d_out || index < 0 || index >= (int)pl->passes.size()) return fail(-1, "bad plan, buffer or pass index");
+	const Pass &P = pl->passes[index];
+	return run_pass(pl, P, P.first ? d_in : d_out, d_out, index + 1 == (int)pl->passes.size(), stream);
+}
+
+extern "C" void dspfft_destroy_plan(dspfft_plan pl)
+{
+	if (!pl) return;
+	for (Pass &P : pl->passes) P.tab.release();
+	delete pl;
+}
+
+extern "C" int dspfft_plan_describe(dspfft_plan pl, char *buf, size_t buflen)
+{
+	if (!pl || !buf || !buflen) return fail(-1, "bad arguments");
+	std::string s = std::string("backend ") + be_name() + "\n";
+	for (const Pass &P : pl->passes) { s += P.desc; if (!P.hostloop.empty()) s += " +hostloop"; s += "\n"; }
+	snprintf(buf, buflen, "%s", s.c_str());
+	return 0;
+}
+
+extern "C" size_t dspfft_plan_algorithmic_bytes(dspfft_plan pl) { return pl ? pl->alg_bytes : 0; }
+
+extern "C" int dspfft_scan_zigzag(uint32_t *d_lin, uint32_t w, uint32_t h, uint64_t first, uint64_t count, void *s)
+{
+	if (!d_lin || !w || !h || first + count > (uint64_t)w * h) return fail(-1, "bad zigzag range");
+	if ((uint64_t)w * h > 0xffffffffull) return fail(-1, "image too large for 32-bit offsets");
+	return be_scan_zigzag(d_lin, w, h, first, count, s) ? fail(-4, "launch failed") : 0;
+}
+extern "C" int dspfft_scan_scatter(float *r, const float *c, const uint32_t *lin, uint64_t count, uint64_t npix, int ch, void *s)
+{
+	if (!r || !c || (!lin && count) || ch < 1) return fail(-1, "bad arguments");
+	return be_scan_scatter(r, c, lin, count, npix, ch, s) ? fail(-4, "launch failed") : 0;
+}
+extern "C" int dspfft_accumulate(float *sum, const float *img, uint64_t len, void *s)
+{
+	if (!sum || !img) return fail(-1, "bad arguments");
+	return be_accumulate(sum, img, len, s) ? fail(-4, "launch failed") : 0;
+}
+extern "C" int dspfft_broadcast_dc(float *sum, const float *c, uint64_t npix, int ch, void *s)
+{
+	if (!sum || !c || ch < 1) return fail(-1, "bad arguments");
+	return be_broadcast_dc(sum, c, npix, ch, s) ? fail(-4, "launch failed") : 0;
+}
+extern "C" int dspfft_u8_to_f32(float *d, const uint8_t *src, uint64_t len, void *s)
+{
+	if (!d || !src) return fail(-1, "bad arguments");
+	return be_u8_to_f32(d, src, len, s) ? fail(-4, "launch failed") : 0;
+}
+extern "C" int dspfft_f32_to_u8(uint8_t *d, const float *src, double mul, uint64_t len, void *s)
+{
+	if (!d || !src) return fail(-1, "bad arguments");
+	return be_f32_to_u8(d, src, mul, len, s) ? fail(-4, "launch failed") : 0;
+}

@@ -1,0 +1,184 @@
+// radix.h -- in-register small DFTs (forward, e^{-2 pi i/R}) with compile-time twiddles.
+//
+// Everything here is plain C++17 usable from device code (hipcc) and, for the CPU-side
+// emulation tests, from host code (g++).  No reference code corresponds to this file: the
+// reference delegates all transform arithmetic to FFTW (include/precision.h:115).
+#pragma once
+#include <stdint.h>
+#include <type_traits>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define DSP_HD __host__ __device__ inline __attribute__((always_inline))
+#else
+#define DSP_HD inline __attribute__((always_inline))
+#endif
+
+#if !defined(__HIPCC__)
+// host-side stand-ins for the HIP vector types (CPU emulation build only)
+struct float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+#endif
+
+namespace dspfft {
+
+struct cf { float x, y; };   // complex<float>, 8 bytes, same layout as float2
+
+DSP_HD cf cmk(float x, float y) { cf r; r.x = x; r.y = y; return r; }
+DSP_HD cf cadd(cf a, cf b) { return cmk(a.x + b.x, a.y + b.y); }
+DSP_HD cf csub(cf a, cf b) { return cmk(a.x - b.x, a.y - b.y); }
+DSP_HD cf cmul(cf a, cf b) { return cmk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+DSP_HD cf cmulc(cf a, cf b) { return cmk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a * conj(b)
+DSP_HD cf cconj(cf a) { return cmk(a.x, -a.y); }
+DSP_HD cf cscale(cf a, float s) { return cmk(a.x * s, a.y * s); }
+DSP_HD cf cmul_mi(cf a) { return cmk(a.y, -a.x); }   // a * (-i)
+DSP_HD cf cmul_pi(cf a) { return cmk(-a.y, a.x); }   // a * (+i)
+
+// ---- compile-time trigonometry: cos/sin(2 pi k / n), exact octant reduction on (k, n) ----
+namespace ct {
+constexpr double kPi = 3.14159265358979323846264338327950288;
+constexpr double taylor_cos(double x) {   // |x| <= pi/4
+	double x2 = x * x, term = 1.0, sum = 1.0;
+	for (int i = 1; i <= 12; i++) { term *= -x2 / double((2 * i - 1) * (2 * i)); sum += term; }
+	return sum;
+}
+constexpr double taylor_sin(double x) {
+	double x2 = x * x, term = x, sum = x;
+	for (int i = 1; i <= 12; i++) { term *= -x2 / double((2 * i) * (2 * i + 1)); sum += term; }
+	return sum;
+}
+struct cs { double c, s; };
+// cos and sin of 2*pi*k/n
+constexpr cs cossin(long k, long n) {
+	k %= n; if (k < 0) k += n;
+	// angle fraction a = k/n in [0,1)
+	bool neg_s = false;
+	if (2 * k > n) { k = n - k; neg_s = true; }             // a > 1/2: reflect about pi
+	bool neg_c = false;
+	if (4 * k > n) { k = n - 2 * k; n = 2 * n; neg_c = true;   // a in (1/4,1/2]: pi - theta; k/n := 1/2 - a
+		// now angle fraction = (n_old - 2k_old) / (2 n_old)
+	}
+	// a in [0, 1/4]
+	bool swap = false;
+	if (8 * k > n) { // a in (1/8, 1/4]: cos(theta) = sin(pi/2 - theta)
+		k = n - 4 * k; n = 4 * n; swap = true;               // 1/4 - a = (n - 4k) / (4n)
+	}
+	double th = 2.0 * kPi * double(k) / double(n);
+	double c = taylor_cos(th), s = taylor_sin(th);
+	if (swap) { double t = c; c = s; s = t; }
+	if (neg_c) c = -c;
+	if (neg_s) s = -s;
+	return cs{c, s};
+}
+}  // namespace ct
+
+// Forward twiddle table w_R^e = exp(-2 pi i e / R), e in [0, R)
+template <int R>
+struct TwTab {
+	float re[R], im[R];
+	constexpr TwTab() : re{}, im{} {
+		for (int e = 0; e < R; e++) {
+			ct::cs v = ct::cossin(e, R);
+			re[e] = float(v.c); im[e] = float(-v.s);
+		}
+	}
+};
+template <int R> struct TwHolder { static constexpr TwTab<R> tab = TwTab<R>(); };
+
+// compile-time loop
+template <int I, int N, class F>
+DSP_HD void static_for(F &&f) {
+	if constexpr (I < N) {
+		f(std::integral_constant<int, I>{});
+		static_for<I + 1, N>(f);
+	}
+}
+
+// x * w_R^E with the trivial cases folded
+template <int R, int E>
+DSP_HD cf twmul(cf a) {
+	constexpr int e = ((E % R) + R) % R;
+	if constexpr (e == 0) return a;
+	else if constexpr (2 * e == R) return cmk(-a.x, -a.y);
+	else if constexpr (4 * e == R) return cmul_mi(a);
+	else if constexpr (4 * e == 3 * R) return cmul_pi(a);
+	else {
+		constexpr float wr = TwHolder<R>::tab.re[e], wi = TwHolder<R>::tab.im[e];
+		return cmk(a.x * wr - a.y * wi, a.x * wi + a.y * wr);
+	}
+}
+
+constexpr int first_factor(int r) {
+	if (r % 4 == 0 && r > 4) return 4;
+	if (r % 2 == 0) return 2;
+	for (int f = 3; f * f <= r; f += 2) if (r % f == 0) return f;
+	return r;
+}
+constexpr bool is_prime_radix(int r) { return first_factor(r) == r; }
+
+template <int R> struct Dft;
+
+template <> struct Dft<1> { static DSP_HD void run(cf *) {} };
+template <> struct Dft<2> {
+	static DSP_HD void run(cf *x) { cf a = x[0], b = x[1]; x[0] = cadd(a, b); x[1] = csub(a, b); }
+};
+template <> struct Dft<4> {
+	static DSP_HD void run(cf *x) {
+		cf s0 = cadd(x[0], x[2]), s1 = csub(x[0], x[2]), s2 = cadd(x[1], x[3]), s3 = cmul_mi(csub(x[1], x[3]));
+		x[0] = cadd(s0, s2); x[1] = cadd(s1, s3); x[2] = csub(s0, s2); x[3] = csub(s1, s3);
+	}
+};
+
+// odd primes: pair up q and p-q
+template <int P>
+struct DftOddPrime {
+	static DSP_HD void run(cf *x) {
+		constexpr int H = (P - 1) / 2;
+		cf a[H], b[H];
+		static_for<0, H>([&](auto q) { a[q] = cadd(x[q + 1], x[P - 1 - q]); b[q] = csub(x[q + 1], x[P - 1 - q]); });
+		cf x0 = x[0];
+		cf sum = x0;
+		static_for<0, H>([&](auto q) { sum = cadd(sum, a[q]); });
+		x[0] = sum;
+		static_for<1, H + 1>([&](auto r) {
+			float cr = x0.x, ci = x0.y, sr = 0.f, si = 0.f;
+			static_for<0, H>([&](auto q) {
+				constexpr int e = ((q + 1) * r) % P;
+				constexpr float c = TwHolder<P>::tab.re[e];
+				constexpr float s = -TwHolder<P>::tab.im[e];          // sin(2 pi e / P)
+				cr += a[q].x * c; ci += a[q].y * c;
+				sr += b[q].x * s; si += b[q].y * s;
+			});
+			// X[r] = C - i S ; X[P-r] = C + i S
+			x[r] = cmk(cr + si, ci - sr);
+			x[P - r] = cmk(cr - si, ci + sr);
+		});
+	}
+};
+template <> struct Dft<3> : DftOddPrime<3> {};
+template <> struct Dft<5> : DftOddPrime<5> {};
+template <> struct Dft<7> : DftOddPrime<7> {};
+template <> struct Dft<11> : DftOddPrime<11> {};
+template <> struct Dft<13> : DftOddPrime<13> {};
+
+// composite: R = P*Q, decimation in frequency; natural order in and out
+template <int R>
+struct Dft {
+	static DSP_HD void run(cf *x) {
+		constexpr int P = first_factor(R), Q = R / P;
+		static_assert(P != R, "prime radix without a specialisation");
+		cf y[P][Q];
+		static_for<0, Q>([&](auto m) {
+			cf t[P];
+			static_for<0, P>([&](auto n1) { t[n1] = x[n1 * Q + m]; });
+			Dft<P>::run(t);
+			static_for<0, P>([&](auto k1) { y[k1][m] = twmul<R, m * k1>(t[k1]); });
+		});
+		static_for<0, P>([&](auto k1) {
+			Dft<Q>::run(y[k1]);
+			static_for<0, Q>([&](auto q) { x[k1 + P * q] = y[k1][q]; });
+		});
+	}
+};
+
+}  // namespace dspfft

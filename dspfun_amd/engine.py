@@ -1,0 +1,101 @@
+"""Host-side mirror of the FFTW plan/execute surface the reference uses (reference
+include/precision.h:115 `fftw(call)`), over DEVICE memory.
+
+    Plan.many_r2r(...)  <->  fftw(plan_many_r2r)   spec/spec.c:63  ispec.c:165  zoom.c:263  scan.c:292,359  motion.c:535-552
+    Plan.r2r_2d(...)    <->  fftw(plan_r2r_2d)     applybasis/draw.c:74
+    plan.execute(...)   <->  fftw(execute)
+    plan.destroy()      <->  fftw(destroy_plan)
+
+Pointers are raw device addresses (ints, e.g. torch.Tensor.data_ptr()); `stream` is a hipStream_t
+handle as an int (torch.cuda.current_stream().cuda_stream) or 0 for the default stream.
+"""
+import ctypes as C
+
+from . import _lib
+
+REDFT01, REDFT10 = _lib.REDFT01, _lib.REDFT10
+
+
+class DspfftError(RuntimeError):
+    pass
+
+
+def _ia(v):
+    return None if v is None else (C.c_int * len(v))(*[int(x) for x in v])
+
+
+class Plan:
+    def __init__(self, handle, lib):
+        self._h = handle
+        self._lib = lib
+
+    @classmethod
+    def many_r2r(cls, n, kinds, howmany=1, inembed=None, istride=1, idist=0, onembed=None, ostride=1, odist=0, lib=None):
+        lib = lib or _lib.load()
+        n = list(n)
+        kinds = list(kinds)
+        if len(kinds) != len(n):
+            raise ValueError("one kind per transformed dimension")
+        h = C.c_void_p()
+        rc = lib.dspfft_plan_many_r2r(C.byref(h), len(n), _ia(n), howmany, _ia(inembed), istride, idist,
+                                      _ia(onembed), ostride, odist, _ia(kinds))
+        if rc:
+            raise DspfftError(lib.dspfft_last_error().decode())
+        return cls(h, lib)
+
+    @classmethod
+    def r2r_2d(cls, n0, n1, kind0, kind1, lib=None):
+        lib = lib or _lib.load()
+        h = C.c_void_p()
+        if lib.dspfft_plan_r2r_2d(C.byref(h), n0, n1, kind0, kind1):
+            raise DspfftError(lib.dspfft_last_error().decode())
+        return cls(h, lib)
+
+    @classmethod
+    def image(cls, h, w, c, kind, lib=None):
+        """The image tools' plan: rank 2 {h,w}, howmany=c, stride=c, dist=1 (interleaved HWC)."""
+        return cls.many_r2r([h, w], [kind, kind], howmany=c, istride=c, idist=1, ostride=c, odist=1, lib=lib)
+
+    def set_scale(self, scale):
+        self._check(self._lib.dspfft_plan_set_scale(self._h, scale))
+        return self
+
+    def set_axis_scale0(self, axis, in_scale0=1.0, out_scale0=1.0):
+        self._check(self._lib.dspfft_plan_set_axis_scale0(self._h, axis, in_scale0, out_scale0))
+        return self
+
+    def execute(self, d_in, d_out=None, stream=0):
+        d_out = d_in if d_out is None else d_out
+        self._check(self._lib.dspfft_execute(self._h, C.c_void_p(d_in), C.c_void_p(d_out), C.c_void_p(stream)))
+
+    @property
+    def num_passes(self):
+        return int(self._lib.dspfft_plan_num_passes(self._h))
+
+    def execute_pass(self, index, d_in, d_out=None, stream=0):
+        d_out = d_in if d_out is None else d_out
+        self._check(self._lib.dspfft_execute_pass(self._h, index, C.c_void_p(d_in), C.c_void_p(d_out), C.c_void_p(stream)))
+
+    def describe(self):
+        buf = C.create_string_buffer(4096)
+        self._check(self._lib.dspfft_plan_describe(self._h, buf, len(buf)))
+        return buf.value.decode()
+
+    @property
+    def algorithmic_bytes(self):
+        return int(self._lib.dspfft_plan_algorithmic_bytes(self._h))
+
+    def destroy(self):
+        if self._h:
+            self._lib.dspfft_destroy_plan(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise DspfftError(self._lib.dspfft_last_error().decode())

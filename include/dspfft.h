@@ -1,0 +1,98 @@
+/*
+ * dspfft.h -- device-resident C ABI of the MI355X real-even DCT engine.
+ *
+ * This is the second-level boundary of SURVEY.md section 8(b): the same plan/execute contract the
+ * reference reaches through `fftw(call)` (include/precision.h:115 of the reference), but on DEVICE
+ * pointers and an explicit HIP stream, so buffers stay resident in HBM between transforms.
+ * include/fftw3.h (the FFTW-named host-pointer shim the tools link against) is a thin adapter over
+ * these entry points.
+ *
+ * All functions return 0 on success and a negative code on failure; dspfft_last_error() describes
+ * the most recent failure of the calling thread.  No function touches user arrays at plan time
+ * (scan/scan.c:354-359 relies on that, see SURVEY.md section 7 "FFTW_MEASURE clobbering").
+ */
+#ifndef DSPFFT_H
+#define DSPFFT_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* same numeric values as FFTW's fftw_r2r_kind for the two kinds the reference uses */
+enum { DSPFFT_REDFT01 = 4, DSPFFT_REDFT10 = 5 };
+
+typedef struct dspfft_plan_s *dspfft_plan;
+
+/* Replaces fftw(plan_many_r2r) -- spec/spec.c:63, spec/ispec.c:165, zoom/zoom.c:263, scan/scan.c:292,359,
+ * motion/motion.c:535-538,549-552.  rank 1..3, kinds[i] in {DSPFFT_REDFT10, DSPFFT_REDFT01}, f32 data.
+ * Addressing follows FFTW's advanced interface: element (i0..i_{r-1}) of transform t is at
+ * t*dist + stride*(((i0*embed[1] + i1)*embed[2] + i2)); embed == NULL means embed = n. */
+int dspfft_plan_many_r2r(dspfft_plan *plan, int rank, const int *n, int howmany,
+                         const int *inembed, int istride, int idist,
+                         const int *onembed, int ostride, int odist, const int *kinds);
+
+/* Replaces fftw(plan_r2r_2d) -- applybasis/draw.c:74. */
+int dspfft_plan_r2r_2d(dspfft_plan *plan, int n0, int n1, int kind0, int kind1);
+
+/* Fused per-index normalisation: every output is multiplied by `scale`; along
+ * transformed axis `axis` (0-based, as in n[]) input index 0 is multiplied by in_scale0 before the
+ * transform and output index 0 by out_scale0 after it.  Defaults: 1, 1, 1.
+ *   spec/spec.c:70-78     = scale 1/(2wh), out_scale0 1/sqrt2 on both axes
+ *   spec/ispec.c:153-159  = scale 1/2,     in_scale0  sqrt2   on both axes
+ *   scan/scan.c:296-298   = scale 1/(4wh)
+ *   motion/motion.c:644-647 (block == scaled) = scale 2 sqrt2, out_scale0 1/sqrt2 on all three axes */
+int dspfft_plan_set_scale(dspfft_plan plan, float scale);
+int dspfft_plan_set_axis_scale0(dspfft_plan plan, int axis, float in_scale0, float out_scale0);
+
+/* Replaces fftw(execute) -- 9 call sites.  d_in/d_out are DEVICE pointers laid out as
+ * the plan describes; d_in == d_out is the in-place case.  Asynchronous on `hip_stream`
+ * (a hipStream_t; NULL = the default stream). */
+int dspfft_execute(dspfft_plan plan, const float *d_in, float *d_out, void *hip_stream);
+
+/* Profiling aid: a plan is a sequence of 1-D axis passes (one kernel launch each, last axis
+ * first).  dspfft_execute_pass runs pass `index` alone, exactly as dspfft_execute would (pass 0
+ * reads d_in, later passes work in place on d_out), so each kernel can be bracketed by events. */
+int dspfft_plan_num_passes(dspfft_plan plan);
+int dspfft_execute_pass(dspfft_plan plan, int index, const float *d_in, float *d_out, void *hip_stream);
+
+/* Replaces fftw(destroy_plan). */
+void dspfft_destroy_plan(dspfft_plan plan);
+
+/* Human-readable list of the passes a plan runs (kernel shape, radices, tile, LDS bytes). */
+int dspfft_plan_describe(dspfft_plan plan, char *buf, size_t buflen);
+
+/* Algorithmic bytes one execute moves (read once + write once per transformed sample, 8 B/sample
+ * for f32) -- the numerator of bench.py's roofline figure. */
+size_t dspfft_plan_algorithmic_bytes(dspfft_plan plan);
+
+const char *dspfft_last_error(void);
+const char *dspfft_version(void);
+
+/* ---- device-side helpers around the transform ---- */
+
+/* scan/scan_methods.c:77-115 (scan_zigzag): lin[i - first] = y*w + x of scan index i, i in [first, first+count).
+ * d_lin: device uint32 array.  Integer, bit-exact. */
+int dspfft_scan_zigzag(uint32_t *d_lin, uint32_t w, uint32_t h, uint64_t first, uint64_t count, void *hip_stream);
+
+/* scan/scan.c:429-432,445: recon = 0 everywhere except the `count` listed pixels (all c channels copied
+ * from coeffs), DC pixel cleared. */
+int dspfft_scan_scatter(float *d_recon, const float *d_coeffs, const uint32_t *d_lin, uint64_t count,
+                        uint64_t npixels, int channels, void *hip_stream);
+
+/* scan/scan.c:451-459 arithmetic: sum += image (len floats). */
+int dspfft_accumulate(float *d_sum, const float *d_image, uint64_t len, void *hip_stream);
+
+/* scan/scan.c:377-383: sum[p*channels + z] = coeffs[z] for every pixel p. */
+int dspfft_broadcast_dc(float *d_sum, const float *d_coeffs, uint64_t npixels, int channels, void *hip_stream);
+
+/* motion/motion.c:617-638 (ispec none, !linear, 8-bit input): coeffs[i] = (float)pix[i]. */
+int dspfft_u8_to_f32(float *d_dst, const uint8_t *d_src, uint64_t len, void *hip_stream);
+
+/* motion/motion.c:756-776 (spec none, !linear, 8-bit output): pix = clamp(lround(c * mul), 0, 255). */
+int dspfft_f32_to_u8(uint8_t *d_dst, const float *d_src, double mul, uint64_t len, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

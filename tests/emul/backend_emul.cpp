@@ -1,0 +1,93 @@
+// backend_emul.cpp -- TEST-ONLY CPU emulation of the device backend.
+//
+// Runs the very same phase functions (dspfun_amd/csrc/dct_core.h) the HIP kernels run, one
+// "workgroup" at a time, with `for (tid)` loops standing in for the threads and the loop
+// boundaries standing in for __syncthreads().  It exists so the planner and the kernel logic can
+// be unit-tested in a container without a GPU.  It is NOT part of the product: nothing under
+// dspfun_amd/ builds, links, loads or falls back to it (libdspfft_emul.so lives under tests/).
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+#include "backend.h"
+#include "elementwise_core.h"
+
+namespace dspfft {
+
+void *be_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
+void be_free(void *p) { free(p); }
+int be_upload(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
+size_t be_max_lds() { const char *e = getenv("DSPFFT_EMUL_LDS"); return e ? (size_t)atol(e) : 160 * 1024; }
+const char *be_name() { return "cpu-emulation (tests only)"; }
+
+#define PHASE(stmt) for (int tid = 0; tid < nthr; tid++) { stmt; }
+
+int be_launch_row(const PassArgs &a, const LaunchGeom &g, void *)
+{
+	std::vector<unsigned char> lds(g.lds_bytes + 16);
+	float *raw = (float *)lds.data();
+	cf *buf = (cf *)(lds.data() + g.raw_bytes);
+	const int nthr = g.nthr, L = a.N / 2;
+	for (int wg = 0; wg < g.nwg; wg++) {
+		long long bin, bout;
+		row_base(a, wg, bin, bout);
+		PHASE(row_load(a, raw, bin, tid, nthr));
+		for (int c0 = 0; c0 < a.C; c0 += a.Bg) {
+			if (a.kind == KIND_REDFT10) { PHASE(row_pack2(a, raw, buf, c0, tid, nthr)); }
+			else { PHASE(row_pre3(a, raw, buf, c0, tid, nthr)); }
+			for (int s = 0; s < a.fft.ns; s++) PHASE(fft_stage(buf, L, a.fft.st[s], a.Bg, a.divB, a.W, tid, nthr));
+			if (a.kind == KIND_REDFT10) { PHASE(row_post2(a, raw, buf, c0, tid, nthr)); }
+			else { PHASE(row_unpack3(a, raw, buf, c0, tid, nthr)); }
+		}
+		PHASE(row_store(a, raw, bout, tid, nthr));
+	}
+	return 0;
+}
+
+int be_launch_col(const PassArgs &a, const LaunchGeom &g, void *)
+{
+	std::vector<unsigned char> lds(g.lds_bytes + 16);
+	cf *buf = (cf *)lds.data();
+	const int nthr = g.nthr;
+	for (int wg = 0; wg < g.nwg; wg++) {
+		long long bin, bout; int valid;
+		col_base(a, wg, bin, bout, valid);
+		if (a.kind == KIND_REDFT10) { PHASE(col_load2(a, buf, bin, valid, tid, nthr)); }
+		else { PHASE(col_pre3(a, buf, bin, valid, tid, nthr)); }
+		for (int s = 0; s < a.fft.ns; s++) PHASE(fft_stage(buf, a.N, a.fft.st[s], a.B, a.divB, a.W, tid, nthr));
+		if (a.kind == KIND_REDFT10) { PHASE(col_post2(a, buf, bout, valid, tid, nthr)); }
+		else { PHASE(col_unpack3(a, buf, bout, valid, tid, nthr)); }
+	}
+	return 0;
+}
+
+int be_launch_dense(const DenseArgs &a, const LaunchGeom &g, void *)
+{
+	std::vector<float> x(a.N);
+	const int nthr = g.nthr;
+	for (int wg = 0; wg < g.nwg; wg++) {
+		long long bin, bout;
+		dense_base(a, wg, bin, bout);
+		PHASE(dense_load(a, x.data(), bin, tid, nthr));
+		PHASE(dense_compute(a, x.data(), bout, tid, nthr));
+	}
+	return 0;
+}
+
+int be_scan_zigzag(uint32_t *lin, uint32_t w, uint32_t h, uint64_t first, uint64_t count, void *)
+{
+	for (uint64_t i = 0; i < count; i++) lin[i] = zigzag_lin(w, h, first + i);
+	return 0;
+}
+int be_scan_scatter(float *recon, const float *coeffs, const uint32_t *lin, uint64_t count, uint64_t npixels, int ch, void *)
+{
+	memset(recon, 0, sizeof(float) * npixels * ch);
+	for (uint64_t i = 0; i < count; i++) if (lin[i]) for (int z = 0; z < ch; z++) recon[(uint64_t)lin[i] * ch + z] = coeffs[(uint64_t)lin[i] * ch + z];
+	return 0;
+}
+int be_accumulate(float *sum, const float *img, uint64_t len, void *) { for (uint64_t i = 0; i < len; i++) sum[i] += img[i]; return 0; }
+int be_broadcast_dc(float *sum, const float *c, uint64_t npix, int ch, void *) { for (uint64_t p = 0; p < npix; p++) for (int z = 0; z < ch; z++) sum[p * ch + z] = c[z]; return 0; }
+int be_u8_to_f32(float *d, const uint8_t *s, uint64_t len, void *) { for (uint64_t i = 0; i < len; i++) d[i] = (float)s[i]; return 0; }
+int be_f32_to_u8(uint8_t *d, const float *s, double mul, uint64_t len, void *) { for (uint64_t i = 0; i < len; i++) d[i] = quantise_u8((double)s[i] * mul); return 0; }
+
+}  // namespace dspfft

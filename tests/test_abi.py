@@ -1,0 +1,39 @@
+"""CPU: the product C-ABI library loads and exports every symbol include/dspfft.h declares
+(no compute calls: there is no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:dspfft|fftwf?)_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_match_binding_list():
+    from dspfun_amd import _lib
+    assert set(declared("dspfft.h")) == set(_lib.SYMBOLS)
+
+
+def test_product_library_exports_every_declared_symbol():
+    from dspfun_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    lib = C.CDLL(_lib.LIB_PATH)
+    for name in declared("dspfft.h"):
+        assert hasattr(lib, name), name
+    assert b"gfx950" in C.c_char_p(C.cast(lib.dspfft_version, C.CFUNCTYPE(C.c_char_p))()).value
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from dspfun_amd import _lib
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()

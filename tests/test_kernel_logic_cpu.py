@@ -1,0 +1,161 @@
+"""CPU: the planner (engine.cpp) and the kernel phase functions (dct_core.h) run through the
+test-only emulation backend and are compared with the oracle.  This is NOT the parity test of the
+product (that is tests/test_gpu_parity.py, -m gpu, through the HIP library); it checks the logic
+that both builds share, in a container without a GPU."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from dspfun_amd.engine import Plan, DspfftError, REDFT10, REDFT01
+from emul_lib import emul
+
+TOL = 2e-6   # f32 FFT-based vs f64 definition, relative to max|ref|
+
+
+def run(plan, x, out=None):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    if out is None:
+        plan.execute(x.ctypes.data)
+        return x
+    plan.execute(x.ctypes.data, out.ctypes.data)
+    return out
+
+
+def relerr(got, ref):
+    return np.abs(got.astype(np.float64) - ref).max() / max(np.abs(ref).max(), 1e-30)
+
+
+@pytest.mark.parametrize("h,w,c", [(48, 64, 3), (16, 16, 3), (30, 60, 3), (54, 120, 3), (8, 2, 3), (2, 8, 1), (60, 90, 1),
+                                    (15, 27, 3), (7, 13, 2), (9, 10, 4), (1, 8, 3), (8, 1, 3), (45, 50, 2)])
+@pytest.mark.parametrize("kind", [REDFT10, REDFT01])
+def test_image_plan_inplace(h, w, c, kind):
+    x = ol.synth_f32(h * 1000 + w, h * w * c).reshape(h, w, c)
+    ref = ol.dct2d_interleaved(x.astype(np.float64), kind, impl="port")
+    p = Plan.image(h, w, c, kind, lib=emul())
+    got = run(p, x.copy())
+    assert relerr(got, ref) < TOL, p.describe()
+
+
+def test_describe_picks_row_and_col():
+    p = Plan.image(48, 64, 3, REDFT10, lib=emul())
+    d = p.describe()
+    assert "ROW" in d and "COL" in d and "DENSE" not in d
+    p = Plan.image(17, 40, 3, REDFT10, lib=emul())   # 17 is a prime > 13 -> dense along y, x still fast
+    d = p.describe()
+    assert "DENSE" in d and "ROW" in d
+
+
+@pytest.mark.parametrize("kind", [REDFT10, REDFT01])
+def test_out_of_place_scan_plan(kind):
+    # scan/scan.c:359: reconstruction -> image, input must stay untouched
+    h, w, c = 24, 40, 3
+    x = ol.synth_f32(77, h * w * c).reshape(h, w, c)
+    keep = x.copy()
+    out = np.full_like(x, np.nan)
+    p = Plan.image(h, w, c, kind, lib=emul())
+    run(p, x, out)
+    assert np.array_equal(x, keep)
+    assert relerr(out, ol.dct2d_interleaved(x.astype(np.float64), kind, impl="port")) < TOL
+
+
+@pytest.mark.parametrize("N", [2, 4, 6, 8, 10, 12, 16, 18, 20, 24, 30, 32, 36, 48, 60, 64, 90, 120, 128, 240, 256, 270, 540, 1080, 1920, 2160, 3840,
+                               1, 3, 5, 7, 9, 15, 17, 19, 27, 31, 45, 75, 77, 97, 135])
+def test_1d_lengths_row_and_strided(N):
+    x = ol.synth_f32(N, N)
+    for kind in (REDFT10, REDFT01):
+        ref = ol.r2r_many(x.astype(np.float64), [N], [kind], impl="port")
+        p = Plan.many_r2r([N], [kind], lib=emul())
+        assert relerr(run(p, x.copy()), ref) < TOL, (N, p.describe())
+    # batch of 6 strided signals: element j of signal t at j*6 + t  (COL shape)
+    xb = ol.synth_f32(N + 5, N * 6).reshape(N, 6)
+    for kind in (REDFT10, REDFT01):
+        ref = np.stack([ol.r2r_many(xb[:, t].astype(np.float64), [N], [kind], impl="port") for t in range(6)], axis=1)
+        p = Plan.many_r2r([N], [kind], howmany=6, istride=6, idist=1, ostride=6, odist=1, lib=emul())
+        assert relerr(run(p, xb.copy()), ref) < TOL, (N, p.describe())
+
+
+def test_volume_embedded_motion_plan(golden):
+    # motion/motion.c:535-552: {d,h,w} inside {md,mh,mw}, in place; gaps must be preserved
+    d, h, w, md, mh, mw = [int(v) for v in golden["vol_dims"]]
+    buf = golden["vol_in"].astype(np.float32)
+    for kind, name in ((REDFT10, "redft10"), (REDFT01, "redft01")):
+        p = Plan.many_r2r([d, h, w], [kind] * 3, inembed=[md, mh, mw], onembed=[md, mh, mw], lib=emul())
+        got = run(p, buf.copy())
+        ref = golden[f"vol_{name}"]
+        assert relerr(got, ref) < TOL, p.describe()
+        mask = np.ones((md, mh, mw), bool); mask[:d, :h, :w] = False
+        assert np.array_equal(got[mask], buf[mask])
+
+
+def test_volume_dense_3d():
+    d, h, w = 8, 12, 20
+    x = ol.synth_f32(9, d * h * w)
+    for kind in (REDFT10, REDFT01):
+        ref = ol.r2r_many(x.astype(np.float64), [d, h, w], [kind] * 3, impl="port")
+        p = Plan.many_r2r([d, h, w], [kind] * 3, lib=emul())
+        assert relerr(run(p, x.copy()), ref) < TOL, p.describe()
+
+
+def test_planar_batch():
+    # howmany planes at dist = h*w (planar), rank 2
+    h, w, b = 12, 20, 3
+    x = ol.synth_f32(11, b * h * w)
+    ref = ol.r2r_many(x.astype(np.float64), [h, w], [REDFT10] * 2, howmany=b, idist=h * w, odist=h * w, impl="port")
+    p = Plan.many_r2r([h, w], [REDFT10] * 2, howmany=b, idist=h * w, odist=h * w, lib=emul())
+    assert relerr(run(p, x.copy()), ref) < TOL, p.describe()
+
+
+def test_r2r_2d_draw_plan():
+    x = ol.synth_f32(13, 10 * 14)
+    p = Plan.r2r_2d(10, 14, REDFT01, REDFT01, lib=emul())
+    ref = ol.r2r_many(x.astype(np.float64), [10, 14], [REDFT01] * 2, impl="port")
+    assert relerr(run(p, x.copy()), ref) < TOL
+
+
+def test_roundtrip_and_fused_spec_normalisation():
+    # spec.c:63-78 as one fused plan, then ispec.c:153-167 as one fused plan == identity
+    h, w, c = 18, 30, 3
+    x = ol.synth_f32(21, h * w * c).reshape(h, w, c)
+    r2 = np.float32(np.sqrt(2.0))
+    fwd = Plan.image(h, w, c, REDFT10, lib=emul()).set_scale(1.0 / (2 * w * h)).set_axis_scale0(0, 1, 1 / r2).set_axis_scale0(1, 1, 1 / r2)
+    inv = Plan.image(h, w, c, REDFT01, lib=emul()).set_scale(0.5).set_axis_scale0(0, r2, 1).set_axis_scale0(1, r2, 1)
+    f = run(fwd, x.copy())
+    ref = np.ascontiguousarray(ol.dct2d_interleaved(x.astype(np.float64), REDFT10))
+    ol.lib().oracle_spec_normalise_f64(ref.ctypes.data, w, h, c)
+    assert np.abs(f - ref).max() < 1e-6          # values are in [-1, 1]
+    y = run(inv, f.copy())
+    assert np.abs(y - x).max() < 5e-6
+
+
+def test_lds_pressure_paths(monkeypatch):
+    # with a small LDS budget the ROW pass falls back to one channel at a time and COL narrows its tile
+    import ctypes as C, os
+    os.environ["DSPFFT_EMUL_LDS"] = "1100"   # ROW needs 768 (raw) + 768 (3 channels) -> one channel at a time
+    try:
+        h, w, c = 24, 64, 3
+        x = ol.synth_f32(31, h * w * c).reshape(h, w, c)
+        p = Plan.image(h, w, c, REDFT10, lib=emul())
+        assert "Bg=1" in p.describe() and "K=10" in p.describe()
+        assert relerr(run(p, x.copy()), ol.dct2d_interleaved(x.astype(np.float64), REDFT10, impl="port")) < TOL
+    finally:
+        del os.environ["DSPFFT_EMUL_LDS"]
+
+
+def test_errors():
+    with pytest.raises(DspfftError):
+        Plan.many_r2r([8, 8, 8, 8], [REDFT10] * 4, lib=emul())
+    with pytest.raises(DspfftError):
+        Plan.many_r2r([8], [3], lib=emul())
+
+
+def test_helpers_zigzag_and_scan_step():
+    import ctypes as C
+    L = emul()
+    for (w, h) in [(8, 8), (6, 4), (4, 6), (16, 9), (9, 16), (1, 7), (7, 1)]:
+        lin = np.zeros(w * h, dtype=np.uint32)
+        assert L.dspfft_scan_zigzag(lin.ctypes.data, w, h, 0, w * h, None) == 0
+        assert np.array_equal(lin.astype(np.uint64), ol.zigzag_order(w, h))
+    # partial range
+    lin = np.zeros(10, dtype=np.uint32)
+    assert L.dspfft_scan_zigzag(lin.ctypes.data, 16, 9, 50, 10, None) == 0
+    assert np.array_equal(lin.astype(np.uint64), ol.zigzag_order(16, 9)[50:60])
