@@ -24,6 +24,11 @@ int be_launch_row(const PassArgs &a, const LaunchGeom &g, void *stream);
 int be_launch_col(const PassArgs &a, const LaunchGeom &g, void *stream);
 int be_launch_dense(const DenseArgs &a, const LaunchGeom &g, void *stream);
 
+// compile-time-specialised kernels (dct_spec.h / spec_list.h)
+struct SpecInfo { int id, nthr, P; size_t lds; };   // P = C (ROW) or K (COL)
+bool be_find_spec(int is_col, int N, int P, SpecInfo *info);
+int be_launch_spec(int is_col, int id, const PassArgs &a, int nwg, void *stream);
+
 // elementwise helpers (dspfft.h, "device-side helpers")
 int be_scan_zigzag(uint32_t *lin, uint32_t w, uint32_t h, uint64_t first, uint64_t count, void *stream);
 int be_scan_scatter(float *recon, const float *coeffs, const uint32_t *lin, uint64_t count, uint64_t npixels, int channels, void *stream);

@@ -7,6 +7,8 @@
 #include <stdio.h>
 
 #include "backend.h"
+#include "dct_spec.h"
+#include "spec_list.h"
 #include "elementwise_core.h"
 
 namespace dspfft {
@@ -57,6 +59,35 @@ __global__ void __launch_bounds__(512) col_kernel(const PassArgs a)
 	}
 	if (KIND == KIND_REDFT10) col_post2(a, buf, bout, valid, tid, nthr);
 	else col_unpack3(a, buf, bout, valid, tid, nthr);
+}
+
+// ---- compile-time-specialised kernels (dct_spec.h) ----
+template <class S, int KIND>
+__global__ void __launch_bounds__(S::T) row_spec_kernel(const PassArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+	cf *planes = reinterpret_cast<cf *>(lds);
+	long long bin, bout;
+	row_base(a, blockIdx.x, bin, bout);
+	const int tid = threadIdx.x;
+	static_for<0, S::NPH>([&](auto ph) {
+		S::template phase<KIND, ph>(a, planes, bin, bout, tid);
+		if constexpr (ph + 1 < S::NPH) __syncthreads();
+	});
+}
+
+template <class S, int KIND>
+__global__ void __launch_bounds__(S::T) col_spec_kernel(const PassArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+	float4 *buf = reinterpret_cast<float4 *>(lds);
+	long long bin, bout;
+	S::base(a, blockIdx.x, bin, bout);
+	const int tid = threadIdx.x;
+	static_for<0, S::NPH>([&](auto ph) {
+		S::template phase<KIND, ph>(a, buf, bin, bout, tid);
+		if constexpr (ph + 1 < S::NPH) __syncthreads();
+	});
 }
 
 __global__ void __launch_bounds__(256) dense_kernel(const DenseArgs a)
@@ -161,6 +192,24 @@ int be_launch_dense(const DenseArgs &a, const LaunchGeom &g, void *stream)
 	HIPCHK(hipGetLastError());
 	return 0;
 }
+
+template <class S, int KIND>
+int launch_row_spec(const PassArgs &a, int nwg, void *stream)
+{
+	if (int rc = allow_lds(row_spec_kernel<S, KIND>, S::LDS)) return rc;
+	hipLaunchKernelGGL((row_spec_kernel<S, KIND>), dim3(nwg), dim3(S::T), S::LDS, (hipStream_t)stream, a);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+template <class S, int KIND>
+int launch_col_spec(const PassArgs &a, int nwg, void *stream)
+{
+	if (int rc = allow_lds(col_spec_kernel<S, KIND>, S::LDS)) return rc;
+	hipLaunchKernelGGL((col_spec_kernel<S, KIND>), dim3(nwg), dim3(S::T), S::LDS, (hipStream_t)stream, a);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+#include "spec_registry.inc"
 
 static inline int ew_grid(uint64_t n) { uint64_t b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b)); }
 

@@ -1,0 +1,282 @@
+// dct_spec.h -- compile-time-specialised ROW / COL passes for the hot sizes (same mathematics as
+// dct_core.h; geometry, radices, thread count and trip counts are template parameters so every
+// index computation constant-folds and every loop unrolls).
+//
+// Differences from the generic passes that matter for MI355X:
+//   ROW  global I/O goes straight between registers and LDS in PIXEL order (one pixel = C floats per
+//        lane, e.g. global_load_dwordx3 for the image tools' RGB buffers: 64 lanes x 12 B = 768 B
+//        contiguous per wave instruction); there is no raw staging copy of the line, so a
+//        3840x3 line needs 46 KB of LDS instead of 92 KB and three workgroups fit on a CU.
+//   COL  each lane moves float4 = two complex columns; LDS rows are [n][K/2] complex; the last radix
+//        is odd so the final stage's strided ds_read_b128 are bank-conflict free; workgroup -> tile
+//        mapping is XCD-aware (tiles that share 128-B lines run on the same XCD's L2).
+// Phases are barrier-separated and numbered 0 .. NS+1 (load/pre, NS FFT stages, post/unpack).
+#pragma once
+#include "dct_core.h"
+
+namespace dspfft {
+
+template <int I, int... Rs> constexpr int pack_get() { constexpr int a[] = {Rs..., 1}; return a[I]; }
+// product of radices I.. (the length of the sub-transforms stage I splits)
+template <int I, int... Rs> constexpr int pack_lc() { constexpr int a[] = {Rs..., 1}; int l = 1; for (int j = I; j < (int)sizeof...(Rs); j++) l *= a[j]; return l; }
+
+// slot of FFT output k after the in-place DIF stages (mixed-radix digit reversal)
+template <int SPAN, int... Rs> struct PosCalc;
+template <int SPAN> struct PosCalc<SPAN> { static DSP_HD int run(int) { return 0; } };
+template <int SPAN, int R0, int... Rest>
+struct PosCalc<SPAN, R0, Rest...> {
+	static DSP_HD int run(int k) { constexpr int span = SPAN / R0; return (k % R0) * span + PosCalc<span, Rest...>::run(k / R0); }
+};
+
+// strided work loop with a compile-time trip count
+template <int TOTAL, int T, class F>
+DSP_HD void tloop(int tid, F &&f)
+{
+	constexpr int FULL = TOTAL / T, REM = TOTAL % T;
+	static_for<0, FULL>([&](auto i) { f(tid + i * T); });
+	if constexpr (REM > 0) { if (tid < REM) f(tid + FULL * T); }
+}
+
+// ---- pixel (C floats) global access ------------------------------------------------------------
+template <int C> struct Pix { float v[C]; };
+
+template <int C> DSP_HD Pix<C> load_pix(const float *p)
+{
+	Pix<C> r;
+#if defined(__HIP_DEVICE_COMPILE__)
+	if constexpr (C == 3) { typedef float f3 __attribute__((ext_vector_type(3))); f3 t; __builtin_memcpy(&t, p, 12); r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; return r; }
+	if constexpr (C == 4) { const float4 t = *reinterpret_cast<const float4 *>(p); r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; return r; }
+	if constexpr (C == 2) { const float2 t = *reinterpret_cast<const float2 *>(p); r.v[0] = t.x; r.v[1] = t.y; return r; }
+#endif
+	static_for<0, C>([&](auto c) { r.v[c] = p[c]; });
+	return r;
+}
+template <int C> DSP_HD void store_pix(float *p, const Pix<C> &r)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	if constexpr (C == 3) { typedef float f3 __attribute__((ext_vector_type(3))); f3 t; t.x = r.v[0]; t.y = r.v[1]; t.z = r.v[2]; __builtin_memcpy(p, &t, 12); return; }
+	if constexpr (C == 4) { float4 t; t.x = r.v[0]; t.y = r.v[1]; t.z = r.v[2]; t.w = r.v[3]; *reinterpret_cast<float4 *>(p) = t; return; }
+	if constexpr (C == 2) { float2 t; t.x = r.v[0]; t.y = r.v[1]; *reinterpret_cast<float2 *>(p) = t; return; }
+#endif
+	static_for<0, C>([&](auto c) { p[c] = r.v[c]; });
+}
+
+// =================================================================================================
+template <int N_, int C_, int T_, int... Rs>
+struct RowSpec {
+	static constexpr int N = N_, C = C_, T = T_, L = N_ / 2, NS = (int)sizeof...(Rs), NPH = NS + 2;
+	static constexpr int PL = L;                       // plane pitch (complex)
+	static constexpr size_t LDS = (size_t)C * PL * 8;
+	static_assert((1 * ... * Rs) == L, "radices must multiply to N/2");
+	static_assert(N % 2 == 0, "ROW needs even N");
+
+	static DSP_HD int pos(int k) { return PosCalc<L, Rs...>::run(k); }
+
+	template <int I>
+	static DSP_HD void stage(const PassArgs &a, cf *planes, int tid)
+	{
+		constexpr int R = pack_get<I, Rs...>(), Lc = pack_lc<I, Rs...>(), M1 = Lc / R, NB = L / R, TW = L / Lc;
+		tloop<C * NB, T>(tid, [&](int it) {
+			const int c = it / NB, q = it - c * NB;
+			const int blk = q / M1, m = q - blk * M1;
+			cf *p = planes + c * PL + blk * Lc + m;
+			cf x[R];
+			static_for<0, R>([&](auto r) { x[r] = p[r * M1]; });
+			Dft<R>::run(x);
+			if constexpr (M1 > 1) {
+				static_for<1, R>([&](auto r) { x[r] = cmul(x[r], a.W[(m * TW) * r]); });
+			}
+			static_for<0, R>([&](auto r) { p[r * M1] = x[r]; });
+		});
+	}
+
+	template <int KIND, int PH>
+	static DSP_HD void phase(const PassArgs &a, cf *planes, long long bin, long long bout, int tid)
+	{
+		float *pf = reinterpret_cast<float *>(planes);
+		if constexpr (PH == 0) {
+			if constexpr (KIND == KIND_REDFT10) {
+				// pixel x -> reordered sample n; float index inside the channel plane is n itself
+				tloop<N, T>(tid, [&](int x) {
+					Pix<C> v = load_pix<C>(a.in + bin + (long long)x * C);
+					const int n = makhoul_dst(x, N);
+					static_for<0, C>([&](auto c) { pf[c * (2 * PL) + n] = (x == 0) ? v.v[c] * a.in_scale0 : v.v[c]; });
+				});
+			} else {
+				tloop<L / 2 + 1, T>(tid, [&](int k) {
+					const float *src = a.in + bin;
+					const Pix<C> xk = load_pix<C>(src + (long long)k * C);
+					const Pix<C> xnk = load_pix<C>(src + (long long)(k ? N - k : 0) * C);
+					const Pix<C> xlk = load_pix<C>(src + (long long)(L - k) * C);
+					const Pix<C> xlpk = load_pix<C>(src + (long long)(L + k) * C);
+					const cf tk = a.T[k], tlk = a.T[L - k], t1 = a.T[4 * k];
+					static_for<0, C>([&](auto c) {
+						const float x0 = (k == 0) ? xk.v[c] * a.in_scale0 : xk.v[c];
+						const cf Vk = cmulc(cmk(x0, k ? -xnk.v[c] : 0.f), tk);
+						const cf Vm = cmulc(cmk(xlk.v[c], -xlpk.v[c]), tlk);
+						const cf S = cadd(Vk, cconj(Vm)), D = csub(Vk, cconj(Vm));
+						const cf Q = cmul_pi(cmulc(D, t1));
+						planes[c * PL + k] = cconj(cadd(S, Q));
+						if (k > 0) planes[c * PL + L - k] = csub(S, Q);
+					});
+				});
+			}
+		} else if constexpr (PH <= NS) {
+			stage<PH - 1>(a, planes, tid);
+		} else {
+			if constexpr (KIND == KIND_REDFT10) {
+				tloop<L / 2 + 1, T>(tid, [&](int k) {
+					const int km = k ? L - k : 0;
+					const int pk = pos(k), pm = pos(km);
+					const cf tk = a.T[k], tlk = a.T[L - k], t1 = a.T[4 * k];
+					Pix<C> o0, o1, o2, o3;
+					static_for<0, C>([&](auto c) {
+						const cf zk = planes[c * PL + pk];
+						const cf zm = cconj(planes[c * PL + pm]);
+						const cf E = cscale(cadd(zk, zm), 0.5f);
+						const cf D = cmul_mi(cscale(csub(zk, zm), 0.5f));
+						const cf P = cmul(t1, D);
+						const cf wk = cmul(tk, cadd(E, P));
+						const cf wm = cmul(tlk, cconj(csub(E, P)));
+						const float sc = a.scale;
+						o0.v[c] = 2.f * wk.x * sc * (k == 0 ? a.out_scale0 : 1.f);
+						o1.v[c] = -2.f * wk.y * sc;
+						o2.v[c] = 2.f * wm.x * sc;
+						o3.v[c] = -2.f * wm.y * sc;
+					});
+					float *dst = a.out + bout;
+					store_pix<C>(dst + (long long)k * C, o0);
+					if (k > 0) store_pix<C>(dst + (long long)(N - k) * C, o1);
+					store_pix<C>(dst + (long long)(L - k) * C, o2);
+					if (k > 0) store_pix<C>(dst + (long long)(L + k) * C, o3);
+				});
+			} else {
+				tloop<N, T>(tid, [&](int x) {
+					const int n = makhoul_dst(x, N), m = n >> 1, part = n & 1;
+					const int p = pos(m);
+					Pix<C> o;
+					const float sc = (x == 0) ? a.scale * a.out_scale0 : a.scale;
+					static_for<0, C>([&](auto c) {
+						const float f = pf[(c * PL + p) * 2 + part];
+						o.v[c] = (part ? -f : f) * sc;
+					});
+					store_pix<C>(a.out + bout + (long long)x * C, o);
+				});
+			}
+		}
+	}
+};
+
+// =================================================================================================
+DSP_HD int xcd_remap(int bid, int n)
+{
+	// blocks b and b+8 share an XCD (observed round-robin dispatch; speed only, never correctness):
+	// give each XCD a contiguous run of tiles so neighbours that share cache lines share an L2.
+	const int per = n >> 3, full = per << 3;
+	if (bid >= full) return bid;
+	return (bid & 7) * per + (bid >> 3);
+}
+
+template <int N_, int K_, int T_, int... Rs>
+struct ColSpec {
+	static constexpr int N = N_, K = K_, T = T_, B = K_ / 2, NP = K_ / 4, NS = (int)sizeof...(Rs), NPH = NS + 2;
+	static constexpr size_t LDS = (size_t)N * B * 8;
+	static_assert((1 * ... * Rs) == N, "radices must multiply to N");
+	static_assert(K % 4 == 0, "tile width must be a multiple of 4 floats");
+
+	static DSP_HD int pos(int k) { return PosCalc<N, Rs...>::run(k); }
+
+	static DSP_HD void base(const PassArgs &a, int wg, long long &bin, long long &bout)
+	{
+		const int bt = wg / a.ntiles, t0 = wg - bt * a.ntiles;
+		const int t = xcd_remap(t0, a.ntiles);
+		const int i1 = bt / a.nb0, i0 = bt - i1 * a.nb0;
+		bin = i0 * a.sb0_in + i1 * a.sb1_in + (long long)t * K;
+		bout = i0 * a.sb0_out + i1 * a.sb1_out + (long long)t * K;
+	}
+
+	template <int I>
+	static DSP_HD void stage(const PassArgs &a, float4 *buf, int tid)
+	{
+		constexpr int R = pack_get<I, Rs...>(), Lc = pack_lc<I, Rs...>(), M1 = Lc / R, NB = N / R, TW = N / Lc;
+		tloop<NB * NP, T>(tid, [&](int it) {
+			const int q = it / NP, jp = it - q * NP;
+			const int blk = q / M1, m = q - blk * M1;
+			float4 *p = buf + (blk * Lc + m) * NP + jp;
+			cf xa[R], xb[R];
+			static_for<0, R>([&](auto r) { const float4 v = p[r * M1 * NP]; xa[r] = cmk(v.x, v.y); xb[r] = cmk(v.z, v.w); });
+			Dft<R>::run(xa);
+			Dft<R>::run(xb);
+			if constexpr (M1 > 1) {
+				static_for<1, R>([&](auto r) { const cf w = a.W[(m * TW) * r]; xa[r] = cmul(xa[r], w); xb[r] = cmul(xb[r], w); });
+			}
+			static_for<0, R>([&](auto r) { float4 v; v.x = xa[r].x; v.y = xa[r].y; v.z = xb[r].x; v.w = xb[r].y; p[r * M1 * NP] = v; });
+		});
+	}
+
+	template <int KIND, int PH>
+	static DSP_HD void phase(const PassArgs &a, float4 *buf, long long bin, long long bout, int tid)
+	{
+		if constexpr (PH == 0) {
+			if constexpr (KIND == KIND_REDFT10) {
+				tloop<N * NP, T>(tid, [&](int it) {
+					const int y = it / NP, jp = it - y * NP;
+					float4 v = *reinterpret_cast<const float4 *>(a.in + bin + (long long)y * a.es_in + 4 * jp);
+					if (y == 0) { v.x *= a.in_scale0; v.y *= a.in_scale0; v.z *= a.in_scale0; v.w *= a.in_scale0; }
+					buf[makhoul_dst(y, N) * NP + jp] = v;
+				});
+			} else {
+				tloop<(N / 2 + 1) * NP, T>(tid, [&](int it) {
+					const int k = it / NP, jp = it - k * NP;
+					const int km = k ? N - k : 0;
+					const float *p = a.in + bin + 4 * jp;
+					float4 xk = *reinterpret_cast<const float4 *>(p + (long long)k * a.es_in);
+					float4 xm = *reinterpret_cast<const float4 *>(p + (long long)km * a.es_in);
+					if (k == 0) { xk.x *= a.in_scale0; xk.y *= a.in_scale0; xk.z *= a.in_scale0; xk.w *= a.in_scale0; xm.x = xm.y = xm.z = xm.w = 0.f; }
+					const cf t = a.T[k];
+					const cf Va0 = cmulc(cmk(xk.x, -xm.x), t), Vb0 = cmulc(cmk(xk.y, -xm.y), t);
+					const cf Va1 = cmulc(cmk(xk.z, -xm.z), t), Vb1 = cmulc(cmk(xk.w, -xm.w), t);
+					float4 lo, hi;
+					lo.x = Va0.x - Vb0.y; lo.y = -Va0.y - Vb0.x; lo.z = Va1.x - Vb1.y; lo.w = -Va1.y - Vb1.x;
+					hi.x = Va0.x + Vb0.y; hi.y = Va0.y - Vb0.x; hi.z = Va1.x + Vb1.y; hi.w = Va1.y - Vb1.x;
+					buf[k * NP + jp] = lo;
+					if (k > 0) buf[km * NP + jp] = hi;
+				});
+			}
+		} else if constexpr (PH <= NS) {
+			stage<PH - 1>(a, buf, tid);
+		} else {
+			if constexpr (KIND == KIND_REDFT10) {
+				tloop<(N / 2 + 1) * NP, T>(tid, [&](int it) {
+					const int k = it / NP, jp = it - k * NP;
+					const int km = k ? N - k : 0;
+					const float4 zk = buf[pos(k) * NP + jp], zm = buf[pos(km) * NP + jp];
+					const cf t = a.T[k];
+					// column 0: (zk.x, zk.y) & conj(zm.x, zm.y); column 1: (.z, .w)
+					const cf A0 = cmk(zk.x + zm.x, zk.y - zm.y), B0 = cmul_mi(cmk(zk.x - zm.x, zk.y + zm.y));
+					const cf A1 = cmk(zk.z + zm.z, zk.w - zm.w), B1 = cmul_mi(cmk(zk.z - zm.z, zk.w + zm.w));
+					const cf wa0 = cmul(t, A0), wb0 = cmul(t, B0), wa1 = cmul(t, A1), wb1 = cmul(t, B1);
+					const float sc = a.scale, s0 = (k == 0) ? sc * a.out_scale0 : sc;
+					float *o = a.out + bout + 4 * jp;
+					float4 r0; r0.x = wa0.x * s0; r0.y = wb0.x * s0; r0.z = wa1.x * s0; r0.w = wb1.x * s0;
+					*reinterpret_cast<float4 *>(o + (long long)k * a.es_out) = r0;
+					if (k > 0 && km != k) {
+						float4 r1; r1.x = -wa0.y * sc; r1.y = -wb0.y * sc; r1.z = -wa1.y * sc; r1.w = -wb1.y * sc;
+						*reinterpret_cast<float4 *>(o + (long long)km * a.es_out) = r1;
+					}
+				});
+			} else {
+				tloop<N * NP, T>(tid, [&](int it) {
+					const int n = it / NP, jp = it - n * NP;
+					const float4 F = buf[pos(n) * NP + jp];
+					const int y = makhoul_src(n, N);
+					const float sc = (y == 0) ? a.scale * a.out_scale0 : a.scale;
+					float4 r; r.x = F.x * sc; r.y = -F.y * sc; r.z = F.z * sc; r.w = -F.w * sc;
+					*reinterpret_cast<float4 *>(a.out + bout + (long long)y * a.es_out + 4 * jp) = r;
+				});
+			}
+		}
+	}
+};
+
+}  // namespace dspfft

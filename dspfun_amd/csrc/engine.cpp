@@ -112,6 +112,10 @@ struct Pass {
 	PassArgs pa;
 	DenseArgs da;
 	LaunchGeom g;
+	bool has_spec = false;     // a compile-time-specialised kernel also covers this pass ...
+	PassArgs spa;              // ... with these arguments (used when the buffers are 16-B aligned)
+	SpecInfo spec;
+	int spec_nwg = 0;
 	std::vector<Dim> hostloop;
 	Tables tab;
 	std::string desc;
@@ -210,6 +214,15 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 				if (upload_tables(P, N, L, pos)) return fail(-3, "table upload failed");
 				snprintf(buf, sizeof buf, "axis %d: ROW  N=%d C=%d Bg=%d fft=%d(%s) lines=%d lds=%zu", a, N, C, Bg, L, radix_string(F).c_str(), P.g.nwg, P.g.lds_bytes);
 				P.desc = buf;
+				// vector pixel access needs the line starts aligned to the pixel vector (C=2: 8 B, C=4: 16 B)
+				const int al = (C == 2 || C == 4) ? C : 1;
+				bool aligned = true;
+				for (const Dim &d : lines) aligned = aligned && (d.is % al == 0) && (d.os % al == 0);
+				if (aligned && be_find_spec(0, N, C, &P.spec)) {
+					P.has_spec = true; P.spa = pa; P.spec_nwg = P.g.nwg;
+					snprintf(buf, sizeof buf, "axis %d: ROW* N=%d C=%d spec#%d threads=%d lines=%d lds=%zu (generic fallback: Bg=%d)", a, N, C, P.spec.id, P.spec.nthr, P.g.nwg, P.spec.lds, Bg);
+					P.desc = buf;
+				}
 				return 0;
 			}
 		}
@@ -250,6 +263,16 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 				if (upload_tables(P, N, N, pos)) return fail(-3, "table upload failed");
 				snprintf(buf, sizeof buf, "axis %d: COL  N=%d K=%d inner=%d tiles=%d fft=%d(%s) wgs=%d lds=%zu", a, N, K, inner.n, pa.ntiles, N, radix_string(F).c_str(), P.g.nwg, P.g.lds_bytes);
 				P.desc = buf;
+				// float4 tile rows: every stride that positions a tile must keep 16-B alignment
+				bool aligned = (ax.is % 4 == 0) && (ax.os % 4 == 0);
+				for (const Dim &d : rest) aligned = aligned && (d.is % 4 == 0) && (d.os % 4 == 0);
+				if (aligned && be_find_spec(1, N, inner.n, &P.spec)) {
+					P.has_spec = true; P.spa = pa;
+					P.spa.K = P.spec.P; P.spa.B = P.spec.P / 2; P.spa.ntiles = inner.n / P.spec.P;
+					P.spec_nwg = P.spa.ntiles * pa.nb0 * pa.nb1;
+					snprintf(buf, sizeof buf, "axis %d: COL* N=%d K=%d spec#%d threads=%d inner=%d tiles=%d wgs=%d lds=%zu (generic fallback: K=%d)", a, N, P.spec.P, P.spec.id, P.spec.nthr, inner.n, P.spa.ntiles, P.spec_nwg, P.spec.lds, K);
+					P.desc = buf;
+				}
 				return 0;
 			}
 		}
@@ -294,9 +317,18 @@ int run_pass(const dspfft_plan_s *pl, const Pass &P, const float *in, float *out
 			a.in = in + oin; a.out = out + oout; a.scale = scale; a.in_scale0 = pl->in0[P.axis]; a.out_scale0 = pl->out0[P.axis];
 			rc = be_launch_dense(a, P.g, stream);
 		} else {
-			PassArgs a = P.pa;
-			a.in = in + oin; a.out = out + oout; a.scale = scale; a.in_scale0 = pl->in0[P.axis]; a.out_scale0 = pl->out0[P.axis];
-			rc = P.type == Pass::ROW ? be_launch_row(a, P.g, stream) : be_launch_col(a, P.g, stream);
+			const bool ptr_ok = P.type == Pass::ROW
+				? ((P.pa.C == 2 ? 7u : P.pa.C == 4 ? 15u : 3u) & ((uintptr_t)(in + oin) | (uintptr_t)(out + oout))) == 0
+				: (15u & ((uintptr_t)(in + oin) | (uintptr_t)(out + oout))) == 0;
+			if (P.has_spec && ptr_ok) {
+				PassArgs a = P.spa;
+				a.in = in + oin; a.out = out + oout; a.scale = scale; a.in_scale0 = pl->in0[P.axis]; a.out_scale0 = pl->out0[P.axis];
+				rc = be_launch_spec(P.type == Pass::COL, P.spec.id, a, P.spec_nwg, stream);
+			} else {
+				PassArgs a = P.pa;
+				a.in = in + oin; a.out = out + oout; a.scale = scale; a.in_scale0 = pl->in0[P.axis]; a.out_scale0 = pl->out0[P.axis];
+				rc = P.type == Pass::ROW ? be_launch_row(a, P.g, stream) : be_launch_col(a, P.g, stream);
+			}
 		}
 		if (rc) return fail(-4, "kernel launch failed (%s): backend code %d", P.desc.c_str(), rc);
 		size_t i = 0;

@@ -1,0 +1,22 @@
+// spec_list.h -- which (length, layout) combinations get a compile-time-specialised kernel.
+// Everything else runs on the generic kernels of dct_core.h.
+//
+// ROW entries: X(N, C, THREADS, radices of N/2 ...)   -- last radix odd => conflict-free last stage
+// COL entries: X(N, K, THREADS, radices of N ...)     -- K = tile width in floats (multiple of 4)
+#pragma once
+
+#define DSPFFT_ROW_SPECS(X)            \
+	X(3840, 3, 384, 8, 16, 15)         \
+	X(1920, 3, 384, 4, 16, 15)         \
+	X(7680, 3, 768, 16, 16, 15)        \
+	X(960, 3, 192, 2, 16, 15)          \
+	X(256, 3, 192, 8, 16)              \
+	X(1920, 1, 128, 4, 16, 15)         \
+	X(960, 1, 64, 2, 16, 15)
+
+#define DSPFFT_COL_SPECS(X)            \
+	X(2160, 8, 384, 12, 12, 15)        \
+	X(1080, 16, 384, 8, 9, 15)         \
+	X(4320, 4, 384, 2, 12, 12, 15)     \
+	X(540, 16, 256, 4, 9, 15)          \
+	X(256, 16, 256, 4, 4, 16)

@@ -10,6 +10,8 @@
 #include <math.h>
 #include <vector>
 #include "backend.h"
+#include "dct_spec.h"
+#include "spec_list.h"
 #include "elementwise_core.h"
 
 namespace dspfft {
@@ -73,6 +75,32 @@ int be_launch_dense(const DenseArgs &a, const LaunchGeom &g, void *)
 	}
 	return 0;
 }
+
+template <class S, int KIND>
+int launch_row_spec(const PassArgs &a, int nwg, void *)
+{
+	std::vector<unsigned char> lds(S::LDS + 16);
+	cf *planes = (cf *)lds.data();
+	for (int wg = 0; wg < nwg; wg++) {
+		long long bin, bout;
+		row_base(a, wg, bin, bout);
+		static_for<0, S::NPH>([&](auto ph) { for (int tid = 0; tid < S::T; tid++) S::template phase<KIND, ph>(a, planes, bin, bout, tid); });
+	}
+	return 0;
+}
+template <class S, int KIND>
+int launch_col_spec(const PassArgs &a, int nwg, void *)
+{
+	std::vector<unsigned char> lds(S::LDS + 16);
+	float4 *buf = (float4 *)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
+	for (int wg = 0; wg < nwg; wg++) {
+		long long bin, bout;
+		S::base(a, wg, bin, bout);
+		static_for<0, S::NPH>([&](auto ph) { for (int tid = 0; tid < S::T; tid++) S::template phase<KIND, ph>(a, buf, bin, bout, tid); });
+	}
+	return 0;
+}
+#include "spec_registry.inc"
 
 int be_scan_zigzag(uint32_t *lin, uint32_t w, uint32_t h, uint64_t first, uint64_t count, void *)
 {

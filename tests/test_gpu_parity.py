@@ -211,3 +211,51 @@ def test_motion_u8_roundtrip(gpu):
     assert L.dspfft_f32_to_u8(out.data_ptr(), c.data_ptr(), 1.0 / (8.0 * d_ * h * w), pix.size, None) == 0
     gpu.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), pix)
+
+
+def test_c3_size_1080p_forward(gpu):
+    """BASELINE config 3's transform: 1920x1080x3 DCT-II (zoom/zoom.c:263), vs the f64 port."""
+    from dspfun_amd import REDFT10, REDFT01
+    h, w, c = 1080, 1920, 3
+    x = ol.synth_f32(0xD5F0003, h * w * c).reshape(h, w, c)
+    for kind in (REDFT10, REDFT01):
+        d = dev(gpu, x)
+        p = plan_image(h, w, c, kind)
+        p.execute(d.data_ptr())
+        gpu.cuda.synchronize()
+        check(d.cpu().numpy(), ol.dct2d_interleaved(x.astype(np.float64), kind, impl="port", threads=8))
+
+
+def test_c4_size_8k_roundtrip(gpu):
+    """BASELINE config 4's frame size, 7680x4320x3 (398 MB): roundtrip identity and DC == 4wh*mean
+    (size-independent properties; the O(N log N) f64 port covers 4K and below)."""
+    from dspfun_amd import REDFT10, REDFT01
+    h, w, c = 4320, 7680, 3
+    x = ol.synth_f32(0xD5F0004, h * w * c).reshape(h, w, c)
+    d = dev(gpu, x)
+    plan_image(h, w, c, REDFT10).execute(d.data_ptr())
+    gpu.cuda.synchronize()
+    dc = d[0, 0].cpu().numpy().astype(np.float64)
+    want = 4.0 * x.astype(np.float64).sum(axis=(0, 1))
+    assert np.abs(dc - want).max() / np.abs(want).max() < 1e-5
+    plan_image(h, w, c, REDFT01).set_scale(1.0 / (4.0 * w * h)).execute(d.data_ptr())
+    gpu.cuda.synchronize()
+    assert float((d.cpu() - gpu.from_numpy(x)).abs().max()) <= 5e-6
+
+
+def test_generic_and_specialised_kernels_agree(gpu):
+    """the same 4K frame through the specialised kernels and (misaligned by one float, so the
+    specialised path is refused) through the generic kernels"""
+    from dspfun_amd import REDFT10
+    h, w, c = 2160, 3840, 3
+    x = ol.synth_f32(42, h * w * c)
+    a = dev(gpu, x)
+    big = gpu.zeros(h * w * c + 4, dtype=gpu.float32, device="cuda:0")
+    b = big[1:1 + h * w * c]
+    b.copy_(a)
+    p = plan_image(h, w, c, REDFT10)
+    assert "ROW*" in p.describe() and "COL*" in p.describe()
+    p.execute(a.data_ptr())
+    p.execute(b.data_ptr())
+    gpu.cuda.synchronize()
+    assert float((a - b).abs().max() / a.abs().max()) < 2e-6

@@ -159,3 +159,43 @@ def test_helpers_zigzag_and_scan_step():
     lin = np.zeros(10, dtype=np.uint32)
     assert L.dspfft_scan_zigzag(lin.ctypes.data, 16, 9, 50, 10, None) == 0
     assert np.array_equal(lin.astype(np.uint64), ol.zigzag_order(16, 9)[50:60])
+
+
+# ---- compile-time-specialised kernels (dct_spec.h / spec_list.h), through the emulation backend ----
+@pytest.mark.parametrize("h,w,c", [(4, 3840, 3), (3, 1920, 3), (2, 7680, 3), (5, 960, 3), (6, 256, 3), (4, 1920, 1), (4, 960, 1),
+                                    (2160, 8, 3), (1080, 16, 3), (4320, 8, 1), (540, 16, 1), (256, 16, 3), (256, 256, 3)])
+@pytest.mark.parametrize("kind", [REDFT10, REDFT01])
+def test_specialised_kernels(h, w, c, kind):
+    x = ol.synth_f32(h * 7 + w, h * w * c).reshape(h, w, c)
+    ref = ol.dct2d_interleaved(x.astype(np.float64), kind, impl="port", threads=4)
+    p = Plan.image(h, w, c, kind, lib=emul())
+    assert "*" in p.describe(), p.describe()
+    got = run(p, x.copy())
+    assert relerr(got, ref) < TOL, p.describe()
+    # fused scaling on the specialised path
+    p.set_scale(0.25).set_axis_scale0(0, 1.5, 0.5).set_axis_scale0(1, 2.0, 0.75)
+    xs = x.astype(np.float64).copy()
+    xs[0, :, :] *= 1.5
+    xs[:, 0, :] *= 2.0
+    r2 = ol.dct2d_interleaved(xs, kind, impl="port", threads=4) * 0.25
+    r2[0, :, :] *= 0.5
+    r2[:, 0, :] *= 0.75
+    assert relerr(run(p, x.copy()), r2) < TOL
+
+
+def test_specialised_out_of_place_and_misaligned_fallback():
+    h, w, c = 2160, 8, 3
+    x = ol.synth_f32(3, h * w * c + 1)
+    xin = x[:-1].reshape(h, w, c)
+    out = np.zeros_like(xin)
+    p = Plan.image(h, w, c, REDFT01, lib=emul())
+    run(p, xin, out)
+    ref = ol.dct2d_interleaved(xin.astype(np.float64), REDFT01, impl="port", threads=4)
+    assert relerr(out, ref) < TOL
+    # a buffer that is only 4-byte aligned must still work (generic kernels take over)
+    xm = x[1:].reshape(h, w, c).copy()
+    buf = np.zeros(h * w * c + 4, dtype=np.float32)
+    view = buf[1:1 + h * w * c]
+    view[:] = xm.ravel()
+    p.execute(view.ctypes.data)
+    assert relerr(view.reshape(h, w, c), ol.dct2d_interleaved(xm.astype(np.float64), REDFT01, impl="port", threads=4)) < TOL
