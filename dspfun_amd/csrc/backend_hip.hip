@@ -70,8 +70,9 @@ __global__ void __launch_bounds__(S::T) row_spec_kernel(const PassArgs a)
 	long long bin, bout;
 	row_base(a, blockIdx.x, bin, bout);
 	const int tid = threadIdx.x;
+	typename S::State st;
 	static_for<0, S::NPH>([&](auto ph) {
-		S::template phase<KIND, ph>(a, planes, bin, bout, tid);
+		S::template phase<KIND, ph>(a, planes, bin, bout, tid, st);
 		if constexpr (ph + 1 < S::NPH) __syncthreads();
 	});
 }
@@ -84,8 +85,9 @@ __global__ void __launch_bounds__(S::T) col_spec_kernel(const PassArgs a)
 	long long bin, bout;
 	S::base(a, blockIdx.x, bin, bout);
 	const int tid = threadIdx.x;
+	typename S::State st;
 	static_for<0, S::NPH>([&](auto ph) {
-		S::template phase<KIND, ph>(a, buf, bin, bout, tid);
+		S::template phase<KIND, ph>(a, buf, bin, bout, tid, st);
 		if constexpr (ph + 1 < S::NPH) __syncthreads();
 	});
 }

@@ -28,6 +28,16 @@ struct PosCalc<SPAN, R0, Rest...> {
 	static DSP_HD int run(int k) { constexpr int span = SPAN / R0; return (k % R0) * span + PosCalc<span, Rest...>::run(k / R0); }
 };
 
+// digit reversal over only the first CNT radices of the pack (SPAN = product of those radices)
+template <int SPAN, int CNT, int R0, int... Rest>
+struct PosCalcFirst {
+	static DSP_HD int run(int k)
+	{
+		if constexpr (CNT == 0) return 0;
+		else { constexpr int span = SPAN / R0; return (k % R0) * span + PosCalcFirst<span, CNT - 1, Rest..., 1>::run(k / R0); }
+	}
+};
+
 // strided work loop with a compile-time trip count
 template <int TOTAL, int T, class F>
 DSP_HD void tloop(int tid, F &&f)
@@ -35,6 +45,19 @@ DSP_HD void tloop(int tid, F &&f)
 	constexpr int FULL = TOTAL / T, REM = TOTAL % T;
 	static_for<0, FULL>([&](auto i) { f(tid + i * T); });
 	if constexpr (REM > 0) { if (tid < REM) f(tid + FULL * T); }
+}
+
+DSP_HD cf csqr(cf a) { return cmk(a.x * a.x - a.y * a.y, 2.f * a.x * a.y); }
+
+// x[r] *= w1^r, r = 1..R-1, powers built by a balanced product tree (depth log2 R) from ONE table
+// value, so a butterfly costs one twiddle load instead of R-1.
+template <int R>
+DSP_HD void twiddle_chain(cf *x, cf w1)
+{
+	cf w[R > 1 ? R : 2];
+	w[1] = w1;
+	static_for<2, R>([&](auto r) { if constexpr (r % 2 == 0) w[r] = csqr(w[r / 2]); else w[r] = cmul(w[r / 2], w[r - r / 2]); });
+	static_for<1, R>([&](auto r) { x[r] = cmul(x[r], w[r]); });
 }
 
 // ---- pixel (C floats) global access ------------------------------------------------------------
@@ -64,14 +87,23 @@ template <int C> DSP_HD void store_pix(float *p, const Pix<C> &r)
 // =================================================================================================
 template <int N_, int C_, int T_, int... Rs>
 struct RowSpec {
-	static constexpr int N = N_, C = C_, T = T_, L = N_ / 2, NS = (int)sizeof...(Rs), NPH = NS + 2;
-	static constexpr int PL = L;                       // plane pitch (complex)
-	static constexpr size_t LDS = (size_t)C * PL * 8;
+	static constexpr int N = N_, C = C_, T = T_, L = N_ / 2, NS = (int)sizeof...(Rs), NPH = NS + 3;
 	static_assert((1 * ... * Rs) == L, "radices must multiply to N/2");
-	static_assert(N % 2 == 0, "ROW needs even N");
+	static_assert(N % 2 == 0 && NS >= 1, "ROW needs even N");
+	// LDS layout of one channel plane while the DIF stages run: slot p lives at p + (p / SB) * PADC,
+	// SB = first-stage sub-block; the pad de-phases the SB-strided accesses of the digit-reversed
+	// gather in the last stage.  After the last stage the plane is in natural order (no pad).
+	static constexpr int R0 = pack_get<0, Rs...>(), RL = pack_get<NS - 1, Rs...>();
+	static constexpr int SB = L / R0, PADC = (NS >= 2) ? 1 : 0;
+	static constexpr int PL = L + R0 * PADC;           // plane pitch (complex)
+	static constexpr size_t LDS = (size_t)C * PL * 8;
+	static constexpr int NBL = L / RL;                 // butterflies of the last stage per channel
+	static constexpr int LAST_ROUNDS = (C * NBL + T - 1) / T;
+	struct State { cf x[LAST_ROUNDS * RL]; };
 
-	static DSP_HD int pos(int k) { return PosCalc<L, Rs...>::run(k); }
+	static DSP_HD int padded(int p) { return p + (p / SB) * PADC; }
 
+	// stages 0 .. NS-2 (in place, padded layout)
 	template <int I>
 	static DSP_HD void stage(const PassArgs &a, cf *planes, int tid)
 	{
@@ -79,28 +111,58 @@ struct RowSpec {
 		tloop<C * NB, T>(tid, [&](int it) {
 			const int c = it / NB, q = it - c * NB;
 			const int blk = q / M1, m = q - blk * M1;
-			cf *p = planes + c * PL + blk * Lc + m;
+			cf *p;
+			int stride;
+			if constexpr (I == 0) { p = planes + c * PL + m; stride = SB + PADC; }
+			else { p = planes + c * PL + padded(blk * Lc) + m; stride = M1; }
 			cf x[R];
-			static_for<0, R>([&](auto r) { x[r] = p[r * M1]; });
+			static_for<0, R>([&](auto r) { x[r] = p[r * stride]; });
 			Dft<R>::run(x);
-			if constexpr (M1 > 1) {
-				static_for<1, R>([&](auto r) { x[r] = cmul(x[r], a.W[(m * TW) * r]); });
+			if constexpr (M1 > 1) twiddle_chain<R>(x, a.W[m * TW]);
+			static_for<0, R>([&](auto r) { p[r * stride] = x[r]; });
+		});
+	}
+
+	// last stage, part 1: gather (digit-reversed) + butterfly into registers
+	static DSP_HD void last_read(cf *planes, State &st, int tid)
+	{
+		static_for<0, LAST_ROUNDS>([&](auto i) {
+			const int it = tid + i * T;
+			if (it < C * NBL) {
+				const int c = it / NBL, kb = it - c * NBL;
+				int blk;
+				if constexpr (NS >= 2) blk = PosCalcFirst<NBL, NS - 1, Rs..., 1>::run(kb); else blk = 0;
+				const cf *p = planes + c * PL + (NS >= 2 ? padded(blk * RL) : 0);
+				static_for<0, RL>([&](auto r) { st.x[i * RL + r] = p[r]; });
+				Dft<RL>::run(&st.x[i * RL]);
 			}
-			static_for<0, R>([&](auto r) { p[r * M1] = x[r]; });
+		});
+	}
+	// last stage, part 2 (after a barrier): natural-order write  k = kb + NBL * r
+	static DSP_HD void last_write(cf *planes, const State &st, int tid)
+	{
+		static_for<0, LAST_ROUNDS>([&](auto i) {
+			const int it = tid + i * T;
+			if (it < C * NBL) {
+				const int c = it / NBL, kb = it - c * NBL;
+				cf *p = planes + c * PL + kb;
+				static_for<0, RL>([&](auto r) { p[r * NBL] = st.x[i * RL + r]; });
+			}
 		});
 	}
 
 	template <int KIND, int PH>
-	static DSP_HD void phase(const PassArgs &a, cf *planes, long long bin, long long bout, int tid)
+	static DSP_HD void phase(const PassArgs &a, cf *planes, long long bin, long long bout, int tid, State &st)
 	{
 		float *pf = reinterpret_cast<float *>(planes);
 		if constexpr (PH == 0) {
 			if constexpr (KIND == KIND_REDFT10) {
-				// pixel x -> reordered sample n; float index inside the channel plane is n itself
+				// pixel x -> reordered sample n; float index inside the (padded) channel plane
 				tloop<N, T>(tid, [&](int x) {
 					Pix<C> v = load_pix<C>(a.in + bin + (long long)x * C);
 					const int n = makhoul_dst(x, N);
-					static_for<0, C>([&](auto c) { pf[c * (2 * PL) + n] = (x == 0) ? v.v[c] * a.in_scale0 : v.v[c]; });
+					const int f = 2 * padded(n >> 1) + (n & 1);
+					static_for<0, C>([&](auto c) { pf[c * (2 * PL) + f] = (x == 0) ? v.v[c] * a.in_scale0 : v.v[c]; });
 				});
 			} else {
 				tloop<L / 2 + 1, T>(tid, [&](int k) {
@@ -109,30 +171,37 @@ struct RowSpec {
 					const Pix<C> xnk = load_pix<C>(src + (long long)(k ? N - k : 0) * C);
 					const Pix<C> xlk = load_pix<C>(src + (long long)(L - k) * C);
 					const Pix<C> xlpk = load_pix<C>(src + (long long)(L + k) * C);
-					const cf tk = a.T[k], tlk = a.T[L - k], t1 = a.T[4 * k];
+					const cf tk = a.T[k];
+					const cf tlk = cmul(cconj(tk), cmk(0.70710678118654752f, -0.70710678118654752f));   // T[L-k]
+					const cf t1 = csqr(csqr(tk));                                                      // T[4k]
 					static_for<0, C>([&](auto c) {
 						const float x0 = (k == 0) ? xk.v[c] * a.in_scale0 : xk.v[c];
 						const cf Vk = cmulc(cmk(x0, k ? -xnk.v[c] : 0.f), tk);
 						const cf Vm = cmulc(cmk(xlk.v[c], -xlpk.v[c]), tlk);
 						const cf S = cadd(Vk, cconj(Vm)), D = csub(Vk, cconj(Vm));
 						const cf Q = cmul_pi(cmulc(D, t1));
-						planes[c * PL + k] = cconj(cadd(S, Q));
-						if (k > 0) planes[c * PL + L - k] = csub(S, Q);
+						planes[c * PL + padded(k)] = cconj(cadd(S, Q));
+						if (k > 0) planes[c * PL + padded(L - k)] = csub(S, Q);
 					});
 				});
 			}
-		} else if constexpr (PH <= NS) {
+		} else if constexpr (PH < NS) {
 			stage<PH - 1>(a, planes, tid);
+		} else if constexpr (PH == NS) {
+			last_read(planes, st, tid);
+		} else if constexpr (PH == NS + 1) {
+			last_write(planes, st, tid);
 		} else {
 			if constexpr (KIND == KIND_REDFT10) {
 				tloop<L / 2 + 1, T>(tid, [&](int k) {
 					const int km = k ? L - k : 0;
-					const int pk = pos(k), pm = pos(km);
-					const cf tk = a.T[k], tlk = a.T[L - k], t1 = a.T[4 * k];
+					const cf tk = a.T[k];
+					const cf tlk = cmul(cconj(tk), cmk(0.70710678118654752f, -0.70710678118654752f));
+					const cf t1 = csqr(csqr(tk));
 					Pix<C> o0, o1, o2, o3;
 					static_for<0, C>([&](auto c) {
-						const cf zk = planes[c * PL + pk];
-						const cf zm = cconj(planes[c * PL + pm]);
+						const cf zk = planes[c * PL + k];
+						const cf zm = cconj(planes[c * PL + km]);
 						const cf E = cscale(cadd(zk, zm), 0.5f);
 						const cf D = cmul_mi(cscale(csub(zk, zm), 0.5f));
 						const cf P = cmul(t1, D);
@@ -152,13 +221,12 @@ struct RowSpec {
 				});
 			} else {
 				tloop<N, T>(tid, [&](int x) {
-					const int n = makhoul_dst(x, N), m = n >> 1, part = n & 1;
-					const int p = pos(m);
+					const int n = makhoul_dst(x, N);
 					Pix<C> o;
 					const float sc = (x == 0) ? a.scale * a.out_scale0 : a.scale;
 					static_for<0, C>([&](auto c) {
-						const float f = pf[(c * PL + p) * 2 + part];
-						o.v[c] = (part ? -f : f) * sc;
+						const float f = pf[c * (2 * PL) + n];
+						o.v[c] = ((n & 1) ? -f : f) * sc;
 					});
 					store_pix<C>(a.out + bout + (long long)x * C, o);
 				});
@@ -179,12 +247,20 @@ DSP_HD int xcd_remap(int bid, int n)
 
 template <int N_, int K_, int T_, int... Rs>
 struct ColSpec {
-	static constexpr int N = N_, K = K_, T = T_, B = K_ / 2, NP = K_ / 4, NS = (int)sizeof...(Rs), NPH = NS + 2;
-	static constexpr size_t LDS = (size_t)N * B * 8;
+	static constexpr int N = N_, K = K_, T = T_, B = K_ / 2, NP = K_ / 4, NS = (int)sizeof...(Rs), NPH = NS + 3;
 	static_assert((1 * ... * Rs) == N, "radices must multiply to N");
-	static_assert(K % 4 == 0, "tile width must be a multiple of 4 floats");
+	static_assert(K % 4 == 0 && NS >= 1, "tile width must be a multiple of 4 floats");
+	// rows of the tile are padded by one row per first-stage sub-block while the DIF stages run
+	// (see RowSpec); natural order, unpadded, after the last stage.
+	static constexpr int R0 = pack_get<0, Rs...>(), RL = pack_get<NS - 1, Rs...>();
+	static constexpr int SB = N / R0, PADC = (NS >= 2) ? 1 : 0;
+	static constexpr int ROWS = N + R0 * PADC;
+	static constexpr size_t LDS = (size_t)ROWS * B * 8;
+	static constexpr int NBL = N / RL;
+	static constexpr int LAST_ROUNDS = (NBL * NP + T - 1) / T;
+	struct State { cf xa[LAST_ROUNDS * RL], xb[LAST_ROUNDS * RL]; };
 
-	static DSP_HD int pos(int k) { return PosCalc<N, Rs...>::run(k); }
+	static DSP_HD int padded(int n) { return n + (n / SB) * PADC; }
 
 	static DSP_HD void base(const PassArgs &a, int wg, long long &bin, long long &bout)
 	{
@@ -202,20 +278,56 @@ struct ColSpec {
 		tloop<NB * NP, T>(tid, [&](int it) {
 			const int q = it / NP, jp = it - q * NP;
 			const int blk = q / M1, m = q - blk * M1;
-			float4 *p = buf + (blk * Lc + m) * NP + jp;
+			float4 *p;
+			int stride;
+			if constexpr (I == 0) { p = buf + m * NP + jp; stride = (SB + PADC) * NP; }
+			else { p = buf + (padded(blk * Lc) + m) * NP + jp; stride = M1 * NP; }
 			cf xa[R], xb[R];
-			static_for<0, R>([&](auto r) { const float4 v = p[r * M1 * NP]; xa[r] = cmk(v.x, v.y); xb[r] = cmk(v.z, v.w); });
+			static_for<0, R>([&](auto r) { const float4 v = p[r * stride]; xa[r] = cmk(v.x, v.y); xb[r] = cmk(v.z, v.w); });
 			Dft<R>::run(xa);
 			Dft<R>::run(xb);
 			if constexpr (M1 > 1) {
-				static_for<1, R>([&](auto r) { const cf w = a.W[(m * TW) * r]; xa[r] = cmul(xa[r], w); xb[r] = cmul(xb[r], w); });
+				cf w[R];
+				w[1] = a.W[m * TW];
+				static_for<2, R>([&](auto r) { if constexpr (r % 2 == 0) w[r] = csqr(w[r / 2]); else w[r] = cmul(w[r / 2], w[r - r / 2]); });
+				static_for<1, R>([&](auto r) { xa[r] = cmul(xa[r], w[r]); xb[r] = cmul(xb[r], w[r]); });
 			}
-			static_for<0, R>([&](auto r) { float4 v; v.x = xa[r].x; v.y = xa[r].y; v.z = xb[r].x; v.w = xb[r].y; p[r * M1 * NP] = v; });
+			static_for<0, R>([&](auto r) { float4 v; v.x = xa[r].x; v.y = xa[r].y; v.z = xb[r].x; v.w = xb[r].y; p[r * stride] = v; });
+		});
+	}
+
+	static DSP_HD void last_read(const float4 *buf, State &st, int tid)
+	{
+		static_for<0, LAST_ROUNDS>([&](auto i) {
+			const int it = tid + i * T;
+			if (it < NBL * NP) {
+				const int kb = it / NP, jp = it - kb * NP;
+				int blk;
+				if constexpr (NS >= 2) blk = PosCalcFirst<NBL, NS - 1, Rs..., 1>::run(kb); else blk = 0;
+				const float4 *p = buf + (NS >= 2 ? padded(blk * RL) : 0) * NP + jp;
+				static_for<0, RL>([&](auto r) { const float4 v = p[r * NP]; st.xa[i * RL + r] = cmk(v.x, v.y); st.xb[i * RL + r] = cmk(v.z, v.w); });
+				Dft<RL>::run(&st.xa[i * RL]);
+				Dft<RL>::run(&st.xb[i * RL]);
+			}
+		});
+	}
+	static DSP_HD void last_write(float4 *buf, const State &st, int tid)
+	{
+		static_for<0, LAST_ROUNDS>([&](auto i) {
+			const int it = tid + i * T;
+			if (it < NBL * NP) {
+				const int kb = it / NP, jp = it - kb * NP;
+				float4 *p = buf + kb * NP + jp;
+				static_for<0, RL>([&](auto r) {
+					float4 v; v.x = st.xa[i * RL + r].x; v.y = st.xa[i * RL + r].y; v.z = st.xb[i * RL + r].x; v.w = st.xb[i * RL + r].y;
+					p[r * NBL * NP] = v;
+				});
+			}
 		});
 	}
 
 	template <int KIND, int PH>
-	static DSP_HD void phase(const PassArgs &a, float4 *buf, long long bin, long long bout, int tid)
+	static DSP_HD void phase(const PassArgs &a, float4 *buf, long long bin, long long bout, int tid, State &st)
 	{
 		if constexpr (PH == 0) {
 			if constexpr (KIND == KIND_REDFT10) {
@@ -223,7 +335,7 @@ struct ColSpec {
 					const int y = it / NP, jp = it - y * NP;
 					float4 v = *reinterpret_cast<const float4 *>(a.in + bin + (long long)y * a.es_in + 4 * jp);
 					if (y == 0) { v.x *= a.in_scale0; v.y *= a.in_scale0; v.z *= a.in_scale0; v.w *= a.in_scale0; }
-					buf[makhoul_dst(y, N) * NP + jp] = v;
+					buf[padded(makhoul_dst(y, N)) * NP + jp] = v;
 				});
 			} else {
 				tloop<(N / 2 + 1) * NP, T>(tid, [&](int it) {
@@ -239,18 +351,22 @@ struct ColSpec {
 					float4 lo, hi;
 					lo.x = Va0.x - Vb0.y; lo.y = -Va0.y - Vb0.x; lo.z = Va1.x - Vb1.y; lo.w = -Va1.y - Vb1.x;
 					hi.x = Va0.x + Vb0.y; hi.y = Va0.y - Vb0.x; hi.z = Va1.x + Vb1.y; hi.w = Va1.y - Vb1.x;
-					buf[k * NP + jp] = lo;
-					if (k > 0) buf[km * NP + jp] = hi;
+					buf[padded(k) * NP + jp] = lo;
+					if (k > 0) buf[padded(km) * NP + jp] = hi;
 				});
 			}
-		} else if constexpr (PH <= NS) {
+		} else if constexpr (PH < NS) {
 			stage<PH - 1>(a, buf, tid);
+		} else if constexpr (PH == NS) {
+			last_read(buf, st, tid);
+		} else if constexpr (PH == NS + 1) {
+			last_write(buf, st, tid);
 		} else {
 			if constexpr (KIND == KIND_REDFT10) {
 				tloop<(N / 2 + 1) * NP, T>(tid, [&](int it) {
 					const int k = it / NP, jp = it - k * NP;
 					const int km = k ? N - k : 0;
-					const float4 zk = buf[pos(k) * NP + jp], zm = buf[pos(km) * NP + jp];
+					const float4 zk = buf[k * NP + jp], zm = buf[km * NP + jp];
 					const cf t = a.T[k];
 					// column 0: (zk.x, zk.y) & conj(zm.x, zm.y); column 1: (.z, .w)
 					const cf A0 = cmk(zk.x + zm.x, zk.y - zm.y), B0 = cmul_mi(cmk(zk.x - zm.x, zk.y + zm.y));
@@ -268,7 +384,7 @@ struct ColSpec {
 			} else {
 				tloop<N * NP, T>(tid, [&](int it) {
 					const int n = it / NP, jp = it - n * NP;
-					const float4 F = buf[pos(n) * NP + jp];
+					const float4 F = buf[n * NP + jp];
 					const int y = makhoul_src(n, N);
 					const float sc = (y == 0) ? a.scale * a.out_scale0 : a.scale;
 					float4 r; r.x = F.x * sc; r.y = -F.y * sc; r.z = F.z * sc; r.w = -F.w * sc;

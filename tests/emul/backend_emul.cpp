@@ -84,7 +84,8 @@ int launch_row_spec(const PassArgs &a, int nwg, void *)
 	for (int wg = 0; wg < nwg; wg++) {
 		long long bin, bout;
 		row_base(a, wg, bin, bout);
-		static_for<0, S::NPH>([&](auto ph) { for (int tid = 0; tid < S::T; tid++) S::template phase<KIND, ph>(a, planes, bin, bout, tid); });
+		std::vector<typename S::State> st(S::T);
+		static_for<0, S::NPH>([&](auto ph) { for (int tid = 0; tid < S::T; tid++) S::template phase<KIND, ph>(a, planes, bin, bout, tid, st[tid]); });
 	}
 	return 0;
 }
@@ -96,7 +97,8 @@ int launch_col_spec(const PassArgs &a, int nwg, void *)
 	for (int wg = 0; wg < nwg; wg++) {
 		long long bin, bout;
 		S::base(a, wg, bin, bout);
-		static_for<0, S::NPH>([&](auto ph) { for (int tid = 0; tid < S::T; tid++) S::template phase<KIND, ph>(a, buf, bin, bout, tid); });
+		std::vector<typename S::State> st(S::T);
+		static_for<0, S::NPH>([&](auto ph) { for (int tid = 0; tid < S::T; tid++) S::template phase<KIND, ph>(a, buf, bin, bout, tid, st[tid]); });
 	}
 	return 0;
 }
