@@ -99,7 +99,44 @@ struct RowSpec {
 	static constexpr size_t LDS = (size_t)C * PL * 8;
 	static constexpr int NBL = L / RL;                 // butterflies of the last stage per channel
 	static constexpr int LAST_ROUNDS = (C * NBL + T - 1) / T;
-	struct State { cf x[LAST_ROUNDS * RL]; };
+	static constexpr int PIX_ROUNDS = (N + T - 1) / T;           // REDFT10: pixels per thread
+	static constexpr int K_ROUNDS = (L / 2 + 1 + T - 1) / T;     // REDFT01: (k, L-k) pairs per thread
+	// per-thread registers that live across barriers: the last stage's butterflies and the
+	// prefetched global data of the NEXT line (persistent workgroups, see backend_hip.hip)
+	template <int KIND> struct State {
+		cf x[LAST_ROUNDS * RL];
+		float pre[(KIND == KIND_REDFT10 ? PIX_ROUNDS : 4 * K_ROUNDS) * C];
+	};
+
+	// issue the global loads of one line into registers (no LDS access, no waiting)
+	template <int KIND, class ST>
+	static DSP_HD void prefetch(const PassArgs &a, long long bin, int tid, ST &st)
+	{
+		if constexpr (KIND == KIND_REDFT10) {
+			static_for<0, PIX_ROUNDS>([&](auto i) {
+				const int x = tid + i * T;
+				if ((i + 1) * T <= N || x < N) {
+					const Pix<C> v = load_pix<C>(a.in + bin + (long long)x * C);
+					static_for<0, C>([&](auto c) { st.pre[i * C + c] = v.v[c]; });
+				}
+			});
+		} else {
+			static_for<0, K_ROUNDS>([&](auto i) {
+				const int k = tid + i * T;
+				if ((i + 1) * T <= L / 2 + 1 || k <= L / 2) {
+					const float *src = a.in + bin;
+					const Pix<C> p0 = load_pix<C>(src + (long long)k * C);
+					const Pix<C> p1 = load_pix<C>(src + (long long)(k ? N - k : 0) * C);
+					const Pix<C> p2 = load_pix<C>(src + (long long)(L - k) * C);
+					const Pix<C> p3 = load_pix<C>(src + (long long)(L + k) * C);
+					static_for<0, C>([&](auto c) {
+						st.pre[(i * 4 + 0) * C + c] = p0.v[c]; st.pre[(i * 4 + 1) * C + c] = p1.v[c];
+						st.pre[(i * 4 + 2) * C + c] = p2.v[c]; st.pre[(i * 4 + 3) * C + c] = p3.v[c];
+					});
+				}
+			});
+		}
+	}
 
 	static DSP_HD int padded(int p) { return p + (p / SB) * PADC; }
 
@@ -124,7 +161,8 @@ struct RowSpec {
 	}
 
 	// last stage, part 1: gather (digit-reversed) + butterfly into registers
-	static DSP_HD void last_read(cf *planes, State &st, int tid)
+	template <class ST>
+	static DSP_HD void last_read(cf *planes, ST &st, int tid)
 	{
 		static_for<0, LAST_ROUNDS>([&](auto i) {
 			const int it = tid + i * T;
@@ -139,7 +177,8 @@ struct RowSpec {
 		});
 	}
 	// last stage, part 2 (after a barrier): natural-order write  k = kb + NBL * r
-	static DSP_HD void last_write(cf *planes, const State &st, int tid)
+	template <class ST>
+	static DSP_HD void last_write(cf *planes, const ST &st, int tid)
 	{
 		static_for<0, LAST_ROUNDS>([&](auto i) {
 			const int it = tid + i * T;
@@ -151,38 +190,41 @@ struct RowSpec {
 		});
 	}
 
-	template <int KIND, int PH>
-	static DSP_HD void phase(const PassArgs &a, cf *planes, long long bin, long long bout, int tid, State &st)
+	// phase 0 consumes the prefetched registers; phases 1.. work on LDS; the last one stores to `bout`
+	template <int KIND, int PH, class ST>
+	static DSP_HD void phase(const PassArgs &a, cf *planes, long long bout, int tid, ST &st)
 	{
 		float *pf = reinterpret_cast<float *>(planes);
 		if constexpr (PH == 0) {
 			if constexpr (KIND == KIND_REDFT10) {
 				// pixel x -> reordered sample n; float index inside the (padded) channel plane
-				tloop<N, T>(tid, [&](int x) {
-					Pix<C> v = load_pix<C>(a.in + bin + (long long)x * C);
-					const int n = makhoul_dst(x, N);
-					const int f = 2 * padded(n >> 1) + (n & 1);
-					static_for<0, C>([&](auto c) { pf[c * (2 * PL) + f] = (x == 0) ? v.v[c] * a.in_scale0 : v.v[c]; });
+				static_for<0, PIX_ROUNDS>([&](auto i) {
+					const int x = tid + i * T;
+					if ((i + 1) * T <= N || x < N) {
+						const int n = makhoul_dst(x, N);
+						const int f = 2 * padded(n >> 1) + (n & 1);
+						static_for<0, C>([&](auto c) { const float v = st.pre[i * C + c]; pf[c * (2 * PL) + f] = (x == 0) ? v * a.in_scale0 : v; });
+					}
 				});
 			} else {
-				tloop<L / 2 + 1, T>(tid, [&](int k) {
-					const float *src = a.in + bin;
-					const Pix<C> xk = load_pix<C>(src + (long long)k * C);
-					const Pix<C> xnk = load_pix<C>(src + (long long)(k ? N - k : 0) * C);
-					const Pix<C> xlk = load_pix<C>(src + (long long)(L - k) * C);
-					const Pix<C> xlpk = load_pix<C>(src + (long long)(L + k) * C);
-					const cf tk = a.T[k];
-					const cf tlk = cmul(cconj(tk), cmk(0.70710678118654752f, -0.70710678118654752f));   // T[L-k]
-					const cf t1 = csqr(csqr(tk));                                                      // T[4k]
-					static_for<0, C>([&](auto c) {
-						const float x0 = (k == 0) ? xk.v[c] * a.in_scale0 : xk.v[c];
-						const cf Vk = cmulc(cmk(x0, k ? -xnk.v[c] : 0.f), tk);
-						const cf Vm = cmulc(cmk(xlk.v[c], -xlpk.v[c]), tlk);
-						const cf S = cadd(Vk, cconj(Vm)), D = csub(Vk, cconj(Vm));
-						const cf Q = cmul_pi(cmulc(D, t1));
-						planes[c * PL + padded(k)] = cconj(cadd(S, Q));
-						if (k > 0) planes[c * PL + padded(L - k)] = csub(S, Q);
-					});
+				static_for<0, K_ROUNDS>([&](auto i) {
+					const int k = tid + i * T;
+					if ((i + 1) * T <= L / 2 + 1 || k <= L / 2) {
+						const cf tk = a.T[k];
+						const cf tlk = cmul(cconj(tk), cmk(0.70710678118654752f, -0.70710678118654752f));   // T[L-k]
+						const cf t1 = csqr(csqr(tk));                                                      // T[4k]
+						static_for<0, C>([&](auto c) {
+							const float xk = st.pre[(i * 4 + 0) * C + c], xnk = st.pre[(i * 4 + 1) * C + c];
+							const float xlk = st.pre[(i * 4 + 2) * C + c], xlpk = st.pre[(i * 4 + 3) * C + c];
+							const float x0 = (k == 0) ? xk * a.in_scale0 : xk;
+							const cf Vk = cmulc(cmk(x0, k ? -xnk : 0.f), tk);
+							const cf Vm = cmulc(cmk(xlk, -xlpk), tlk);
+							const cf S = cadd(Vk, cconj(Vm)), D = csub(Vk, cconj(Vm));
+							const cf Q = cmul_pi(cmulc(D, t1));
+							planes[c * PL + padded(k)] = cconj(cadd(S, Q));
+							if (k > 0) planes[c * PL + padded(L - k)] = csub(S, Q);
+						});
+					}
 				});
 			}
 		} else if constexpr (PH < NS) {
@@ -202,16 +244,16 @@ struct RowSpec {
 					static_for<0, C>([&](auto c) {
 						const cf zk = planes[c * PL + k];
 						const cf zm = cconj(planes[c * PL + km]);
-						const cf E = cscale(cadd(zk, zm), 0.5f);
-						const cf D = cmul_mi(cscale(csub(zk, zm), 0.5f));
+						const cf E = cadd(zk, zm);                  // 2E
+						const cf D = cmul_mi(csub(zk, zm));         // 2D
 						const cf P = cmul(t1, D);
-						const cf wk = cmul(tk, cadd(E, P));
-						const cf wm = cmul(tlk, cconj(csub(E, P)));
+						const cf wk = cmul(tk, cadd(E, P));         // 2 * T[k] V[k]
+						const cf wm = cmul(tlk, cconj(csub(E, P))); // 2 * T[L-k] V[L-k]
 						const float sc = a.scale;
-						o0.v[c] = 2.f * wk.x * sc * (k == 0 ? a.out_scale0 : 1.f);
-						o1.v[c] = -2.f * wk.y * sc;
-						o2.v[c] = 2.f * wm.x * sc;
-						o3.v[c] = -2.f * wm.y * sc;
+						o0.v[c] = wk.x * (k == 0 ? sc * a.out_scale0 : sc);
+						o1.v[c] = -wk.y * sc;
+						o2.v[c] = wm.x * sc;
+						o3.v[c] = -wm.y * sc;
 					});
 					float *dst = a.out + bout;
 					store_pix<C>(dst + (long long)k * C, o0);
@@ -258,13 +300,43 @@ struct ColSpec {
 	static constexpr size_t LDS = (size_t)ROWS * B * 8;
 	static constexpr int NBL = N / RL;
 	static constexpr int LAST_ROUNDS = (NBL * NP + T - 1) / T;
-	struct State { cf xa[LAST_ROUNDS * RL], xb[LAST_ROUNDS * RL]; };
+	static constexpr int Y_ROUNDS = (N * NP + T - 1) / T;              // REDFT10: (row, column-pair) items per thread
+	static constexpr int K_ROUNDS = ((N / 2 + 1) * NP + T - 1) / T;    // REDFT01: (k, column-pair) items per thread
+	template <int KIND> struct State {
+		cf xa[LAST_ROUNDS * RL], xb[LAST_ROUNDS * RL];
+		float4 pre[KIND == KIND_REDFT10 ? Y_ROUNDS : 2 * K_ROUNDS];
+	};
+
+	template <int KIND, class ST>
+	static DSP_HD void prefetch(const PassArgs &a, long long bin, int tid, ST &st)
+	{
+		if constexpr (KIND == KIND_REDFT10) {
+			static_for<0, Y_ROUNDS>([&](auto i) {
+				const int it = tid + i * T;
+				if ((i + 1) * T <= N * NP || it < N * NP) {
+					const int y = it / NP, jp = it - y * NP;
+					st.pre[i] = *reinterpret_cast<const float4 *>(a.in + bin + (long long)y * a.es_in + 4 * jp);
+				}
+			});
+		} else {
+			static_for<0, K_ROUNDS>([&](auto i) {
+				const int it = tid + i * T;
+				if ((i + 1) * T <= (N / 2 + 1) * NP || it < (N / 2 + 1) * NP) {
+					const int k = it / NP, jp = it - k * NP;
+					const int km = k ? N - k : 0;
+					const float *p = a.in + bin + 4 * jp;
+					st.pre[2 * i] = *reinterpret_cast<const float4 *>(p + (long long)k * a.es_in);
+					st.pre[2 * i + 1] = *reinterpret_cast<const float4 *>(p + (long long)km * a.es_in);
+				}
+			});
+		}
+	}
 
 	static DSP_HD int padded(int n) { return n + (n / SB) * PADC; }
 
-	static DSP_HD void base(const PassArgs &a, int wg, long long &bin, long long &bout)
+	static DSP_HD void base(const PassArgs &a, int work, long long &bin, long long &bout)
 	{
-		const int bt = wg / a.ntiles, t0 = wg - bt * a.ntiles;
+		const int bt = work / a.ntiles, t0 = work - bt * a.ntiles;
 		const int t = xcd_remap(t0, a.ntiles);
 		const int i1 = bt / a.nb0, i0 = bt - i1 * a.nb0;
 		bin = i0 * a.sb0_in + i1 * a.sb1_in + (long long)t * K;
@@ -296,7 +368,8 @@ struct ColSpec {
 		});
 	}
 
-	static DSP_HD void last_read(const float4 *buf, State &st, int tid)
+	template <class ST>
+	static DSP_HD void last_read(const float4 *buf, ST &st, int tid)
 	{
 		static_for<0, LAST_ROUNDS>([&](auto i) {
 			const int it = tid + i * T;
@@ -311,7 +384,8 @@ struct ColSpec {
 			}
 		});
 	}
-	static DSP_HD void last_write(float4 *buf, const State &st, int tid)
+	template <class ST>
+	static DSP_HD void last_write(float4 *buf, const ST &st, int tid)
 	{
 		static_for<0, LAST_ROUNDS>([&](auto i) {
 			const int it = tid + i * T;
@@ -326,33 +400,37 @@ struct ColSpec {
 		});
 	}
 
-	template <int KIND, int PH>
-	static DSP_HD void phase(const PassArgs &a, float4 *buf, long long bin, long long bout, int tid, State &st)
+	template <int KIND, int PH, class ST>
+	static DSP_HD void phase(const PassArgs &a, float4 *buf, long long bout, int tid, ST &st)
 	{
 		if constexpr (PH == 0) {
 			if constexpr (KIND == KIND_REDFT10) {
-				tloop<N * NP, T>(tid, [&](int it) {
-					const int y = it / NP, jp = it - y * NP;
-					float4 v = *reinterpret_cast<const float4 *>(a.in + bin + (long long)y * a.es_in + 4 * jp);
-					if (y == 0) { v.x *= a.in_scale0; v.y *= a.in_scale0; v.z *= a.in_scale0; v.w *= a.in_scale0; }
-					buf[padded(makhoul_dst(y, N)) * NP + jp] = v;
+				static_for<0, Y_ROUNDS>([&](auto i) {
+					const int it = tid + i * T;
+					if ((i + 1) * T <= N * NP || it < N * NP) {
+						const int y = it / NP, jp = it - y * NP;
+						float4 v = st.pre[i];
+						if (y == 0) { v.x *= a.in_scale0; v.y *= a.in_scale0; v.z *= a.in_scale0; v.w *= a.in_scale0; }
+						buf[padded(makhoul_dst(y, N)) * NP + jp] = v;
+					}
 				});
 			} else {
-				tloop<(N / 2 + 1) * NP, T>(tid, [&](int it) {
-					const int k = it / NP, jp = it - k * NP;
-					const int km = k ? N - k : 0;
-					const float *p = a.in + bin + 4 * jp;
-					float4 xk = *reinterpret_cast<const float4 *>(p + (long long)k * a.es_in);
-					float4 xm = *reinterpret_cast<const float4 *>(p + (long long)km * a.es_in);
-					if (k == 0) { xk.x *= a.in_scale0; xk.y *= a.in_scale0; xk.z *= a.in_scale0; xk.w *= a.in_scale0; xm.x = xm.y = xm.z = xm.w = 0.f; }
-					const cf t = a.T[k];
-					const cf Va0 = cmulc(cmk(xk.x, -xm.x), t), Vb0 = cmulc(cmk(xk.y, -xm.y), t);
-					const cf Va1 = cmulc(cmk(xk.z, -xm.z), t), Vb1 = cmulc(cmk(xk.w, -xm.w), t);
-					float4 lo, hi;
-					lo.x = Va0.x - Vb0.y; lo.y = -Va0.y - Vb0.x; lo.z = Va1.x - Vb1.y; lo.w = -Va1.y - Vb1.x;
-					hi.x = Va0.x + Vb0.y; hi.y = Va0.y - Vb0.x; hi.z = Va1.x + Vb1.y; hi.w = Va1.y - Vb1.x;
-					buf[padded(k) * NP + jp] = lo;
-					if (k > 0) buf[padded(km) * NP + jp] = hi;
+				static_for<0, K_ROUNDS>([&](auto i) {
+					const int it = tid + i * T;
+					if ((i + 1) * T <= (N / 2 + 1) * NP || it < (N / 2 + 1) * NP) {
+						const int k = it / NP, jp = it - k * NP;
+						const int km = k ? N - k : 0;
+						float4 xk = st.pre[2 * i], xm = st.pre[2 * i + 1];
+						if (k == 0) { xk.x *= a.in_scale0; xk.y *= a.in_scale0; xk.z *= a.in_scale0; xk.w *= a.in_scale0; xm.x = xm.y = xm.z = xm.w = 0.f; }
+						const cf t = a.T[k];
+						const cf Va0 = cmulc(cmk(xk.x, -xm.x), t), Vb0 = cmulc(cmk(xk.y, -xm.y), t);
+						const cf Va1 = cmulc(cmk(xk.z, -xm.z), t), Vb1 = cmulc(cmk(xk.w, -xm.w), t);
+						float4 lo, hi;
+						lo.x = Va0.x - Vb0.y; lo.y = -Va0.y - Vb0.x; lo.z = Va1.x - Vb1.y; lo.w = -Va1.y - Vb1.x;
+						hi.x = Va0.x + Vb0.y; hi.y = Va0.y - Vb0.x; hi.z = Va1.x + Vb1.y; hi.w = Va1.y - Vb1.x;
+						buf[padded(k) * NP + jp] = lo;
+						if (k > 0) buf[padded(km) * NP + jp] = hi;
+					}
 				});
 			}
 		} else if constexpr (PH < NS) {

@@ -7,16 +7,16 @@
 
 #define DSPFFT_ROW_SPECS(X)            \
 	X(3840, 3, 512, 8, 15, 16)         \
-	X(1920, 3, 384, 4, 16, 15)         \
-	X(7680, 3, 768, 16, 16, 15)        \
+	X(1920, 3, 256, 4, 15, 16)         \
+	X(7680, 3, 1024, 16, 15, 16)        \
 	X(960, 3, 192, 2, 16, 15)          \
 	X(256, 3, 192, 8, 16)              \
 	X(1920, 1, 128, 4, 16, 15)         \
 	X(960, 1, 64, 2, 16, 15)
 
 #define DSPFFT_COL_SPECS(X)            \
-	X(2160, 8, 256, 12, 12, 15)        \
-	X(1080, 16, 384, 8, 9, 15)         \
-	X(4320, 4, 384, 2, 12, 12, 15)     \
+	X(2160, 8, 512, 12, 12, 15)        \
+	X(1080, 16, 512, 8, 9, 15)         \
+	X(4320, 4, 512, 2, 12, 12, 15)     \
 	X(540, 16, 256, 4, 9, 15)          \
 	X(256, 16, 256, 4, 4, 16)
