@@ -1,0 +1,83 @@
+/*
+ * scan_gpu -- plain-C harness reproducing the arithmetic of the reference's `scan` main loop
+ * (scan/scan.c:289-298 forward transform and normalisation, :352-359 buffers and the out-of-place
+ * FFTW_MEASURE inverse plan, :377-383 DC broadcast, :421-459 per-frame scatter / inverse / accumulate)
+ * over include/fftw3.h, with the zigzag order (scan/scan_methods.c:77-115) from the engine's
+ * dspfft_scan_zigzag.  Output: the final `sum` image (== input when every index was scanned) and,
+ * per frame, max|sum - input| on stderr (the quantity --measure-parity thresholds, scan.c:508-526).
+ *
+ *   scan_gpu in.{ppm,pf} out.pf [step]
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <fftw3.h>
+#include <dspfft.h>
+#include <hip/hip_runtime_api.h>
+#include "precision.h"
+#include "rawio.h"
+
+int main(int argc, char *argv[])
+{
+	if (argc < 3) { fprintf(stderr, "usage: %s <in> <out.pf> [step]\n", argv[0]); return 2; }
+	size_t width, height, channels = 3;
+	float *pix;
+	if (read_image(argv[1], &width, &height, &pix)) { fprintf(stderr, "cannot read %s\n", argv[1]); return 1; }
+	size_t limit = width * height, step = argc > 3 ? strtoul(argv[3], NULL, 10) : (limit + 31) / 32;
+	if (!step) step = 1;
+
+	coeff *coeffs = fftw(alloc_real)(width * height * channels);    /* scan.c:275 */
+	memcpy(coeffs, pix, sizeof(coeff) * width * height * channels);
+
+	fftw(init_threads)();                                           /* scan.c:289-290 */
+	fftw(plan_with_nthreads)(1);
+	fftw(plan) forward = fftw(plan_many_r2r)(2, (int[2]){height, width}, channels, coeffs, NULL, channels, 1, coeffs, NULL, channels, 1,
+	                                         (fftw(r2r_kind)[2]){FFTW_REDFT10, FFTW_REDFT10}, FFTW_ESTIMATE);
+	fftw(execute)(forward);
+	fftw(destroy_plan)(forward);
+	for (size_t i = 0; i < width * height * channels; i++) coeffs[i] /= width * height * 4;   /* scan.c:296-298 */
+
+	/* scan order: the engine's device zigzag, copied back once */
+	uint32_t *order = malloc(sizeof(uint32_t) * limit), *d_order;
+	if (hipMalloc((void **)&d_order, sizeof(uint32_t) * limit) != hipSuccess ||
+	    dspfft_scan_zigzag(d_order, width, height, 0, limit, NULL) ||
+	    hipMemcpy(order, d_order, sizeof(uint32_t) * limit, hipMemcpyDeviceToHost) != hipSuccess) {
+		fprintf(stderr, "zigzag failed: %s\n", dspfft_last_error());
+		return 1;
+	}
+	hipFree(d_order);
+
+	size_t nframes = (limit + step - 1) / step;                      /* scan.c:347-348 */
+	coeff *reconstruction = fftw(alloc_real)(width * height * channels);   /* scan.c:352-354 */
+	coeff *image = fftw(alloc_real)(width * height * channels);
+	memset(reconstruction, 0, sizeof(*reconstruction) * width * height * channels);
+	fftw(plan) inverse = fftw(plan_many_r2r)(2, (int[2]){height, width}, channels, reconstruction, NULL, channels, 1, image, NULL, channels, 1,
+	                                         (fftw(r2r_kind)[2]){FFTW_REDFT01, FFTW_REDFT01}, FFTW_MEASURE);   /* scan.c:359 */
+	coeff *sum = calloc(width * height * channels, sizeof(*sum));
+	for (size_t i = 0; i < width * height; i++) memcpy(sum + i * channels, coeffs, sizeof(*sum) * channels);   /* scan.c:382-383 */
+
+	for (size_t i = 0; i < nframes; i++) {                           /* scan.c:421-459 */
+		memset(reconstruction, 0, sizeof(*reconstruction) * width * height * channels);
+		for (size_t s = i * step; s < i * step + step && s < limit; s++) {
+			size_t o = order[s];
+			memcpy(reconstruction + o * channels, coeffs + o * channels, sizeof(*reconstruction) * channels);
+		}
+		memset(reconstruction, 0, sizeof(*coeffs) * channels);       /* clear DC, scan.c:445 */
+		fftw(execute)(inverse);
+		double err = 0;
+		for (size_t j = 0; j < width * height * channels; j++) {
+			sum[j] += image[j];
+			double e = fabs((double)sum[j] - pix[j]);
+			if (e > err) err = e;
+		}
+		fprintf(stderr, "frame %zu/%zu max|sum-input| = %.3e\n", i + 1, nframes, err);
+	}
+	int rc = write_pf(argv[2], width, height, sum);
+	fftw(destroy_plan)(inverse);
+	fftw(free)(reconstruction); fftw(free)(image); fftw(free)(coeffs);
+	free(sum); free(order); free(pix);
+	fftw(cleanup)(); fftw(cleanup_threads)();                        /* scan.c:563-564 */
+	return rc;
+}

@@ -31,6 +31,23 @@ def test_product_library_exports_every_declared_symbol():
     assert b"gfx950" in C.c_char_p(C.cast(lib.dspfft_version, C.CFUNCTYPE(C.c_char_p))()).value
 
 
+def test_product_library_exports_the_fftw_named_boundary():
+    """every function include/fftw3.h declares (the FFTW functions the tools use, x {fftwf_, fftw_})"""
+    from dspfun_amd import _lib
+    lib = C.CDLL(_lib.LIB_PATH)
+    names = declared("fftw3.h")
+    assert len(names) == 24, names      # 12 functions x {fftwf_, fftw_}
+    for name in names:
+        assert hasattr(lib, name), name
+
+
+def test_host_harnesses_build():
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    for exe in ("spec_gpu", "scan_gpu"):
+        assert os.access(os.path.join(ROOT, "host", exe), os.X_OK)
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from dspfun_amd import _lib
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))

@@ -1,0 +1,156 @@
+"""GPU (-m gpu): the FFTW-named host-pointer boundary (include/fftw3.h) and the plain-C harnesses
+built on it (host/), against the oracle."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def fftw():
+    import torch
+    assert torch.cuda.is_available()
+    from dspfun_amd import _lib
+    lib = C.CDLL(_lib.LIB_PATH)
+    ip = C.POINTER(C.c_int)
+    lib.fftwf_alloc_real.restype = C.c_void_p
+    lib.fftwf_alloc_real.argtypes = [C.c_size_t]
+    lib.fftwf_free.argtypes = [C.c_void_p]
+    lib.fftwf_plan_many_r2r.restype = C.c_void_p
+    lib.fftwf_plan_many_r2r.argtypes = [C.c_int, ip, C.c_int, C.c_void_p, ip, C.c_int, C.c_int, C.c_void_p, ip, C.c_int, C.c_int, ip, C.c_uint]
+    lib.fftwf_execute.argtypes = [C.c_void_p]
+    lib.fftwf_destroy_plan.argtypes = [C.c_void_p]
+    lib.fftw_alloc_real.restype = C.c_void_p
+    lib.fftw_alloc_real.argtypes = [C.c_size_t]
+    lib.fftw_free.argtypes = [C.c_void_p]
+    lib.fftw_plan_many_r2r.restype = C.c_void_p
+    lib.fftw_plan_many_r2r.argtypes = lib.fftwf_plan_many_r2r.argtypes
+    lib.fftw_execute.argtypes = [C.c_void_p]
+    lib.fftw_destroy_plan.argtypes = [C.c_void_p]
+    return lib
+
+
+def _ia(v):
+    return (C.c_int * len(v))(*v)
+
+
+def _host_array(ptr, n, dtype):
+    ct = C.c_float if dtype == np.float32 else C.c_double
+    return np.ctypeslib.as_array((ct * n).from_address(ptr))
+
+
+def test_spec_plan_in_place_on_host_pointers(fftw):
+    # spec/spec.c:59-64 exactly: alloc_real, plan_many_r2r(2,{h,w},d,f,NULL,d,1,f,NULL,d,1,REDFT10^2,ESTIMATE), execute
+    h, w, d = 256, 256, 3
+    x = (ol.synth_u8(0xD5F0001, h * w * d).astype(np.float32) / np.float32(255)).reshape(h, w, d)
+    p = fftw.fftwf_alloc_real(h * w * d)
+    f = _host_array(p, h * w * d, np.float32)
+    f[:] = x.ravel()
+    plan = fftw.fftwf_plan_many_r2r(2, _ia([h, w]), d, p, None, d, 1, p, None, d, 1, _ia([5, 5]), 1 << 6)
+    assert plan
+    fftw.fftwf_execute(plan)
+    ref = ol.dct2d_interleaved(x.astype(np.float64), ol.REDFT10, impl="port")
+    assert np.abs(f.reshape(h, w, d) - ref).max() <= 1e-5 * np.abs(ref).max()
+    fftw.fftwf_destroy_plan(plan)
+    fftw.fftwf_free(p)
+
+
+def test_scan_plan_out_of_place_measure_does_not_touch_arrays(fftw):
+    # scan/scan.c:352-359: buffers zeroed BEFORE planning with FFTW_MEASURE, input must stay intact after execute
+    h, w, c = 64, 96, 3
+    n = h * w * c
+    pin, pout = fftw.fftwf_alloc_real(n), fftw.fftwf_alloc_real(n)
+    a, b = _host_array(pin, n, np.float32), _host_array(pout, n, np.float32)
+    a[:] = 0
+    b[:] = 7
+    plan = fftw.fftwf_plan_many_r2r(2, _ia([h, w]), c, pin, None, c, 1, pout, None, c, 1, _ia([4, 4]), 0)
+    assert np.all(a == 0) and np.all(b == 7)          # plan time: untouched
+    x = ol.synth_f32(9, n)
+    a[:] = x
+    fftw.fftwf_execute(plan)
+    assert np.array_equal(a, x)
+    ref = ol.dct2d_interleaved(x.reshape(h, w, c).astype(np.float64), ol.REDFT01, impl="port")
+    assert np.abs(b.reshape(h, w, c) - ref).max() <= 1e-5 * np.abs(ref).max()
+    fftw.fftwf_execute(plan)                            # executes repeatedly (scan.c:447)
+    assert np.abs(b.reshape(h, w, c) - ref).max() <= 1e-5 * np.abs(ref).max()
+    fftw.fftwf_destroy_plan(plan)
+    fftw.fftwf_free(pin)
+    fftw.fftwf_free(pout)
+
+
+def test_motion_plan_embedded_3d_host(fftw, golden):
+    d, h, w, md, mh, mw = [int(v) for v in golden["vol_dims"]]
+    n = md * mh * mw
+    p = fftw.fftwf_alloc_real(n)
+    f = _host_array(p, n, np.float32)
+    f[:] = golden["vol_in"].astype(np.float32).ravel()
+    plan = fftw.fftwf_plan_many_r2r(3, _ia([d, h, w]), 1, p, _ia([md, mh, mw]), 1, 0, p, _ia([md, mh, mw]), 1, 0, _ia([5, 5, 5]), 1 << 6)
+    fftw.fftwf_execute(plan)
+    ref = golden["vol_redft10"]
+    assert np.abs(f.reshape(md, mh, mw) - ref).max() <= 1e-5 * np.abs(ref).max()
+    fftw.fftwf_destroy_plan(plan)
+    fftw.fftwf_free(p)
+
+
+def test_double_precision_entry_points(fftw):
+    h, w, d = 48, 64, 3
+    x = ol.synth_f32(5, h * w * d).astype(np.float64)
+    p = fftw.fftw_alloc_real(h * w * d)
+    f = _host_array(p, h * w * d, np.float64)
+    f[:] = x
+    plan = fftw.fftw_plan_many_r2r(2, _ia([h, w]), d, p, None, d, 1, p, None, d, 1, _ia([5, 5]), 1 << 6)
+    fftw.fftw_execute(plan)
+    ref = ol.dct2d_interleaved(x.reshape(h, w, d), ol.REDFT10)
+    assert np.abs(f.reshape(h, w, d) - ref).max() <= 1e-5 * np.abs(ref).max()
+    fftw.fftw_destroy_plan(plan)
+    fftw.fftw_free(p)
+
+
+def _write_ppm(path, img_u8):
+    h, w, _ = img_u8.shape
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (w, h))
+        f.write(img_u8.tobytes())
+
+
+def _read_pf(path):
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"PF"
+        w, h = [int(v) for v in f.readline().split()]
+        f.readline()
+        return np.frombuffer(f.read(), dtype=np.float32).reshape(h, w, 3)
+
+
+def test_c1_spec_ispec_harness_roundtrip(tmp_path):
+    """BASELINE config 1: 256x256 3-channel PPM through the C harness (spec.c:63-78, ispec.c:153-167)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    img = ol.synth_u8(0xD5F0001, 256 * 256 * 3).reshape(256, 256, 3)
+    ppm, spec, back = tmp_path / "in.ppm", tmp_path / "spec.pf", tmp_path / "back.pf"
+    _write_ppm(ppm, img)
+    exe = os.path.join(ROOT, "host", "spec_gpu")
+    subprocess.check_call([exe, "spec", str(ppm), str(spec)])
+    subprocess.check_call([exe, "ispec", str(spec), str(back)])
+    x = img.astype(np.float64) / 255.0
+    ref = np.ascontiguousarray(ol.dct2d_interleaved(x, ol.REDFT10))
+    ol.lib().oracle_spec_normalise_f64(ref.ctypes.data, 256, 256, 3)
+    got = _read_pf(spec)
+    assert np.abs(got - ref).max() <= 1e-6                       # uniform range [-1,1]
+    assert np.abs(_read_pf(back) - x).max() <= 1e-6              # roundtrip <= 1e-6 abs
+
+
+def test_scan_harness(tmp_path):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    img = ol.synth_u8(0xD5F0004, 96 * 64 * 3).reshape(64, 96, 3)
+    ppm, out = tmp_path / "in.ppm", tmp_path / "sum.pf"
+    _write_ppm(ppm, img)
+    r = subprocess.run([os.path.join(ROOT, "host", "scan_gpu"), str(ppm), str(out), "500"], stderr=subprocess.PIPE, check=True)
+    assert np.abs(_read_pf(out) - img.astype(np.float64) / 255.0).max() <= 5e-6
+    errs = [float(ln.split("=")[1]) for ln in r.stderr.decode().splitlines() if "max|sum-input|" in ln]
+    assert len(errs) == (96 * 64 + 499) // 500 and errs[-1] <= 5e-6 and errs[0] > errs[-1]
