@@ -16,7 +16,7 @@ SYMBOLS = [
     "dspfft_plan_many_r2r", "dspfft_plan_r2r_2d", "dspfft_plan_set_scale", "dspfft_plan_set_axis_scale0",
     "dspfft_execute", "dspfft_plan_num_passes", "dspfft_execute_pass", "dspfft_destroy_plan", "dspfft_plan_describe", "dspfft_plan_algorithmic_bytes",
     "dspfft_last_error", "dspfft_version",
-    "dspfft_scan_zigzag", "dspfft_scan_scatter", "dspfft_accumulate", "dspfft_broadcast_dc",
+    "dspfft_scan_zigzag", "dspfft_scan_zigzag_frame_ids", "dspfft_execute_masked_accumulate", "dspfft_scan_scatter", "dspfft_accumulate", "dspfft_broadcast_dc",
     "dspfft_u8_to_f32", "dspfft_f32_to_u8",
 ]
 
@@ -42,6 +42,8 @@ def bind(lib):
     lib.dspfft_last_error.restype = C.c_char_p
     lib.dspfft_version.restype = C.c_char_p
     lib.dspfft_scan_zigzag.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, vp]
+    lib.dspfft_scan_zigzag_frame_ids.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, vp]
+    lib.dspfft_execute_masked_accumulate.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, C.c_int, vp]
     lib.dspfft_scan_scatter.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_int, vp]
     lib.dspfft_accumulate.argtypes = [vp, vp, C.c_uint64, vp]
     lib.dspfft_broadcast_dc.argtypes = [vp, vp, C.c_uint64, C.c_int, vp]

@@ -31,6 +31,7 @@ int be_launch_spec(int is_col, int id, const PassArgs &a, int nwg, void *stream)
 
 // elementwise helpers (dspfft.h, "device-side helpers")
 int be_scan_zigzag(uint32_t *lin, uint32_t w, uint32_t h, uint64_t first, uint64_t count, void *stream);
+int be_scan_zigzag_frame_ids(uint32_t *ids, uint32_t w, uint32_t h, uint64_t step, void *stream);
 int be_scan_scatter(float *recon, const float *coeffs, const uint32_t *lin, uint64_t count, uint64_t npixels, int channels, void *stream);
 int be_accumulate(float *sum, const float *image, uint64_t len, void *stream);
 int be_broadcast_dc(float *sum, const float *coeffs, uint64_t npixels, int channels, void *stream);

@@ -122,6 +122,13 @@ __global__ void zigzag_kernel(uint32_t *lin, uint32_t w, uint32_t h, uint64_t fi
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x)
 		lin[i] = zigzag_lin(w, h, first + i);
 }
+__global__ void zigzag_ids_kernel(uint32_t *ids, uint32_t w, uint32_t h, uint64_t step, uint64_t count)
+{
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t p = zigzag_lin(w, h, i);
+		ids[p] = p ? (uint32_t)(i / step) : 0xffffffffu;   // the DC pixel never matches: scan.c:445 clears it
+	}
+}
 __global__ void scatter_kernel(float *recon, const float *coeffs, const uint32_t *lin, uint64_t count, int ch)
 {
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -236,6 +243,13 @@ int be_scan_zigzag(uint32_t *lin, uint32_t w, uint32_t h, uint64_t first, uint64
 {
 	if (!count) return 0;
 	hipLaunchKernelGGL(zigzag_kernel, dim3(ew_grid(count)), dim3(256), 0, (hipStream_t)stream, lin, w, h, first, count);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+int be_scan_zigzag_frame_ids(uint32_t *ids, uint32_t w, uint32_t h, uint64_t step, void *stream)
+{
+	const uint64_t count = (uint64_t)w * h;
+	hipLaunchKernelGGL(zigzag_ids_kernel, dim3(ew_grid(count)), dim3(256), 0, (hipStream_t)stream, ids, w, h, step, count);
 	HIPCHK(hipGetLastError());
 	return 0;
 }

@@ -75,9 +75,20 @@ struct PassArgs {
 	float scale;          // every output is multiplied by scale ...
 	float out_scale0;     // ... and output index 0 of this axis additionally by out_scale0
 	float in_scale0;      // input index 0 of this axis is multiplied by in_scale0 before transforming
+	// fused scan step (scan/scan.c:429-459): the FIRST pass zeroes every input element whose owner
+	// id differs (mask[offset / mask_div] != mask_id); the LAST pass adds into `out` instead of storing
+	const uint32_t *mask;
+	uint32_t mask_id;
+	int mask_div;
+	int accumulate;
 	FftDesc fft;
 	FastDiv divB;         // divide by (ROW: Bg, COL: B)
 };
+
+DSP_HD float masked(const PassArgs &a, long long off, float v)
+{
+	return (a.mask && a.mask[off / a.mask_div] != a.mask_id) ? 0.f : v;
+}
 
 // ------------------------------------------------------------------------------------------------
 // FFT stage (in place in LDS).  Signals are interleaved: element n of signal s is buf[n*B + s].
@@ -138,7 +149,9 @@ DSP_HD void row_load(const PassArgs &a, float *raw, long long bin, int tid, int 
 {
 	const int n = a.N * a.C;
 	const float *src = a.in + bin;
-	if (((bin & 3) == 0) && ((n & 3) == 0) && ((((uintptr_t)a.in) & 15) == 0)) {
+	if (a.mask) {
+		for (int i = tid; i < n; i += nthr) raw[i] = masked(a, bin + i, src[i]);
+	} else if (((bin & 3) == 0) && ((n & 3) == 0) && ((((uintptr_t)a.in) & 15) == 0)) {
 		const float4 *s4 = reinterpret_cast<const float4 *>(src);
 		float4 *r4 = reinterpret_cast<float4 *>(raw);
 		for (int i = tid; i < n / 4; i += nthr) r4[i] = s4[i];
@@ -151,7 +164,9 @@ DSP_HD void row_store(const PassArgs &a, const float *raw, long long bout, int t
 {
 	const int n = a.N * a.C;
 	float *dst = a.out + bout;
-	if (((bout & 3) == 0) && ((n & 3) == 0) && ((((uintptr_t)a.out) & 15) == 0)) {
+	if (a.accumulate) {
+		for (int i = tid; i < n; i += nthr) dst[i] += raw[i];
+	} else if (((bout & 3) == 0) && ((n & 3) == 0) && ((((uintptr_t)a.out) & 15) == 0)) {
 		const float4 *r4 = reinterpret_cast<const float4 *>(raw);
 		float4 *d4 = reinterpret_cast<float4 *>(dst);
 		for (int i = tid; i < n / 4; i += nthr) d4[i] = r4[i];
@@ -247,6 +262,7 @@ DSP_HD void col_base(const PassArgs &a, int wg, long long &bin, long long &bout,
 	if (valid > a.K) valid = a.K;
 }
 
+DSP_HD cf ld2m(const PassArgs &a, long long off, bool vec, int nvalid);
 DSP_HD cf ld2(const float *p, bool vec, int nvalid)
 {
 	if (nvalid >= 2) {
@@ -254,6 +270,18 @@ DSP_HD cf ld2(const float *p, bool vec, int nvalid)
 		return cmk(p[0], p[1]);
 	}
 	return cmk(nvalid >= 1 ? p[0] : 0.f, 0.f);
+}
+DSP_HD cf ld2m(const PassArgs &a, long long off, bool vec, int nvalid)
+{
+	cf v = ld2(a.in + off, vec, nvalid);
+	if (a.mask) { v.x = masked(a, off, v.x); if (nvalid >= 2) v.y = masked(a, off + 1, v.y); }
+	return v;
+}
+DSP_HD void st2(float *p, bool vec, int nvalid, float a, float b);
+DSP_HD void st2a(const PassArgs &a, float *p, bool vec, int nvalid, float x, float y)
+{
+	if (a.accumulate) { if (nvalid >= 1) p[0] += x; if (nvalid >= 2) p[1] += y; }
+	else st2(p, vec, nvalid, x, y);
 }
 DSP_HD void st2(float *p, bool vec, int nvalid, float a, float b)
 {
@@ -272,7 +300,7 @@ DSP_HD void col_load2(const PassArgs &a, cf *buf, long long bin, int valid, int 
 	const bool vec = (((bin | a.es_in) & 1) == 0) && ((((uintptr_t)a.in) & 7) == 0);
 	for (int it = tid; it < N * B; it += nthr) {
 		const int y = (int)a.divB.div((uint32_t)it), j = it - y * B;
-		cf v = ld2(a.in + bin + (long long)y * a.es_in + 2 * j, vec, valid - 2 * j);
+		cf v = ld2m(a, bin + (long long)y * a.es_in + 2 * j, vec, valid - 2 * j);
 		if (y == 0) { v.x *= a.in_scale0; v.y *= a.in_scale0; }
 		buf[makhoul_dst(y, N) * B + j] = v;
 	}
@@ -296,8 +324,8 @@ DSP_HD void col_post2(const PassArgs &a, const cf *buf, long long bout, int vali
 		const float sc = a.scale;
 		float *o = a.out + bout + 2 * j;
 		const float s0 = (k == 0) ? sc * a.out_scale0 : sc;
-		st2(o + (long long)k * a.es_out, vec, valid - 2 * j, wa.x * s0, wb.x * s0);
-		if (k > 0 && km != k) st2(o + (long long)km * a.es_out, vec, valid - 2 * j, -wa.y * sc, -wb.y * sc);
+		st2a(a, o + (long long)k * a.es_out, vec, valid - 2 * j, wa.x * s0, wb.x * s0);
+		if (k > 0 && km != k) st2a(a, o + (long long)km * a.es_out, vec, valid - 2 * j, -wa.y * sc, -wb.y * sc);
 	}
 }
 
@@ -310,9 +338,9 @@ DSP_HD void col_pre3(const PassArgs &a, cf *buf, long long bin, int valid, int t
 	for (int it = tid; it < nk * B; it += nthr) {
 		const int k = (int)a.divB.div((uint32_t)it), j = it - k * B;
 		const int km = k ? N - k : 0;
-		const float *p = a.in + bin + 2 * j;
-		cf xk = ld2(p + (long long)k * a.es_in, vec, valid - 2 * j);
-		cf xm = k ? ld2(p + (long long)km * a.es_in, vec, valid - 2 * j) : cmk(0.f, 0.f);
+		const long long p = bin + 2 * j;
+		cf xk = ld2m(a, p + (long long)k * a.es_in, vec, valid - 2 * j);
+		cf xm = k ? ld2m(a, p + (long long)km * a.es_in, vec, valid - 2 * j) : cmk(0.f, 0.f);
 		if (k == 0) { xk.x *= a.in_scale0; xk.y *= a.in_scale0; }
 		const cf t = a.T[k];
 		const cf Va = cmulc(cmk(xk.x, -xm.x), t);     // conj(T[k]) (Xa[k] - i Xa[N-k])
@@ -332,7 +360,7 @@ DSP_HD void col_unpack3(const PassArgs &a, const cf *buf, long long bout, int va
 		const cf F = buf[a.pos[n] * B + j];
 		const int y = makhoul_src(n, N);
 		const float sc = (y == 0) ? a.scale * a.out_scale0 : a.scale;
-		st2(a.out + bout + (long long)y * a.es_out + 2 * j, vec, valid - 2 * j, F.x * sc, -F.y * sc);
+		st2a(a, a.out + bout + (long long)y * a.es_out + 2 * j, vec, valid - 2 * j, F.x * sc, -F.y * sc);
 	}
 }
 
@@ -348,6 +376,10 @@ struct DenseArgs {
 	long long sb0_in, sb1_in, sb2_in, sb0_out, sb1_out, sb2_out;
 	const float *cosTab;
 	float scale, out_scale0, in_scale0;
+	const uint32_t *mask;
+	uint32_t mask_id;
+	int mask_div;
+	int accumulate;
 };
 
 DSP_HD void dense_base(const DenseArgs &a, long long line, long long &bin, long long &bout)
@@ -359,7 +391,11 @@ DSP_HD void dense_base(const DenseArgs &a, long long line, long long &bin, long 
 }
 DSP_HD void dense_load(const DenseArgs &a, float *x, long long bin, int tid, int nthr)
 {
-	for (int j = tid; j < a.N; j += nthr) x[j] = a.in[bin + (long long)j * a.es_in] * (j == 0 ? a.in_scale0 : 1.f);
+	for (int j = tid; j < a.N; j += nthr) {
+		const long long off = bin + (long long)j * a.es_in;
+		const float v = (a.mask && a.mask[off / a.mask_div] != a.mask_id) ? 0.f : a.in[off];
+		x[j] = v * (j == 0 ? a.in_scale0 : 1.f);
+	}
 }
 DSP_HD void dense_compute(const DenseArgs &a, const float *x, long long bout, int tid, int nthr)
 {
@@ -383,7 +419,8 @@ DSP_HD void dense_compute(const DenseArgs &a, const float *x, long long bout, in
 			}
 			acc = x[0] + 2.f * acc;
 		}
-		a.out[bout + (long long)k * a.es_out] = acc * a.scale * (k == 0 ? a.out_scale0 : 1.f);
+		const float r = acc * a.scale * (k == 0 ? a.out_scale0 : 1.f);
+		if (a.accumulate) a.out[bout + (long long)k * a.es_out] += r; else a.out[bout + (long long)k * a.es_out] = r;
 	}
 }
 

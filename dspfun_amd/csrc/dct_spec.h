@@ -84,6 +84,30 @@ template <int C> DSP_HD void store_pix(float *p, const Pix<C> &r)
 	static_for<0, C>([&](auto c) { p[c] = r.v[c]; });
 }
 
+template <int C> DSP_HD Pix<C> load_pix_m(const PassArgs &a, long long off)
+{
+	Pix<C> v = load_pix<C>(a.in + off);
+	if (a.mask) static_for<0, C>([&](auto c) { v.v[c] = masked(a, off + c, v.v[c]); });
+	return v;
+}
+template <int C> DSP_HD void store_pix_a(const PassArgs &a, long long off, Pix<C> r)
+{
+	if (a.accumulate) { const Pix<C> o = load_pix<C>(a.out + off); static_for<0, C>([&](auto c) { r.v[c] += o.v[c]; }); }
+	store_pix<C>(a.out + off, r);
+}
+DSP_HD float4 load4_m(const PassArgs &a, long long off)
+{
+	float4 v = *reinterpret_cast<const float4 *>(a.in + off);
+	if (a.mask) { v.x = masked(a, off, v.x); v.y = masked(a, off + 1, v.y); v.z = masked(a, off + 2, v.z); v.w = masked(a, off + 3, v.w); }
+	return v;
+}
+DSP_HD void store4_a(const PassArgs &a, long long off, float4 r)
+{
+	float4 *p = reinterpret_cast<float4 *>(a.out + off);
+	if (a.accumulate) { const float4 o = *p; r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
+	*p = r;
+}
+
 // =================================================================================================
 template <int N_, int C_, int T_, int... Rs>
 struct RowSpec {
@@ -116,7 +140,7 @@ struct RowSpec {
 			static_for<0, PIX_ROUNDS>([&](auto i) {
 				const int x = tid + i * T;
 				if ((i + 1) * T <= N || x < N) {
-					const Pix<C> v = load_pix<C>(a.in + bin + (long long)x * C);
+					const Pix<C> v = load_pix_m<C>(a, bin + (long long)x * C);
 					static_for<0, C>([&](auto c) { st.pre[i * C + c] = v.v[c]; });
 				}
 			});
@@ -124,11 +148,10 @@ struct RowSpec {
 			static_for<0, K_ROUNDS>([&](auto i) {
 				const int k = tid + i * T;
 				if ((i + 1) * T <= L / 2 + 1 || k <= L / 2) {
-					const float *src = a.in + bin;
-					const Pix<C> p0 = load_pix<C>(src + (long long)k * C);
-					const Pix<C> p1 = load_pix<C>(src + (long long)(k ? N - k : 0) * C);
-					const Pix<C> p2 = load_pix<C>(src + (long long)(L - k) * C);
-					const Pix<C> p3 = load_pix<C>(src + (long long)(L + k) * C);
+					const Pix<C> p0 = load_pix_m<C>(a, bin + (long long)k * C);
+					const Pix<C> p1 = load_pix_m<C>(a, bin + (long long)(k ? N - k : 0) * C);
+					const Pix<C> p2 = load_pix_m<C>(a, bin + (long long)(L - k) * C);
+					const Pix<C> p3 = load_pix_m<C>(a, bin + (long long)(L + k) * C);
 					static_for<0, C>([&](auto c) {
 						st.pre[(i * 4 + 0) * C + c] = p0.v[c]; st.pre[(i * 4 + 1) * C + c] = p1.v[c];
 						st.pre[(i * 4 + 2) * C + c] = p2.v[c]; st.pre[(i * 4 + 3) * C + c] = p3.v[c];
@@ -255,11 +278,10 @@ struct RowSpec {
 						o2.v[c] = wm.x * sc;
 						o3.v[c] = -wm.y * sc;
 					});
-					float *dst = a.out + bout;
-					store_pix<C>(dst + (long long)k * C, o0);
-					if (k > 0) store_pix<C>(dst + (long long)(N - k) * C, o1);
-					store_pix<C>(dst + (long long)(L - k) * C, o2);
-					if (k > 0) store_pix<C>(dst + (long long)(L + k) * C, o3);
+					store_pix_a<C>(a, bout + (long long)k * C, o0);
+					if (k > 0) store_pix_a<C>(a, bout + (long long)(N - k) * C, o1);
+					if (L - k != k) store_pix_a<C>(a, bout + (long long)(L - k) * C, o2);
+					if (k > 0 && L + k != N - k) store_pix_a<C>(a, bout + (long long)(L + k) * C, o3);
 				});
 			} else {
 				tloop<N, T>(tid, [&](int x) {
@@ -270,7 +292,7 @@ struct RowSpec {
 						const float f = pf[c * (2 * PL) + n];
 						o.v[c] = ((n & 1) ? -f : f) * sc;
 					});
-					store_pix<C>(a.out + bout + (long long)x * C, o);
+					store_pix_a<C>(a, bout + (long long)x * C, o);
 				});
 			}
 		}
@@ -315,7 +337,7 @@ struct ColSpec {
 				const int it = tid + i * T;
 				if ((i + 1) * T <= N * NP || it < N * NP) {
 					const int y = it / NP, jp = it - y * NP;
-					st.pre[i] = *reinterpret_cast<const float4 *>(a.in + bin + (long long)y * a.es_in + 4 * jp);
+					st.pre[i] = load4_m(a, bin + (long long)y * a.es_in + 4 * jp);
 				}
 			});
 		} else {
@@ -324,9 +346,9 @@ struct ColSpec {
 				if ((i + 1) * T <= (N / 2 + 1) * NP || it < (N / 2 + 1) * NP) {
 					const int k = it / NP, jp = it - k * NP;
 					const int km = k ? N - k : 0;
-					const float *p = a.in + bin + 4 * jp;
-					st.pre[2 * i] = *reinterpret_cast<const float4 *>(p + (long long)k * a.es_in);
-					st.pre[2 * i + 1] = *reinterpret_cast<const float4 *>(p + (long long)km * a.es_in);
+					const long long p = bin + 4 * jp;
+					st.pre[2 * i] = load4_m(a, p + (long long)k * a.es_in);
+					st.pre[2 * i + 1] = load4_m(a, p + (long long)km * a.es_in);
 				}
 			});
 		}
@@ -451,12 +473,12 @@ struct ColSpec {
 					const cf A1 = cmk(zk.z + zm.z, zk.w - zm.w), B1 = cmul_mi(cmk(zk.z - zm.z, zk.w + zm.w));
 					const cf wa0 = cmul(t, A0), wb0 = cmul(t, B0), wa1 = cmul(t, A1), wb1 = cmul(t, B1);
 					const float sc = a.scale, s0 = (k == 0) ? sc * a.out_scale0 : sc;
-					float *o = a.out + bout + 4 * jp;
+					const long long o = bout + 4 * jp;
 					float4 r0; r0.x = wa0.x * s0; r0.y = wb0.x * s0; r0.z = wa1.x * s0; r0.w = wb1.x * s0;
-					*reinterpret_cast<float4 *>(o + (long long)k * a.es_out) = r0;
+					store4_a(a, o + (long long)k * a.es_out, r0);
 					if (k > 0 && km != k) {
 						float4 r1; r1.x = -wa0.y * sc; r1.y = -wb0.y * sc; r1.z = -wa1.y * sc; r1.w = -wb1.y * sc;
-						*reinterpret_cast<float4 *>(o + (long long)km * a.es_out) = r1;
+						store4_a(a, o + (long long)km * a.es_out, r1);
 					}
 				});
 			} else {
@@ -466,7 +488,7 @@ struct ColSpec {
 					const int y = makhoul_src(n, N);
 					const float sc = (y == 0) ? a.scale * a.out_scale0 : a.scale;
 					float4 r; r.x = F.x * sc; r.y = -F.y * sc; r.z = F.z * sc; r.w = -F.w * sc;
-					*reinterpret_cast<float4 *>(a.out + bout + (long long)y * a.es_out + 4 * jp) = r;
+					store4_a(a, bout + (long long)y * a.es_out + 4 * jp, r);
 				});
 			}
 		}

@@ -303,7 +303,9 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 	}
 }
 
-int run_pass(const dspfft_plan_s *pl, const Pass &P, const float *in, float *out, bool last, void *stream)
+struct Fuse { const uint32_t *mask = nullptr; uint32_t id = 0; int div = 1; bool accumulate = false; };
+
+int run_pass(const dspfft_plan_s *pl, const Pass &P, const float *in, float *out, bool last, void *stream, const Fuse &fz = Fuse())
 {
 	const float scale = last ? pl->scale : 1.f;
 	// iterate the host-side batch dims (rare: more batch levels than a kernel takes)
@@ -315,6 +317,7 @@ int run_pass(const dspfft_plan_s *pl, const Pass &P, const float *in, float *out
 		if (P.type == Pass::DENSE) {
 			DenseArgs a = P.da;
 			a.in = in + oin; a.out = out + oout; a.scale = scale; a.in_scale0 = pl->in0[P.axis]; a.out_scale0 = pl->out0[P.axis];
+			a.mask = fz.mask; a.mask_id = fz.id; a.mask_div = fz.div; a.accumulate = fz.accumulate;
 			rc = be_launch_dense(a, P.g, stream);
 		} else {
 			const bool ptr_ok = P.type == Pass::ROW
@@ -323,10 +326,12 @@ int run_pass(const dspfft_plan_s *pl, const Pass &P, const float *in, float *out
 			if (P.has_spec && ptr_ok) {
 				PassArgs a = P.spa;
 				a.in = in + oin; a.out = out + oout; a.scale = scale; a.in_scale0 = pl->in0[P.axis]; a.out_scale0 = pl->out0[P.axis];
+				a.mask = fz.mask; a.mask_id = fz.id; a.mask_div = fz.div; a.accumulate = fz.accumulate;
 				rc = be_launch_spec(P.type == Pass::COL, P.spec.id, a, P.spec_nwg, stream);
 			} else {
 				PassArgs a = P.pa;
 				a.in = in + oin; a.out = out + oout; a.scale = scale; a.in_scale0 = pl->in0[P.axis]; a.out_scale0 = pl->out0[P.axis];
+				a.mask = fz.mask; a.mask_id = fz.id; a.mask_div = fz.div; a.accumulate = fz.accumulate;
 				rc = P.type == Pass::ROW ? be_launch_row(a, P.g, stream) : be_launch_col(a, P.g, stream);
 			}
 		}
@@ -402,6 +407,35 @@ extern "C" int dspfft_execute(dspfft_plan pl, const float *d_in, float *d_out, v
 		if (rc) return rc;
 	}
 	return 0;
+}
+
+extern "C" int dspfft_execute_masked_accumulate(dspfft_plan pl, const float *d_in, float *d_work, float *d_acc,
+                                                const uint32_t *d_ids, uint32_t id, int elems_per_id, void *stream)
+{
+	if (!pl || !d_in || !d_work || !d_acc) return fail(-1, "null plan or buffer");
+	if (d_ids && elems_per_id < 1) return fail(-1, "elems_per_id must be >= 1");
+	const size_t np = pl->passes.size();
+	for (const Pass &P : pl->passes)
+		if (!P.hostloop.empty()) return fail(-2, "masked/accumulating execution is not available for plans that need a host-side batch loop");
+	for (size_t i = 0; i < np; i++) {
+		const Pass &P = pl->passes[i];
+		const bool firstp = i == 0, lastp = i + 1 == np;
+		Fuse fz;
+		if (firstp && d_ids) { fz.mask = d_ids; fz.id = id; fz.div = elems_per_id; }
+		fz.accumulate = lastp;
+		const float *src = firstp ? d_in : d_work;
+		float *dst = lastp ? d_acc : d_work;
+		int rc = run_pass(pl, P, src, dst, lastp, stream, fz);
+		if (rc) return rc;
+	}
+	return 0;
+}
+
+extern "C" int dspfft_scan_zigzag_frame_ids(uint32_t *d_ids, uint32_t w, uint32_t h, uint64_t step, void *s)
+{
+	if (!d_ids || !w || !h || !step) return fail(-1, "bad arguments");
+	if ((uint64_t)w * h > 0xffffffffull) return fail(-1, "image too large for 32-bit offsets");
+	return be_scan_zigzag_frame_ids(d_ids, w, h, step, s) ? fail(-4, "launch failed") : 0;
 }
 
 extern "C" int dspfft_plan_num_passes(dspfft_plan pl) { return pl ? (int)pl->passes.size() : 0; }

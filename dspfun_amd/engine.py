@@ -76,6 +76,11 @@ class Plan:
         d_out = d_in if d_out is None else d_out
         self._check(self._lib.dspfft_execute_pass(self._h, index, C.c_void_p(d_in), C.c_void_p(d_out), C.c_void_p(stream)))
 
+    def execute_masked_accumulate(self, d_in, d_work, d_acc, d_ids=0, frame_id=0, elems_per_id=1, stream=0):
+        """scan/scan.c:429-459 fused: d_acc += plan(d_in where ids == frame_id)"""
+        self._check(self._lib.dspfft_execute_masked_accumulate(
+            self._h, C.c_void_p(d_in), C.c_void_p(d_work), C.c_void_p(d_acc), C.c_void_p(d_ids or None), frame_id, elems_per_id, C.c_void_p(stream)))
+
     def describe(self):
         buf = C.create_string_buffer(4096)
         self._check(self._lib.dspfft_plan_describe(self._h, buf, len(buf)))

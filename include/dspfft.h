@@ -80,6 +80,19 @@ int dspfft_scan_zigzag(uint32_t *d_lin, uint32_t w, uint32_t h, uint64_t first, 
 int dspfft_scan_scatter(float *d_recon, const float *d_coeffs, const uint32_t *d_lin, uint64_t count,
                         uint64_t npixels, int channels, void *hip_stream);
 
+/* The whole per-frame step of scan's hot loop (scan/scan.c:429-432,445-459) as one fused execution of an
+ * inverse plan:   d_acc += plan( d_in restricted to elements e with d_ids[e / elems_per_id] == id )
+ * The first pass masks while loading (no zeroed `reconstruction` buffer, no scatter), the last pass
+ * adds into d_acc while storing (no `image` buffer, no separate sum pass): 21.3 B/sample of traffic for
+ * a 3-channel image instead of 32.  d_work: scratch with the plan's output layout.  d_ids == NULL
+ * disables masking.  elems_per_id = channels for the image tools' interleaved buffers. */
+int dspfft_execute_masked_accumulate(dspfft_plan plan, const float *d_in, float *d_work, float *d_acc,
+                                     const uint32_t *d_ids, uint32_t id, int elems_per_id, void *hip_stream);
+
+/* d_ids[y*w+x] = (zigzag scan index of (y,x)) / step -- the output frame (scan/scan.c:421-427) that
+ * reconstructs coefficient (y,x); the DC pixel gets 0xFFFFFFFF (it is pre-added, scan.c:377-383,445). */
+int dspfft_scan_zigzag_frame_ids(uint32_t *d_ids, uint32_t w, uint32_t h, uint64_t step, void *hip_stream);
+
 /* scan/scan.c:451-459 arithmetic: sum += image (len floats). */
 int dspfft_accumulate(float *d_sum, const float *d_image, uint64_t len, void *hip_stream);
 

@@ -137,6 +137,11 @@ int be_scan_zigzag(uint32_t *lin, uint32_t w, uint32_t h, uint64_t first, uint64
 	for (uint64_t i = 0; i < count; i++) lin[i] = zigzag_lin(w, h, first + i);
 	return 0;
 }
+int be_scan_zigzag_frame_ids(uint32_t *ids, uint32_t w, uint32_t h, uint64_t step, void *)
+{
+	for (uint64_t i = 0; i < (uint64_t)w * h; i++) { const uint32_t p = zigzag_lin(w, h, i); ids[p] = p ? (uint32_t)(i / step) : 0xffffffffu; }
+	return 0;
+}
 int be_scan_scatter(float *recon, const float *coeffs, const uint32_t *lin, uint64_t count, uint64_t npixels, int ch, void *)
 {
 	memset(recon, 0, sizeof(float) * npixels * ch);

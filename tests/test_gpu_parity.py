@@ -259,3 +259,37 @@ def test_generic_and_specialised_kernels_agree(gpu):
     p.execute(b.data_ptr())
     gpu.cuda.synchronize()
     assert float((a - b).abs().max() / a.abs().max()) < 2e-6
+
+
+def test_fused_scan_step_c4_like(gpu):
+    """the fused per-frame step (dspfft_execute_masked_accumulate) against the unfused device path
+    and the f64 restatement, 960x540x3, zigzag, 6 frames"""
+    from dspfun_amd import _lib, REDFT10, REDFT01
+    L = _lib.load()
+    w, h, c = 960, 540, 3
+    x = ol.synth_f32(0xD5F0004, w * h * c).reshape(h, w, c)
+    coeffs = dev(gpu, x)
+    plan_image(h, w, c, REDFT10).set_scale(1.0 / (4.0 * w * h)).execute(coeffs.data_ptr())
+    inv = plan_image(h, w, c, REDFT01)
+    assert "ROW*" in inv.describe() and "COL*" in inv.describe()
+    nframes = 6
+    step = (w * h + nframes - 1) // nframes
+    ids = gpu.zeros(w * h, dtype=gpu.int32, device="cuda:0")
+    assert L.dspfft_scan_zigzag_frame_ids(ids.data_ptr(), w, h, step, None) == 0
+    acc = gpu.empty_like(coeffs)
+    work = gpu.empty_like(coeffs)
+    assert L.dspfft_broadcast_dc(acc.data_ptr(), coeffs.data_ptr(), w * h, c, None) == 0
+    cf64 = np.ascontiguousarray(ol.dct2d_interleaved(x.astype(np.float64), REDFT10, impl="port"))
+    ol.lib().oracle_scan_normalise_f64(cf64.ctypes.data, w, h, c)
+    ref = np.ascontiguousarray(np.broadcast_to(cf64[0, 0], (h, w, c)).copy())
+    idh = (ol.zigzag_order(w, h), None)
+    frame_of = np.empty(w * h, dtype=np.int64)
+    frame_of[idh[0].astype(np.int64)] = np.arange(w * h) // step
+    frame_of[0] = -1
+    for f in range(nframes):
+        inv.execute_masked_accumulate(coeffs.data_ptr(), work.data_ptr(), acc.data_ptr(), ids.data_ptr(), f, c)
+        rec = np.where((frame_of.reshape(h, w) == f)[:, :, None], cf64, 0.0)
+        ref += ol.dct2d_interleaved(rec, REDFT01, impl="port", threads=8)
+        gpu.cuda.synchronize()
+        assert np.abs(acc.cpu().numpy() - ref).max() < 5e-6, f
+    assert np.abs(acc.cpu().numpy() - x).max() <= 5e-6

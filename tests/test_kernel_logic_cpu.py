@@ -199,3 +199,30 @@ def test_specialised_out_of_place_and_misaligned_fallback():
     view[:] = xm.ravel()
     p.execute(view.ctypes.data)
     assert relerr(view.reshape(h, w, c), ol.dct2d_interleaved(xm.astype(np.float64), REDFT01, impl="port", threads=4)) < TOL
+
+
+@pytest.mark.parametrize("h,w,c", [(24, 40, 3), (4, 3840, 3), (2160, 8, 3), (17, 40, 3), (30, 45, 1)])
+def test_fused_scan_step(h, w, c):
+    """scan/scan.c:429-459 in one fused execution == scatter + REDFT01^2 + accumulate, frame by frame"""
+    import ctypes as C
+    L = emul()
+    x = ol.synth_f32(h * 3 + w, h * w * c).reshape(h, w, c)
+    coeffs = x.copy()
+    Plan.image(h, w, c, REDFT10, lib=L).set_scale(1.0 / (4 * w * h)).execute(coeffs.ctypes.data)
+    ids = np.zeros(h * w, dtype=np.uint32)
+    nframes = 5
+    step = (h * w + nframes - 1) // nframes
+    assert L.dspfft_scan_zigzag_frame_ids(ids.ctypes.data, w, h, step, None) == 0
+    zz = ol.zigzag_order(w, h)
+    assert ids[0] == 0xFFFFFFFF and np.array_equal(ids[zz[1:].astype(np.int64)], (np.arange(1, h * w) // step).astype(np.uint32))
+    inv = Plan.image(h, w, c, REDFT01, lib=L)
+    acc = np.ascontiguousarray(np.broadcast_to(coeffs[0, 0], (h, w, c)).copy())
+    work = np.zeros_like(acc)
+    ref = acc.astype(np.float64).copy()
+    c64 = coeffs.astype(np.float64)
+    for f in range(nframes):
+        inv.execute_masked_accumulate(coeffs.ctypes.data, work.ctypes.data, acc.ctypes.data, ids.ctypes.data, f, c)
+        rec = np.where((ids.reshape(h, w) == f)[:, :, None], c64, 0.0)
+        ref += ol.dct2d_interleaved(rec, REDFT01, impl="port")
+        assert np.abs(acc - ref).max() < 1e-5, f
+    assert np.abs(acc - x).max() < 1e-5
