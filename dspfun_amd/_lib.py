@@ -18,6 +18,8 @@ SYMBOLS = [
     "dspfft_last_error", "dspfft_version",
     "dspfft_scan_zigzag", "dspfft_scan_zigzag_frame_ids", "dspfft_execute_masked_accumulate", "dspfft_scan_scatter", "dspfft_accumulate", "dspfft_broadcast_dc",
     "dspfft_u8_to_f32", "dspfft_f32_to_u8",
+    "dspfft_zoom_ncomponents", "dspfft_zoom_basis", "dspfft_zoom_work_floats", "dspfft_zoom_product", "dspfft_gemm_nt_f32",
+    "dspfft_zoom_last_error",
 ]
 
 _lib = None
@@ -49,6 +51,16 @@ def bind(lib):
     lib.dspfft_broadcast_dc.argtypes = [vp, vp, C.c_uint64, C.c_int, vp]
     lib.dspfft_u8_to_f32.argtypes = [vp, vp, C.c_uint64, vp]
     lib.dspfft_f32_to_u8.argtypes = [vp, vp, C.c_double, C.c_uint64, vp]
+    if hasattr(lib, "dspfft_zoom_product"):      # HIP-only entry points (absent from the CPU emulation used in tests)
+        lib.dspfft_zoom_ncomponents.restype = C.c_size_t
+        lib.dspfft_zoom_ncomponents.argtypes = [C.c_double, C.c_double, C.c_size_t]
+        lib.dspfft_zoom_basis.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_size_t, C.c_size_t, vp]
+        lib.dspfft_zoom_work_floats.restype = C.c_size_t
+        lib.dspfft_zoom_work_floats.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_int]
+        lib.dspfft_zoom_product.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_int, C.c_int, vp, vp]
+        lib.dspfft_gemm_nt_f32.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_longlong, C.c_longlong, C.c_int,
+                                           C.c_int, C.c_longlong, C.c_longlong, C.c_longlong, C.c_float, vp]
+        lib.dspfft_zoom_last_error.restype = C.c_char_p
     return lib
 
 

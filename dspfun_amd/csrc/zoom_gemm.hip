@@ -1,0 +1,165 @@
+// zoom_gemm.hip -- zoom's dense separable basis product (zoom/zoom.c:36-68 basis, :361-375 product)
+// on the f32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32: exact f32 multiply-accumulate at the
+// vector-FP32 rate, 157 TFLOP/s peak).  This is the one place on the hot path that is a true dense
+// GEMM: at BASELINE config 3 it is 310.6 GFLOP against ~0.45 GB of operands.
+//
+//   per channel z:   Tt = XB (vw x cw) . C_z^T (cw x ch)          -> Tt  (vw x ch)
+//                    out_z = YB (vh x ch) . Tt^T (ch x vw) / (w h) -> out (vh x vw), interleaved store
+// where XB/YB are the reference's bases with the halved DC term folded in as column 0 = 1/2
+// (zoom.c:364 `tmp = C[row][0]/2`, :369 `s = tmp[0]/2`).  Both products are "NT" GEMMs (both
+// operands have the summed index contiguous), so one kernel serves both.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+
+#include "../../include/dspfft.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 8, LDP = BM + 4;   // LDS tiles are [k][row], padded
+
+// C[m*ldc + n*cs] = alpha * sum_k A[m*lda + k] * B[n*ldb + k];  batch b offsets: sa, sb, sc
+__global__ void __launch_bounds__(256) gemm_nt_f32_mfma(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
+                                                        int M, int N, int K, long long lda, long long ldb, long long ldc, int cs,
+                                                        long long sa, long long sb, long long sc, float alpha)
+{
+	__shared__ float As[2][BK][LDP];
+	__shared__ float Bs[2][BK][LDP];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int wm = wave >> 1, wn = wave & 1;                 // 2 x 2 waves, each 64 x 64
+	const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
+	A += (long long)blockIdx.z * sa; B += (long long)blockIdx.z * sb; C += (long long)blockIdx.z * sc;
+
+	// staging: thread -> (row = tid / 2, k4 = tid % 2): one float4 along K from A and one from B
+	const int srow = tid >> 1, sk = (tid & 1) * 4;
+	const bool a_ok = bm + srow < M, b_ok = bn + srow < N;
+	const float *ap = A + (long long)(bm + srow) * lda + sk;
+	const float *bp = B + (long long)(bn + srow) * ldb + sk;
+	const bool vec = ((lda | ldb | sa | sb) & 3) == 0 && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0;
+
+	auto fetch = [&](const float *p, bool ok, int k0) -> float4 {
+		float4 v; v.x = v.y = v.z = v.w = 0.f;
+		if (!ok) return v;
+		if (vec && k0 + sk + 3 < K) return *reinterpret_cast<const float4 *>(p + k0);
+		if (k0 + sk + 0 < K) v.x = p[k0 + 0];
+		if (k0 + sk + 1 < K) v.y = p[k0 + 1];
+		if (k0 + sk + 2 < K) v.z = p[k0 + 2];
+		if (k0 + sk + 3 < K) v.w = p[k0 + 3];
+		return v;
+	};
+	auto stash = [&](int buf, float4 a, float4 b) {
+		As[buf][sk + 0][srow] = a.x; As[buf][sk + 1][srow] = a.y; As[buf][sk + 2][srow] = a.z; As[buf][sk + 3][srow] = a.w;
+		Bs[buf][sk + 0][srow] = b.x; Bs[buf][sk + 1][srow] = b.y; Bs[buf][sk + 2][srow] = b.z; Bs[buf][sk + 3][srow] = b.w;
+	};
+
+	f32x16 acc[2][2];
+	for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+	float4 ra = fetch(ap, a_ok, 0), rb = fetch(bp, b_ok, 0);
+	stash(0, ra, rb);
+	__syncthreads();
+	const int nk = (K + BK - 1) / BK;
+	const int li = lane & 31, lk = lane >> 5;
+	for (int kt = 0; kt < nk; kt++) {
+		const int cur = kt & 1;
+		if (kt + 1 < nk) { ra = fetch(ap, a_ok, (kt + 1) * BK); rb = fetch(bp, b_ok, (kt + 1) * BK); }
+#pragma unroll
+		for (int s = 0; s < BK / 2; s++) {
+			const float a0 = As[cur][2 * s + lk][wm * 64 + li], a1 = As[cur][2 * s + lk][wm * 64 + 32 + li];
+			const float b0 = Bs[cur][2 * s + lk][wn * 64 + li], b1 = Bs[cur][2 * s + lk][wn * 64 + 32 + li];
+			acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+			acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+			acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+			acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+		}
+		if (kt + 1 < nk) stash(cur ^ 1, ra, rb);
+		__syncthreads();
+	}
+	// C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+	for (int i = 0; i < 2; i++)
+		for (int j = 0; j < 2; j++) {
+			const int n = bn + wn * 64 + j * 32 + li;
+			if (n >= N) continue;
+			for (int r = 0; r < 16; r++) {
+				const int m = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+				if (m < M) C[(long long)m * ldc + (long long)n * cs] = alpha * acc[i][j][r];
+			}
+		}
+}
+
+// zoom/zoom.c:36-68 with column 0 = 1/2 (the halved DC term) and columns 1.. = the reference's basis
+__global__ void zoom_basis_kernel(float *basis, int type, double scale_num, double scale_den, double offset, size_t nvectors, size_t len, size_t nc)
+{
+	const size_t total = nvectors * nc;
+	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+		const size_t b = i / nc, n = i - b * nc;
+		if (n == 0) { basis[i] = 0.5f; continue; }
+		double k, N;
+		if (type == 2) { k = b + offset; N = len * scale_num / scale_den; }                                   /* native  (zoom.c:50-53) */
+		else if (type == 0) { k = (b + offset) * scale_den / scale_num; N = (double)len; }                    /* interpolated (:54-57) */
+		else { k = (b + offset) * (len - 1) * scale_den / (len * scale_num - scale_den); N = (double)len; }   /* centered (:58-61) */
+		basis[i] = (float)cos(M_PI * (k + 0.5) * (double)n / N);
+	}
+}
+
+__global__ void deinterleave3_kernel(float *planes, const float *img, size_t npix)
+{
+	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npix * 3; i += (size_t)gridDim.x * blockDim.x) {
+		const size_t p = i / 3, z = i - p * 3;
+		planes[z * npix + p] = img[i];
+	}
+}
+
+thread_local char g_zerr[256] = "";
+
+}  // namespace
+
+extern "C" const char *dspfft_zoom_last_error(void) { return g_zerr; }
+
+extern "C" size_t dspfft_zoom_ncomponents(double scale_num, double scale_den, size_t len)
+{
+	if (len * scale_num / scale_den < 1) { scale_num = 1; scale_den = (double)len; }      /* zoom.c:37-40 */
+	const double want = round(len * scale_num / scale_den);
+	return want < (double)len ? (size_t)want : len;                                       /* zoom.c:41 */
+}
+
+extern "C" int dspfft_zoom_basis(float *d_basis, int type, double scale_num, double scale_den, double offset,
+                                 size_t nvectors, size_t len, void *stream)
+{
+	if (!d_basis || type < 0 || type > 2 || !nvectors || !len) { snprintf(g_zerr, sizeof g_zerr, "bad arguments"); return -1; }
+	if (len * scale_num / scale_den < 1) { scale_num = 1; scale_den = (double)len; }
+	const size_t nc = dspfft_zoom_ncomponents(scale_num, scale_den, len);
+	hipLaunchKernelGGL(zoom_basis_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, d_basis, type, scale_num, scale_den, offset, nvectors, len, nc);
+	return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+extern "C" int dspfft_gemm_nt_f32(const float *A, const float *B, float *C, int M, int N, int K,
+                                  long long lda, long long ldb, long long ldc, int cs,
+                                  int batch, long long sa, long long sb, long long sc, float alpha, void *stream)
+{
+	if (!A || !B || !C || M < 1 || N < 1 || K < 1 || batch < 1 || cs < 1) { snprintf(g_zerr, sizeof g_zerr, "bad arguments"); return -1; }
+	dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
+	hipLaunchKernelGGL(gemm_nt_f32_mfma, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, cs, sa, sb, sc, alpha);
+	return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+extern "C" size_t dspfft_zoom_work_floats(int w, int h, size_t ch, int vw)
+{
+	return (size_t)3 * w * h + (size_t)3 * vw * ch;      // planar copy of the coefficients + Tt for 3 channels
+}
+
+extern "C" int dspfft_zoom_product(const float *d_coeffs, int w, int h, const float *d_xb, size_t cw, const float *d_yb, size_t ch,
+                                   float *d_out, int vw, int vh, float *d_work, void *stream)
+{
+	if (!d_coeffs || !d_xb || !d_yb || !d_out || !d_work || cw < 1 || ch < 1 || cw > (size_t)w || ch > (size_t)h) { snprintf(g_zerr, sizeof g_zerr, "bad arguments"); return -1; }
+	const size_t npix = (size_t)w * h;
+	float *planes = d_work, *Tt = d_work + 3 * npix;
+	hipLaunchKernelGGL(deinterleave3_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, planes, d_coeffs, npix);
+	// Tt_z (vw x ch) = XB (vw x cw) . plane_z[:ch, :cw]^T
+	int rc = dspfft_gemm_nt_f32(d_xb, planes, Tt, vw, (int)ch, (int)cw, (long long)cw, w, (long long)ch, 1, 3, 0, (long long)npix, (long long)vw * ch, 1.f, stream);
+	if (rc) return rc;
+	// out_z (vh x vw, interleaved) = YB (vh x ch) . Tt_z^T / (w h)
+	return dspfft_gemm_nt_f32(d_yb, Tt, d_out, vh, vw, (int)ch, (long long)ch, (long long)ch, (long long)vw * 3, 3, 3, 0, (long long)vw * ch, 1, 1.f / ((float)w * (float)h), stream);
+}

@@ -1,0 +1,40 @@
+"""Host-side mirror of zoom's frame computation (zoom/zoom.c:263-265 forward transform,
+:347-375 basis generation and dense separable product) over device memory."""
+import ctypes as C
+
+from . import _lib
+from .engine import Plan, DspfftError, REDFT10
+
+INTERPOLATED, CENTERED, NATIVE = 0, 1, 2     # zoom/zoom.c:20-26
+
+
+class Zoom:
+    """coeffs = REDFT10^2(image) once (zoom.c:263-265); frame(...) per output frame (zoom.c:320-375)."""
+
+    def __init__(self, torch, image_hwc):
+        self.torch = torch
+        self.lib = _lib.load()
+        self.h, self.w, c = image_hwc.shape
+        assert c == 3 and image_hwc.dtype == torch.float32 and image_hwc.is_cuda
+        self.coeffs = image_hwc.contiguous().clone()
+        Plan.image(self.h, self.w, 3, REDFT10).execute(self.coeffs.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+
+    def _basis(self, basis_type, num, den, offset, nvectors, length):
+        nc = self.lib.dspfft_zoom_ncomponents(num, den, length)
+        b = self.torch.empty(nvectors * nc, dtype=self.torch.float32, device=self.coeffs.device)
+        if self.lib.dspfft_zoom_basis(b.data_ptr(), basis_type, num, den, offset, nvectors, length, None):
+            raise DspfftError(self.lib.dspfft_zoom_last_error().decode())
+        return b, nc
+
+    def frame(self, vw, vh, xscale=(1.0, 1.0), yscale=(1.0, 1.0), vx=0.0, vy=0.0, basis_type=INTERPOLATED):
+        """one output frame: (vh, vw, 3) f32"""
+        torch = self.torch
+        xb, cw = self._basis(basis_type, xscale[0], xscale[1], vx, vw, self.w)
+        yb, ch = self._basis(basis_type, yscale[0], yscale[1], vy, vh, self.h)
+        out = torch.empty((vh, vw, 3), dtype=torch.float32, device=self.coeffs.device)
+        work = torch.empty(self.lib.dspfft_zoom_work_floats(self.w, self.h, ch, vw), dtype=torch.float32, device=self.coeffs.device)
+        rc = self.lib.dspfft_zoom_product(self.coeffs.data_ptr(), self.w, self.h, xb.data_ptr(), cw, yb.data_ptr(), ch,
+                                          out.data_ptr(), vw, vh, work.data_ptr(), None)
+        if rc:
+            raise DspfftError(self.lib.dspfft_zoom_last_error().decode())
+        return out

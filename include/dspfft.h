@@ -105,6 +105,30 @@ int dspfft_u8_to_f32(float *d_dst, const uint8_t *d_src, uint64_t len, void *hip
 /* motion/motion.c:756-776 (spec none, !linear, 8-bit output): pix = clamp(lround(c * mul), 0, 255). */
 int dspfft_f32_to_u8(uint8_t *d_dst, const float *d_src, double mul, uint64_t len, void *hip_stream);
 
+/* ---- zoom's dense basis product on the f32 matrix cores ---- */
+
+/* zoom/zoom.c:37-41: number of cosine components kept for a (scale, length) pair. */
+size_t dspfft_zoom_ncomponents(double scale_num, double scale_den, size_t len);
+
+/* zoom/zoom.c:36-68 (generate_scaled_basis): d_basis[b*nc + n], nc = dspfft_zoom_ncomponents(...), with
+ * column 0 = 1/2 (the halved DC term of zoom.c:364,369) and column n >= 1 = cos(pi (k+1/2) n / N).
+ * type: 0 interpolated, 1 centered, 2 native (zoom/zoom.c:20-26). */
+int dspfft_zoom_basis(float *d_basis, int type, double scale_num, double scale_den, double offset,
+                      size_t nvectors, size_t len, void *hip_stream);
+
+/* zoom/zoom.c:361-375: out (vh x vw x 3) = YB . (C_z[:ch,:cw] . XB^T) / (w h) for the three channels of the
+ * unnormalised REDFT10^2 coefficients d_coeffs (h x w x 3 interleaved).  d_work: dspfft_zoom_work_floats(). */
+size_t dspfft_zoom_work_floats(int w, int h, size_t ch, int vw);
+int dspfft_zoom_product(const float *d_coeffs, int w, int h, const float *d_xb, size_t cw, const float *d_yb, size_t ch,
+                        float *d_out, int vw, int vh, float *d_work, void *hip_stream);
+
+/* The GEMM underneath (also the building block for applybasis' basis x pixel sums):
+ * C[m*ldc + n*cs] = alpha * sum_k A[m*lda + k] * B[n*ldb + k], `batch` problems at offsets sa/sb/sc. */
+int dspfft_gemm_nt_f32(const float *A, const float *B, float *C, int M, int N, int K,
+                       long long lda, long long ldb, long long ldc, int cs,
+                       int batch, long long sa, long long sb, long long sc, float alpha, void *hip_stream);
+const char *dspfft_zoom_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,78 @@
+"""CPU: the multi-process path (dspfun_amd/dist.py) with world_size 2 over gloo.  The local transforms
+run on the test-only emulation backend (there is no GPU here); what is under test is the sharding
+and the all-to-all re-slabbing, against the single-process oracle."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, d, h, w, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle_lib as ol
+        from emul_lib import emul
+        from dspfun_amd.dist import SlabDCT3D, shard_range
+        vol = ol.synth_u8(0xD5F0005, d * h * w).astype(np.float32).reshape(d, h, w)
+        lo, hi = shard_range(d, rank, world)
+        eng = SlabDCT3D(d, h, w, lib=emul())
+        mine = torch.from_numpy(vol[lo:hi].copy())
+        c = eng.forward(mine)
+        # reference: REDFT10^3 with motion's uniform scaling, rows of my slab
+        ref = ol.r2r_many(vol.astype(np.float64), [d, h, w], [ol.REDFT10] * 3, impl="port")
+        ol.lib().oracle_motion_uniform_f64(ref.ctypes.data, d, h, w, h, w, 1)
+        ref = ref.reshape(d, h, w)
+        hl = h // world
+        err_f = np.abs(c.numpy() - ref[:, rank * hl:(rank + 1) * hl, :]).max() / np.abs(ref).max()
+        back = eng.inverse(c)
+        err_b = np.abs(back.numpy() - vol[lo:hi]).max()
+        q.put((rank, float(err_f), float(err_b)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("d,h,w", [(8, 12, 10), (16, 30, 24)])
+def test_slab_dct3d_world2(d, h, w):
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "emul")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(os.path.dirname(HERE), "oracle"), "liboracle.so"])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, d, h, w, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err_f, err_b in res:
+        assert err_f < 1e-5, (rank, err_f)
+        assert err_b < 2e-3, (rank, err_b)       # pixel domain 0..255: far below half an LSB
+
+
+def test_shard_range_covers_everything():
+    from dspfun_amd.dist import shard_range
+    for n in (1, 7, 8, 256, 1001):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1

@@ -293,3 +293,95 @@ def test_fused_scan_step_c4_like(gpu):
         gpu.cuda.synchronize()
         assert np.abs(acc.cpu().numpy() - ref).max() < 5e-6, f
     assert np.abs(acc.cpu().numpy() - x).max() <= 5e-6
+
+
+# ---- zoom: dense basis product on the f32 matrix cores ----
+@pytest.mark.parametrize("w,h,scale,off,btype", [(12, 10, 3, 0.0, 0), (40, 24, 2, 0.5, 0), (33, 17, 2, 0.0, 2), (24, 40, 1, 0.0, 1), (64, 48, 0.5, 0.0, 0)])
+def test_zoom_small_vs_oracle(gpu, w, h, scale, off, btype):
+    from dspfun_amd.zoom import Zoom
+    x = ol.synth_f32(w * h, w * h * 3).reshape(h, w, 3)
+    vw, vh = max(1, int(round(w * scale))), max(1, int(round(h * scale)))
+    z = Zoom(gpu, dev(gpu, x))
+    got = z.frame(vw, vh, (scale, 1.0), (scale, 1.0), off, off, btype).cpu().numpy()
+    L = ol.lib()
+    cf = np.ascontiguousarray(ol.dct2d_interleaved(x.astype(np.float64), ol.REDFT10))
+    cw = L.oracle_zoom_basis_f64(None, btype, scale, 1.0, off, vw, w)
+    ch = L.oracle_zoom_basis_f64(None, btype, scale, 1.0, off, vh, h)
+    xb = np.zeros(max(1, vw * (cw - 1))); yb = np.zeros(max(1, vh * (ch - 1)))
+    L.oracle_zoom_basis_f64(xb.ctypes.data, btype, scale, 1.0, off, vw, w)
+    L.oracle_zoom_basis_f64(yb.ctypes.data, btype, scale, 1.0, off, vh, h)
+    ref = np.zeros((vh, vw, 3))
+    L.oracle_zoom_product_f64(cf.ctypes.data, w, h, xb.ctypes.data, cw, yb.ctypes.data, ch, ref.ctypes.data, vw, vh)
+    assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_c3_zoom_4x_1080p(gpu):
+    """BASELINE config 3: 1920x1080 RGB -> 7680x4320, scale 4/1, offset 0, interpolated basis.
+    Property (SURVEY 8d): out[::4, ::4] == input (samples coincide at integer scale)."""
+    from dspfun_amd.zoom import Zoom
+    w, h = 1920, 1080
+    x = ol.synth_f32(0xD5F0003, w * h * 3).reshape(h, w, 3)
+    z = Zoom(gpu, dev(gpu, x))
+    out = z.frame(4 * w, 4 * h, (4.0, 1.0), (4.0, 1.0))
+    gpu.cuda.synchronize()
+    sub = out[::4, ::4].cpu().numpy()
+    assert np.abs(sub - x).max() <= 2e-5
+    # one full output row against the f64 restatement (row 1234 of 4320)
+    L = ol.lib()
+    cf = ol.dct2d_interleaved(x.astype(np.float64), ol.REDFT10, impl="port", threads=8)
+    cw = L.oracle_zoom_basis_f64(None, 0, 4.0, 1.0, 0.0, 4 * w, w)
+    xb = np.zeros(4 * w * (cw - 1)); L.oracle_zoom_basis_f64(xb.ctypes.data, 0, 4.0, 1.0, 0.0, 4 * w, w)
+    j = 1234
+    kv = np.arange(1, h)
+    ybj = np.cos(np.pi * ((j / 4.0) + 0.5) * kv / h)
+    trow = cf[0] / 2 + np.tensordot(ybj, cf[1:], axes=(0, 0))              # (w, 3): sum over v
+    XB = np.concatenate([np.full((4 * w, 1), 0.5), xb.reshape(4 * w, cw - 1)], axis=1)
+    ref_row = (XB @ trow) / (w * h)
+    assert np.abs(out[j].cpu().numpy() - ref_row).max() <= 2e-5
+
+
+def test_c5_motion_plane_full_size(gpu):
+    """BASELINE config 5, luma plane as ONE 3-D block (`-b 0x0x0`): 1920x1080x256 u8 -> REDFT10^3 with
+    motion's uniform scaling (motion.c:644-647) -> inverse (:748-753) -> u8 (:756-776): identical."""
+    from dspfun_amd import Plan, _lib, REDFT10, REDFT01
+    L = _lib.load()
+    d_, h, w = 256, 1080, 1920
+    g = gpu.Generator(device="cuda:0"); g.manual_seed(0xD5F0005)
+    pix = gpu.randint(0, 256, (d_, h, w), dtype=gpu.uint8, device="cuda:0", generator=g)
+    c = gpu.empty((d_, h, w), dtype=gpu.float32, device="cuda:0")
+    assert L.dspfft_u8_to_f32(c.data_ptr(), pix.data_ptr(), pix.numel(), None) == 0
+    r2 = float(np.sqrt(2.0))
+    fwd = Plan.many_r2r([d_, h, w], [REDFT10] * 3).set_scale(2 * r2)
+    inv = Plan.many_r2r([d_, h, w], [REDFT01] * 3).set_scale(1.0 / (2 * r2))
+    for a in range(3):
+        fwd.set_axis_scale0(a, 1.0, 1.0 / r2)
+        inv.set_axis_scale0(a, r2, 1.0)
+    assert fwd.describe().count("*") == 3, fwd.describe()      # all three passes on specialised kernels
+    fwd.execute(c.data_ptr())
+    gpu.cuda.synchronize()
+    mean = float(pix.double().mean())
+    assert abs(float(c[0, 0, 0]) / (8.0 * d_ * h * w) - mean) < 1e-3
+    inv.execute(c.data_ptr())
+    out = gpu.empty_like(pix)
+    assert L.dspfft_f32_to_u8(out.data_ptr(), c.data_ptr(), 1.0 / (8.0 * d_ * h * w), pix.numel(), None) == 0
+    gpu.cuda.synchronize()
+    assert int((out != pix).sum()) == 0
+
+
+def test_slab_dct3d_single_rank_matches_rank3_plan(gpu):
+    from dspfun_amd import Plan, REDFT10
+    from dspfun_amd.dist import SlabDCT3D
+    d_, h, w = 16, 270, 480
+    x = dev(gpu, ol.synth_u8(3, d_ * h * w).astype(np.float32).reshape(d_, h, w))
+    r2 = float(np.sqrt(2.0))
+    p = Plan.many_r2r([d_, h, w], [REDFT10] * 3).set_scale(2 * r2)
+    for a in range(3):
+        p.set_axis_scale0(a, 1.0, 1.0 / r2)
+    a_ = x.clone(); p.execute(a_.data_ptr())
+    eng = SlabDCT3D(d_, h, w)
+    b_ = eng.forward(x.clone())
+    gpu.cuda.synchronize()
+    assert float((a_ - b_).abs().max() / a_.abs().max()) < 2e-6
+    back = eng.inverse(b_)
+    gpu.cuda.synchronize()
+    assert float((back - x).abs().max()) < 1e-3
