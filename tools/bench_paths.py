@@ -1,0 +1,83 @@
+"""Secondary measurements (not the headline): zoom C3 (MFMA), scan C4 fused frame step, motion C5 3-D.
+Prints one JSON object.  Run on the GPU box: python tools/bench_paths.py"""
+import json, math, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dspfun_amd import Plan, _lib, REDFT10, REDFT01
+from dspfun_amd.zoom import Zoom
+
+L = _lib.load()
+dev = "cuda:0"
+res = {}
+
+
+def timeit(fn, reps=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+# ---- zoom, config 3: 1920x1080 -> 7680x4320 ----
+w, h = 1920, 1080
+z = Zoom(torch, torch.rand(h, w, 3, device=dev))
+ms = timeit(lambda: z.frame(4 * w, 4 * h, (4.0, 1.0), (4.0, 1.0)), reps=5, warm=1)
+flop = 2.0 * 3 * (h * (4 * w) * w + (4 * h) * (4 * w) * h)
+res["zoom_c3"] = {"ms_per_frame": round(ms, 3), "TFLOPs": round(flop / ms / 1e9, 2), "GFLOP": round(flop / 1e9, 1),
+                  "mfma_f32_peak_TFLOPs": 157.3, "frac": round(flop / ms / 1e9 / 157.3, 4), "note": "includes basis generation + deinterleave"}
+
+# ---- scan, config 4: 7680x4320x3, zigzag, step 2^20 -> 32 frames, fused step ----
+w, h, c = 7680, 4320, 3
+coeffs = torch.rand(h, w, c, device=dev)
+Plan.image(h, w, c, REDFT10).set_scale(1.0 / (4.0 * w * h)).execute(coeffs.data_ptr())
+inv = Plan.image(h, w, c, REDFT01)
+ids = torch.zeros(w * h, dtype=torch.int32, device=dev)
+step = 1 << 20
+nframes = (w * h + step - 1) // step
+L.dspfft_scan_zigzag_frame_ids(ids.data_ptr(), w, h, step, None)
+acc = torch.empty_like(coeffs); work = torch.empty_like(coeffs); recon = torch.empty_like(coeffs); image = torch.empty_like(coeffs)
+order = torch.zeros(w * h, dtype=torch.int32, device=dev)
+L.dspfft_scan_zigzag(order.data_ptr(), w, h, 0, w * h, None)
+f = [0]
+def fused():
+    inv.execute_masked_accumulate(coeffs.data_ptr(), work.data_ptr(), acc.data_ptr(), ids.data_ptr(), f[0] % nframes, c); f[0] += 1
+def unfused():
+    k = f[0] % nframes; f[0] += 1
+    first = k * step; cnt = min(step, w * h - first)
+    L.dspfft_scan_scatter(recon.data_ptr(), coeffs.data_ptr(), order.data_ptr() + 4 * first, cnt, w * h, c, None)
+    inv.execute(recon.data_ptr(), image.data_ptr())
+    L.dspfft_accumulate(acc.data_ptr(), image.data_ptr(), w * h * c, None)
+msf = timeit(fused, reps=8); msu = timeit(unfused, reps=8)
+samples = w * h * c
+res["scan_c4_frame_step"] = {"fused_ms": round(msf, 3), "unfused_ms": round(msu, 3), "algorithmic_GBps_fused": round(samples * 12 / msf / 1e6, 1),
+                             "frac_of_8TBps": round(samples * 12 / msf / 1e6 / 8000, 4), "frames": nframes, "note": "12 B/sample algorithmic (SURVEY 8d); 1 GPU, all 3 channels"}
+
+# ---- motion, config 5 luma plane: 1920x1080x256 3-D roundtrip ----
+d_, h, w = 256, 1080, 1920
+vol = torch.rand(d_, h, w, device=dev)
+r2 = math.sqrt(2.0)
+fwd = Plan.many_r2r([d_, h, w], [REDFT10] * 3).set_scale(2 * r2)
+invp = Plan.many_r2r([d_, h, w], [REDFT01] * 3).set_scale(1.0 / (2 * r2) / (8.0 * d_ * h * w))
+for a in range(3):
+    fwd.set_axis_scale0(a, 1.0, 1.0 / r2); invp.set_axis_scale0(a, r2, 1.0)
+def rt():
+    fwd.execute(vol.data_ptr()); invp.execute(vol.data_ptr())
+ms = timeit(rt, reps=3, warm=1)
+n = d_ * h * w
+res["motion_c5_luma_3d_roundtrip"] = {"ms": round(ms, 2), "Msamples_per_s": round(n / ms / 1e3, 1), "algorithmic_GBps": round(n * 16 / ms / 1e6, 1),
+                                      "frac_of_8TBps": round(n * 16 / ms / 1e6 / 8000, 4), "plan": fwd.describe()}
+# per-frame 2-D (default -b 0x0x1) over the same 256 frames, one batched plan
+f2 = Plan.many_r2r([h, w], [REDFT10] * 2, howmany=d_, idist=h * w, odist=h * w)
+i2 = Plan.many_r2r([h, w], [REDFT01] * 2, howmany=d_, idist=h * w, odist=h * w).set_scale(1.0 / (4.0 * h * w))
+def rt2():
+    f2.execute(vol.data_ptr()); i2.execute(vol.data_ptr())
+ms = timeit(rt2, reps=3, warm=1)
+res["motion_c5_luma_per_frame_2d_roundtrip"] = {"ms": round(ms, 2), "Msamples_per_s": round(n / ms / 1e3, 1), "algorithmic_GBps": round(n * 16 / ms / 1e6, 1),
+                                                "frac_of_8TBps": round(n * 16 / ms / 1e6 / 8000, 4)}
+print(json.dumps(res, indent=1))
