@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--frames", type=int, default=4, help="independent frames per GPU per step")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("BENCH_STREAMS", "2")), help="HIP streams the independent frames are spread over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -106,10 +107,17 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     ptrs = [frames[f].data_ptr() for f in range(args.frames)]
 
+    # independent frames may run on separate HIP streams: kernels of different frames (and different
+    # pass shapes) then share the CUs, so one frame's memory-bound phases overlap another's butterflies
+    nstreams = max(1, min(args.streams, args.frames))
+    side = [torch.cuda.Stream(device=dev) for _ in range(nstreams)] if nstreams > 1 else []
+    handles = [s_.cuda_stream for s_ in side] if side else [stream]
+
     def step():
-        for p in ptrs:
-            fwd.execute(p, stream=stream)
-            inv.execute(p, stream=stream)
+        for i, p in enumerate(ptrs):
+            h_ = handles[i % len(handles)]
+            fwd.execute(p, stream=h_)
+            inv.execute(p, stream=h_)
 
     def barrier():
         torch.cuda.synchronize()
@@ -178,7 +186,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (splitmix64 uniform [0,1), SURVEY.md 8d seed 0xD5F0002)",
             "config": {"workload": "spec + ispec roundtrip on 3840x2160 RGB float32 (BASELINE configs[1])",
-                       "frames_per_gpu_per_step": args.frames, "layout": "interleaved HWC, in place, device-resident",
+                       "frames_per_gpu_per_step": args.frames, "hip_streams": nstreams, "layout": "interleaved HWC, in place, device-resident",
                        "parallelism": f"frame-sharded x{world}, no collective"},
             "roundtrip_frac_of_hbm_roofline": round(value * 1e6 * ALG_BYTES_PER_PIXEL / HBM_PEAK, 4),
             "max_abs_drift_after_all_roundtrips": drift,

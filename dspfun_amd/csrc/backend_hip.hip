@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(512) col_kernel(const PassArgs a)
 // registers was measured slower on MI355X: the extra ~60 VGPRs cost a resident workgroup per CU,
 // and co-resident workgroups already overlap each other's memory and LDS phases.)
 template <class S, int KIND>
-__global__ void __launch_bounds__(S::T) row_spec_kernel(const PassArgs a)
+__global__ void __launch_bounds__(S::T, S::WPE) row_spec_kernel(const PassArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	cf *planes = reinterpret_cast<cf *>(lds);
@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(S::T) row_spec_kernel(const PassArgs a)
 }
 
 template <class S, int KIND>
-__global__ void __launch_bounds__(S::T) col_spec_kernel(const PassArgs a)
+__global__ void __launch_bounds__(S::T, S::WPE) col_spec_kernel(const PassArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	float4 *buf = reinterpret_cast<float4 *>(lds);

@@ -163,7 +163,7 @@ def test_helpers_zigzag_and_scan_step():
 
 # ---- compile-time-specialised kernels (dct_spec.h / spec_list.h), through the emulation backend ----
 @pytest.mark.parametrize("h,w,c", [(4, 3840, 3), (3, 1920, 3), (2, 7680, 3), (5, 960, 3), (6, 256, 3), (4, 1920, 1), (4, 960, 1),
-                                    (2160, 8, 3), (1080, 16, 3), (4320, 8, 1), (540, 16, 1), (256, 16, 3), (256, 256, 3)])
+                                    (2160, 8, 3), (1080, 16, 3), (1080, 32, 1), (4320, 8, 1), (4320, 4, 3), (540, 16, 1), (256, 16, 3), (256, 256, 3)])
 @pytest.mark.parametrize("kind", [REDFT10, REDFT01])
 def test_specialised_kernels(h, w, c, kind):
     x = ol.synth_f32(h * 7 + w, h * w * c).reshape(h, w, c)
@@ -201,7 +201,7 @@ def test_specialised_out_of_place_and_misaligned_fallback():
     assert relerr(view.reshape(h, w, c), ol.dct2d_interleaved(xm.astype(np.float64), REDFT01, impl="port", threads=4)) < TOL
 
 
-@pytest.mark.parametrize("h,w,c", [(24, 40, 3), (4, 3840, 3), (2160, 8, 3), (17, 40, 3), (30, 45, 1)])
+@pytest.mark.parametrize("h,w,c", [(24, 40, 3), (4, 3840, 3), (2160, 8, 3), (2160, 16, 3), (17, 40, 3), (30, 45, 1)])
 def test_fused_scan_step(h, w, c):
     """scan/scan.c:429-459 in one fused execution == scatter + REDFT01^2 + accumulate, frame by frame"""
     import ctypes as C
