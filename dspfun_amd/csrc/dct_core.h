@@ -79,7 +79,7 @@ struct PassArgs {
 	// id differs (mask[offset / mask_div] != mask_id); the LAST pass adds into `out` instead of storing
 	const uint32_t *mask;
 	uint32_t mask_id;
-	int mask_div;
+	FastDiv mask_div;     // elements per owner id (32-bit offsets: masked runs are limited to 2^32 / d elements)
 	int accumulate;
 	FftDesc fft;
 	FastDiv divB;         // divide by (ROW: Bg, COL: B)
@@ -87,7 +87,8 @@ struct PassArgs {
 
 DSP_HD float masked(const PassArgs &a, long long off, float v)
 {
-	return (a.mask && a.mask[off / a.mask_div] != a.mask_id) ? 0.f : v;
+	if (!a.mask) return v;
+	return a.mask[a.mask_div.div((uint32_t)off)] != a.mask_id ? 0.f : v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -378,7 +379,7 @@ struct DenseArgs {
 	float scale, out_scale0, in_scale0;
 	const uint32_t *mask;
 	uint32_t mask_id;
-	int mask_div;
+	FastDiv mask_div;
 	int accumulate;
 };
 
@@ -393,7 +394,7 @@ DSP_HD void dense_load(const DenseArgs &a, float *x, long long bin, int tid, int
 {
 	for (int j = tid; j < a.N; j += nthr) {
 		const long long off = bin + (long long)j * a.es_in;
-		const float v = (a.mask && a.mask[off / a.mask_div] != a.mask_id) ? 0.f : a.in[off];
+		const float v = (a.mask && a.mask[a.mask_div.div((uint32_t)off)] != a.mask_id) ? 0.f : a.in[off];
 		x[j] = v * (j == 0 ? a.in_scale0 : 1.f);
 	}
 }

@@ -304,6 +304,7 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 }
 
 struct Fuse { const uint32_t *mask = nullptr; uint32_t id = 0; int div = 1; bool accumulate = false; };
+FastDiv make_div(uint32_t d);
 
 int run_pass(const dspfft_plan_s *pl, const Pass &P, const float *in, float *out, bool last, void *stream, const Fuse &fz = Fuse())
 {
@@ -317,7 +318,7 @@ int run_pass(const dspfft_plan_s *pl, const Pass &P, const float *in, float *out
 		if (P.type == Pass::DENSE) {
 			DenseArgs a = P.da;
 			a.in = in + oin; a.out = out + oout; a.scale = scale; a.in_scale0 = pl->in0[P.axis]; a.out_scale0 = pl->out0[P.axis];
-			a.mask = fz.mask; a.mask_id = fz.id; a.mask_div = fz.div; a.accumulate = fz.accumulate;
+			a.mask = fz.mask; a.mask_id = fz.id; a.mask_div = make_div((uint32_t)fz.div); a.accumulate = fz.accumulate;
 			rc = be_launch_dense(a, P.g, stream);
 		} else {
 			const bool ptr_ok = P.type == Pass::ROW
@@ -326,12 +327,12 @@ int run_pass(const dspfft_plan_s *pl, const Pass &P, const float *in, float *out
 			if (P.has_spec && ptr_ok) {
 				PassArgs a = P.spa;
 				a.in = in + oin; a.out = out + oout; a.scale = scale; a.in_scale0 = pl->in0[P.axis]; a.out_scale0 = pl->out0[P.axis];
-				a.mask = fz.mask; a.mask_id = fz.id; a.mask_div = fz.div; a.accumulate = fz.accumulate;
+				a.mask = fz.mask; a.mask_id = fz.id; a.mask_div = make_div((uint32_t)fz.div); a.accumulate = fz.accumulate;
 				rc = be_launch_spec(P.type == Pass::COL, P.spec.id, a, P.spec_nwg, stream);
 			} else {
 				PassArgs a = P.pa;
 				a.in = in + oin; a.out = out + oout; a.scale = scale; a.in_scale0 = pl->in0[P.axis]; a.out_scale0 = pl->out0[P.axis];
-				a.mask = fz.mask; a.mask_id = fz.id; a.mask_div = fz.div; a.accumulate = fz.accumulate;
+				a.mask = fz.mask; a.mask_id = fz.id; a.mask_div = make_div((uint32_t)fz.div); a.accumulate = fz.accumulate;
 				rc = P.type == Pass::ROW ? be_launch_row(a, P.g, stream) : be_launch_col(a, P.g, stream);
 			}
 		}
@@ -414,6 +415,8 @@ extern "C" int dspfft_execute_masked_accumulate(dspfft_plan pl, const float *d_i
 {
 	if (!pl || !d_in || !d_work || !d_acc) return fail(-1, "null plan or buffer");
 	if (d_ids && elems_per_id < 1) return fail(-1, "elems_per_id must be >= 1");
+	if (d_ids && (unsigned long long)pl->alg_bytes / 8 * (unsigned)elems_per_id >= (1ull << 32))
+		return fail(-2, "masked execution addresses elements with 32-bit offsets: plan too large");
 	const size_t np = pl->passes.size();
 	for (const Pass &P : pl->passes)
 		if (!P.hostloop.empty()) return fail(-2, "masked/accumulating execution is not available for plans that need a host-side batch loop");

@@ -25,6 +25,7 @@
 #define DSPFFT_COL_SPECS(X)            \
 	X(2160, 8, 512, 12, 12, 15)        \
 	X(1080, 16, 512, 8, 9, 15)         \
+	X(4320, 8, 1024, 2, 12, 12, 15)    \
 	X(4320, 4, 512, 2, 12, 12, 15)     \
 	X(540, 16, 256, 4, 9, 15)          \
 	X(256, 16, 256, 4, 4, 16)
