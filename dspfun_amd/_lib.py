@@ -19,7 +19,7 @@ SYMBOLS = [
     "dspfft_scan_zigzag", "dspfft_scan_zigzag_frame_ids", "dspfft_execute_masked_accumulate", "dspfft_scan_scatter", "dspfft_accumulate", "dspfft_broadcast_dc",
     "dspfft_u8_to_f32", "dspfft_f32_to_u8",
     "dspfft_zoom_ncomponents", "dspfft_zoom_basis", "dspfft_zoom_work_floats", "dspfft_zoom_product", "dspfft_gemm_nt_f32",
-    "dspfft_zoom_last_error",
+    "dspfft_zoom_last_error", "dspfft_applybasis_work_floats", "dspfft_applybasis_partsums",
 ]
 
 _lib = None
@@ -61,6 +61,9 @@ def bind(lib):
         lib.dspfft_gemm_nt_f32.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_longlong, C.c_longlong, C.c_int,
                                            C.c_int, C.c_longlong, C.c_longlong, C.c_longlong, C.c_float, vp]
         lib.dspfft_zoom_last_error.restype = C.c_char_p
+        lib.dspfft_applybasis_work_floats.restype = C.c_size_t
+        lib.dspfft_applybasis_work_floats.argtypes = [C.c_int] * 7
+        lib.dspfft_applybasis_partsums.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_longlong, vp, vp]
     return lib
 
 

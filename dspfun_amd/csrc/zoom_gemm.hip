@@ -112,6 +112,59 @@ __global__ void deinterleave3_kernel(float *planes, const float *img, size_t npi
 	}
 }
 
+// ---- applybasis (applybasis/applybasis.c:77-140): basis matrices F[k][n] = f(k + offset, n, N, ortho) ----
+__device__ void ab_basis(int func, long long k, long long n, unsigned long long N, int ortho, double &re, double &im)
+{
+	const double r2 = 1.41421356237309504880, pi = 3.14159265358979323846;
+	double c; im = 0.0;
+	switch (func) {
+	case 0: { double a = (-2.0 * pi * (double)(k * n)) / (double)N; re = cos(a); im = sin(a); return; }
+	case 1: { double a = (2.0 * pi * (double)(k * n)) / (double)N; re = cos(a); im = sin(a); return; }
+	case 2: c = (n && N - 1 - n) ? cos((pi * (double)(k * n)) / (double)(N - 1)) : (n ? ((k & 1) ? -1.0 : 1.0) : 1.0) / 2; if (ortho) c *= r2; break;
+	case 3: c = cos((pi * (double)(k * (2 * n + 1))) / (double)(2 * N)); if (ortho) c *= (k ? r2 : 1); break;
+	case 4: c = n ? cos((pi * (double)(n * (2 * k + 1))) / (double)(2 * N)) : 0.5; if (ortho) c *= n ? r2 : 2; break;
+	case 5: c = cos((pi * (double)((2 * k + 1) * (2 * n + 1))) / (double)(4 * N)); if (ortho) c *= r2; break;
+	case 6: c = sin((pi * (double)((k + 1) * (n + 1))) / (double)(N + 1)); if (ortho) c *= r2; break;
+	case 7: c = sin((pi * (double)((k + 1) * (2 * n + 1))) / (double)(2 * N)); if (ortho) c *= (N - 1 - k) ? r2 : 1; break;
+	case 8: c = (N - 1 - n) ? sin((pi * (double)((2 * k + 1) * (n + 1))) / (double)(2 * N)) : ((k & 1) ? -1.0 : 1.0) / 2; if (ortho) c *= (N - 1 - n) ? r2 : 2; break;
+	case 9: c = sin((pi * (double)((2 * k + 1) * (2 * n + 1))) / (double)(4 * N)); if (ortho) c *= r2; break;
+	case 10: {
+		unsigned long long L = (unsigned long long)log2((double)N), nn = (unsigned long long)n, kk = (unsigned long long)k;
+		unsigned long long sig = (nn & (kk >> (L - 1))) & 1ULL;
+		for (L--, nn >>= 1; L; L--, nn >>= 1) sig += (nn & ((kk >> (L - 1)) + (kk >> L))) & 1ULL;
+		c = (sig & 1) ? -1.0 : 1.0; break;
+	}
+	default: c = r2 * cos(2 * pi * (double)n * (double)k / (double)N - pi / 4); break;
+	}
+	re = c;
+}
+__global__ void ab_basis_kernel(float *re, float *im, int func, int ortho, long long terms, long long offset, unsigned long long N)
+{
+	const size_t total = (size_t)terms * N;
+	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+		const long long k = (long long)(i / N), n = (long long)(i - (size_t)k * N);
+		double r, m; ab_basis(func, k + offset, n, N, ortho, r, m);
+		re[i] = (float)r; if (im) im[i] = (float)m;
+	}
+}
+// out[kh][kw][nh][nw][j] (re, im)  <-  P[c][kh][nh][kw*Nw+nw] products (see dspfft_applybasis_partsums)
+__global__ void ab_combine_kernel(float *out, const float *P, int cplx, int Kh, int Kw, int Nh, int Nw)
+{
+	const size_t per = (size_t)Kh * Nh * Kw * Nw, total = per * 3;
+	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+		const size_t j = i / per, r = i - j * per;               // channel-major temp
+		const size_t kh = r / ((size_t)Nh * Kw * Nw), r2 = r - kh * ((size_t)Nh * Kw * Nw);
+		const size_t nh = r2 / ((size_t)Kw * Nw), r3 = r2 - nh * ((size_t)Kw * Nw);
+		const size_t kw = r3 / Nw, nw = r3 - kw * Nw;
+		const size_t o = ((((kh * Kw + kw) * Nh + nh) * Nw + nw) * 3 + j) * 2;
+		if (cplx) {
+			// P blocks: 0 = Fh_re.T_re, 1 = Fh_im.T_im, 2 = Fh_re.T_im, 3 = Fh_im.T_re   (each 3*per floats)
+			out[o] = P[i] - P[3 * per + i];
+			out[o + 1] = P[2 * 3 * per + i] + P[3 * 3 * per + i];
+		} else { out[o] = P[i]; out[o + 1] = 0.f; }
+	}
+}
+
 thread_local char g_zerr[256] = "";
 
 }  // namespace
@@ -162,4 +215,57 @@ extern "C" int dspfft_zoom_product(const float *d_coeffs, int w, int h, const fl
 	if (rc) return rc;
 	// out_z (vh x vw, interleaved) = YB (vh x ch) . Tt_z^T / (w h)
 	return dspfft_gemm_nt_f32(d_yb, Tt, d_out, vh, vw, (int)ch, (long long)ch, (long long)ch, (long long)vw * 3, 3, 3, 0, (long long)vw * ch, 1, 1.f / ((float)w * (float)h), stream);
+}
+
+// ---- applybasis' forward partial sums (applybasis/applybasis.c:410-431) as batched NT GEMMs ----
+extern "C" size_t dspfft_applybasis_work_floats(int w, int h, int Kw, int Kh, int Pw, int Ph, int func)
+{
+	const size_t Nw = (size_t)w / Pw, Nh = (size_t)h / Ph, cplx = func <= 1 ? 2 : 1;
+	return (size_t)3 * w * h                       /* planar pixels */
+	     + cplx * ((size_t)Kw * w + (size_t)Kh * h) /* basis matrices */
+	     + cplx * 3 * (size_t)Kw * Nw * h           /* Tt */
+	     + cplx * cplx * 3 * (size_t)Kh * Nh * Kw * Nw; /* products */
+}
+
+extern "C" int dspfft_applybasis_partsums(float *d_out, const float *d_pixels, int w, int h, int func, int ortho,
+                                          int Kw, int Kh, int Pw, int Ph, long long offw, long long offh,
+                                          float *d_work, void *stream)
+{
+	if (!d_out || !d_pixels || !d_work || func < 0 || func > 11 || Kw < 1 || Kh < 1 || Pw < 1 || Ph < 1 || w % Pw || h % Ph) {
+		snprintf(g_zerr, sizeof g_zerr, "bad arguments (the partial-sum block must divide the image)"); return -1;
+	}
+	hipStream_t s = (hipStream_t)stream;
+	const int Nw = w / Pw, Nh = h / Ph, cplx = func <= 1;
+	const size_t npix = (size_t)w * h;
+	float *planes = d_work;
+	float *Fw_re = planes + 3 * npix, *Fw_im = cplx ? Fw_re + (size_t)Kw * w : nullptr;
+	float *Fh_re = Fw_re + (cplx ? 2 : 1) * (size_t)Kw * w, *Fh_im = cplx ? Fh_re + (size_t)Kh * h : nullptr;
+	float *Tt = Fh_re + (cplx ? 2 : 1) * (size_t)Kh * h;                       // [c?][3][Kw][Nw][h]
+	const size_t tsz = (size_t)3 * Kw * Nw * h;
+	float *P = Tt + (cplx ? 2 : 1) * tsz;                                       // [blocks][3][Kh][Nh][Kw*Nw]
+	const size_t per = (size_t)Kh * Nh * Kw * Nw, psz = 3 * per;
+	hipLaunchKernelGGL(deinterleave3_kernel, dim3(1024), dim3(256), 0, s, planes, d_pixels, npix);
+	hipLaunchKernelGGL(ab_basis_kernel, dim3(512), dim3(256), 0, s, Fw_re, Fw_im, func, ortho, (long long)Kw, offw, (unsigned long long)w);
+	hipLaunchKernelGGL(ab_basis_kernel, dim3(512), dim3(256), 0, s, Fh_re, Fh_im, func, ortho, (long long)Kh, offh, (unsigned long long)h);
+	// step 1: Tt[j][kw][nw][y] = sum_{sw} Fw[kw][nw Pw + sw] pix_j[y][nw Pw + sw]      (batch over nw, per channel)
+	for (int part = 0; part < (cplx ? 2 : 1); part++)
+		for (int j = 0; j < 3; j++) {
+			int rc = dspfft_gemm_nt_f32(part ? Fw_im : Fw_re, planes + j * npix, Tt + part * tsz + (size_t)j * Kw * Nw * h,
+			                            Kw, h, Pw, w, w, (long long)Nw * h, 1, Nw, Pw, Pw, h, 1.f, stream);
+			if (rc) return rc;
+		}
+	// step 2: P[j][kh][nh][kw*Nw+nw] = sum_{sh} Fh[kh][nh Ph + sh] Tt[j][kw][nw][nh Ph + sh]   (batch over nh, per channel)
+	for (int hp = 0; hp < (cplx ? 2 : 1); hp++)        // Fh part
+		for (int tp = 0; tp < (cplx ? 2 : 1); tp++) {  // Tt part
+			// block order expected by ab_combine_kernel: 0 re.re, 1 im.im, 2 re.im, 3 im.re
+			const int slot = cplx ? (hp == 0 && tp == 0 ? 0 : hp == 1 && tp == 1 ? 1 : hp == 0 ? 2 : 3) : 0;
+			for (int j = 0; j < 3; j++) {
+				int rc = dspfft_gemm_nt_f32(hp ? Fh_im : Fh_re, Tt + tp * tsz + (size_t)j * Kw * Nw * h, P + slot * psz + (size_t)j * per,
+				                            Kh, Kw * Nw, Ph, h, h, (long long)Nh * Kw * Nw, 1, Nh, Ph, Ph, (long long)Kw * Nw, 1.f, stream);
+				if (rc) return rc;
+			}
+
+		}
+	hipLaunchKernelGGL(ab_combine_kernel, dim3(1024), dim3(256), 0, s, d_out, P, cplx, Kh, Kw, Nh, Nw);
+	return hipGetLastError() == hipSuccess ? 0 : -4;
 }

@@ -129,6 +129,17 @@ int dspfft_gemm_nt_f32(const float *A, const float *B, float *C, int M, int N, i
                        int batch, long long sa, long long sb, long long sc, float alpha, void *hip_stream);
 const char *dspfft_zoom_last_error(void);
 
+/* ---- applybasis' basis x pixel partial sums on the matrix cores ----
+ * applybasis/applybasis.c:410-431, forward direction:
+ *   out[k_h][k_w][n_h][n_w][j] = sum_{s_h < Ph, s_w < Pw} f(k_h + offh, n_h Ph + s_h, h) f(k_w + offw, n_w Pw + s_w, w) pix[..][j]
+ * func: 0 dft, 1 idft, 2..5 dct1-4, 6..9 dst1-4, 10 wht, 11 dht (applybasis.c:77-140); d_pixels: h x w x 3 f32 already
+ * range-mapped (applybasis.c:358-360); d_out: Kh*Kw*(h/Ph)*(w/Pw)*3 complex (re, im) floats in the order of the tool's
+ * `.coeff` dump (applybasis.c:443).  d_work: dspfft_applybasis_work_floats() floats. */
+size_t dspfft_applybasis_work_floats(int w, int h, int Kw, int Kh, int Pw, int Ph, int func);
+int dspfft_applybasis_partsums(float *d_out, const float *d_pixels, int w, int h, int func, int ortho,
+                               int Kw, int Kh, int Pw, int Ph, long long offw, long long offh,
+                               float *d_work, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

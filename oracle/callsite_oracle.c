@@ -114,3 +114,63 @@ void oracle_zoom_product_f64(const double *coeffs, int w, int h,
 		}
 	free(tmp);
 }
+
+/* ---- applybasis (applybasis/applybasis.c) ---------------------------------------------------
+ * Basis functions f(k, n, N, ortho) of applybasis.c:77-140 (ids in the order of the tool's -f option:
+ * 0 dft, 1 idft, 2 dct1, 3 dct2, 4 dct3, 5 dct4, 6 dst1, 7 dst2, 8 dst3, 9 dst4, 10 wht, 11 dht) and the
+ * forward partial sums of applybasis.c:410-431:
+ *   out[k_h][k_w][n_h][n_w][j] = sum_{s_h<P_h, s_w<P_w} f(k_h+off_h, n_h P_h + s_h, H) f(k_w+off_w, n_w P_w + s_w, W) pix[..][j]
+ * (the offset is added to the term index while the function is evaluated, :416-418).  Complex result as
+ * (re, im) pairs; the loop order is the order of the tool's `.coeff` dump (:443). */
+#include <complex.h>
+static double complex ab_basis(int func, long long k, long long n, unsigned long long N, int ortho)
+{
+	const double r2 = sqrt(2.0);
+	double c;
+	switch (func) {
+	case 0: return cexp((-2 * I * M_PI * k * n) / N);
+	case 1: return cexp((2 * I * M_PI * k * n) / N);
+	case 2: c = (n && N - 1 - n) ? cos((M_PI * (k * n)) / (N - 1)) : (n ? pow(-1, k) : 1.0) / 2; if (ortho) c *= r2; return c;
+	case 3: c = cos((M_PI * (k * (2 * n + 1))) / (2 * N)); if (ortho) c *= (k ? r2 : 1); return c;
+	case 4: c = n ? cos((M_PI * (n * (2 * k + 1))) / (2 * N)) : 0.5; if (ortho) c *= n ? r2 : 2; return c;
+	case 5: c = cos((M_PI * ((2 * k + 1) * (2 * n + 1))) / (4 * N)); if (ortho) c *= r2; return c;
+	case 6: c = sin((M_PI * ((k + 1) * (n + 1))) / (N + 1)); if (ortho) c *= r2; return c;
+	case 7: c = sin((M_PI * ((k + 1) * (2 * n + 1))) / (2 * N)); if (ortho) c *= (N - 1 - k) ? r2 : 1; return c;
+	case 8: c = (N - 1 - n) ? sin((M_PI * ((2 * k + 1) * (n + 1))) / (2 * N)) : pow(-1, k) / 2; if (ortho) c *= (N - 1 - n) ? r2 : 2; return c;
+	case 9: c = sin((M_PI * ((2 * k + 1) * (2 * n + 1))) / (4 * N)); if (ortho) c *= r2; return c;
+	case 10: {
+		unsigned long long L = (unsigned long long)log2((double)N), nn = (unsigned long long)n, kk = (unsigned long long)k;
+		unsigned long long sig = (nn & (kk >> (L - 1))) & 1ULL;
+		for (L--, nn >>= 1; L; L--, nn >>= 1) sig += (nn & ((kk >> (L - 1)) + (kk >> L))) & 1ULL;
+		return pow(-1, (double)sig);
+	}
+	default: return r2 * cos(2 * M_PI * n * k / N - M_PI / 4);
+	}
+}
+void oracle_applybasis_basis_f64(double *re, double *im, int func, int ortho, long long terms, long long offset, unsigned long long N)
+{
+	for (long long k = 0; k < terms; k++)
+		for (unsigned long long n = 0; n < N; n++) {
+			double complex v = ab_basis(func, k + offset, (long long)n, N, ortho);
+			re[k * N + n] = creal(v); im[k * N + n] = cimag(v);
+		}
+}
+void oracle_applybasis_partsums_f64(double *out /* [Kh][Kw][Nh][Nw][3][2] */, const double *pix, int w, int h, int func, int ortho,
+                                    int Kw, int Kh, int Pw, int Ph, long long offw, long long offh)
+{
+	const int Nw = w / Pw, Nh = h / Ph;
+	for (int kh = 0; kh < Kh; kh++)
+		for (int kw = 0; kw < Kw; kw++)
+			for (int nh = 0; nh < Nh; nh++)
+				for (int nw = 0; nw < Nw; nw++) {
+					double complex ps[3] = {0, 0, 0};
+					for (int sh = 0; sh < Ph; sh++)
+						for (int sw = 0; sw < Pw; sw++) {
+							double complex comp = ab_basis(func, kw + offw, (long long)nw * Pw + sw, (unsigned long long)w, ortho) *
+							                      ab_basis(func, kh + offh, (long long)nh * Ph + sh, (unsigned long long)h, ortho);
+							for (int j = 0; j < 3; j++) ps[j] += comp * pix[((size_t)(nh * Ph + sh) * w + (size_t)nw * Pw + sw) * 3 + j];
+						}
+					double *o = out + ((((size_t)kh * Kw + kw) * Nh + nh) * Nw + nw) * 6;
+					for (int j = 0; j < 3; j++) { o[2 * j] = creal(ps[j]); o[2 * j + 1] = cimag(ps[j]); }
+				}
+}

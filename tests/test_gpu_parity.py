@@ -385,3 +385,21 @@ def test_slab_dct3d_single_rank_matches_rank3_plan(gpu):
     back = eng.inverse(b_)
     gpu.cuda.synchronize()
     assert float((back - x).abs().max()) < 1e-3
+
+
+# ---- applybasis: basis x pixel partial sums on the f32 matrix cores ----
+@pytest.mark.parametrize("func", ["dft", "idft", "dct1", "dct2", "dct3", "dct4", "dst1", "dst2", "dst3", "dst4", "wht", "dht"])
+@pytest.mark.parametrize("w,h,terms,psum,off,ortho", [(16, 8, None, (16, 8), (0, 0), True), (16, 8, (5, 3), (4, 2), (1, 2), False), (32, 32, (8, 8), (1, 1), (0, 0), False)])
+def test_applybasis_partsums_vs_oracle(gpu, func, w, h, terms, psum, off, ortho):
+    from dspfun_amd.applybasis import partsums, FUNCTIONS
+    import ctypes as C
+    x = (ol.synth_f32(w * 31 + h, w * h * 3).reshape(h, w, 3) * 2 - 1).astype(np.float32)      # shift2 range (applybasis.c:358-360)
+    got = partsums(gpu, dev(gpu, x), func, ortho, terms, psum, off).cpu().numpy()
+    kw, kh = terms if terms else (w, h)
+    ref = np.zeros(got.shape + (2,), dtype=np.float64)
+    L = ol.lib()
+    L.oracle_applybasis_partsums_f64.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_longlong] * 2
+    x64 = np.ascontiguousarray(x.astype(np.float64))
+    L.oracle_applybasis_partsums_f64(ref.ctypes.data, x64.ctypes.data, w, h, FUNCTIONS.index(func), int(ortho), kw, kh, psum[0], psum[1], off[0], off[1])
+    refc = ref[..., 0] + 1j * ref[..., 1]
+    assert np.abs(got - refc).max() <= 1e-5 * max(1.0, np.abs(refc).max())

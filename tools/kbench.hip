@@ -11,7 +11,8 @@
 using namespace dspfft;
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
-// persistent-workgroup wrappers (same control flow as backend_hip.hip); ABL=1 skips the FFT phases
+__device__ int g_stagger;   // initial delay (x 64*64 cycles) per 256-block group (experiment)
+// workgroup wrappers (same control flow as backend_hip.hip); ABL=1 skips the FFT phases
 template <class S, int KIND, int ABL, int WPE>
 __global__ void __launch_bounds__(S::T, WPE) row_k(const PassArgs a)
 {
@@ -21,6 +22,7 @@ __global__ void __launch_bounds__(S::T, WPE) row_k(const PassArgs a)
 	typename S::template State<KIND> st;
 	long long bin, bout;
 	row_base(a, blockIdx.x, bin, bout);
+	{ const int grp = blockIdx.x >> 8; if (g_stagger > 0 && grp >= 1 && grp <= 2) for (int i = 0; i < g_stagger * grp; i++) __builtin_amdgcn_s_sleep(64); }
 	S::template prefetch<KIND>(a, bin, tid, st);
 	S::template phase<KIND, 0>(a, planes, bout, tid, st);
 	__syncthreads();
@@ -40,6 +42,7 @@ __global__ void __launch_bounds__(S::T, WPE) col_k(const PassArgs a)
 	typename S::template State<KIND> st;
 	long long bin, bout;
 	S::base(a, blockIdx.x, bin, bout);
+	{ const int grp = blockIdx.x >> 8; if (g_stagger > 0 && grp == 1) for (int i = 0; i < g_stagger; i++) __builtin_amdgcn_s_sleep(64); }
 	S::template prefetch<KIND>(a, bin, tid, st);
 	S::template phase<KIND, 0>(a, buf, bout, tid, st);
 	__syncthreads();
@@ -92,10 +95,10 @@ static void run_row(const char *name)
 	int occ = 0; CHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)row_k<S, KIND, ABL, WPE>, S::T, S::LDS));
 	printf("%-40s kind=%d abl=%d wpe=%d occ=%d |", name, KIND, ABL, WPE, occ);
 	for (int wpc : {0}) {
-		if (wpc > occ) continue;
-		int grid = wpc ? 256 * wpc : a.nwork; if (grid > a.nwork) grid = a.nwork;
+		{ int sg = wpc; CHK(hipMemcpyToSymbol(HIP_SYMBOL(g_stagger), &sg, sizeof sg)); }
+		int grid = a.nwork;
 		double us = time_us([&] { hipLaunchKernelGGL((row_k<S, KIND, ABL, WPE>), dim3(grid), dim3(S::T), S::LDS, 0, a); }) / g_frames;
-		printf(" wpc%d:%6.1fus", wpc, us);
+		printf(" stg%d:%6.1fus", wpc, us);
 	}
 	printf("\n"); fflush(stdout);
 }
@@ -111,10 +114,10 @@ static void run_col(const char *name)
 	int occ = 0; CHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)col_k<S, KIND, ABL, WPE>, S::T, S::LDS));
 	printf("%-40s kind=%d abl=%d wpe=%d occ=%d |", name, KIND, ABL, WPE, occ);
 	for (int wpc : {0}) {
-		if (wpc > occ) continue;
-		int grid = wpc ? 256 * wpc : a.nwork; if (grid > a.nwork) grid = a.nwork;
+		{ int sg = wpc; CHK(hipMemcpyToSymbol(HIP_SYMBOL(g_stagger), &sg, sizeof sg)); }
+		int grid = a.nwork;
 		double us = time_us([&] { hipLaunchKernelGGL((col_k<S, KIND, ABL, WPE>), dim3(grid), dim3(S::T), S::LDS, 0, a); }) / g_frames;
-		printf(" wpc%d:%6.1fus", wpc, us);
+		printf(" stg%d:%6.1fus", wpc, us);
 	}
 	printf("\n"); fflush(stdout);
 }
