@@ -6,7 +6,7 @@
 #pragma once
 
 #define DSPFFT_ROW_SPECS(X)            \
-	X(3840, 3, 512, 8, 15, 16)         \
+	X(3840, 3, 512, 12, 10, 16)        \
 	X(1920, 3, 256, 4, 15, 16)         \
 	X(7680, 3, 1024, 16, 15, 16)        \
 	X(960, 3, 192, 2, 16, 15)          \

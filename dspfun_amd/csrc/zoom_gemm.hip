@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/dspfft.h"
 
@@ -18,21 +19,25 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 8, LDP = BM + 4;   // LDS tiles are [k][row], padded
+constexpr int BM = 128, BN = 128, LDP = BM + 4;   // LDS tiles are [k][row], padded
 
 // C[m*ldc + n*cs] = alpha * sum_k A[m*lda + k] * B[n*ldb + k];  batch b offsets: sa, sb, sc
+// 128 x 128 x BK block tile, 256 threads = 2 x 2 waves of 64 x 64, each 2 x 2 MFMA 32x32x2 tiles;
+// global -> registers -> LDS double buffer (the next K-tile's loads are in flight during the MFMAs).
+template <int BK>
 __global__ void __launch_bounds__(256) gemm_nt_f32_mfma(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
                                                         int M, int N, int K, long long lda, long long ldb, long long ldc, int cs,
                                                         long long sa, long long sb, long long sc, float alpha)
 {
 	__shared__ float As[2][BK][LDP];
 	__shared__ float Bs[2][BK][LDP];
+	constexpr int NV = BK / 8;                               // float4 per thread per operand per K-tile
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int wm = wave >> 1, wn = wave & 1;                 // 2 x 2 waves, each 64 x 64
 	const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
 	A += (long long)blockIdx.z * sa; B += (long long)blockIdx.z * sb; C += (long long)blockIdx.z * sc;
 
-	// staging: thread -> (row = tid / 2, k4 = tid % 2): one float4 along K from A and one from B
+	// staging: thread -> (row = tid / 2, k4 = (tid % 2) * 4 + 8 v): float4 along K
 	const int srow = tid >> 1, sk = (tid & 1) * 4;
 	const bool a_ok = bm + srow < M, b_ok = bn + srow < N;
 	const float *ap = A + (long long)(bm + srow) * lda + sk;
@@ -49,22 +54,31 @@ __global__ void __launch_bounds__(256) gemm_nt_f32_mfma(const float *__restrict_
 		if (k0 + sk + 3 < K) v.w = p[k0 + 3];
 		return v;
 	};
-	auto stash = [&](int buf, float4 a, float4 b) {
-		As[buf][sk + 0][srow] = a.x; As[buf][sk + 1][srow] = a.y; As[buf][sk + 2][srow] = a.z; As[buf][sk + 3][srow] = a.w;
-		Bs[buf][sk + 0][srow] = b.x; Bs[buf][sk + 1][srow] = b.y; Bs[buf][sk + 2][srow] = b.z; Bs[buf][sk + 3][srow] = b.w;
+	float4 ra[NV], rb[NV];
+	auto fetch_tile = [&](int k0) {
+#pragma unroll
+		for (int v = 0; v < NV; v++) { ra[v] = fetch(ap, a_ok, k0 + 8 * v); rb[v] = fetch(bp, b_ok, k0 + 8 * v); }
+	};
+	auto stash = [&](int buf) {
+#pragma unroll
+		for (int v = 0; v < NV; v++) {
+			const int k = sk + 8 * v;
+			As[buf][k + 0][srow] = ra[v].x; As[buf][k + 1][srow] = ra[v].y; As[buf][k + 2][srow] = ra[v].z; As[buf][k + 3][srow] = ra[v].w;
+			Bs[buf][k + 0][srow] = rb[v].x; Bs[buf][k + 1][srow] = rb[v].y; Bs[buf][k + 2][srow] = rb[v].z; Bs[buf][k + 3][srow] = rb[v].w;
+		}
 	};
 
 	f32x16 acc[2][2];
 	for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-	float4 ra = fetch(ap, a_ok, 0), rb = fetch(bp, b_ok, 0);
-	stash(0, ra, rb);
+	fetch_tile(0);
+	stash(0);
 	__syncthreads();
 	const int nk = (K + BK - 1) / BK;
 	const int li = lane & 31, lk = lane >> 5;
 	for (int kt = 0; kt < nk; kt++) {
 		const int cur = kt & 1;
-		if (kt + 1 < nk) { ra = fetch(ap, a_ok, (kt + 1) * BK); rb = fetch(bp, b_ok, (kt + 1) * BK); }
+		if (kt + 1 < nk) fetch_tile((kt + 1) * BK);
 #pragma unroll
 		for (int s = 0; s < BK / 2; s++) {
 			const float a0 = As[cur][2 * s + lk][wm * 64 + li], a1 = As[cur][2 * s + lk][wm * 64 + 32 + li];
@@ -74,7 +88,7 @@ __global__ void __launch_bounds__(256) gemm_nt_f32_mfma(const float *__restrict_
 			acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
 			acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
 		}
-		if (kt + 1 < nk) stash(cur ^ 1, ra, rb);
+		if (kt + 1 < nk) stash(cur ^ 1);
 		__syncthreads();
 	}
 	// C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
@@ -194,7 +208,10 @@ extern "C" int dspfft_gemm_nt_f32(const float *A, const float *B, float *C, int 
 {
 	if (!A || !B || !C || M < 1 || N < 1 || K < 1 || batch < 1 || cs < 1) { snprintf(g_zerr, sizeof g_zerr, "bad arguments"); return -1; }
 	dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
-	hipLaunchKernelGGL(gemm_nt_f32_mfma, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, cs, sa, sb, sc, alpha);
+	static const int bk = getenv("DSPFFT_GEMM_BK") ? atoi(getenv("DSPFFT_GEMM_BK")) : 8;
+	if (K >= 32 && bk == 32) hipLaunchKernelGGL(gemm_nt_f32_mfma<32>, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, cs, sa, sb, sc, alpha);
+	else if (K >= 16 && bk >= 16) hipLaunchKernelGGL(gemm_nt_f32_mfma<16>, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, cs, sa, sb, sc, alpha);
+	else hipLaunchKernelGGL(gemm_nt_f32_mfma<8>, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, cs, sa, sb, sc, alpha);
 	return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

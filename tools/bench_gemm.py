@@ -1,0 +1,34 @@
+import os, sys
+sys.path.insert(0, os.getcwd())
+import torch
+from dspfun_amd import _lib
+from dspfun_amd.zoom import Zoom
+L = _lib.load()
+def t(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+w, h = 1920, 1080
+z = Zoom(torch, torch.rand(h, w, 3, device="cuda:0"))
+vw, vh = 4 * w, 4 * h
+xb, cw = z._basis(0, 4.0, 1.0, 0.0, vw, w); yb, ch = z._basis(0, 4.0, 1.0, 0.0, vh, h)
+print("basis gen ms", t(lambda: (z._basis(0, 4.0, 1.0, 0.0, vw, w), z._basis(0, 4.0, 1.0, 0.0, vh, h))))
+out = torch.empty((vh, vw, 3), device="cuda:0"); work = torch.empty(L.dspfft_zoom_work_floats(w, h, ch, vw), device="cuda:0")
+ms = t(lambda: L.dspfft_zoom_product(z.coeffs.data_ptr(), w, h, xb.data_ptr(), cw, yb.data_ptr(), ch, out.data_ptr(), vw, vh, work.data_ptr(), None))
+fl = 2.0 * 3 * (ch * vw * cw + vh * vw * ch)
+print("product ms", ms, "TF", fl / ms / 1e9)
+# plain GEMMs
+A = torch.rand(7680, 1920, device="cuda:0"); B = torch.rand(1080, 1920, device="cuda:0"); Cc = torch.empty(7680, 1080, device="cuda:0")
+ms = t(lambda: L.dspfft_gemm_nt_f32(A.data_ptr(), B.data_ptr(), Cc.data_ptr(), 7680, 1080, 1920, 1920, 1920, 1080, 1, 1, 0, 0, 0, 1.0, None))
+print("gemm1 7680x1080x1920 ms", ms, "TF", 2 * 7680 * 1080 * 1920 / ms / 1e9)
+A2 = torch.rand(4320, 1080, device="cuda:0"); B2 = torch.rand(7680, 1080, device="cuda:0"); C2 = torch.empty(4320, 7680 * 3, device="cuda:0")
+ms = t(lambda: L.dspfft_gemm_nt_f32(A2.data_ptr(), B2.data_ptr(), C2.data_ptr(), 4320, 7680, 1080, 1080, 1080, 7680 * 3, 3, 1, 0, 0, 0, 1.0, None))
+print("gemm2 4320x7680x1080 cs=3 ms", ms, "TF", 2 * 4320 * 7680 * 1080 / ms / 1e9)
+ms = t(lambda: L.dspfft_gemm_nt_f32(A2.data_ptr(), B2.data_ptr(), C2.data_ptr(), 4320, 7680, 1080, 1080, 1080, 7680, 1, 1, 0, 0, 0, 1.0, None))
+print("gemm2 4320x7680x1080 cs=1 ms", ms, "TF", 2 * 4320 * 7680 * 1080 / ms / 1e9)
+A3 = torch.rand(8192, 4096, device="cuda:0"); B3 = torch.rand(8192, 4096, device="cuda:0"); C3 = torch.empty(8192, 8192, device="cuda:0")
+ms = t(lambda: L.dspfft_gemm_nt_f32(A3.data_ptr(), B3.data_ptr(), C3.data_ptr(), 8192, 8192, 4096, 4096, 4096, 8192, 1, 1, 0, 0, 0, 1.0, None))
+print("gemm 8192x8192x4096 ms", ms, "TF", 2 * 8192 * 8192 * 4096 / ms / 1e9)

@@ -130,6 +130,8 @@ static void run_col(const char *name)
 #define COL2(K, T, WPE, ...) run_col<ColSplit2<2160, K, T, __VA_ARGS__>, KIND_REDFT10, 0, WPE>("COL2 K=" #K " T=" #T " R=" #__VA_ARGS__)
 #define COL2A(K, T, WPE, ...) run_col<ColSplit2<2160, K, T, __VA_ARGS__>, KIND_REDFT10, 1, WPE>("COL2 K=" #K " T=" #T " R=" #__VA_ARGS__)
 #define COL23(K, T, WPE, ...) run_col<ColSplit2<2160, K, T, __VA_ARGS__>, KIND_REDFT01, 0, WPE>("COL2 K=" #K " T=" #T " R=" #__VA_ARGS__)
+#define COL3A(K, T, WPE, ...) run_col<ColSpec<2160, K, T, __VA_ARGS__>, KIND_REDFT01, 1, WPE>("COL K=" #K " T=" #T " R=" #__VA_ARGS__)
+#define ROW3A(T, WPE, ...) run_row<RowSpec<3840, 3, T, __VA_ARGS__>, KIND_REDFT01, 1, WPE>("ROW T=" #T " R=" #__VA_ARGS__)
 #define COL3(K, T, WPE, ...) run_col<ColSpec<2160, K, T, __VA_ARGS__>, KIND_REDFT01, 0, WPE>("COL K=" #K " T=" #T " R=" #__VA_ARGS__)
 
 int main()
