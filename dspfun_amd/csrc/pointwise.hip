@@ -1,0 +1,154 @@
+// pointwise.hip -- the elementwise stages the tools run either side of the transform,
+// as device kernels so buffers never leave HBM between the DCT and its display encoding / filtering:
+//   spec/spec.c:81-139   coefficient -> spectrogram encoding (gain, range, log/linear scale, sign mapping)
+//   spec/ispec.c:84-151  the inverse decoding (without the separate sign-map image of :91-99)
+//   motion/motion.c:683-744  band-pass damp / boost, threshold, DC preservation, quantisation
+// Scalar math follows the reference's `intermediate` = double.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+
+#include "../../include/dspfft.h"
+
+namespace {
+
+enum { RANGE_ONE = 0, RANGE_DC = 1, RANGE_DCS = 2 };
+enum { SCALE_LOG = 0, SCALE_LINEAR = 1 };
+enum { SIGN_ABS = 0, SIGN_SHIFT = 1, SIGN_SATURATE = 2, SIGN_RETAIN = 3 };
+
+// spec.c:92-110 (+ :115 log1p): per-channel divisor from the (gain-multiplied) DC terms
+__global__ void spec_max_kernel(double *mx, const float *f, int d, double gain, int rangetype, int scaletype)
+{
+	if (threadIdx.x || blockIdx.x) return;
+	float m[8];
+	if (rangetype == RANGE_ONE) for (int z = 0; z < d; z++) m[z] = (float)gain;
+	else if (rangetype == RANGE_DC) {
+		float best = (float)(f[0] * gain);
+		for (int z = 1; z < d; z++) { float v = (float)(f[z] * gain); if (v > best) best = v; }
+		for (int z = 0; z < d; z++) m[z] = best;
+	} else for (int z = 0; z < d; z++) m[z] = (float)(f[z] * gain);
+	for (int z = 0; z < d; z++) mx[z] = scaletype == SCALE_LOG ? (double)log1pf(m[z]) : (double)m[z];   // mc(log1p) on coeff max[] (spec.c:115)
+}
+
+__global__ void spec_encode_kernel(float *f, size_t len, int d, double gain, const double *mx, int scaletype, int signtype)
+{
+	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x) {
+		float v = (float)(f[i] * gain);                                                   // spec.c:88-89
+		const float m = (float)mx[i % d];
+		if (scaletype == SCALE_LOG) v = (float)(copysign(log1p((double)fabsf(v)), (double)v) / m);   // :117
+		else v = v / m;                                                                     // :121
+		if (signtype == SIGN_ABS) v = fabsf(v);                                             // :128
+		else if (signtype == SIGN_SHIFT) v = (float)(((double)v / 2. + 0.5) * 254 / 255);   // :132
+		else if (signtype == SIGN_SATURATE) { if (i >= (size_t)d) v = !signbit(v); }        // :135-136
+		f[i] = v;
+	}
+}
+
+__global__ void ispec_decode_kernel(float *f, size_t len, int d, double gain, double m0, double m1, double m2, double m3,
+                                    int scaletype, int signtype, int restore_dc, double dc0, double dc1, double dc2, double dc3)
+{
+	const double mx[4] = {m0, m1, m2, m3}, dc[4] = {dc0, dc1, dc2, dc3};
+	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x) {
+		float v = f[i];
+		if (signtype == SIGN_SHIFT) v = (float)(((double)v * 255. / 254 - 0.5) * 2);        // ispec.c:102
+		else if (signtype == SIGN_SATURATE) { if (i >= (size_t)d) v = v * 2 - 1; }          // :106
+		const double m = mx[i % d];
+		if (scaletype == SCALE_LOG) v = (float)copysign(expm1((double)fabsf((float)(v * m))), (double)v);   // :142
+		else v = (float)(v * m);                                                             // :146
+		v = (float)(v / gain);                                                               // :150-151
+		if (restore_dc && i < (size_t)d) v = (float)dc[i];                                   // :161-163 (the fused plan scaling is 1 at the corner)
+		f[i] = v;
+	}
+}
+
+struct MotionFilter {
+	int ad, ah, aw, mh, mw;
+	int b0d, b0h, b0w, b1d, b1h, b1w;
+	float damp, boost, thr_lo, thr_hi;
+	int preserve_dc;     // 0 none, 1 dc, 2 grey
+	float grey_add, quantizer;
+};
+
+__global__ void motion_filter_kernel(float *c, MotionFilter p, unsigned long long *coded)
+{
+	const size_t total = (size_t)p.ad * p.ah * p.aw;
+	unsigned long long mine = 0;
+	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+		const int x = (int)(i % p.aw), y = (int)((i / p.aw) % p.ah), z = (int)(i / ((size_t)p.aw * p.ah));
+		const size_t o = ((size_t)z * p.mh + y) * p.mw + x;
+		float v = c[o];
+		const float dc = v;                                                        // motion.c:650 (element 0 only)
+		const bool inside = z >= p.b0d && z < p.b1d && y >= p.b0h && y < p.b1h && x >= p.b0w && x < p.b1w;
+		if (!inside) { if (p.damp != 1.f) v *= p.damp; }                          // :683-714 the six face slabs = the complement of the box
+		else if (p.boost != 1.f) v *= p.boost;                                    // :715-719
+		if (p.thr_hi > 0.f) { const float a = fabsf(v); if (a < p.thr_lo || a > p.thr_hi) v = 0.f; }   // :721-728
+		if (i == 0 && p.preserve_dc) {                                            // :730-738
+			const bool dcstop = p.b0d || p.b0h || p.b0w;
+			if (dcstop || p.boost != 1.f || p.thr_hi > 0.f) {
+				if (p.preserve_dc == 1) v = dc;
+				else v += p.grey_add;
+			}
+		}
+		if (p.quantizer > 0.f) { v = (float)(round((double)v / p.quantizer) * p.quantizer); mine += (v != 0.f); }   // :740-744
+		c[o] = v;
+	}
+	if (coded && mine) atomicAdd(coded, mine);
+}
+
+thread_local char g_perr[256] = "";
+int bad(const char *m) { snprintf(g_perr, sizeof g_perr, "%s", m); return -1; }
+inline int grid_for(size_t n) { size_t b = (n + 255) / 256; return (int)(b < 1 ? 1 : b > 4096 ? 4096 : b); }
+
+}  // namespace
+
+extern "C" const char *dspfft_pointwise_last_error(void) { return g_perr; }
+
+extern "C" int dspfft_spec_encode(float *d_f, size_t npixels, int channels, double gain, int rangetype, int scaletype, int signtype, void *stream)
+{
+	if (!d_f || channels < 1 || channels > 8 || rangetype < 0 || rangetype > 2 || scaletype < 0 || scaletype > 1 || signtype < 0 || signtype > 3) return bad("bad arguments");
+	hipStream_t s = (hipStream_t)stream;
+	double *mx = nullptr;
+	if (hipMallocAsync((void **)&mx, sizeof(double) * 8, s) != hipSuccess) return bad("hipMallocAsync failed");
+	hipLaunchKernelGGL(spec_max_kernel, dim3(1), dim3(64), 0, s, mx, d_f, channels, gain, rangetype, scaletype);
+	const size_t len = npixels * channels;
+	hipLaunchKernelGGL(spec_encode_kernel, dim3(grid_for(len)), dim3(256), 0, s, d_f, len, channels, gain, mx, scaletype, signtype);
+	(void)hipFreeAsync(mx, s);
+	return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+extern "C" int dspfft_ispec_decode(float *d_f, size_t npixels, int channels, double gain, int rangetype, int scaletype, int signtype,
+                                   const double *dc, int restore_dc, void *stream)
+{
+	if (!d_f || channels < 1 || channels > 4 || rangetype < 0 || rangetype > 2 || scaletype < 0 || scaletype > 1 || signtype < 0 || signtype > 3) return bad("bad arguments (up to 4 channels)");
+	if ((rangetype != RANGE_ONE || restore_dc) && !dc) return bad("the DC values from the spectrogram header are required for range dc/dcs and for DC restoration");
+	double mx[4] = {0, 0, 0, 0}, d4[4] = {0, 0, 0, 0};
+	for (int z = 0; z < channels && dc; z++) d4[z] = dc[z];
+	// ispec.c:118-134 (max[] is `coeff`, i.e. float) and :138-139 (log1p in double)
+	float m[4];
+	if (rangetype == RANGE_ONE) for (int z = 0; z < channels; z++) m[z] = (float)gain;
+	else if (rangetype == RANGE_DC) {
+		float best = (float)(dc[0] * gain);
+		for (int z = 1; z < channels; z++) if (dc[z] * gain > best) best = (float)(dc[z] * gain);
+		for (int z = 0; z < channels; z++) m[z] = best;
+	} else for (int z = 0; z < channels; z++) m[z] = (float)(dc[z] * gain);
+	for (int z = 0; z < channels; z++) mx[z] = scaletype == SCALE_LOG ? (double)(float)log1p((double)m[z]) : (double)m[z];
+	const size_t len = npixels * channels;
+	hipLaunchKernelGGL(ispec_decode_kernel, dim3(grid_for(len)), dim3(256), 0, (hipStream_t)stream, d_f, len, channels, gain,
+	                   mx[0], mx[1], mx[2], mx[3], scaletype, signtype, restore_dc, d4[0], d4[1], d4[2], d4[3]);
+	return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+extern "C" int dspfft_motion_filter(float *d_coeffs, const int active[3], const int minbuf_hw[2], const int band_begin[3], const int band_end[3],
+                                    float damp, float boost, float threshold_lo, float threshold_hi, int preserve_dc, float grey_add,
+                                    float quantizer, unsigned long long *d_coeffs_coded, void *stream)
+{
+	if (!d_coeffs || !active || !minbuf_hw || !band_begin || !band_end || preserve_dc < 0 || preserve_dc > 2) return bad("bad arguments");
+	MotionFilter p;
+	p.ad = active[0]; p.ah = active[1]; p.aw = active[2]; p.mh = minbuf_hw[0]; p.mw = minbuf_hw[1];
+	p.b0d = band_begin[0]; p.b0h = band_begin[1]; p.b0w = band_begin[2]; p.b1d = band_end[0]; p.b1h = band_end[1]; p.b1w = band_end[2];
+	p.damp = damp; p.boost = boost; p.thr_lo = threshold_lo; p.thr_hi = threshold_hi; p.preserve_dc = preserve_dc; p.grey_add = grey_add; p.quantizer = quantizer;
+	const size_t total = (size_t)p.ad * p.ah * p.aw;
+	if (!total) return 0;
+	hipLaunchKernelGGL(motion_filter_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, d_coeffs, p, d_coeffs_coded);
+	return hipGetLastError() == hipSuccess ? 0 : -4;
+}

@@ -140,6 +140,29 @@ int dspfft_applybasis_partsums(float *d_out, const float *d_pixels, int w, int h
                                int Kw, int Kh, int Pw, int Ph, long long offw, long long offh,
                                float *d_work, void *hip_stream);
 
+/* ---- elementwise stages either side of the transform, on the device ---- */
+
+/* spec/spec.c:81-139 on uniform-range coefficients (after the fused normalisation): f *= gain; divisor per channel
+ * from rangetype (0 one, 1 dc, 2 dcs; spec.c:92-110); scaletype 0 log (copysign(log1p|f|)/log1p(max), :113-118) or
+ * 1 linear (:120-122); signtype 0 abs, 1 shift, 2 saturate, 3 retain (:124-139).  `gain` is the resolved multiplier
+ * (native 127.5*sqrt(4wh), reference 127.5*1024, or custom; spec.c:82-87). */
+int dspfft_spec_encode(float *d_f, size_t npixels, int channels, double gain, int rangetype, int scaletype, int signtype, void *hip_stream);
+
+/* spec/ispec.c:100-151, the inverse (the separate sign-map image of :91-99 is not handled).  dc: `channels` doubles
+ * from the spectrogram's "DC" property (host memory; needed for rangetype dc/dcs and for restore_dc, ispec.c:161-163). */
+int dspfft_ispec_decode(float *d_f, size_t npixels, int channels, double gain, int rangetype, int scaletype, int signtype,
+                        const double *dc, int restore_dc, void *hip_stream);
+
+/* motion/motion.c:683-744 on one block of uniform-range coefficients embedded in {., minbuf_h, minbuf_w}: damp outside /
+ * boost inside the band-pass box [band_begin, band_end), threshold on |c| (threshold_hi <= 0 disables; bounds already scaled
+ * as motion.c:571-572), DC preservation (0 none, 1 dc, 2 grey with grey_add = (1 - (dcstop ? damp : boost)) * 127.5 /
+ * (normalization^2 * scalefactor), :736), quantisation round(c/Q)*Q (Q <= 0 disables).  d_coeffs_coded (optional, device)
+ * accumulates the count of non-zero quantised coefficients (:744).  All index triples are {d, h, w}. */
+int dspfft_motion_filter(float *d_coeffs, const int active[3], const int minbuf_hw[2], const int band_begin[3], const int band_end[3],
+                         float damp, float boost, float threshold_lo, float threshold_hi, int preserve_dc, float grey_add,
+                         float quantizer, unsigned long long *d_coeffs_coded, void *hip_stream);
+const char *dspfft_pointwise_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

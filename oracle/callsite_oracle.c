@@ -174,3 +174,71 @@ void oracle_applybasis_partsums_f64(double *out /* [Kh][Kw][Nh][Nw][3][2] */, co
 					for (int j = 0; j < 3; j++) { o[2 * j] = creal(ps[j]); o[2 * j + 1] = cimag(ps[j]); }
 				}
 }
+
+/* ---- spectrogram encoding / decoding and motion's coefficient filters, as the reference computes them with
+ * COEFF_PRECISION=F, INTERMEDIATE_PRECISION=D (coeff = float, intermediate = double) ------------------------- */
+
+/* spec/spec.c:88-139.  rangetype 0 one / 1 dc / 2 dcs; scaletype 0 log / 1 linear; signtype 0 abs / 1 shift / 2 saturate / 3 retain */
+void oracle_spec_encode_f32(float *f, size_t npix, int d, double gain, int rangetype, int scaletype, int signtype)
+{
+	const size_t l = npix * d;
+	for (size_t i = 0; i < l; i++) f[i] *= gain;
+	float max[16];
+	if (rangetype == 0) *max = gain;
+	else if (rangetype == 1) { *max = f[0]; for (int z = 1; z < d; z++) if (f[z] > *max) *max = f[z]; }
+	else for (int z = 0; z < d; z++) max[z] = f[z];
+	if (rangetype != 2) for (int z = 1; z < d; z++) max[z] = max[0];
+	if (scaletype == 0) {
+		for (int z = 0; z < d; z++) max[z] = log1pf(max[z]);
+		for (size_t i = 0; i < l; i++) f[i] = copysign(log1p(fabsf(f[i])), f[i]) / max[i % d];
+	} else for (size_t i = 0; i < l; i++) f[i] /= max[i % d];
+	if (signtype == 0) for (size_t i = 0; i < l; i++) f[i] = fabsf(f[i]);
+	else if (signtype == 1) for (size_t i = 0; i < l; i++) f[i] = (f[i] / 2. + 0.5) * 254 / 255;
+	else if (signtype == 2) for (size_t i = d; i < l; i++) f[i] = !signbit(f[i]);
+}
+
+/* spec/ispec.c:100-151 (+ the preserve_dc store of :161-163, which the fused plan scaling leaves unchanged) */
+void oracle_ispec_decode_f32(float *f, size_t npix, int d, double gain, int rangetype, int scaletype, int signtype, const double *DC, int restore_dc)
+{
+	const size_t l = npix * d;
+	if (signtype == 1) for (size_t i = 0; i < l; i++) f[i] = (f[i] * 255. / 254 - 0.5) * 2;
+	else if (signtype == 2) for (size_t i = d; i < l; i++) f[i] = f[i] * 2 - 1;
+	float max[16];
+	if (rangetype == 0) *max = gain;
+	else if (rangetype == 1) { *max = DC[0] * gain; for (int z = 1; z < d; z++) if (DC[z] * gain > *max) *max = DC[z] * gain; }
+	else for (int z = 0; z < d; z++) max[z] = DC[z] * gain;
+	if (rangetype != 2) for (int z = 1; z < d; z++) max[z] = max[0];
+	if (scaletype == 0) {
+		for (int z = 0; z < d; z++) max[z] = log1p(max[z]);
+		for (size_t i = 0; i < l; i++) f[i] = copysign(expm1(fabsf(f[i] * max[i % d])), f[i]);
+	} else for (size_t i = 0; i < l; i++) f[i] *= max[i % d];
+	for (size_t i = 0; i < l; i++) f[i] /= gain;
+	if (restore_dc) for (int z = 0; z < d; z++) f[z] = DC[z];
+}
+
+/* motion/motion.c:650,683-744 on one block (expr == NULL, coeff_limit == 0) */
+unsigned long long oracle_motion_filter_f32(float *coeffs, const int active[3], const int minbuf_hw[2], const int bb[3], const int be[3],
+                                            float damp, float boost, float thr_lo, float thr_hi, int preserve_dc, double grey_add, float quantizer)
+{
+	const int ad = active[0], ah = active[1], aw = active[2], mh = minbuf_hw[0], mw = minbuf_hw[1];
+	unsigned long long coded = 0;
+#define AT(z, y, x) coeffs[((size_t)(z) * mh + (y)) * mw + (x)]
+	float dc = coeffs[0];
+	if (damp != 1) {
+		if (bb[0]) for (int z = 0; z < bb[0]; z++) for (int y = 0; y < ah; y++) for (int x = 0; x < aw; x++) AT(z, y, x) *= damp;
+		if (be[0] < ad) for (int z = be[0]; z < ad; z++) for (int y = 0; y < ah; y++) for (int x = 0; x < aw; x++) AT(z, y, x) *= damp;
+		if (bb[1]) for (int z = bb[0]; z < be[0]; z++) for (int y = 0; y < bb[1]; y++) for (int x = 0; x < aw; x++) AT(z, y, x) *= damp;
+		if (be[1] < ah) for (int z = bb[0]; z < be[0]; z++) for (int y = be[1]; y < ah; y++) for (int x = 0; x < aw; x++) AT(z, y, x) *= damp;
+		if (bb[2]) for (int z = bb[0]; z < be[0]; z++) for (int y = bb[1]; y < be[1]; y++) for (int x = 0; x < bb[2]; x++) AT(z, y, x) *= damp;
+		if (be[2] < aw) for (int z = bb[0]; z < be[0]; z++) for (int y = bb[1]; y < be[1]; y++) for (int x = be[2]; x < aw; x++) AT(z, y, x) *= damp;
+	}
+	if (boost != 1) for (int z = bb[0]; z < be[0]; z++) for (int y = bb[1]; y < be[1]; y++) for (int x = bb[2]; x < be[2]; x++) AT(z, y, x) *= boost;
+	if (thr_hi > 0) for (int z = 0; z < ad; z++) for (int y = 0; y < ah; y++) for (int x = 0; x < aw; x++) { float c = fabsf(AT(z, y, x)); if (c < thr_lo || c > thr_hi) AT(z, y, x) = 0; }
+	if (preserve_dc) {
+		int dcstop = bb[0] || bb[1] || bb[2];
+		if (dcstop || boost != 1 || thr_hi > 0) { if (preserve_dc == 1) coeffs[0] = dc; else coeffs[0] += grey_add; }
+	}
+	if (quantizer > 0) for (int z = 0; z < ad; z++) for (int y = 0; y < ah; y++) for (int x = 0; x < aw; x++) coded += !!(AT(z, y, x) = round(AT(z, y, x) / quantizer) * quantizer);
+#undef AT
+	return coded;
+}

@@ -403,3 +403,70 @@ def test_applybasis_partsums_vs_oracle(gpu, func, w, h, terms, psum, off, ortho)
     L.oracle_applybasis_partsums_f64(ref.ctypes.data, x64.ctypes.data, w, h, FUNCTIONS.index(func), int(ortho), kw, kh, psum[0], psum[1], off[0], off[1])
     refc = ref[..., 0] + 1j * ref[..., 1]
     assert np.abs(got - refc).max() <= 1e-5 * max(1.0, np.abs(refc).max())
+
+
+# ---- elementwise stages either side of the transform ----
+@pytest.mark.parametrize("rangetype", [0, 1, 2])
+@pytest.mark.parametrize("scaletype", [0, 1])
+@pytest.mark.parametrize("signtype", [0, 1, 2, 3])
+def test_spec_encode_decode_vs_oracle(gpu, rangetype, scaletype, signtype):
+    import ctypes as C
+    from dspfun_amd import _lib, Plan, REDFT10
+    L = _lib.load()
+    h, w, d = 45, 64, 3
+    x = ol.synth_f32(rangetype * 10 + scaletype * 5 + signtype, h * w * d).reshape(h, w, d)
+    r2 = float(np.sqrt(2.0))
+    f = dev(gpu, x)
+    Plan.image(h, w, d, REDFT10).set_scale(1.0 / (2 * w * h)).set_axis_scale0(0, 1, 1 / r2).set_axis_scale0(1, 1, 1 / r2).execute(f.data_ptr())
+    gpu.cuda.synchronize()
+    coeffs = f.cpu().numpy().copy()                       # uniform-range coefficients (spec.c:78)
+    gain = 127.5 * np.sqrt(4.0 * w * h)                   # gaintype native (spec.c:84)
+    assert L.dspfft_spec_encode(f.data_ptr(), h * w, d, gain, rangetype, scaletype, signtype, None) == 0
+    gpu.cuda.synchronize()
+    enc = f.cpu().numpy()
+    ref = coeffs.copy()
+    O = ol.lib()
+    O.oracle_spec_encode_f32.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int]
+    O.oracle_spec_encode_f32(ref.ctypes.data, h * w, d, gain, rangetype, scaletype, signtype)
+    assert np.abs(enc - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())
+    # decode (not invertible for abs / saturate: those drop the sign; compare with the oracle's decode of the same input)
+    DC = (coeffs[0, 0].astype(np.float64)).copy()       # spec.c:66-68 stores f[z]/(4wh) of the unnormalised output == uniform-range DC
+    dc_arr = (C.c_double * d)(*DC)
+    assert L.dspfft_ispec_decode(f.data_ptr(), h * w, d, gain, rangetype, scaletype, signtype, dc_arr, 1, None) == 0
+    gpu.cuda.synchronize()
+    dec = f.cpu().numpy()
+    ref2 = ref.copy()
+    O.oracle_ispec_decode_f32.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    O.oracle_ispec_decode_f32(ref2.ctypes.data, h * w, d, gain, rangetype, scaletype, signtype, DC.ctypes.data, 1)
+    scale = max(1e-3, np.abs(ref2).max())
+    assert np.abs(dec - ref2).max() <= 1e-5 * scale
+    if signtype in (1, 3):                                # sign-preserving encodings invert back to the coefficients
+        assert np.abs(dec - coeffs).max() <= 2e-5 * max(1e-3, np.abs(coeffs).max())
+
+
+@pytest.mark.parametrize("cfg", [dict(damp=0.5, boost=1.0, bb=(0, 2, 3), be=(6, 20, 30)), dict(damp=1.0, boost=1.5, bb=(1, 0, 0), be=(8, 24, 40), preserve_dc=1),
+                                  dict(damp=0.0, boost=2.0, bb=(0, 0, 0), be=(4, 12, 20), thr=(5.0, 5000.0), preserve_dc=2, quant=3.0),
+                                  dict(damp=1.0, boost=1.0, bb=(0, 0, 0), be=(8, 24, 40), quant=7.5)])
+def test_motion_filter_vs_oracle(gpu, cfg):
+    import ctypes as C
+    from dspfun_amd import _lib
+    L = _lib.load()
+    ad, ah, aw, mh, mw = 8, 24, 40, 26, 48
+    c = ((ol.synth_f32(99, 10 * mh * mw) - 0.5) * 4000).astype(np.float32)
+    d = dev(gpu, c)
+    I3, I2 = C.c_int * 3, C.c_int * 2
+    thr = cfg.get("thr", (0.0, 0.0))
+    grey = 12.5
+    coded = gpu.zeros(1, dtype=gpu.int64, device="cuda:0")
+    assert L.dspfft_motion_filter(d.data_ptr(), I3(ad, ah, aw), I2(mh, mw), I3(*cfg["bb"]), I3(*cfg["be"]), cfg["damp"], cfg["boost"], thr[0], thr[1],
+                                  cfg.get("preserve_dc", 0), grey, cfg.get("quant", 0.0), coded.data_ptr(), None) == 0
+    gpu.cuda.synchronize()
+    ref = c.copy()
+    O = ol.lib()
+    O.oracle_motion_filter_f32.restype = C.c_ulonglong
+    O.oracle_motion_filter_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_double, C.c_float]
+    n = O.oracle_motion_filter_f32(ref.ctypes.data, I3(ad, ah, aw), I2(mh, mw), I3(*cfg["bb"]), I3(*cfg["be"]), cfg["damp"], cfg["boost"], thr[0], thr[1],
+                                   cfg.get("preserve_dc", 0), grey, cfg.get("quant", 0.0))
+    assert np.array_equal(d.cpu().numpy(), ref)
+    if cfg.get("quant"):
+        assert int(coded[0]) == n
