@@ -44,7 +44,7 @@ def test_product_library_exports_the_fftw_named_boundary():
 def test_host_harnesses_build():
     import subprocess
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
-    for exe in ("spec_gpu", "scan_gpu"):
+    for exe in ("spec_gpu", "scan_gpu", "motion_gpu"):
         assert os.access(os.path.join(ROOT, "host", exe), os.X_OK)
 
 

@@ -154,3 +154,63 @@ def test_scan_harness(tmp_path):
     assert np.abs(_read_pf(out) - img.astype(np.float64) / 255.0).max() <= 5e-6
     errs = [float(ln.split("=")[1]) for ln in r.stderr.decode().splitlines() if "max|sum-input|" in ln]
     assert len(errs) == (96 * 64 + 499) // 500 and errs[-1] <= 5e-6 and errs[0] > errs[-1]
+
+
+def _y4m(path, frames_yuv, w, h):
+    with open(path, "wb") as f:
+        f.write(b"YUV4MPEG2 W%d H%d F25:1 Ip A1:1 C420jpeg\n" % (w, h))
+        for fr in frames_yuv:
+            f.write(b"FRAME\n")
+            f.write(fr.tobytes())
+
+
+def _read_y4m(path, fb):
+    raw = open(path, "rb").read()
+    body = raw[raw.index(b"\n") + 1:]
+    out = []
+    while body:
+        assert body.startswith(b"FRAME\n")
+        out.append(np.frombuffer(body[6:6 + fb], dtype=np.uint8))
+        body = body[6 + fb:]
+    return out
+
+
+@pytest.mark.parametrize("depth", [1, 4, 0])
+def test_motion_harness_y4m_roundtrip(tmp_path, depth):
+    """config 5's pipeline at small size: yuv420p Y4M through motion's block loop (2-D per frame, 3-D blocks of 4,
+    whole clip as one 3-D block) reproduces every 8-bit sample (motion.c:617-776 with no filter)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    w, h, n = 96, 54, 8                     # chroma 48x27
+    fb = w * h + 2 * ((w + 1) // 2) * ((h + 1) // 2)
+    frames = [ol.synth_u8(0xD5F0005 + i, fb) for i in range(n)]
+    src, dst = tmp_path / "in.y4m", tmp_path / "out.y4m"
+    _y4m(src, frames, w, h)
+    subprocess.check_call([os.path.join(ROOT, "host", "motion_gpu"), str(src), str(dst), str(depth)])
+    got = _read_y4m(dst, fb)
+    assert len(got) == n
+    for a, b in zip(got, frames):
+        assert np.array_equal(a, b)
+
+
+def test_motion_harness_quantiser_matches_oracle(tmp_path):
+    """-q: uniform-range coefficients rounded to multiples of q*8*sqrt(N) (motion.c:570,740-744), checked on the luma
+    plane of a single 3-D block against the f64 restatement"""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    w, h, n, q = 64, 32, 4, 0.02
+    fb = w * h + 2 * (w // 2) * (h // 2)
+    frames = [ol.synth_u8(77 + i, fb) for i in range(n)]
+    src, dst = tmp_path / "in.y4m", tmp_path / "out.y4m"
+    _y4m(src, frames, w, h)
+    subprocess.check_call([os.path.join(ROOT, "host", "motion_gpu"), str(src), str(dst), "0", str(q)])
+    got = np.stack([g[:w * h] for g in _read_y4m(dst, fb)]).reshape(n, h, w)
+    vol = np.stack([f[:w * h] for f in frames]).astype(np.float64).reshape(n, h, w)
+    c = ol.r2r_many(vol, [n, h, w], [ol.REDFT10] * 3, impl="port")
+    ol.lib().oracle_motion_uniform_f64(c.ctypes.data, n, h, w, h, w, 1)
+    Q = np.float32(q * 8 * np.sqrt(float(w * h * n)))
+    c = np.round(c / Q) * Q
+    ol.lib().oracle_motion_uniform_f64(c.ctypes.data, n, h, w, h, w, -1)
+    back = ol.r2r_many(c, [n, h, w], [ol.REDFT01] * 3, impl="port").reshape(n, h, w) / (8.0 * w * h * n)
+    ref = np.clip(np.round(back), 0, 255).astype(np.uint8)
+    # coefficients sitting exactly on a rounding boundary may flip between f32 and f64: allow a handful of +-1 LSB pixels
+    diff = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+    assert diff.max() <= 2 and (diff > 0).mean() < 0.02
