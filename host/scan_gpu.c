@@ -6,7 +6,8 @@
  * dspfft_scan_zigzag.  Output: the final `sum` image (== input when every index was scanned) and,
  * per frame, max|sum - input| on stderr (the quantity --measure-parity thresholds, scan.c:508-526).
  *
- *   scan_gpu in.{ppm,pf} out.pf [step]
+ *   scan_gpu in.{ppm,pf} out.pf [step] [method-prefix]      (default method: zigzag, from the device;
+ *                                                            other methods from host/scan_orders.c)
  */
 #include <math.h>
 #include <stdint.h>
@@ -18,6 +19,7 @@
 #include <hip/hip_runtime_api.h>
 #include "precision.h"
 #include "rawio.h"
+#include "scan_orders.h"
 
 int main(int argc, char *argv[])
 {
@@ -25,7 +27,11 @@ int main(int argc, char *argv[])
 	size_t width, height, channels = 3;
 	float *pix;
 	if (read_image(argv[1], &width, &height, &pix)) { fprintf(stderr, "cannot read %s\n", argv[1]); return 1; }
-	size_t limit = width * height, step = argc > 3 ? strtoul(argv[3], NULL, 10) : (limit + 31) / 32;
+	const int method = argc > 4 ? scan_order_find_prefix(argv[4]) : SCAN_ZIGZAG;    /* scan.c:176 scan_method_find_prefix */
+	if (method < 0) { fprintf(stderr, "unknown scan method %s\n", argv[4]); return 2; }
+	size_t limit = scan_order_limit(method, width, height);                             /* scan_context.c:30 */
+	size_t max_interval = scan_order_max_interval(method, width, height);
+	size_t step = argc > 3 ? strtoul(argv[3], NULL, 10) : (limit + 31) / 32;
 	if (!step) step = 1;
 
 	coeff *coeffs = fftw(alloc_real)(width * height * channels);    /* scan.c:275 */
@@ -39,15 +45,19 @@ int main(int argc, char *argv[])
 	fftw(destroy_plan)(forward);
 	for (size_t i = 0; i < width * height * channels; i++) coeffs[i] /= width * height * 4;   /* scan.c:296-298 */
 
-	/* scan order: the engine's device zigzag, copied back once */
-	uint32_t *order = malloc(sizeof(uint32_t) * limit), *d_order;
-	if (hipMalloc((void **)&d_order, sizeof(uint32_t) * limit) != hipSuccess ||
-	    dspfft_scan_zigzag(d_order, width, height, 0, limit, NULL) ||
-	    hipMemcpy(order, d_order, sizeof(uint32_t) * limit, hipMemcpyDeviceToHost) != hipSuccess) {
-		fprintf(stderr, "zigzag failed: %s\n", dspfft_last_error());
-		return 1;
+	/* zigzag: the engine's device generator, copied back once; other methods: host/scan_orders.c per index */
+	uint32_t *order = NULL, *d_order;
+	if (method == SCAN_ZIGZAG) {
+		order = malloc(sizeof(uint32_t) * limit);
+		if (hipMalloc((void **)&d_order, sizeof(uint32_t) * limit) != hipSuccess ||
+		    dspfft_scan_zigzag(d_order, width, height, 0, limit, NULL) ||
+		    hipMemcpy(order, d_order, sizeof(uint32_t) * limit, hipMemcpyDeviceToHost) != hipSuccess) {
+			fprintf(stderr, "zigzag failed: %s\n", dspfft_last_error());
+			return 1;
+		}
+		hipFree(d_order);
 	}
-	hipFree(d_order);
+	size_t (*coords)[2] = malloc(sizeof(*coords) * (max_interval + 1) * step);         /* scan.c:346 */
 
 	size_t nframes = (limit + step - 1) / step;                      /* scan.c:347-348 */
 	coeff *reconstruction = fftw(alloc_real)(width * height * channels);   /* scan.c:352-354 */
@@ -60,9 +70,17 @@ int main(int argc, char *argv[])
 
 	for (size_t i = 0; i < nframes; i++) {                           /* scan.c:421-459 */
 		memset(reconstruction, 0, sizeof(*reconstruction) * width * height * channels);
-		for (size_t s = i * step; s < i * step + step && s < limit; s++) {
-			size_t o = order[s];
-			memcpy(reconstruction + o * channels, coeffs + o * channels, sizeof(*reconstruction) * channels);
+		size_t ncoords = 0;
+		for (size_t s = i * step; s < i * step + step && s < limit; s++) {               /* scan.c:423-427 */
+			if (order) { coords[ncoords][0] = order[s] / width; coords[ncoords][1] = order[s] % width; ncoords++; }
+			else ncoords += scan_order_coords(method, width, height, s, coords + ncoords);
+		}
+		for (size_t ci = 0; ci < ncoords; ci++) {                                        /* scan.c:430-432 */
+			size_t y = coords[ci][0], x = coords[ci][1];
+			size_t lin = y * width + x;                   /* `box` emits x = i >= width on tall images: the reference's pointer arithmetic
+			                                                 lands in a later row; past the end of the buffer it is undefined, skipped here */
+			if (lin >= width * height) continue;
+			memcpy(reconstruction + lin * channels, coeffs + lin * channels, sizeof(*reconstruction) * channels);
 		}
 		memset(reconstruction, 0, sizeof(*coeffs) * channels);       /* clear DC, scan.c:445 */
 		fftw(execute)(inverse);
@@ -77,7 +95,7 @@ int main(int argc, char *argv[])
 	int rc = write_pf(argv[2], width, height, sum);
 	fftw(destroy_plan)(inverse);
 	fftw(free)(reconstruction); fftw(free)(image); fftw(free)(coeffs);
-	free(sum); free(order); free(pix);
+	free(sum); free(order); free(coords); free(pix);
 	fftw(cleanup)(); fftw(cleanup_threads)();                        /* scan.c:563-564 */
 	return rc;
 }

@@ -214,3 +214,14 @@ def test_motion_harness_quantiser_matches_oracle(tmp_path):
     # coefficients sitting exactly on a rounding boundary may flip between f32 and f64: allow a handful of +-1 LSB pixels
     diff = np.abs(got.astype(np.int32) - ref.astype(np.int32))
     assert diff.max() <= 2 and (diff > 0).mean() < 0.02
+
+
+@pytest.mark.parametrize("method,step", [("diagonal", 9), ("mirror", 5), ("radial", 7), ("horizontal", 700), ("column", 11)])
+def test_scan_harness_other_methods(tmp_path, method, step):
+    """every permutation scan method reconstructs the image exactly once all indices are summed (scan.c:377-459)"""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    img = ol.synth_u8(31, 80 * 48 * 3).reshape(48, 80, 3)
+    ppm, out = tmp_path / "in.ppm", tmp_path / "sum.pf"
+    _write_ppm(ppm, img)
+    subprocess.run([os.path.join(ROOT, "host", "scan_gpu"), str(ppm), str(out), str(step), method], stderr=subprocess.PIPE, check=True)
+    assert np.abs(_read_pf(out) - img.astype(np.float64) / 255.0).max() <= 5e-6

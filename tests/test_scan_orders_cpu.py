@@ -1,0 +1,114 @@
+"""CPU: host/scan_orders.c (the harness-side scan library) against the oracle restatements and the reference's
+known answers.  Integer work: bit-exact."""
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import scan_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+METHODS = ["horizontal", "vertical", "zigzag", "row", "column", "diagonal", "mirror", "box", "ibox", "radial", "iradial"]
+
+
+@pytest.fixture(scope="module")
+def so():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host"), "libscanorders.so"])
+    lib = C.CDLL(os.path.join(ROOT, "host", "libscanorders.so"))
+    lib.scan_order_limit.restype = C.c_size_t
+    lib.scan_order_limit.argtypes = [C.c_int, C.c_size_t, C.c_size_t]
+    lib.scan_order_max_interval.restype = C.c_size_t
+    lib.scan_order_max_interval.argtypes = [C.c_int, C.c_size_t, C.c_size_t]
+    lib.scan_order_coords.restype = C.c_size_t
+    lib.scan_order_coords.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
+    lib.scan_order_find_prefix.argtypes = [C.c_char_p]
+    lib.scan_order_serialize_coordinate.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_void_p]
+    lib.scan_order_serialize_index.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_void_p]
+    return lib
+
+
+def product_orders(so, method, w, h):
+    m = METHODS.index(method)
+    buf = np.zeros((so.scan_order_max_interval(m, w, h) + 1, 2), dtype=np.uint64)
+    out = []
+    for i in range(so.scan_order_limit(m, w, h)):
+        n = so.scan_order_coords(m, w, h, i, buf.ctypes.data)
+        out.append([(int(buf[j, 0]), int(buf[j, 1])) for j in range(n)])
+    return out
+
+
+def oracle_orders(method, w, h):
+    L = ol.lib()
+    if method in ("mirror", "box", "ibox", "radial", "iradial"):
+        return scan_ref.orders(method, w, h)
+    if method in ("horizontal", "vertical", "zigzag"):
+        fn = getattr(L, "oracle_scan_" + method)
+        fn.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
+        yx = (C.c_size_t * 2)()
+        out = []
+        for i in range(w * h):
+            fn(w, h, i, yx)
+            out.append([(yx[0], yx[1])])
+        return out
+    fn = getattr(L, "oracle_scan_" + method)
+    fn.restype = C.c_size_t
+    fn.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
+    limit = {"row": h, "column": w, "diagonal": w + h - 1}[method]
+    buf = np.zeros((w + h + 1, 2), dtype=np.uint64)
+    out = []
+    for i in range(limit):
+        n = fn(w, h, i, buf.ctypes.data)
+        out.append([(int(buf[j, 0]), int(buf[j, 1])) for j in range(n)])
+    return out
+
+
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("w,h", [(8, 8), (16, 9), (9, 16), (5, 1), (1, 5), (7, 3)])
+def test_scan_orders_match_oracle(so, method, w, h):
+    assert product_orders(so, method, w, h) == oracle_orders(method, w, h)
+
+
+def test_box_quirks_recorded_by_the_survey(so):
+    # `box` emits 84 out-of-range x on 9x16 and 84 duplicate coordinates on 16x9
+    o = [c for idx in product_orders(so, "box", 9, 16) for c in idx]
+    assert sum(1 for (y, x) in o if x >= 9) == 84
+    o = [c for idx in product_orders(so, "box", 16, 9) for c in idx]
+    assert len(o) - len(set(o)) == 84
+    # `ibox` emits its corner twice per index (scan_methods.c:135-144)
+    o = product_orders(so, "ibox", 6, 4)
+    assert all(idx.count((i, i)) == 2 for i, idx in enumerate(o))
+
+
+def test_prefix_lookup(so):
+    assert so.scan_order_find_prefix(b"z") == METHODS.index("zigzag")
+    assert so.scan_order_find_prefix(b"r") == METHODS.index("row")          # shortest name with the prefix (scan_methods.c:581-591)
+    assert so.scan_order_find_prefix(b"rad") == METHODS.index("radial")
+    assert so.scan_order_find_prefix(b"nope") == -1
+
+
+def test_serialisers_reproduce_readme_listings(so, scan_golden):
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    m = METHODS.index("diagonal")
+    for fn, key in ((so.scan_order_serialize_index, "diagonal_8x8_index"), (so.scan_order_serialize_coordinate, "diagonal_8x8_coordinate")):
+        with tempfile.NamedTemporaryFile(suffix=".txt", delete=False) as tf:
+            path = tf.name
+        f = libc.fopen(path.encode(), b"w")
+        assert fn(m, 8, 8, f) == 0
+        libc.fclose(f)
+        lines = [ln.rstrip() for ln in open(path).read().splitlines()]
+        os.unlink(path)
+        assert lines == [ln.rstrip() for ln in scan_golden[key]]
+
+
+@pytest.mark.parametrize("method", ["horizontal", "vertical", "zigzag", "row", "column", "diagonal", "mirror", "radial", "iradial"])
+def test_permutation_methods_cover_every_pixel_once(so, method):
+    w, h = 12, 7
+    flat = [c for idx in product_orders(so, method, w, h) for c in idx]
+    assert sorted(flat) == [(y, x) for y in range(h) for x in range(w)]
