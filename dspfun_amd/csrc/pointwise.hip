@@ -95,6 +95,36 @@ __global__ void motion_filter_kernel(float *c, MotionFilter p, unsigned long lon
 	if (coded && mine) atomicAdd(coded, mine);
 }
 
+// scan/scan.c:20-28 basis matrix entries B_N[k][j] = j ? 2 cos(pi j (k + 1/2) / N) : 1, for the selected j only
+__global__ void pruned_basis_kernel(float *by, float *bx, const uint32_t *lin, int ncoords, int w, int h)
+{
+	const int total = ncoords * (w + h);
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+		const int n = i / (w + h), r = i - n * (w + h);
+		const uint32_t p = lin[n];
+		const int cy = (int)(p / (uint32_t)w), cx = (int)(p % (uint32_t)w);
+		if (r < h) by[n * h + r] = cy ? (float)(2.0 * cos(M_PI * cy * (r + 0.5) / h)) : 1.f;
+		else { const int x = r - h; bx[n * w + x] = cx ? (float)(2.0 * cos(M_PI * cx * (x + 0.5) / w)) : 1.f; }
+	}
+}
+// scan/scan.c:30-41 + :451-459: sum += sum_n coeff[n] * B_h[y][cy_n] * B_w[x][cx_n]   (DC pixel excluded by the caller's list)
+__global__ void pruned_accumulate_kernel(float *sum, const float *coeffs, const uint32_t *lin, const float *by, const float *bx,
+                                         int ncoords, int w, int h, int ch)
+{
+	const size_t total = (size_t)w * h * ch;
+	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+		const int z = (int)(i % ch);
+		const size_t p = i / ch;
+		const int x = (int)(p % w), y = (int)(p / w);
+		float acc = 0.f;
+		for (int n = 0; n < ncoords; n++) {
+			const float c = coeffs[(size_t)lin[n] * ch + z] * by[n * h + y] * bx[n * w + x];
+			acc = n ? acc + c : c;
+		}
+		sum[i] += acc;
+	}
+}
+
 thread_local char g_perr[256] = "";
 int bad(const char *m) { snprintf(g_perr, sizeof g_perr, "%s", m); return -1; }
 inline int grid_for(size_t n) { size_t b = (n + 255) / 256; return (int)(b < 1 ? 1 : b > 4096 ? 4096 : b); }
@@ -150,5 +180,22 @@ extern "C" int dspfft_motion_filter(float *d_coeffs, const int active[3], const 
 	const size_t total = (size_t)p.ad * p.ah * p.aw;
 	if (!total) return 0;
 	hipLaunchKernelGGL(motion_filter_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, d_coeffs, p, d_coeffs_coded);
+	return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+/* scan's pruned inverse (scan/scan.c:20-41,449): for frames that add only a few coefficients, the direct sum of
+ * rank-1 basis products replaces the two-pass REDFT01 -- one read + one write of `sum`, no intermediate. */
+extern "C" int dspfft_scan_pruned_accumulate(float *d_sum, const float *d_coeffs, const uint32_t *d_lin, int ncoords,
+                                             int w, int h, int channels, void *stream)
+{
+	if (!d_sum || !d_coeffs || (!d_lin && ncoords) || ncoords < 0 || w < 1 || h < 1 || channels < 1) return bad("bad arguments");
+	if (!ncoords) return 0;
+	hipStream_t s = (hipStream_t)stream;
+	float *tab = nullptr;
+	if (hipMallocAsync((void **)&tab, sizeof(float) * (size_t)ncoords * (w + h), s) != hipSuccess) return bad("hipMallocAsync failed");
+	float *by = tab, *bx = tab + (size_t)ncoords * h;
+	hipLaunchKernelGGL(pruned_basis_kernel, dim3(grid_for((size_t)ncoords * (w + h))), dim3(256), 0, s, by, bx, d_lin, ncoords, w, h);
+	hipLaunchKernelGGL(pruned_accumulate_kernel, dim3(grid_for((size_t)w * h * channels)), dim3(256), 0, s, d_sum, d_coeffs, d_lin, by, bx, ncoords, w, h, channels);
+	(void)hipFreeAsync(tab, s);
 	return hipGetLastError() == hipSuccess ? 0 : -4;
 }

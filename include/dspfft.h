@@ -161,6 +161,12 @@ int dspfft_ispec_decode(float *d_f, size_t npixels, int channels, double gain, i
 int dspfft_motion_filter(float *d_coeffs, const int active[3], const int minbuf_hw[2], const int band_begin[3], const int band_end[3],
                          float damp, float boost, float threshold_lo, float threshold_hi, int preserve_dc, float grey_add,
                          float quantizer, unsigned long long *d_coeffs_coded, void *hip_stream);
+/* scan/scan.c:20-41,449 (pruned_idct) fused with the accumulate of :451-459:
+ *   sum[y][x][z] += sum_n coeffs[lin[n]][z] * B_h[y][cy_n] * B_w[x][cx_n],  B_N[k][j] = j ? 2 cos(pi j (k+1/2)/N) : 1
+ * for the `ncoords` coefficients (device list of y*w+x offsets) one output frame adds.  The reference takes this path
+ * when step * max_interval <= log2(w*h) (scan.c:349-350).  The caller leaves the DC pixel out of the list (scan.c:445). */
+int dspfft_scan_pruned_accumulate(float *d_sum, const float *d_coeffs, const uint32_t *d_lin, int ncoords,
+                                  int w, int h, int channels, void *hip_stream);
 const char *dspfft_pointwise_last_error(void);
 
 #ifdef __cplusplus

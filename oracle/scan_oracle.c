@@ -160,3 +160,21 @@ size_t oracle_interval_diagonal(void *o, size_t w, size_t h, size_t i)
 	if (i < hi) return lo;
 	return lo - (i - hi) - 1;
 }
+
+/* scan/scan.c:20-41 (generate_basis_matrix + pruned_idct) followed by the accumulate of :451-459, in the reference's
+ * precisions (coeff = float storage, basis computed in double and stored as float) */
+void oracle_scan_pruned_accumulate_f32(float *sum, const float *coeffs, const uint64_t *lin, size_t ncoords, int w, int h, int c)
+{
+	float *by = malloc(sizeof(float) * (size_t)h * h), *bx = malloc(sizeof(float) * (size_t)w * w);
+	for (int k = 0; k < h; k++) { by[(size_t)k * h] = 1; for (int j = 1; j < h; j++) by[(size_t)k * h + j] = 2. * cos(M_PI * j * (k + 0.5) / h); }
+	for (int k = 0; k < w; k++) { bx[(size_t)k * w] = 1; for (int j = 1; j < w; j++) bx[(size_t)k * w + j] = 2. * cos(M_PI * j * (k + 0.5) / w); }
+	float *image = calloc((size_t)w * h * c, sizeof(float));
+	if (ncoords) {
+		for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) for (int z = 0; z < c; z++)
+			image[((size_t)y * w + x) * c + z] = coeffs[lin[0] * c + z] * by[(size_t)y * h + lin[0] / w] * bx[(size_t)x * w + lin[0] % w];
+		for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) for (size_t n = 1; n < ncoords; n++) for (int z = 0; z < c; z++)
+			image[((size_t)y * w + x) * c + z] += coeffs[lin[n] * c + z] * by[(size_t)y * h + lin[n] / w] * bx[(size_t)x * w + lin[n] % w];
+	}
+	for (size_t i = 0; i < (size_t)w * h * c; i++) sum[i] += image[i];
+	free(by); free(bx); free(image);
+}

@@ -470,3 +470,37 @@ def test_motion_filter_vs_oracle(gpu, cfg):
     assert np.array_equal(d.cpu().numpy(), ref)
     if cfg.get("quant"):
         assert int(coded[0]) == n
+
+
+def test_scan_pruned_idct_path(gpu):
+    """scan.c:20-41,449: few coefficients per frame -> direct rank-1 sums; against the restatement and against the
+    transform path (dspfft_execute_masked_accumulate) on the same frames"""
+    import ctypes as C
+    from dspfun_amd import _lib, REDFT10, REDFT01
+    L = _lib.load()
+    w, h, c = 96, 54, 3
+    x = ol.synth_f32(123, w * h * c).reshape(h, w, c)
+    coeffs = dev(gpu, x)
+    plan_image(h, w, c, REDFT10).set_scale(1.0 / (4.0 * w * h)).execute(coeffs.data_ptr())
+    gpu.cuda.synchronize()
+    ch = coeffs.cpu().numpy()
+    zz = ol.zigzag_order(w, h)
+    step = 12                                        # 12 <= log2(96*54) = 12.3 -> the reference would prune (scan.c:349-350)
+    order = dev(gpu, zz.astype(np.uint32).view(np.int32))
+    total = gpu.zeros_like(coeffs); total2 = gpu.zeros_like(coeffs); work = gpu.empty_like(coeffs)
+    ids = gpu.zeros(w * h, dtype=gpu.int32, device="cuda:0")
+    assert L.dspfft_scan_zigzag_frame_ids(ids.data_ptr(), w, h, step, None) == 0
+    inv = plan_image(h, w, c, REDFT01)
+    ref = np.zeros_like(ch)
+    O = ol.lib()
+    O.oracle_scan_pruned_accumulate_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int]
+    for f in range(6):
+        first = f * step + (1 if f == 0 else 0)       # frame 0 skips the DC index (scan.c:445)
+        cnt = (f + 1) * step - first
+        assert L.dspfft_scan_pruned_accumulate(total.data_ptr(), coeffs.data_ptr(), order.data_ptr() + 4 * first, cnt, w, h, c, None) == 0
+        inv.execute_masked_accumulate(coeffs.data_ptr(), work.data_ptr(), total2.data_ptr(), ids.data_ptr(), f, c)
+        lin = np.ascontiguousarray(zz[first:first + cnt])
+        O.oracle_scan_pruned_accumulate_f32(ref.ctypes.data, ch.ctypes.data, lin.ctypes.data, cnt, w, h, c)
+        gpu.cuda.synchronize()
+        assert np.abs(total.cpu().numpy() - ref).max() <= 2e-6
+        assert float((total - total2).abs().max()) <= 5e-6
