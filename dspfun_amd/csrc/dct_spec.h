@@ -270,7 +270,9 @@ struct RowSpec {
 			last_write(planes, st, tid);
 		} else {
 			if constexpr (KIND == KIND_REDFT10) {
-				tloop<L / 2 + 1, T>(tid, [&](int k) {
+				static_for<0, K_ROUNDS>([&](auto ri) {
+					const int k = tid + ri * T;
+					if (!((ri + 1) * T <= L / 2 + 1 || k <= L / 2)) return;
 					const int km = k ? L - k : 0;
 					const cf tk = a.T[k];
 					const cf tlk = cmul(cconj(tk), cmk(0.70710678118654752f, -0.70710678118654752f));
@@ -340,11 +342,18 @@ struct ColSpec {
 	template <int KIND> struct State {
 		cf xa[LAST_ROUNDS * RL], xb[LAST_ROUNDS * RL];
 		float4 pre[KIND == KIND_REDFT10 ? Y_ROUNDS : 2 * K_ROUNDS];
+		cf tw[KIND == KIND_REDFT01 ? K_ROUNDS : 1];   // REDFT01: T[k] of this thread's items, fetched with the data (measured: -5 us);
+		                                              // REDFT10 loads T[k] where it is used (prefetching it there measured slower)
 	};
 
 	template <int KIND, class ST>
 	static DSP_HD void prefetch(const PassArgs &a, long long bin, int tid, ST &st)
 	{
+		if constexpr (KIND == KIND_REDFT01)
+			static_for<0, K_ROUNDS>([&](auto i) {
+				const int it = tid + i * T;
+				if ((i + 1) * T <= (N / 2 + 1) * NP || it < (N / 2 + 1) * NP) st.tw[i] = a.T[it / NP];
+			});
 		if constexpr (KIND == KIND_REDFT10) {
 			static_for<0, Y_ROUNDS>([&](auto i) {
 				const int it = tid + i * T;
@@ -457,7 +466,7 @@ struct ColSpec {
 						const int km = k ? N - k : 0;
 						float4 xk = st.pre[2 * i], xm = st.pre[2 * i + 1];
 						if (k == 0) { xk.x *= a.in_scale0; xk.y *= a.in_scale0; xk.z *= a.in_scale0; xk.w *= a.in_scale0; xm.x = xm.y = xm.z = xm.w = 0.f; }
-						const cf t = a.T[k];
+						const cf t = st.tw[i];
 						const cf Va0 = cmulc(cmk(xk.x, -xm.x), t), Vb0 = cmulc(cmk(xk.y, -xm.y), t);
 						const cf Va1 = cmulc(cmk(xk.z, -xm.z), t), Vb1 = cmulc(cmk(xk.w, -xm.w), t);
 						float4 lo, hi;
@@ -476,7 +485,9 @@ struct ColSpec {
 			last_write(buf, st, tid);
 		} else {
 			if constexpr (KIND == KIND_REDFT10) {
-				tloop<(N / 2 + 1) * NP, T>(tid, [&](int it) {
+				static_for<0, K_ROUNDS>([&](auto ri) {
+					const int it = tid + ri * T;
+					if (!((ri + 1) * T <= (N / 2 + 1) * NP || it < (N / 2 + 1) * NP)) return;
 					const int k = it / NP, jp = it - k * NP;
 					const int km = k ? N - k : 0;
 					const float4 zk = buf[k * NP + jp], zm = buf[km * NP + jp];
