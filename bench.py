@@ -104,6 +104,7 @@ def main():
     inv = Plan.image(H, W, C, REDFT01).set_scale(1.0 / (4.0 * W * H))
     frames = synth_frames(torch, args.frames, dev)
     ref0 = frames[0].clone()
+    torch.cuda.synchronize()          # the frames are used on other streams from here on
     stream = torch.cuda.current_stream().cuda_stream
     ptrs = [frames[f].data_ptr() for f in range(args.frames)]
 
