@@ -220,8 +220,7 @@ int launch_row_spec(const PassArgs &a, int nwork, void *stream)
 {
 	static int lds_ok = allow_lds(row_spec_kernel<S, KIND>, S::LDS);
 	if (lds_ok) return lds_ok;
-	PassArgs b = a; b.nwork = nwork;
-	hipLaunchKernelGGL((row_spec_kernel<S, KIND>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, b);
+	hipLaunchKernelGGL((row_spec_kernel<S, KIND>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a);
 	HIPCHK(hipGetLastError());
 	return 0;
 }
@@ -230,8 +229,7 @@ int launch_col_spec(const PassArgs &a, int nwork, void *stream)
 {
 	static int lds_ok = allow_lds(col_spec_kernel<S, KIND>, S::LDS);
 	if (lds_ok) return lds_ok;
-	PassArgs b = a; b.nwork = nwork;
-	hipLaunchKernelGGL((col_spec_kernel<S, KIND>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, b);
+	hipLaunchKernelGGL((col_spec_kernel<S, KIND>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a);
 	HIPCHK(hipGetLastError());
 	return 0;
 }

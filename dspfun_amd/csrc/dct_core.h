@@ -63,7 +63,6 @@ struct PassArgs {
 	int B;            // complex columns per tile = K/2
 	int ninner;       // extent of the inner contiguous dimension
 	int ntiles;       // ceil(ninner / K)
-	int nwork;        // spec kernels: total lines (ROW) / tiles (COL) of the launch; workgroups stride over them
 	long long es_in, es_out;   // stride (elements) between consecutive samples of the axis (COL)
 	// batch dimensions (two levels) -- line/tile base = i0*sb0 + i1*sb1
 	int nb0, nb1;

@@ -519,252 +519,4 @@ struct ColSpec {
 	}
 };
 
-// =================================================================================================
-// COL pass with an OUTER radix-2 split: N = 2H.  The first decimation-in-frequency butterfly runs on the
-// way in from global memory: sums (-> even outputs) go to LDS, twiddled differences (-> odd outputs)
-// wait in registers; the H-point FFT + post-processing then runs twice in the SAME half-size LDS tile.
-// LDS per tile is H x K/2 complex, so a 2160-row tile can be K = 16 floats (64-B row segments, the
-// efficient width for the memory system) in the 69 KB that previously held K = 8.
-// Pairs (k, N-k) of the DCT post-processing have equal parity, so they never straddle the two halves.
-template <int N_, int K_, int T_, int... Rs>
-struct ColSplit2 {
-	static constexpr int N = N_, H = N_ / 2, K = K_, T = T_, B = K_ / 2, NP = K_ / 4, NS = (int)sizeof...(Rs);
-	static constexpr int NIN = NS + 1;                 // phases of one inner FFT: NS-1 stages, last_read, last_write
-	static constexpr int NPH = 2 * NIN + 4;            // load | inner A | post A | unhold B | inner B | post B
-	// two workgroups per CU need <= 128 VGPRs at 512 threads; the kernel wants ~139, so ask for 4 waves/SIMD
-	static constexpr int WPE = (T_ >= 512) ? 4 : 1;
-	static_assert((1 * ... * Rs) == H, "radices must multiply to N/2");
-	static_assert(N % 4 == 0 && K % 4 == 0 && NS >= 1, "ColSplit2 needs N % 4 == 0");
-	static constexpr int R0 = pack_get<0, Rs...>(), RL = pack_get<NS - 1, Rs...>();
-	static constexpr int SB = H / R0, PADC = (NS >= 2) ? 1 : 0;
-	static constexpr int ROWS = H + R0 * PADC;
-	static constexpr size_t LDS = (size_t)ROWS * B * 8;
-	static constexpr int NBL = H / RL;
-	static constexpr int LAST_ROUNDS = (NBL * NP + T - 1) / T;
-	static constexpr int M_ROUNDS = (H * NP + T - 1) / T;               // REDFT10: outer butterflies per thread
-	static constexpr int Q_ROUNDS = ((H / 2 + 1) * NP + T - 1) / T;     // REDFT01: quads per thread (two butterflies each)
-	template <int KIND> struct State {
-		cf xa[LAST_ROUNDS * RL], xb[LAST_ROUNDS * RL];
-		float4 hold[KIND == KIND_REDFT10 ? M_ROUNDS : 2 * Q_ROUNDS];     // the odd half, waiting for its turn in LDS
-		long long bin;
-	};
-
-	static DSP_HD int padded(int n) { return n + (n / SB) * PADC; }
-	static DSP_HD void base(const PassArgs &a, int work, long long &bin, long long &bout)
-	{
-		const int bt = work / a.ntiles, t0 = work - bt * a.ntiles;
-		const int t = xcd_remap(t0, a.ntiles);
-		const int i1 = bt / a.nb0, i0 = bt - i1 * a.nb0;
-		bin = i0 * a.sb0_in + i1 * a.sb1_in + (long long)t * K;
-		bout = i0 * a.sb0_out + i1 * a.sb1_out + (long long)t * K;
-	}
-	static DSP_HD float4 f4(cf a, cf b) { float4 v; v.x = a.x; v.y = a.y; v.z = b.x; v.w = b.y; return v; }
-	static DSP_HD float4 add4(float4 a, float4 b) { float4 v; v.x = a.x + b.x; v.y = a.y + b.y; v.z = a.z + b.z; v.w = a.w + b.w; return v; }
-	static DSP_HD float4 sub4(float4 a, float4 b) { float4 v; v.x = a.x - b.x; v.y = a.y - b.y; v.z = a.z - b.z; v.w = a.w - b.w; return v; }
-	static DSP_HD float4 mulw4(float4 a, cf w) { const cf p = cmul(cmk(a.x, a.y), w), q = cmul(cmk(a.z, a.w), w); return f4(p, q); }
-
-	// loads happen inside phase 0, a few rounds at a time, so at most 4 float4 per lane are in flight
-	// (holding the whole tile's loads in registers next to `hold` cost a resident workgroup per CU)
-	template <int KIND, class ST>
-	static DSP_HD void prefetch(const PassArgs &, long long bin, int, ST &st) { st.bin = bin; }
-
-	// conj-spectrum entries built from rows k and N-k (see ColSpec phase 0, REDFT01):  lo = buf[k], hi = buf[N-k]
-	static DSP_HD void pre3_pair(const PassArgs &a, int k, float4 xk, float4 xm, float4 &lo, float4 &hi)
-	{
-		if (k == 0) { xk.x *= a.in_scale0; xk.y *= a.in_scale0; xk.z *= a.in_scale0; xk.w *= a.in_scale0; xm.x = xm.y = xm.z = xm.w = 0.f; }
-		const cf t = a.T[k];
-		const cf Va0 = cmulc(cmk(xk.x, -xm.x), t), Vb0 = cmulc(cmk(xk.y, -xm.y), t);
-		const cf Va1 = cmulc(cmk(xk.z, -xm.z), t), Vb1 = cmulc(cmk(xk.w, -xm.w), t);
-		lo.x = Va0.x - Vb0.y; lo.y = -Va0.y - Vb0.x; lo.z = Va1.x - Vb1.y; lo.w = -Va1.y - Vb1.x;
-		hi.x = Va0.x + Vb0.y; hi.y = Va0.y - Vb0.x; hi.z = Va1.x + Vb1.y; hi.w = Va1.y - Vb1.x;
-	}
-
-	template <int I>
-	static DSP_HD void stage(const PassArgs &a, float4 *buf, int tid)
-	{
-		constexpr int R = pack_get<I, Rs...>(), Lc = pack_lc<I, Rs...>(), M1 = Lc / R, NB = H / R, TW = H / Lc;
-		tloop<NB * NP, T>(tid, [&](int it) {
-			const int q = it / NP, jp = it - q * NP;
-			const int blk = q / M1, m = q - blk * M1;
-			float4 *p;
-			int stride;
-			if constexpr (I == 0) { p = buf + m * NP + jp; stride = (SB + PADC) * NP; }
-			else { p = buf + (padded(blk * Lc) + m) * NP + jp; stride = M1 * NP; }
-			cf xa[R], xb[R];
-			static_for<0, R>([&](auto r) { const float4 v = p[r * stride]; xa[r] = cmk(v.x, v.y); xb[r] = cmk(v.z, v.w); });
-			Dft<R>::run(xa);
-			Dft<R>::run(xb);
-			if constexpr (M1 > 1) {
-				cf w[R];
-				w[1] = a.W[2 * (m * TW)];          // w_H^e = w_N^{2e}: the table holds w_N
-				static_for<2, R>([&](auto r) { if constexpr (r % 2 == 0) w[r] = csqr(w[r / 2]); else w[r] = cmul(w[r / 2], w[r - r / 2]); });
-				static_for<1, R>([&](auto r) { xa[r] = cmul(xa[r], w[r]); xb[r] = cmul(xb[r], w[r]); });
-			}
-			static_for<0, R>([&](auto r) { p[r * stride] = f4(xa[r], xb[r]); });
-		});
-	}
-	template <class ST>
-	static DSP_HD void last_read(const float4 *buf, ST &st, int tid)
-	{
-		static_for<0, LAST_ROUNDS>([&](auto i) {
-			const int it = tid + i * T;
-			if (it < NBL * NP) {
-				const int kb = it / NP, jp = it - kb * NP;
-				int blk;
-				if constexpr (NS >= 2) blk = PosCalcFirst<NBL, NS - 1, Rs..., 1>::run(kb); else blk = 0;
-				const float4 *p = buf + (NS >= 2 ? padded(blk * RL) : 0) * NP + jp;
-				static_for<0, RL>([&](auto r) { const float4 v = p[r * NP]; st.xa[i * RL + r] = cmk(v.x, v.y); st.xb[i * RL + r] = cmk(v.z, v.w); });
-				Dft<RL>::run(&st.xa[i * RL]);
-				Dft<RL>::run(&st.xb[i * RL]);
-			}
-		});
-	}
-	template <class ST>
-	static DSP_HD void last_write(float4 *buf, const ST &st, int tid)
-	{
-		static_for<0, LAST_ROUNDS>([&](auto i) {
-			const int it = tid + i * T;
-			if (it < NBL * NP) {
-				const int kb = it / NP, jp = it - kb * NP;
-				float4 *p = buf + kb * NP + jp;
-				static_for<0, RL>([&](auto r) { p[r * NBL * NP] = f4(st.xa[i * RL + r], st.xb[i * RL + r]); });
-			}
-		});
-	}
-	template <int PHI, class ST>   // PHI = 0 .. NIN-1
-	static DSP_HD void inner(const PassArgs &a, float4 *buf, int tid, ST &st)
-	{
-		if constexpr (PHI < NS - 1) stage<PHI>(a, buf, tid);
-		else if constexpr (PHI == NS - 1) last_read(buf, st, tid);
-		else last_write(buf, st, tid);
-	}
-
-	// post-processing of one half (natural order in LDS).  PAR = 0: outputs k = 2q, PAR = 1: k = 2q+1.
-	template <int KIND, int PAR>
-	static DSP_HD void post(const PassArgs &a, const float4 *buf, long long bout, int tid)
-	{
-		if constexpr (KIND == KIND_REDFT10) {
-			// pairs (k, N-k): PAR 0: q <-> H-q (q in 0..H/2);  PAR 1: q <-> H-1-q (q in 0..H/2-1)
-			constexpr int NQ = PAR == 0 ? H / 2 + 1 : H / 2;
-			tloop<NQ * NP, T>(tid, [&](int it) {
-				const int q = it / NP, jp = it - q * NP;
-				const int qm = PAR == 0 ? (q ? H - q : 0) : H - 1 - q;
-				const int k = 2 * q + PAR, km = PAR == 0 ? (q ? N - k : 0) : N - k;
-				const float4 zk = buf[q * NP + jp], zm = buf[qm * NP + jp];
-				const cf t = a.T[k];
-				const cf A0 = cmk(zk.x + zm.x, zk.y - zm.y), B0 = cmul_mi(cmk(zk.x - zm.x, zk.y + zm.y));
-				const cf A1 = cmk(zk.z + zm.z, zk.w - zm.w), B1 = cmul_mi(cmk(zk.z - zm.z, zk.w + zm.w));
-				const cf wa0 = cmul(t, A0), wb0 = cmul(t, B0), wa1 = cmul(t, A1), wb1 = cmul(t, B1);
-				const float sc = a.scale, s0 = (k == 0) ? sc * a.out_scale0 : sc;
-				const long long o = bout + 4 * jp;
-				float4 r0; r0.x = wa0.x * s0; r0.y = wb0.x * s0; r0.z = wa1.x * s0; r0.w = wb1.x * s0;
-				store4_a(a, o + (long long)k * a.es_out, r0);
-				if (k > 0 && km != k) {
-					float4 r1; r1.x = -wa0.y * sc; r1.y = -wb0.y * sc; r1.z = -wa1.y * sc; r1.w = -wb1.y * sc;
-					store4_a(a, o + (long long)km * a.es_out, r1);
-				}
-			});
-		} else {
-			tloop<H * NP, T>(tid, [&](int it) {
-				const int q = it / NP, jp = it - q * NP;
-				const float4 F = buf[q * NP + jp];
-				const int y = makhoul_src(2 * q + PAR, N);
-				const float sc = (y == 0) ? a.scale * a.out_scale0 : a.scale;
-				float4 r; r.x = F.x * sc; r.y = -F.y * sc; r.z = F.z * sc; r.w = -F.w * sc;
-				store4_a(a, bout + (long long)y * a.es_out + 4 * jp, r);
-			});
-		}
-	}
-
-	template <int KIND, int PH, class ST>
-	static DSP_HD void phase(const PassArgs &a, float4 *buf, long long bout, int tid, ST &st)
-	{
-		if constexpr (PH == 0) {
-			const long long bin = st.bin;
-			if constexpr (KIND == KIND_REDFT10) {
-				constexpr int CH = 2;                                  // rounds per load burst
-				static_for<0, (M_ROUNDS + CH - 1) / CH>([&](auto c) {
-					float4 x0[CH], x1[CH];
-					static_for<0, CH>([&](auto j) {
-						constexpr int i = c * CH + j;
-						if constexpr (i < M_ROUNDS) {
-							const int it = tid + i * T;
-							if ((i + 1) * T <= H * NP || it < H * NP) {
-								const int m = it / NP, jp = it - m * NP;
-								// reordered samples n = m and n = m + H live in rows 2m and N-1-2m
-								x0[j] = load4_m(a, bin + (long long)(2 * m) * a.es_in + 4 * jp);
-								x1[j] = load4_m(a, bin + (long long)(N - 1 - 2 * m) * a.es_in + 4 * jp);
-							}
-						}
-					});
-					static_for<0, CH>([&](auto j) {
-						constexpr int i = c * CH + j;
-						if constexpr (i < M_ROUNDS) {
-							const int it = tid + i * T;
-							if ((i + 1) * T <= H * NP || it < H * NP) {
-								const int m = it / NP, jp = it - m * NP;
-								float4 u = x0[j];
-								if (m == 0) { u.x *= a.in_scale0; u.y *= a.in_scale0; u.z *= a.in_scale0; u.w *= a.in_scale0; }   // row 0 is sample n = 0
-								buf[padded(m) * NP + jp] = add4(u, x1[j]);
-								st.hold[i] = mulw4(sub4(u, x1[j]), a.W[m]);
-								DSP_PIN4(st.hold[i]);
-							}
-						}
-					});
-					DSP_SCHED_FENCE();
-				});
-			} else {
-				static_for<0, Q_ROUNDS>([&](auto i) {
-					const int it = tid + i * T;
-					if ((i + 1) * T <= (H / 2 + 1) * NP || it < (H / 2 + 1) * NP) {
-						const int m = it / NP, jp = it - m * NP;
-						const long long p = bin + 4 * jp;
-						const float4 r0 = load4_m(a, p + (long long)m * a.es_in);
-						const float4 r1 = load4_m(a, p + (long long)(m ? N - m : 0) * a.es_in);
-						const float4 r2 = load4_m(a, p + (long long)(H - m) * a.es_in);
-						const float4 r3 = load4_m(a, p + (long long)(H + m) * a.es_in);
-						float4 lo_m, hi_m, lo_h, hi_h;
-						pre3_pair(a, m, r0, r1, lo_m, hi_m);          // buf[m], buf[N-m]
-						pre3_pair(a, H - m, r2, r3, lo_h, hi_h);      // buf[H-m], buf[H+m]
-						// butterfly j = m: buf[m] with buf[m+H];  butterfly j = H-m (m > 0): buf[H-m] with buf[N-m]
-						buf[padded(m) * NP + jp] = add4(lo_m, hi_h);
-						st.hold[2 * i] = mulw4(sub4(lo_m, hi_h), a.W[m]);
-						DSP_PIN4(st.hold[2 * i]);
-						if (m > 0 && 2 * m != H) {
-							buf[padded(H - m) * NP + jp] = add4(lo_h, hi_m);
-							st.hold[2 * i + 1] = mulw4(sub4(lo_h, hi_m), a.W[H - m]);
-						}
-						DSP_PIN4(st.hold[2 * i + 1]);
-					}
-					DSP_SCHED_FENCE();
-				});
-			}
-		} else if constexpr (PH <= NIN) {
-			inner<PH - 1>(a, buf, tid, st);
-		} else if constexpr (PH == NIN + 1) {
-			post<KIND, 0>(a, buf, bout, tid);
-		} else if constexpr (PH == NIN + 2) {
-			if constexpr (KIND == KIND_REDFT10) {
-				static_for<0, M_ROUNDS>([&](auto i) {
-					const int it = tid + i * T;
-					if ((i + 1) * T <= H * NP || it < H * NP) { const int m = it / NP, jp = it - m * NP; buf[padded(m) * NP + jp] = st.hold[i]; }
-				});
-			} else {
-				static_for<0, Q_ROUNDS>([&](auto i) {
-					const int it = tid + i * T;
-					if ((i + 1) * T <= (H / 2 + 1) * NP || it < (H / 2 + 1) * NP) {
-						const int m = it / NP, jp = it - m * NP;
-						buf[padded(m) * NP + jp] = st.hold[2 * i];
-						if (m > 0 && 2 * m != H) buf[padded(H - m) * NP + jp] = st.hold[2 * i + 1];
-					}
-				});
-			}
-		} else if constexpr (PH <= 2 * NIN + 2) {
-			inner<PH - (NIN + 3)>(a, buf, tid, st);
-		} else {
-			post<KIND, 1>(a, buf, bout, tid);
-		}
-	}
-};
-
 }  // namespace dspfft

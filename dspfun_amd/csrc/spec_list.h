@@ -14,13 +14,10 @@
 	X(1920, 1, 128, 4, 16, 15)         \
 	X(960, 1, 64, 2, 16, 15)
 
-// COL2 entries: X(N, K, THREADS, radices of N/2 ...) -- outer radix-2 split (ColSplit2), tried before COL.
-// (2160, K=16) was measured slower than the plain K=8 tile (57/68 vs 49/53 us) and is not listed.
-// None listed: on MI355X the split was measured SLOWER than the plain tiles at every size tried --
-// 2160 (K=16): 57/68 us vs 49/53 us; 4320 (K=8): 1242 vs 1226 us per 8K roundtrip; 1080 (K=32): 85 vs 66 us --
-// the held half costs ~40 VGPRs (one resident workgroup per CU) and doubles the barrier count, which
-// outweighs the wider row segments.  The code stays (CPU-emulation tested) as a documented negative result.
-#define DSPFFT_COL2_SPECS(X)
+// (An outer radix-2 column split -- half of the tile parked in registers so 2160-row tiles could be K = 16 wide in
+// the same 69 KB -- was built and measured SLOWER at every size tried: 2160 (K=16): 57/68 us vs 49/53 us; 4320 (K=8):
+// 1242 vs 1226 us per 8K roundtrip; 1080 (K=32): 85 vs 66 us.  The held half costs ~40 VGPRs, i.e. a resident
+// workgroup per CU, and doubles the barrier count.  Removed; see git history for `ColSplit2`.)
 
 #define DSPFFT_COL_SPECS(X)            \
 	X(2160, 8, 512, 12, 12, 15)        \

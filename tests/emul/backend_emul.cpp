@@ -76,57 +76,33 @@ int be_launch_dense(const DenseArgs &a, const LaunchGeom &g, void *)
 	return 0;
 }
 
-// persistent-workgroup control flow of backend_hip.hip, with a deliberately small grid so the
-// multi-iteration (prefetch) path is exercised
-static int emul_grid(int nwork) { const char *e = getenv("DSPFFT_EMUL_GRID"); int g = e ? atoi(e) : 3; return g < nwork ? g : nwork; }
-
+// one "workgroup" per line / tile, as in backend_hip.hip: prefetch (global loads into the per-thread State),
+// then the barrier-separated phases
 template <class S, int KIND>
-int launch_row_spec(const PassArgs &a0, int nwork, void *)
+int launch_row_spec(const PassArgs &a, int nwork, void *)
 {
-	PassArgs a = a0; a.nwork = nwork;
-	const int grid = emul_grid(nwork);
 	std::vector<unsigned char> lds(S::LDS + 16);
 	cf *planes = (cf *)lds.data();
-	for (int wg = 0; wg < grid; wg++) {
+	for (int wg = 0; wg < nwork; wg++) {
 		std::vector<typename S::template State<KIND>> st(S::T);
-		int work = wg;
 		long long bin, bout;
-		row_base(a, work, bin, bout);
+		row_base(a, wg, bin, bout);
 		for (int tid = 0; tid < S::T; tid++) S::template prefetch<KIND>(a, bin, tid, st[tid]);
-		for (;;) {
-			for (int tid = 0; tid < S::T; tid++) S::template phase<KIND, 0>(a, planes, bout, tid, st[tid]);
-			const int next = work + grid;
-			long long bin_next = 0, bout_next = 0;
-			if (next < nwork) { row_base(a, next, bin_next, bout_next); for (int tid = 0; tid < S::T; tid++) S::template prefetch<KIND>(a, bin_next, tid, st[tid]); }
-			static_for<1, S::NPH>([&](auto ph) { for (int tid = 0; tid < S::T; tid++) S::template phase<KIND, ph>(a, planes, bout, tid, st[tid]); });
-			if (next >= nwork) break;
-			work = next; bout = bout_next;
-		}
+		static_for<0, S::NPH>([&](auto ph) { for (int tid = 0; tid < S::T; tid++) S::template phase<KIND, ph>(a, planes, bout, tid, st[tid]); });
 	}
 	return 0;
 }
 template <class S, int KIND>
-int launch_col_spec(const PassArgs &a0, int nwork, void *)
+int launch_col_spec(const PassArgs &a, int nwork, void *)
 {
-	PassArgs a = a0; a.nwork = nwork;
-	const int grid = emul_grid(nwork);
 	std::vector<unsigned char> lds(S::LDS + 32);
 	float4 *buf = (float4 *)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
-	for (int wg = 0; wg < grid; wg++) {
+	for (int wg = 0; wg < nwork; wg++) {
 		std::vector<typename S::template State<KIND>> st(S::T);
-		int work = wg;
 		long long bin, bout;
-		S::base(a, work, bin, bout);
+		S::base(a, wg, bin, bout);
 		for (int tid = 0; tid < S::T; tid++) S::template prefetch<KIND>(a, bin, tid, st[tid]);
-		for (;;) {
-			for (int tid = 0; tid < S::T; tid++) S::template phase<KIND, 0>(a, buf, bout, tid, st[tid]);
-			const int next = work + grid;
-			long long bin_next = 0, bout_next = 0;
-			if (next < nwork) { S::base(a, next, bin_next, bout_next); for (int tid = 0; tid < S::T; tid++) S::template prefetch<KIND>(a, bin_next, tid, st[tid]); }
-			static_for<1, S::NPH>([&](auto ph) { for (int tid = 0; tid < S::T; tid++) S::template phase<KIND, ph>(a, buf, bout, tid, st[tid]); });
-			if (next >= nwork) break;
-			work = next; bout = bout_next;
-		}
+		static_for<0, S::NPH>([&](auto ph) { for (int tid = 0; tid < S::T; tid++) S::template phase<KIND, ph>(a, buf, bout, tid, st[tid]); });
 	}
 	return 0;
 }

@@ -90,13 +90,14 @@ static void run_row(const char *name)
 	PassArgs a; memset((void *)&a, 0, sizeof a);
 	a.in = g_frame; a.out = g_frame; a.N = S::N; a.kind = KIND; a.C = S::C; a.nb0 = H; a.nb1 = g_frames; a.sb0_in = a.sb0_out = (long long)W * C;
 	a.sb1_in = a.sb1_out = (long long)H * W * C;
-	a.T = tb.T; a.W = tb.Wt; a.scale = 1.f / 7680.f; a.in_scale0 = a.out_scale0 = 1.f; a.nwork = H * g_frames;
+	a.T = tb.T; a.W = tb.Wt; a.scale = 1.f / 7680.f; a.in_scale0 = a.out_scale0 = 1.f;
+	const int NWORK = H * g_frames;
 	CHK(hipFuncSetAttribute((const void *)row_k<S, KIND, ABL, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS));
 	int occ = 0; CHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)row_k<S, KIND, ABL, WPE>, S::T, S::LDS));
 	printf("%-40s kind=%d abl=%d wpe=%d occ=%d |", name, KIND, ABL, WPE, occ);
 	for (int wpc : {0}) {
 		{ int sg = wpc; CHK(hipMemcpyToSymbol(HIP_SYMBOL(g_stagger), &sg, sizeof sg)); }
-		int grid = a.nwork;
+		int grid = NWORK;
 		double us = time_us([&] { hipLaunchKernelGGL((row_k<S, KIND, ABL, WPE>), dim3(grid), dim3(S::T), S::LDS, 0, a); }) / g_frames;
 		printf(" stg%d:%6.1fus", wpc, us);
 	}
@@ -109,13 +110,14 @@ static void run_col(const char *name)
 	PassArgs a; memset((void *)&a, 0, sizeof a);
 	a.in = g_frame; a.out = g_frame; a.N = S::N; a.kind = KIND; a.K = S::K; a.B = S::B; a.ninner = W * C; a.ntiles = W * C / S::K;
 	a.es_in = a.es_out = (long long)W * C; a.nb0 = g_frames; a.nb1 = 1; a.sb0_in = a.sb0_out = (long long)H * W * C;
-	a.T = tb.T; a.W = tb.Wt; a.scale = 1.f / 4320.f; a.in_scale0 = a.out_scale0 = 1.f; a.nwork = a.ntiles * g_frames;
+	a.T = tb.T; a.W = tb.Wt; a.scale = 1.f / 4320.f; a.in_scale0 = a.out_scale0 = 1.f;
+	const int NWORK = a.ntiles * g_frames;
 	CHK(hipFuncSetAttribute((const void *)col_k<S, KIND, ABL, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS));
 	int occ = 0; CHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)col_k<S, KIND, ABL, WPE>, S::T, S::LDS));
 	printf("%-40s kind=%d abl=%d wpe=%d occ=%d |", name, KIND, ABL, WPE, occ);
 	for (int wpc : {0}) {
 		{ int sg = wpc; CHK(hipMemcpyToSymbol(HIP_SYMBOL(g_stagger), &sg, sizeof sg)); }
-		int grid = a.nwork;
+		int grid = NWORK;
 		double us = time_us([&] { hipLaunchKernelGGL((col_k<S, KIND, ABL, WPE>), dim3(grid), dim3(S::T), S::LDS, 0, a); }) / g_frames;
 		printf(" stg%d:%6.1fus", wpc, us);
 	}
@@ -127,9 +129,6 @@ static void run_col(const char *name)
 #define ROW3(T, WPE, ...) run_row<RowSpec<3840, 3, T, __VA_ARGS__>, KIND_REDFT01, 0, WPE>("ROW T=" #T " R=" #__VA_ARGS__)
 #define COL(K, T, WPE, ...) run_col<ColSpec<2160, K, T, __VA_ARGS__>, KIND_REDFT10, 0, WPE>("COL K=" #K " T=" #T " R=" #__VA_ARGS__)
 #define COLA(K, T, WPE, ...) run_col<ColSpec<2160, K, T, __VA_ARGS__>, KIND_REDFT10, 1, WPE>("COL K=" #K " T=" #T " R=" #__VA_ARGS__)
-#define COL2(K, T, WPE, ...) run_col<ColSplit2<2160, K, T, __VA_ARGS__>, KIND_REDFT10, 0, WPE>("COL2 K=" #K " T=" #T " R=" #__VA_ARGS__)
-#define COL2A(K, T, WPE, ...) run_col<ColSplit2<2160, K, T, __VA_ARGS__>, KIND_REDFT10, 1, WPE>("COL2 K=" #K " T=" #T " R=" #__VA_ARGS__)
-#define COL23(K, T, WPE, ...) run_col<ColSplit2<2160, K, T, __VA_ARGS__>, KIND_REDFT01, 0, WPE>("COL2 K=" #K " T=" #T " R=" #__VA_ARGS__)
 #define COL3A(K, T, WPE, ...) run_col<ColSpec<2160, K, T, __VA_ARGS__>, KIND_REDFT01, 1, WPE>("COL K=" #K " T=" #T " R=" #__VA_ARGS__)
 #define ROW3A(T, WPE, ...) run_row<RowSpec<3840, 3, T, __VA_ARGS__>, KIND_REDFT01, 1, WPE>("ROW T=" #T " R=" #__VA_ARGS__)
 #define COL3(K, T, WPE, ...) run_col<ColSpec<2160, K, T, __VA_ARGS__>, KIND_REDFT01, 0, WPE>("COL K=" #K " T=" #T " R=" #__VA_ARGS__)
