@@ -96,3 +96,70 @@ class SlabDCT3D:
         x = self._to_frames(coeffs)
         self.inv_yx.execute(x.data_ptr(), stream=self._stream(x))
         return x
+
+
+class ChannelShardedScan:
+    """BASELINE config 4's multi-GPU layout: scan's progressive reconstruction (scan/scan.c:292-298,377-383,421-459)
+    with the colour planes of the interleaved image spread over the ranks (plane z on rank z % G; a rank may own
+    several planes or none).  Planes are independent, so there is NO collective in the frame loop; `gather()` uses
+    one all_gather to rebuild the interleaved sum on every rank (e.g. to encode the output frame).
+
+    Each rank holds its planes planar ([h][w] f32): forward REDFT10^2 with the 1/(4wh) normalisation fused, zigzag
+    frame ids, then per output frame one fused masked-accumulate execution (or the pruned path for tiny steps)."""
+
+    def __init__(self, image_hwc, step, group=None, lib=None):
+        from . import _lib
+        self.lib = lib or _lib.load()
+        self.group = group
+        self.G = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.h, self.w, self.c = image_hwc.shape
+        self.step = int(step)
+        self.nframes = (self.w * self.h + self.step - 1) // self.step          # scan.c:347-348 with limit = w*h
+        self.mine = [z for z in range(self.c) if z % self.G == self.rank]
+        dev = image_hwc.device
+        self.coeffs = [image_hwc[:, :, z].contiguous().clone() for z in self.mine]
+        self.fwd = Plan.many_r2r([self.h, self.w], [REDFT10] * 2, lib=lib).set_scale(1.0 / (4.0 * self.w * self.h))
+        self.inv = Plan.many_r2r([self.h, self.w], [REDFT01] * 2, lib=lib)
+        self.ids = torch.zeros(self.w * self.h, dtype=torch.int32, device=dev)
+        self._check(self.lib.dspfft_scan_zigzag_frame_ids(self.ids.data_ptr(), self.w, self.h, self.step, None))
+        self.work = torch.empty((self.h, self.w), dtype=torch.float32, device=dev)
+        self.sums = []
+        for cz in self.coeffs:
+            self.fwd.execute(cz.data_ptr(), stream=SlabDCT3D._stream(cz))
+            s = torch.empty_like(cz)
+            self._check(self.lib.dspfft_broadcast_dc(s.data_ptr(), cz.data_ptr(), self.w * self.h, 1, None))   # scan.c:377-383
+            self.sums.append(s)
+        self.frame = 0
+
+    def _check(self, rc):
+        if rc:
+            raise RuntimeError(self.lib.dspfft_last_error().decode())
+
+    def next_frame(self):
+        """adds the coefficients of output frame `self.frame` into this rank's running sums"""
+        if self.frame >= self.nframes:
+            return False
+        for cz, s in zip(self.coeffs, self.sums):
+            self.inv.execute_masked_accumulate(cz.data_ptr(), self.work.data_ptr(), s.data_ptr(), self.ids.data_ptr(), self.frame, 1,
+                                               stream=SlabDCT3D._stream(cz))
+        self.frame += 1
+        return True
+
+    def gather(self):
+        """interleaved (h, w, c) running sum on every rank"""
+        dev = self.ids.device
+        out = torch.empty((self.h, self.w, self.c), dtype=torch.float32, device=dev)
+        if self.G == 1:
+            for z, s in zip(self.mine, self.sums):
+                out[:, :, z] = s
+            return out
+        per = (self.c + self.G - 1) // self.G
+        send = torch.zeros((per, self.h, self.w), dtype=torch.float32, device=dev)
+        for i, s in enumerate(self.sums):
+            send[i] = s
+        recv = [torch.empty_like(send) for _ in range(self.G)]
+        dist.all_gather(recv, send, group=self.group)
+        for z in range(self.c):
+            out[:, :, z] = recv[z % self.G][z // self.G]
+        return out

@@ -76,3 +76,50 @@ def test_shard_range_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def _scan_worker(rank, world, port, h, w, step, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle_lib as ol
+        from emul_lib import emul
+        from dspfun_amd.dist import ChannelShardedScan
+        x = ol.synth_f32(0xD5F0004, h * w * 3).reshape(h, w, 3)
+        eng = ChannelShardedScan(torch.from_numpy(x.copy()), step, lib=emul())
+        # reference after 2 frames and at the end (f64 restatement on the interleaved image)
+        c64 = np.ascontiguousarray(ol.dct2d_interleaved(x.astype(np.float64), ol.REDFT10))
+        ol.lib().oracle_scan_normalise_f64(c64.ctypes.data, w, h, 3)
+        ref = np.ascontiguousarray(np.broadcast_to(c64[0, 0], (h, w, 3)).copy())
+        zz = ol.zigzag_order(w, h)
+        errs = []
+        k = 0
+        while eng.next_frame():
+            lin = np.ascontiguousarray(zz[k * step:(k + 1) * step])
+            ol.lib().oracle_scan_frame_f64(w, h, 3, c64.ctypes.data, lin.ctypes.data, lin.size, ref.ctypes.data)
+            k += 1
+            if k in (2, eng.nframes):
+                errs.append(float(np.abs(eng.gather().numpy() - ref).max()))
+        errs.append(float(np.abs(eng.gather().numpy() - x).max()))
+        q.put((rank, len(eng.mine), errs))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_channel_sharded_scan_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_scan_worker, args=(r, 2, port, 12, 20, 37, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(n for _, n, _ in res) == [1, 2]          # 3 planes over 2 ranks
+    for rank, _, errs in res:
+        assert max(errs) < 1e-5, (rank, errs)

@@ -387,6 +387,34 @@ def test_slab_dct3d_single_rank_matches_rank3_plan(gpu):
     assert float((back - x).abs().max()) < 1e-3
 
 
+def test_channel_sharded_scan_single_rank(gpu):
+    """config 4's channel-sharded layout (planar planes, dspfun_amd.dist.ChannelShardedScan) reconstructs the
+    same running sums as the interleaved path; world size 1 here, world 2 in tests/test_dist_cpu.py"""
+    from dspfun_amd.dist import ChannelShardedScan
+    w, h, c = 960, 540, 3
+    x = ol.synth_f32(0xD5F0004, w * h * c).reshape(h, w, c)
+    step = (w * h + 4) // 5
+    eng = ChannelShardedScan(dev(gpu, x), step)
+    assert eng.nframes == 5 and eng.mine == [0, 1, 2]
+    cf64 = np.ascontiguousarray(ol.dct2d_interleaved(x.astype(np.float64), 5, impl="port"))
+    ol.lib().oracle_scan_normalise_f64(cf64.ctypes.data, w, h, c)
+    ref = np.ascontiguousarray(np.broadcast_to(cf64[0, 0], (h, w, c)).copy())
+    zz = ol.zigzag_order(w, h)
+    k = 0
+    while eng.next_frame():
+        lin = np.ascontiguousarray(zz[k * step:(k + 1) * step])
+        if k < 2:      # the direct-sum restatement is O(points * w * h): check the first frames, then the total
+            frame_of = np.full(w * h, -2, dtype=np.int64)
+            frame_of[lin.astype(np.int64)] = k
+            frame_of[0] = -1
+            rec = np.where((frame_of.reshape(h, w) == k)[:, :, None], cf64, 0.0)
+            ref += ol.dct2d_interleaved(rec, 4, impl="port", threads=8)
+            assert np.abs(eng.gather().cpu().numpy() - ref).max() < 5e-6, k
+        k += 1
+    assert k == 5
+    assert np.abs(eng.gather().cpu().numpy() - x).max() <= 5e-6
+
+
 # ---- applybasis (SURVEY.md 8 row a8): basis x pixel partial sums on the f32 matrix cores ----
 @pytest.mark.parametrize("func", ["dft", "idft", "dct1", "dct2", "dct3", "dct4", "dst1", "dst2", "dst3", "dst4", "wht", "dht"])
 @pytest.mark.parametrize("w,h,terms,psum,off,ortho", [(16, 8, None, (16, 8), (0, 0), True), (16, 8, (5, 3), (4, 2), (1, 2), False), (32, 32, (8, 8), (1, 1), (0, 0), False)])
