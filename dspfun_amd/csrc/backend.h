@@ -23,6 +23,10 @@ const char *be_name();
 int be_launch_row(const PassArgs &a, const LaunchGeom &g, void *stream);
 int be_launch_col(const PassArgs &a, const LaunchGeom &g, void *stream);
 int be_launch_dense(const DenseArgs &a, const LaunchGeom &g, void *stream);
+// double-precision samples (the fftw_ API of spec's default build): generic kernels only
+int be_launch_row(const PassArgsD &a, const LaunchGeom &g, void *stream);
+int be_launch_col(const PassArgsD &a, const LaunchGeom &g, void *stream);
+int be_launch_dense(const DenseArgsD &a, const LaunchGeom &g, void *stream);
 
 // compile-time-specialised kernels (dct_spec.h / spec_list.h)
 struct SpecInfo { int id, nthr, P; size_t lds; };   // P = C (ROW) or K (COL)

@@ -16,12 +16,12 @@ namespace dspfft {
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 // ---------------------------------------------------------------------------------------------
-template <int KIND>
-__global__ void __launch_bounds__(256) row_kernel(const PassArgs a, const unsigned raw_bytes)
+template <int KIND, class R>
+__global__ void __launch_bounds__(256) row_kernel(const PassArgsT<R> a, const unsigned raw_bytes)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-	float *raw = reinterpret_cast<float *>(lds);
-	cf *buf = reinterpret_cast<cf *>(lds + raw_bytes);
+	R *raw = reinterpret_cast<R *>(lds);
+	cx<R> *buf = reinterpret_cast<cx<R> *>(lds + raw_bytes);
 	const int tid = threadIdx.x, nthr = blockDim.x, L = a.N / 2;
 	long long bin, bout;
 	row_base(a, blockIdx.x, bin, bout);
@@ -42,11 +42,11 @@ __global__ void __launch_bounds__(256) row_kernel(const PassArgs a, const unsign
 	row_store(a, raw, bout, tid, nthr);
 }
 
-template <int KIND>
-__global__ void __launch_bounds__(512) col_kernel(const PassArgs a)
+template <int KIND, class R>
+__global__ void __launch_bounds__(512) col_kernel(const PassArgsT<R> a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-	cf *buf = reinterpret_cast<cf *>(lds);
+	cx<R> *buf = reinterpret_cast<cx<R> *>(lds);
 	const int tid = threadIdx.x, nthr = blockDim.x;
 	long long bin, bout; int valid;
 	col_base(a, blockIdx.x, bin, bout, valid);
@@ -105,10 +105,11 @@ __global__ void __launch_bounds__(S::T, S::WPE) col_spec_kernel(const PassArgs a
 	});
 }
 
-__global__ void __launch_bounds__(256) dense_kernel(const DenseArgs a)
+template <class R>
+__global__ void __launch_bounds__(256) dense_kernel(const DenseArgsT<R> a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-	float *x = reinterpret_cast<float *>(lds);
+	R *x = reinterpret_cast<R *>(lds);
 	long long bin, bout;
 	dense_base(a, blockIdx.x, bin, bout);
 	dense_load(a, x, bin, threadIdx.x, blockDim.x);
@@ -179,41 +180,51 @@ static int allow_lds(K kernel, size_t bytes)
 	return 0;
 }
 
-int be_launch_row(const PassArgs &a, const LaunchGeom &g, void *stream)
+template <class R>
+static int launch_row(const PassArgsT<R> &a, const LaunchGeom &g, void *stream)
 {
 	hipStream_t s = (hipStream_t)stream;
 	if (a.kind == KIND_REDFT10) {
-		if (int rc = allow_lds(row_kernel<KIND_REDFT10>, g.lds_bytes)) return rc;
-		hipLaunchKernelGGL(row_kernel<KIND_REDFT10>, dim3(g.nwg), dim3(g.nthr), g.lds_bytes, s, a, (unsigned)g.raw_bytes);
+		if (int rc = allow_lds(row_kernel<KIND_REDFT10, R>, g.lds_bytes)) return rc;
+		hipLaunchKernelGGL((row_kernel<KIND_REDFT10, R>), dim3(g.nwg), dim3(g.nthr), g.lds_bytes, s, a, (unsigned)g.raw_bytes);
 	} else {
-		if (int rc = allow_lds(row_kernel<KIND_REDFT01>, g.lds_bytes)) return rc;
-		hipLaunchKernelGGL(row_kernel<KIND_REDFT01>, dim3(g.nwg), dim3(g.nthr), g.lds_bytes, s, a, (unsigned)g.raw_bytes);
+		if (int rc = allow_lds(row_kernel<KIND_REDFT01, R>, g.lds_bytes)) return rc;
+		hipLaunchKernelGGL((row_kernel<KIND_REDFT01, R>), dim3(g.nwg), dim3(g.nthr), g.lds_bytes, s, a, (unsigned)g.raw_bytes);
 	}
 	HIPCHK(hipGetLastError());
 	return 0;
 }
 
-int be_launch_col(const PassArgs &a, const LaunchGeom &g, void *stream)
+template <class R>
+static int launch_col(const PassArgsT<R> &a, const LaunchGeom &g, void *stream)
 {
 	hipStream_t s = (hipStream_t)stream;
 	if (a.kind == KIND_REDFT10) {
-		if (int rc = allow_lds(col_kernel<KIND_REDFT10>, g.lds_bytes)) return rc;
-		hipLaunchKernelGGL(col_kernel<KIND_REDFT10>, dim3(g.nwg), dim3(g.nthr), g.lds_bytes, s, a);
+		if (int rc = allow_lds(col_kernel<KIND_REDFT10, R>, g.lds_bytes)) return rc;
+		hipLaunchKernelGGL((col_kernel<KIND_REDFT10, R>), dim3(g.nwg), dim3(g.nthr), g.lds_bytes, s, a);
 	} else {
-		if (int rc = allow_lds(col_kernel<KIND_REDFT01>, g.lds_bytes)) return rc;
-		hipLaunchKernelGGL(col_kernel<KIND_REDFT01>, dim3(g.nwg), dim3(g.nthr), g.lds_bytes, s, a);
+		if (int rc = allow_lds(col_kernel<KIND_REDFT01, R>, g.lds_bytes)) return rc;
+		hipLaunchKernelGGL((col_kernel<KIND_REDFT01, R>), dim3(g.nwg), dim3(g.nthr), g.lds_bytes, s, a);
 	}
 	HIPCHK(hipGetLastError());
 	return 0;
 }
 
-int be_launch_dense(const DenseArgs &a, const LaunchGeom &g, void *stream)
+template <class R>
+static int launch_dense(const DenseArgsT<R> &a, const LaunchGeom &g, void *stream)
 {
-	if (int rc = allow_lds(dense_kernel, g.lds_bytes)) return rc;
-	hipLaunchKernelGGL(dense_kernel, dim3(g.nwg), dim3(g.nthr), g.lds_bytes, (hipStream_t)stream, a);
+	if (int rc = allow_lds(dense_kernel<R>, g.lds_bytes)) return rc;
+	hipLaunchKernelGGL((dense_kernel<R>), dim3(g.nwg), dim3(g.nthr), g.lds_bytes, (hipStream_t)stream, a);
 	HIPCHK(hipGetLastError());
 	return 0;
 }
+
+int be_launch_row(const PassArgs &a, const LaunchGeom &g, void *stream) { return launch_row(a, g, stream); }
+int be_launch_col(const PassArgs &a, const LaunchGeom &g, void *stream) { return launch_col(a, g, stream); }
+int be_launch_dense(const DenseArgs &a, const LaunchGeom &g, void *stream) { return launch_dense(a, g, stream); }
+int be_launch_row(const PassArgsD &a, const LaunchGeom &g, void *stream) { return launch_row(a, g, stream); }
+int be_launch_col(const PassArgsD &a, const LaunchGeom &g, void *stream) { return launch_col(a, g, stream); }
+int be_launch_dense(const DenseArgsD &a, const LaunchGeom &g, void *stream) { return launch_dense(a, g, stream); }
 
 template <class S, int KIND>
 int launch_row_spec(const PassArgs &a, int nwork, void *stream)

@@ -50,16 +50,15 @@ struct FftDesc {
 
 enum { KIND_REDFT10 = 0, KIND_REDFT01 = 1 };
 
-struct PassArgs {
-	const float *in;
-	float *out;
+// everything about a pass that does not depend on the sample type
+struct PassGeom {
 	int N;            // real transform length
 	int kind;         // KIND_*
 	// ROW
 	int C;            // interleaved signals per line
 	int Bg;           // channels transformed together (C, or 1 when LDS is tight)
 	// COL
-	int K;            // tile width in floats (even)
+	int K;            // tile width in samples (even)
 	int B;            // complex columns per tile = K/2
 	int ninner;       // extent of the inner contiguous dimension
 	int ntiles;       // ceil(ninner / K)
@@ -67,13 +66,7 @@ struct PassArgs {
 	// batch dimensions (two levels) -- line/tile base = i0*sb0 + i1*sb1
 	int nb0, nb1;
 	long long sb0_in, sb1_in, sb0_out, sb1_out;
-	// tables (device memory)
-	const cf *T;          // T[j] = exp(-i pi j / (2N)), j in [0, N]
-	const cf *W;          // W[t] = exp(-2 pi i t / L),  t in [0, L)
 	const uint32_t *pos;  // pos[k] = LDS slot holding FFT output k after the DIF stages
-	float scale;          // every output is multiplied by scale ...
-	float out_scale0;     // ... and output index 0 of this axis additionally by out_scale0
-	float in_scale0;      // input index 0 of this axis is multiplied by in_scale0 before transforming
 	// fused scan step (scan/scan.c:429-459): the FIRST pass zeroes every input element whose owner
 	// id differs (mask[offset / mask_div] != mask_id); the LAST pass adds into `out` instead of storing
 	const uint32_t *mask;
@@ -84,16 +77,36 @@ struct PassArgs {
 	FastDiv divB;         // divide by (ROW: Bg, COL: B)
 };
 
-DSP_HD float masked(const PassArgs &a, long long off, float v)
+template <class R>
+struct PassArgsT : PassGeom {
+	const R *in;
+	R *out;
+	// tables (device memory)
+	const cx<R> *T;       // T[j] = exp(-i pi j / (2N)), j in [0, N]
+	const cx<R> *W;       // W[t] = exp(-2 pi i t / L),  t in [0, L)
+	R scale;              // every output is multiplied by scale ...
+	R out_scale0;         // ... and output index 0 of this axis additionally by out_scale0
+	R in_scale0;          // input index 0 of this axis is multiplied by in_scale0 before transforming
+};
+typedef PassArgsT<float> PassArgs;      // the tuned single-precision path (and dct_spec.h)
+typedef PassArgsT<double> PassArgsD;    // the fftw_ (double) API: generic kernels only
+
+// 16-byte and two-sample vector types of each sample type
+template <class R> struct vec_of;
+template <> struct vec_of<float> { typedef float4 v16; typedef float2 v2; };
+template <> struct vec_of<double> { typedef double2 v16; typedef double2 v2; };
+
+template <class R>
+DSP_HD R masked(const PassArgsT<R> &a, long long off, R v)
 {
 	if (!a.mask) return v;
-	return a.mask[a.mask_div.div((uint32_t)off)] != a.mask_id ? 0.f : v;
+	return a.mask[a.mask_div.div((uint32_t)off)] != a.mask_id ? R(0) : v;
 }
 
 // ------------------------------------------------------------------------------------------------
 // FFT stage (in place in LDS).  Signals are interleaved: element n of signal s is buf[n*B + s].
-template <int R>
-DSP_HD void fft_stage_r(cf *buf, int L, const StageDesc &S, int B, FastDiv divB, const cf *W, int tid, int nthr)
+template <int R, class C>
+DSP_HD void fft_stage_r(C *buf, int L, const StageDesc &S, int B, FastDiv divB, const C *W, int tid, int nthr)
 {
 	const int nitems = (L / R) * B;
 	const int stride = S.M1 * B;
@@ -101,7 +114,7 @@ DSP_HD void fft_stage_r(cf *buf, int L, const StageDesc &S, int B, FastDiv divB,
 		const int q = (int)divB.div((uint32_t)it), s = it - q * B;
 		const int blk = (int)S.divM1.div((uint32_t)q), m = q - blk * S.M1;
 		const int base = (blk * S.Lc + m) * B + s;
-		cf x[R];
+		C x[R];
 		static_for<0, R>([&](auto r) { x[r] = buf[base + r * stride]; });
 		Dft<R>::run(x);
 		if (S.M1 > 1) {
@@ -112,7 +125,8 @@ DSP_HD void fft_stage_r(cf *buf, int L, const StageDesc &S, int B, FastDiv divB,
 	}
 }
 
-DSP_HD void fft_stage(cf *buf, int L, const StageDesc &S, int B, FastDiv divB, const cf *W, int tid, int nthr)
+template <class C>
+DSP_HD void fft_stage(C *buf, int L, const StageDesc &S, int B, FastDiv divB, const C *W, int tid, int nthr)
 {
 	switch (S.R) {
 	case 2: fft_stage_r<2>(buf, L, S, B, divB, W, tid, nthr); break;
@@ -138,121 +152,133 @@ DSP_HD void fft_stage(cf *buf, int L, const StageDesc &S, int B, FastDiv divB, c
 // index of sample v[n] of the even/odd-reordered signal inside the original signal
 DSP_HD int makhoul_src(int n, int N) { return 2 * n < N ? 2 * n : 2 * (N - 1 - n) + 1; }
 
-DSP_HD void row_base(const PassArgs &a, int line, long long &bin, long long &bout)
+DSP_HD void row_base(const PassGeom &a, int line, long long &bin, long long &bout)
 {
 	const int i1 = line / a.nb0, i0 = line - i1 * a.nb0;
 	bin = i0 * a.sb0_in + i1 * a.sb1_in;
 	bout = i0 * a.sb0_out + i1 * a.sb1_out;
 }
 
-DSP_HD void row_load(const PassArgs &a, float *raw, long long bin, int tid, int nthr)
+template <class R>
+DSP_HD void row_load(const PassArgsT<R> &a, R *raw, long long bin, int tid, int nthr)
 {
+	typedef typename vec_of<R>::v16 V;
+	constexpr int NV = 16 / (int)sizeof(R);
 	const int n = a.N * a.C;
-	const float *src = a.in + bin;
+	const R *src = a.in + bin;
 	if (a.mask) {
 		for (int i = tid; i < n; i += nthr) raw[i] = masked(a, bin + i, src[i]);
-	} else if (((bin & 3) == 0) && ((n & 3) == 0) && ((((uintptr_t)a.in) & 15) == 0)) {
-		const float4 *s4 = reinterpret_cast<const float4 *>(src);
-		float4 *r4 = reinterpret_cast<float4 *>(raw);
-		for (int i = tid; i < n / 4; i += nthr) r4[i] = s4[i];
+	} else if (((bin & (NV - 1)) == 0) && ((n & (NV - 1)) == 0) && ((((uintptr_t)a.in) & 15) == 0)) {
+		const V *s4 = reinterpret_cast<const V *>(src);
+		V *r4 = reinterpret_cast<V *>(raw);
+		for (int i = tid; i < n / NV; i += nthr) r4[i] = s4[i];
 	} else {
 		for (int i = tid; i < n; i += nthr) raw[i] = src[i];
 	}
 }
 
-DSP_HD void row_store(const PassArgs &a, const float *raw, long long bout, int tid, int nthr)
+template <class R>
+DSP_HD void row_store(const PassArgsT<R> &a, const R *raw, long long bout, int tid, int nthr)
 {
+	typedef typename vec_of<R>::v16 V;
+	constexpr int NV = 16 / (int)sizeof(R);
 	const int n = a.N * a.C;
-	float *dst = a.out + bout;
+	R *dst = a.out + bout;
 	if (a.accumulate) {
 		for (int i = tid; i < n; i += nthr) dst[i] += raw[i];
-	} else if (((bout & 3) == 0) && ((n & 3) == 0) && ((((uintptr_t)a.out) & 15) == 0)) {
-		const float4 *r4 = reinterpret_cast<const float4 *>(raw);
-		float4 *d4 = reinterpret_cast<float4 *>(dst);
-		for (int i = tid; i < n / 4; i += nthr) d4[i] = r4[i];
+	} else if (((bout & (NV - 1)) == 0) && ((n & (NV - 1)) == 0) && ((((uintptr_t)a.out) & 15) == 0)) {
+		const V *r4 = reinterpret_cast<const V *>(raw);
+		V *d4 = reinterpret_cast<V *>(dst);
+		for (int i = tid; i < n / NV; i += nthr) d4[i] = r4[i];
 	} else {
 		for (int i = tid; i < n; i += nthr) dst[i] = raw[i];
 	}
 }
 
 // REDFT10: pack channels [c0, c0+Bg) of raw into buf
-DSP_HD void row_pack2(const PassArgs &a, const float *raw, cf *buf, int c0, int tid, int nthr)
+template <class R>
+DSP_HD void row_pack2(const PassArgsT<R> &a, const R *raw, cx<R> *buf, int c0, int tid, int nthr)
 {
 	const int L = a.N / 2, Bg = a.Bg, C = a.C, N = a.N;
 	for (int it = tid; it < L * Bg; it += nthr) {
 		const int m = (int)a.divB.div((uint32_t)it), s = it - m * Bg;
 		const int i0 = makhoul_src(2 * m, N), i1 = makhoul_src(2 * m + 1, N);
-		float re = raw[i0 * C + c0 + s], im = raw[i1 * C + c0 + s];
+		R re = raw[i0 * C + c0 + s], im = raw[i1 * C + c0 + s];
 		if (i0 == 0) re *= a.in_scale0;
-		buf[it] = cmk(re, im);
+		buf[it] = cmk<R>(re, im);
 	}
 }
 
 // REDFT10: FFT output -> 4 real outputs per (k, L-k) pair, written back into raw
-DSP_HD void row_post2(const PassArgs &a, float *raw, const cf *buf, int c0, int tid, int nthr)
+template <class R>
+DSP_HD void row_post2(const PassArgsT<R> &a, R *raw, const cx<R> *buf, int c0, int tid, int nthr)
 {
 	const int L = a.N / 2, Bg = a.Bg, C = a.C, N = a.N;
 	const int nk = L / 2 + 1;
 	for (int it = tid; it < nk * Bg; it += nthr) {
 		const int k = (int)a.divB.div((uint32_t)it), s = it - k * Bg;
 		const int km = k ? L - k : 0;
-		const cf zk = buf[a.pos[k] * Bg + s];
-		const cf zm = cconj(buf[a.pos[km] * Bg + s]);
-		const cf E = cscale(cadd(zk, zm), 0.5f);
-		const cf Dh = cscale(csub(zk, zm), 0.5f);
-		const cf D = cmul_mi(Dh);                 // (zk - conj zm) / (2i)
-		const cf P = cmul(a.T[4 * k], D);         // exp(-2 pi i k / N) * D
-		const cf Vk = cadd(E, P);
-		const cf Vm = cconj(csub(E, P));          // V[L-k]
-		const cf wk = cmul(a.T[k], Vk);
-		const cf wm = cmul(a.T[L - k], Vm);
-		float *o = raw + c0 + s;
-		const float sc = a.scale;
-		o[k * C] = 2.f * wk.x * sc * (k == 0 ? a.out_scale0 : 1.f);
-		if (k > 0) o[(N - k) * C] = -2.f * wk.y * sc;
-		o[(L - k) * C] = 2.f * wm.x * sc;
-		if (k > 0) o[(L + k) * C] = -2.f * wm.y * sc;
+		typedef cx<R> C_;
+		const C_ zk = buf[a.pos[k] * Bg + s];
+		const C_ zm = cconj(buf[a.pos[km] * Bg + s]);
+		const C_ E = cscale(cadd(zk, zm), R(0.5));
+		const C_ Dh = cscale(csub(zk, zm), R(0.5));
+		const C_ D = cmul_mi(Dh);                 // (zk - conj zm) / (2i)
+		const C_ P = cmul(a.T[4 * k], D);         // exp(-2 pi i k / N) * D
+		const C_ Vk = cadd(E, P);
+		const C_ Vm = cconj(csub(E, P));          // V[L-k]
+		const C_ wk = cmul(a.T[k], Vk);
+		const C_ wm = cmul(a.T[L - k], Vm);
+		R *o = raw + c0 + s;
+		const R sc = a.scale;
+		o[k * C] = R(2) * wk.x * sc * (k == 0 ? a.out_scale0 : R(1));
+		if (k > 0) o[(N - k) * C] = R(-2) * wk.y * sc;
+		o[(L - k) * C] = R(2) * wm.x * sc;
+		if (k > 0) o[(L + k) * C] = R(-2) * wm.y * sc;
 	}
 }
 
 // REDFT01: natural-order input in raw -> conj of the half-length spectrum in buf
-DSP_HD void row_pre3(const PassArgs &a, const float *raw, cf *buf, int c0, int tid, int nthr)
+template <class R>
+DSP_HD void row_pre3(const PassArgsT<R> &a, const R *raw, cx<R> *buf, int c0, int tid, int nthr)
 {
 	const int L = a.N / 2, Bg = a.Bg, C = a.C, N = a.N;
 	const int nk = L / 2 + 1;
 	for (int it = tid; it < nk * Bg; it += nthr) {
 		const int k = (int)a.divB.div((uint32_t)it), s = it - k * Bg;
-		const float *x = raw + c0 + s;
-		const float xk = x[k * C] * (k == 0 ? a.in_scale0 : 1.f);
-		const float xnk = k ? x[(N - k) * C] : 0.f;
-		const float xlk = x[(L - k) * C];
-		const float xlpk = x[(L + k) * C];                     // k <= L/2 so L+k <= N-1
-		const cf Vk = cmulc(cmk(xk, -xnk), a.T[k]);            // conj(T[k]) * (X[k] - i X[N-k])
-		const cf Vm = cmulc(cmk(xlk, -xlpk), a.T[L - k]);      // V[L-k]
-		const cf S = cadd(Vk, cconj(Vm));
-		const cf D = csub(Vk, cconj(Vm));
-		const cf Q = cmul_pi(cmulc(D, a.T[4 * k]));            // i * conj(t1[k]) * D
+		typedef cx<R> C_;
+		const R *x = raw + c0 + s;
+		const R xk = x[k * C] * (k == 0 ? a.in_scale0 : R(1));
+		const R xnk = k ? x[(N - k) * C] : R(0);
+		const R xlk = x[(L - k) * C];
+		const R xlpk = x[(L + k) * C];                         // k <= L/2 so L+k <= N-1
+		const C_ Vk = cmulc(cmk<R>(xk, -xnk), a.T[k]);         // conj(T[k]) * (X[k] - i X[N-k])
+		const C_ Vm = cmulc(cmk<R>(xlk, -xlpk), a.T[L - k]);   // V[L-k]
+		const C_ S = cadd(Vk, cconj(Vm));
+		const C_ D = csub(Vk, cconj(Vm));
+		const C_ Q = cmul_pi(cmulc(D, a.T[4 * k]));            // i * conj(t1[k]) * D
 		buf[k * Bg + s] = cconj(cadd(S, Q));
 		if (k > 0) buf[(L - k) * Bg + s] = csub(S, Q);
 	}
 }
 
 // REDFT01: FFT output -> time samples, un-reordered, into raw
-DSP_HD void row_unpack3(const PassArgs &a, float *raw, const cf *buf, int c0, int tid, int nthr)
+template <class R>
+DSP_HD void row_unpack3(const PassArgsT<R> &a, R *raw, const cx<R> *buf, int c0, int tid, int nthr)
 {
 	const int L = a.N / 2, Bg = a.Bg, C = a.C, N = a.N;
 	for (int it = tid; it < L * Bg; it += nthr) {
 		const int m = (int)a.divB.div((uint32_t)it), s = it - m * Bg;
-		const cf F = buf[a.pos[m] * Bg + s];
+		const cx<R> F = buf[a.pos[m] * Bg + s];
 		const int i0 = makhoul_src(2 * m, N), i1 = makhoul_src(2 * m + 1, N);
-		raw[i0 * C + c0 + s] = F.x * a.scale * (i0 == 0 ? a.out_scale0 : 1.f);
+		raw[i0 * C + c0 + s] = F.x * a.scale * (i0 == 0 ? a.out_scale0 : R(1));
 		raw[i1 * C + c0 + s] = -F.y * a.scale;
 	}
 }
 
 // ------------------------------------------------------------------------------------------------
 // COL pass.  LDS: buf[N*B] complex.  Tile t of batch (i0,i1) covers floats [t*K, t*K+K) of the inner dim.
-DSP_HD void col_base(const PassArgs &a, int wg, long long &bin, long long &bout, int &valid)
+DSP_HD void col_base(const PassGeom &a, int wg, long long &bin, long long &bout, int &valid)
 {
 	const int bt = wg / a.ntiles, t = wg - bt * a.ntiles;
 	const int i1 = bt / a.nb0, i0 = bt - i1 * a.nb0;
@@ -262,104 +288,115 @@ DSP_HD void col_base(const PassArgs &a, int wg, long long &bin, long long &bout,
 	if (valid > a.K) valid = a.K;
 }
 
-DSP_HD cf ld2m(const PassArgs &a, long long off, bool vec, int nvalid);
-DSP_HD cf ld2(const float *p, bool vec, int nvalid)
+template <class R>
+DSP_HD cx<R> ld2(const R *p, bool vec, int nvalid)
 {
 	if (nvalid >= 2) {
-		if (vec) { const float2 v = *reinterpret_cast<const float2 *>(p); return cmk(v.x, v.y); }
-		return cmk(p[0], p[1]);
+		if (vec) { const typename vec_of<R>::v2 v = *reinterpret_cast<const typename vec_of<R>::v2 *>(p); return cmk<R>(v.x, v.y); }
+		return cmk<R>(p[0], p[1]);
 	}
-	return cmk(nvalid >= 1 ? p[0] : 0.f, 0.f);
+	return cmk<R>(nvalid >= 1 ? p[0] : R(0), R(0));
 }
-DSP_HD cf ld2m(const PassArgs &a, long long off, bool vec, int nvalid)
+template <class R>
+DSP_HD cx<R> ld2m(const PassArgsT<R> &a, long long off, bool vec, int nvalid)
 {
-	cf v = ld2(a.in + off, vec, nvalid);
+	cx<R> v = ld2(a.in + off, vec, nvalid);
 	if (a.mask) { v.x = masked(a, off, v.x); if (nvalid >= 2) v.y = masked(a, off + 1, v.y); }
 	return v;
 }
-DSP_HD void st2(float *p, bool vec, int nvalid, float a, float b);
-DSP_HD void st2a(const PassArgs &a, float *p, bool vec, int nvalid, float x, float y)
+template <class R>
+DSP_HD void st2(R *p, bool vec, int nvalid, R a, typename same_t<R>::type b)
+{
+	if (nvalid >= 2) {
+		if (vec) { typename vec_of<R>::v2 v; v.x = a; v.y = b; *reinterpret_cast<typename vec_of<R>::v2 *>(p) = v; }
+		else { p[0] = a; p[1] = b; }
+	} else if (nvalid >= 1) p[0] = a;
+}
+template <class R>
+DSP_HD void st2a(const PassArgsT<R> &a, R *p, bool vec, int nvalid, R x, typename same_t<R>::type y)
 {
 	if (a.accumulate) { if (nvalid >= 1) p[0] += x; if (nvalid >= 2) p[1] += y; }
 	else st2(p, vec, nvalid, x, y);
 }
-DSP_HD void st2(float *p, bool vec, int nvalid, float a, float b)
-{
-	if (nvalid >= 2) {
-		if (vec) { float2 v; v.x = a; v.y = b; *reinterpret_cast<float2 *>(p) = v; }
-		else { p[0] = a; p[1] = b; }
-	} else if (nvalid >= 1) p[0] = a;
-}
+// two-sample vector access: both strides even and the base pointer aligned to two samples
+template <class R>
+DSP_HD bool vec2_ok(long long base, long long es, const R *p) { return (((base | es) & 1) == 0) && ((((uintptr_t)p) & (2 * sizeof(R) - 1)) == 0); }
 
 DSP_HD int makhoul_dst(int y, int N) { return (y & 1) ? N - 1 - (y >> 1) : (y >> 1); }
 
 // REDFT10: load tile rows, even/odd reorder along the axis
-DSP_HD void col_load2(const PassArgs &a, cf *buf, long long bin, int valid, int tid, int nthr)
+template <class R>
+DSP_HD void col_load2(const PassArgsT<R> &a, cx<R> *buf, long long bin, int valid, int tid, int nthr)
 {
 	const int N = a.N, B = a.B;
-	const bool vec = (((bin | a.es_in) & 1) == 0) && ((((uintptr_t)a.in) & 7) == 0);
+	const bool vec = vec2_ok(bin, a.es_in, a.in);
 	for (int it = tid; it < N * B; it += nthr) {
 		const int y = (int)a.divB.div((uint32_t)it), j = it - y * B;
-		cf v = ld2m(a, bin + (long long)y * a.es_in + 2 * j, vec, valid - 2 * j);
+		cx<R> v = ld2m(a, bin + (long long)y * a.es_in + 2 * j, vec, valid - 2 * j);
 		if (y == 0) { v.x *= a.in_scale0; v.y *= a.in_scale0; }
 		buf[makhoul_dst(y, N) * B + j] = v;
 	}
 }
 
 // REDFT10: separate the two real transforms, quarter-sample twiddle, store rows k and N-k
-DSP_HD void col_post2(const PassArgs &a, const cf *buf, long long bout, int valid, int tid, int nthr)
+template <class R>
+DSP_HD void col_post2(const PassArgsT<R> &a, const cx<R> *buf, long long bout, int valid, int tid, int nthr)
 {
+	typedef cx<R> C_;
 	const int N = a.N, B = a.B;
 	const int nk = N / 2 + 1;
-	const bool vec = (((bout | a.es_out) & 1) == 0) && ((((uintptr_t)a.out) & 7) == 0);
+	const bool vec = vec2_ok(bout, a.es_out, a.out);
 	for (int it = tid; it < nk * B; it += nthr) {
 		const int k = (int)a.divB.div((uint32_t)it), j = it - k * B;
 		const int km = k ? N - k : 0;
-		const cf zk = buf[a.pos[k] * B + j];
-		const cf zm = cconj(buf[a.pos[km] * B + j]);
-		const cf A2 = cadd(zk, zm);                   // 2 A[k]
-		const cf B2 = cmul_mi(csub(zk, zm));          // 2 B[k]
-		const cf t = a.T[k];
-		const cf wa = cmul(t, A2), wb = cmul(t, B2);
-		const float sc = a.scale;
-		float *o = a.out + bout + 2 * j;
-		const float s0 = (k == 0) ? sc * a.out_scale0 : sc;
+		const C_ zk = buf[a.pos[k] * B + j];
+		const C_ zm = cconj(buf[a.pos[km] * B + j]);
+		const C_ A2 = cadd(zk, zm);                   // 2 A[k]
+		const C_ B2 = cmul_mi(csub(zk, zm));          // 2 B[k]
+		const C_ t = a.T[k];
+		const C_ wa = cmul(t, A2), wb = cmul(t, B2);
+		const R sc = a.scale;
+		R *o = a.out + bout + 2 * j;
+		const R s0 = (k == 0) ? sc * a.out_scale0 : sc;
 		st2a(a, o + (long long)k * a.es_out, vec, valid - 2 * j, wa.x * s0, wb.x * s0);
 		if (k > 0 && km != k) st2a(a, o + (long long)km * a.es_out, vec, valid - 2 * j, -wa.y * sc, -wb.y * sc);
 	}
 }
 
 // REDFT01: rows k and N-k -> conj spectrum of (a + i b)
-DSP_HD void col_pre3(const PassArgs &a, cf *buf, long long bin, int valid, int tid, int nthr)
+template <class R>
+DSP_HD void col_pre3(const PassArgsT<R> &a, cx<R> *buf, long long bin, int valid, int tid, int nthr)
 {
+	typedef cx<R> C_;
 	const int N = a.N, B = a.B;
 	const int nk = N / 2 + 1;
-	const bool vec = (((bin | a.es_in) & 1) == 0) && ((((uintptr_t)a.in) & 7) == 0);
+	const bool vec = vec2_ok(bin, a.es_in, a.in);
 	for (int it = tid; it < nk * B; it += nthr) {
 		const int k = (int)a.divB.div((uint32_t)it), j = it - k * B;
 		const int km = k ? N - k : 0;
 		const long long p = bin + 2 * j;
-		cf xk = ld2m(a, p + (long long)k * a.es_in, vec, valid - 2 * j);
-		cf xm = k ? ld2m(a, p + (long long)km * a.es_in, vec, valid - 2 * j) : cmk(0.f, 0.f);
+		C_ xk = ld2m(a, p + (long long)k * a.es_in, vec, valid - 2 * j);
+		C_ xm = k ? ld2m(a, p + (long long)km * a.es_in, vec, valid - 2 * j) : cmk<R>(R(0), R(0));
 		if (k == 0) { xk.x *= a.in_scale0; xk.y *= a.in_scale0; }
-		const cf t = a.T[k];
-		const cf Va = cmulc(cmk(xk.x, -xm.x), t);     // conj(T[k]) (Xa[k] - i Xa[N-k])
-		const cf Vb = cmulc(cmk(xk.y, -xm.y), t);
-		buf[k * B + j] = cmk(Va.x - Vb.y, -Va.y - Vb.x);            // conj(Va) - i conj(Vb)
-		if (k > 0) buf[km * B + j] = cmk(Va.x + Vb.y, Va.y - Vb.x); // Va - i Vb
+		const C_ t = a.T[k];
+		const C_ Va = cmulc(cmk<R>(xk.x, -xm.x), t);     // conj(T[k]) (Xa[k] - i Xa[N-k])
+		const C_ Vb = cmulc(cmk<R>(xk.y, -xm.y), t);
+		buf[k * B + j] = cmk<R>(Va.x - Vb.y, -Va.y - Vb.x);            // conj(Va) - i conj(Vb)
+		if (k > 0) buf[km * B + j] = cmk<R>(Va.x + Vb.y, Va.y - Vb.x); // Va - i Vb
 	}
 }
 
 // REDFT01: FFT output -> both real signals, un-reordered, store
-DSP_HD void col_unpack3(const PassArgs &a, const cf *buf, long long bout, int valid, int tid, int nthr)
+template <class R>
+DSP_HD void col_unpack3(const PassArgsT<R> &a, const cx<R> *buf, long long bout, int valid, int tid, int nthr)
 {
 	const int N = a.N, B = a.B;
-	const bool vec = (((bout | a.es_out) & 1) == 0) && ((((uintptr_t)a.out) & 7) == 0);
+	const bool vec = vec2_ok(bout, a.es_out, a.out);
 	for (int it = tid; it < N * B; it += nthr) {
 		const int n = (int)a.divB.div((uint32_t)it), j = it - n * B;
-		const cf F = buf[a.pos[n] * B + j];
+		const cx<R> F = buf[a.pos[n] * B + j];
 		const int y = makhoul_src(n, N);
-		const float sc = (y == 0) ? a.scale * a.out_scale0 : a.scale;
+		const R sc = (y == 0) ? a.scale * a.out_scale0 : a.scale;
 		st2a(a, a.out + bout + (long long)y * a.es_out + 2 * j, vec, valid - 2 * j, F.x * sc, -F.y * sc);
 	}
 }
@@ -367,41 +404,48 @@ DSP_HD void col_unpack3(const PassArgs &a, const cf *buf, long long bout, int va
 // ------------------------------------------------------------------------------------------------
 // DENSE pass: any N, any stride; O(N^2) by the definition with an exactly reduced phase table.
 // LDS: x[N] floats.  cosTab[t] = cos(pi t / (2N)), t in [0, 4N).
-struct DenseArgs {
-	const float *in;
-	float *out;
+struct DenseGeom {
 	int N, kind;
 	long long es_in, es_out;
 	int nb0, nb1, nb2;                       // three batch levels
 	long long sb0_in, sb1_in, sb2_in, sb0_out, sb1_out, sb2_out;
-	const float *cosTab;
-	float scale, out_scale0, in_scale0;
 	const uint32_t *mask;
 	uint32_t mask_id;
 	FastDiv mask_div;
 	int accumulate;
 };
+template <class R>
+struct DenseArgsT : DenseGeom {
+	const R *in;
+	R *out;
+	const R *cosTab;
+	R scale, out_scale0, in_scale0;
+};
+typedef DenseArgsT<float> DenseArgs;
+typedef DenseArgsT<double> DenseArgsD;
 
-DSP_HD void dense_base(const DenseArgs &a, long long line, long long &bin, long long &bout)
+DSP_HD void dense_base(const DenseGeom &a, long long line, long long &bin, long long &bout)
 {
 	const long long i2 = line / ((long long)a.nb0 * a.nb1), r = line - i2 * a.nb0 * a.nb1;
 	const long long i1 = r / a.nb0, i0 = r - i1 * a.nb0;
 	bin = i0 * a.sb0_in + i1 * a.sb1_in + i2 * a.sb2_in;
 	bout = i0 * a.sb0_out + i1 * a.sb1_out + i2 * a.sb2_out;
 }
-DSP_HD void dense_load(const DenseArgs &a, float *x, long long bin, int tid, int nthr)
+template <class R>
+DSP_HD void dense_load(const DenseArgsT<R> &a, R *x, long long bin, int tid, int nthr)
 {
 	for (int j = tid; j < a.N; j += nthr) {
 		const long long off = bin + (long long)j * a.es_in;
-		const float v = (a.mask && a.mask[a.mask_div.div((uint32_t)off)] != a.mask_id) ? 0.f : a.in[off];
-		x[j] = v * (j == 0 ? a.in_scale0 : 1.f);
+		const R v = (a.mask && a.mask[a.mask_div.div((uint32_t)off)] != a.mask_id) ? R(0) : a.in[off];
+		x[j] = v * (j == 0 ? a.in_scale0 : R(1));
 	}
 }
-DSP_HD void dense_compute(const DenseArgs &a, const float *x, long long bout, int tid, int nthr)
+template <class R>
+DSP_HD void dense_compute(const DenseArgsT<R> &a, const R *x, long long bout, int tid, int nthr)
 {
 	const int N = a.N, fourN = 4 * N;
 	for (int k = tid; k < N; k += nthr) {
-		float acc = 0.f;
+		R acc = 0;
 		if (a.kind == KIND_REDFT10) {
 			int t = k % fourN;                 // (2j+1) k mod 4N, j = 0
 			const int step = (2 * k) % fourN;
@@ -409,7 +453,7 @@ DSP_HD void dense_compute(const DenseArgs &a, const float *x, long long bout, in
 				acc += x[j] * a.cosTab[t];
 				t += step; if (t >= fourN) t -= fourN;
 			}
-			acc *= 2.f;
+			acc *= R(2);
 		} else {
 			const int step = (2 * k + 1) % fourN;   // j (2k+1) mod 4N
 			int t = step;
@@ -417,9 +461,9 @@ DSP_HD void dense_compute(const DenseArgs &a, const float *x, long long bout, in
 				acc += x[j] * a.cosTab[t];
 				t += step; if (t >= fourN) t -= fourN;
 			}
-			acc = x[0] + 2.f * acc;
+			acc = x[0] + R(2) * acc;
 		}
-		const float r = acc * a.scale * (k == 0 ? a.out_scale0 : 1.f);
+		const R r = acc * a.scale * (k == 0 ? a.out_scale0 : R(1));
 		if (a.accumulate) a.out[bout + (long long)k * a.es_out] += r; else a.out[bout + (long long)k * a.es_out] = r;
 	}
 }

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/dspfft.h"
@@ -109,11 +110,11 @@ struct Pass {
 	enum Type { ROW, COL, DENSE } type;
 	int axis;
 	bool first;
-	PassArgs pa;
-	DenseArgs da;
+	PassGeom pa;               // typed pointers, tables and scales are filled in per launch (run_pass)
+	DenseGeom da;
 	LaunchGeom g;
 	bool has_spec = false;     // a compile-time-specialised kernel also covers this pass ...
-	PassArgs spa;              // ... with these arguments (used when the buffers are 16-B aligned)
+	PassGeom spa;              // ... with this geometry (used when the buffers are 16-B aligned)
 	SpecInfo spec;
 	int spec_nwg = 0;
 	std::vector<Dim> hostloop;
@@ -127,7 +128,8 @@ struct dspfft_plan_s {
 	int rank, howmany;
 	int n[3], kinds[3];
 	Dim axes[3], batch;
-	float scale, in0[3], out0[3];
+	bool f64;                  // samples are double (dspfft_plan_many_r2r_f64): generic kernels, double tables
+	double scale, in0[3], out0[3];
 	std::vector<Pass> passes;
 	size_t alg_bytes;
 };
@@ -144,21 +146,28 @@ void merge_dims(std::vector<Dim> &d)
 	}
 }
 
-int upload_tables(Pass &P, int N, int L, const std::vector<uint32_t> &pos)
+// T and W in the plan's sample type (computed in long double either way); the pass keeps them as void* in
+// P.tab and run_pass hands them to the kernel arguments of the matching type
+template <class R>
+int upload_tables_t(Pass &P, int N, int L, const std::vector<uint32_t> &pos)
 {
 	const long double pi = 3.14159265358979323846264338327950288L;
-	std::vector<cf> T(N + 1), W(std::max(L, 1));
-	for (int j = 0; j <= N; j++) T[j] = cmk((float)cosl(pi * j / (2.0L * N)), (float)-sinl(pi * j / (2.0L * N)));
-	for (int t = 0; t < L; t++) W[t] = cmk((float)cosl(2 * pi * t / L), (float)-sinl(2 * pi * t / L));
-	P.tab.T = be_alloc(T.size() * sizeof(cf));
-	P.tab.W = be_alloc(W.size() * sizeof(cf));
+	std::vector<cx<R>> T(N + 1), W(std::max(L, 1));
+	for (int j = 0; j <= N; j++) T[j] = cmk<R>((R)cosl(pi * j / (2.0L * N)), (R)-sinl(pi * j / (2.0L * N)));
+	for (int t = 0; t < L; t++) W[t] = cmk<R>((R)cosl(2 * pi * t / L), (R)-sinl(2 * pi * t / L));
+	P.tab.T = be_alloc(T.size() * sizeof(cx<R>));
+	P.tab.W = be_alloc(W.size() * sizeof(cx<R>));
 	P.tab.pos = be_alloc(pos.size() * sizeof(uint32_t));
 	if (!P.tab.T || !P.tab.W || !P.tab.pos) return -1;
-	if (be_upload(P.tab.T, T.data(), T.size() * sizeof(cf))) return -1;
-	if (be_upload(P.tab.W, W.data(), W.size() * sizeof(cf))) return -1;
+	if (be_upload(P.tab.T, T.data(), T.size() * sizeof(cx<R>))) return -1;
+	if (be_upload(P.tab.W, W.data(), W.size() * sizeof(cx<R>))) return -1;
 	if (be_upload(P.tab.pos, pos.data(), pos.size() * sizeof(uint32_t))) return -1;
-	P.pa.T = (const cf *)P.tab.T; P.pa.W = (const cf *)P.tab.W; P.pa.pos = (const uint32_t *)P.tab.pos;
+	P.pa.pos = (const uint32_t *)P.tab.pos;
 	return 0;
+}
+int upload_tables(Pass &P, bool f64, int N, int L, const std::vector<uint32_t> &pos)
+{
+	return f64 ? upload_tables_t<double>(P, N, L, pos) : upload_tables_t<float>(P, N, L, pos);
 }
 
 std::string radix_string(const FftDesc &F)
@@ -181,6 +190,8 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 	for (int b = 0; b < pl->rank; b++) if (b != a && pl->n[b] > 1) others.push_back(eff(pl->axes[b]));
 	if (pl->howmany > 1) others.push_back(eff(pl->batch));
 	const size_t maxlds = be_max_lds();
+	const size_t es = pl->f64 ? 8 : 4;         // bytes per sample; a complex LDS slot is 2*es
+	const char *tag = pl->f64 ? " f64" : "";
 	char buf[256];
 
 	// ---------------- ROW ----------------
@@ -196,29 +207,29 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 		if (ok) ok = build_fft(N / 2, F, pos);
 		if (ok) {
 			const int L = N / 2;
-			size_t raw_bytes = (((size_t)N * C * 4) + 15) & ~(size_t)15;
+			size_t raw_bytes = (((size_t)N * C * es) + 15) & ~(size_t)15;
 			int Bg = C;
-			if (raw_bytes + (size_t)L * Bg * 8 > maxlds) Bg = 1;
-			if (raw_bytes + (size_t)L * Bg * 8 > maxlds) ok = false;
+			if (raw_bytes + (size_t)L * Bg * 2 * es > maxlds) Bg = 1;
+			if (raw_bytes + (size_t)L * Bg * 2 * es > maxlds) ok = false;
 			if (ok) {
 				std::vector<Dim> lines;
 				for (size_t i = 0; i < others.size(); i++) if ((int)i != cdim) lines.push_back(others[i]);
 				merge_dims(lines);
-				PassArgs &pa = P.pa;
+				PassGeom &pa = P.pa;
 				pa.N = N; pa.kind = kind; pa.C = C; pa.Bg = Bg; pa.fft = F; pa.divB = make_div((uint32_t)Bg);
 				pa.nb0 = lines.size() > 0 ? lines[0].n : 1; pa.sb0_in = lines.size() > 0 ? lines[0].is : 0; pa.sb0_out = lines.size() > 0 ? lines[0].os : 0;
 				pa.nb1 = lines.size() > 1 ? lines[1].n : 1; pa.sb1_in = lines.size() > 1 ? lines[1].is : 0; pa.sb1_out = lines.size() > 1 ? lines[1].os : 0;
 				for (size_t i = 2; i < lines.size(); i++) P.hostloop.push_back(lines[i]);
 				P.type = Pass::ROW;
-				P.g.nwg = pa.nb0 * pa.nb1; P.g.nthr = 256; P.g.raw_bytes = raw_bytes; P.g.lds_bytes = raw_bytes + (size_t)L * Bg * 8;
-				if (upload_tables(P, N, L, pos)) return fail(-3, "table upload failed");
-				snprintf(buf, sizeof buf, "axis %d: ROW  N=%d C=%d Bg=%d fft=%d(%s) lines=%d lds=%zu", a, N, C, Bg, L, radix_string(F).c_str(), P.g.nwg, P.g.lds_bytes);
+				P.g.nwg = pa.nb0 * pa.nb1; P.g.nthr = 256; P.g.raw_bytes = raw_bytes; P.g.lds_bytes = raw_bytes + (size_t)L * Bg * 2 * es;
+				if (upload_tables(P, pl->f64, N, L, pos)) return fail(-3, "table upload failed");
+				snprintf(buf, sizeof buf, "axis %d: ROW%s  N=%d C=%d Bg=%d fft=%d(%s) lines=%d lds=%zu", a, tag, N, C, Bg, L, radix_string(F).c_str(), P.g.nwg, P.g.lds_bytes);
 				P.desc = buf;
 				// vector pixel access needs the line starts aligned to the pixel vector (C=2: 8 B, C=4: 16 B)
 				const int al = (C == 2 || C == 4) ? C : 1;
 				bool aligned = true;
 				for (const Dim &d : lines) aligned = aligned && (d.is % al == 0) && (d.os % al == 0);
-				if (aligned && be_find_spec(0, N, C, &P.spec)) {
+				if (!pl->f64 && aligned && be_find_spec(0, N, C, &P.spec)) {
 					P.has_spec = true; P.spa = pa; P.spec_nwg = P.g.nwg;
 					snprintf(buf, sizeof buf, "axis %d: ROW* N=%d C=%d spec#%d threads=%d lines=%d lds=%zu (generic fallback: Bg=%d)", a, N, C, P.spec.id, P.spec.nthr, P.g.nwg, P.spec.lds, Bg);
 					P.desc = buf;
@@ -248,9 +259,9 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 			}
 			merge_dims(rest);
 			int K = std::min(16, (inner.n + 1) & ~1);
-			while (K >= 2 && (size_t)N * (K / 2) * 8 > maxlds) K -= 2;
+			while (K >= 2 && (size_t)N * (K / 2) * 2 * es > maxlds) K -= 2;
 			if (K >= 2) {
-				PassArgs &pa = P.pa;
+				PassGeom &pa = P.pa;
 				pa.N = N; pa.kind = kind; pa.K = K; pa.B = K / 2; pa.ninner = inner.n; pa.ntiles = (inner.n + K - 1) / K;
 				pa.es_in = ax.is; pa.es_out = ax.os; pa.fft = F; pa.divB = make_div((uint32_t)pa.B);
 				pa.nb0 = rest.size() > 0 ? rest[0].n : 1; pa.sb0_in = rest.size() > 0 ? rest[0].is : 0; pa.sb0_out = rest.size() > 0 ? rest[0].os : 0;
@@ -259,14 +270,14 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 				P.type = Pass::COL;
 				P.g.nwg = pa.ntiles * pa.nb0 * pa.nb1;
 				P.g.nthr = ((long long)N * pa.B >= 8192) ? 512 : 256;
-				P.g.lds_bytes = (size_t)N * pa.B * 8; P.g.raw_bytes = 0;
-				if (upload_tables(P, N, N, pos)) return fail(-3, "table upload failed");
-				snprintf(buf, sizeof buf, "axis %d: COL  N=%d K=%d inner=%d tiles=%d fft=%d(%s) wgs=%d lds=%zu", a, N, K, inner.n, pa.ntiles, N, radix_string(F).c_str(), P.g.nwg, P.g.lds_bytes);
+				P.g.lds_bytes = (size_t)N * pa.B * 2 * es; P.g.raw_bytes = 0;
+				if (upload_tables(P, pl->f64, N, N, pos)) return fail(-3, "table upload failed");
+				snprintf(buf, sizeof buf, "axis %d: COL%s  N=%d K=%d inner=%d tiles=%d fft=%d(%s) wgs=%d lds=%zu", a, tag, N, K, inner.n, pa.ntiles, N, radix_string(F).c_str(), P.g.nwg, P.g.lds_bytes);
 				P.desc = buf;
 				// float4 tile rows: every stride that positions a tile must keep 16-B alignment
 				bool aligned = (ax.is % 4 == 0) && (ax.os % 4 == 0);
 				for (const Dim &d : rest) aligned = aligned && (d.is % 4 == 0) && (d.os % 4 == 0);
-				if (aligned && be_find_spec(1, N, inner.n, &P.spec)) {
+				if (!pl->f64 && aligned && be_find_spec(1, N, inner.n, &P.spec)) {
 					P.has_spec = true; P.spa = pa;
 					P.spa.K = P.spec.P; P.spa.B = P.spec.P / 2; P.spa.ntiles = inner.n / P.spec.P;
 					P.spec_nwg = P.spa.ntiles * pa.nb0 * pa.nb1;
@@ -279,25 +290,33 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 	}
 	// ---------------- DENSE ----------------
 	{
-		if ((size_t)N * 4 > maxlds) return fail(-2, "axis %d: length %d has a prime factor > 13 (or no usable layout) and exceeds the dense path's LDS limit", a, N);
+		if ((size_t)N * es > maxlds) return fail(-2, "axis %d: length %d has a prime factor > 13 (or no usable layout) and exceeds the dense path's LDS limit", a, N);
 		merge_dims(others);
-		DenseArgs &da = P.da;
+		DenseGeom &da = P.da;
 		da.N = N; da.kind = kind; da.es_in = ax.is; da.es_out = ax.os;
 		da.nb0 = others.size() > 0 ? others[0].n : 1; da.sb0_in = others.size() > 0 ? others[0].is : 0; da.sb0_out = others.size() > 0 ? others[0].os : 0;
 		da.nb1 = others.size() > 1 ? others[1].n : 1; da.sb1_in = others.size() > 1 ? others[1].is : 0; da.sb1_out = others.size() > 1 ? others[1].os : 0;
 		da.nb2 = others.size() > 2 ? others[2].n : 1; da.sb2_in = others.size() > 2 ? others[2].is : 0; da.sb2_out = others.size() > 2 ? others[2].os : 0;
 		for (size_t i = 3; i < others.size(); i++) P.hostloop.push_back(others[i]);
 		const long double pi = 3.14159265358979323846264338327950288L;
-		std::vector<float> ct((size_t)4 * N);
-		for (int t = 0; t < 4 * N; t++) ct[t] = (float)cosl(pi * t / (2.0L * N));
-		P.tab.cosTab = be_alloc(ct.size() * 4);
-		if (!P.tab.cosTab || be_upload(P.tab.cosTab, ct.data(), ct.size() * 4)) return fail(-3, "table upload failed");
-		da.cosTab = (const float *)P.tab.cosTab;
+		P.tab.cosTab = be_alloc((size_t)4 * N * es);
+		if (!P.tab.cosTab) return fail(-3, "table upload failed");
+		int urc;
+		if (pl->f64) {
+			std::vector<double> ct((size_t)4 * N);
+			for (int t = 0; t < 4 * N; t++) ct[t] = (double)cosl(pi * t / (2.0L * N));
+			urc = be_upload(P.tab.cosTab, ct.data(), ct.size() * 8);
+		} else {
+			std::vector<float> ct((size_t)4 * N);
+			for (int t = 0; t < 4 * N; t++) ct[t] = (float)cosl(pi * t / (2.0L * N));
+			urc = be_upload(P.tab.cosTab, ct.data(), ct.size() * 4);
+		}
+		if (urc) return fail(-3, "table upload failed");
 		P.type = Pass::DENSE;
 		long long lines = (long long)da.nb0 * da.nb1 * da.nb2;
 		if (lines > 0x7fffffff) return fail(-2, "too many lines for the dense path");
-		P.g.nwg = (int)lines; P.g.nthr = 256; P.g.lds_bytes = (size_t)N * 4;
-		snprintf(buf, sizeof buf, "axis %d: DENSE N=%d lines=%lld lds=%zu", a, N, lines, P.g.lds_bytes);
+		P.g.nwg = (int)lines; P.g.nthr = 256; P.g.lds_bytes = (size_t)N * es;
+		snprintf(buf, sizeof buf, "axis %d: DENSE%s N=%d lines=%lld lds=%zu", a, tag, N, lines, P.g.lds_bytes);
 		P.desc = buf;
 		return 0;
 	}
@@ -306,33 +325,48 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 struct Fuse { const uint32_t *mask = nullptr; uint32_t id = 0; int div = 1; bool accumulate = false; };
 FastDiv make_div(uint32_t d);
 
-int run_pass(const dspfft_plan_s *pl, const Pass &P, const float *in, float *out, bool last, void *stream, const Fuse &fz = Fuse())
+template <class R>
+void fill_args(PassArgsT<R> &a, const PassGeom &g, const dspfft_plan_s *pl, const Pass &P, const R *in, R *out, double scale, const Fuse &fz)
 {
-	const float scale = last ? pl->scale : 1.f;
+	static_cast<PassGeom &>(a) = g;
+	a.in = in; a.out = out; a.T = (const cx<R> *)P.tab.T; a.W = (const cx<R> *)P.tab.W;
+	a.scale = (R)scale; a.in_scale0 = (R)pl->in0[P.axis]; a.out_scale0 = (R)pl->out0[P.axis];
+	a.mask = fz.mask; a.mask_id = fz.id; a.mask_div = make_div((uint32_t)fz.div); a.accumulate = fz.accumulate;
+}
+
+template <class R>
+int run_pass(const dspfft_plan_s *pl, const Pass &P, const R *in, R *out, bool last, void *stream, const Fuse &fz = Fuse())
+{
+	const double scale = last ? pl->scale : 1.0;
 	// iterate the host-side batch dims (rare: more batch levels than a kernel takes)
 	std::vector<int> idx(P.hostloop.size(), 0);
 	for (;;) {
 		long long oin = 0, oout = 0;
 		for (size_t i = 0; i < idx.size(); i++) { oin += idx[i] * P.hostloop[i].is; oout += idx[i] * P.hostloop[i].os; }
-		int rc;
+		int rc = 0;
 		if (P.type == Pass::DENSE) {
-			DenseArgs a = P.da;
-			a.in = in + oin; a.out = out + oout; a.scale = scale; a.in_scale0 = pl->in0[P.axis]; a.out_scale0 = pl->out0[P.axis];
+			DenseArgsT<R> a;
+			static_cast<DenseGeom &>(a) = P.da;
+			a.in = in + oin; a.out = out + oout; a.cosTab = (const R *)P.tab.cosTab;
+			a.scale = (R)scale; a.in_scale0 = (R)pl->in0[P.axis]; a.out_scale0 = (R)pl->out0[P.axis];
 			a.mask = fz.mask; a.mask_id = fz.id; a.mask_div = make_div((uint32_t)fz.div); a.accumulate = fz.accumulate;
 			rc = be_launch_dense(a, P.g, stream);
 		} else {
-			const bool ptr_ok = P.type == Pass::ROW
-				? ((P.pa.C == 2 ? 7u : P.pa.C == 4 ? 15u : 3u) & ((uintptr_t)(in + oin) | (uintptr_t)(out + oout))) == 0
-				: (15u & ((uintptr_t)(in + oin) | (uintptr_t)(out + oout))) == 0;
-			if (P.has_spec && ptr_ok) {
-				PassArgs a = P.spa;
-				a.in = in + oin; a.out = out + oout; a.scale = scale; a.in_scale0 = pl->in0[P.axis]; a.out_scale0 = pl->out0[P.axis];
-				a.mask = fz.mask; a.mask_id = fz.id; a.mask_div = make_div((uint32_t)fz.div); a.accumulate = fz.accumulate;
-				rc = be_launch_spec(P.type == Pass::COL, P.spec.id, a, P.spec_nwg, stream);
-			} else {
-				PassArgs a = P.pa;
-				a.in = in + oin; a.out = out + oout; a.scale = scale; a.in_scale0 = pl->in0[P.axis]; a.out_scale0 = pl->out0[P.axis];
-				a.mask = fz.mask; a.mask_id = fz.id; a.mask_div = make_div((uint32_t)fz.div); a.accumulate = fz.accumulate;
+			bool use_spec = false;
+			if constexpr (std::is_same<R, float>::value) {
+				const bool ptr_ok = P.type == Pass::ROW
+					? ((P.pa.C == 2 ? 7u : P.pa.C == 4 ? 15u : 3u) & ((uintptr_t)(in + oin) | (uintptr_t)(out + oout))) == 0
+					: (15u & ((uintptr_t)(in + oin) | (uintptr_t)(out + oout))) == 0;
+				use_spec = P.has_spec && ptr_ok;
+				if (use_spec) {
+					PassArgs a;
+					fill_args(a, P.spa, pl, P, in + oin, out + oout, scale, fz);
+					rc = be_launch_spec(P.type == Pass::COL, P.spec.id, a, P.spec_nwg, stream);
+				}
+			}
+			if (!use_spec) {
+				PassArgsT<R> a;
+				fill_args(a, P.pa, pl, P, in + oin, out + oout, scale, fz);
 				rc = P.type == Pass::ROW ? be_launch_row(a, P.g, stream) : be_launch_col(a, P.g, stream);
 			}
 		}
@@ -346,9 +380,9 @@ int run_pass(const dspfft_plan_s *pl, const Pass &P, const float *in, float *out
 
 }  // namespace
 
-extern "C" int dspfft_plan_many_r2r(dspfft_plan *plan, int rank, const int *n, int howmany,
-                                    const int *inembed, int istride, int idist,
-                                    const int *onembed, int ostride, int odist, const int *kinds)
+static int plan_many(dspfft_plan *plan, int rank, const int *n, int howmany,
+                     const int *inembed, int istride, int idist,
+                     const int *onembed, int ostride, int odist, const int *kinds, bool f64)
 {
 	if (!plan) return fail(-1, "null plan pointer");
 	*plan = nullptr;
@@ -360,17 +394,17 @@ extern "C" int dspfft_plan_many_r2r(dspfft_plan *plan, int rank, const int *n, i
 		if ((inembed && inembed[a] < n[a] && a > 0) || (onembed && onembed[a] < n[a] && a > 0)) return fail(-1, "embed smaller than n");
 	}
 	dspfft_plan_s *pl = new dspfft_plan_s();
-	pl->rank = rank; pl->howmany = howmany; pl->scale = 1.f;
+	pl->rank = rank; pl->howmany = howmany; pl->scale = 1.0; pl->f64 = f64;
 	long long is = istride, os = ostride;
 	for (int a = rank - 1; a >= 0; a--) {
-		pl->n[a] = n[a]; pl->kinds[a] = kinds[a]; pl->in0[a] = pl->out0[a] = 1.f;
+		pl->n[a] = n[a]; pl->kinds[a] = kinds[a]; pl->in0[a] = pl->out0[a] = 1.0;
 		pl->axes[a].n = n[a]; pl->axes[a].is = is; pl->axes[a].os = os;
 		is *= inembed ? inembed[a] : n[a]; os *= onembed ? onembed[a] : n[a];
 	}
 	pl->batch.n = howmany; pl->batch.is = idist; pl->batch.os = odist;
 	size_t samples = (size_t)howmany;
 	for (int a = 0; a < rank; a++) samples *= (size_t)n[a];
-	pl->alg_bytes = samples * 8;
+	pl->alg_bytes = samples * (f64 ? 16 : 8);
 	bool first = true;
 	for (int a = rank - 1; a >= 0; a--) {
 		pl->passes.emplace_back();
@@ -380,6 +414,19 @@ extern "C" int dspfft_plan_many_r2r(dspfft_plan *plan, int rank, const int *n, i
 	}
 	*plan = pl;
 	return 0;
+}
+
+extern "C" int dspfft_plan_many_r2r(dspfft_plan *plan, int rank, const int *n, int howmany,
+                                    const int *inembed, int istride, int idist,
+                                    const int *onembed, int ostride, int odist, const int *kinds)
+{
+	return plan_many(plan, rank, n, howmany, inembed, istride, idist, onembed, ostride, odist, kinds, false);
+}
+extern "C" int dspfft_plan_many_r2r_f64(dspfft_plan *plan, int rank, const int *n, int howmany,
+                                        const int *inembed, int istride, int idist,
+                                        const int *onembed, int ostride, int odist, const int *kinds)
+{
+	return plan_many(plan, rank, n, howmany, inembed, istride, idist, onembed, ostride, odist, kinds, true);
 }
 
 extern "C" int dspfft_plan_r2r_2d(dspfft_plan *plan, int n0, int n1, int kind0, int kind1)
@@ -398,24 +445,55 @@ extern "C" int dspfft_plan_set_axis_scale0(dspfft_plan pl, int axis, float in_sc
 	if (!pl || axis < 0 || axis >= pl->rank) return fail(-1, "bad plan/axis");
 	pl->in0[axis] = in_scale0; pl->out0[axis] = out_scale0; return 0;
 }
+extern "C" int dspfft_plan_set_scale_f64(dspfft_plan pl, double scale)
+{
+	if (!pl) return fail(-1, "null plan");
+	pl->scale = scale; return 0;
+}
+extern "C" int dspfft_plan_set_axis_scale0_f64(dspfft_plan pl, int axis, double in_scale0, double out_scale0)
+{
+	if (!pl || axis < 0 || axis >= pl->rank) return fail(-1, "bad plan/axis");
+	pl->in0[axis] = in_scale0; pl->out0[axis] = out_scale0; return 0;
+}
 
-extern "C" int dspfft_execute(dspfft_plan pl, const float *d_in, float *d_out, void *stream)
+namespace {
+template <class R>
+int execute_t(dspfft_plan pl, const R *d_in, R *d_out, void *stream)
 {
 	if (!pl || !d_in || !d_out) return fail(-1, "null plan or buffer");
+	if (pl->f64 != std::is_same<R, double>::value) return fail(-1, "plan and buffers differ in sample type (f32 plan <-> dspfft_execute, f64 plan <-> dspfft_execute_f64)");
 	for (size_t i = 0; i < pl->passes.size(); i++) {
 		const Pass &P = pl->passes[i];
-		int rc = run_pass(pl, P, P.first ? d_in : d_out, d_out, i + 1 == pl->passes.size(), stream);
+		int rc = run_pass<R>(pl, P, P.first ? d_in : d_out, d_out, i + 1 == pl->passes.size(), stream);
 		if (rc) return rc;
 	}
 	return 0;
 }
+template <class R>
+int execute_masked_accumulate_t(dspfft_plan pl, const R *d_in, R *d_work, R *d_acc, const uint32_t *d_ids, uint32_t id, int elems_per_id, void *stream);
+}  // namespace
 
+extern "C" int dspfft_execute(dspfft_plan pl, const float *d_in, float *d_out, void *stream) { return execute_t<float>(pl, d_in, d_out, stream); }
+extern "C" int dspfft_execute_f64(dspfft_plan pl, const double *d_in, double *d_out, void *stream) { return execute_t<double>(pl, d_in, d_out, stream); }
 extern "C" int dspfft_execute_masked_accumulate(dspfft_plan pl, const float *d_in, float *d_work, float *d_acc,
                                                 const uint32_t *d_ids, uint32_t id, int elems_per_id, void *stream)
 {
+	return execute_masked_accumulate_t<float>(pl, d_in, d_work, d_acc, d_ids, id, elems_per_id, stream);
+}
+extern "C" int dspfft_execute_masked_accumulate_f64(dspfft_plan pl, const double *d_in, double *d_work, double *d_acc,
+                                                    const uint32_t *d_ids, uint32_t id, int elems_per_id, void *stream)
+{
+	return execute_masked_accumulate_t<double>(pl, d_in, d_work, d_acc, d_ids, id, elems_per_id, stream);
+}
+
+namespace {
+template <class R>
+int execute_masked_accumulate_t(dspfft_plan pl, const R *d_in, R *d_work, R *d_acc, const uint32_t *d_ids, uint32_t id, int elems_per_id, void *stream)
+{
 	if (!pl || !d_in || !d_work || !d_acc) return fail(-1, "null plan or buffer");
+	if (pl->f64 != std::is_same<R, double>::value) return fail(-1, "plan and buffers differ in sample type");
 	if (d_ids && elems_per_id < 1) return fail(-1, "elems_per_id must be >= 1");
-	if (d_ids && (unsigned long long)pl->alg_bytes / 8 * (unsigned)elems_per_id >= (1ull << 32))
+	if (d_ids && (unsigned long long)pl->alg_bytes / (2 * sizeof(R)) * (unsigned)elems_per_id >= (1ull << 32))
 		return fail(-2, "masked execution addresses elements with 32-bit offsets: plan too large");
 	const size_t np = pl->passes.size();
 	for (const Pass &P : pl->passes)
@@ -426,13 +504,14 @@ extern "C" int dspfft_execute_masked_accumulate(dspfft_plan pl, const float *d_i
 		Fuse fz;
 		if (firstp && d_ids) { fz.mask = d_ids; fz.id = id; fz.div = elems_per_id; }
 		fz.accumulate = lastp;
-		const float *src = firstp ? d_in : d_work;
-		float *dst = lastp ? d_acc : d_work;
-		int rc = run_pass(pl, P, src, dst, lastp, stream, fz);
+		const R *src = firstp ? d_in : d_work;
+		R *dst = lastp ? d_acc : d_work;
+		int rc = run_pass<R>(pl, P, src, dst, lastp, stream, fz);
 		if (rc) return rc;
 	}
 	return 0;
 }
+}  // namespace
 
 extern "C" int dspfft_scan_zigzag_frame_ids(uint32_t *d_ids, uint32_t w, uint32_t h, uint64_t step, void *s)
 {
@@ -446,8 +525,9 @@ extern "C" int dspfft_plan_num_passes(dspfft_plan pl) { return pl ? (int)pl->pas
 extern "C" int dspfft_execute_pass(dspfft_plan pl, int index, const float *d_in, float *d_out, void *stream)
 {
 	if (!pl || !d_in || !d_out || index < 0 || index >= (int)pl->passes.size()) return fail(-1, "bad plan, buffer or pass index");
+	if (pl->f64) return fail(-1, "dspfft_execute_pass takes f32 plans");
 	const Pass &P = pl->passes[index];
-	return run_pass(pl, P, P.first ? d_in : d_out, d_out, index + 1 == (int)pl->passes.size(), stream);
+	return run_pass<float>(pl, P, P.first ? d_in : d_out, d_out, index + 1 == (int)pl->passes.size(), stream);
 }
 
 extern "C" void dspfft_destroy_plan(dspfft_plan pl)

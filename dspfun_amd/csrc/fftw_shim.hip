@@ -57,41 +57,33 @@ struct Shim {
 	dspfft_plan plan = nullptr;
 	void *h_in = nullptr, *h_out = nullptr;
 	size_t in_len = 0, out_len = 0;          // elements
-	float *d_in = nullptr, *d_out = nullptr; // d_out == d_in when in-place
-	double *d_stage = nullptr;               // f64 API: staging for the conversion kernels
-	bool f64 = false;
+	size_t es = 4;                           // bytes per element: 4 (fftwf_) or 8 (fftw_)
+	void *d_in = nullptr, *d_out = nullptr;  // d_out == d_in when in-place
 	hipStream_t stream = nullptr;
 };
-
-__global__ void f64_to_f32(float *d, const double *s, size_t n)
-{
-	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = (float)s[i];
-}
-__global__ void f32_to_f64(double *d, const float *s, size_t n)
-{
-	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = (double)s[i];
-}
 
 Shim *make_plan(int rank, const int *n, int howmany, void *in, const int *inembed, int istride, int idist,
                 void *out, const int *onembed, int ostride, int odist, const int *kinds, bool f64)
 {
 	if (!in || !out || !n || !kinds) { fprintf(stderr, "dspfft: plan_many_r2r: null argument\n"); return nullptr; }
 	Shim *s = new Shim();
-	s->f64 = f64; s->h_in = in; s->h_out = out;
-	if (dspfft_plan_many_r2r(&s->plan, rank, n, howmany, inembed, istride, idist, onembed, ostride, odist, kinds)) {
+	s->es = f64 ? sizeof(double) : sizeof(float); s->h_in = in; s->h_out = out;
+	// fftw_ (double) plans compute in double on the device, as the reference's default build does on the CPU
+	const int rc = f64 ? dspfft_plan_many_r2r_f64(&s->plan, rank, n, howmany, inembed, istride, idist, onembed, ostride, odist, kinds)
+	                   : dspfft_plan_many_r2r(&s->plan, rank, n, howmany, inembed, istride, idist, onembed, ostride, odist, kinds);
+	if (rc) {
 		fprintf(stderr, "dspfft: plan_many_r2r failed: %s\n", dspfft_last_error());
 		delete s; return nullptr;
 	}
 	s->in_len = span(rank, n, inembed, istride, idist, howmany);
 	s->out_len = span(rank, n, onembed, ostride, odist, howmany);
-	bool ok = hipMalloc(&s->d_in, s->in_len * sizeof(float)) == hipSuccess;
+	bool ok = hipMalloc(&s->d_in, s->in_len * s->es) == hipSuccess;
 	if (in == out) s->d_out = s->d_in;
-	else ok = ok && hipMalloc(&s->d_out, s->out_len * sizeof(float)) == hipSuccess;
-	if (f64) { size_t m = s->in_len > s->out_len ? s->in_len : s->out_len; ok = ok && hipMalloc(&s->d_stage, m * sizeof(double)) == hipSuccess; }
+	else ok = ok && hipMalloc(&s->d_out, s->out_len * s->es) == hipSuccess;
 	ok = ok && hipStreamCreate(&s->stream) == hipSuccess;
 	if (!ok) {
-		fprintf(stderr, "dspfft: device allocation failed (%zu + %zu floats)\n", s->in_len, s->out_len);
-		dspfft_destroy_plan(s->plan); (void)hipFree(s->d_in); if (s->d_out != s->d_in) (void)hipFree(s->d_out); (void)hipFree(s->d_stage);
+		fprintf(stderr, "dspfft: device allocation failed (%zu + %zu elements)\n", s->in_len, s->out_len);
+		dspfft_destroy_plan(s->plan); (void)hipFree(s->d_in); if (s->d_out != s->d_in) (void)hipFree(s->d_out);
 		delete s; return nullptr;
 	}
 	return s;
@@ -100,27 +92,15 @@ Shim *make_plan(int rank, const int *n, int howmany, void *in, const int *inembe
 void run(Shim *s)
 {
 	if (!s) { fprintf(stderr, "dspfft: execute on a NULL plan\n"); return; }
-	const int grid = 2048;
-	bool ok = true;
-	if (!s->f64) {
-		ok = ok && hipMemcpyAsync(s->d_in, s->h_in, s->in_len * sizeof(float), hipMemcpyHostToDevice, s->stream) == hipSuccess;
-		// out-of-place with embedding gaps: elements the transform does not write must survive in `out`
-		if (s->d_out != s->d_in) ok = ok && hipMemcpyAsync(s->d_out, s->h_out, s->out_len * sizeof(float), hipMemcpyHostToDevice, s->stream) == hipSuccess;
-	} else {
-		ok = ok && hipMemcpyAsync(s->d_stage, s->h_in, s->in_len * sizeof(double), hipMemcpyHostToDevice, s->stream) == hipSuccess;
-		hipLaunchKernelGGL(f64_to_f32, dim3(grid), dim3(256), 0, s->stream, s->d_in, s->d_stage, s->in_len);
-		if (s->d_out != s->d_in) {
-			ok = ok && hipMemcpyAsync(s->d_stage, s->h_out, s->out_len * sizeof(double), hipMemcpyHostToDevice, s->stream) == hipSuccess;
-			hipLaunchKernelGGL(f64_to_f32, dim3(grid), dim3(256), 0, s->stream, s->d_out, s->d_stage, s->out_len);
-		}
+	bool ok = hipMemcpyAsync(s->d_in, s->h_in, s->in_len * s->es, hipMemcpyHostToDevice, s->stream) == hipSuccess;
+	// out-of-place with embedding gaps: elements the transform does not write must survive in `out`
+	if (s->d_out != s->d_in) ok = ok && hipMemcpyAsync(s->d_out, s->h_out, s->out_len * s->es, hipMemcpyHostToDevice, s->stream) == hipSuccess;
+	if (ok) {
+		const int rc = s->es == 8 ? dspfft_execute_f64(s->plan, (const double *)s->d_in, (double *)s->d_out, s->stream)
+		                          : dspfft_execute(s->plan, (const float *)s->d_in, (float *)s->d_out, s->stream);
+		if (rc) { fprintf(stderr, "dspfft: execute failed: %s\n", dspfft_last_error()); return; }
 	}
-	if (ok && dspfft_execute(s->plan, s->d_in, s->d_out, s->stream)) { fprintf(stderr, "dspfft: execute failed: %s\n", dspfft_last_error()); return; }
-	if (!s->f64) {
-		ok = ok && hipMemcpyAsync(s->h_out, s->d_out, s->out_len * sizeof(float), hipMemcpyDeviceToHost, s->stream) == hipSuccess;
-	} else {
-		hipLaunchKernelGGL(f32_to_f64, dim3(grid), dim3(256), 0, s->stream, s->d_stage, s->d_out, s->out_len);
-		ok = ok && hipMemcpyAsync(s->h_out, s->d_stage, s->out_len * sizeof(double), hipMemcpyDeviceToHost, s->stream) == hipSuccess;
-	}
+	ok = ok && hipMemcpyAsync(s->h_out, s->d_out, s->out_len * s->es, hipMemcpyDeviceToHost, s->stream) == hipSuccess;
 	ok = ok && hipStreamSynchronize(s->stream) == hipSuccess;
 	if (!ok) fprintf(stderr, "dspfft: execute: HIP error %s\n", hipGetErrorString(hipGetLastError()));
 }
@@ -130,7 +110,7 @@ void destroy(Shim *s)
 	if (!s) return;
 	dspfft_destroy_plan(s->plan);
 	if (s->d_out != s->d_in) (void)hipFree(s->d_out);
-	(void)hipFree(s->d_in); (void)hipFree(s->d_stage);
+	(void)hipFree(s->d_in);
 	if (s->stream) (void)hipStreamDestroy(s->stream);
 	delete s;
 }

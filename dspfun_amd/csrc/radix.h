@@ -18,21 +18,26 @@
 // host-side stand-ins for the HIP vector types (CPU emulation build only)
 struct float2 { float x, y; };
 struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(16) double2 { double x, y; };
 #endif
 
 namespace dspfft {
 
-struct cf { float x, y; };   // complex<float>, 8 bytes, same layout as float2
+// complex number over float (the tuned path; 8 bytes, same layout as float2) or double (the fftw_ double API)
+template <class R> struct cx { typedef R real; R x, y; };
+typedef cx<float> cf;
+typedef cx<double> cd;
+template <class R> struct same_t { typedef R type; };   // keeps a scalar argument out of template deduction
 
-DSP_HD cf cmk(float x, float y) { cf r; r.x = x; r.y = y; return r; }
-DSP_HD cf cadd(cf a, cf b) { return cmk(a.x + b.x, a.y + b.y); }
-DSP_HD cf csub(cf a, cf b) { return cmk(a.x - b.x, a.y - b.y); }
-DSP_HD cf cmul(cf a, cf b) { return cmk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-DSP_HD cf cmulc(cf a, cf b) { return cmk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a * conj(b)
-DSP_HD cf cconj(cf a) { return cmk(a.x, -a.y); }
-DSP_HD cf cscale(cf a, float s) { return cmk(a.x * s, a.y * s); }
-DSP_HD cf cmul_mi(cf a) { return cmk(a.y, -a.x); }   // a * (-i)
-DSP_HD cf cmul_pi(cf a) { return cmk(-a.y, a.x); }   // a * (+i)
+template <class R> DSP_HD cx<R> cmk(R x, typename same_t<R>::type y) { cx<R> r; r.x = x; r.y = y; return r; }
+template <class R> DSP_HD cx<R> cadd(cx<R> a, cx<R> b) { return cmk<R>(a.x + b.x, a.y + b.y); }
+template <class R> DSP_HD cx<R> csub(cx<R> a, cx<R> b) { return cmk<R>(a.x - b.x, a.y - b.y); }
+template <class R> DSP_HD cx<R> cmul(cx<R> a, cx<R> b) { return cmk<R>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+template <class R> DSP_HD cx<R> cmulc(cx<R> a, cx<R> b) { return cmk<R>(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a * conj(b)
+template <class R> DSP_HD cx<R> cconj(cx<R> a) { return cmk<R>(a.x, -a.y); }
+template <class R> DSP_HD cx<R> cscale(cx<R> a, typename same_t<R>::type s) { return cmk<R>(a.x * s, a.y * s); }
+template <class R> DSP_HD cx<R> cmul_mi(cx<R> a) { return cmk<R>(a.y, -a.x); }   // a * (-i)
+template <class R> DSP_HD cx<R> cmul_pi(cx<R> a) { return cmk<R>(-a.y, a.x); }   // a * (+i)
 
 // ---- compile-time trigonometry: cos/sin(2 pi k / n), exact octant reduction on (k, n) ----
 namespace ct {
@@ -75,11 +80,11 @@ constexpr cs cossin(long k, long n) {
 // Forward twiddle table w_R^e = exp(-2 pi i e / R), e in [0, R)
 template <int R>
 struct TwTab {
-	float re[R], im[R];
+	double re[R], im[R];      // rounded to the kernel's real type where they are used
 	constexpr TwTab() : re{}, im{} {
 		for (int e = 0; e < R; e++) {
 			ct::cs v = ct::cossin(e, R);
-			re[e] = float(v.c); im[e] = float(-v.s);
+			re[e] = v.c; im[e] = -v.s;
 		}
 	}
 };
@@ -95,16 +100,16 @@ DSP_HD void static_for(F &&f) {
 }
 
 // x * w_R^E with the trivial cases folded
-template <int R, int E>
-DSP_HD cf twmul(cf a) {
+template <int R, int E, class Re>
+DSP_HD cx<Re> twmul(cx<Re> a) {
 	constexpr int e = ((E % R) + R) % R;
 	if constexpr (e == 0) return a;
-	else if constexpr (2 * e == R) return cmk(-a.x, -a.y);
+	else if constexpr (2 * e == R) return cmk<Re>(-a.x, -a.y);
 	else if constexpr (4 * e == R) return cmul_mi(a);
 	else if constexpr (4 * e == 3 * R) return cmul_pi(a);
 	else {
-		constexpr float wr = TwHolder<R>::tab.re[e], wi = TwHolder<R>::tab.im[e];
-		return cmk(a.x * wr - a.y * wi, a.x * wi + a.y * wr);
+		constexpr Re wr = (Re)TwHolder<R>::tab.re[e], wi = (Re)TwHolder<R>::tab.im[e];
+		return cmk<Re>(a.x * wr - a.y * wi, a.x * wi + a.y * wr);
 	}
 }
 
@@ -118,13 +123,13 @@ constexpr bool is_prime_radix(int r) { return first_factor(r) == r; }
 
 template <int R> struct Dft;
 
-template <> struct Dft<1> { static DSP_HD void run(cf *) {} };
+template <> struct Dft<1> { template <class C> static DSP_HD void run(C *) {} };
 template <> struct Dft<2> {
-	static DSP_HD void run(cf *x) { cf a = x[0], b = x[1]; x[0] = cadd(a, b); x[1] = csub(a, b); }
+	template <class C> static DSP_HD void run(C *x) { C a = x[0], b = x[1]; x[0] = cadd(a, b); x[1] = csub(a, b); }
 };
 template <> struct Dft<4> {
-	static DSP_HD void run(cf *x) {
-		cf s0 = cadd(x[0], x[2]), s1 = csub(x[0], x[2]), s2 = cadd(x[1], x[3]), s3 = cmul_mi(csub(x[1], x[3]));
+	template <class C> static DSP_HD void run(C *x) {
+		C s0 = cadd(x[0], x[2]), s1 = csub(x[0], x[2]), s2 = cadd(x[1], x[3]), s3 = cmul_mi(csub(x[1], x[3]));
 		x[0] = cadd(s0, s2); x[1] = cadd(s1, s3); x[2] = csub(s0, s2); x[3] = csub(s1, s3);
 	}
 };
@@ -132,26 +137,27 @@ template <> struct Dft<4> {
 // odd primes: pair up q and p-q
 template <int P>
 struct DftOddPrime {
-	static DSP_HD void run(cf *x) {
+	template <class C> static DSP_HD void run(C *x) {
+		typedef typename C::real Re;
 		constexpr int H = (P - 1) / 2;
-		cf a[H], b[H];
+		C a[H], b[H];
 		static_for<0, H>([&](auto q) { a[q] = cadd(x[q + 1], x[P - 1 - q]); b[q] = csub(x[q + 1], x[P - 1 - q]); });
-		cf x0 = x[0];
-		cf sum = x0;
+		C x0 = x[0];
+		C sum = x0;
 		static_for<0, H>([&](auto q) { sum = cadd(sum, a[q]); });
 		x[0] = sum;
 		static_for<1, H + 1>([&](auto r) {
-			float cr = x0.x, ci = x0.y, sr = 0.f, si = 0.f;
+			Re cr = x0.x, ci = x0.y, sr = 0, si = 0;
 			static_for<0, H>([&](auto q) {
 				constexpr int e = ((q + 1) * r) % P;
-				constexpr float c = TwHolder<P>::tab.re[e];
-				constexpr float s = -TwHolder<P>::tab.im[e];          // sin(2 pi e / P)
+				constexpr Re c = (Re)TwHolder<P>::tab.re[e];
+				constexpr Re s = (Re)-TwHolder<P>::tab.im[e];         // sin(2 pi e / P)
 				cr += a[q].x * c; ci += a[q].y * c;
 				sr += b[q].x * s; si += b[q].y * s;
 			});
 			// X[r] = C - i S ; X[P-r] = C + i S
-			x[r] = cmk(cr + si, ci - sr);
-			x[P - r] = cmk(cr - si, ci + sr);
+			x[r] = cmk<Re>(cr + si, ci - sr);
+			x[P - r] = cmk<Re>(cr - si, ci + sr);
 		});
 	}
 };
@@ -164,12 +170,12 @@ template <> struct Dft<13> : DftOddPrime<13> {};
 // composite: R = P*Q, decimation in frequency; natural order in and out
 template <int R>
 struct Dft {
-	static DSP_HD void run(cf *x) {
+	template <class C> static DSP_HD void run(C *x) {
 		constexpr int P = first_factor(R), Q = R / P;
 		static_assert(P != R, "prime radix without a specialisation");
-		cf y[P][Q];
+		C y[P][Q];
 		static_for<0, Q>([&](auto m) {
-			cf t[P];
+			C t[P];
 			static_for<0, P>([&](auto n1) { t[n1] = x[n1 * Q + m]; });
 			Dft<P>::run(t);
 			static_for<0, P>([&](auto k1) { y[k1][m] = twmul<R, m * k1>(t[k1]); });

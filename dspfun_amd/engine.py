@@ -25,23 +25,29 @@ def _ia(v):
 
 
 class Plan:
-    def __init__(self, handle, lib):
+    """dtype "f32" (default; the fftwf_ API, COEFF_PRECISION=F) or "f64" (the fftw_ API of spec's, zoom's and
+    applybasis's default build, include/precision.h:50-53): buffers, arithmetic and fused scales in that type."""
+
+    def __init__(self, handle, lib, f64=False):
         self._h = handle
         self._lib = lib
+        self.f64 = f64
 
     @classmethod
-    def many_r2r(cls, n, kinds, howmany=1, inembed=None, istride=1, idist=0, onembed=None, ostride=1, odist=0, lib=None):
+    def many_r2r(cls, n, kinds, howmany=1, inembed=None, istride=1, idist=0, onembed=None, ostride=1, odist=0, lib=None, dtype="f32"):
+        if dtype not in ("f32", "f64"):
+            raise ValueError("dtype must be 'f32' or 'f64'")
         lib = lib or _lib.load()
         n = list(n)
         kinds = list(kinds)
         if len(kinds) != len(n):
             raise ValueError("one kind per transformed dimension")
         h = C.c_void_p()
-        rc = lib.dspfft_plan_many_r2r(C.byref(h), len(n), _ia(n), howmany, _ia(inembed), istride, idist,
-                                      _ia(onembed), ostride, odist, _ia(kinds))
+        make = lib.dspfft_plan_many_r2r_f64 if dtype == "f64" else lib.dspfft_plan_many_r2r
+        rc = make(C.byref(h), len(n), _ia(n), howmany, _ia(inembed), istride, idist, _ia(onembed), ostride, odist, _ia(kinds))
         if rc:
             raise DspfftError(lib.dspfft_last_error().decode())
-        return cls(h, lib)
+        return cls(h, lib, dtype == "f64")
 
     @classmethod
     def r2r_2d(cls, n0, n1, kind0, kind1, lib=None):
@@ -52,21 +58,28 @@ class Plan:
         return cls(h, lib)
 
     @classmethod
-    def image(cls, h, w, c, kind, lib=None):
+    def image(cls, h, w, c, kind, lib=None, dtype="f32"):
         """The image tools' plan: rank 2 {h,w}, howmany=c, stride=c, dist=1 (interleaved HWC)."""
-        return cls.many_r2r([h, w], [kind, kind], howmany=c, istride=c, idist=1, ostride=c, odist=1, lib=lib)
+        return cls.many_r2r([h, w], [kind, kind], howmany=c, istride=c, idist=1, ostride=c, odist=1, lib=lib, dtype=dtype)
 
     def set_scale(self, scale):
-        self._check(self._lib.dspfft_plan_set_scale(self._h, scale))
+        if self.f64:
+            self._check(self._lib.dspfft_plan_set_scale_f64(self._h, scale))
+        else:
+            self._check(self._lib.dspfft_plan_set_scale(self._h, scale))
         return self
 
     def set_axis_scale0(self, axis, in_scale0=1.0, out_scale0=1.0):
-        self._check(self._lib.dspfft_plan_set_axis_scale0(self._h, axis, in_scale0, out_scale0))
+        if self.f64:
+            self._check(self._lib.dspfft_plan_set_axis_scale0_f64(self._h, axis, in_scale0, out_scale0))
+        else:
+            self._check(self._lib.dspfft_plan_set_axis_scale0(self._h, axis, in_scale0, out_scale0))
         return self
 
     def execute(self, d_in, d_out=None, stream=0):
         d_out = d_in if d_out is None else d_out
-        self._check(self._lib.dspfft_execute(self._h, C.c_void_p(d_in), C.c_void_p(d_out), C.c_void_p(stream)))
+        run = self._lib.dspfft_execute_f64 if self.f64 else self._lib.dspfft_execute
+        self._check(run(self._h, C.c_void_p(d_in), C.c_void_p(d_out), C.c_void_p(stream)))
 
     @property
     def num_passes(self):
@@ -78,7 +91,8 @@ class Plan:
 
     def execute_masked_accumulate(self, d_in, d_work, d_acc, d_ids=0, frame_id=0, elems_per_id=1, stream=0):
         """scan/scan.c:429-459 fused: d_acc += plan(d_in where ids == frame_id)"""
-        self._check(self._lib.dspfft_execute_masked_accumulate(
+        run = self._lib.dspfft_execute_masked_accumulate_f64 if self.f64 else self._lib.dspfft_execute_masked_accumulate
+        self._check(run(
             self._h, C.c_void_p(d_in), C.c_void_p(d_work), C.c_void_p(d_acc), C.c_void_p(d_ids or None), frame_id, elems_per_id, C.c_void_p(stream)))
 
     def describe(self):

@@ -7,6 +7,8 @@
  *
  *   spec_gpu  spec  in.{ppm,pf} out.pf     uniform-range coefficients in [-1,1]
  *   spec_gpu  ispec in.pf       out.pf     image back
+ * spec_gpu_d is the same source built with -DCOEFF_PRECISION_D: coeff = double and fftw(call) = fftw_call, the
+ * reference's default build of spec (spec/Makefile:1); its files are "PD" (f64 samples).
  */
 #include <math.h>
 #include <stdio.h>
@@ -24,8 +26,8 @@ int main(int argc, char *argv[])
 	}
 	const int inverse = !strcmp(argv[1], "ispec");
 	size_t w, h, d = 3, l;
-	float *pix;
-	if (read_image(argv[2], &w, &h, &pix)) { fprintf(stderr, "cannot read %s\n", argv[2]); return 1; }
+	coeff *pix;
+	if (read_image_coeff(argv[2], &w, &h, &pix)) { fprintf(stderr, "cannot read %s\n", argv[2]); return 1; }
 	l = w * h * d;
 
 	coeff *f = fftw(alloc_real)(l);                                  /* spec.c:59 / ispec.c:80 */
@@ -58,7 +60,7 @@ int main(int argc, char *argv[])
 		fftw(execute)(p);
 		fftw(destroy_plan)(p);
 	}
-	int rc = write_pf(argv[3], w, h, f);
+	int rc = write_coeff(argv[3], w, h, f);
 	fftw(free)(f);
 	fftw(cleanup)();
 	return rc;

@@ -56,6 +56,21 @@ int dspfft_execute(dspfft_plan plan, const float *d_in, float *d_out, void *hip_
 int dspfft_plan_num_passes(dspfft_plan plan);
 int dspfft_execute_pass(dspfft_plan plan, int index, const float *d_in, float *d_out, void *hip_stream);
 
+/* Double-precision samples: the fftw_ (no suffix) API that spec, zoom and applybasis use in their default
+ * build (COEFF_PRECISION ?= D: spec/Makefile:1, applybasis/Makefile:1; include/precision.h:50-53,66-72).
+ * Same geometry and call-site contract as above with `double` buffers; arithmetic, twiddle tables and the
+ * fused scales are double.  These plans run the runtime-geometry kernels (the compile-time-specialised
+ * ones are f32 only).  The _f64 scale setters also work on f32 plans (rounded to float there);
+ * dspfft_execute on an f64 plan, or dspfft_execute_f64 on an f32 plan, fails with an error. */
+int dspfft_plan_many_r2r_f64(dspfft_plan *plan, int rank, const int *n, int howmany,
+                             const int *inembed, int istride, int idist,
+                             const int *onembed, int ostride, int odist, const int *kinds);
+int dspfft_plan_set_scale_f64(dspfft_plan plan, double scale);
+int dspfft_plan_set_axis_scale0_f64(dspfft_plan plan, int axis, double in_scale0, double out_scale0);
+int dspfft_execute_f64(dspfft_plan plan, const double *d_in, double *d_out, void *hip_stream);
+int dspfft_execute_masked_accumulate_f64(dspfft_plan plan, const double *d_in, double *d_work, double *d_acc,
+                                         const uint32_t *d_ids, uint32_t id, int elems_per_id, void *hip_stream);
+
 /* Replaces fftw(destroy_plan). */
 void dspfft_destroy_plan(dspfft_plan plan);
 
@@ -63,7 +78,7 @@ void dspfft_destroy_plan(dspfft_plan plan);
 int dspfft_plan_describe(dspfft_plan plan, char *buf, size_t buflen);
 
 /* Algorithmic bytes one execute moves (read once + write once per transformed sample, 8 B/sample
- * for f32) -- the numerator of bench.py's roofline figure. */
+ * for f32, 16 for f64) -- the numerator of bench.py's roofline figure. */
 size_t dspfft_plan_algorithmic_bytes(dspfft_plan plan);
 
 const char *dspfft_last_error(void);

@@ -24,11 +24,13 @@ const char *be_name() { return "cpu-emulation (tests only)"; }
 
 #define PHASE(stmt) for (int tid = 0; tid < nthr; tid++) { stmt; }
 
-int be_launch_row(const PassArgs &a, const LaunchGeom &g, void *)
+template <class R>
+static int emul_row(const PassArgsT<R> &a, const LaunchGeom &g)
 {
-	std::vector<unsigned char> lds(g.lds_bytes + 16);
-	float *raw = (float *)lds.data();
-	cf *buf = (cf *)(lds.data() + g.raw_bytes);
+	std::vector<unsigned char> lds(g.lds_bytes + 32);
+	unsigned char *base = (unsigned char *)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
+	R *raw = (R *)base;
+	cx<R> *buf = (cx<R> *)(base + g.raw_bytes);
 	const int nthr = g.nthr, L = a.N / 2;
 	for (int wg = 0; wg < g.nwg; wg++) {
 		long long bin, bout;
@@ -46,10 +48,11 @@ int be_launch_row(const PassArgs &a, const LaunchGeom &g, void *)
 	return 0;
 }
 
-int be_launch_col(const PassArgs &a, const LaunchGeom &g, void *)
+template <class R>
+static int emul_col(const PassArgsT<R> &a, const LaunchGeom &g)
 {
-	std::vector<unsigned char> lds(g.lds_bytes + 16);
-	cf *buf = (cf *)lds.data();
+	std::vector<unsigned char> lds(g.lds_bytes + 32);
+	cx<R> *buf = (cx<R> *)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
 	const int nthr = g.nthr;
 	for (int wg = 0; wg < g.nwg; wg++) {
 		long long bin, bout; int valid;
@@ -63,9 +66,10 @@ int be_launch_col(const PassArgs &a, const LaunchGeom &g, void *)
 	return 0;
 }
 
-int be_launch_dense(const DenseArgs &a, const LaunchGeom &g, void *)
+template <class R>
+static int emul_dense(const DenseArgsT<R> &a, const LaunchGeom &g)
 {
-	std::vector<float> x(a.N);
+	std::vector<R> x(a.N);
 	const int nthr = g.nthr;
 	for (int wg = 0; wg < g.nwg; wg++) {
 		long long bin, bout;
@@ -75,6 +79,13 @@ int be_launch_dense(const DenseArgs &a, const LaunchGeom &g, void *)
 	}
 	return 0;
 }
+
+int be_launch_row(const PassArgs &a, const LaunchGeom &g, void *) { return emul_row(a, g); }
+int be_launch_col(const PassArgs &a, const LaunchGeom &g, void *) { return emul_col(a, g); }
+int be_launch_dense(const DenseArgs &a, const LaunchGeom &g, void *) { return emul_dense(a, g); }
+int be_launch_row(const PassArgsD &a, const LaunchGeom &g, void *) { return emul_row(a, g); }
+int be_launch_col(const PassArgsD &a, const LaunchGeom &g, void *) { return emul_col(a, g); }
+int be_launch_dense(const DenseArgsD &a, const LaunchGeom &g, void *) { return emul_dense(a, g); }
 
 // one "workgroup" per line / tile, as in backend_hip.hip: prefetch (global loads into the per-thread State),
 // then the barrier-separated phases

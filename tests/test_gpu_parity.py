@@ -295,6 +295,47 @@ def test_fused_scan_step_c4_like(gpu):
     assert np.abs(acc.cpu().numpy() - x).max() <= 5e-6
 
 
+# ---- double precision (the fftw_ API: spec / zoom / applybasis default build, include/precision.h:50-53) ----
+TOL64 = 1e-13
+
+
+@pytest.mark.parametrize("h,w,c", [(48, 64, 3), (270, 480, 3), (17, 40, 3), (45, 50, 2), (9, 10, 4), (60, 90, 1)])
+@pytest.mark.parametrize("kind", [5, 4])
+def test_f64_plan_vs_oracle(gpu, h, w, c, kind):
+    from dspfun_amd import Plan
+    x = ol.synth_f32(h * 7 + w, h * w * c).astype(np.float64).reshape(h, w, c) + 1e-9
+    p = Plan.image(h, w, c, kind, dtype="f64")
+    assert "f64" in p.describe()
+    d = gpu.from_numpy(x.copy()).to("cuda:0")
+    p.execute(d.data_ptr())
+    gpu.cuda.synchronize()
+    ref = ol.dct2d_interleaved(x, kind, impl="port", threads=8) if h * w > 20000 else ol.dct2d_interleaved(x, kind)
+    check(d.cpu().numpy(), ref, tol=TOL64)
+
+
+def test_f64_c2_frame_roundtrip_with_spec_normalisation(gpu):
+    """3840x2160x3 in double: spec.c:63-78 then ispec.c:153-167, normalisation fused, against the f64 port and
+    by the round trip"""
+    from dspfun_amd import Plan
+    h, w, c = 2160, 3840, 3
+    x = ol.synth_f32(0xD5F0002, h * w * c).astype(np.float64).reshape(h, w, c)
+    r2 = np.sqrt(2.0)
+    fwd = Plan.image(h, w, c, 5, dtype="f64").set_scale(1.0 / (2.0 * w * h))
+    inv = Plan.image(h, w, c, 4, dtype="f64").set_scale(0.5)
+    for a in range(2):
+        fwd.set_axis_scale0(a, 1.0, 1.0 / r2)
+        inv.set_axis_scale0(a, r2, 1.0)
+    d = gpu.from_numpy(x).to("cuda:0")
+    fwd.execute(d.data_ptr())
+    gpu.cuda.synchronize()
+    ref = np.ascontiguousarray(ol.dct2d_interleaved(x, 5, impl="port", threads=8))
+    ol.lib().oracle_spec_normalise_f64(ref.ctypes.data, w, h, c)
+    check(d.cpu().numpy(), ref, tol=TOL64)
+    inv.execute(d.data_ptr())
+    gpu.cuda.synchronize()
+    assert np.abs(d.cpu().numpy() - x).max() <= 1e-13
+
+
 # ---- zoom (SURVEY.md 8 row a7): dense basis product on the f32 matrix cores ----
 @pytest.mark.parametrize("w,h,scale,off,btype", [(12, 10, 3, 0.0, 0), (40, 24, 2, 0.5, 0), (33, 17, 2, 0.0, 2), (24, 40, 1, 0.0, 1), (64, 48, 0.5, 0.0, 0)])
 def test_zoom_small_vs_oracle(gpu, w, h, scale, off, btype):

@@ -226,3 +226,90 @@ def test_fused_scan_step(h, w, c):
         ref += ol.dct2d_interleaved(rec, REDFT01, impl="port")
         assert np.abs(acc - ref).max() < 1e-5, f
     assert np.abs(acc - x).max() < 1e-5
+
+
+# ---- double-precision plans (the fftw_ API of spec's default build, include/precision.h:50-53) ----
+TOL64 = 5e-14   # f64 FFT-based kernels vs the f64 direct-definition restatement, relative to max|ref|
+
+
+def run64(plan, x, out=None):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    if out is None:
+        plan.execute(x.ctypes.data)
+        return x
+    plan.execute(x.ctypes.data, out.ctypes.data)
+    return out
+
+
+@pytest.mark.parametrize("h,w,c", [(48, 64, 3), (30, 60, 3), (8, 2, 3), (60, 90, 1), (15, 27, 3), (7, 13, 2), (9, 10, 4), (17, 40, 3), (1, 8, 3)])
+@pytest.mark.parametrize("kind", [REDFT10, REDFT01])
+def test_f64_image_plan(h, w, c, kind):
+    x = ol.synth_f32(h * 1000 + w, h * w * c).astype(np.float64).reshape(h, w, c) + 1e-9 * np.arange(h * w * c).reshape(h, w, c)
+    ref = ol.dct2d_interleaved(x, kind)                       # direct definition, f64
+    p = Plan.image(h, w, c, kind, lib=emul(), dtype="f64")
+    assert "f64" in p.describe()
+    got = run64(p, x.copy())
+    assert relerr(got, ref) < TOL64, p.describe()
+    # the f32 plan of the same geometry cannot get there: the f64 path is not a converted f32 path
+    p32 = Plan.image(h, w, c, kind, lib=emul())
+    got32 = run(p32, x.astype(np.float32))
+    if h * w > 16:
+        assert relerr(got32, ref) > 100 * TOL64
+
+
+@pytest.mark.parametrize("N", [2, 6, 16, 30, 64, 270, 1080, 3840, 1, 3, 17, 45, 97, 135])
+def test_f64_1d_lengths(N):
+    x = ol.synth_f32(N, N).astype(np.float64) * (1 + 2.0 ** -30)
+    for kind in (REDFT10, REDFT01):
+        ref = ol.r2r_many(x, [N], [kind])
+        p = Plan.many_r2r([N], [kind], lib=emul(), dtype="f64")
+        assert relerr(run64(p, x.copy()), ref) < TOL64, (N, p.describe())
+    xb = ol.synth_f32(N + 5, N * 6).astype(np.float64).reshape(N, 6)
+    for kind in (REDFT10, REDFT01):
+        ref = np.stack([ol.r2r_many(xb[:, t].copy(), [N], [kind]) for t in range(6)], axis=1)
+        p = Plan.many_r2r([N], [kind], howmany=6, istride=6, idist=1, ostride=6, odist=1, lib=emul(), dtype="f64")
+        assert relerr(run64(p, xb.copy()), ref) < TOL64, (N, p.describe())
+
+
+def test_f64_spec_normalisation_roundtrip_and_out_of_place():
+    """spec/spec.c:63-78 then spec/ispec.c:153-167 in double, normalisation fused; out-of-place leaves the input alone"""
+    h, w, c = 36, 60, 3
+    x = ol.synth_f32(5, h * w * c).astype(np.float64).reshape(h, w, c)
+    r2 = np.sqrt(2.0)
+    fwd = Plan.image(h, w, c, REDFT10, lib=emul(), dtype="f64").set_scale(1.0 / (2.0 * w * h))
+    inv = Plan.image(h, w, c, REDFT01, lib=emul(), dtype="f64").set_scale(0.5)
+    for a in range(2):
+        fwd.set_axis_scale0(a, 1.0, 1.0 / r2)
+        inv.set_axis_scale0(a, r2, 1.0)
+    f = np.full_like(x, np.nan)
+    keep = x.copy()
+    run64(fwd, x, f)
+    assert np.array_equal(x, keep)
+    ref = np.ascontiguousarray(ol.dct2d_interleaved(x, REDFT10))
+    ol.lib().oracle_spec_normalise_f64(ref.ctypes.data, w, h, c)
+    assert np.abs(f - ref).max() < 1e-15 * 50
+    y = run64(inv, f.copy())
+    assert np.abs(y - x).max() < 1e-14
+
+
+def test_f64_fused_scan_step_and_type_mismatch():
+    h, w, c = 24, 40, 3
+    L = emul()
+    x = ol.synth_f32(9, h * w * c).astype(np.float64).reshape(h, w, c)
+    coeffs = x.copy()
+    Plan.image(h, w, c, REDFT10, lib=L, dtype="f64").set_scale(1.0 / (4 * w * h)).execute(coeffs.ctypes.data)
+    ids = np.zeros(h * w, dtype=np.uint32)
+    nframes = 4
+    step = (h * w + nframes - 1) // nframes
+    assert L.dspfft_scan_zigzag_frame_ids(ids.ctypes.data, w, h, step, None) == 0
+    inv = Plan.image(h, w, c, REDFT01, lib=L, dtype="f64")
+    acc = np.ascontiguousarray(np.broadcast_to(coeffs[0, 0], (h, w, c)).copy())
+    work = np.zeros_like(acc)
+    for f in range(nframes):
+        inv.execute_masked_accumulate(coeffs.ctypes.data, work.ctypes.data, acc.ctypes.data, ids.ctypes.data, f, c)
+    assert np.abs(acc - x).max() < 1e-14
+    # an f64 plan refuses the f32 entry point and vice versa
+    import ctypes as C
+    assert L.dspfft_execute(inv._h, C.c_void_p(acc.ctypes.data), C.c_void_p(acc.ctypes.data), None) != 0
+    p32 = Plan.image(h, w, c, REDFT01, lib=L)
+    assert L.dspfft_execute_f64(p32._h, C.c_void_p(acc.ctypes.data), C.c_void_p(acc.ctypes.data), None) != 0
