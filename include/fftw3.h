@@ -61,9 +61,10 @@ int fftwf_import_wisdom_from_filename(const char *filename);   /* motion.c:519 *
 int fftwf_export_wisdom_to_filename(const char *filename);     /* motion.c:557 */
 
 /* ---------------- double precision: COEFF_PRECISION=D (spec/Makefile, zoom/Makefile default) ----------------
- * Same engine: the arrays are converted to f32 on the device, transformed, and converted back, so
- * results carry f32 accuracy (~1e-7 of max|coeff|).  Build the tools with COEFF_PRECISION=F to avoid
- * the conversion passes. */
+ * Same engine with double buffers, double arithmetic and double tables on the device
+ * (dspfft_plan_many_r2r_f64 / dspfft_execute_f64): results agree with a double FFTW to ~1e-14 of max|coeff|.
+ * These plans run the runtime-geometry kernels; the tuned kernels are single precision, so build the tools
+ * with COEFF_PRECISION=F when f32 accuracy is enough. */
 typedef struct fftw_plan_s *fftw_plan;
 double *fftw_alloc_real(size_t n);
 void fftw_free(void *p);
