@@ -80,4 +80,25 @@ def rt2():
 ms = timeit(rt2, reps=3, warm=1)
 res["motion_c5_luma_per_frame_2d_roundtrip"] = {"ms": round(ms, 2), "Msamples_per_s": round(n / ms / 1e3, 1), "algorithmic_GBps": round(n * 16 / ms / 1e6, 1),
                                                 "frac_of_8TBps": round(n * 16 / ms / 1e6 / 8000, 4)}
+del vol
+# ---- double precision (fftw_ API, spec's default build): 4K frame roundtrip on the runtime-geometry kernels ----
+h, w, c = 2160, 3840, 3
+x64 = torch.rand(h, w, c, device=dev, dtype=torch.float64)
+f64f = Plan.image(h, w, c, REDFT10, dtype="f64").set_scale(1.0 / (4.0 * w * h))
+f64i = Plan.image(h, w, c, REDFT01, dtype="f64")
+def rt64():
+    f64f.execute(x64.data_ptr()); f64i.execute(x64.data_ptr())
+ms = timeit(rt64, reps=10, warm=2)
+res["f64_c2_frame_roundtrip"] = {"ms": round(ms, 3), "Mpixels_per_s": round(h * w / ms / 1e3, 1), "algorithmic_GBps": round(h * w * c * 32 / ms / 1e6, 1),
+                                 "frac_of_8TBps": round(h * w * c * 32 / ms / 1e6 / 8000, 4), "plan": f64f.describe()}
+# the same frame in f32 with the specialised kernels disabled (DSPFFT_NO_SPEC=1 at plan time): the generic kernels' own speed
+os.environ["DSPFFT_NO_SPEC"] = "1"
+x32 = torch.rand(h, w, c, device=dev)
+g32f = Plan.image(h, w, c, REDFT10).set_scale(1.0 / (4.0 * w * h))
+g32i = Plan.image(h, w, c, REDFT01)
+del os.environ["DSPFFT_NO_SPEC"]
+def rt32g():
+    g32f.execute(x32.data_ptr()); g32i.execute(x32.data_ptr())
+ms = timeit(rt32g, reps=10, warm=2)
+res["f32_generic_c2_frame_roundtrip"] = {"ms": round(ms, 3), "Mpixels_per_s": round(h * w / ms / 1e3, 1)}
 print(json.dumps(res, indent=1))
