@@ -12,7 +12,16 @@
 	X(960, 3, 192, 2, 16, 15)          \
 	X(256, 3, 192, 8, 16)              \
 	X(1920, 1, 128, 4, 16, 15)         \
-	X(960, 1, 64, 2, 16, 15)
+	X(960, 1, 64, 2, 16, 15)           \
+	X(4096, 3, 512, 8, 16, 16)         \
+	X(2560, 3, 512, 8, 10, 16)         \
+	X(2048, 3, 256, 4, 16, 16)         \
+	X(1280, 3, 256, 4, 10, 16)         \
+	X(1024, 3, 192, 4, 8, 16)          \
+	X(720, 3, 128, 4, 6, 15)           \
+	X(640, 3, 128, 4, 5, 16)           \
+	X(512, 3, 64, 16, 16)              \
+	X(1280, 1, 128, 4, 10, 16)
 
 // (An outer radix-2 column split -- half of the tile parked in registers so 2160-row tiles could be K = 16 wide in
 // the same 69 KB -- was built and measured SLOWER at every size tried: 2160 (K=16): 57/68 us vs 49/53 us; 4320 (K=8):
@@ -25,4 +34,12 @@
 	X(4320, 8, 1024, 2, 12, 12, 15)    \
 	X(4320, 4, 512, 2, 12, 12, 15)     \
 	X(540, 16, 256, 4, 9, 15)          \
-	X(256, 16, 256, 4, 4, 16)
+	X(256, 16, 256, 4, 4, 16)          \
+	X(4096, 8, 1024, 16, 16, 16)       \
+	X(4096, 4, 512, 16, 16, 16)        \
+	X(2048, 8, 512, 8, 16, 16)         \
+	X(1440, 8, 512, 8, 12, 15)         \
+	X(1024, 16, 512, 4, 16, 16)        \
+	X(720, 16, 256, 6, 8, 15)          \
+	X(512, 16, 256, 4, 8, 16)          \
+	X(480, 16, 256, 4, 8, 15)

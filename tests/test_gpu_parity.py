@@ -261,6 +261,24 @@ def test_generic_and_specialised_kernels_agree(gpu):
     assert float((a - b).abs().max() / a.abs().max()) < 2e-6
 
 
+@pytest.mark.parametrize("h,w,c", [(720, 1280, 3), (1440, 2560, 3), (480, 640, 3), (480, 720, 3), (512, 512, 3), (1024, 1024, 3), (2048, 2048, 3),
+                                    (2160, 4096, 3), (4096, 4096, 3), (720, 1280, 1), (4096, 4100, 1)])
+def test_common_resolutions_specialised_vs_oracle(gpu, h, w, c):
+    """spec_list.h's entries for the common frame sizes: both transforms against the f64 port, and a roundtrip"""
+    from dspfun_amd import REDFT10, REDFT01
+    x = ol.synth_f32(h + w, h * w * c).reshape(h, w, c)
+    fwd, inv = plan_image(h, w, c, REDFT10), plan_image(h, w, c, REDFT01)
+    assert fwd.describe().count("*") >= (2 if w != 4100 else 1), fwd.describe()
+    d = dev(gpu, x)
+    fwd.execute(d.data_ptr())
+    gpu.cuda.synchronize()
+    check(d.cpu().numpy(), ol.dct2d_interleaved(x.astype(np.float64), REDFT10, impl="port", threads=8))
+    inv.set_scale(1.0 / (4.0 * h * w)).execute(d.data_ptr())
+    gpu.cuda.synchronize()
+    # 4100 = 2^2 5^2 41 runs the O(N^2) dense kernel along x: 4100-term f32 sums
+    assert np.abs(d.cpu().numpy() - x).max() <= (2e-6 if w != 4100 else 1e-5)
+
+
 def test_fused_scan_step_c4_like(gpu):
     """the fused per-frame step (dspfft_execute_masked_accumulate) against the unfused device path
     and the f64 restatement, 960x540x3, zigzag, 6 frames"""
