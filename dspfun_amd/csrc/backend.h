@@ -27,6 +27,9 @@ int be_launch_dense(const DenseArgs &a, const LaunchGeom &g, void *stream);
 int be_launch_row(const PassArgsD &a, const LaunchGeom &g, void *stream);
 int be_launch_col(const PassArgsD &a, const LaunchGeom &g, void *stream);
 int be_launch_dense(const DenseArgsD &a, const LaunchGeom &g, void *stream);
+// COL pass with the tile's DFT done by Bluestein's convolution (lengths with prime factors > 13)
+int be_launch_blue(const BlueArgs &a, const LaunchGeom &g, void *stream);
+int be_launch_blue(const BlueArgsD &a, const LaunchGeom &g, void *stream);
 
 // compile-time-specialised kernels (dct_spec.h / spec_list.h)
 struct SpecInfo { int id, nthr, P; size_t lds; };   // P = C (ROW) or K (COL)

@@ -61,6 +61,35 @@ __global__ void __launch_bounds__(512) col_kernel(const PassArgsT<R> a)
 	else col_unpack3(a, buf, bout, valid, tid, nthr);
 }
 
+template <int KIND, class R>
+__global__ void __launch_bounds__(512) blue_kernel(const BlueArgsT<R> a)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+	cx<R> *A = reinterpret_cast<cx<R> *>(lds);
+	const int tid = threadIdx.x, nthr = blockDim.x;
+	long long bin, bout; int valid;
+	col_base(a, blockIdx.x, bin, bout, valid);
+	if (KIND == KIND_REDFT10) col_load2(a, A, bin, valid, tid, nthr);
+	else col_pre3(a, A, bin, valid, tid, nthr);
+	__syncthreads();
+	blue_chirp_in(a, A, tid, nthr);
+	__syncthreads();
+	for (int s = 0; s < a.fftM.ns; s++) {
+		fft_stage(A, a.M, a.fftM.st[s], a.B, a.divB, a.WM, tid, nthr);
+		__syncthreads();
+	}
+	blue_mul(a, A, tid, nthr);
+	__syncthreads();
+	for (int s = a.fftM.ns - 1; s >= 0; s--) {
+		fft_stage_inv(A, a.M, a.fftM.st[s], a.B, a.divB, a.WM, tid, nthr);
+		__syncthreads();
+	}
+	blue_chirp_out(a, A, tid, nthr);
+	__syncthreads();
+	if (KIND == KIND_REDFT10) col_post2(a, A, bout, valid, tid, nthr);
+	else col_unpack3(a, A, bout, valid, tid, nthr);
+}
+
 // ---- compile-time-specialised kernels (dct_spec.h) ----
 // One workgroup per line / tile.  (A persistent variant that prefetched the next item into
 // registers was measured slower on MI355X: the extra ~60 VGPRs cost a resident workgroup per CU,
@@ -218,6 +247,23 @@ static int launch_dense(const DenseArgsT<R> &a, const LaunchGeom &g, void *strea
 	HIPCHK(hipGetLastError());
 	return 0;
 }
+
+template <class R>
+static int launch_blue(const BlueArgsT<R> &a, const LaunchGeom &g, void *stream)
+{
+	hipStream_t s = (hipStream_t)stream;
+	if (a.kind == KIND_REDFT10) {
+		if (int rc = allow_lds(blue_kernel<KIND_REDFT10, R>, g.lds_bytes)) return rc;
+		hipLaunchKernelGGL((blue_kernel<KIND_REDFT10, R>), dim3(g.nwg), dim3(g.nthr), g.lds_bytes, s, a);
+	} else {
+		if (int rc = allow_lds(blue_kernel<KIND_REDFT01, R>, g.lds_bytes)) return rc;
+		hipLaunchKernelGGL((blue_kernel<KIND_REDFT01, R>), dim3(g.nwg), dim3(g.nthr), g.lds_bytes, s, a);
+	}
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+int be_launch_blue(const BlueArgs &a, const LaunchGeom &g, void *stream) { return launch_blue(a, g, stream); }
+int be_launch_blue(const BlueArgsD &a, const LaunchGeom &g, void *stream) { return launch_blue(a, g, stream); }
 
 int be_launch_row(const PassArgs &a, const LaunchGeom &g, void *stream) { return launch_row(a, g, stream); }
 int be_launch_col(const PassArgs &a, const LaunchGeom &g, void *stream) { return launch_col(a, g, stream); }

@@ -147,6 +147,50 @@ DSP_HD void fft_stage(C *buf, int L, const StageDesc &S, int B, FastDiv divB, co
 	}
 }
 
+// Exact inverse of fft_stage (up to the factor R): undo the twiddles, then the conjugate butterfly.  Running the
+// stages of a transform LAST TO FIRST with this function takes the digit-reversed spectrum back to natural-order
+// samples (times L), in place, with no reordering pass -- used by the Bluestein convolution below.
+template <int R, class C>
+DSP_HD void fft_stage_inv_r(C *buf, int L, const StageDesc &S, int B, FastDiv divB, const C *W, int tid, int nthr)
+{
+	const int nitems = (L / R) * B;
+	const int stride = S.M1 * B;
+	for (int it = tid; it < nitems; it += nthr) {
+		const int q = (int)divB.div((uint32_t)it), s = it - q * B;
+		const int blk = (int)S.divM1.div((uint32_t)q), m = q - blk * S.M1;
+		const int base = (blk * S.Lc + m) * B + s;
+		C x[R];
+		static_for<0, R>([&](auto r) { x[r] = buf[base + r * stride]; });
+		if (S.M1 > 1) {
+			const int tw = m * S.twstep;
+			static_for<1, R>([&](auto r) { x[r] = cmulc(x[r], W[tw * r]); });
+		}
+		static_for<0, R>([&](auto r) { x[r] = cconj(x[r]); });
+		Dft<R>::run(x);
+		static_for<0, R>([&](auto r) { buf[base + r * stride] = cconj(x[r]); });
+	}
+}
+
+template <class C>
+DSP_HD void fft_stage_inv(C *buf, int L, const StageDesc &S, int B, FastDiv divB, const C *W, int tid, int nthr)
+{
+	switch (S.R) {
+	case 2: fft_stage_inv_r<2>(buf, L, S, B, divB, W, tid, nthr); break;
+	case 3: fft_stage_inv_r<3>(buf, L, S, B, divB, W, tid, nthr); break;
+	case 4: fft_stage_inv_r<4>(buf, L, S, B, divB, W, tid, nthr); break;
+	case 5: fft_stage_inv_r<5>(buf, L, S, B, divB, W, tid, nthr); break;
+	case 6: fft_stage_inv_r<6>(buf, L, S, B, divB, W, tid, nthr); break;
+	case 7: fft_stage_inv_r<7>(buf, L, S, B, divB, W, tid, nthr); break;
+	case 8: fft_stage_inv_r<8>(buf, L, S, B, divB, W, tid, nthr); break;
+	case 9: fft_stage_inv_r<9>(buf, L, S, B, divB, W, tid, nthr); break;
+	case 10: fft_stage_inv_r<10>(buf, L, S, B, divB, W, tid, nthr); break;
+	case 12: fft_stage_inv_r<12>(buf, L, S, B, divB, W, tid, nthr); break;
+	case 15: fft_stage_inv_r<15>(buf, L, S, B, divB, W, tid, nthr); break;
+	case 16: fft_stage_inv_r<16>(buf, L, S, B, divB, W, tid, nthr); break;
+	default: break;       // 11 and 13 never occur: the convolution length is 7-smooth
+	}
+}
+
 // ------------------------------------------------------------------------------------------------
 // ROW pass.  LDS: raw[N*C] floats (the line as it lies in memory) + buf[L*Bg] complex, L = N/2.
 // index of sample v[n] of the even/odd-reordered signal inside the original signal
@@ -398,6 +442,57 @@ DSP_HD void col_unpack3(const PassArgsT<R> &a, const cx<R> *buf, long long bout,
 		const int y = makhoul_src(n, N);
 		const R sc = (y == 0) ? a.scale * a.out_scale0 : a.scale;
 		st2a(a, a.out + bout + (long long)y * a.es_out + 2 * j, vec, valid - 2 * j, F.x * sc, -F.y * sc);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// BLUESTEIN variant of the COL pass: lengths with a prime factor > 13.  The tile's N-point DFT (the only part of
+// the COL pass that needs N to factor) becomes a length-M circular convolution, M >= 2N-1 and 7-smooth:
+//   V[k] = conj(c[k]) * sum_n (v[n] conj(c[n])) c[k-n],   c[n] = exp(+i pi n^2 / N)
+// computed in place as  conj(c) . IFFT_M( FFT_M(v conj(c), zero-padded) . Bhat ):  the forward stages leave the
+// spectrum digit-reversed, Bhat = FFT_M(c wrapped to M) / M is stored in that same order (host, exact phase
+// reduction n^2 mod 2N), and the inverse stages (fft_stage_inv, last to first) return natural-order samples.
+// Loading, the two-for-one split, the quarter-sample twiddles, masks, scales and stores are the COL pass's own
+// functions; `pos` is the identity because the DFT result lies in natural order.  LDS: M*B complex.
+template <class R>
+struct BlueArgsT : PassArgsT<R> {
+	int M;                    // convolution length
+	FftDesc fftM;
+	const cx<R> *WM;          // exp(-2 pi i t / M)
+	const cx<R> *chirp;       // c[n], n in [0, N)
+	const cx<R> *Bhat;        // Bhat[p] = FFT_M(b)[k] / M at the LDS slot p that holds spectrum index k
+};
+typedef BlueArgsT<float> BlueArgs;
+typedef BlueArgsT<double> BlueArgsD;
+
+// A[n] *= conj(c[n]) for n < N; zero rows [N, M)
+template <class R>
+DSP_HD void blue_chirp_in(const BlueArgsT<R> &a, cx<R> *A, int tid, int nthr)
+{
+	const int B = a.B;
+	for (int it = tid; it < a.M * B; it += nthr) {
+		const int n = (int)a.divB.div((uint32_t)it);
+		A[it] = n < a.N ? cmulc(A[it], a.chirp[n]) : cmk<R>(R(0), R(0));
+	}
+}
+// pointwise product with the filter's spectrum (both digit-reversed)
+template <class R>
+DSP_HD void blue_mul(const BlueArgsT<R> &a, cx<R> *A, int tid, int nthr)
+{
+	const int B = a.B;
+	for (int it = tid; it < a.M * B; it += nthr) {
+		const int p = (int)a.divB.div((uint32_t)it);
+		A[it] = cmul(A[it], a.Bhat[p]);
+	}
+}
+// A[k] *= conj(c[k]) for k < N
+template <class R>
+DSP_HD void blue_chirp_out(const BlueArgsT<R> &a, cx<R> *A, int tid, int nthr)
+{
+	const int B = a.B;
+	for (int it = tid; it < a.N * B; it += nthr) {
+		const int k = (int)a.divB.div((uint32_t)it);
+		A[it] = cmulc(A[it], a.chirp[k]);
 	}
 }
 

@@ -8,9 +8,11 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <complex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -78,7 +80,12 @@ FastDiv make_div(uint32_t d)
 
 struct Tables {
 	void *T = nullptr, *W = nullptr, *pos = nullptr, *cosTab = nullptr;
-	void release() { be_free(T); be_free(W); be_free(pos); be_free(cosTab); T = W = pos = cosTab = nullptr; }
+	void *WM = nullptr, *chirp = nullptr, *Bhat = nullptr;     // Bluestein (BLUE passes)
+	void release()
+	{
+		be_free(T); be_free(W); be_free(pos); be_free(cosTab); be_free(WM); be_free(chirp); be_free(Bhat);
+		T = W = pos = cosTab = WM = chirp = Bhat = nullptr;
+	}
 };
 
 bool build_fft(int L, FftDesc &F, std::vector<uint32_t> &pos)
@@ -107,7 +114,9 @@ bool build_fft(int L, FftDesc &F, std::vector<uint32_t> &pos)
 }
 
 struct Pass {
-	enum Type { ROW, COL, DENSE } type;
+	enum Type { ROW, COL, DENSE, BLUE } type;   // BLUE = COL geometry, tile DFT by Bluestein's convolution
+	int blueM = 0;
+	FftDesc fftM;
 	int axis;
 	bool first;
 	PassGeom pa;               // typed pointers, tables and scales are filled in per launch (run_pass)
@@ -168,6 +177,80 @@ int upload_tables_t(Pass &P, int N, int L, const std::vector<uint32_t> &pos)
 int upload_tables(Pass &P, bool f64, int N, int L, const std::vector<uint32_t> &pos)
 {
 	return f64 ? upload_tables_t<double>(P, N, L, pos) : upload_tables_t<float>(P, N, L, pos);
+}
+
+// ---- Bluestein tables --------------------------------------------------------------------------
+typedef std::complex<long double> cld;
+const long double kPiL = 3.14159265358979323846264338327950288L;
+
+// in-place forward DFT of any length whose prime factors are small (recursive decimation in time; host, plan time)
+void host_fft(std::vector<cld> &x)
+{
+	const size_t n = x.size();
+	if (n <= 1) return;
+	size_t r = n;
+	for (size_t f = 2; f * f <= n; f++) if (n % f == 0) { r = f; break; }
+	const size_t m = n / r;
+	std::vector<std::vector<cld>> sub(r, std::vector<cld>(m));
+	for (size_t j = 0; j < r; j++) for (size_t i = 0; i < m; i++) sub[j][i] = x[i * r + j];
+	for (size_t j = 0; j < r; j++) host_fft(sub[j]);
+	std::vector<cld> w(n);
+	for (size_t t = 0; t < n; t++) w[t] = cld(cosl(2 * kPiL * t / n), -sinl(2 * kPiL * t / n));
+	for (size_t k = 0; k < n; k++) {
+		cld acc = 0;
+		for (size_t j = 0; j < r; j++) acc += w[(j * k) % n] * sub[j][k % m];
+		x[k] = acc;
+	}
+}
+
+// convolution length: 7-smooth M in [lo, 1.3 lo] minimising (stages x M) -- every stage is one pass over the M-row
+// LDS buffer -- e.g. lo = 2731: 2880 = 12x15x16 (3 stages) beats 2744 = 7x7x7x8 (4 stages of costlier butterflies).
+// DSPFFT_NO_BLUESTEIN=1 (plan time) disables the path (the O(N^2) DENSE kernel takes over; used by its tests).
+int blue_length(int lo, FftDesc &F, std::vector<uint32_t> &pos)
+{
+	const char *e = getenv("DSPFFT_NO_BLUESTEIN");
+	if (e && *e == '1') return 0;
+	int best = 0; long long bestcost = 0;
+	for (int M = lo; M <= lo + lo / 3 + 16; M++) {
+		int r = M;
+		for (int p : {2, 3, 5, 7}) while (r % p == 0) r /= p;
+		if (r != 1) continue;
+		FftDesc f; std::vector<uint32_t> q;
+		if (!build_fft(M, f, q)) continue;
+		const long long cost = (long long)f.ns * M;
+		if (!best || cost < bestcost) { best = M; bestcost = cost; }
+	}
+	if (best) build_fft(best, F, pos);
+	return best;
+}
+
+template <class R>
+int upload_blue_tables_t(Pass &P, int N, int M, const std::vector<uint32_t> &posM)
+{
+	std::vector<cld> c(N), b(M, cld(0));
+	for (long long n = 0; n < N; n++) {
+		const long long r = (n * n) % (2LL * N);                    // exact phase reduction
+		c[n] = cld(cosl(kPiL * r / N), sinl(kPiL * r / N));
+	}
+	b[0] = c[0];
+	for (int m = 1; m < N; m++) { b[m] = c[m]; b[M - m] = c[m]; }
+	host_fft(b);
+	std::vector<cx<R>> T(N + 1), WM(M), chirp(N), Bhat(M);
+	std::vector<uint32_t> ident(N);
+	for (int j = 0; j <= N; j++) T[j] = cmk<R>((R)cosl(kPiL * j / (2.0L * N)), (R)-sinl(kPiL * j / (2.0L * N)));
+	for (int t = 0; t < M; t++) WM[t] = cmk<R>((R)cosl(2 * kPiL * t / M), (R)-sinl(2 * kPiL * t / M));
+	for (int n = 0; n < N; n++) { chirp[n] = cmk<R>((R)c[n].real(), (R)c[n].imag()); ident[n] = (uint32_t)n; }
+	for (int k = 0; k < M; k++) Bhat[posM[k]] = cmk<R>((R)(b[k].real() / M), (R)(b[k].imag() / M));   // digit-reversed, like the spectrum it multiplies
+	struct { void **dst; const void *src; size_t bytes; } up[] = {
+		{&P.tab.T, T.data(), T.size() * sizeof(cx<R>)}, {&P.tab.WM, WM.data(), WM.size() * sizeof(cx<R>)},
+		{&P.tab.chirp, chirp.data(), chirp.size() * sizeof(cx<R>)}, {&P.tab.Bhat, Bhat.data(), Bhat.size() * sizeof(cx<R>)},
+		{&P.tab.pos, ident.data(), ident.size() * sizeof(uint32_t)}};
+	for (auto &u : up) {
+		*u.dst = be_alloc(u.bytes);
+		if (!*u.dst || be_upload(*u.dst, u.src, u.bytes)) return -1;
+	}
+	P.pa.pos = (const uint32_t *)P.tab.pos;
+	return 0;
 }
 
 std::string radix_string(const FftDesc &F)
@@ -238,28 +321,30 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 			}
 		}
 	}
-	// ---------------- COL ----------------
+	// ---------------- COL (and its Bluestein variant) ----------------
 	{
-		FftDesc F; std::vector<uint32_t> pos;
-		bool ok = build_fft(N, F, pos);
+		FftDesc F, FM; std::vector<uint32_t> pos, posM;
+		const bool direct = build_fft(N, F, pos);
+		const int M = direct ? 0 : blue_length(2 * N - 1, FM, posM);
+		bool ok = direct || M > 0;
 		int idim = -1;
-		if (ok) {
-			for (size_t i = 0; i < others.size(); i++) if (others[i].is == 1 && others[i].os == 1) idim = (int)i;
-			ok = idim >= 0;
-		}
+		for (size_t i = 0; i < others.size(); i++) if (others[i].is == 1 && others[i].os == 1) idim = (int)i;
 		if (ok) {
 			// merge dims that continue the inner run contiguously (dense embeddings)
 			std::vector<Dim> rest;
-			Dim inner = others[idim];
+			// no unit-stride dimension beside the axis (planar lines): a one-sample-wide "inner" run, i.e. tiles of one
+			// real signal whose partner column is empty
+			Dim inner = idim >= 0 ? others[idim] : Dim{1, 1, 1};
 			for (size_t i = 0; i < others.size(); i++) if ((int)i != idim) rest.push_back(others[i]);
 			std::sort(rest.begin(), rest.end(), [](const Dim &x, const Dim &y) { return x.os < y.os; });
-			for (size_t i = 0; i < rest.size();) {
+			for (size_t i = 0; idim >= 0 && i < rest.size();) {
 				if (rest[i].is == inner.n && rest[i].os == inner.n && (long long)inner.n * rest[i].n < (1 << 30)) { inner.n *= rest[i].n; rest.erase(rest.begin() + i); i = 0; }
 				else i++;
 			}
 			merge_dims(rest);
+			const size_t rows = direct ? (size_t)N : (size_t)M;           // complex LDS rows per tile column pair
 			int K = std::min(16, (inner.n + 1) & ~1);
-			while (K >= 2 && (size_t)N * (K / 2) * 2 * es > maxlds) K -= 2;
+			while (K >= 2 && rows * (K / 2) * 2 * es > maxlds) K -= 2;
 			if (K >= 2) {
 				PassGeom &pa = P.pa;
 				pa.N = N; pa.kind = kind; pa.K = K; pa.B = K / 2; pa.ninner = inner.n; pa.ntiles = (inner.n + K - 1) / K;
@@ -267,10 +352,20 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 				pa.nb0 = rest.size() > 0 ? rest[0].n : 1; pa.sb0_in = rest.size() > 0 ? rest[0].is : 0; pa.sb0_out = rest.size() > 0 ? rest[0].os : 0;
 				pa.nb1 = rest.size() > 1 ? rest[1].n : 1; pa.sb1_in = rest.size() > 1 ? rest[1].is : 0; pa.sb1_out = rest.size() > 1 ? rest[1].os : 0;
 				for (size_t i = 2; i < rest.size(); i++) P.hostloop.push_back(rest[i]);
+				long long nwg = (long long)pa.ntiles * pa.nb0 * pa.nb1;
+				if (nwg > 0x7fffffff) return fail(-2, "too many tiles for one launch");
+				P.g.nwg = (int)nwg;
+				P.g.nthr = ((long long)(direct ? N : M) * pa.B >= 8192) ? 512 : 256;
+				P.g.lds_bytes = rows * pa.B * 2 * es; P.g.raw_bytes = 0;
+				if (!direct) {
+					P.type = Pass::BLUE; P.blueM = M; P.fftM = FM;
+					memset(&pa.fft, 0, sizeof pa.fft);
+					if (pl->f64 ? upload_blue_tables_t<double>(P, N, M, posM) : upload_blue_tables_t<float>(P, N, M, posM)) return fail(-3, "table upload failed");
+					snprintf(buf, sizeof buf, "axis %d: BLUE%s N=%d K=%d inner=%d tiles=%d conv=%d(%s) wgs=%d lds=%zu", a, tag, N, K, inner.n, pa.ntiles, M, radix_string(FM).c_str(), P.g.nwg, P.g.lds_bytes);
+					P.desc = buf;
+					return 0;
+				}
 				P.type = Pass::COL;
-				P.g.nwg = pa.ntiles * pa.nb0 * pa.nb1;
-				P.g.nthr = ((long long)N * pa.B >= 8192) ? 512 : 256;
-				P.g.lds_bytes = (size_t)N * pa.B * 2 * es; P.g.raw_bytes = 0;
 				if (upload_tables(P, pl->f64, N, N, pos)) return fail(-3, "table upload failed");
 				snprintf(buf, sizeof buf, "axis %d: COL%s  N=%d K=%d inner=%d tiles=%d fft=%d(%s) wgs=%d lds=%zu", a, tag, N, K, inner.n, pa.ntiles, N, radix_string(F).c_str(), P.g.nwg, P.g.lds_bytes);
 				P.desc = buf;
@@ -364,7 +459,13 @@ int run_pass(const dspfft_plan_s *pl, const Pass &P, const R *in, R *out, bool l
 					rc = be_launch_spec(P.type == Pass::COL, P.spec.id, a, P.spec_nwg, stream);
 				}
 			}
-			if (!use_spec) {
+			if (P.type == Pass::BLUE) {
+				BlueArgsT<R> a;
+				fill_args(a, P.pa, pl, P, in + oin, out + oout, scale, fz);
+				a.M = P.blueM; a.fftM = P.fftM;
+				a.WM = (const cx<R> *)P.tab.WM; a.chirp = (const cx<R> *)P.tab.chirp; a.Bhat = (const cx<R> *)P.tab.Bhat;
+				rc = be_launch_blue(a, P.g, stream);
+			} else if (!use_spec) {
 				PassArgsT<R> a;
 				fill_args(a, P.pa, pl, P, in + oin, out + oout, scale, fz);
 				rc = P.type == Pass::ROW ? be_launch_row(a, P.g, stream) : be_launch_col(a, P.g, stream);

@@ -80,6 +80,30 @@ static int emul_dense(const DenseArgsT<R> &a, const LaunchGeom &g)
 	return 0;
 }
 
+template <class R>
+static int emul_blue(const BlueArgsT<R> &a, const LaunchGeom &g)
+{
+	std::vector<unsigned char> lds(g.lds_bytes + 32);
+	cx<R> *A = (cx<R> *)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
+	const int nthr = g.nthr;
+	for (int wg = 0; wg < g.nwg; wg++) {
+		long long bin, bout; int valid;
+		col_base(a, wg, bin, bout, valid);
+		if (a.kind == KIND_REDFT10) { PHASE(col_load2(a, A, bin, valid, tid, nthr)); }
+		else { PHASE(col_pre3(a, A, bin, valid, tid, nthr)); }
+		PHASE(blue_chirp_in(a, A, tid, nthr));
+		for (int s = 0; s < a.fftM.ns; s++) PHASE(fft_stage(A, a.M, a.fftM.st[s], a.B, a.divB, a.WM, tid, nthr));
+		PHASE(blue_mul(a, A, tid, nthr));
+		for (int s = a.fftM.ns - 1; s >= 0; s--) PHASE(fft_stage_inv(A, a.M, a.fftM.st[s], a.B, a.divB, a.WM, tid, nthr));
+		PHASE(blue_chirp_out(a, A, tid, nthr));
+		if (a.kind == KIND_REDFT10) { PHASE(col_post2(a, A, bout, valid, tid, nthr)); }
+		else { PHASE(col_unpack3(a, A, bout, valid, tid, nthr)); }
+	}
+	return 0;
+}
+int be_launch_blue(const BlueArgs &a, const LaunchGeom &g, void *) { return emul_blue(a, g); }
+int be_launch_blue(const BlueArgsD &a, const LaunchGeom &g, void *) { return emul_blue(a, g); }
+
 int be_launch_row(const PassArgs &a, const LaunchGeom &g, void *) { return emul_row(a, g); }
 int be_launch_col(const PassArgs &a, const LaunchGeom &g, void *) { return emul_col(a, g); }
 int be_launch_dense(const DenseArgs &a, const LaunchGeom &g, void *) { return emul_dense(a, g); }

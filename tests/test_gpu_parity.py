@@ -269,14 +269,14 @@ def test_common_resolutions_specialised_vs_oracle(gpu, h, w, c):
     x = ol.synth_f32(h + w, h * w * c).reshape(h, w, c)
     fwd, inv = plan_image(h, w, c, REDFT10), plan_image(h, w, c, REDFT01)
     assert fwd.describe().count("*") >= (2 if w != 4100 else 1), fwd.describe()
+    assert ("BLUE N=4100" in fwd.describe()) == (w == 4100)      # 4100 = 2^2 5^2 41: Bluestein along x
     d = dev(gpu, x)
     fwd.execute(d.data_ptr())
     gpu.cuda.synchronize()
     check(d.cpu().numpy(), ol.dct2d_interleaved(x.astype(np.float64), REDFT10, impl="port", threads=8))
     inv.set_scale(1.0 / (4.0 * h * w)).execute(d.data_ptr())
     gpu.cuda.synchronize()
-    # 4100 = 2^2 5^2 41 runs the O(N^2) dense kernel along x: 4100-term f32 sums
-    assert np.abs(d.cpu().numpy() - x).max() <= (2e-6 if w != 4100 else 1e-5)
+    assert np.abs(d.cpu().numpy() - x).max() <= 2e-6
 
 
 def test_fused_scan_step_c4_like(gpu):
@@ -352,6 +352,44 @@ def test_f64_c2_frame_roundtrip_with_spec_normalisation(gpu):
     inv.execute(d.data_ptr())
     gpu.cuda.synchronize()
     assert np.abs(d.cpu().numpy() - x).max() <= 1e-13
+
+
+# ---- lengths with prime factors > 13: Bluestein inside the column pass; the O(N^2) kernel only as the fallback ----
+@pytest.mark.parametrize("h,w,c", [(768, 1366, 3), (683, 1031, 1), (17, 40, 3), (1087, 1933, 3), (31, 2731, 1)])
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_bluestein_sizes_vs_oracle(gpu, h, w, c, dtype):
+    from dspfun_amd import Plan
+    f64 = dtype == "f64"
+    x = ol.synth_f32(h * 3 + w, h * w * c).reshape(h, w, c)
+    x = x.astype(np.float64) * (1 + 2.0 ** -31) if f64 else x
+    for kind in (5, 4):
+        p = Plan.image(h, w, c, kind, dtype=dtype)
+        assert "BLUE" in p.describe() and "DENSE" not in p.describe(), p.describe()
+        d = gpu.from_numpy(x.copy()).to("cuda:0")
+        p.execute(d.data_ptr())
+        gpu.cuda.synchronize()
+        ref = ol.dct2d_interleaved(x.astype(np.float64), kind, impl="port", threads=8)
+        check(d.cpu().numpy(), ref, tol=2e-13 if f64 else TOL)
+
+
+def test_dense_fallback_matches_bluestein(gpu):
+    import os
+    from dspfun_amd import Plan
+    h, w, c = 97, 194, 3
+    x = ol.synth_f32(11, h * w * c).reshape(h, w, c)
+    os.environ["DSPFFT_NO_BLUESTEIN"] = "1"
+    try:
+        pd = Plan.image(h, w, c, 5)
+    finally:
+        del os.environ["DSPFFT_NO_BLUESTEIN"]
+    pb = Plan.image(h, w, c, 5)
+    assert pd.describe().count("DENSE") == 2 and pb.describe().count("BLUE") == 2
+    a, b = dev(gpu, x), dev(gpu, x)
+    pd.execute(a.data_ptr()); pb.execute(b.data_ptr())
+    gpu.cuda.synchronize()
+    ref = ol.dct2d_interleaved(x.astype(np.float64), 5, impl="port")
+    check(a.cpu().numpy(), ref)
+    check(b.cpu().numpy(), ref)
 
 
 # ---- zoom: dense basis product on the f32 matrix cores ----

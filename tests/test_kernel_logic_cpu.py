@@ -2,6 +2,8 @@
 test-only emulation backend and are compared with the oracle.  This is NOT the parity test of the
 product (that is tests/test_gpu_parity.py, -m gpu, through the HIP library); it checks the logic
 that both builds share, in a container without a GPU."""
+import os
+
 import numpy as np
 import pytest
 
@@ -40,9 +42,17 @@ def test_describe_picks_row_and_col():
     p = Plan.image(48, 64, 3, REDFT10, lib=emul())
     d = p.describe()
     assert "ROW" in d and "COL" in d and "DENSE" not in d
-    p = Plan.image(17, 40, 3, REDFT10, lib=emul())   # 17 is a prime > 13 -> dense along y, x still fast
+    p = Plan.image(17, 40, 3, REDFT10, lib=emul())   # 17 is a prime > 13 -> Bluestein along y, x still direct
     d = p.describe()
-    assert "DENSE" in d and "ROW" in d
+    assert "BLUE" in d and "conv=35" in d and "ROW" in d and "DENSE" not in d
+    p = Plan.image(8, 1366, 3, REDFT10, lib=emul())   # 1366 = 2 x 683: 2880 = 12x15x16 beats the smaller 2744 = 7x7x7x8
+    assert "BLUE N=1366" in p.describe() and "conv=2880" in p.describe()
+    os.environ["DSPFFT_NO_BLUESTEIN"] = "1"
+    try:
+        d = Plan.image(17, 40, 3, REDFT10, lib=emul()).describe()
+        assert "DENSE" in d and "ROW" in d
+    finally:
+        del os.environ["DSPFFT_NO_BLUESTEIN"]
 
 
 @pytest.mark.parametrize("kind", [REDFT10, REDFT01])
@@ -315,3 +325,52 @@ def test_f64_fused_scan_step_and_type_mismatch():
     assert L.dspfft_execute(inv._h, C.c_void_p(acc.ctypes.data), C.c_void_p(acc.ctypes.data), None) != 0
     p32 = Plan.image(h, w, c, REDFT01, lib=L)
     assert L.dspfft_execute_f64(p32._h, C.c_void_p(acc.ctypes.data), C.c_void_p(acc.ctypes.data), None) != 0
+
+
+# ---- lengths with prime factors > 13: Bluestein's convolution inside the column pass (and the O(N^2) fallback) ----
+@pytest.mark.parametrize("h,w,c", [(17, 40, 3), (6, 34, 3), (8, 1366, 3), (97, 6, 1), (5, 683, 1), (31, 31, 1), (19, 23, 2), (1, 17, 3), (29, 1, 1), (3, 2731, 1)])
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_bluestein_lengths(h, w, c, dtype):
+    for kind in (REDFT10, REDFT01):
+        if dtype == "f32":
+            x = ol.synth_f32(h * 31 + w, h * w * c).reshape(h, w, c)
+            ref = ol.dct2d_interleaved(x.astype(np.float64), kind, impl="port")
+            p = Plan.image(h, w, c, kind, lib=emul())
+            assert "BLUE" in p.describe() and "DENSE" not in p.describe(), p.describe()
+            assert relerr(run(p, x.copy()), ref) < TOL, p.describe()
+        else:
+            x = ol.synth_f32(h * 31 + w, h * w * c).astype(np.float64).reshape(h, w, c) * (1 + 2.0 ** -31)
+            ref = ol.dct2d_interleaved(x, kind, impl="port")
+            p = Plan.image(h, w, c, kind, lib=emul(), dtype="f64")
+            assert "BLUE f64" in p.describe(), p.describe()
+            assert relerr(run64(p, x.copy()), ref) < 2e-13, p.describe()
+
+
+def test_bluestein_fused_scan_step_and_dense_fallback():
+    """the fused masked/accumulating execution runs through the Bluestein pass unchanged; with the path disabled the
+    O(N^2) kernel gives the same answer"""
+    h, w, c = 17, 46, 3
+    L = emul()
+    x = ol.synth_f32(4, h * w * c).reshape(h, w, c)
+    coeffs = x.copy()
+    Plan.image(h, w, c, REDFT10, lib=L).set_scale(1.0 / (4 * w * h)).execute(coeffs.ctypes.data)
+    ids = np.zeros(h * w, dtype=np.uint32)
+    step = (h * w + 2) // 3
+    assert L.dspfft_scan_zigzag_frame_ids(ids.ctypes.data, w, h, step, None) == 0
+    inv = Plan.image(h, w, c, REDFT01, lib=L)
+    assert inv.describe().count("BLUE") == 2
+    acc = np.ascontiguousarray(np.broadcast_to(coeffs[0, 0], (h, w, c)).copy())
+    work = np.zeros_like(acc)
+    for f in range(3):
+        inv.execute_masked_accumulate(coeffs.ctypes.data, work.ctypes.data, acc.ctypes.data, ids.ctypes.data, f, c)
+    assert np.abs(acc - x).max() < 1e-5
+    os.environ["DSPFFT_NO_BLUESTEIN"] = "1"
+    try:
+        pd = Plan.image(h, w, c, REDFT10, lib=L)
+    finally:
+        del os.environ["DSPFFT_NO_BLUESTEIN"]
+    assert pd.describe().count("DENSE") == 2
+    a, b = x.copy(), x.copy()
+    pd.execute(a.ctypes.data)
+    Plan.image(h, w, c, REDFT10, lib=L).execute(b.ctypes.data)
+    assert relerr(a, b.astype(np.float64)) < TOL
