@@ -17,7 +17,7 @@ namespace dspfft {
 
 // ---------------------------------------------------------------------------------------------
 template <int KIND, class R>
-__global__ void __launch_bounds__(256) row_kernel(const PassArgsT<R> a, const unsigned raw_bytes)
+__global__ void __launch_bounds__(1024) row_kernel(const PassArgsT<R> a, const unsigned raw_bytes)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	R *raw = reinterpret_cast<R *>(lds);
@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(256) row_kernel(const PassArgsT<R> a, const un
 }
 
 template <int KIND, class R>
-__global__ void __launch_bounds__(512) col_kernel(const PassArgsT<R> a)
+__global__ void __launch_bounds__(1024) col_kernel(const PassArgsT<R> a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	cx<R> *buf = reinterpret_cast<cx<R> *>(lds);
@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(512) col_kernel(const PassArgsT<R> a)
 }
 
 template <int KIND, class R>
-__global__ void __launch_bounds__(512) blue_kernel(const BlueArgsT<R> a)
+__global__ void __launch_bounds__(1024) blue_kernel(const BlueArgsT<R> a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	cx<R> *A = reinterpret_cast<cx<R> *>(lds);

@@ -78,6 +78,9 @@ FastDiv make_div(uint32_t d)
 	FastDiv f; f.d = d; f.mul = d >= 2 ? (uint32_t)((((uint64_t)1 << 32) + d - 1) / d) : 0; return f;
 }
 
+// tuning overrides for experiments (read at plan time; 0 = use the built-in choice)
+int env_int(const char *name) { const char *e = getenv(name); return e ? atoi(e) : 0; }
+
 struct Tables {
 	void *T = nullptr, *W = nullptr, *pos = nullptr, *cosTab = nullptr;
 	void *WM = nullptr, *chirp = nullptr, *Bhat = nullptr;     // Bluestein (BLUE passes)
@@ -292,7 +295,7 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 			const int L = N / 2;
 			size_t raw_bytes = (((size_t)N * C * es) + 15) & ~(size_t)15;
 			int Bg = C;
-			if (raw_bytes + (size_t)L * Bg * 2 * es > maxlds) Bg = 1;
+			if (raw_bytes + (size_t)L * Bg * 2 * es > maxlds || env_int("DSPFFT_ROW_BG") == 1) Bg = 1;
 			if (raw_bytes + (size_t)L * Bg * 2 * es > maxlds) ok = false;
 			if (ok) {
 				std::vector<Dim> lines;
@@ -304,7 +307,10 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 				pa.nb1 = lines.size() > 1 ? lines[1].n : 1; pa.sb1_in = lines.size() > 1 ? lines[1].is : 0; pa.sb1_out = lines.size() > 1 ? lines[1].os : 0;
 				for (size_t i = 2; i < lines.size(); i++) P.hostloop.push_back(lines[i]);
 				P.type = Pass::ROW;
-				P.g.nwg = pa.nb0 * pa.nb1; P.g.nthr = 256; P.g.raw_bytes = raw_bytes; P.g.lds_bytes = raw_bytes + (size_t)L * Bg * 2 * es;
+				P.g.nwg = pa.nb0 * pa.nb1; P.g.raw_bytes = raw_bytes; P.g.lds_bytes = raw_bytes + (size_t)L * Bg * 2 * es;
+				// about 16 waves per CU: one big-LDS workgroup of 1024 threads, two of 512, otherwise 256 (measured, tools/sweep_generic.py)
+				P.g.nthr = P.g.lds_bytes > 80 * 1024 ? 1024 : P.g.lds_bytes > 53 * 1024 ? 512 : 256;
+				if (env_int("DSPFFT_ROW_THREADS")) P.g.nthr = env_int("DSPFFT_ROW_THREADS");
 				if (upload_tables(P, pl->f64, N, L, pos)) return fail(-3, "table upload failed");
 				snprintf(buf, sizeof buf, "axis %d: ROW%s  N=%d C=%d Bg=%d fft=%d(%s) lines=%d lds=%zu", a, tag, N, C, Bg, L, radix_string(F).c_str(), P.g.nwg, P.g.lds_bytes);
 				P.desc = buf;
@@ -343,7 +349,7 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 			}
 			merge_dims(rest);
 			const size_t rows = direct ? (size_t)N : (size_t)M;           // complex LDS rows per tile column pair
-			int K = std::min(16, (inner.n + 1) & ~1);
+			int K = std::min(env_int("DSPFFT_COL_K") ? env_int("DSPFFT_COL_K") : 16, (inner.n + 1) & ~1);
 			while (K >= 2 && rows * (K / 2) * 2 * es > maxlds) K -= 2;
 			if (K >= 2) {
 				PassGeom &pa = P.pa;
@@ -355,8 +361,10 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 				long long nwg = (long long)pa.ntiles * pa.nb0 * pa.nb1;
 				if (nwg > 0x7fffffff) return fail(-2, "too many tiles for one launch");
 				P.g.nwg = (int)nwg;
-				P.g.nthr = ((long long)(direct ? N : M) * pa.B >= 8192) ? 512 : 256;
 				P.g.lds_bytes = rows * pa.B * 2 * es; P.g.raw_bytes = 0;
+				const long long slots = (long long)rows * pa.B;
+				P.g.nthr = (slots >= 12000 || P.g.lds_bytes > 80 * 1024) ? 1024 : slots >= 4096 ? 512 : 256;   // measured, tools/sweep_generic.py
+				if (env_int("DSPFFT_COL_THREADS")) P.g.nthr = env_int("DSPFFT_COL_THREADS");
 				if (!direct) {
 					P.type = Pass::BLUE; P.blueM = M; P.fftM = FM;
 					memset(&pa.fft, 0, sizeof pa.fft);
