@@ -15,6 +15,7 @@ REDFT01, REDFT10 = 4, 5
 SYMBOLS = [
     "dspfft_plan_many_r2r", "dspfft_plan_r2r_2d", "dspfft_plan_set_scale", "dspfft_plan_set_axis_scale0",
     "dspfft_plan_many_r2r_f64", "dspfft_plan_set_scale_f64", "dspfft_plan_set_axis_scale0_f64", "dspfft_execute_f64", "dspfft_execute_masked_accumulate_f64",
+    "dspfft_plan_many_r2r_ordered", "dspfft_execute_roundtrip",
     "dspfft_execute", "dspfft_plan_num_passes", "dspfft_execute_pass", "dspfft_destroy_plan", "dspfft_plan_describe", "dspfft_plan_algorithmic_bytes",
     "dspfft_last_error", "dspfft_version",
     "dspfft_scan_zigzag", "dspfft_scan_zigzag_frame_ids", "dspfft_execute_masked_accumulate", "dspfft_scan_scatter", "dspfft_accumulate", "dspfft_broadcast_dc",
@@ -23,6 +24,13 @@ SYMBOLS = [
     "dspfft_zoom_last_error", "dspfft_applybasis_work_floats", "dspfft_applybasis_partsums",
     "dspfft_spec_encode", "dspfft_ispec_decode", "dspfft_motion_filter", "dspfft_scan_pruned_accumulate", "dspfft_pointwise_last_error",
 ]
+
+class MotionFilterParams(C.Structure):
+    """dspfft_motion_filter_params (include/dspfft.h)"""
+    _fields_ = [("active", C.c_int * 3), ("minbuf_hw", C.c_int * 2), ("block_depth", C.c_int), ("band_begin", C.c_int * 3), ("band_end", C.c_int * 3),
+                ("damp", C.c_float), ("boost", C.c_float), ("threshold_lo", C.c_float), ("threshold_hi", C.c_float),
+                ("preserve_dc", C.c_int), ("grey_add", C.c_float), ("quantizer", C.c_float)]
+
 
 _lib = None
 
@@ -37,6 +45,8 @@ def bind(lib):
     lib.dspfft_plan_set_axis_scale0.argtypes = [vp, C.c_int, C.c_float, C.c_float]
     lib.dspfft_execute.argtypes = [vp, vp, vp, vp]
     lib.dspfft_plan_many_r2r_f64.argtypes = lib.dspfft_plan_many_r2r.argtypes
+    lib.dspfft_plan_many_r2r_ordered.argtypes = lib.dspfft_plan_many_r2r.argtypes + [C.c_int]
+    lib.dspfft_execute_roundtrip.argtypes = [vp, vp, vp, vp, C.POINTER(MotionFilterParams), vp, vp]
     lib.dspfft_plan_set_scale_f64.argtypes = [vp, C.c_double]
     lib.dspfft_plan_set_axis_scale0_f64.argtypes = [vp, C.c_int, C.c_double, C.c_double]
     lib.dspfft_execute_f64.argtypes = [vp, vp, vp, vp]

@@ -4,6 +4,7 @@
 #pragma once
 #include <stddef.h>
 #include "dct_core.h"
+#include "motion_filter.h"
 
 namespace dspfft {
 
@@ -35,6 +36,11 @@ int be_launch_blue(const BlueArgsD &a, const LaunchGeom &g, void *stream);
 struct SpecInfo { int id, nthr, P; size_t lds; };   // P = C (ROW) or K (COL)
 bool be_find_spec(int is_col, int N, int P, SpecInfo *info);
 int be_launch_spec(int is_col, int id, const PassArgs &a, int nwg, void *stream);
+// fused column roundtrip: REDFT10 along the tile axis (af), pointwise filter, REDFT01 (ai); both passes share spec `id`
+int be_launch_roundtrip(int id, const PassArgs &af, const PassArgs &ai, const MotionFilter &filt, unsigned long long *coded, int nwg, void *stream);
+
+// motion's filter over every active element of a buffer of `span` elements (the unfused form of the roundtrip's middle step)
+int be_motion_filter(float *buf, const MotionFilter &filt, uint64_t span, unsigned long long *coded, void *stream);
 
 // elementwise helpers (dspfft.h, "device-side helpers")
 int be_scan_zigzag(uint32_t *lin, uint32_t w, uint32_t h, uint64_t first, uint64_t count, void *stream);

@@ -134,6 +134,68 @@ __global__ void __launch_bounds__(S::T, S::WPE) col_spec_kernel(const PassArgs a
 	});
 }
 
+// forward REDFT10 -> motion filter -> inverse REDFT01 along the tile's axis in one launch: the tile is read once and
+// written once instead of three times each (forward store + filter read/write + inverse load saved)
+struct FilterOp {
+	MotionFilter p;
+	__device__ float4 operator()(long long e, float4 v, unsigned long long &coded) const
+	{
+		return p.enabled ? motion_filter4(p, (uint32_t)e, v, coded) : v;
+	}
+};
+
+// waves per SIMD to ask of the register allocator so that as many workgroups stay resident as the tile's LDS allows
+// (capped at 4 = 128 VGPRs): without the cap the allocator spends the whole budget and one workgroup fills a CU
+template <class S> constexpr int rt_waves_per_simd()
+{
+	const int wgs = (int)((160 * 1024) / S::LDS), w = wgs * S::T / 256;
+	return w < 1 ? 1 : w > 4 ? 4 : w;
+}
+
+template <class S>
+__global__ void __launch_bounds__(S::T, rt_waves_per_simd<S>()) col_roundtrip_kernel(const PassArgs af, const PassArgs ai, const FilterOp filt, unsigned long long *coded)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+	__shared__ unsigned int wg_coded;       // non-zero quantised coefficients of this tile (one global atomic per workgroup)
+	float4 *buf = reinterpret_cast<float4 *>(lds);
+	const int tid = threadIdx.x;
+	if (tid == 0) wg_coded = 0;
+	typename S::StateRT st;
+	long long bin, bout;
+	S::base(af, blockIdx.x, bin, bout);
+	S::template prefetch<KIND_REDFT10>(af, bin, tid, st);
+	S::template phase<KIND_REDFT10, 0>(af, buf, bout, tid, st);
+	__syncthreads();
+	// The empty asm statements make the thread index (and, below, the inverse plan's table pointers) opaque at each
+	// phase: otherwise index arithmetic and twiddle loads of LATER phases are hoisted to the top of the kernel and
+	// stay live across every barrier (measured: 176 VGPRs -> 1 workgroup per CU; with them: <= 128).
+	static_for<1, S::NS + 2>([&](auto ph) {
+		int t = tid; asm volatile("" : "+v"(t));
+		S::template phase<KIND_REDFT10, ph>(af, buf, bout, t, st);
+		__syncthreads();
+	});
+	unsigned long long mine = 0;
+	int t = tid; asm volatile("" : "+v"(t));
+	S::mid_read(af, ai, buf, bout, t, st, filt, mine);
+	if (coded) {
+		unsigned int m = (unsigned int)mine;
+		for (int off = 32; off > 0; off >>= 1) m += __shfl_xor(m, off);
+		if ((tid & 63) == 0 && m) atomicAdd(&wg_coded, m);
+	}
+	__syncthreads();
+	if (coded && tid == 0 && wg_coded) atomicAdd(coded, (unsigned long long)wg_coded);
+	asm volatile("" : "+v"(t));
+	S::mid_write(buf, t, st);
+	__syncthreads();
+	PassArgs a2 = ai;
+	asm volatile("" : "+s"(a2.W), "+s"(a2.T), "+s"(a2.out));
+	static_for<1, S::NPH>([&](auto ph) {
+		asm volatile("" : "+v"(t));
+		S::template phase<KIND_REDFT01, ph>(a2, buf, bout, t, st);
+		if constexpr (ph + 1 < S::NPH) __syncthreads();
+	});
+}
+
 template <class R>
 __global__ void __launch_bounds__(256) dense_kernel(const DenseArgsT<R> a)
 {
@@ -290,7 +352,36 @@ int launch_col_spec(const PassArgs &a, int nwork, void *stream)
 	HIPCHK(hipGetLastError());
 	return 0;
 }
+template <class S>
+int launch_col_roundtrip(const PassArgs &af, const PassArgs &ai, const MotionFilter &filt, unsigned long long *coded, int nwork, void *stream)
+{
+	static int lds_ok = allow_lds(col_roundtrip_kernel<S>, S::LDS);
+	if (lds_ok) return lds_ok;
+	FilterOp f; f.p = filt;
+	hipLaunchKernelGGL((col_roundtrip_kernel<S>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, af, ai, f, coded);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
 #include "spec_registry.inc"
+
+__global__ void motion_filter_span_kernel(float *c, MotionFilter p, uint64_t span, unsigned long long *coded)
+{
+	unsigned long long mine = 0;
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < span; i += (uint64_t)gridDim.x * blockDim.x)
+		c[i] = motion_filter_elem(p, (uint32_t)i, c[i], mine);
+	if (coded) {
+		for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+		if ((threadIdx.x & 63) == 0 && mine) atomicAdd(coded, mine);
+	}
+}
+int be_motion_filter(float *buf, const MotionFilter &filt, uint64_t span, unsigned long long *coded, void *stream)
+{
+	if (!span) return 0;
+	uint64_t b = (span + 255) / 256;
+	hipLaunchKernelGGL(motion_filter_span_kernel, dim3((unsigned)(b > 8192 ? 8192 : b)), dim3(256), 0, (hipStream_t)stream, buf, filt, span, coded);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
 
 static inline int ew_grid(uint64_t n) { uint64_t b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b)); }
 

@@ -20,6 +20,17 @@
 #pragma once
 #include "radix.h"
 
+// keeps the compiler from hoisting every load of a phase above the first use (register pressure)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DSP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// pins a float4 in registers HERE: without it the compiler sinks the computation of values that are
+// consumed several barriers later and keeps their (twice as many) inputs alive instead
+#define DSP_PIN4(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
+#else
+#define DSP_SCHED_FENCE() ((void)0)
+#define DSP_PIN4(v) ((void)0)
+#endif
+
 namespace dspfft {
 
 struct FastDiv {
@@ -31,6 +42,13 @@ struct FastDiv {
 #else
 		return (uint32_t)(((uint64_t)n * mul) >> 32);
 #endif
+	}
+	// exact for every n < 2^31 (div() overshoots by one when n * (mul * d - 2^32) reaches 2^32)
+	DSP_HD uint32_t div_exact(uint32_t n) const
+	{
+		uint32_t q = div(n);
+		if (q * d > n) q--;
+		return q;
 	}
 };
 

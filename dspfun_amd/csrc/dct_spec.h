@@ -14,17 +14,6 @@
 #pragma once
 #include "dct_core.h"
 
-// keeps the compiler from hoisting every load of a phase above the first use (register pressure)
-#if defined(__HIP_DEVICE_COMPILE__)
-#define DSP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-// pins a float4 in registers HERE: without it the compiler sinks the computation of values that are
-// consumed several barriers later and keeps their (twice as many) inputs alive instead
-#define DSP_PIN4(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
-#else
-#define DSP_SCHED_FENCE() ((void)0)
-#define DSP_PIN4(v) ((void)0)
-#endif
-
 namespace dspfft {
 
 template <int I, int... Rs> constexpr int pack_get() { constexpr int a[] = {Rs..., 1}; return a[I]; }
@@ -441,6 +430,64 @@ struct ColSpec {
 					p[r * NBL * NP] = v;
 				});
 			}
+		});
+	}
+
+	// ---- fused forward -> pointwise filter -> inverse along this axis (dspfft_execute_roundtrip) ----
+	// The tile never leaves LDS between the two transforms.  mid_read turns the forward FFT output into the
+	// coefficient rows k and N-k (exactly REDFT10's last phase), filters them, and applies REDFT01's first phase;
+	// the results wait in registers across one barrier because the inverse's padded layout overlaps slots other
+	// threads still have to read.
+	struct StateRT {
+		cf xa[LAST_ROUNDS * RL], xb[LAST_ROUNDS * RL];
+		float4 pre[(Y_ROUNDS > 2 * K_ROUNDS) ? Y_ROUNDS : 2 * K_ROUNDS];
+		cf tw[1];
+	};
+	template <class ST, class F>
+	static DSP_HD void mid_read(const PassArgs &af, const PassArgs &ai, const float4 *buf, long long bout, int tid, ST &st, const F &filt, unsigned long long &coded)
+	{
+		static_for<0, K_ROUNDS>([&](auto ri) {
+			const int it = tid + ri * T;
+			if (!((ri + 1) * T <= (N / 2 + 1) * NP || it < (N / 2 + 1) * NP)) return;
+			const int k = it / NP, jp = it - k * NP;
+			const int km = k ? N - k : 0;
+			const float4 zk = buf[k * NP + jp], zm = buf[km * NP + jp];
+			const cf t = af.T[k];
+			const cf A0 = cmk(zk.x + zm.x, zk.y - zm.y), B0 = cmul_mi(cmk(zk.x - zm.x, zk.y + zm.y));
+			const cf A1 = cmk(zk.z + zm.z, zk.w - zm.w), B1 = cmul_mi(cmk(zk.z - zm.z, zk.w + zm.w));
+			const cf wa0 = cmul(t, A0), wb0 = cmul(t, B0), wa1 = cmul(t, A1), wb1 = cmul(t, B1);
+			const float sc = af.scale, s0 = (k == 0) ? sc * af.out_scale0 : sc;
+			const long long o = bout + 4 * jp;
+			float4 xk, xm;
+			xk.x = wa0.x * s0; xk.y = wb0.x * s0; xk.z = wa1.x * s0; xk.w = wb1.x * s0;          // coefficient row k
+			xm.x = -wa0.y * sc; xm.y = -wb0.y * sc; xm.z = -wa1.y * sc; xm.w = -wb1.y * sc;      // coefficient row N-k
+			DSP_SCHED_FENCE();
+			xk = filt(o + (long long)k * af.es_out, xk, coded);
+			DSP_SCHED_FENCE();
+			if (k > 0 && km != k) xm = filt(o + (long long)km * af.es_out, xm, coded);
+			else if (km == k && k > 0) xm = xk;
+			DSP_SCHED_FENCE();                                                   // k = N/2: the same row
+			// REDFT01's first phase on rows k and N-k (ColSpec::phase<KIND_REDFT01, 0>)
+			if (k == 0) { xk.x *= ai.in_scale0; xk.y *= ai.in_scale0; xk.z *= ai.in_scale0; xk.w *= ai.in_scale0; xm.x = xm.y = xm.z = xm.w = 0.f; }
+			const cf Va0 = cmulc(cmk(xk.x, -xm.x), t), Vb0 = cmulc(cmk(xk.y, -xm.y), t);
+			const cf Va1 = cmulc(cmk(xk.z, -xm.z), t), Vb1 = cmulc(cmk(xk.w, -xm.w), t);
+			float4 lo, hi;
+			lo.x = Va0.x - Vb0.y; lo.y = -Va0.y - Vb0.x; lo.z = Va1.x - Vb1.y; lo.w = -Va1.y - Vb1.x;
+			hi.x = Va0.x + Vb0.y; hi.y = Va0.y - Vb0.x; hi.z = Va1.x + Vb1.y; hi.w = Va1.y - Vb1.x;
+			st.pre[2 * ri] = lo; st.pre[2 * ri + 1] = hi;
+			DSP_SCHED_FENCE();
+		});
+	}
+	template <class ST>
+	static DSP_HD void mid_write(float4 *buf, int tid, const ST &st)
+	{
+		static_for<0, K_ROUNDS>([&](auto ri) {
+			const int it = tid + ri * T;
+			if (!((ri + 1) * T <= (N / 2 + 1) * NP || it < (N / 2 + 1) * NP)) return;
+			const int k = it / NP, jp = it - k * NP;
+			const int km = k ? N - k : 0;
+			buf[padded(k) * NP + jp] = st.pre[2 * ri];
+			if (k > 0) buf[padded(km) * NP + jp] = st.pre[2 * ri + 1];
 		});
 	}
 

@@ -491,7 +491,7 @@ int run_pass(const dspfft_plan_s *pl, const Pass &P, const R *in, R *out, bool l
 
 static int plan_many(dspfft_plan *plan, int rank, const int *n, int howmany,
                      const int *inembed, int istride, int idist,
-                     const int *onembed, int ostride, int odist, const int *kinds, bool f64)
+                     const int *onembed, int ostride, int odist, const int *kinds, bool f64, bool first_axis_first = false)
 {
 	if (!plan) return fail(-1, "null plan pointer");
 	*plan = nullptr;
@@ -515,7 +515,8 @@ static int plan_many(dspfft_plan *plan, int rank, const int *n, int howmany,
 	for (int a = 0; a < rank; a++) samples *= (size_t)n[a];
 	pl->alg_bytes = samples * (f64 ? 16 : 8);
 	bool first = true;
-	for (int a = rank - 1; a >= 0; a--) {
+	for (int i = 0; i < rank; i++) {
+		const int a = first_axis_first ? i : rank - 1 - i;
 		pl->passes.emplace_back();
 		int rc = build_pass(pl, a, first, pl->passes.back());
 		if (rc) { dspfft_destroy_plan(pl); return rc; }
@@ -536,6 +537,13 @@ extern "C" int dspfft_plan_many_r2r_f64(dspfft_plan *plan, int rank, const int *
                                         const int *onembed, int ostride, int odist, const int *kinds)
 {
 	return plan_many(plan, rank, n, howmany, inembed, istride, idist, onembed, ostride, odist, kinds, true);
+}
+
+extern "C" int dspfft_plan_many_r2r_ordered(dspfft_plan *plan, int rank, const int *n, int howmany,
+                                            const int *inembed, int istride, int idist,
+                                            const int *onembed, int ostride, int odist, const int *kinds, int first_axis_first)
+{
+	return plan_many(plan, rank, n, howmany, inembed, istride, idist, onembed, ostride, odist, kinds, false, first_axis_first != 0);
 }
 
 extern "C" int dspfft_plan_r2r_2d(dspfft_plan *plan, int n0, int n1, int kind0, int kind1)
@@ -621,6 +629,60 @@ int execute_masked_accumulate_t(dspfft_plan pl, const R *d_in, R *d_work, R *d_a
 	return 0;
 }
 }  // namespace
+
+extern "C" int dspfft_execute_roundtrip(dspfft_plan fwd, dspfft_plan inv, const float *d_in, float *d_out,
+                                        const dspfft_motion_filter_params *fp, unsigned long long *d_coeffs_coded, void *stream)
+{
+	if (!fwd || !inv || !d_in || !d_out) return fail(-1, "null plan or buffer");
+	if (fwd->f64 || inv->f64) return fail(-1, "the fused roundtrip takes f32 plans");
+	const size_t nf = fwd->passes.size(), ni = inv->passes.size();
+	const Pass &F = fwd->passes[nf - 1], &I = inv->passes[0];
+	if (F.axis != I.axis || fwd->rank != inv->rank || fwd->howmany != inv->howmany)
+		return fail(-1, "the forward plan's last pass and the inverse plan's first pass must run along the same axis (create the inverse with dspfft_plan_many_r2r_ordered(..., 1))");
+	for (int a = 0; a < fwd->rank; a++)
+		if (fwd->n[a] != inv->n[a] || fwd->axes[a].os != inv->axes[a].is || inv->axes[a].is != inv->axes[a].os || fwd->kinds[a] != DSPFFT_REDFT10 || inv->kinds[a] != DSPFFT_REDFT01)
+			return fail(-1, "roundtrip: the inverse must be REDFT01, in place, on the forward (REDFT10) plan's output layout");
+	if (fwd->howmany > 1 && (fwd->batch.os != inv->batch.is || inv->batch.is != inv->batch.os)) return fail(-1, "roundtrip: batch layouts differ");
+	MotionFilter mf;
+	memset(&mf, 0, sizeof mf);
+	if (fp) {
+		if (fp->preserve_dc < 0 || fp->preserve_dc > 2 || fp->minbuf_hw[0] < 1 || fp->minbuf_hw[1] < 1 || fp->block_depth < 1) return fail(-1, "bad filter parameters");
+		mf.ad = fp->active[0]; mf.ah = fp->active[1]; mf.aw = fp->active[2]; mf.mh = fp->minbuf_hw[0]; mf.mw = fp->minbuf_hw[1];
+		mf.b0d = fp->band_begin[0]; mf.b0h = fp->band_begin[1]; mf.b0w = fp->band_begin[2];
+		mf.b1d = fp->band_end[0]; mf.b1h = fp->band_end[1]; mf.b1w = fp->band_end[2];
+		mf.damp = fp->damp; mf.boost = fp->boost; mf.thr_lo = fp->threshold_lo; mf.thr_hi = fp->threshold_hi;
+		mf.preserve_dc = fp->preserve_dc; mf.grey_add = fp->grey_add; mf.quantizer = fp->quantizer; mf.enabled = 1;
+		motion_filter_set_divs(mf, fp->block_depth);
+	}
+	// extent of the working buffer in elements (the filter addresses it with 32-bit offsets)
+	long long span = 1;
+	for (int a = 0; a < fwd->rank; a++) span += (long long)(fwd->n[a] - 1) * fwd->axes[a].os;
+	span += (long long)(fwd->howmany - 1) * fwd->batch.os;
+	if (fp && span >= (1ll << 31)) return fail(-2, "filtered roundtrip addresses the buffer with 31-bit offsets: buffer too large");
+	for (size_t i = 0; i + 1 < nf; i++) {
+		const Pass &P = fwd->passes[i];
+		if (int rc = run_pass<float>(fwd, P, P.first ? d_in : d_out, d_out, false, stream)) return rc;
+	}
+	const float *src = nf == 1 ? d_in : d_out;
+	const bool fusable = F.type == Pass::COL && I.type == Pass::COL && F.has_spec && I.has_spec && F.spec.id == I.spec.id && F.spec_nwg == I.spec_nwg &&
+	                     F.hostloop.empty() && I.hostloop.empty() && (15u & ((uintptr_t)src | (uintptr_t)d_out)) == 0 &&
+	                     !(getenv("DSPFFT_NO_FUSED_ROUNDTRIP") && *getenv("DSPFFT_NO_FUSED_ROUNDTRIP") == '1');
+	if (fusable) {
+		PassArgs af, ai;
+		fill_args(af, F.spa, fwd, F, src, d_out, fwd->scale, Fuse());
+		fill_args(ai, I.spa, inv, I, (const float *)d_out, d_out, ni == 1 ? inv->scale : 1.0, Fuse());
+		if (int rc = be_launch_roundtrip(F.spec.id, af, ai, mf, d_coeffs_coded, F.spec_nwg, stream)) return fail(-4, "kernel launch failed (fused roundtrip): backend code %d", rc);
+	} else {
+		if (int rc = run_pass<float>(fwd, F, src, d_out, true, stream)) return rc;
+		if (fp && be_motion_filter(d_out, mf, (uint64_t)span, d_coeffs_coded, stream)) return fail(-4, "filter launch failed");
+		if (int rc = run_pass<float>(inv, I, (const float *)d_out, d_out, ni == 1, stream)) return rc;
+	}
+	for (size_t i = 1; i < ni; i++) {
+		const Pass &P = inv->passes[i];
+		if (int rc = run_pass<float>(inv, P, (const float *)d_out, d_out, i + 1 == ni, stream)) return rc;
+	}
+	return 0;
+}
 
 extern "C" int dspfft_scan_zigzag_frame_ids(uint32_t *d_ids, uint32_t w, uint32_t h, uint64_t step, void *s)
 {

@@ -1,0 +1,79 @@
+// motion_filter.h -- motion's coefficient-domain filter (motion/motion.c:683-744) as one pointwise function of
+// (coefficient position, value), shared by the standalone kernel (pointwise.hip: dspfft_motion_filter) and by the
+// fused forward -> filter -> inverse column pass (dct_spec.h: ColSpec::mid_*, dspfft_execute_roundtrip).
+#pragma once
+#include <math.h>
+#include "dct_core.h"
+
+namespace dspfft {
+
+struct MotionFilter {
+	int ad, ah, aw, mh, mw;                  // active block and the buffer's row/plane extents
+	int b0d, b0h, b0w, b1d, b1h, b1w;        // pass band [begin, end) per axis
+	float damp, boost, thr_lo, thr_hi;
+	int preserve_dc;                         // 0 none, 1 dc, 2 grey
+	float grey_add, quantizer;
+	// position from an element offset into the buffer: x = e % mw, y = (e / mw) % mh, z = (e / (mw mh)) % bd
+	FastDiv div_mw, div_mh, div_bd;
+	int bd;                                  // frames per block as laid out (the embedding depth; 1 = every frame its own block)
+	int enabled;
+};
+
+inline FastDiv motion_filter_div(uint32_t d)
+{
+	FastDiv f; f.d = d; f.mul = d >= 2 ? (uint32_t)((((uint64_t)1 << 32) + d - 1) / d) : 0; return f;
+}
+inline void motion_filter_set_divs(MotionFilter &p, int block_depth)
+{
+	p.bd = block_depth;
+	p.div_mw = motion_filter_div((uint32_t)p.mw); p.div_mh = motion_filter_div((uint32_t)p.mh); p.div_bd = motion_filter_div((uint32_t)block_depth);
+}
+
+// one coefficient at block position (z, y, x); `coded` counts the non-zero quantised coefficients (motion.c:743)
+DSP_HD float motion_filter_at(const MotionFilter &p, int z, int y, int x, float v, unsigned long long &coded)
+{
+	const float dc = v;                                                        // motion.c:650 (element 0 only)
+	const bool inside = z >= p.b0d && z < p.b1d && y >= p.b0h && y < p.b1h && x >= p.b0w && x < p.b1w;
+	if (!inside) { if (p.damp != 1.f) v *= p.damp; }                          // :683-714 the six face slabs = the complement of the box
+	else if (p.boost != 1.f) v *= p.boost;                                    // :715-719
+	if (p.thr_hi > 0.f) { const float a = fabsf(v); if (a < p.thr_lo || a > p.thr_hi) v = 0.f; }   // :721-728
+	if (x == 0 && y == 0 && z == 0 && p.preserve_dc) {                        // :730-738
+		const bool dcstop = p.b0d || p.b0h || p.b0w;
+		if (dcstop || p.boost != 1.f || p.thr_hi > 0.f) {
+			if (p.preserve_dc == 1) v = dc;
+			else v += p.grey_add;
+		}
+	}
+	if (p.quantizer > 0.f) { v = (float)(round((double)v / p.quantizer) * p.quantizer); coded += (v != 0.f); }   // :740-744
+	return v;
+}
+
+// one element by offset; elements outside the active block (embedding padding) are returned unchanged
+DSP_HD float motion_filter_elem(const MotionFilter &p, uint32_t e, float v, unsigned long long &coded)
+{
+	const uint32_t row = p.div_mw.div_exact(e), x = e - row * (uint32_t)p.mw;
+	const uint32_t pl = p.div_mh.div_exact(row), y = row - pl * (uint32_t)p.mh;
+	const uint32_t z = pl - p.div_bd.div_exact(pl) * (uint32_t)p.bd;
+	if ((int)x >= p.aw || (int)y >= p.ah || (int)z >= p.ad) return v;
+	return motion_filter_at(p, (int)z, (int)y, (int)x, v, coded);
+}
+
+// four consecutive elements starting at element offset e (< 2^31) of the working buffer
+DSP_HD float4 motion_filter4(const MotionFilter &p, uint32_t e, float4 v, unsigned long long &coded)
+{
+	const uint32_t row = p.div_mw.div_exact(e);
+	int x = (int)(e - row * (uint32_t)p.mw);
+	const uint32_t pl = p.div_mh.div_exact(row);
+	int y = (int)(row - pl * (uint32_t)p.mh);
+	int z = (int)(pl - p.div_bd.div_exact(pl) * (uint32_t)p.bd);
+	float r[4] = {v.x, v.y, v.z, v.w};
+	for (int q = 0; q < 4; q++) {
+		r[q] = motion_filter_at(p, z, y, x, r[q], coded);
+		if (++x == p.mw) { x = 0; if (++y == p.mh) { y = 0; if (++z == p.bd) z = 0; } }
+		DSP_SCHED_FENCE();      // one double-precision quantiser at a time: interleaved, four of them cost ~60 VGPRs
+	}
+	float4 o; o.x = r[0]; o.y = r[1]; o.z = r[2]; o.w = r[3];
+	return o;
+}
+
+}  // namespace dspfft

@@ -9,6 +9,7 @@
 #include <stdio.h>
 
 #include "../../include/dspfft.h"
+#include "motion_filter.h"
 
 namespace {
 
@@ -61,38 +62,19 @@ __global__ void ispec_decode_kernel(float *f, size_t len, int d, double gain, do
 	}
 }
 
-struct MotionFilter {
-	int ad, ah, aw, mh, mw;
-	int b0d, b0h, b0w, b1d, b1h, b1w;
-	float damp, boost, thr_lo, thr_hi;
-	int preserve_dc;     // 0 none, 1 dc, 2 grey
-	float grey_add, quantizer;
-};
-
-__global__ void motion_filter_kernel(float *c, MotionFilter p, unsigned long long *coded)
+__global__ void motion_filter_kernel(float *c, dspfft::MotionFilter p, unsigned long long *coded)
 {
 	const size_t total = (size_t)p.ad * p.ah * p.aw;
 	unsigned long long mine = 0;
 	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
 		const int x = (int)(i % p.aw), y = (int)((i / p.aw) % p.ah), z = (int)(i / ((size_t)p.aw * p.ah));
 		const size_t o = ((size_t)z * p.mh + y) * p.mw + x;
-		float v = c[o];
-		const float dc = v;                                                        // motion.c:650 (element 0 only)
-		const bool inside = z >= p.b0d && z < p.b1d && y >= p.b0h && y < p.b1h && x >= p.b0w && x < p.b1w;
-		if (!inside) { if (p.damp != 1.f) v *= p.damp; }                          // :683-714 the six face slabs = the complement of the box
-		else if (p.boost != 1.f) v *= p.boost;                                    // :715-719
-		if (p.thr_hi > 0.f) { const float a = fabsf(v); if (a < p.thr_lo || a > p.thr_hi) v = 0.f; }   // :721-728
-		if (i == 0 && p.preserve_dc) {                                            // :730-738
-			const bool dcstop = p.b0d || p.b0h || p.b0w;
-			if (dcstop || p.boost != 1.f || p.thr_hi > 0.f) {
-				if (p.preserve_dc == 1) v = dc;
-				else v += p.grey_add;
-			}
-		}
-		if (p.quantizer > 0.f) { v = (float)(round((double)v / p.quantizer) * p.quantizer); mine += (v != 0.f); }   // :740-744
-		c[o] = v;
+		c[o] = dspfft::motion_filter_at(p, z, y, x, c[o], mine);
 	}
-	if (coded && mine) atomicAdd(coded, mine);
+	if (coded) {      // one atomic per wave
+		for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+		if ((threadIdx.x & 63) == 0 && mine) atomicAdd(coded, mine);
+	}
 }
 
 // scan/scan.c:20-28 basis matrix entries B_N[k][j] = j ? 2 cos(pi j (k + 1/2) / N) : 1, for the selected j only
@@ -173,10 +155,11 @@ extern "C" int dspfft_motion_filter(float *d_coeffs, const int active[3], const 
                                     float quantizer, unsigned long long *d_coeffs_coded, void *stream)
 {
 	if (!d_coeffs || !active || !minbuf_hw || !band_begin || !band_end || preserve_dc < 0 || preserve_dc > 2) return bad("bad arguments");
-	MotionFilter p;
+	dspfft::MotionFilter p;
 	p.ad = active[0]; p.ah = active[1]; p.aw = active[2]; p.mh = minbuf_hw[0]; p.mw = minbuf_hw[1];
 	p.b0d = band_begin[0]; p.b0h = band_begin[1]; p.b0w = band_begin[2]; p.b1d = band_end[0]; p.b1h = band_end[1]; p.b1w = band_end[2];
 	p.damp = damp; p.boost = boost; p.thr_lo = threshold_lo; p.thr_hi = threshold_hi; p.preserve_dc = preserve_dc; p.grey_add = grey_add; p.quantizer = quantizer;
+	p.enabled = 1; dspfft::motion_filter_set_divs(p, p.ad > 0 ? p.ad : 1);
 	const size_t total = (size_t)p.ad * p.ah * p.aw;
 	if (!total) return 0;
 	hipLaunchKernelGGL(motion_filter_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, d_coeffs, p, d_coeffs_coded);

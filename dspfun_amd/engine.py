@@ -34,17 +34,25 @@ class Plan:
         self.f64 = f64
 
     @classmethod
-    def many_r2r(cls, n, kinds, howmany=1, inembed=None, istride=1, idist=0, onembed=None, ostride=1, odist=0, lib=None, dtype="f32"):
+    def many_r2r(cls, n, kinds, howmany=1, inembed=None, istride=1, idist=0, onembed=None, ostride=1, odist=0, lib=None, dtype="f32",
+                 first_axis_first=False):
+        """first_axis_first: run axis 0 first and the contiguous axis last (f32 only); the inverse half of
+        `roundtrip` is created this way"""
         if dtype not in ("f32", "f64"):
             raise ValueError("dtype must be 'f32' or 'f64'")
+        if first_axis_first and dtype != "f32":
+            raise ValueError("first_axis_first is an f32 plan option")
         lib = lib or _lib.load()
         n = list(n)
         kinds = list(kinds)
         if len(kinds) != len(n):
             raise ValueError("one kind per transformed dimension")
         h = C.c_void_p()
-        make = lib.dspfft_plan_many_r2r_f64 if dtype == "f64" else lib.dspfft_plan_many_r2r
-        rc = make(C.byref(h), len(n), _ia(n), howmany, _ia(inembed), istride, idist, _ia(onembed), ostride, odist, _ia(kinds))
+        if first_axis_first:
+            rc = lib.dspfft_plan_many_r2r_ordered(C.byref(h), len(n), _ia(n), howmany, _ia(inembed), istride, idist, _ia(onembed), ostride, odist, _ia(kinds), 1)
+        else:
+            make = lib.dspfft_plan_many_r2r_f64 if dtype == "f64" else lib.dspfft_plan_many_r2r
+            rc = make(C.byref(h), len(n), _ia(n), howmany, _ia(inembed), istride, idist, _ia(onembed), ostride, odist, _ia(kinds))
         if rc:
             raise DspfftError(lib.dspfft_last_error().decode())
         return cls(h, lib, dtype == "f64")
@@ -94,6 +102,22 @@ class Plan:
         run = self._lib.dspfft_execute_masked_accumulate_f64 if self.f64 else self._lib.dspfft_execute_masked_accumulate
         self._check(run(
             self._h, C.c_void_p(d_in), C.c_void_p(d_work), C.c_void_p(d_acc), C.c_void_p(d_ids or None), frame_id, elems_per_id, C.c_void_p(stream)))
+
+    def roundtrip(self, inv, d_in, d_out=None, filter=None, d_coded=0, stream=0):
+        """motion/motion.c:641-753: self (REDFT10) -> filter -> inv (REDFT01, created with first_axis_first=True), the middle axis
+        fused into one launch when both plans have a specialised column kernel.  filter: dict with the fields of
+        dspfft_motion_filter_params, or None."""
+        d_out = d_in if d_out is None else d_out
+        fp = None
+        if filter is not None:
+            fp = _lib.MotionFilterParams()
+            fp.active = (C.c_int * 3)(*filter["active"]); fp.minbuf_hw = (C.c_int * 2)(*filter["minbuf_hw"]); fp.block_depth = int(filter["block_depth"])
+            fp.band_begin = (C.c_int * 3)(*filter["band_begin"]); fp.band_end = (C.c_int * 3)(*filter["band_end"])
+            fp.damp = filter.get("damp", 1.0); fp.boost = filter.get("boost", 1.0)
+            fp.threshold_lo = filter.get("threshold_lo", 0.0); fp.threshold_hi = filter.get("threshold_hi", 0.0)
+            fp.preserve_dc = filter.get("preserve_dc", 0); fp.grey_add = filter.get("grey_add", 0.0); fp.quantizer = filter.get("quantizer", 0.0)
+        self._check(self._lib.dspfft_execute_roundtrip(self._h, inv._h, C.c_void_p(d_in), C.c_void_p(d_out), C.byref(fp) if fp is not None else None,
+                                                       C.c_void_p(d_coded or None), C.c_void_p(stream)))
 
     def describe(self):
         buf = C.create_string_buffer(4096)

@@ -71,6 +71,34 @@ int dspfft_execute_f64(dspfft_plan plan, const double *d_in, double *d_out, void
 int dspfft_execute_masked_accumulate_f64(dspfft_plan plan, const double *d_in, double *d_work, double *d_acc,
                                          const uint32_t *d_ids, uint32_t id, int elems_per_id, void *hip_stream);
 
+/* As dspfft_plan_many_r2r, with the order of the axis passes chosen: first_axis_first = 0 is the default (last axis
+ * first), 1 runs axis 0 first and the contiguous axis last.  The results are the same; the order decides which pass
+ * reads the caller's input layout and which one ends the plan. */
+int dspfft_plan_many_r2r_ordered(dspfft_plan *plan, int rank, const int *n, int howmany,
+                                 const int *inembed, int istride, int idist,
+                                 const int *onembed, int ostride, int odist, const int *kinds, int first_axis_first);
+
+/* motion's transform -> filter -> inverse loop (motion/motion.c:641-753) as one call.  `fwd` is a REDFT10 plan in
+ * the default order, `inv` a REDFT01 plan created with first_axis_first = 1, in place on fwd's output layout; then
+ * fwd's last pass and inv's first pass run along the same axis, and when both have a specialised column kernel
+ * they execute as ONE launch: the tile stays in LDS through forward transform, filter and inverse transform
+ * (8 B/sample of HBM traffic instead of 24 for that axis and the filter).  Otherwise the three steps run
+ * separately.  filter == NULL skips the filter.  The filter is motion.c:683-744 (see dspfft_motion_filter below):
+ * positions are taken inside blocks of block_depth planes of minbuf_hw[0] x minbuf_hw[1] elements (block_depth =
+ * the embedding depth for one 3-D block, 1 when every frame is its own block, motion's default -b 0x0x1);
+ * d_coeffs_coded (device, may be NULL) is incremented by the number of non-zero quantised coefficients. */
+typedef struct {
+	int active[3];            /* block extent {d, h, w} actually transformed */
+	int minbuf_hw[2];         /* rows and row pitch of the buffer's planes */
+	int block_depth;
+	int band_begin[3], band_end[3];
+	float damp, boost, threshold_lo, threshold_hi;
+	int preserve_dc;          /* 0 none, 1 dc, 2 grey */
+	float grey_add, quantizer;
+} dspfft_motion_filter_params;
+int dspfft_execute_roundtrip(dspfft_plan fwd, dspfft_plan inv, const float *d_in, float *d_out,
+                             const dspfft_motion_filter_params *filter, unsigned long long *d_coeffs_coded, void *hip_stream);
+
 /* Replaces fftw(destroy_plan). */
 void dspfft_destroy_plan(dspfft_plan plan);
 

@@ -141,7 +141,39 @@ int launch_col_spec(const PassArgs &a, int nwork, void *)
 	}
 	return 0;
 }
+struct FilterOp {
+	MotionFilter p;
+	float4 operator()(long long e, float4 v, unsigned long long &coded) const { return p.enabled ? motion_filter4(p, (uint32_t)e, v, coded) : v; }
+};
+template <class S>
+int launch_col_roundtrip(const PassArgs &af, const PassArgs &ai, const MotionFilter &filt, unsigned long long *coded, int nwork, void *)
+{
+	std::vector<unsigned char> lds(S::LDS + 32);
+	float4 *buf = (float4 *)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
+	FilterOp f; f.p = filt;
+	unsigned long long mine = 0;
+	for (int wg = 0; wg < nwork; wg++) {
+		std::vector<typename S::StateRT> st(S::T);
+		long long bin, bout;
+		S::base(af, wg, bin, bout);
+		for (int tid = 0; tid < S::T; tid++) S::template prefetch<KIND_REDFT10>(af, bin, tid, st[tid]);
+		static_for<0, S::NS + 2>([&](auto ph) { for (int tid = 0; tid < S::T; tid++) S::template phase<KIND_REDFT10, ph>(af, buf, bout, tid, st[tid]); });
+		for (int tid = 0; tid < S::T; tid++) S::mid_read(af, ai, buf, bout, tid, st[tid], f, mine);
+		for (int tid = 0; tid < S::T; tid++) S::mid_write(buf, tid, st[tid]);
+		static_for<1, S::NPH>([&](auto ph) { for (int tid = 0; tid < S::T; tid++) S::template phase<KIND_REDFT01, ph>(ai, buf, bout, tid, st[tid]); });
+	}
+	if (coded) *coded += mine;
+	return 0;
+}
 #include "spec_registry.inc"
+
+int be_motion_filter(float *buf, const MotionFilter &filt, uint64_t span, unsigned long long *coded, void *)
+{
+	unsigned long long mine = 0;
+	for (uint64_t i = 0; i < span; i++) buf[i] = motion_filter_elem(filt, (uint32_t)i, buf[i], mine);
+	if (coded) *coded += mine;
+	return 0;
+}
 
 int be_scan_zigzag(uint32_t *lin, uint32_t w, uint32_t h, uint64_t first, uint64_t count, void *)
 {

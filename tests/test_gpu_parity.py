@@ -597,6 +597,69 @@ def test_motion_filter_vs_oracle(gpu, cfg):
         assert int(coded[0]) == n
 
 
+@pytest.mark.parametrize("case", ["volume", "frames", "frames_nofilter", "volume_quant"])
+def test_fused_roundtrip_vs_unfused_and_oracle(gpu, case):
+    """motion/motion.c:641-753 as one call: forward, filter, inverse with the middle axis fused into one launch;
+    against the oracle's filter between separately executed plans, and against the unfused execution of the same plans"""
+    import os
+    from dspfun_amd import Plan, REDFT10, REDFT01
+    import test_kernel_logic_cpu as tk
+    r2 = float(np.sqrt(2.0))
+    if case.startswith("volume"):
+        d, h, w = 256, 54, 96
+        n, howmany, dist, bd, active, frames = [d, h, w], 1, 0, d, (d, h, w), 1
+    else:
+        d, h, w = 5, 1080, 1920
+        n, howmany, dist, bd, active, frames = [h, w], d, h * w, 1, (1, h, w), d
+    x = ol.synth_u8(7, d * h * w).astype(np.float32).reshape(d, h, w)
+    rank = len(n)
+    nrm = 1.0 / np.prod([2.0 * v for v in n])
+    fwd = Plan.many_r2r(n, [REDFT10] * rank, howmany=howmany, idist=dist, odist=dist).set_scale(2 * r2)
+    inv = Plan.many_r2r(n, [REDFT01] * rank, howmany=howmany, idist=dist, odist=dist, first_axis_first=True).set_scale(nrm / (2 * r2))
+    ref_inv = Plan.many_r2r(n, [REDFT01] * rank, howmany=howmany, idist=dist, odist=dist).set_scale(nrm / (2 * r2))
+    for a in range(rank):
+        fwd.set_axis_scale0(a, 1.0, 1.0 / r2); inv.set_axis_scale0(a, r2, 1.0); ref_inv.set_axis_scale0(a, r2, 1.0)
+    assert "COL*" in fwd.describe().splitlines()[-1] and "COL*" in inv.describe().splitlines()[1]
+    flt = None
+    if case == "volume":
+        flt = dict(active=active, minbuf_hw=(h, w), block_depth=bd, band_begin=(0, 1, 2), band_end=(100, 40, 70), damp=0.25, boost=1.5, preserve_dc=1)
+    elif case == "volume_quant":
+        flt = dict(active=active, minbuf_hw=(h, w), block_depth=bd, band_begin=(0, 0, 0), band_end=active, threshold_lo=2.0, threshold_hi=1e9, preserve_dc=2, grey_add=3.5, quantizer=4.0)
+    elif case == "frames":
+        flt = dict(active=active, minbuf_hw=(h, w), block_depth=bd, band_begin=(0, 3, 1), band_end=(1, 800, 1500), damp=0.5, boost=1.0, quantizer=2.5)
+    dref = dev(gpu, x)
+    fwd.execute(dref.data_ptr())
+    gpu.cuda.synchronize()
+    ref = dref.cpu().numpy()
+    ncoded = 0
+    if flt:
+        for f in range(frames):
+            ncoded += tk._oracle_filter(ref.reshape(frames, -1)[f], active, (h, w), flt)
+    dref = dev(gpu, ref)
+    ref_inv.execute(dref.data_ptr())
+    gpu.cuda.synchronize()
+    ref = dref.cpu().numpy()
+    got = dev(gpu, x)
+    coded = gpu.zeros(1, dtype=gpu.int64, device="cuda:0")
+    fwd.roundtrip(inv, got.data_ptr(), filter=flt, d_coded=coded.data_ptr())
+    gpu.cuda.synchronize()
+    g = got.cpu().numpy()
+    assert np.abs(g - ref).max() <= 1e-3, np.abs(g - ref).max()          # values in the u8 range; two pass orders and a quantiser in between
+    if flt and flt.get("quantizer"):
+        assert abs(int(coded[0]) - ncoded) <= max(2, ncoded // 100000)    # a coefficient on a rounding boundary may flip between the two orders
+    if not flt:
+        assert np.abs(g - x).max() < 2e-3
+    os.environ["DSPFFT_NO_FUSED_ROUNDTRIP"] = "1"
+    try:
+        got2 = dev(gpu, x)
+        coded2 = gpu.zeros(1, dtype=gpu.int64, device="cuda:0")
+        fwd.roundtrip(inv, got2.data_ptr(), filter=flt, d_coded=coded2.data_ptr())
+        gpu.cuda.synchronize()
+    finally:
+        del os.environ["DSPFFT_NO_FUSED_ROUNDTRIP"]
+    assert gpu.equal(got, got2) and int(coded[0]) == int(coded2[0])        # same arithmetic, tile kept in LDS
+
+
 def test_scan_pruned_idct_path(gpu):
     """scan.c:20-41,449: few coefficients per frame -> direct rank-1 sums; against the restatement and against the
     transform path (dspfft_execute_masked_accumulate) on the same frames"""

@@ -374,3 +374,84 @@ def test_bluestein_fused_scan_step_and_dense_fallback():
     pd.execute(a.ctypes.data)
     Plan.image(h, w, c, REDFT10, lib=L).execute(b.ctypes.data)
     assert relerr(a, b.astype(np.float64)) < TOL
+
+
+# ---- pass order and the fused forward -> filter -> inverse column pass (motion/motion.c:641-753) ----
+def _oracle_filter(c, active, minbuf_hw, flt):
+    import ctypes as C
+    O = ol.lib()
+    I3, I2 = C.c_int * 3, C.c_int * 2
+    O.oracle_motion_filter_f32.restype = C.c_ulonglong
+    O.oracle_motion_filter_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_double, C.c_float]
+    return O.oracle_motion_filter_f32(c.ctypes.data, I3(*active), I2(*minbuf_hw), I3(*flt["band_begin"]), I3(*flt["band_end"]), flt.get("damp", 1.0), flt.get("boost", 1.0),
+                                      flt.get("threshold_lo", 0.0), flt.get("threshold_hi", 0.0), flt.get("preserve_dc", 0), flt.get("grey_add", 0.0), flt.get("quantizer", 0.0))
+
+
+def test_first_axis_first_order_gives_the_same_transform():
+    d, h, w = 6, 10, 16
+    x = ol.synth_f32(3, d * h * w)
+    for kind in (REDFT10, REDFT01):
+        a, b = x.copy(), x.copy()
+        pa = Plan.many_r2r([d, h, w], [kind] * 3, lib=emul())
+        pb = Plan.many_r2r([d, h, w], [kind] * 3, lib=emul(), first_axis_first=True)
+        assert pa.describe().splitlines()[1].startswith("axis 2") and pb.describe().splitlines()[1].startswith("axis 0")
+        pa.execute(a.ctypes.data); pb.execute(b.ctypes.data)
+        assert relerr(b, a.astype(np.float64)) < 1e-6
+
+
+@pytest.mark.parametrize("case", ["volume", "frames", "frames_nofilter", "volume_quant"])
+def test_fused_roundtrip_matches_unfused_and_oracle(case):
+    import ctypes as C
+    L = emul()
+    r2 = float(np.sqrt(2.0))
+    if case.startswith("volume"):
+        d, h, w = 256, 4, 8                       # one 3-D block: z is the fused axis (COL* N=256 K=16, inner = h*w = 32)
+        n, howmany, dist, bd = [d, h, w], 1, 0, d
+        active, frames = (d, h, w), 1
+    else:
+        d, h, w = 3, 480, 16                      # per-frame 2-D blocks (motion's default -b 0x0x1): y is the fused axis
+        n, howmany, dist, bd = [h, w], d, h * w, 1
+        active, frames = (1, h, w), d
+    x = (ol.synth_u8(7, d * h * w).astype(np.float32)).reshape(d, h, w)
+    rank = len(n)
+    nrm = 1.0 / np.prod([2.0 * v for v in n])     # REDFT01(REDFT10(x)) = prod(2 n) x
+    fwd = Plan.many_r2r(n, [REDFT10] * rank, howmany=howmany, idist=dist, odist=dist, lib=L).set_scale(2 * r2)
+    inv = Plan.many_r2r(n, [REDFT01] * rank, howmany=howmany, idist=dist, odist=dist, lib=L, first_axis_first=True).set_scale(nrm / (2 * r2))
+    ref_inv = Plan.many_r2r(n, [REDFT01] * rank, howmany=howmany, idist=dist, odist=dist, lib=L).set_scale(nrm / (2 * r2))
+    for a in range(rank):
+        fwd.set_axis_scale0(a, 1.0, 1.0 / r2); inv.set_axis_scale0(a, r2, 1.0); ref_inv.set_axis_scale0(a, r2, 1.0)
+    assert "COL*" in fwd.describe().splitlines()[-1] and "COL*" in inv.describe().splitlines()[1]
+    flt = None
+    if case == "volume":
+        flt = dict(active=active, minbuf_hw=(h, w), block_depth=bd, band_begin=(0, 1, 2), band_end=(100, 4, 7), damp=0.25, boost=1.5, preserve_dc=1)
+    elif case == "volume_quant":
+        flt = dict(active=active, minbuf_hw=(h, w), block_depth=bd, band_begin=(0, 0, 0), band_end=active, threshold_lo=2.0, threshold_hi=1e9, preserve_dc=2, grey_add=3.5, quantizer=4.0)
+    elif case == "frames":
+        flt = dict(active=active, minbuf_hw=(h, w), block_depth=bd, band_begin=(0, 3, 1), band_end=(1, 300, 12), damp=0.5, boost=1.0, quantizer=2.5)
+    # reference: forward, the oracle's filter block by block, inverse in the default order
+    ref = x.copy()
+    fwd.execute(ref.ctypes.data)
+    ncoded = 0
+    if flt:
+        for f in range(frames):
+            blk = ref.reshape(frames, -1)[f]
+            ncoded += _oracle_filter(blk, active, (h, w), flt)
+    ref_inv.execute(ref.ctypes.data)
+    # fused
+    got = x.copy()
+    coded = np.zeros(1, dtype=np.uint64)
+    fwd.roundtrip(inv, got.ctypes.data, filter=flt, d_coded=coded.ctypes.data)
+    assert np.abs(got - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), np.abs(got - ref).max()     # u8-range values, two pass orders
+    if flt and flt.get("quantizer"):
+        assert int(coded[0]) == ncoded
+    if not flt:
+        assert np.abs(got - x).max() < 2e-3
+    # unfused execution of the same plan pair: bit-identical
+    os.environ["DSPFFT_NO_FUSED_ROUNDTRIP"] = "1"
+    try:
+        got2 = x.copy()
+        coded2 = np.zeros(1, dtype=np.uint64)
+        fwd.roundtrip(inv, got2.ctypes.data, filter=flt, d_coded=coded2.ctypes.data)
+    finally:
+        del os.environ["DSPFFT_NO_FUSED_ROUNDTRIP"]
+    assert np.array_equal(got, got2) and coded[0] == coded2[0]

@@ -1,6 +1,6 @@
 """Secondary measurements (not the headline): zoom C3 (MFMA), scan C4 fused frame step, motion C5 3-D.
 Prints one JSON object.  Run on the GPU box: python tools/bench_paths.py"""
-import json, math, os, sys, time
+import ctypes as C, json, math, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dspfun_amd import Plan, _lib, REDFT10, REDFT01
@@ -80,6 +80,34 @@ def rt2():
 ms = timeit(rt2, reps=3, warm=1)
 res["motion_c5_luma_per_frame_2d_roundtrip"] = {"ms": round(ms, 2), "Msamples_per_s": round(n / ms / 1e3, 1), "algorithmic_GBps": round(n * 16 / ms / 1e6, 1),
                                                 "frac_of_8TBps": round(n * 16 / ms / 1e6 / 8000, 4)}
+# the same through dspfft_execute_roundtrip (inverse in first-axis-first order, middle axis fused) with motion's quantiser
+import os as _os
+flt = dict(active=(d_, h, w), minbuf_hw=(h, w), block_depth=d_, band_begin=(0, 0, 0), band_end=(d_, h, w), quantizer=3.0)
+inv3 = Plan.many_r2r([d_, h, w], [REDFT01] * 3, first_axis_first=True).set_scale(1.0 / (2 * r2) / (8.0 * d_ * h * w))
+for a in range(3):
+    inv3.set_axis_scale0(a, r2, 1.0)
+coded = torch.zeros(1, dtype=torch.int64, device=dev)
+I3, I2 = (C.c_int * 3), (C.c_int * 2)
+def rt_unfused_filter():
+    fwd.execute(vol.data_ptr())
+    L.dspfft_motion_filter(vol.data_ptr(), I3(d_, h, w), I2(h, w), I3(0, 0, 0), I3(d_, h, w), 1.0, 1.0, 0.0, 0.0, 0, 0.0, 3.0, coded.data_ptr(), None)
+    invp.execute(vol.data_ptr())
+vol.copy_(torch.rand(d_, h, w, device=dev) * 255)
+ms_u = timeit(rt_unfused_filter, reps=3, warm=1)
+vol.copy_(torch.rand(d_, h, w, device=dev) * 255)
+ms_f = timeit(lambda: fwd.roundtrip(inv3, vol.data_ptr(), filter=flt, d_coded=coded.data_ptr()), reps=3, warm=1)
+res["motion_c5_luma_3d_filtered_roundtrip"] = {"unfused_ms": round(ms_u, 2), "fused_ms": round(ms_f, 2), "speedup": round(ms_u / ms_f, 2),
+                                               "fused_algorithmic_GBps": round(n * 40 / ms_f / 1e6, 1), "note": "fused: 5 launches, 40 B/sample; unfused: 7 launches, 56 B/sample"}
+flt2 = dict(active=(1, h, w), minbuf_hw=(h, w), block_depth=1, band_begin=(0, 0, 0), band_end=(1, h, w), quantizer=3.0)
+i2r = Plan.many_r2r([h, w], [REDFT01] * 2, howmany=d_, idist=h * w, odist=h * w, first_axis_first=True).set_scale(1.0 / (4.0 * h * w))
+vol.copy_(torch.rand(d_, h, w, device=dev) * 255)
+ms_f2 = timeit(lambda: f2.roundtrip(i2r, vol.data_ptr(), filter=flt2, d_coded=coded.data_ptr()), reps=3, warm=1)
+vol.copy_(torch.rand(d_, h, w, device=dev) * 255)
+_os.environ["DSPFFT_NO_FUSED_ROUNDTRIP"] = "1"
+ms_u2 = timeit(lambda: f2.roundtrip(i2r, vol.data_ptr(), filter=flt2, d_coded=coded.data_ptr()), reps=3, warm=1)
+del _os.environ["DSPFFT_NO_FUSED_ROUNDTRIP"]
+res["motion_c5_luma_per_frame_filtered_roundtrip"] = {"unfused_ms": round(ms_u2, 2), "fused_ms": round(ms_f2, 2), "speedup": round(ms_u2 / ms_f2, 2),
+                                                      "fused_algorithmic_GBps": round(n * 24 / ms_f2 / 1e6, 1), "note": "256 frames of 1920x1080, fused: 3 launches, 24 B/sample; unfused: 5 launches, 40 B/sample"}
 del vol
 # ---- double precision (fftw_ API, spec's default build): 4K frame roundtrip on the runtime-geometry kernels ----
 h, w, c = 2160, 3840, 3
