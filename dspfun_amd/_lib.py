@@ -15,7 +15,7 @@ REDFT01, REDFT10 = 4, 5
 SYMBOLS = [
     "dspfft_plan_many_r2r", "dspfft_plan_r2r_2d", "dspfft_plan_set_scale", "dspfft_plan_set_axis_scale0",
     "dspfft_plan_many_r2r_f64", "dspfft_plan_set_scale_f64", "dspfft_plan_set_axis_scale0_f64", "dspfft_execute_f64", "dspfft_execute_masked_accumulate_f64",
-    "dspfft_plan_many_r2r_ordered", "dspfft_execute_roundtrip",
+    "dspfft_plan_many_r2r_ordered", "dspfft_execute_roundtrip", "dspfft_execute_roundtrip_u8",
     "dspfft_execute", "dspfft_plan_num_passes", "dspfft_execute_pass", "dspfft_destroy_plan", "dspfft_plan_describe", "dspfft_plan_algorithmic_bytes",
     "dspfft_last_error", "dspfft_version",
     "dspfft_scan_zigzag", "dspfft_scan_zigzag_frame_ids", "dspfft_execute_masked_accumulate", "dspfft_scan_scatter", "dspfft_accumulate", "dspfft_broadcast_dc",
@@ -47,6 +47,7 @@ def bind(lib):
     lib.dspfft_plan_many_r2r_f64.argtypes = lib.dspfft_plan_many_r2r.argtypes
     lib.dspfft_plan_many_r2r_ordered.argtypes = lib.dspfft_plan_many_r2r.argtypes + [C.c_int]
     lib.dspfft_execute_roundtrip.argtypes = [vp, vp, vp, vp, C.POINTER(MotionFilterParams), vp, vp]
+    lib.dspfft_execute_roundtrip_u8.argtypes = [vp, vp, vp, vp, vp, C.c_double, C.POINTER(MotionFilterParams), vp, vp]
     lib.dspfft_plan_set_scale_f64.argtypes = [vp, C.c_double]
     lib.dspfft_plan_set_axis_scale0_f64.argtypes = [vp, C.c_int, C.c_double, C.c_double]
     lib.dspfft_execute_f64.argtypes = [vp, vp, vp, vp]

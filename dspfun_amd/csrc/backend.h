@@ -5,6 +5,7 @@
 #include <stddef.h>
 #include "dct_core.h"
 #include "motion_filter.h"
+#include "dct_spec.h"
 
 namespace dspfft {
 
@@ -36,6 +37,9 @@ int be_launch_blue(const BlueArgsD &a, const LaunchGeom &g, void *stream);
 struct SpecInfo { int id, nthr, P; size_t lds; };   // P = C (ROW) or K (COL)
 bool be_find_spec(int is_col, int N, int P, SpecInfo *info);
 int be_launch_spec(int is_col, int id, const PassArgs &a, int nwg, void *stream);
+// planar row pass reading u8 (REDFT10) or writing quantised u8 (REDFT01); only specs with C == 1 have it
+bool be_spec_has_u8(int row_spec_id);
+int be_launch_spec_u8(int row_spec_id, const PassArgs &a, const U8IO &io, int nwg, void *stream);
 // fused column roundtrip: REDFT10 along the tile axis (af), pointwise filter, REDFT01 (ai); both passes share spec `id`
 int be_launch_roundtrip(int id, const PassArgs &af, const PassArgs &ai, const MotionFilter &filt, unsigned long long *coded, int nwg, void *stream);
 

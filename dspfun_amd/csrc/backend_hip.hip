@@ -114,6 +114,27 @@ __global__ void __launch_bounds__(S::T, S::WPE) row_spec_kernel(const PassArgs a
 	});
 }
 
+// the same with 8-bit input (REDFT10) or quantised 8-bit output (REDFT01): planar rows only
+template <class S, int KIND>
+__global__ void __launch_bounds__(S::T, S::WPE) row_spec_u8_kernel(const PassArgs a, const U8IO io)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+	cf *planes = reinterpret_cast<cf *>(lds);
+	const int tid = threadIdx.x;
+	typename S::template State<KIND> st;
+	long long bin, bout;
+	row_base(a, blockIdx.x, bin, bout);
+	S::template prefetch<KIND>(a, bin, tid, st, &io);
+	S::template phase<KIND, 0>(a, planes, bout, tid, st, &io);
+	__syncthreads();
+	static_for<1, S::NPH>([&](auto ph) {
+		{
+			S::template phase<KIND, ph>(a, planes, bout, tid, st, &io);
+			if constexpr (ph + 1 < S::NPH) __syncthreads();
+		}
+	});
+}
+
 template <class S, int KIND>
 __global__ void __launch_bounds__(S::T, S::WPE) col_spec_kernel(const PassArgs a)
 {
@@ -349,6 +370,15 @@ int launch_col_spec(const PassArgs &a, int nwork, void *stream)
 	static int lds_ok = allow_lds(col_spec_kernel<S, KIND>, S::LDS);
 	if (lds_ok) return lds_ok;
 	hipLaunchKernelGGL((col_spec_kernel<S, KIND>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+template <class S, int KIND>
+int launch_row_spec_u8(const PassArgs &a, const U8IO &io, int nwork, void *stream)
+{
+	static int lds_ok = allow_lds(row_spec_u8_kernel<S, KIND>, S::LDS);
+	if (lds_ok) return lds_ok;
+	hipLaunchKernelGGL((row_spec_u8_kernel<S, KIND>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a, io);
 	HIPCHK(hipGetLastError());
 	return 0;
 }

@@ -13,6 +13,7 @@
 // Phases are barrier-separated and numbered 0 .. NS+1 (load/pre, NS FFT stages, post/unpack).
 #pragma once
 #include "dct_core.h"
+#include "elementwise_core.h"
 
 namespace dspfft {
 
@@ -108,6 +109,11 @@ DSP_HD void store4_a(const PassArgs &a, long long off, float4 r)
 	*p = r;
 }
 
+// 8-bit samples at the ends of motion's pipeline (motion/motion.c:617-640 load, :760-776 store), fused into the
+// planar (C = 1) row passes: `in` replaces the float input of a REDFT10 pass, `out` receives
+// quantise_u8(value * mul) instead of the float output of a REDFT01 pass.  Offsets are the plan's element offsets.
+struct U8IO { const uint8_t *in; uint8_t *out; double mul; };
+
 // =================================================================================================
 template <int N_, int C_, int T_, int... Rs>
 struct RowSpec {
@@ -126,17 +132,33 @@ struct RowSpec {
 	static constexpr int LAST_ROUNDS = (C * NBL + T - 1) / T;
 	static constexpr int PIX_ROUNDS = (N + T - 1) / T;           // REDFT10: pixels per thread
 	static constexpr int K_ROUNDS = (L / 2 + 1 + T - 1) / T;     // REDFT01: (k, L-k) pairs per thread
+	// 8-bit ends (U8IO, planar rows): a thread moves FOUR consecutive pixels as one dword, x = 4 (tid + i T) + q
+	static constexpr int U8_ROUNDS = (N / 4 + T - 1) / T;
+	static constexpr bool U8_OK = (C == 1) && (N % 4 == 0);
 	// per-thread registers that live across barriers: the last stage's butterflies and the
 	// prefetched global data of the NEXT line (persistent workgroups, see backend_hip.hip)
 	template <int KIND> struct State {
 		cf x[LAST_ROUNDS * RL];
-		float pre[(KIND == KIND_REDFT10 ? PIX_ROUNDS : 4 * K_ROUNDS) * C];
+		float pre[(KIND == KIND_REDFT10 ? (U8_OK && 4 * U8_ROUNDS > PIX_ROUNDS ? 4 * U8_ROUNDS : PIX_ROUNDS) : 4 * K_ROUNDS) * C];
 	};
 
 	// issue the global loads of one line into registers (no LDS access, no waiting)
 	template <int KIND, class ST>
-	static DSP_HD void prefetch(const PassArgs &a, long long bin, int tid, ST &st)
+	static DSP_HD void prefetch(const PassArgs &a, long long bin, int tid, ST &st, const U8IO *io = nullptr)
 	{
+		if constexpr (KIND == KIND_REDFT10 && U8_OK) {
+			if (io && io->in) {
+				static_for<0, U8_ROUNDS>([&](auto i) {
+					const int g = tid + i * T;
+					if ((i + 1) * T <= N / 4 || g < N / 4) {
+						uint32_t w4;
+						__builtin_memcpy(&w4, io->in + bin + 4 * g, 4);
+						static_for<0, 4>([&](auto q) { st.pre[i * 4 + q] = (float)((w4 >> (8 * q)) & 0xffu); });
+					}
+				});
+				return;
+			}
+		}
 		if constexpr (KIND == KIND_REDFT10) {
 			static_for<0, PIX_ROUNDS>([&](auto i) {
 				const int x = tid + i * T;
@@ -216,10 +238,24 @@ struct RowSpec {
 
 	// phase 0 consumes the prefetched registers; phases 1.. work on LDS; the last one stores to `bout`
 	template <int KIND, int PH, class ST>
-	static DSP_HD void phase(const PassArgs &a, cf *planes, long long bout, int tid, ST &st)
+	static DSP_HD void phase(const PassArgs &a, cf *planes, long long bout, int tid, ST &st, const U8IO *io = nullptr)
 	{
 		float *pf = reinterpret_cast<float *>(planes);
 		if constexpr (PH == 0) {
+			if constexpr (KIND == KIND_REDFT10 && U8_OK) {
+				if (io && io->in) {       // the prefetch took four consecutive pixels per round
+					static_for<0, U8_ROUNDS>([&](auto i) {
+						const int g = tid + i * T;
+						if ((i + 1) * T <= N / 4 || g < N / 4)
+							static_for<0, 4>([&](auto q) {
+								const int x = 4 * g + q, n = makhoul_dst(x, N);
+								const float v = st.pre[i * 4 + q];
+								pf[2 * padded(n >> 1) + (n & 1)] = (x == 0) ? v * a.in_scale0 : v;
+							});
+					});
+					return;
+				}
+			}
 			if constexpr (KIND == KIND_REDFT10) {
 				// pixel x -> reordered sample n; float index inside the (padded) channel plane
 				static_for<0, PIX_ROUNDS>([&](auto i) {
@@ -287,6 +323,21 @@ struct RowSpec {
 					if (k > 0 && L + k != N - k) store_pix_a<C>(a, bout + (long long)(L + k) * C, o3);
 				});
 			} else {
+				if constexpr (U8_OK) {
+					if (io && io->out) {      // four consecutive quantised pixels per dword store
+						tloop<N / 4, T>(tid, [&](int g) {
+							uint32_t w4 = 0;
+							static_for<0, 4>([&](auto q) {
+								const int x = 4 * g + q, n = makhoul_dst(x, N);
+								const float sc = (x == 0) ? a.scale * a.out_scale0 : a.scale;
+								const float f = pf[n];
+								w4 |= (uint32_t)quantise_u8((double)(((n & 1) ? -f : f) * sc) * io->mul) << (8 * q);
+							});
+							__builtin_memcpy(io->out + bout + 4 * g, &w4, 4);
+						});
+						return;
+					}
+				}
 				tloop<N, T>(tid, [&](int x) {
 					const int n = makhoul_dst(x, N);
 					Pix<C> o;

@@ -630,10 +630,23 @@ int execute_masked_accumulate_t(dspfft_plan pl, const R *d_in, R *d_work, R *d_a
 }
 }  // namespace
 
-extern "C" int dspfft_execute_roundtrip(dspfft_plan fwd, dspfft_plan inv, const float *d_in, float *d_out,
-                                        const dspfft_motion_filter_params *fp, unsigned long long *d_coeffs_coded, void *stream)
+namespace {
+// a planar row pass that can take / produce 8-bit samples itself
+bool pass_has_u8(const Pass &P) { return P.type == Pass::ROW && P.has_spec && P.pa.C == 1 && P.hostloop.empty() && be_spec_has_u8(P.spec.id); }
+
+int run_pass_u8(const dspfft_plan_s *pl, const Pass &P, const float *in, float *out, bool last, const U8IO &io, void *stream)
 {
-	if (!fwd || !inv || !d_in || !d_out) return fail(-1, "null plan or buffer");
+	PassArgs a;
+	fill_args(a, P.spa, pl, P, in, out, last ? pl->scale : 1.0, Fuse());
+	if (int rc = be_launch_spec_u8(P.spec.id, a, io, P.spec_nwg, stream)) return fail(-4, "kernel launch failed (%s, u8): backend code %d", P.desc.c_str(), rc);
+	return 0;
+}
+
+// d_in8 / d_out8 non-NULL: 8-bit samples at the two ends (dspfft_execute_roundtrip_u8), d_out is then the float work buffer
+int roundtrip_core(dspfft_plan fwd, dspfft_plan inv, const float *d_in, float *d_out, const uint8_t *d_in8, uint8_t *d_out8, double mul8,
+                   const dspfft_motion_filter_params *fp, unsigned long long *d_coeffs_coded, void *stream)
+{
+	if (!fwd || !inv || !(d_in || d_in8) || !d_out) return fail(-1, "null plan or buffer");
 	if (fwd->f64 || inv->f64) return fail(-1, "the fused roundtrip takes f32 plans");
 	const size_t nf = fwd->passes.size(), ni = inv->passes.size();
 	const Pass &F = fwd->passes[nf - 1], &I = inv->passes[0];
@@ -659,8 +672,25 @@ extern "C" int dspfft_execute_roundtrip(dspfft_plan fwd, dspfft_plan inv, const 
 	for (int a = 0; a < fwd->rank; a++) span += (long long)(fwd->n[a] - 1) * fwd->axes[a].os;
 	span += (long long)(fwd->howmany - 1) * fwd->batch.os;
 	if (fp && span >= (1ll << 31)) return fail(-2, "filtered roundtrip addresses the buffer with 31-bit offsets: buffer too large");
+	if (d_in8 || d_out8) {
+		// the 8-bit buffers share the plans' element layout; the unfused conversions below walk whole spans
+		if (nf < 2 || ni < 2) return fail(-2, "8-bit roundtrip needs at least two transformed axes");
+		long long ispan = 1;
+		for (int a = 0; a < fwd->rank; a++) ispan += (long long)(fwd->n[a] - 1) * fwd->axes[a].is;
+		ispan += (long long)(fwd->howmany - 1) * fwd->batch.is;
+		if (d_in8 && !pass_has_u8(fwd->passes[0])) {
+			if (ispan != span) return fail(-2, "8-bit input without a planar specialised row pass needs identical input and work layouts");
+			if (be_u8_to_f32(d_out, d_in8, (uint64_t)span, stream)) return fail(-4, "launch failed");
+			d_in = d_out; d_in8 = nullptr;
+		}
+	}
 	for (size_t i = 0; i + 1 < nf; i++) {
 		const Pass &P = fwd->passes[i];
+		if (i == 0 && d_in8) {
+			U8IO io; io.in = d_in8; io.out = nullptr; io.mul = 1.0;
+			if (int rc = run_pass_u8(fwd, P, d_out, d_out, false, io, stream)) return rc;
+			continue;
+		}
 		if (int rc = run_pass<float>(fwd, P, P.first ? d_in : d_out, d_out, false, stream)) return rc;
 	}
 	const float *src = nf == 1 ? d_in : d_out;
@@ -679,9 +709,30 @@ extern "C" int dspfft_execute_roundtrip(dspfft_plan fwd, dspfft_plan inv, const 
 	}
 	for (size_t i = 1; i < ni; i++) {
 		const Pass &P = inv->passes[i];
+		if (i + 1 == ni && d_out8 && pass_has_u8(P)) {
+			U8IO io; io.in = nullptr; io.out = d_out8; io.mul = mul8;
+			if (int rc = run_pass_u8(inv, P, d_out, d_out, true, io, stream)) return rc;
+			return 0;
+		}
 		if (int rc = run_pass<float>(inv, P, (const float *)d_out, d_out, i + 1 == ni, stream)) return rc;
 	}
+	if (d_out8 && be_f32_to_u8(d_out8, d_out, mul8, (uint64_t)span, stream)) return fail(-4, "launch failed");
 	return 0;
+}
+}  // namespace
+
+extern "C" int dspfft_execute_roundtrip(dspfft_plan fwd, dspfft_plan inv, const float *d_in, float *d_out,
+                                        const dspfft_motion_filter_params *fp, unsigned long long *d_coeffs_coded, void *stream)
+{
+	if (!d_in) return fail(-1, "null plan or buffer");
+	return roundtrip_core(fwd, inv, d_in, d_out, nullptr, nullptr, 1.0, fp, d_coeffs_coded, stream);
+}
+
+extern "C" int dspfft_execute_roundtrip_u8(dspfft_plan fwd, dspfft_plan inv, const uint8_t *d_in, uint8_t *d_out, float *d_work, double out_mul,
+                                           const dspfft_motion_filter_params *fp, unsigned long long *d_coeffs_coded, void *stream)
+{
+	if (!d_in || !d_out || !d_work) return fail(-1, "null plan or buffer");
+	return roundtrip_core(fwd, inv, nullptr, d_work, d_in, d_out, out_mul, fp, d_coeffs_coded, stream);
 }
 
 extern "C" int dspfft_scan_zigzag_frame_ids(uint32_t *d_ids, uint32_t w, uint32_t h, uint64_t step, void *s)

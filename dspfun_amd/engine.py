@@ -103,21 +103,33 @@ class Plan:
         self._check(run(
             self._h, C.c_void_p(d_in), C.c_void_p(d_work), C.c_void_p(d_acc), C.c_void_p(d_ids or None), frame_id, elems_per_id, C.c_void_p(stream)))
 
+    @staticmethod
+    def _filter_params(filter):
+        if filter is None:
+            return None
+        fp = _lib.MotionFilterParams()
+        fp.active = (C.c_int * 3)(*filter["active"]); fp.minbuf_hw = (C.c_int * 2)(*filter["minbuf_hw"]); fp.block_depth = int(filter["block_depth"])
+        fp.band_begin = (C.c_int * 3)(*filter["band_begin"]); fp.band_end = (C.c_int * 3)(*filter["band_end"])
+        fp.damp = filter.get("damp", 1.0); fp.boost = filter.get("boost", 1.0)
+        fp.threshold_lo = filter.get("threshold_lo", 0.0); fp.threshold_hi = filter.get("threshold_hi", 0.0)
+        fp.preserve_dc = filter.get("preserve_dc", 0); fp.grey_add = filter.get("grey_add", 0.0); fp.quantizer = filter.get("quantizer", 0.0)
+        return fp
+
     def roundtrip(self, inv, d_in, d_out=None, filter=None, d_coded=0, stream=0):
         """motion/motion.c:641-753: self (REDFT10) -> filter -> inv (REDFT01, created with first_axis_first=True), the middle axis
         fused into one launch when both plans have a specialised column kernel.  filter: dict with the fields of
         dspfft_motion_filter_params, or None."""
         d_out = d_in if d_out is None else d_out
-        fp = None
-        if filter is not None:
-            fp = _lib.MotionFilterParams()
-            fp.active = (C.c_int * 3)(*filter["active"]); fp.minbuf_hw = (C.c_int * 2)(*filter["minbuf_hw"]); fp.block_depth = int(filter["block_depth"])
-            fp.band_begin = (C.c_int * 3)(*filter["band_begin"]); fp.band_end = (C.c_int * 3)(*filter["band_end"])
-            fp.damp = filter.get("damp", 1.0); fp.boost = filter.get("boost", 1.0)
-            fp.threshold_lo = filter.get("threshold_lo", 0.0); fp.threshold_hi = filter.get("threshold_hi", 0.0)
-            fp.preserve_dc = filter.get("preserve_dc", 0); fp.grey_add = filter.get("grey_add", 0.0); fp.quantizer = filter.get("quantizer", 0.0)
+        fp = self._filter_params(filter)
         self._check(self._lib.dspfft_execute_roundtrip(self._h, inv._h, C.c_void_p(d_in), C.c_void_p(d_out), C.byref(fp) if fp is not None else None,
                                                        C.c_void_p(d_coded or None), C.c_void_p(stream)))
+
+    def roundtrip_u8(self, inv, d_in_u8, d_out_u8, d_work, out_mul, filter=None, d_coded=0, stream=0):
+        """the same with motion's 8-bit samples at both ends (motion.c:617-640, :760-776): u8 in, float work buffer, u8 out =
+        quantise(value * out_mul); the conversions ride on the first and last row passes when those are planar specialised passes"""
+        fp = self._filter_params(filter)
+        self._check(self._lib.dspfft_execute_roundtrip_u8(self._h, inv._h, C.c_void_p(d_in_u8), C.c_void_p(d_out_u8), C.c_void_p(d_work), out_mul,
+                                                          C.byref(fp) if fp is not None else None, C.c_void_p(d_coded or None), C.c_void_p(stream)))
 
     def describe(self):
         buf = C.create_string_buffer(4096)

@@ -99,6 +99,15 @@ typedef struct {
 int dspfft_execute_roundtrip(dspfft_plan fwd, dspfft_plan inv, const float *d_in, float *d_out,
                              const dspfft_motion_filter_params *filter, unsigned long long *d_coeffs_coded, void *hip_stream);
 
+/* The same with motion's 8-bit samples at both ends (motion/motion.c:617-640 load, :760-776 store): d_in and d_out
+ * hold uint8 samples in the plans' input / output element layout, d_work is a float buffer in the plans' working
+ * layout.  When the first forward pass and the last inverse pass are planar specialised row passes they read the
+ * bytes and write quantise(value * out_mul) themselves (5 B/sample each instead of 13); otherwise the conversions
+ * run as separate sweeps (dspfft_u8_to_f32 / dspfft_f32_to_u8), which requires input, work and output layouts to be
+ * identical and dense. */
+int dspfft_execute_roundtrip_u8(dspfft_plan fwd, dspfft_plan inv, const uint8_t *d_in, uint8_t *d_out, float *d_work, double out_mul,
+                                const dspfft_motion_filter_params *filter, unsigned long long *d_coeffs_coded, void *hip_stream);
+
 /* Replaces fftw(destroy_plan). */
 void dspfft_destroy_plan(dspfft_plan plan);
 

@@ -141,6 +141,20 @@ int launch_col_spec(const PassArgs &a, int nwork, void *)
 	}
 	return 0;
 }
+template <class S, int KIND>
+int launch_row_spec_u8(const PassArgs &a, const U8IO &io, int nwork, void *)
+{
+	std::vector<unsigned char> lds(S::LDS + 16);
+	cf *planes = (cf *)lds.data();
+	for (int wg = 0; wg < nwork; wg++) {
+		std::vector<typename S::template State<KIND>> st(S::T);
+		long long bin, bout;
+		row_base(a, wg, bin, bout);
+		for (int tid = 0; tid < S::T; tid++) S::template prefetch<KIND>(a, bin, tid, st[tid], &io);
+		static_for<0, S::NPH>([&](auto ph) { for (int tid = 0; tid < S::T; tid++) S::template phase<KIND, ph>(a, planes, bout, tid, st[tid], &io); });
+	}
+	return 0;
+}
 struct FilterOp {
 	MotionFilter p;
 	float4 operator()(long long e, float4 v, unsigned long long &coded) const { return p.enabled ? motion_filter4(p, (uint32_t)e, v, coded) : v; }

@@ -660,6 +660,43 @@ def test_fused_roundtrip_vs_unfused_and_oracle(gpu, case):
     assert gpu.equal(got, got2) and int(coded[0]) == int(coded2[0])        # same arithmetic, tile kept in LDS
 
 
+@pytest.mark.parametrize("case", ["volume", "frames", "fallback"])
+def test_roundtrip_u8_matches_float_path(gpu, case):
+    """motion's 8-bit ends fused into the planar row passes (motion.c:617-640, :760-776): identical bytes to
+    dspfft_u8_to_f32 -> float roundtrip -> dspfft_f32_to_u8, and within the quantiser's step of the input"""
+    from dspfun_amd import Plan, _lib, REDFT10, REDFT01
+    L = _lib.load()
+    if case == "volume":
+        d, h, w = 256, 54, 1920
+        n, howmany, dist, bd, active = [d, h, w], 1, 0, d, (d, h, w)
+    elif case == "frames":
+        d, h, w = 4, 1080, 1920
+        n, howmany, dist, bd, active = [h, w], d, h * w, 1, (1, h, w)
+    else:
+        d, h, w = 3, 1080, 1936
+        n, howmany, dist, bd, active = [h, w], d, h * w, 1, (1, h, w)
+    rank = len(n)
+    u8 = ol.synth_u8(21, d * h * w)
+    nrm = 1.0 / np.prod([2.0 * v for v in n])
+    fwd = Plan.many_r2r(n, [REDFT10] * rank, howmany=howmany, idist=dist, odist=dist)
+    inv = Plan.many_r2r(n, [REDFT01] * rank, howmany=howmany, idist=dist, odist=dist, first_axis_first=True).set_scale(nrm)
+    assert ("ROW*" in fwd.describe().splitlines()[1]) == (case != "fallback"), fwd.describe()
+    flt = dict(active=active, minbuf_hw=(h, w), block_depth=bd, band_begin=(0, 0, 0), band_end=active, quantizer=6.0)
+    mul = 0.97
+    d8 = gpu.from_numpy(u8).to("cuda:0")
+    f = gpu.empty(d * h * w, dtype=gpu.float32, device="cuda:0")
+    assert L.dspfft_u8_to_f32(f.data_ptr(), d8.data_ptr(), d * h * w, None) == 0
+    fwd.roundtrip(inv, f.data_ptr(), filter=flt)
+    ref = gpu.zeros(d * h * w, dtype=gpu.uint8, device="cuda:0")
+    assert L.dspfft_f32_to_u8(ref.data_ptr(), f.data_ptr(), mul, d * h * w, None) == 0
+    out = gpu.zeros(d * h * w, dtype=gpu.uint8, device="cuda:0")
+    work = gpu.full((d * h * w,), float("nan"), dtype=gpu.float32, device="cuda:0")
+    fwd.roundtrip_u8(inv, d8.data_ptr(), out.data_ptr(), work.data_ptr(), mul, filter=flt)
+    gpu.cuda.synchronize()
+    assert gpu.equal(out, ref)
+    assert np.abs(out.cpu().numpy().astype(np.float64) - np.clip(np.floor(u8 * mul + 0.5), 0, 255)).max() <= 6
+
+
 def test_scan_pruned_idct_path(gpu):
     """scan.c:20-41,449: few coefficients per frame -> direct rank-1 sums; against the restatement and against the
     transform path (dspfft_execute_masked_accumulate) on the same frames"""

@@ -455,3 +455,39 @@ def test_fused_roundtrip_matches_unfused_and_oracle(case):
     finally:
         del os.environ["DSPFFT_NO_FUSED_ROUNDTRIP"]
     assert np.array_equal(got, got2) and coded[0] == coded2[0]
+
+
+@pytest.mark.parametrize("case", ["volume", "frames", "fallback"])
+def test_roundtrip_u8_matches_float_path(case):
+    """motion's 8-bit ends (motion.c:617-640, :760-776) fused into the planar row passes: identical bytes to
+    u8 -> float, float roundtrip, dspfft_f32_to_u8"""
+    L = emul()
+    if case == "volume":
+        d, h, w = 256, 2, 960
+        n, howmany, dist, bd, active = [d, h, w], 1, 0, d, (d, h, w)
+    elif case == "frames":
+        d, h, w = 2, 480, 960
+        n, howmany, dist, bd, active = [h, w], d, h * w, 1, (1, h, w)
+    else:
+        d, h, w = 2, 480, 48                      # no specialised row kernel for 48-sample rows: conversions run as separate sweeps
+        n, howmany, dist, bd, active = [h, w], d, h * w, 1, (1, h, w)
+    rank = len(n)
+    u8 = ol.synth_u8(21, d * h * w)
+    nrm = 1.0 / np.prod([2.0 * v for v in n])
+    fwd = Plan.many_r2r(n, [REDFT10] * rank, howmany=howmany, idist=dist, odist=dist, lib=L)
+    inv = Plan.many_r2r(n, [REDFT01] * rank, howmany=howmany, idist=dist, odist=dist, lib=L, first_axis_first=True).set_scale(nrm)
+    assert ("ROW*" in fwd.describe().splitlines()[1]) == (case != "fallback")
+    flt = dict(active=active, minbuf_hw=(h, w), block_depth=bd, band_begin=(0, 0, 0), band_end=active, quantizer=6.0)
+    mul = 0.97
+    # float path
+    f = u8.astype(np.float32)
+    fwd.roundtrip(inv, f.ctypes.data, filter=flt)
+    ref = np.zeros(d * h * w, dtype=np.uint8)
+    assert L.dspfft_f32_to_u8(ref.ctypes.data, f.ctypes.data, mul, d * h * w, None) == 0
+    # 8-bit path
+    out = np.zeros(d * h * w, dtype=np.uint8)
+    work = np.full(d * h * w, np.nan, dtype=np.float32)
+    fwd.roundtrip_u8(inv, u8.ctypes.data, out.ctypes.data, work.ctypes.data, mul, filter=flt)
+    assert np.array_equal(out, ref)
+    # and it is the right answer: the quantiser is the only loss
+    assert np.abs(out.astype(np.float64) - np.clip(np.floor(u8 * mul + 0.5), 0, 255)).max() <= 6

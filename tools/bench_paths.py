@@ -108,7 +108,31 @@ ms_u2 = timeit(lambda: f2.roundtrip(i2r, vol.data_ptr(), filter=flt2, d_coded=co
 del _os.environ["DSPFFT_NO_FUSED_ROUNDTRIP"]
 res["motion_c5_luma_per_frame_filtered_roundtrip"] = {"unfused_ms": round(ms_u2, 2), "fused_ms": round(ms_f2, 2), "speedup": round(ms_u2 / ms_f2, 2),
                                                       "fused_algorithmic_GBps": round(n * 24 / ms_f2 / 1e6, 1), "note": "256 frames of 1920x1080, fused: 3 launches, 24 B/sample; unfused: 5 launches, 40 B/sample"}
-del vol
+# ---- motion end to end on 8-bit frames (motion.c:617-776): u8 load, transform, quantise, inverse, u8 store ----
+v8 = (torch.rand(d_, h, w, device=dev) * 255).to(torch.uint8)
+o8 = torch.empty_like(v8)
+def motion_unfused_3d():
+    L.dspfft_u8_to_f32(vol.data_ptr(), v8.data_ptr(), n, None)
+    fwd.execute(vol.data_ptr())
+    L.dspfft_motion_filter(vol.data_ptr(), I3(d_, h, w), I2(h, w), I3(0, 0, 0), I3(d_, h, w), 1.0, 1.0, 0.0, 0.0, 0, 0.0, 3.0, coded.data_ptr(), None)
+    invp.execute(vol.data_ptr())
+    L.dspfft_f32_to_u8(o8.data_ptr(), vol.data_ptr(), 1.0, n, None)
+ms_u = timeit(motion_unfused_3d, reps=3, warm=1)
+ms_f = timeit(lambda: fwd.roundtrip_u8(inv3, v8.data_ptr(), o8.data_ptr(), vol.data_ptr(), 1.0, filter=flt, d_coded=coded.data_ptr()), reps=3, warm=1)
+res["motion_c5_luma_3d_u8_to_u8"] = {"separate_steps_ms": round(ms_u, 2), "fused_ms": round(ms_f, 2), "speedup": round(ms_u / ms_f, 2),
+                                     "Msamples_per_s": round(n / ms_f / 1e3, 1), "note": "separate: 9 launches, 66 B/sample; fused: 5 launches, 34 B/sample"}
+def motion_unfused_2d():
+    L.dspfft_u8_to_f32(vol.data_ptr(), v8.data_ptr(), n, None)
+    f2.execute(vol.data_ptr())
+    L.dspfft_motion_filter(vol.data_ptr(), I3(d_, h, w), I2(h, w), I3(0, 0, 0), I3(d_, h, w), 1.0, 1.0, 0.0, 0.0, 0, 0.0, 3.0, coded.data_ptr(), None)
+    i2.execute(vol.data_ptr())
+    L.dspfft_f32_to_u8(o8.data_ptr(), vol.data_ptr(), 1.0, n, None)
+ms_u2 = timeit(motion_unfused_2d, reps=3, warm=1)
+ms_f2 = timeit(lambda: f2.roundtrip_u8(i2r, v8.data_ptr(), o8.data_ptr(), vol.data_ptr(), 1.0, filter=flt2, d_coded=coded.data_ptr()), reps=3, warm=1)
+res["motion_c5_luma_per_frame_u8_to_u8"] = {"separate_steps_ms": round(ms_u2, 2), "fused_ms": round(ms_f2, 2), "speedup": round(ms_u2 / ms_f2, 2),
+                                            "Msamples_per_s": round(n / ms_f2 / 1e3, 1), "fps_1080p_luma": round(d_ / ms_f2 * 1e3, 0),
+                                            "note": "256 frames; separate: 7 launches, 50 B/sample; fused: 3 launches, 18 B/sample"}
+del vol, v8, o8
 # ---- double precision (fftw_ API, spec's default build): 4K frame roundtrip on the runtime-geometry kernels ----
 h, w, c = 2160, 3840, 3
 x64 = torch.rand(h, w, c, device=dev, dtype=torch.float64)
