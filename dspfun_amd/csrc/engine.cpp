@@ -307,6 +307,7 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 				pa.nb1 = lines.size() > 1 ? lines[1].n : 1; pa.sb1_in = lines.size() > 1 ? lines[1].is : 0; pa.sb1_out = lines.size() > 1 ? lines[1].os : 0;
 				for (size_t i = 2; i < lines.size(); i++) P.hostloop.push_back(lines[i]);
 				P.type = Pass::ROW;
+				if ((long long)pa.nb0 * pa.nb1 > 0x7fffffffLL) return fail(-2, "too many lines for one launch");
 				P.g.nwg = pa.nb0 * pa.nb1; P.g.raw_bytes = raw_bytes; P.g.lds_bytes = raw_bytes + (size_t)L * Bg * 2 * es;
 				// about 16 waves per CU: one big-LDS workgroup of 1024 threads, two of 512, otherwise 256 (measured, tools/sweep_generic.py)
 				P.g.nthr = P.g.lds_bytes > 80 * 1024 ? 1024 : P.g.lds_bytes > 53 * 1024 ? 512 : 256;
