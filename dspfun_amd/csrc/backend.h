@@ -13,7 +13,6 @@ struct LaunchGeom {
 	int nwg;          // workgroups
 	int nthr;         // threads per workgroup
 	size_t lds_bytes; // dynamic LDS
-	size_t raw_bytes; // ROW: offset of buf[] inside LDS (raw[] comes first)
 };
 
 void *be_alloc(size_t bytes);

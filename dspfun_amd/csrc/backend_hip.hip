@@ -17,29 +17,22 @@ namespace dspfft {
 
 // ---------------------------------------------------------------------------------------------
 template <int KIND, class R>
-__global__ void __launch_bounds__(1024) row_kernel(const PassArgsT<R> a, const unsigned raw_bytes)
+__global__ void __launch_bounds__(1024) row_kernel(const PassArgsT<R> a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-	R *raw = reinterpret_cast<R *>(lds);
-	cx<R> *buf = reinterpret_cast<cx<R> *>(lds + raw_bytes);
+	cx<R> *buf = reinterpret_cast<cx<R> *>(lds);
 	const int tid = threadIdx.x, nthr = blockDim.x, L = a.N / 2;
 	long long bin, bout;
 	row_base(a, blockIdx.x, bin, bout);
-	row_load(a, raw, bin, tid, nthr);
+	if (KIND == KIND_REDFT10) row_load10(a, buf, bin, tid, nthr);
+	else row_load01(a, buf, bin, tid, nthr);
 	__syncthreads();
-	for (int c0 = 0; c0 < a.C; c0 += a.Bg) {
-		if (KIND == KIND_REDFT10) row_pack2(a, raw, buf, c0, tid, nthr);
-		else row_pre3(a, raw, buf, c0, tid, nthr);
-		__syncthreads();
-		for (int s = 0; s < a.fft.ns; s++) {
-			fft_stage(buf, L, a.fft.st[s], a.Bg, a.divB, a.W, tid, nthr);
-			__syncthreads();
-		}
-		if (KIND == KIND_REDFT10) row_post2(a, raw, buf, c0, tid, nthr);
-		else row_unpack3(a, raw, buf, c0, tid, nthr);
+	for (int s = 0; s < a.fft.ns; s++) {
+		fft_stage(buf, L, a.fft.st[s], a.C, a.divB, a.W, tid, nthr);
 		__syncthreads();
 	}
-	row_store(a, raw, bout, tid, nthr);
+	if (KIND == KIND_REDFT10) row_post10(a, buf, bout, tid, nthr);
+	else row_store01(a, buf, bout, tid, nthr);
 }
 
 template <int KIND, class R>
@@ -298,10 +291,10 @@ static int launch_row(const PassArgsT<R> &a, const LaunchGeom &g, void *stream)
 	hipStream_t s = (hipStream_t)stream;
 	if (a.kind == KIND_REDFT10) {
 		if (int rc = allow_lds(row_kernel<KIND_REDFT10, R>, g.lds_bytes)) return rc;
-		hipLaunchKernelGGL((row_kernel<KIND_REDFT10, R>), dim3(g.nwg), dim3(g.nthr), g.lds_bytes, s, a, (unsigned)g.raw_bytes);
+		hipLaunchKernelGGL((row_kernel<KIND_REDFT10, R>), dim3(g.nwg), dim3(g.nthr), g.lds_bytes, s, a);
 	} else {
 		if (int rc = allow_lds(row_kernel<KIND_REDFT01, R>, g.lds_bytes)) return rc;
-		hipLaunchKernelGGL((row_kernel<KIND_REDFT01, R>), dim3(g.nwg), dim3(g.nthr), g.lds_bytes, s, a, (unsigned)g.raw_bytes);
+		hipLaunchKernelGGL((row_kernel<KIND_REDFT01, R>), dim3(g.nwg), dim3(g.nthr), g.lds_bytes, s, a);
 	}
 	HIPCHK(hipGetLastError());
 	return 0;

@@ -12,7 +12,8 @@
 // Two pass shapes:
 //   ROW  -- the transformed axis is (nearly) contiguous: a line is N*C consecutive floats holding C
 //           interleaved signals (C = 3 for the image tools' HWC buffers, 1 for motion's planar rows).
-//           N even; each real signal is packed into an N/2-point complex FFT (even/odd "Makhoul" order).
+//           N even; each real signal is packed into an N/2-point complex FFT (even/odd "Makhoul" order);
+//           all C signals of the line are transformed together.
 //   COL  -- the axis is strided and an inner contiguous dimension exists: a workgroup owns a tile of K
 //           adjacent floats x all N rows; adjacent float columns are paired into one complex signal
 //           (two real transforms per complex FFT of length N; any N).
@@ -74,7 +75,6 @@ struct PassGeom {
 	int kind;         // KIND_*
 	// ROW
 	int C;            // interleaved signals per line
-	int Bg;           // channels transformed together (C, or 1 when LDS is tight)
 	// COL
 	int K;            // tile width in samples (even)
 	int B;            // complex columns per tile = K/2
@@ -92,7 +92,7 @@ struct PassGeom {
 	FastDiv mask_div;     // elements per owner id (32-bit offsets: masked runs are limited to 2^32 / d elements)
 	int accumulate;
 	FftDesc fft;
-	FastDiv divB;         // divide by (ROW: Bg, COL: B)
+	FastDiv divB;         // divide by (ROW: C, COL: B)
 };
 
 template <class R>
@@ -210,9 +210,12 @@ DSP_HD void fft_stage_inv(C *buf, int L, const StageDesc &S, int B, FastDiv divB
 }
 
 // ------------------------------------------------------------------------------------------------
-// ROW pass.  LDS: raw[N*C] floats (the line as it lies in memory) + buf[L*Bg] complex, L = N/2.
+// ROW pass.  LDS: buf[L*C] complex, L = N/2, channel s of packed sample m at buf[m*C + s].  The line goes from global
+// memory straight into the packed FFT input and from the FFT output straight back (no staging copy of the line), so
+// all loads of a line happen before its first store: in place is safe.
 // index of sample v[n] of the even/odd-reordered signal inside the original signal
 DSP_HD int makhoul_src(int n, int N) { return 2 * n < N ? 2 * n : 2 * (N - 1 - n) + 1; }
+DSP_HD int makhoul_dst(int y, int N) { return (y & 1) ? N - 1 - (y >> 1) : (y >> 1); }
 
 DSP_HD void row_base(const PassGeom &a, int line, long long &bin, long long &bout)
 {
@@ -222,119 +225,101 @@ DSP_HD void row_base(const PassGeom &a, int line, long long &bin, long long &bou
 }
 
 template <class R>
-DSP_HD void row_load(const PassArgsT<R> &a, R *raw, long long bin, int tid, int nthr)
+DSP_HD void row_put(const PassArgsT<R> &a, long long off, R v)
 {
-	typedef typename vec_of<R>::v16 V;
-	constexpr int NV = 16 / (int)sizeof(R);
-	const int n = a.N * a.C;
-	const R *src = a.in + bin;
-	if (a.mask) {
-		for (int i = tid; i < n; i += nthr) raw[i] = masked(a, bin + i, src[i]);
-	} else if (((bin & (NV - 1)) == 0) && ((n & (NV - 1)) == 0) && ((((uintptr_t)a.in) & 15) == 0)) {
-		const V *s4 = reinterpret_cast<const V *>(src);
-		V *r4 = reinterpret_cast<V *>(raw);
-		for (int i = tid; i < n / NV; i += nthr) r4[i] = s4[i];
-	} else {
-		for (int i = tid; i < n; i += nthr) raw[i] = src[i];
+	if (a.accumulate) a.out[off] += v; else a.out[off] = v;
+}
+
+// REDFT10: pixels in memory order -> even/odd reordered, packed two reals per complex slot
+template <class R>
+DSP_HD void row_load10(const PassArgsT<R> &a, cx<R> *buf, long long bin, int tid, int nthr)
+{
+	const int N = a.N, C = a.C;
+	R *bf = reinterpret_cast<R *>(buf);
+	for (int it = tid; it < N * C; it += nthr) {
+		const int x = (int)a.divB.div((uint32_t)it), s = it - x * C;
+		R v = masked(a, bin + it, a.in[bin + it]);
+		if (x == 0) v *= a.in_scale0;
+		const int n = makhoul_dst(x, N);
+		bf[2 * ((n >> 1) * C + s) + (n & 1)] = v;
 	}
 }
 
+// REDFT10: FFT output -> 4 real outputs per (k, L-k) pair, stored
 template <class R>
-DSP_HD void row_store(const PassArgsT<R> &a, const R *raw, long long bout, int tid, int nthr)
+DSP_HD void row_post10(const PassArgsT<R> &a, const cx<R> *buf, long long bout, int tid, int nthr)
 {
-	typedef typename vec_of<R>::v16 V;
-	constexpr int NV = 16 / (int)sizeof(R);
-	const int n = a.N * a.C;
-	R *dst = a.out + bout;
-	if (a.accumulate) {
-		for (int i = tid; i < n; i += nthr) dst[i] += raw[i];
-	} else if (((bout & (NV - 1)) == 0) && ((n & (NV - 1)) == 0) && ((((uintptr_t)a.out) & 15) == 0)) {
-		const V *r4 = reinterpret_cast<const V *>(raw);
-		V *d4 = reinterpret_cast<V *>(dst);
-		for (int i = tid; i < n / NV; i += nthr) d4[i] = r4[i];
-	} else {
-		for (int i = tid; i < n; i += nthr) dst[i] = raw[i];
-	}
-}
-
-// REDFT10: pack channels [c0, c0+Bg) of raw into buf
-template <class R>
-DSP_HD void row_pack2(const PassArgsT<R> &a, const R *raw, cx<R> *buf, int c0, int tid, int nthr)
-{
-	const int L = a.N / 2, Bg = a.Bg, C = a.C, N = a.N;
-	for (int it = tid; it < L * Bg; it += nthr) {
-		const int m = (int)a.divB.div((uint32_t)it), s = it - m * Bg;
-		const int i0 = makhoul_src(2 * m, N), i1 = makhoul_src(2 * m + 1, N);
-		R re = raw[i0 * C + c0 + s], im = raw[i1 * C + c0 + s];
-		if (i0 == 0) re *= a.in_scale0;
-		buf[it] = cmk<R>(re, im);
-	}
-}
-
-// REDFT10: FFT output -> 4 real outputs per (k, L-k) pair, written back into raw
-template <class R>
-DSP_HD void row_post2(const PassArgsT<R> &a, R *raw, const cx<R> *buf, int c0, int tid, int nthr)
-{
-	const int L = a.N / 2, Bg = a.Bg, C = a.C, N = a.N;
+	typedef cx<R> C_;
+	const int L = a.N / 2, C = a.C, N = a.N;
 	const int nk = L / 2 + 1;
-	for (int it = tid; it < nk * Bg; it += nthr) {
-		const int k = (int)a.divB.div((uint32_t)it), s = it - k * Bg;
+	for (int it = tid; it < nk * C; it += nthr) {
+		const int k = (int)a.divB.div((uint32_t)it), s = it - k * C;
 		const int km = k ? L - k : 0;
-		typedef cx<R> C_;
-		const C_ zk = buf[a.pos[k] * Bg + s];
-		const C_ zm = cconj(buf[a.pos[km] * Bg + s]);
+		const C_ zk = buf[a.pos[k] * C + s];
+		const C_ zm = cconj(buf[a.pos[km] * C + s]);
 		const C_ E = cscale(cadd(zk, zm), R(0.5));
 		const C_ Dh = cscale(csub(zk, zm), R(0.5));
 		const C_ D = cmul_mi(Dh);                 // (zk - conj zm) / (2i)
-		const C_ P = cmul(a.T[4 * k], D);         // exp(-2 pi i k / N) * D
+		// one table value per item: T[L-k] = e^{-i pi/4} conj(T[k]) and T[4k] = T[k]^4
+		const C_ tk = a.T[k];
+		const C_ tlk = cmul(cconj(tk), cmk<R>(R(0.70710678118654752440), R(-0.70710678118654752440)));
+		const C_ t2 = cmk<R>(tk.x * tk.x - tk.y * tk.y, R(2) * tk.x * tk.y);
+		const C_ t4 = cmk<R>(t2.x * t2.x - t2.y * t2.y, R(2) * t2.x * t2.y);
+		const C_ P = cmul(t4, D);                 // exp(-2 pi i k / N) * D
 		const C_ Vk = cadd(E, P);
 		const C_ Vm = cconj(csub(E, P));          // V[L-k]
-		const C_ wk = cmul(a.T[k], Vk);
-		const C_ wm = cmul(a.T[L - k], Vm);
-		R *o = raw + c0 + s;
+		const C_ wk = cmul(tk, Vk);
+		const C_ wm = cmul(tlk, Vm);
+		const long long o = bout + s;
 		const R sc = a.scale;
-		o[k * C] = R(2) * wk.x * sc * (k == 0 ? a.out_scale0 : R(1));
-		if (k > 0) o[(N - k) * C] = R(-2) * wk.y * sc;
-		o[(L - k) * C] = R(2) * wm.x * sc;
-		if (k > 0) o[(L + k) * C] = R(-2) * wm.y * sc;
+		row_put(a, o + (long long)k * C, R(2) * wk.x * sc * (k == 0 ? a.out_scale0 : R(1)));
+		if (k > 0) row_put(a, o + (long long)(N - k) * C, R(-2) * wk.y * sc);
+		if (L - k != k) row_put(a, o + (long long)(L - k) * C, R(2) * wm.x * sc);
+		if (k > 0 && L + k != N - k) row_put(a, o + (long long)(L + k) * C, R(-2) * wm.y * sc);
 	}
 }
 
-// REDFT01: natural-order input in raw -> conj of the half-length spectrum in buf
+// REDFT01: natural-order input -> conj of the half-length spectrum in buf
 template <class R>
-DSP_HD void row_pre3(const PassArgsT<R> &a, const R *raw, cx<R> *buf, int c0, int tid, int nthr)
+DSP_HD void row_load01(const PassArgsT<R> &a, cx<R> *buf, long long bin, int tid, int nthr)
 {
-	const int L = a.N / 2, Bg = a.Bg, C = a.C, N = a.N;
+	typedef cx<R> C_;
+	const int L = a.N / 2, C = a.C, N = a.N;
 	const int nk = L / 2 + 1;
-	for (int it = tid; it < nk * Bg; it += nthr) {
-		const int k = (int)a.divB.div((uint32_t)it), s = it - k * Bg;
-		typedef cx<R> C_;
-		const R *x = raw + c0 + s;
-		const R xk = x[k * C] * (k == 0 ? a.in_scale0 : R(1));
-		const R xnk = k ? x[(N - k) * C] : R(0);
-		const R xlk = x[(L - k) * C];
-		const R xlpk = x[(L + k) * C];                         // k <= L/2 so L+k <= N-1
-		const C_ Vk = cmulc(cmk<R>(xk, -xnk), a.T[k]);         // conj(T[k]) * (X[k] - i X[N-k])
-		const C_ Vm = cmulc(cmk<R>(xlk, -xlpk), a.T[L - k]);   // V[L-k]
+	for (int it = tid; it < nk * C; it += nthr) {
+		const int k = (int)a.divB.div((uint32_t)it), s = it - k * C;
+		const long long o = bin + s;
+		auto ld = [&](int px) { const long long e = o + (long long)px * C; return masked(a, e, a.in[e]); };
+		const R xk = ld(k) * (k == 0 ? a.in_scale0 : R(1));
+		const R xnk = k ? ld(N - k) : R(0);
+		const R xlk = ld(L - k);
+		const R xlpk = ld(L + k);                              // k <= L/2 so L+k <= N-1
+		const C_ tk = a.T[k];
+		const C_ tlk = cmul(cconj(tk), cmk<R>(R(0.70710678118654752440), R(-0.70710678118654752440)));   // T[L-k]
+		const C_ t2 = cmk<R>(tk.x * tk.x - tk.y * tk.y, R(2) * tk.x * tk.y);
+		const C_ t4 = cmk<R>(t2.x * t2.x - t2.y * t2.y, R(2) * t2.x * t2.y);                              // T[4k]
+		const C_ Vk = cmulc(cmk<R>(xk, -xnk), tk);             // conj(T[k]) * (X[k] - i X[N-k])
+		const C_ Vm = cmulc(cmk<R>(xlk, -xlpk), tlk);          // V[L-k]
 		const C_ S = cadd(Vk, cconj(Vm));
 		const C_ D = csub(Vk, cconj(Vm));
-		const C_ Q = cmul_pi(cmulc(D, a.T[4 * k]));            // i * conj(t1[k]) * D
-		buf[k * Bg + s] = cconj(cadd(S, Q));
-		if (k > 0) buf[(L - k) * Bg + s] = csub(S, Q);
+		const C_ Q = cmul_pi(cmulc(D, t4));                    // i * conj(t1[k]) * D
+		buf[k * C + s] = cconj(cadd(S, Q));
+		if (k > 0) buf[(L - k) * C + s] = csub(S, Q);
 	}
 }
 
-// REDFT01: FFT output -> time samples, un-reordered, into raw
+// REDFT01: FFT output -> time samples in memory order
 template <class R>
-DSP_HD void row_unpack3(const PassArgsT<R> &a, R *raw, const cx<R> *buf, int c0, int tid, int nthr)
+DSP_HD void row_store01(const PassArgsT<R> &a, const cx<R> *buf, long long bout, int tid, int nthr)
 {
-	const int L = a.N / 2, Bg = a.Bg, C = a.C, N = a.N;
-	for (int it = tid; it < L * Bg; it += nthr) {
-		const int m = (int)a.divB.div((uint32_t)it), s = it - m * Bg;
-		const cx<R> F = buf[a.pos[m] * Bg + s];
-		const int i0 = makhoul_src(2 * m, N), i1 = makhoul_src(2 * m + 1, N);
-		raw[i0 * C + c0 + s] = F.x * a.scale * (i0 == 0 ? a.out_scale0 : R(1));
-		raw[i1 * C + c0 + s] = -F.y * a.scale;
+	const int N = a.N, C = a.C;
+	const R *bf = reinterpret_cast<const R *>(buf);
+	for (int it = tid; it < N * C; it += nthr) {
+		const int x = (int)a.divB.div((uint32_t)it), s = it - x * C;
+		const int n = makhoul_dst(x, N);
+		const R f = bf[2 * (a.pos[n >> 1] * C + s) + (n & 1)];
+		const R sc = (x == 0) ? a.scale * a.out_scale0 : a.scale;
+		row_put(a, bout + it, ((n & 1) ? -f : f) * sc);
 	}
 }
 
@@ -383,8 +368,6 @@ DSP_HD void st2a(const PassArgsT<R> &a, R *p, bool vec, int nvalid, R x, typenam
 // two-sample vector access: both strides even and the base pointer aligned to two samples
 template <class R>
 DSP_HD bool vec2_ok(long long base, long long es, const R *p) { return (((base | es) & 1) == 0) && ((((uintptr_t)p) & (2 * sizeof(R) - 1)) == 0); }
-
-DSP_HD int makhoul_dst(int y, int N) { return (y & 1) ? N - 1 - (y >> 1) : (y >> 1); }
 
 // REDFT10: load tile rows, even/odd reorder along the axis
 template <class R>

@@ -293,27 +293,24 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 		if (ok) ok = build_fft(N / 2, F, pos);
 		if (ok) {
 			const int L = N / 2;
-			size_t raw_bytes = (((size_t)N * C * es) + 15) & ~(size_t)15;
-			int Bg = C;
-			if (raw_bytes + (size_t)L * Bg * 2 * es > maxlds || env_int("DSPFFT_ROW_BG") == 1) Bg = 1;
-			if (raw_bytes + (size_t)L * Bg * 2 * es > maxlds) ok = false;
+			if ((size_t)L * C * 2 * es > maxlds) ok = false;       // the line's C signals sit in LDS together; longer lines go to the column pass
 			if (ok) {
 				std::vector<Dim> lines;
 				for (size_t i = 0; i < others.size(); i++) if ((int)i != cdim) lines.push_back(others[i]);
 				merge_dims(lines);
 				PassGeom &pa = P.pa;
-				pa.N = N; pa.kind = kind; pa.C = C; pa.Bg = Bg; pa.fft = F; pa.divB = make_div((uint32_t)Bg);
+				pa.N = N; pa.kind = kind; pa.C = C; pa.fft = F; pa.divB = make_div((uint32_t)C);
 				pa.nb0 = lines.size() > 0 ? lines[0].n : 1; pa.sb0_in = lines.size() > 0 ? lines[0].is : 0; pa.sb0_out = lines.size() > 0 ? lines[0].os : 0;
 				pa.nb1 = lines.size() > 1 ? lines[1].n : 1; pa.sb1_in = lines.size() > 1 ? lines[1].is : 0; pa.sb1_out = lines.size() > 1 ? lines[1].os : 0;
 				for (size_t i = 2; i < lines.size(); i++) P.hostloop.push_back(lines[i]);
 				P.type = Pass::ROW;
 				if ((long long)pa.nb0 * pa.nb1 > 0x7fffffffLL) return fail(-2, "too many lines for one launch");
-				P.g.nwg = pa.nb0 * pa.nb1; P.g.raw_bytes = raw_bytes; P.g.lds_bytes = raw_bytes + (size_t)L * Bg * 2 * es;
+				P.g.nwg = pa.nb0 * pa.nb1; P.g.lds_bytes = (size_t)L * C * 2 * es;
 				// about 16 waves per CU: one big-LDS workgroup of 1024 threads, two of 512, otherwise 256 (measured, tools/sweep_generic.py)
-				P.g.nthr = P.g.lds_bytes > 80 * 1024 ? 1024 : P.g.lds_bytes > 53 * 1024 ? 512 : 256;
+				P.g.nthr = P.g.lds_bytes > 80 * 1024 ? 1024 : P.g.lds_bytes > 24 * 1024 ? 512 : 256;
 				if (env_int("DSPFFT_ROW_THREADS")) P.g.nthr = env_int("DSPFFT_ROW_THREADS");
 				if (upload_tables(P, pl->f64, N, L, pos)) return fail(-3, "table upload failed");
-				snprintf(buf, sizeof buf, "axis %d: ROW%s  N=%d C=%d Bg=%d fft=%d(%s) lines=%d lds=%zu", a, tag, N, C, Bg, L, radix_string(F).c_str(), P.g.nwg, P.g.lds_bytes);
+				snprintf(buf, sizeof buf, "axis %d: ROW%s  N=%d C=%d fft=%d(%s) lines=%d lds=%zu", a, tag, N, C, L, radix_string(F).c_str(), P.g.nwg, P.g.lds_bytes);
 				P.desc = buf;
 				// vector pixel access needs the line starts aligned to the pixel vector (C=2: 8 B, C=4: 16 B)
 				const int al = (C == 2 || C == 4) ? C : 1;
@@ -321,7 +318,7 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 				for (const Dim &d : lines) aligned = aligned && (d.is % al == 0) && (d.os % al == 0);
 				if (!pl->f64 && aligned && be_find_spec(0, N, C, &P.spec)) {
 					P.has_spec = true; P.spa = pa; P.spec_nwg = P.g.nwg;
-					snprintf(buf, sizeof buf, "axis %d: ROW* N=%d C=%d spec#%d threads=%d lines=%d lds=%zu (generic fallback: Bg=%d)", a, N, C, P.spec.id, P.spec.nthr, P.g.nwg, P.spec.lds, Bg);
+					snprintf(buf, sizeof buf, "axis %d: ROW* N=%d C=%d spec#%d threads=%d lines=%d lds=%zu", a, N, C, P.spec.id, P.spec.nthr, P.g.nwg, P.spec.lds);
 					P.desc = buf;
 				}
 				return 0;
@@ -362,7 +359,7 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 				long long nwg = (long long)pa.ntiles * pa.nb0 * pa.nb1;
 				if (nwg > 0x7fffffff) return fail(-2, "too many tiles for one launch");
 				P.g.nwg = (int)nwg;
-				P.g.lds_bytes = rows * pa.B * 2 * es; P.g.raw_bytes = 0;
+				P.g.lds_bytes = rows * pa.B * 2 * es;
 				const long long slots = (long long)rows * pa.B;
 				P.g.nthr = (slots >= 12000 || P.g.lds_bytes > 80 * 1024) ? 1024 : slots >= 4096 ? 512 : 256;   // measured, tools/sweep_generic.py
 				if (env_int("DSPFFT_COL_THREADS")) P.g.nthr = env_int("DSPFFT_COL_THREADS");

@@ -28,22 +28,16 @@ template <class R>
 static int emul_row(const PassArgsT<R> &a, const LaunchGeom &g)
 {
 	std::vector<unsigned char> lds(g.lds_bytes + 32);
-	unsigned char *base = (unsigned char *)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
-	R *raw = (R *)base;
-	cx<R> *buf = (cx<R> *)(base + g.raw_bytes);
+	cx<R> *buf = (cx<R> *)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
 	const int nthr = g.nthr, L = a.N / 2;
 	for (int wg = 0; wg < g.nwg; wg++) {
 		long long bin, bout;
 		row_base(a, wg, bin, bout);
-		PHASE(row_load(a, raw, bin, tid, nthr));
-		for (int c0 = 0; c0 < a.C; c0 += a.Bg) {
-			if (a.kind == KIND_REDFT10) { PHASE(row_pack2(a, raw, buf, c0, tid, nthr)); }
-			else { PHASE(row_pre3(a, raw, buf, c0, tid, nthr)); }
-			for (int s = 0; s < a.fft.ns; s++) PHASE(fft_stage(buf, L, a.fft.st[s], a.Bg, a.divB, a.W, tid, nthr));
-			if (a.kind == KIND_REDFT10) { PHASE(row_post2(a, raw, buf, c0, tid, nthr)); }
-			else { PHASE(row_unpack3(a, raw, buf, c0, tid, nthr)); }
-		}
-		PHASE(row_store(a, raw, bout, tid, nthr));
+		if (a.kind == KIND_REDFT10) { PHASE(row_load10(a, buf, bin, tid, nthr)); }
+		else { PHASE(row_load01(a, buf, bin, tid, nthr)); }
+		for (int s = 0; s < a.fft.ns; s++) PHASE(fft_stage(buf, L, a.fft.st[s], a.C, a.divB, a.W, tid, nthr));
+		if (a.kind == KIND_REDFT10) { PHASE(row_post10(a, buf, bout, tid, nthr)); }
+		else { PHASE(row_store01(a, buf, bout, tid, nthr)); }
 	}
 	return 0;
 }

@@ -138,14 +138,18 @@ def test_roundtrip_and_fused_spec_normalisation():
 
 
 def test_lds_pressure_paths(monkeypatch):
-    # with a small LDS budget the ROW pass falls back to one channel at a time and COL narrows its tile
+    # with a small LDS budget COL narrows its tile; a line that no longer fits the ROW pass goes to the column pass
     import ctypes as C, os
-    os.environ["DSPFFT_EMUL_LDS"] = "1100"   # ROW needs 768 (raw) + 768 (3 channels) -> one channel at a time
+    os.environ["DSPFFT_EMUL_LDS"] = "1100"   # the 64-pixel RGB line needs 32*3*8 = 768 B: still ROW; the 24-row tile shrinks to K=10
     try:
         h, w, c = 24, 64, 3
         x = ol.synth_f32(31, h * w * c).reshape(h, w, c)
         p = Plan.image(h, w, c, REDFT10, lib=emul())
-        assert "Bg=1" in p.describe() and "K=10" in p.describe()
+        assert "ROW" in p.describe() and "K=10" in p.describe()
+        assert relerr(run(p, x.copy()), ol.dct2d_interleaved(x.astype(np.float64), REDFT10, impl="port")) < TOL
+        os.environ["DSPFFT_EMUL_LDS"] = "700"
+        p = Plan.image(h, w, c, REDFT10, lib=emul())
+        assert "ROW" not in p.describe() and p.describe().count("COL") == 2, p.describe()
         assert relerr(run(p, x.copy()), ol.dct2d_interleaved(x.astype(np.float64), REDFT10, impl="port")) < TOL
     finally:
         del os.environ["DSPFFT_EMUL_LDS"]
