@@ -136,8 +136,12 @@ DSP_HD void fft_stage_r(C *buf, int L, const StageDesc &S, int B, FastDiv divB, 
 		static_for<0, R>([&](auto r) { x[r] = buf[base + r * stride]; });
 		Dft<R>::run(x);
 		if (S.M1 > 1) {
-			const int tw = m * S.twstep;
-			static_for<1, R>([&](auto r) { x[r] = cmul(x[r], W[tw * r]); });
+			// w^r for r = 2..R-1 from the one table value w = W[m * twstep] by a product tree (depth log2 R):
+			// one table load per butterfly instead of R-1
+			C w[R > 1 ? R : 2];
+			w[1] = W[m * S.twstep];
+			static_for<2, R>([&](auto r) { w[r] = cmul(w[r / 2], w[r - r / 2]); });
+			static_for<1, R>([&](auto r) { x[r] = cmul(x[r], w[r]); });
 		}
 		static_for<0, R>([&](auto r) { buf[base + r * stride] = x[r]; });
 	}
@@ -180,8 +184,10 @@ DSP_HD void fft_stage_inv_r(C *buf, int L, const StageDesc &S, int B, FastDiv di
 		C x[R];
 		static_for<0, R>([&](auto r) { x[r] = buf[base + r * stride]; });
 		if (S.M1 > 1) {
-			const int tw = m * S.twstep;
-			static_for<1, R>([&](auto r) { x[r] = cmulc(x[r], W[tw * r]); });
+			C w[R > 1 ? R : 2];
+			w[1] = W[m * S.twstep];
+			static_for<2, R>([&](auto r) { w[r] = cmul(w[r / 2], w[r - r / 2]); });
+			static_for<1, R>([&](auto r) { x[r] = cmulc(x[r], w[r]); });
 		}
 		static_for<0, R>([&](auto r) { x[r] = cconj(x[r]); });
 		Dft<R>::run(x);
