@@ -495,3 +495,40 @@ def test_roundtrip_u8_matches_float_path(case):
     assert np.array_equal(out, ref)
     # and it is the right answer: the quantiser is the only loss
     assert np.abs(out.astype(np.float64) - np.clip(np.floor(u8 * mul + 0.5), 0, 255)).max() <= 6
+
+
+@pytest.mark.parametrize("shape", ["rank1", "image_fused", "image_generic", "out_of_place"])
+def test_roundtrip_plan_shapes(shape):
+    """dspfft_execute_roundtrip on plan pairs other than motion's: rank 1 (nothing to fuse), interleaved images with and
+    without a specialised column kernel, and out of place (the forward plan reads d_in, everything else works on d_out)"""
+    L = emul()
+    if shape == "rank1":
+        n, kw = [96], {}
+        x = ol.synth_f32(1, 96)
+    elif shape == "image_fused":
+        h, w, c = 256, 16, 3
+        n, kw = [h, w], dict(howmany=c, istride=c, idist=1, ostride=c, odist=1)
+        x = ol.synth_f32(2, h * w * c)
+    else:
+        h, w, c = 30, 20, 3
+        n, kw = [h, w], dict(howmany=c, istride=c, idist=1, ostride=c, odist=1)
+        x = ol.synth_f32(3, h * w * c)
+    nrm = 1.0 / np.prod([2.0 * v for v in n])
+    fwd = Plan.many_r2r(n, [REDFT10] * len(n), lib=L, **kw)
+    inv = Plan.many_r2r(n, [REDFT01] * len(n), lib=L, first_axis_first=True, **kw).set_scale(nrm)
+    if shape == "image_fused":
+        assert "COL*" in fwd.describe().splitlines()[-1]
+    if shape == "out_of_place":
+        src, dst = x.copy(), np.full_like(x, np.nan)
+        fwd.roundtrip(inv, src.ctypes.data, dst.ctypes.data)
+        assert np.array_equal(src, x)
+        got = dst
+    else:
+        got = x.copy()
+        fwd.roundtrip(inv, got.ctypes.data)
+    assert np.abs(got - x).max() < 5e-6
+    # a plan pair whose middle axes differ is refused
+    if len(n) == 2:
+        bad = Plan.many_r2r(n, [REDFT01] * 2, lib=L, **kw)
+        with pytest.raises(DspfftError):
+            fwd.roundtrip(bad, got.ctypes.data)
