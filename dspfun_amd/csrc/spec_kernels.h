@@ -1,0 +1,187 @@
+// spec_kernels.h -- the compile-time-specialised kernels (dct_spec.h) and their host launchers, as templates.
+// backend_hip.hip only REFERENCES the instantiations (extern template); spec_inst_*.hip define them, one group of
+// specs per translation unit, so the groups compile in parallel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "backend.h"
+#include "dct_spec.h"
+#include "spec_list.h"
+
+namespace dspfft {
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+template <class K>
+static int allow_lds(K kernel, size_t bytes)
+{
+	if (bytes > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+	return 0;
+}
+
+// ---- compile-time-specialised kernels (dct_spec.h) ----
+// One workgroup per line / tile.  (A persistent variant that prefetched the next item into
+// registers was measured slower on MI355X: the extra ~60 VGPRs cost a resident workgroup per CU,
+// and co-resident workgroups already overlap each other's memory and LDS phases.)
+template <class S, int KIND>
+__global__ void __launch_bounds__(S::T, S::WPE) row_spec_kernel(const PassArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+	cf *planes = reinterpret_cast<cf *>(lds);
+	const int tid = threadIdx.x;
+	typename S::template State<KIND> st;
+	long long bin, bout;
+	row_base(a, blockIdx.x, bin, bout);
+	S::template prefetch<KIND>(a, bin, tid, st);
+	S::template phase<KIND, 0>(a, planes, bout, tid, st);
+	__syncthreads();
+	static_for<1, S::NPH>([&](auto ph) {
+		{
+			S::template phase<KIND, ph>(a, planes, bout, tid, st);
+			if constexpr (ph + 1 < S::NPH) __syncthreads();
+		}
+	});
+}
+
+// the same with 8-bit input (REDFT10) or quantised 8-bit output (REDFT01): planar rows only
+template <class S, int KIND>
+__global__ void __launch_bounds__(S::T, S::WPE) row_spec_u8_kernel(const PassArgs a, const U8IO io)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+	cf *planes = reinterpret_cast<cf *>(lds);
+	const int tid = threadIdx.x;
+	typename S::template State<KIND> st;
+	long long bin, bout;
+	row_base(a, blockIdx.x, bin, bout);
+	S::template prefetch<KIND>(a, bin, tid, st, &io);
+	S::template phase<KIND, 0>(a, planes, bout, tid, st, &io);
+	__syncthreads();
+	static_for<1, S::NPH>([&](auto ph) {
+		{
+			S::template phase<KIND, ph>(a, planes, bout, tid, st, &io);
+			if constexpr (ph + 1 < S::NPH) __syncthreads();
+		}
+	});
+}
+
+template <class S, int KIND>
+__global__ void __launch_bounds__(S::T, S::WPE) col_spec_kernel(const PassArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+	float4 *buf = reinterpret_cast<float4 *>(lds);
+	const int tid = threadIdx.x;
+	typename S::template State<KIND> st;
+	long long bin, bout;
+	S::base(a, blockIdx.x, bin, bout);
+	S::template prefetch<KIND>(a, bin, tid, st);
+	S::template phase<KIND, 0>(a, buf, bout, tid, st);
+	__syncthreads();
+	static_for<1, S::NPH>([&](auto ph) {
+		{
+			S::template phase<KIND, ph>(a, buf, bout, tid, st);
+			if constexpr (ph + 1 < S::NPH) __syncthreads();
+		}
+	});
+}
+
+// forward REDFT10 -> motion filter -> inverse REDFT01 along the tile's axis in one launch: the tile is read once and
+// written once instead of three times each (forward store + filter read/write + inverse load saved)
+struct FilterOp {
+	MotionFilter p;
+	__device__ float4 operator()(long long e, float4 v, unsigned long long &coded) const
+	{
+		return p.enabled ? motion_filter4(p, (uint32_t)e, v, coded) : v;
+	}
+};
+
+// waves per SIMD to ask of the register allocator so that as many workgroups stay resident as the tile's LDS allows
+// (capped at 4 = 128 VGPRs): without the cap the allocator spends the whole budget and one workgroup fills a CU
+template <class S> constexpr int rt_waves_per_simd()
+{
+	const int wgs = (int)((160 * 1024) / S::LDS), w = wgs * S::T / 256;
+	return w < 1 ? 1 : w > 4 ? 4 : w;
+}
+
+template <class S>
+__global__ void __launch_bounds__(S::T, rt_waves_per_simd<S>()) col_roundtrip_kernel(const PassArgs af, const PassArgs ai, const FilterOp filt, unsigned long long *coded)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+	__shared__ unsigned int wg_coded;       // non-zero quantised coefficients of this tile (one global atomic per workgroup)
+	float4 *buf = reinterpret_cast<float4 *>(lds);
+	const int tid = threadIdx.x;
+	if (tid == 0) wg_coded = 0;
+	typename S::StateRT st;
+	long long bin, bout;
+	S::base(af, blockIdx.x, bin, bout);
+	S::template prefetch<KIND_REDFT10>(af, bin, tid, st);
+	S::template phase<KIND_REDFT10, 0>(af, buf, bout, tid, st);
+	__syncthreads();
+	// The empty asm statements make the thread index (and, below, the inverse plan's table pointers) opaque at each
+	// phase: otherwise index arithmetic and twiddle loads of LATER phases are hoisted to the top of the kernel and
+	// stay live across every barrier (measured: 176 VGPRs -> 1 workgroup per CU; with them: <= 128).
+	static_for<1, S::NS + 2>([&](auto ph) {
+		int t = tid; asm volatile("" : "+v"(t));
+		S::template phase<KIND_REDFT10, ph>(af, buf, bout, t, st);
+		__syncthreads();
+	});
+	unsigned long long mine = 0;
+	int t = tid; asm volatile("" : "+v"(t));
+	S::mid_read(af, ai, buf, bout, t, st, filt, mine);
+	if (coded) {
+		unsigned int m = (unsigned int)mine;
+		for (int off = 32; off > 0; off >>= 1) m += __shfl_xor(m, off);
+		if ((tid & 63) == 0 && m) atomicAdd(&wg_coded, m);
+	}
+	__syncthreads();
+	if (coded && tid == 0 && wg_coded) atomicAdd(coded, (unsigned long long)wg_coded);
+	asm volatile("" : "+v"(t));
+	S::mid_write(buf, t, st);
+	__syncthreads();
+	PassArgs a2 = ai;
+	asm volatile("" : "+s"(a2.W), "+s"(a2.T), "+s"(a2.out));
+	static_for<1, S::NPH>([&](auto ph) {
+		asm volatile("" : "+v"(t));
+		S::template phase<KIND_REDFT01, ph>(a2, buf, bout, t, st);
+		if constexpr (ph + 1 < S::NPH) __syncthreads();
+	});
+}
+
+
+template <class S, int KIND>
+int launch_row_spec(const PassArgs &a, int nwork, void *stream)
+{
+	static int lds_ok = allow_lds(row_spec_kernel<S, KIND>, S::LDS);
+	if (lds_ok) return lds_ok;
+	hipLaunchKernelGGL((row_spec_kernel<S, KIND>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+template <class S, int KIND>
+int launch_col_spec(const PassArgs &a, int nwork, void *stream)
+{
+	static int lds_ok = allow_lds(col_spec_kernel<S, KIND>, S::LDS);
+	if (lds_ok) return lds_ok;
+	hipLaunchKernelGGL((col_spec_kernel<S, KIND>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+template <class S, int KIND>
+int launch_row_spec_u8(const PassArgs &a, const U8IO &io, int nwork, void *stream)
+{
+	static int lds_ok = allow_lds(row_spec_u8_kernel<S, KIND>, S::LDS);
+	if (lds_ok) return lds_ok;
+	hipLaunchKernelGGL((row_spec_u8_kernel<S, KIND>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a, io);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+template <class S>
+int launch_col_roundtrip(const PassArgs &af, const PassArgs &ai, const MotionFilter &filt, unsigned long long *coded, int nwork, void *stream)
+{
+	static int lds_ok = allow_lds(col_roundtrip_kernel<S>, S::LDS);
+	if (lds_ok) return lds_ok;
+	FilterOp f; f.p = filt;
+	hipLaunchKernelGGL((col_roundtrip_kernel<S>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, af, ai, f, coded);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+}  // namespace dspfft

@@ -28,18 +28,23 @@
 // 1242 vs 1226 us per 8K roundtrip; 1080 (K=32): 85 vs 66 us.  The held half costs ~40 VGPRs, i.e. a resident
 // workgroup per CU, and doubles the barrier count.  Removed; see git history for `ColSplit2`.)
 
-#define DSPFFT_COL_SPECS(X)            \
-	X(2160, 8, 512, 12, 12, 15)        \
-	X(1080, 16, 512, 8, 9, 15)         \
-	X(4320, 8, 1024, 2, 12, 12, 15)    \
-	X(4320, 4, 512, 2, 12, 12, 15)     \
-	X(540, 16, 256, 4, 9, 15)          \
-	X(256, 16, 256, 4, 4, 16)          \
-	X(4096, 8, 1024, 16, 16, 16)       \
-	X(4096, 4, 512, 16, 16, 16)        \
-	X(2048, 8, 512, 8, 16, 16)         \
-	X(1440, 8, 512, 8, 12, 15)         \
-	X(1024, 16, 512, 4, 16, 16)        \
-	X(720, 16, 256, 6, 8, 15)          \
-	X(512, 16, 256, 4, 8, 16)          \
+// two groups, so the column kernels compile in two translation units (spec_inst_col_a/b.hip)
+#define DSPFFT_COL_SPECS_A(X) \
+	X(2160, 8, 512, 12, 12, 15) \
+	X(1080, 16, 512, 8, 9, 15) \
+	X(4320, 8, 1024, 2, 12, 12, 15) \
+	X(4320, 4, 512, 2, 12, 12, 15) \
+	X(540, 16, 256, 4, 9, 15) \
+	X(256, 16, 256, 4, 4, 16) \
+	X(4096, 8, 1024, 16, 16, 16)
+
+#define DSPFFT_COL_SPECS_B(X) \
+	X(4096, 4, 512, 16, 16, 16) \
+	X(2048, 8, 512, 8, 16, 16) \
+	X(1440, 8, 512, 8, 12, 15) \
+	X(1024, 16, 512, 4, 16, 16) \
+	X(720, 16, 256, 6, 8, 15) \
+	X(512, 16, 256, 4, 8, 16) \
 	X(480, 16, 256, 4, 8, 15)
+
+#define DSPFFT_COL_SPECS(X) DSPFFT_COL_SPECS_A(X) DSPFFT_COL_SPECS_B(X)
