@@ -120,6 +120,13 @@ DSP_HD R masked(const PassArgsT<R> &a, long long off, R v)
 	if (!a.mask) return v;
 	return a.mask[a.mask_div.div((uint32_t)off)] != a.mask_id ? R(0) : v;
 }
+// a.in[off] under the mask, without fetching elements that are masked out
+template <class R>
+DSP_HD R load_masked(const PassArgsT<R> &a, long long off)
+{
+	if (a.mask && a.mask[a.mask_div.div((uint32_t)off)] != a.mask_id) return R(0);
+	return a.in[off];
+}
 
 // ------------------------------------------------------------------------------------------------
 // FFT stage (in place in LDS).  Signals are interleaved: element n of signal s is buf[n*B + s].
@@ -244,7 +251,7 @@ DSP_HD void row_load10(const PassArgsT<R> &a, cx<R> *buf, long long bin, int tid
 	R *bf = reinterpret_cast<R *>(buf);
 	for (int it = tid; it < N * C; it += nthr) {
 		const int x = (int)a.divB.div((uint32_t)it), s = it - x * C;
-		R v = masked(a, bin + it, a.in[bin + it]);
+		R v = load_masked(a, bin + it);
 		if (x == 0) v *= a.in_scale0;
 		const int n = makhoul_dst(x, N);
 		bf[2 * ((n >> 1) * C + s) + (n & 1)] = v;
@@ -295,7 +302,7 @@ DSP_HD void row_load01(const PassArgsT<R> &a, cx<R> *buf, long long bin, int tid
 	for (int it = tid; it < nk * C; it += nthr) {
 		const int k = (int)a.divB.div((uint32_t)it), s = it - k * C;
 		const long long o = bin + s;
-		auto ld = [&](int px) { const long long e = o + (long long)px * C; return masked(a, e, a.in[e]); };
+		auto ld = [&](int px) { return load_masked(a, o + (long long)px * C); };
 		const R xk = ld(k) * (k == 0 ? a.in_scale0 : R(1));
 		const R xnk = k ? ld(N - k) : R(0);
 		const R xlk = ld(L - k);

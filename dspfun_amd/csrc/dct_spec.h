@@ -87,9 +87,19 @@ template <int C> DSP_HD void store_pix(float *p, const Pix<C> &r)
 
 template <int C> DSP_HD Pix<C> load_pix_m(const PassArgs &a, long long off)
 {
-	Pix<C> v = load_pix<C>(a.in + off);
-	if (a.mask) static_for<0, C>([&](auto c) { v.v[c] = masked(a, off + c, v.v[c]); });
-	return v;
+	if (a.mask) {
+		// fused scan step: look at the owner ids first and do not fetch coefficients that are masked out
+		// (a frame keeps 1/32 of them at BASELINE config 4, so most of the first pass's reads disappear)
+		uint32_t id[C];
+		bool any = false;
+		static_for<0, C>([&](auto c) { id[c] = a.mask[a.mask_div.div((uint32_t)(off + c))]; any = any || id[c] == a.mask_id; });
+		Pix<C> v;
+		if (!any) { static_for<0, C>([&](auto c) { v.v[c] = 0.f; }); return v; }
+		v = load_pix<C>(a.in + off);
+		static_for<0, C>([&](auto c) { if (id[c] != a.mask_id) v.v[c] = 0.f; });
+		return v;
+	}
+	return load_pix<C>(a.in + off);
 }
 template <int C> DSP_HD void store_pix_a(const PassArgs &a, long long off, Pix<C> r)
 {
@@ -98,9 +108,19 @@ template <int C> DSP_HD void store_pix_a(const PassArgs &a, long long off, Pix<C
 }
 DSP_HD float4 load4_m(const PassArgs &a, long long off)
 {
-	float4 v = *reinterpret_cast<const float4 *>(a.in + off);
-	if (a.mask) { v.x = masked(a, off, v.x); v.y = masked(a, off + 1, v.y); v.z = masked(a, off + 2, v.z); v.w = masked(a, off + 3, v.w); }
-	return v;
+	if (a.mask) {
+		const uint32_t i0 = a.mask[a.mask_div.div((uint32_t)off)], i1 = a.mask[a.mask_div.div((uint32_t)off + 1)];
+		const uint32_t i2 = a.mask[a.mask_div.div((uint32_t)off + 2)], i3 = a.mask[a.mask_div.div((uint32_t)off + 3)];
+		float4 v; v.x = v.y = v.z = v.w = 0.f;
+		if (i0 != a.mask_id && i1 != a.mask_id && i2 != a.mask_id && i3 != a.mask_id) return v;
+		v = *reinterpret_cast<const float4 *>(a.in + off);
+		if (i0 != a.mask_id) v.x = 0.f;
+		if (i1 != a.mask_id) v.y = 0.f;
+		if (i2 != a.mask_id) v.z = 0.f;
+		if (i3 != a.mask_id) v.w = 0.f;
+		return v;
+	}
+	return *reinterpret_cast<const float4 *>(a.in + off);
 }
 DSP_HD void store4_a(const PassArgs &a, long long off, float4 r)
 {
