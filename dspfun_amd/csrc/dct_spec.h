@@ -156,7 +156,7 @@ struct RowSpec {
 	static constexpr int U8_ROUNDS = (N / 4 + T - 1) / T;
 	static constexpr bool U8_OK = (C == 1) && (N % 4 == 0);
 	// per-thread registers that live across barriers: the last stage's butterflies and the
-	// prefetched global data of the NEXT line (persistent workgroups, see backend_hip.hip)
+	// line's global data, loaded before the first LDS phase
 	template <int KIND> struct State {
 		cf x[LAST_ROUNDS * RL];
 		float pre[(KIND == KIND_REDFT10 ? (U8_OK && 4 * U8_ROUNDS > PIX_ROUNDS ? 4 * U8_ROUNDS : PIX_ROUNDS) : 4 * K_ROUNDS) * C];

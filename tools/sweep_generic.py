@@ -15,11 +15,11 @@ def t(fn, reps=10):
 sizes = [tuple(int(v) for v in s.split("x")) for s in sys.argv[1:]] or [(2160, 3840, 3), (1000, 1500, 3), (1536, 2048, 3), (3000, 4000, 3), (600, 800, 3)]
 for (h, w, c) in sizes:
     x = torch.rand(h, w, c, device="cuda:0")
-    for thr, bg in itertools.product((256, 512, 1024), (0, 1)):
-        os.environ["DSPFFT_ROW_THREADS"] = str(thr); os.environ["DSPFFT_ROW_BG"] = str(bg)
+    for thr in (256, 512, 1024):
+        os.environ["DSPFFT_ROW_THREADS"] = str(thr)
         f = Plan.image(h, w, c, REDFT10); i = Plan.image(h, w, c, REDFT01)
-        print(f"{h}x{w}x{c} ROW thr={thr} bg1={bg}: II {t(lambda: f.execute_pass(0, x.data_ptr())):7.1f} III {t(lambda: i.execute_pass(0, x.data_ptr())):7.1f} us   {f.describe().splitlines()[1][:70]}", flush=True)
-    os.environ.pop("DSPFFT_ROW_THREADS"); os.environ.pop("DSPFFT_ROW_BG")
+        print(f"{h}x{w}x{c} ROW thr={thr}: II {t(lambda: f.execute_pass(0, x.data_ptr())):7.1f} III {t(lambda: i.execute_pass(0, x.data_ptr())):7.1f} us   {f.describe().splitlines()[1][:70]}", flush=True)
+    os.environ.pop("DSPFFT_ROW_THREADS")
     for K, thr in itertools.product((4, 8, 16), (256, 512, 1024)):
         os.environ["DSPFFT_COL_K"] = str(K); os.environ["DSPFFT_COL_THREADS"] = str(thr)
         f = Plan.image(h, w, c, REDFT10); i = Plan.image(h, w, c, REDFT01)
