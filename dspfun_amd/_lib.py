@@ -15,7 +15,7 @@ REDFT01, REDFT10 = 4, 5
 SYMBOLS = [
     "dspfft_plan_many_r2r", "dspfft_plan_r2r_2d", "dspfft_plan_set_scale", "dspfft_plan_set_axis_scale0",
     "dspfft_plan_many_r2r_f64", "dspfft_plan_set_scale_f64", "dspfft_plan_set_axis_scale0_f64", "dspfft_execute_f64", "dspfft_execute_masked_accumulate_f64",
-    "dspfft_plan_many_r2r_ordered", "dspfft_execute_roundtrip", "dspfft_execute_roundtrip_u8",
+    "dspfft_plan_many_r2r_ordered", "dspfft_plan_guru_r2r", "dspfft_execute_roundtrip", "dspfft_execute_roundtrip_u8",
     "dspfft_execute", "dspfft_plan_num_passes", "dspfft_execute_pass", "dspfft_destroy_plan", "dspfft_plan_describe", "dspfft_plan_algorithmic_bytes",
     "dspfft_last_error", "dspfft_version",
     "dspfft_scan_zigzag", "dspfft_scan_zigzag_frame_ids", "dspfft_execute_masked_accumulate", "dspfft_scan_scatter", "dspfft_accumulate", "dspfft_broadcast_dc",
@@ -24,6 +24,11 @@ SYMBOLS = [
     "dspfft_zoom_last_error", "dspfft_applybasis_work_floats", "dspfft_applybasis_partsums",
     "dspfft_spec_encode", "dspfft_ispec_decode", "dspfft_motion_filter", "dspfft_scan_pruned_accumulate", "dspfft_pointwise_last_error",
 ]
+
+class IoDim(C.Structure):
+    """dspfft_iodim (include/dspfft.h): extent, input stride, output stride in elements"""
+    _fields_ = [("n", C.c_int), ("is_", C.c_int), ("os", C.c_int)]
+
 
 class MotionFilterParams(C.Structure):
     """dspfft_motion_filter_params (include/dspfft.h)"""
@@ -46,6 +51,7 @@ def bind(lib):
     lib.dspfft_execute.argtypes = [vp, vp, vp, vp]
     lib.dspfft_plan_many_r2r_f64.argtypes = lib.dspfft_plan_many_r2r.argtypes
     lib.dspfft_plan_many_r2r_ordered.argtypes = lib.dspfft_plan_many_r2r.argtypes + [C.c_int]
+    lib.dspfft_plan_guru_r2r.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(IoDim), C.c_int, C.POINTER(IoDim), ip, C.c_int]
     lib.dspfft_execute_roundtrip.argtypes = [vp, vp, vp, vp, C.POINTER(MotionFilterParams), vp, vp]
     lib.dspfft_execute_roundtrip_u8.argtypes = [vp, vp, vp, vp, vp, C.c_double, C.POINTER(MotionFilterParams), vp, vp]
     lib.dspfft_plan_set_scale_f64.argtypes = [vp, C.c_double]

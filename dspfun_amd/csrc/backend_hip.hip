@@ -95,6 +95,13 @@ __global__ void __launch_bounds__(1024) blue_kernel(const BlueArgsT<R> a)
 	else col_unpack3(a, A, bout, valid, tid, nthr);
 }
 
+template <int N, int KIND, class R>
+__global__ void __launch_bounds__(256) tiny_kernel(const TinyArgsT<R> a)
+{
+	const long long line = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+	if (line < a.nlines) tiny_line<N, KIND>(a, line);
+}
+
 template <class R>
 __global__ void __launch_bounds__(256) dense_kernel(const DenseArgsT<R> a)
 {
@@ -219,6 +226,29 @@ static int launch_blue(const BlueArgsT<R> &a, const LaunchGeom &g, void *stream)
 }
 int be_launch_blue(const BlueArgs &a, const LaunchGeom &g, void *stream) { return launch_blue(a, g, stream); }
 int be_launch_blue(const BlueArgsD &a, const LaunchGeom &g, void *stream) { return launch_blue(a, g, stream); }
+
+template <int N, class R>
+static int launch_tiny_n(const TinyArgsT<R> &a, void *stream)
+{
+	const unsigned grid = (unsigned)((a.nlines + 255) / 256);
+	if (a.kind == KIND_REDFT10) hipLaunchKernelGGL((tiny_kernel<N, KIND_REDFT10, R>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+	else hipLaunchKernelGGL((tiny_kernel<N, KIND_REDFT01, R>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+template <class R>
+static int launch_tiny(const TinyArgsT<R> &a, void *stream)
+{
+	switch (a.N) {
+#define DSP_TINY_CASE(n) case n: return launch_tiny_n<n>(a, stream);
+	DSP_TINY_CASE(1) DSP_TINY_CASE(2) DSP_TINY_CASE(3) DSP_TINY_CASE(4) DSP_TINY_CASE(5) DSP_TINY_CASE(6) DSP_TINY_CASE(7) DSP_TINY_CASE(8)
+	DSP_TINY_CASE(9) DSP_TINY_CASE(10) DSP_TINY_CASE(11) DSP_TINY_CASE(12) DSP_TINY_CASE(13) DSP_TINY_CASE(14) DSP_TINY_CASE(15) DSP_TINY_CASE(16)
+#undef DSP_TINY_CASE
+	default: return -1;
+	}
+}
+int be_launch_tiny(const TinyArgs &a, void *stream) { return launch_tiny(a, stream); }
+int be_launch_tiny(const TinyArgsD &a, void *stream) { return launch_tiny(a, stream); }
 
 int be_launch_row(const PassArgs &a, const LaunchGeom &g, void *stream) { return launch_row(a, g, stream); }
 int be_launch_col(const PassArgs &a, const LaunchGeom &g, void *stream) { return launch_col(a, g, stream); }

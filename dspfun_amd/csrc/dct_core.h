@@ -511,6 +511,68 @@ DSP_HD void blue_chirp_out(const BlueArgsT<R> &a, cx<R> *A, int tid, int nthr)
 }
 
 // ------------------------------------------------------------------------------------------------
+// TINY pass: lengths up to 16 (motion's small blocks, e.g. -b 8x8x8: motion/README.md "3-dimensional analog to
+// JPEG-style compression").  A whole line lives in one thread's registers and is transformed by the definition with
+// compile-time cosines; no LDS, no barriers.  Lines are enumerated over up to six batch dimensions ordered by stride,
+// so neighbouring threads touch neighbouring memory.
+struct TinyGeom {
+	int N, kind;
+	long long es_in, es_out;
+	int nd;                                   // batch dimensions in use
+	int bn[6];
+	long long bis[6], bos[6];
+	FastDiv bdiv[6];
+	long long nlines;
+	const uint32_t *mask;
+	uint32_t mask_id;
+	FastDiv mask_div;
+	int accumulate;
+};
+template <class R>
+struct TinyArgsT : TinyGeom {
+	const R *in;
+	R *out;
+	R scale, out_scale0, in_scale0;
+};
+typedef TinyArgsT<float> TinyArgs;
+typedef TinyArgsT<double> TinyArgsD;
+
+// cos(pi t / (2N)) for integer t, by the octant-reduced compile-time evaluation of radix.h
+template <int N> constexpr double tiny_cos(long t) { return ct::cossin(t, 4L * N).c; }
+
+template <int N, int KIND, class R>
+DSP_HD void tiny_line(const TinyArgsT<R> &a, long long line)
+{
+	long long bin = 0, bout = 0;
+	uint32_t rem = (uint32_t)line;            // nlines < 2^31 (planner)
+	for (int d = 0; d < a.nd; d++) {
+		const uint32_t q = a.bdiv[d].div_exact(rem), i = rem - q * (uint32_t)a.bn[d];
+		bin += (long long)i * a.bis[d]; bout += (long long)i * a.bos[d];
+		rem = q;
+	}
+	R x[N];
+	static_for<0, N>([&](auto j) {
+		const long long off = bin + (long long)j * a.es_in;
+		const bool drop = a.mask && a.mask[a.mask_div.div((uint32_t)off)] != a.mask_id;
+		x[j] = drop ? R(0) : a.in[off];
+	});
+	x[0] *= a.in_scale0;
+	static_for<0, N>([&](auto k) {
+		R acc;
+		if constexpr (KIND == KIND_REDFT10) {
+			acc = R(0);
+			static_for<0, N>([&](auto j) { constexpr R c = (R)(2.0 * tiny_cos<N>((2L * j + 1) * k)); acc += x[j] * c; });
+		} else {
+			acc = x[0];
+			static_for<1, N>([&](auto j) { constexpr R c = (R)(2.0 * tiny_cos<N>((long)j * (2L * k + 1))); acc += x[j] * c; });
+		}
+		const R r = acc * a.scale * (k == 0 ? a.out_scale0 : R(1));
+		const long long off = bout + (long long)k * a.es_out;
+		if (a.accumulate) a.out[off] += r; else a.out[off] = r;
+	});
+}
+
+// ------------------------------------------------------------------------------------------------
 // DENSE pass: any N, any stride; O(N^2) by the definition with an exactly reduced phase table.
 // LDS: x[N] floats.  cosTab[t] = cos(pi t / (2N)), t in [0, 4N).
 struct DenseGeom {

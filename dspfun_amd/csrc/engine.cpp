@@ -117,7 +117,8 @@ bool build_fft(int L, FftDesc &F, std::vector<uint32_t> &pos)
 }
 
 struct Pass {
-	enum Type { ROW, COL, DENSE, BLUE } type;   // BLUE = COL geometry, tile DFT by Bluestein's convolution
+	enum Type { ROW, COL, DENSE, BLUE, TINY } type;   // BLUE = COL geometry, tile DFT by Bluestein's convolution; TINY = one line per thread
+	TinyGeom tg;
 	int blueM = 0;
 	FftDesc fftM;
 	int axis;
@@ -139,7 +140,8 @@ struct Pass {
 struct dspfft_plan_s {
 	int rank, howmany;
 	int n[3], kinds[3];
-	Dim axes[3], batch;
+	Dim axes[3];
+	std::vector<Dim> batches;  // howmany/dist (one entry) or the guru interface's howmany_dims
 	bool f64;                  // samples are double (dspfft_plan_many_r2r_f64): generic kernels, double tables
 	double scale, in0[3], out0[3];
 	std::vector<Pass> passes;
@@ -274,12 +276,30 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 	const Dim ax = eff(pl->axes[a]);
 	std::vector<Dim> others;
 	for (int b = 0; b < pl->rank; b++) if (b != a && pl->n[b] > 1) others.push_back(eff(pl->axes[b]));
-	if (pl->howmany > 1) others.push_back(eff(pl->batch));
+	for (const Dim &b : pl->batches) if (b.n > 1) others.push_back(eff(b));
 	const size_t maxlds = be_max_lds();
 	const size_t es = pl->f64 ? 8 : 4;         // bytes per sample; a complex LDS slot is 2*es
 	const char *tag = pl->f64 ? " f64" : "";
 	char buf[256];
 
+	// ---------------- TINY ----------------
+	if (N <= 16 && !(env_int("DSPFFT_NO_TINY") == 1)) {
+		std::vector<Dim> d = others;
+		merge_dims(d);
+		long long nlines = 1;
+		for (const Dim &x : d) nlines *= x.n;
+		if (d.size() <= 6 && nlines < (1ll << 31)) {
+			TinyGeom &tg = P.tg;
+			memset(&tg, 0, sizeof tg);
+			tg.N = N; tg.kind = kind; tg.es_in = ax.is; tg.es_out = ax.os; tg.nd = (int)d.size(); tg.nlines = nlines;
+			for (size_t i = 0; i < d.size(); i++) { tg.bn[i] = d[i].n; tg.bis[i] = d[i].is; tg.bos[i] = d[i].os; tg.bdiv[i] = make_div((uint32_t)d[i].n); }
+			P.type = Pass::TINY;
+			P.g.nwg = (int)((nlines + 255) / 256); P.g.nthr = 256; P.g.lds_bytes = 0;
+			snprintf(buf, sizeof buf, "axis %d: TINY%s N=%d lines=%lld dims=%d", a, tag, N, nlines, tg.nd);
+			P.desc = buf;
+			return 0;
+		}
+	}
 	// ---------------- ROW ----------------
 	{
 		bool ok = (N % 2 == 0) && ax.is == ax.os && ax.is >= 1 && ax.is <= 4;
@@ -445,7 +465,14 @@ int run_pass(const dspfft_plan_s *pl, const Pass &P, const R *in, R *out, bool l
 		long long oin = 0, oout = 0;
 		for (size_t i = 0; i < idx.size(); i++) { oin += idx[i] * P.hostloop[i].is; oout += idx[i] * P.hostloop[i].os; }
 		int rc = 0;
-		if (P.type == Pass::DENSE) {
+		if (P.type == Pass::TINY) {
+			TinyArgsT<R> a;
+			static_cast<TinyGeom &>(a) = P.tg;
+			a.in = in + oin; a.out = out + oout;
+			a.scale = (R)scale; a.in_scale0 = (R)pl->in0[P.axis]; a.out_scale0 = (R)pl->out0[P.axis];
+			a.mask = fz.mask; a.mask_id = fz.id; a.mask_div = make_div((uint32_t)fz.div); a.accumulate = fz.accumulate;
+			rc = be_launch_tiny(a, stream);
+		} else if (P.type == Pass::DENSE) {
 			DenseArgsT<R> a;
 			static_cast<DenseGeom &>(a) = P.da;
 			a.in = in + oin; a.out = out + oout; a.cosTab = (const R *)P.tab.cosTab;
@@ -487,6 +514,25 @@ int run_pass(const dspfft_plan_s *pl, const Pass &P, const R *in, R *out, bool l
 
 }  // namespace
 
+static int plan_finish(dspfft_plan_s *pl, dspfft_plan *plan, bool first_axis_first)
+{
+	size_t samples = 1;
+	pl->howmany = 1;
+	for (const Dim &b : pl->batches) { samples *= (size_t)b.n; pl->howmany *= b.n; }
+	for (int a = 0; a < pl->rank; a++) samples *= (size_t)pl->n[a];
+	pl->alg_bytes = samples * (pl->f64 ? 16 : 8);
+	bool first = true;
+	for (int i = 0; i < pl->rank; i++) {
+		const int a = first_axis_first ? i : pl->rank - 1 - i;
+		pl->passes.emplace_back();
+		int rc = build_pass(pl, a, first, pl->passes.back());
+		if (rc) { dspfft_destroy_plan(pl); return rc; }
+		first = false;
+	}
+	*plan = pl;
+	return 0;
+}
+
 static int plan_many(dspfft_plan *plan, int rank, const int *n, int howmany,
                      const int *inembed, int istride, int idist,
                      const int *onembed, int ostride, int odist, const int *kinds, bool f64, bool first_axis_first = false)
@@ -501,27 +547,15 @@ static int plan_many(dspfft_plan *plan, int rank, const int *n, int howmany,
 		if ((inembed && inembed[a] < n[a] && a > 0) || (onembed && onembed[a] < n[a] && a > 0)) return fail(-1, "embed smaller than n");
 	}
 	dspfft_plan_s *pl = new dspfft_plan_s();
-	pl->rank = rank; pl->howmany = howmany; pl->scale = 1.0; pl->f64 = f64;
+	pl->rank = rank; pl->scale = 1.0; pl->f64 = f64;
 	long long is = istride, os = ostride;
 	for (int a = rank - 1; a >= 0; a--) {
 		pl->n[a] = n[a]; pl->kinds[a] = kinds[a]; pl->in0[a] = pl->out0[a] = 1.0;
 		pl->axes[a].n = n[a]; pl->axes[a].is = is; pl->axes[a].os = os;
 		is *= inembed ? inembed[a] : n[a]; os *= onembed ? onembed[a] : n[a];
 	}
-	pl->batch.n = howmany; pl->batch.is = idist; pl->batch.os = odist;
-	size_t samples = (size_t)howmany;
-	for (int a = 0; a < rank; a++) samples *= (size_t)n[a];
-	pl->alg_bytes = samples * (f64 ? 16 : 8);
-	bool first = true;
-	for (int i = 0; i < rank; i++) {
-		const int a = first_axis_first ? i : rank - 1 - i;
-		pl->passes.emplace_back();
-		int rc = build_pass(pl, a, first, pl->passes.back());
-		if (rc) { dspfft_destroy_plan(pl); return rc; }
-		first = false;
-	}
-	*plan = pl;
-	return 0;
+	if (howmany > 1) pl->batches.push_back(Dim{howmany, idist, odist});
+	return plan_finish(pl, plan, first_axis_first);
 }
 
 extern "C" int dspfft_plan_many_r2r(dspfft_plan *plan, int rank, const int *n, int howmany,
@@ -535,6 +569,31 @@ extern "C" int dspfft_plan_many_r2r_f64(dspfft_plan *plan, int rank, const int *
                                         const int *onembed, int ostride, int odist, const int *kinds)
 {
 	return plan_many(plan, rank, n, howmany, inembed, istride, idist, onembed, ostride, odist, kinds, true);
+}
+
+// FFTW's guru interface shape (fftw_plan_guru_r2r): every transformed and every batch dimension has its own extent and
+// input / output strides, so e.g. all 8x8x8 blocks of a volume (motion --blocksize 8x8x8) are ONE plan
+extern "C" int dspfft_plan_guru_r2r(dspfft_plan *plan, int rank, const dspfft_iodim *dims, int howmany_rank, const dspfft_iodim *howmany_dims,
+                                    const int *kinds, int f64)
+{
+	if (!plan) return fail(-1, "null plan pointer");
+	*plan = nullptr;
+	if (rank < 1 || rank > 3 || !dims || !kinds) return fail(-1, "rank %d unsupported (1..3)", rank);
+	if (howmany_rank < 0 || howmany_rank > 6 || (howmany_rank && !howmany_dims)) return fail(-1, "howmany_rank %d unsupported (0..6)", howmany_rank);
+	for (int a = 0; a < rank; a++) {
+		if (dims[a].n < 1 || dims[a].is < 1 || dims[a].os < 1) return fail(-1, "dims[%d] must have n, is, os >= 1", a);
+		if (kinds[a] != DSPFFT_REDFT10 && kinds[a] != DSPFFT_REDFT01) return fail(-1, "kind %d unsupported (REDFT10/REDFT01 only)", kinds[a]);
+	}
+	for (int b = 0; b < howmany_rank; b++)
+		if (howmany_dims[b].n < 1 || howmany_dims[b].is < 0 || howmany_dims[b].os < 0) return fail(-1, "howmany_dims[%d] must have n >= 1 and non-negative strides", b);
+	dspfft_plan_s *pl = new dspfft_plan_s();
+	pl->rank = rank; pl->scale = 1.0; pl->f64 = f64 != 0;
+	for (int a = 0; a < rank; a++) {
+		pl->n[a] = dims[a].n; pl->kinds[a] = kinds[a]; pl->in0[a] = pl->out0[a] = 1.0;
+		pl->axes[a].n = dims[a].n; pl->axes[a].is = dims[a].is; pl->axes[a].os = dims[a].os;
+	}
+	for (int b = 0; b < howmany_rank; b++) if (howmany_dims[b].n > 1) pl->batches.push_back(Dim{howmany_dims[b].n, howmany_dims[b].is, howmany_dims[b].os});
+	return plan_finish(pl, plan, false);
 }
 
 extern "C" int dspfft_plan_many_r2r_ordered(dspfft_plan *plan, int rank, const int *n, int howmany,
@@ -653,7 +712,9 @@ int roundtrip_core(dspfft_plan fwd, dspfft_plan inv, const float *d_in, float *d
 	for (int a = 0; a < fwd->rank; a++)
 		if (fwd->n[a] != inv->n[a] || fwd->axes[a].os != inv->axes[a].is || inv->axes[a].is != inv->axes[a].os || fwd->kinds[a] != DSPFFT_REDFT10 || inv->kinds[a] != DSPFFT_REDFT01)
 			return fail(-1, "roundtrip: the inverse must be REDFT01, in place, on the forward (REDFT10) plan's output layout");
-	if (fwd->howmany > 1 && (fwd->batch.os != inv->batch.is || inv->batch.is != inv->batch.os)) return fail(-1, "roundtrip: batch layouts differ");
+	if (fwd->batches.size() != inv->batches.size()) return fail(-1, "roundtrip: batch layouts differ");
+	for (size_t b = 0; b < fwd->batches.size(); b++)
+		if (fwd->batches[b].n != inv->batches[b].n || fwd->batches[b].os != inv->batches[b].is || inv->batches[b].is != inv->batches[b].os) return fail(-1, "roundtrip: batch layouts differ");
 	MotionFilter mf;
 	memset(&mf, 0, sizeof mf);
 	if (fp) {
@@ -668,14 +729,14 @@ int roundtrip_core(dspfft_plan fwd, dspfft_plan inv, const float *d_in, float *d
 	// extent of the working buffer in elements (the filter addresses it with 32-bit offsets)
 	long long span = 1;
 	for (int a = 0; a < fwd->rank; a++) span += (long long)(fwd->n[a] - 1) * fwd->axes[a].os;
-	span += (long long)(fwd->howmany - 1) * fwd->batch.os;
+	for (const Dim &b : fwd->batches) span += (long long)(b.n - 1) * b.os;
 	if (fp && span >= (1ll << 31)) return fail(-2, "filtered roundtrip addresses the buffer with 31-bit offsets: buffer too large");
 	if (d_in8 || d_out8) {
 		// the 8-bit buffers share the plans' element layout; the unfused conversions below walk whole spans
 		if (nf < 2 || ni < 2) return fail(-2, "8-bit roundtrip needs at least two transformed axes");
 		long long ispan = 1;
 		for (int a = 0; a < fwd->rank; a++) ispan += (long long)(fwd->n[a] - 1) * fwd->axes[a].is;
-		ispan += (long long)(fwd->howmany - 1) * fwd->batch.is;
+		for (const Dim &b : fwd->batches) ispan += (long long)(b.n - 1) * b.is;
 		if (d_in8 && !pass_has_u8(fwd->passes[0])) {
 			if (ispan != span) return fail(-2, "8-bit input without a planar specialised row pass needs identical input and work layouts");
 			if (be_u8_to_f32(d_out, d_in8, (uint64_t)span, stream)) return fail(-4, "launch failed");

@@ -58,6 +58,22 @@ class Plan:
         return cls(h, lib, dtype == "f64")
 
     @classmethod
+    def guru(cls, dims, howmany_dims, kinds, lib=None, dtype="f32"):
+        """The shape of fftw_plan_guru_r2r: dims and howmany_dims are lists of (n, in_stride, out_stride) in elements.  One plan for
+        e.g. every 8x8x8 block of a volume (motion --blocksize 8x8x8)."""
+        lib = lib or _lib.load()
+        def arr(d):
+            a = (_lib.IoDim * max(1, len(d)))()
+            for i, (n, is_, os_) in enumerate(d):
+                a[i].n, a[i].is_, a[i].os = int(n), int(is_), int(os_)
+            return a
+        h = C.c_void_p()
+        rc = lib.dspfft_plan_guru_r2r(C.byref(h), len(dims), arr(dims), len(howmany_dims), arr(howmany_dims), _ia(list(kinds)), 1 if dtype == "f64" else 0)
+        if rc:
+            raise DspfftError(lib.dspfft_last_error().decode())
+        return cls(h, lib, dtype == "f64")
+
+    @classmethod
     def r2r_2d(cls, n0, n1, kind0, kind1, lib=None):
         lib = lib or _lib.load()
         h = C.c_void_p()

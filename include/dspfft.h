@@ -71,6 +71,16 @@ int dspfft_execute_f64(dspfft_plan plan, const double *d_in, double *d_out, void
 int dspfft_execute_masked_accumulate_f64(dspfft_plan plan, const double *d_in, double *d_work, double *d_acc,
                                          const uint32_t *d_ids, uint32_t id, int elems_per_id, void *hip_stream);
 
+/* The shape of FFTW's guru interface (fftw_plan_guru_r2r; not called by the reference's tools, which loop over blocks
+ * on the host instead: motion/motion.c:591-615): every transformed dimension and every batch dimension carries its own
+ * extent and input / output strides (in elements).  One plan then covers, e.g., all 8x8x8 blocks of a [D][H][W] volume
+ * (motion --blocksize 8x8x8, motion/README.md): dims = {8,HW,HW},{8,W,W},{8,1,1}, howmany_dims =
+ * {D/8,8HW,8HW},{H/8,8W,8W},{W/8,8,8}.  rank 1..3, howmany_rank 0..6; f64 != 0 selects double samples.  Lengths up to
+ * 16 run one line per thread in registers. */
+typedef struct { int n; int is; int os; } dspfft_iodim;
+int dspfft_plan_guru_r2r(dspfft_plan *plan, int rank, const dspfft_iodim *dims, int howmany_rank, const dspfft_iodim *howmany_dims,
+                         const int *kinds, int f64);
+
 /* As dspfft_plan_many_r2r, with the order of the axis passes chosen: first_axis_first = 0 is the default (last axis
  * first), 1 runs axis 0 first and the contiguous axis last.  The results are the same; the order decides which pass
  * reads the caller's input layout and which one ends the plan. */

@@ -98,6 +98,28 @@ static int emul_blue(const BlueArgsT<R> &a, const LaunchGeom &g)
 int be_launch_blue(const BlueArgs &a, const LaunchGeom &g, void *) { return emul_blue(a, g); }
 int be_launch_blue(const BlueArgsD &a, const LaunchGeom &g, void *) { return emul_blue(a, g); }
 
+template <int N, class R>
+static int emul_tiny_n(const TinyArgsT<R> &a)
+{
+	for (long long line = 0; line < a.nlines; line++) {
+		if (a.kind == KIND_REDFT10) tiny_line<N, KIND_REDFT10>(a, line); else tiny_line<N, KIND_REDFT01>(a, line);
+	}
+	return 0;
+}
+template <class R>
+static int emul_tiny(const TinyArgsT<R> &a)
+{
+	switch (a.N) {
+#define DSP_TINY_CASE(n) case n: return emul_tiny_n<n>(a);
+	DSP_TINY_CASE(1) DSP_TINY_CASE(2) DSP_TINY_CASE(3) DSP_TINY_CASE(4) DSP_TINY_CASE(5) DSP_TINY_CASE(6) DSP_TINY_CASE(7) DSP_TINY_CASE(8)
+	DSP_TINY_CASE(9) DSP_TINY_CASE(10) DSP_TINY_CASE(11) DSP_TINY_CASE(12) DSP_TINY_CASE(13) DSP_TINY_CASE(14) DSP_TINY_CASE(15) DSP_TINY_CASE(16)
+#undef DSP_TINY_CASE
+	default: return -1;
+	}
+}
+int be_launch_tiny(const TinyArgs &a, void *) { return emul_tiny(a); }
+int be_launch_tiny(const TinyArgsD &a, void *) { return emul_tiny(a); }
+
 int be_launch_row(const PassArgs &a, const LaunchGeom &g, void *) { return emul_row(a, g); }
 int be_launch_col(const PassArgs &a, const LaunchGeom &g, void *) { return emul_col(a, g); }
 int be_launch_dense(const DenseArgs &a, const LaunchGeom &g, void *) { return emul_dense(a, g); }

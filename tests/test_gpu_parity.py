@@ -697,6 +697,35 @@ def test_roundtrip_u8_matches_float_path(gpu, case):
     assert np.abs(out.cpu().numpy().astype(np.float64) - np.clip(np.floor(u8 * mul + 0.5), 0, 255)).max() <= 6
 
 
+@pytest.mark.parametrize("block", [(8, 8, 8), (16, 16, 4), (5, 12, 15)])
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_guru_blocks_of_a_volume(gpu, block, dtype):
+    """all blocks of a [D][H][W] volume in one plan (motion --blocksize: motion.c:591-615 walks them one by one); each block
+    against the definition"""
+    from dspfun_amd import Plan
+    bd, bh, bw = block
+    D, H, W = 4 * bd, 6 * bh, 8 * bw
+    f64 = dtype == "f64"
+    x = ol.synth_f32(77, D * H * W).reshape(D, H, W)
+    x = x.astype(np.float64) * (1 + 2.0 ** -30) if f64 else x
+    dims = [(bd, H * W, H * W), (bh, W, W), (bw, 1, 1)]
+    how = [(D // bd, bd * H * W, bd * H * W), (H // bh, bh * W, bh * W), (W // bw, bw, bw)]
+    for kind in (5, 4):
+        p = Plan.guru(dims, how, [kind] * 3, dtype=dtype)
+        assert p.describe().count("TINY") == 3, p.describe()
+        d = gpu.from_numpy(x.copy()).to("cuda:0")
+        p.execute(d.data_ptr())
+        gpu.cuda.synchronize()
+        got = d.cpu().numpy()
+        # blocks are independent: transform them as a batch with the oracle (block-major copy)
+        blocks = x.reshape(D // bd, bd, H // bh, bh, W // bw, bw).transpose(0, 2, 4, 1, 3, 5).reshape(-1, bd, bh, bw).astype(np.float64)
+        gb = got.reshape(D // bd, bd, H // bh, bh, W // bw, bw).transpose(0, 2, 4, 1, 3, 5).reshape(-1, bd, bh, bw)
+        nb = blocks.shape[0]
+        ref = ol.r2r_many(np.ascontiguousarray(blocks).ravel(), [bd, bh, bw], [kind] * 3, howmany=nb, idist=bd * bh * bw, odist=bd * bh * bw,
+                          impl="port", threads=8).reshape(nb, bd, bh, bw)
+        check(gb, ref, tol=1e-13 if f64 else TOL)
+
+
 def test_scan_pruned_idct_path(gpu):
     """scan.c:20-41,449: few coefficients per frame -> direct rank-1 sums; against the restatement and against the
     transform path (dspfft_execute_masked_accumulate) on the same frames"""

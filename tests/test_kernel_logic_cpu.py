@@ -532,3 +532,72 @@ def test_roundtrip_plan_shapes(shape):
         bad = Plan.many_r2r(n, [REDFT01] * 2, lib=L, **kw)
         with pytest.raises(DspfftError):
             fwd.roundtrip(bad, got.ctypes.data)
+
+
+# ---- lengths up to 16 in registers (TINY) and the guru-shaped batch interface (motion --blocksize 8x8x8) ----
+@pytest.mark.parametrize("N", list(range(1, 17)))
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_tiny_lengths(N, dtype):
+    f64 = dtype == "f64"
+    for kind in (REDFT10, REDFT01):
+        xb = ol.synth_f32(N + 50, N * 10).reshape(N, 10)
+        xb = xb.astype(np.float64) * (1 + 2.0 ** -30) if f64 else xb
+        ref = np.stack([ol.r2r_many(xb[:, t].astype(np.float64).copy(), [N], [kind]) for t in range(10)], axis=1)
+        p = Plan.many_r2r([N], [kind], howmany=10, istride=10, idist=1, ostride=10, odist=1, lib=emul(), dtype=dtype)
+        assert "TINY" in p.describe(), p.describe()
+        got = run64(p, xb.copy()) if f64 else run(p, xb.copy())
+        assert relerr(got, ref) < (1e-14 if f64 else 1e-6), (N, kind)
+        # contiguous lines
+        xc = np.ascontiguousarray(xb.T)
+        p = Plan.many_r2r([N], [kind], howmany=10, idist=N, odist=N, lib=emul(), dtype=dtype)
+        got = run64(p, xc.copy()) if f64 else run(p, xc.copy())
+        assert relerr(got, ref.T) < (1e-14 if f64 else 1e-6), (N, kind)
+
+
+@pytest.mark.parametrize("block", [(8, 8, 8), (4, 6, 16), (2, 3, 5)])
+def test_guru_blocks_of_a_volume(block):
+    """every block of a [D][H][W] volume in ONE plan (motion --blocksize WxHxD processes them one by one, motion.c:591-615)"""
+    bd, bh, bw = block
+    D, H, W = 2 * bd, 3 * bh, 2 * bw
+    x = ol.synth_f32(77, D * H * W).reshape(D, H, W)
+    dims = [(bd, H * W, H * W), (bh, W, W), (bw, 1, 1)]
+    how = [(D // bd, bd * H * W, bd * H * W), (H // bh, bh * W, bh * W), (W // bw, bw, bw)]
+    for kind in (REDFT10, REDFT01):
+        p = Plan.guru(dims, how, [kind] * 3, lib=emul())
+        assert p.describe().count("TINY") == 3, p.describe()
+        got = run(p, x.copy())
+        ref = np.empty((D, H, W))
+        for z in range(0, D, bd):
+            for y in range(0, H, bh):
+                for xx in range(0, W, bw):
+                    blk = np.ascontiguousarray(x[z:z + bd, y:y + bh, xx:xx + bw]).astype(np.float64)
+                    ref[z:z + bd, y:y + bh, xx:xx + bw] = ol.r2r_many(blk.ravel(), [bd, bh, bw], [kind] * 3).reshape(bd, bh, bw)
+        assert relerr(got, ref) < TOL, (block, kind)
+    # the same geometry with a long axis: 1x1xD blocks = a temporal transform per pixel (motion --blocksize 1x1x0)
+    p = Plan.guru([(D, H * W, H * W)], [(H * W, 1, 1)], [REDFT10], lib=emul())
+    got = run(p, x.copy())
+    ref = np.stack([ol.r2r_many(x.reshape(D, -1)[:, i].astype(np.float64).copy(), [D], [REDFT10]) for i in range(H * W)], axis=1).reshape(D, H, W)
+    assert relerr(got, ref) < TOL
+
+
+def test_guru_rejects_bad_arguments_and_tiny_fused_scan():
+    with pytest.raises(DspfftError):
+        Plan.guru([(8, 1, 1)] * 4, [], [REDFT10] * 4, lib=emul())
+    with pytest.raises(DspfftError):
+        Plan.guru([(8, 0, 1)], [], [REDFT10], lib=emul())
+    # masked + accumulating execution through TINY passes (a 12x16 image: both axes in registers)
+    h, w, c = 12, 16, 3
+    L = emul()
+    x = ol.synth_f32(8, h * w * c).reshape(h, w, c)
+    coeffs = x.copy()
+    Plan.image(h, w, c, REDFT10, lib=L).set_scale(1.0 / (4 * w * h)).execute(coeffs.ctypes.data)
+    ids = np.zeros(h * w, dtype=np.uint32)
+    step = (h * w + 3) // 4
+    assert L.dspfft_scan_zigzag_frame_ids(ids.ctypes.data, w, h, step, None) == 0
+    inv = Plan.image(h, w, c, REDFT01, lib=L)
+    assert inv.describe().count("TINY") == 2
+    acc = np.ascontiguousarray(np.broadcast_to(coeffs[0, 0], (h, w, c)).copy())
+    work = np.zeros_like(acc)
+    for f in range(4):
+        inv.execute_masked_accumulate(coeffs.ctypes.data, work.ctypes.data, acc.ctypes.data, ids.ctypes.data, f, c)
+    assert np.abs(acc - x).max() < 1e-5
