@@ -28,8 +28,10 @@ DSPFFT_ROW_SPECS(DSP_EXTERN_ROW)
 DSPFFT_COL_SPECS(DSP_EXTERN_COL)
 
 // ---------------------------------------------------------------------------------------------
-template <int KIND, class R>
-__global__ void __launch_bounds__(1024) row_kernel(const PassArgsT<R> a)
+// MAXT: the largest workgroup the instantiation is launched with (512 leaves the register allocator 256 VGPRs, which
+// the double-precision radix-16 butterflies need; 1024 caps it at 128)
+template <int KIND, class R, int MAXT>
+__global__ void __launch_bounds__(MAXT) row_kernel(const PassArgsT<R> a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	cx<R> *buf = reinterpret_cast<cx<R> *>(lds);
@@ -47,8 +49,8 @@ __global__ void __launch_bounds__(1024) row_kernel(const PassArgsT<R> a)
 	else row_store01(a, buf, bout, tid, nthr);
 }
 
-template <int KIND, class R>
-__global__ void __launch_bounds__(1024) col_kernel(const PassArgsT<R> a)
+template <int KIND, class R, int MAXT>
+__global__ void __launch_bounds__(MAXT) col_kernel(const PassArgsT<R> a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	cx<R> *buf = reinterpret_cast<cx<R> *>(lds);
@@ -66,8 +68,8 @@ __global__ void __launch_bounds__(1024) col_kernel(const PassArgsT<R> a)
 	else col_unpack3(a, buf, bout, valid, tid, nthr);
 }
 
-template <int KIND, class R>
-__global__ void __launch_bounds__(1024) blue_kernel(const BlueArgsT<R> a)
+template <int KIND, class R, int MAXT>
+__global__ void __launch_bounds__(MAXT) blue_kernel(const BlueArgsT<R> a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	cx<R> *A = reinterpret_cast<cx<R> *>(lds);
@@ -171,34 +173,27 @@ size_t be_max_lds() { return 160 * 1024; }
 const char *be_name() { return "hip-gfx950"; }
 
 
-template <class R>
-static int launch_row(const PassArgsT<R> &a, const LaunchGeom &g, void *stream)
+template <class K, class A>
+static int launch_lds_kernel(K kernel, const A &a, const LaunchGeom &g, void *stream)
 {
-	hipStream_t s = (hipStream_t)stream;
-	if (a.kind == KIND_REDFT10) {
-		if (int rc = allow_lds(row_kernel<KIND_REDFT10, R>, g.lds_bytes)) return rc;
-		hipLaunchKernelGGL((row_kernel<KIND_REDFT10, R>), dim3(g.nwg), dim3(g.nthr), g.lds_bytes, s, a);
-	} else {
-		if (int rc = allow_lds(row_kernel<KIND_REDFT01, R>, g.lds_bytes)) return rc;
-		hipLaunchKernelGGL((row_kernel<KIND_REDFT01, R>), dim3(g.nwg), dim3(g.nthr), g.lds_bytes, s, a);
-	}
+	if (int rc = allow_lds(kernel, g.lds_bytes)) return rc;
+	hipLaunchKernelGGL(kernel, dim3(g.nwg), dim3(g.nthr), g.lds_bytes, (hipStream_t)stream, a);
 	HIPCHK(hipGetLastError());
 	return 0;
 }
 
 template <class R>
+static int launch_row(const PassArgsT<R> &a, const LaunchGeom &g, void *stream)
+{
+	if (a.kind == KIND_REDFT10) return g.nthr > 512 ? launch_lds_kernel(row_kernel<KIND_REDFT10, R, 1024>, a, g, stream) : launch_lds_kernel(row_kernel<KIND_REDFT10, R, 512>, a, g, stream);
+	return g.nthr > 512 ? launch_lds_kernel(row_kernel<KIND_REDFT01, R, 1024>, a, g, stream) : launch_lds_kernel(row_kernel<KIND_REDFT01, R, 512>, a, g, stream);
+}
+
+template <class R>
 static int launch_col(const PassArgsT<R> &a, const LaunchGeom &g, void *stream)
 {
-	hipStream_t s = (hipStream_t)stream;
-	if (a.kind == KIND_REDFT10) {
-		if (int rc = allow_lds(col_kernel<KIND_REDFT10, R>, g.lds_bytes)) return rc;
-		hipLaunchKernelGGL((col_kernel<KIND_REDFT10, R>), dim3(g.nwg), dim3(g.nthr), g.lds_bytes, s, a);
-	} else {
-		if (int rc = allow_lds(col_kernel<KIND_REDFT01, R>, g.lds_bytes)) return rc;
-		hipLaunchKernelGGL((col_kernel<KIND_REDFT01, R>), dim3(g.nwg), dim3(g.nthr), g.lds_bytes, s, a);
-	}
-	HIPCHK(hipGetLastError());
-	return 0;
+	if (a.kind == KIND_REDFT10) return g.nthr > 512 ? launch_lds_kernel(col_kernel<KIND_REDFT10, R, 1024>, a, g, stream) : launch_lds_kernel(col_kernel<KIND_REDFT10, R, 512>, a, g, stream);
+	return g.nthr > 512 ? launch_lds_kernel(col_kernel<KIND_REDFT01, R, 1024>, a, g, stream) : launch_lds_kernel(col_kernel<KIND_REDFT01, R, 512>, a, g, stream);
 }
 
 template <class R>
@@ -213,16 +208,8 @@ static int launch_dense(const DenseArgsT<R> &a, const LaunchGeom &g, void *strea
 template <class R>
 static int launch_blue(const BlueArgsT<R> &a, const LaunchGeom &g, void *stream)
 {
-	hipStream_t s = (hipStream_t)stream;
-	if (a.kind == KIND_REDFT10) {
-		if (int rc = allow_lds(blue_kernel<KIND_REDFT10, R>, g.lds_bytes)) return rc;
-		hipLaunchKernelGGL((blue_kernel<KIND_REDFT10, R>), dim3(g.nwg), dim3(g.nthr), g.lds_bytes, s, a);
-	} else {
-		if (int rc = allow_lds(blue_kernel<KIND_REDFT01, R>, g.lds_bytes)) return rc;
-		hipLaunchKernelGGL((blue_kernel<KIND_REDFT01, R>), dim3(g.nwg), dim3(g.nthr), g.lds_bytes, s, a);
-	}
-	HIPCHK(hipGetLastError());
-	return 0;
+	if (a.kind == KIND_REDFT10) return g.nthr > 512 ? launch_lds_kernel(blue_kernel<KIND_REDFT10, R, 1024>, a, g, stream) : launch_lds_kernel(blue_kernel<KIND_REDFT10, R, 512>, a, g, stream);
+	return g.nthr > 512 ? launch_lds_kernel(blue_kernel<KIND_REDFT01, R, 1024>, a, g, stream) : launch_lds_kernel(blue_kernel<KIND_REDFT01, R, 512>, a, g, stream);
 }
 int be_launch_blue(const BlueArgs &a, const LaunchGeom &g, void *stream) { return launch_blue(a, g, stream); }
 int be_launch_blue(const BlueArgsD &a, const LaunchGeom &g, void *stream) { return launch_blue(a, g, stream); }

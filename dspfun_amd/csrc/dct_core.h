@@ -538,7 +538,12 @@ typedef TinyArgsT<float> TinyArgs;
 typedef TinyArgsT<double> TinyArgsD;
 
 // cos(pi t / (2N)) for integer t, by the octant-reduced compile-time evaluation of radix.h
-template <int N> constexpr double tiny_cos(long t) { return ct::cossin(t, 4L * N).c; }
+template <int N>
+struct TinyCosTab {
+	double c[4 * N];
+	constexpr TinyCosTab() : c{} { for (int t = 0; t < 4 * N; t++) c[t] = ct::cossin(t, 4L * N).c; }
+};
+
 
 template <int N, int KIND, class R>
 DSP_HD void tiny_line(const TinyArgsT<R> &a, long long line)
@@ -550,26 +555,32 @@ DSP_HD void tiny_line(const TinyArgsT<R> &a, long long line)
 		bin += (long long)i * a.bis[d]; bout += (long long)i * a.bos[d];
 		rem = q;
 	}
-	R x[N];
-	static_for<0, N>([&](auto j) {
+	// plain loops, fully unrolled: after unrolling every index below is a constant, so x[] and y[] live in registers
+	// and the cosines fold into literals (the static_for form of this cost minutes of compile time per length)
+	constexpr TinyCosTab<N> tab = TinyCosTab<N>();
+	R x[N], y[N];
+#pragma unroll
+	for (int j = 0; j < N; j++) {
 		const long long off = bin + (long long)j * a.es_in;
 		const bool drop = a.mask && a.mask[a.mask_div.div((uint32_t)off)] != a.mask_id;
 		x[j] = drop ? R(0) : a.in[off];
-	});
+	}
 	x[0] *= a.in_scale0;
-	static_for<0, N>([&](auto k) {
-		R acc;
-		if constexpr (KIND == KIND_REDFT10) {
-			acc = R(0);
-			static_for<0, N>([&](auto j) { constexpr R c = (R)(2.0 * tiny_cos<N>((2L * j + 1) * k)); acc += x[j] * c; });
-		} else {
-			acc = x[0];
-			static_for<1, N>([&](auto j) { constexpr R c = (R)(2.0 * tiny_cos<N>((long)j * (2L * k + 1))); acc += x[j] * c; });
+#pragma unroll
+	for (int k = 0; k < N; k++) {
+		R acc = (KIND == KIND_REDFT10) ? R(0) : x[0];
+#pragma unroll
+		for (int j = (KIND == KIND_REDFT10 ? 0 : 1); j < N; j++) {
+			const int t = (KIND == KIND_REDFT10) ? ((2 * j + 1) * k) % (4 * N) : (j * (2 * k + 1)) % (4 * N);
+			acc += x[j] * (R)(2.0 * tab.c[t]);
 		}
-		const R r = acc * a.scale * (k == 0 ? a.out_scale0 : R(1));
+		y[k] = acc * a.scale * (k == 0 ? a.out_scale0 : R(1));
+	}
+#pragma unroll
+	for (int k = 0; k < N; k++) {
 		const long long off = bout + (long long)k * a.es_out;
-		if (a.accumulate) a.out[off] += r; else a.out[off] = r;
-	});
+		if (a.accumulate) a.out[off] += y[k]; else a.out[off] = y[k];
+	}
 }
 
 // ------------------------------------------------------------------------------------------------
