@@ -28,7 +28,7 @@ int be_launch_dense(const DenseArgs &a, const LaunchGeom &g, void *stream);
 int be_launch_row(const PassArgsD &a, const LaunchGeom &g, void *stream);
 int be_launch_col(const PassArgsD &a, const LaunchGeom &g, void *stream);
 int be_launch_dense(const DenseArgsD &a, const LaunchGeom &g, void *stream);
-// lengths 1..16: one line per thread, in registers
+// lengths 1..32: one line per thread, in registers
 int be_launch_tiny(const TinyArgs &a, void *stream);
 int be_launch_tiny(const TinyArgsD &a, void *stream);
 // COL pass with the tile's DFT done by Bluestein's convolution (lengths with prime factors > 13)

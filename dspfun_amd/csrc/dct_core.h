@@ -511,7 +511,7 @@ DSP_HD void blue_chirp_out(const BlueArgsT<R> &a, cx<R> *A, int tid, int nthr)
 }
 
 // ------------------------------------------------------------------------------------------------
-// TINY pass: lengths up to 16 (motion's small blocks, e.g. -b 8x8x8: motion/README.md "3-dimensional analog to
+// TINY pass: lengths up to 32 (motion's small blocks, e.g. -b 8x8x8: motion/README.md "3-dimensional analog to
 // JPEG-style compression").  A whole line lives in one thread's registers and is transformed by the definition with
 // compile-time cosines; no LDS, no barriers.  Lines are enumerated over up to six batch dimensions ordered by stride,
 // so neighbouring threads touch neighbouring memory.

@@ -283,7 +283,7 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 	char buf[256];
 
 	// ---------------- TINY ----------------
-	if (N <= 16 && !(env_int("DSPFFT_NO_TINY") == 1)) {
+	if (N <= 32 && !(env_int("DSPFFT_NO_TINY") == 1)) {
 		std::vector<Dim> d = others;
 		merge_dims(d);
 		long long nlines = 1;

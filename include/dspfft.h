@@ -76,7 +76,7 @@ int dspfft_execute_masked_accumulate_f64(dspfft_plan plan, const double *d_in, d
  * extent and input / output strides (in elements).  One plan then covers, e.g., all 8x8x8 blocks of a [D][H][W] volume
  * (motion --blocksize 8x8x8, motion/README.md): dims = {8,HW,HW},{8,W,W},{8,1,1}, howmany_dims =
  * {D/8,8HW,8HW},{H/8,8W,8W},{W/8,8,8}.  rank 1..3, howmany_rank 0..6; f64 != 0 selects double samples.  Lengths up to
- * 16 run one line per thread in registers. */
+ * 32 run one line per thread in registers. */
 typedef struct { int n; int is; int os; } dspfft_iodim;
 int dspfft_plan_guru_r2r(dspfft_plan *plan, int rank, const dspfft_iodim *dims, int howmany_rank, const dspfft_iodim *howmany_dims,
                          const int *kinds, int f64);

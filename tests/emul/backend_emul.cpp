@@ -113,6 +113,8 @@ static int emul_tiny(const TinyArgsT<R> &a)
 #define DSP_TINY_CASE(n) case n: return emul_tiny_n<n>(a);
 	DSP_TINY_CASE(1) DSP_TINY_CASE(2) DSP_TINY_CASE(3) DSP_TINY_CASE(4) DSP_TINY_CASE(5) DSP_TINY_CASE(6) DSP_TINY_CASE(7) DSP_TINY_CASE(8)
 	DSP_TINY_CASE(9) DSP_TINY_CASE(10) DSP_TINY_CASE(11) DSP_TINY_CASE(12) DSP_TINY_CASE(13) DSP_TINY_CASE(14) DSP_TINY_CASE(15) DSP_TINY_CASE(16)
+	DSP_TINY_CASE(17) DSP_TINY_CASE(18) DSP_TINY_CASE(19) DSP_TINY_CASE(20) DSP_TINY_CASE(21) DSP_TINY_CASE(22) DSP_TINY_CASE(23) DSP_TINY_CASE(24)
+	DSP_TINY_CASE(25) DSP_TINY_CASE(26) DSP_TINY_CASE(27) DSP_TINY_CASE(28) DSP_TINY_CASE(29) DSP_TINY_CASE(30) DSP_TINY_CASE(31) DSP_TINY_CASE(32)
 #undef DSP_TINY_CASE
 	default: return -1;
 	}

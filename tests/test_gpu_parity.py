@@ -355,7 +355,7 @@ def test_f64_c2_frame_roundtrip_with_spec_normalisation(gpu):
 
 
 # ---- lengths with prime factors > 13: Bluestein inside the column pass; the O(N^2) kernel only as the fallback ----
-@pytest.mark.parametrize("h,w,c", [(768, 1366, 3), (683, 1031, 1), (17, 40, 3), (1087, 1933, 3), (31, 2731, 1)])
+@pytest.mark.parametrize("h,w,c", [(768, 1366, 3), (683, 1031, 1), (37, 40, 3), (1087, 1933, 3), (41, 2731, 1)])
 @pytest.mark.parametrize("dtype", ["f32", "f64"])
 def test_bluestein_sizes_vs_oracle(gpu, h, w, c, dtype):
     from dspfun_amd import Plan

@@ -42,14 +42,15 @@ def test_describe_picks_row_and_col():
     p = Plan.image(48, 64, 3, REDFT10, lib=emul())
     d = p.describe()
     assert "ROW" in d and "COL" in d and "DENSE" not in d
-    p = Plan.image(17, 40, 3, REDFT10, lib=emul())   # 17 is a prime > 13 -> Bluestein along y, x still direct
+    p = Plan.image(37, 40, 3, REDFT10, lib=emul())   # 37 is a prime > 13 (and too long for the in-register pass) -> Bluestein along y, x still direct
     d = p.describe()
-    assert "BLUE" in d and "conv=35" in d and "ROW" in d and "DENSE" not in d
+    assert "BLUE" in d and "conv=75" in d and "ROW" in d and "DENSE" not in d
+    assert "TINY" in Plan.image(17, 40, 3, REDFT10, lib=emul()).describe()      # up to 32: one line per thread, any factorisation
     p = Plan.image(8, 1366, 3, REDFT10, lib=emul())   # 1366 = 2 x 683: 2880 = 12x15x16 beats the smaller 2744 = 7x7x7x8
     assert "BLUE N=1366" in p.describe() and "conv=2880" in p.describe()
     os.environ["DSPFFT_NO_BLUESTEIN"] = "1"
     try:
-        d = Plan.image(17, 40, 3, REDFT10, lib=emul()).describe()
+        d = Plan.image(37, 40, 3, REDFT10, lib=emul()).describe()
         assert "DENSE" in d and "ROW" in d
     finally:
         del os.environ["DSPFFT_NO_BLUESTEIN"]
@@ -140,12 +141,12 @@ def test_roundtrip_and_fused_spec_normalisation():
 def test_lds_pressure_paths(monkeypatch):
     # with a small LDS budget COL narrows its tile; a line that no longer fits the ROW pass goes to the column pass
     import ctypes as C, os
-    os.environ["DSPFFT_EMUL_LDS"] = "1100"   # the 64-pixel RGB line needs 32*3*8 = 768 B: still ROW; the 24-row tile shrinks to K=10
+    os.environ["DSPFFT_EMUL_LDS"] = "1100"   # the 64-pixel RGB line needs 32*3*8 = 768 B: still ROW; the 48-row tile shrinks to K=4
     try:
-        h, w, c = 24, 64, 3
+        h, w, c = 48, 64, 3
         x = ol.synth_f32(31, h * w * c).reshape(h, w, c)
         p = Plan.image(h, w, c, REDFT10, lib=emul())
-        assert "ROW" in p.describe() and "K=10" in p.describe()
+        assert "ROW" in p.describe() and "K=4" in p.describe()
         assert relerr(run(p, x.copy()), ol.dct2d_interleaved(x.astype(np.float64), REDFT10, impl="port")) < TOL
         os.environ["DSPFFT_EMUL_LDS"] = "700"
         p = Plan.image(h, w, c, REDFT10, lib=emul())
@@ -332,7 +333,7 @@ def test_f64_fused_scan_step_and_type_mismatch():
 
 
 # ---- lengths with prime factors > 13: Bluestein's convolution inside the column pass (and the O(N^2) fallback) ----
-@pytest.mark.parametrize("h,w,c", [(17, 40, 3), (6, 34, 3), (8, 1366, 3), (97, 6, 1), (5, 683, 1), (31, 31, 1), (19, 23, 2), (1, 17, 3), (29, 1, 1), (3, 2731, 1)])
+@pytest.mark.parametrize("h,w,c", [(37, 40, 3), (6, 34, 3), (8, 1366, 3), (97, 6, 1), (5, 683, 1), (41, 41, 1), (43, 47, 2), (1, 37, 3), (53, 1, 1), (3, 2731, 1)])
 @pytest.mark.parametrize("dtype", ["f32", "f64"])
 def test_bluestein_lengths(h, w, c, dtype):
     for kind in (REDFT10, REDFT01):
@@ -353,7 +354,7 @@ def test_bluestein_lengths(h, w, c, dtype):
 def test_bluestein_fused_scan_step_and_dense_fallback():
     """the fused masked/accumulating execution runs through the Bluestein pass unchanged; with the path disabled the
     O(N^2) kernel gives the same answer"""
-    h, w, c = 17, 46, 3
+    h, w, c = 37, 74, 3
     L = emul()
     x = ol.synth_f32(4, h * w * c).reshape(h, w, c)
     coeffs = x.copy()
@@ -534,8 +535,8 @@ def test_roundtrip_plan_shapes(shape):
             fwd.roundtrip(bad, got.ctypes.data)
 
 
-# ---- lengths up to 16 in registers (TINY) and the guru-shaped batch interface (motion --blocksize 8x8x8) ----
-@pytest.mark.parametrize("N", list(range(1, 17)))
+# ---- lengths up to 32 in registers (TINY) and the guru-shaped batch interface (motion --blocksize 8x8x8) ----
+@pytest.mark.parametrize("N", list(range(1, 33)))
 @pytest.mark.parametrize("dtype", ["f32", "f64"])
 def test_tiny_lengths(N, dtype):
     f64 = dtype == "f64"
