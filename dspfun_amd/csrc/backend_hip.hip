@@ -104,6 +104,19 @@ __global__ void __launch_bounds__(256) tiny_kernel(const TinyArgsT<R> a)
 	if (line < a.nlines) tiny_line<N, KIND>(a, line);
 }
 
+template <int N, int KIND, class R>
+__global__ void __launch_bounds__(TINY_CHUNK) tiny_row_kernel(const TinyArgsT<R> a)
+{
+	__shared__ R lds[TINY_CHUNK * tiny_pitch<N>()];
+	long long bin, bout; int cnt;
+	tiny_row_base(a, blockIdx.x, bin, bout, cnt);
+	tiny_row_load<N>(a, lds, bin, cnt, threadIdx.x, TINY_CHUNK);
+	__syncthreads();
+	tiny_row_compute<N, KIND>(a, lds, cnt, threadIdx.x);
+	__syncthreads();
+	tiny_row_store<N>(a, lds, bout, cnt, threadIdx.x, TINY_CHUNK);
+}
+
 template <class R>
 __global__ void __launch_bounds__(256) dense_kernel(const DenseArgsT<R> a)
 {
@@ -217,6 +230,15 @@ int be_launch_blue(const BlueArgsD &a, const LaunchGeom &g, void *stream) { retu
 template <int N, class R>
 static int launch_tiny_n(const TinyArgsT<R> &a, void *stream)
 {
+	if (a.packed) {
+		long long rest = 1;
+		for (int d = 1; d < a.nd; d++) rest *= a.bn[d];
+		const unsigned grid = (unsigned)(rest * a.chunk_div.d);
+		if (a.kind == KIND_REDFT10) hipLaunchKernelGGL((tiny_row_kernel<N, KIND_REDFT10, R>), dim3(grid), dim3(TINY_CHUNK), 0, (hipStream_t)stream, a);
+		else hipLaunchKernelGGL((tiny_row_kernel<N, KIND_REDFT01, R>), dim3(grid), dim3(TINY_CHUNK), 0, (hipStream_t)stream, a);
+		HIPCHK(hipGetLastError());
+		return 0;
+	}
 	const unsigned grid = (unsigned)((a.nlines + 255) / 256);
 	if (a.kind == KIND_REDFT10) hipLaunchKernelGGL((tiny_kernel<N, KIND_REDFT10, R>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
 	else hipLaunchKernelGGL((tiny_kernel<N, KIND_REDFT01, R>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);

@@ -523,6 +523,8 @@ struct TinyGeom {
 	long long bis[6], bos[6];
 	FastDiv bdiv[6];
 	long long nlines;
+	int packed;                               // lines lie back to back (dimension 0 has stride N): chunked through LDS
+	FastDiv chunk_div;                        // chunks per run of dimension 0
 	const uint32_t *mask;
 	uint32_t mask_id;
 	FastDiv mask_div;
@@ -545,26 +547,13 @@ struct TinyCosTab {
 };
 
 
+// y = transform of x by the definition, scaled.  Plain loops, fully unrolled: after unrolling every index is a
+// constant, so x[] and y[] live in registers and the cosines fold into literals (a static_for form of this cost
+// minutes of compile time per length).
 template <int N, int KIND, class R>
-DSP_HD void tiny_line(const TinyArgsT<R> &a, long long line)
+DSP_HD void tiny_dct(const TinyArgsT<R> &a, R *x, R *y)
 {
-	long long bin = 0, bout = 0;
-	uint32_t rem = (uint32_t)line;            // nlines < 2^31 (planner)
-	for (int d = 0; d < a.nd; d++) {
-		const uint32_t q = a.bdiv[d].div_exact(rem), i = rem - q * (uint32_t)a.bn[d];
-		bin += (long long)i * a.bis[d]; bout += (long long)i * a.bos[d];
-		rem = q;
-	}
-	// plain loops, fully unrolled: after unrolling every index below is a constant, so x[] and y[] live in registers
-	// and the cosines fold into literals (the static_for form of this cost minutes of compile time per length)
 	constexpr TinyCosTab<N> tab = TinyCosTab<N>();
-	R x[N], y[N];
-#pragma unroll
-	for (int j = 0; j < N; j++) {
-		const long long off = bin + (long long)j * a.es_in;
-		const bool drop = a.mask && a.mask[a.mask_div.div((uint32_t)off)] != a.mask_id;
-		x[j] = drop ? R(0) : a.in[off];
-	}
 	x[0] *= a.in_scale0;
 #pragma unroll
 	for (int k = 0; k < N; k++) {
@@ -576,11 +565,85 @@ DSP_HD void tiny_line(const TinyArgsT<R> &a, long long line)
 		}
 		y[k] = acc * a.scale * (k == 0 ? a.out_scale0 : R(1));
 	}
+}
+
+// base offsets of batch element `idx` over dimensions [d0, nd)
+template <class R>
+DSP_HD void tiny_base(const TinyArgsT<R> &a, uint32_t idx, int d0, long long &bin, long long &bout)
+{
+	bin = 0; bout = 0;
+	for (int d = d0; d < a.nd; d++) {
+		const uint32_t q = a.bdiv[d].div_exact(idx), i = idx - q * (uint32_t)a.bn[d];
+		bin += (long long)i * a.bis[d]; bout += (long long)i * a.bos[d];
+		idx = q;
+	}
+}
+
+// strided lines: thread = line; neighbouring threads are neighbouring lines of the smallest-stride batch dimension
+template <int N, int KIND, class R>
+DSP_HD void tiny_line(const TinyArgsT<R> &a, long long line)
+{
+	long long bin, bout;
+	tiny_base(a, (uint32_t)line, 0, bin, bout);      // nlines < 2^31 (planner)
+	R x[N], y[N];
+#pragma unroll
+	for (int j = 0; j < N; j++) {
+		const long long off = bin + (long long)j * a.es_in;
+		const bool drop = a.mask && a.mask[a.mask_div.div((uint32_t)off)] != a.mask_id;
+		x[j] = drop ? R(0) : a.in[off];
+	}
+	tiny_dct<N, KIND>(a, x, y);
 #pragma unroll
 	for (int k = 0; k < N; k++) {
 		const long long off = bout + (long long)k * a.es_out;
 		if (a.accumulate) a.out[off] += y[k]; else a.out[off] = y[k];
 	}
+}
+
+// contiguous lines packed back to back (batch dimension 0 has stride N, e.g. the x axis of motion's blocks): a
+// workgroup moves a chunk of TINY_CHUNK lines = TINY_CHUNK*N consecutive samples through LDS so that global accesses
+// are element-contiguous across the wave; line pitch N|1 (odd) keeps the per-thread LDS accesses conflict-free
+enum { TINY_CHUNK = 256 };
+template <int N> constexpr int tiny_pitch() { return N | 1; }
+
+template <int N, class R>
+DSP_HD void tiny_row_load(const TinyArgsT<R> &a, R *lds, long long bin, int cnt, int tid, int nthr)
+{
+	for (int e = tid; e < cnt * N; e += nthr) {
+		const long long off = bin + e;
+		const bool drop = a.mask && a.mask[a.mask_div.div((uint32_t)off)] != a.mask_id;
+		lds[(e / N) * tiny_pitch<N>() + e % N] = drop ? R(0) : a.in[off];
+	}
+}
+template <int N, int KIND, class R>
+DSP_HD void tiny_row_compute(const TinyArgsT<R> &a, R *lds, int cnt, int tid)
+{
+	if (tid >= cnt) return;
+	R x[N], y[N];
+	R *p = lds + tid * tiny_pitch<N>();
+#pragma unroll
+	for (int j = 0; j < N; j++) x[j] = p[j];
+	tiny_dct<N, KIND>(a, x, y);
+#pragma unroll
+	for (int k = 0; k < N; k++) p[k] = y[k];
+}
+template <int N, class R>
+DSP_HD void tiny_row_store(const TinyArgsT<R> &a, const R *lds, long long bout, int cnt, int tid, int nthr)
+{
+	for (int e = tid; e < cnt * N; e += nthr) {
+		const R v = lds[(e / N) * tiny_pitch<N>() + e % N];
+		if (a.accumulate) a.out[bout + e] += v; else a.out[bout + e] = v;
+	}
+}
+// workgroup -> (chunk of dimension 0, element of the remaining dimensions)
+template <class R>
+DSP_HD void tiny_row_base(const TinyArgsT<R> &a, uint32_t wg, long long &bin, long long &bout, int &cnt)
+{
+	const uint32_t r = a.chunk_div.div_exact(wg), c = wg - r * a.chunk_div.d;
+	tiny_base(a, r, 1, bin, bout);
+	bin += (long long)c * TINY_CHUNK * a.N; bout += (long long)c * TINY_CHUNK * a.N;
+	cnt = a.bn[0] - (int)c * TINY_CHUNK;
+	if (cnt > TINY_CHUNK) cnt = TINY_CHUNK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -293,9 +293,12 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 			memset(&tg, 0, sizeof tg);
 			tg.N = N; tg.kind = kind; tg.es_in = ax.is; tg.es_out = ax.os; tg.nd = (int)d.size(); tg.nlines = nlines;
 			for (size_t i = 0; i < d.size(); i++) { tg.bn[i] = d[i].n; tg.bis[i] = d[i].is; tg.bos[i] = d[i].os; tg.bdiv[i] = make_div((uint32_t)d[i].n); }
+			// contiguous lines packed back to back: element-contiguous global access through LDS chunks
+			tg.packed = d.size() >= 1 && ax.is == 1 && ax.os == 1 && d[0].is == N && d[0].os == N;
+			tg.chunk_div = make_div((uint32_t)(tg.packed ? (d[0].n + TINY_CHUNK - 1) / TINY_CHUNK : 1));
 			P.type = Pass::TINY;
 			P.g.nwg = (int)((nlines + 255) / 256); P.g.nthr = 256; P.g.lds_bytes = 0;
-			snprintf(buf, sizeof buf, "axis %d: TINY%s N=%d lines=%lld dims=%d", a, tag, N, nlines, tg.nd);
+			snprintf(buf, sizeof buf, "axis %d: TINY%s N=%d lines=%lld dims=%d%s", a, tag, N, nlines, tg.nd, tg.packed ? " packed" : "");
 			P.desc = buf;
 			return 0;
 		}

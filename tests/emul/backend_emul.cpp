@@ -101,6 +101,21 @@ int be_launch_blue(const BlueArgsD &a, const LaunchGeom &g, void *) { return emu
 template <int N, class R>
 static int emul_tiny_n(const TinyArgsT<R> &a)
 {
+	if (a.packed) {
+		long long rest = 1;
+		for (int d = 1; d < a.nd; d++) rest *= a.bn[d];
+		std::vector<R> lds((size_t)TINY_CHUNK * tiny_pitch<N>());
+		for (long long wg = 0; wg < rest * a.chunk_div.d; wg++) {
+			long long bin, bout; int cnt;
+			tiny_row_base(a, (uint32_t)wg, bin, bout, cnt);
+			for (int tid = 0; tid < TINY_CHUNK; tid++) tiny_row_load<N>(a, lds.data(), bin, cnt, tid, TINY_CHUNK);
+			for (int tid = 0; tid < TINY_CHUNK; tid++) {
+				if (a.kind == KIND_REDFT10) tiny_row_compute<N, KIND_REDFT10>(a, lds.data(), cnt, tid); else tiny_row_compute<N, KIND_REDFT01>(a, lds.data(), cnt, tid);
+			}
+			for (int tid = 0; tid < TINY_CHUNK; tid++) tiny_row_store<N>(a, lds.data(), bout, cnt, tid, TINY_CHUNK);
+		}
+		return 0;
+	}
 	for (long long line = 0; line < a.nlines; line++) {
 		if (a.kind == KIND_REDFT10) tiny_line<N, KIND_REDFT10>(a, line); else tiny_line<N, KIND_REDFT01>(a, line);
 	}

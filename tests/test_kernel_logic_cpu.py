@@ -602,3 +602,23 @@ def test_guru_rejects_bad_arguments_and_tiny_fused_scan():
     for f in range(4):
         inv.execute_masked_accumulate(coeffs.ctypes.data, work.ctypes.data, acc.ctypes.data, ids.ctypes.data, f, c)
     assert np.abs(acc - x).max() < 1e-5
+
+
+@pytest.mark.parametrize("N,lines", [(8, 600), (5, 257), (32, 300), (16, 256)])
+def test_tiny_packed_lines_many_chunks(N, lines):
+    """contiguous lines back to back go through LDS in chunks of 256 lines; several chunks and a ragged tail"""
+    x = ol.synth_f32(N * 3 + lines, N * lines).reshape(lines, N)
+    for kind in (REDFT10, REDFT01):
+        p = Plan.many_r2r([N], [kind], howmany=lines, idist=N, odist=N, lib=emul())
+        assert "packed" in p.describe()
+        ref = ol.r2r_many(x.astype(np.float64).ravel(), [N], [kind], howmany=lines, idist=N, odist=N).reshape(lines, N)
+        assert relerr(run(p, x.copy()), ref) < 1e-6
+    # two batch levels: 3 separate runs of `lines` packed lines each, with a gap between runs
+    buf = ol.synth_f32(9, 3 * (N * lines + 7)).reshape(3, N * lines + 7)
+    p = Plan.guru([(N, 1, 1)], [(lines, N, N), (3, N * lines + 7, N * lines + 7)], [REDFT10], lib=emul())
+    assert "packed" in p.describe()
+    got = buf.copy(); p.execute(got.ctypes.data)
+    for r in range(3):
+        ref = ol.r2r_many(buf[r, :N * lines].astype(np.float64).copy(), [N], [REDFT10], howmany=lines, idist=N, odist=N)
+        assert relerr(got[r, :N * lines], ref) < 1e-6
+        assert np.array_equal(got[r, N * lines:], buf[r, N * lines:])
