@@ -209,7 +209,7 @@ def main():
             "config": {"workload": "spec + ispec roundtrip on 3840x2160 RGB float32 (BASELINE configs[1])",
                        "frames_per_gpu_per_step": args.frames, "hip_streams": nstreams, "layout": "interleaved HWC, in place, device-resident",
                        "parallelism": f"frame-sharded x{world}, no collective"},
-            "roundtrip_frac_of_hbm_roofline": round(value * 1e6 * ALG_BYTES_PER_PIXEL / HBM_PEAK, 4),
+            "roundtrip_frac_of_hbm_roofline": round(value * 1e6 * ALG_BYTES_PER_PIXEL / (HBM_PEAK * world), 4),      # per GPU
             "max_abs_drift_after_all_roundtrips": drift,
             "roofline": roof,
         }
