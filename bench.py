@@ -74,8 +74,8 @@ def cpu_baseline(max_seconds=30.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--frames", type=int, default=4, help="independent frames per GPU per step")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("BENCH_STREAMS", "2")), help="HIP streams the independent frames are spread over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
