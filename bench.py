@@ -117,42 +117,44 @@ def main():
 
     passes = [(fwd, i) for i in range(fwd.num_passes)] + [(inv, i) for i in range(inv.num_passes)]
     npass = len(passes)
-    # HIP events bracket every launch that touches frame 0 inside the timed region (on the stream the
-    # kernel is launched on) -> average in-region duration per kernel for the roofline object
+    # HIP events bracket the launches of ONE frame per step inside the timed region (on the stream the kernel is
+    # launched on), rotating through the frames of the step, so the in-region average per kernel samples every
+    # position in the step -- the population rocprofv3 averages -- at a quarter of the event traffic (events on every
+    # launch were measured to cost 7 % of the throughput)
     ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(npass)] for _ in range(args.steps)]
     tstreams = side if side else [torch.cuda.current_stream()]
 
     # Two schedules for the frames of a step on two streams.  "free": each stream runs its frames back to back.
-    # "aligned" (default): the streams start every frame together (each waits for the other's previous frame), so
-    # kernels of the same pass shape overlap.  Measured on this pool's MI355X boxes: free-running reaches 54K Mpix/s
-    # while the two streams sit in a favourable interleave, but falls to 42-44K (no better than one stream) when they
-    # drift into an unfavourable one -- per box, per process and sometimes within a run; aligned gives 50.3-50.8K
-    # every time.  "auto" times both for a moment (untimed) and keeps the faster.
+    # "aligned" (default): the streams start every STEP together (each waits for the other's previous step), which
+    # keeps kernels of the same pass shape overlapping.  Measured on this pool's MI355X boxes: free-running reaches
+    # 53-54K Mpix/s while the two streams sit in a favourable interleave, but falls to 42-44K (no better than one
+    # stream) when they drift into an unfavourable one -- per box, per process and sometimes within a run; aligned
+    # gives 50-51K every time.  "auto" times both for a moment (untimed) and keeps the faster.
     sched = {"aligned": False, "last": [None] * max(1, nstreams)}
 
     def step(k=None):
+        if sched["aligned"]:
+            # the streams start the step together: each waits for the others' work of the previous step
+            for a_ in range(len(side)):
+                for b_ in range(len(side)):
+                    if a_ != b_ and sched["last"][b_] is not None:
+                        side[a_].wait_event(sched["last"][b_])
         for i, p in enumerate(ptrs):
-            si = i % len(handles)
-            h_ = handles[si]
-            if sched["aligned"] and si == 0:
-                # a new round of frames (one per stream) begins: every stream waits for all streams' previous frames
-                for a_ in range(len(side)):
-                    for b_ in range(len(side)):
-                        if a_ != b_ and sched["last"][b_] is not None:
-                            side[a_].wait_event(sched["last"][b_])
-            if k is None or i != 0:
+            h_ = handles[i % len(handles)]
+            if k is None or i != k % len(ptrs):
                 fwd.execute(p, stream=h_)
                 inv.execute(p, stream=h_)
             else:
-                ts = tstreams[0]
+                ts = tstreams[i % len(tstreams)]
                 for j, (plan, idx) in enumerate(passes):
                     ev[k][j][0].record(ts)
                     plan.execute_pass(idx, p, stream=h_)
                     ev[k][j][1].record(ts)
-            if sched["aligned"]:
+        if sched["aligned"]:
+            for a_ in range(len(side)):
                 e_ = torch.cuda.Event()
-                e_.record(side[si])
-                sched["last"][si] = e_
+                e_.record(side[a_])
+                sched["last"][a_] = e_
 
     schedule = "single stream" if nstreams == 1 else "free"
     if nstreams == 2 and args.schedule == "auto":
@@ -170,10 +172,10 @@ def main():
         t_free, t_al = min(trial(False), trial(False)), min(trial(True), trial(True))
         sched["aligned"] = t_al < t_free
         sched["last"] = [None] * nstreams
-        schedule = "frame-aligned" if sched["aligned"] else "free"
+        schedule = "step-aligned" if sched["aligned"] else "free"
     elif nstreams >= 2 and args.schedule == "aligned":
         sched["aligned"] = True
-        schedule = "frame-aligned"
+        schedule = "step-aligned"
 
     def barrier():
         torch.cuda.synchronize()
