@@ -120,11 +120,12 @@ DSP_HD R masked(const PassArgsT<R> &a, long long off, R v)
 	if (!a.mask) return v;
 	return a.mask[a.mask_div.div((uint32_t)off)] != a.mask_id ? R(0) : v;
 }
-// a.in[off] under the mask, without fetching elements that are masked out
-template <class R>
+// a.in[off] under the mask, without fetching elements that are masked out.  MASKED is chosen once per phase (a.mask
+// is uniform): a test around every load would make each load wait for its data before the next one is issued
+template <bool MASKED, class R>
 DSP_HD R load_masked(const PassArgsT<R> &a, long long off)
 {
-	if (a.mask && a.mask[a.mask_div.div((uint32_t)off)] != a.mask_id) return R(0);
+	if constexpr (MASKED) { if (a.mask[a.mask_div.div((uint32_t)off)] != a.mask_id) return R(0); }
 	return a.in[off];
 }
 
@@ -244,18 +245,24 @@ DSP_HD void row_put(const PassArgsT<R> &a, long long off, R v)
 }
 
 // REDFT10: pixels in memory order -> even/odd reordered, packed two reals per complex slot
-template <class R>
-DSP_HD void row_load10(const PassArgsT<R> &a, cx<R> *buf, long long bin, int tid, int nthr)
+template <bool MASKED, class R>
+DSP_HD void row_load10_m(const PassArgsT<R> &a, cx<R> *buf, long long bin, int tid, int nthr)
 {
 	const int N = a.N, C = a.C;
 	R *bf = reinterpret_cast<R *>(buf);
 	for (int it = tid; it < N * C; it += nthr) {
 		const int x = (int)a.divB.div((uint32_t)it), s = it - x * C;
-		R v = load_masked(a, bin + it);
+		R v = load_masked<MASKED>(a, bin + it);
 		if (x == 0) v *= a.in_scale0;
 		const int n = makhoul_dst(x, N);
 		bf[2 * ((n >> 1) * C + s) + (n & 1)] = v;
 	}
+}
+
+template <class R>
+DSP_HD void row_load10(const PassArgsT<R> &a, cx<R> *buf, long long bin, int tid, int nthr)
+{
+	if (a.mask) row_load10_m<true>(a, buf, bin, tid, nthr); else row_load10_m<false>(a, buf, bin, tid, nthr);
 }
 
 // REDFT10: FFT output -> 4 real outputs per (k, L-k) pair, stored
@@ -293,8 +300,8 @@ DSP_HD void row_post10(const PassArgsT<R> &a, const cx<R> *buf, long long bout, 
 }
 
 // REDFT01: natural-order input -> conj of the half-length spectrum in buf
-template <class R>
-DSP_HD void row_load01(const PassArgsT<R> &a, cx<R> *buf, long long bin, int tid, int nthr)
+template <bool MASKED, class R>
+DSP_HD void row_load01_m(const PassArgsT<R> &a, cx<R> *buf, long long bin, int tid, int nthr)
 {
 	typedef cx<R> C_;
 	const int L = a.N / 2, C = a.C, N = a.N;
@@ -302,7 +309,7 @@ DSP_HD void row_load01(const PassArgsT<R> &a, cx<R> *buf, long long bin, int tid
 	for (int it = tid; it < nk * C; it += nthr) {
 		const int k = (int)a.divB.div((uint32_t)it), s = it - k * C;
 		const long long o = bin + s;
-		auto ld = [&](int px) { return load_masked(a, o + (long long)px * C); };
+		auto ld = [&](int px) { return load_masked<MASKED>(a, o + (long long)px * C); };
 		const R xk = ld(k) * (k == 0 ? a.in_scale0 : R(1));
 		const R xnk = k ? ld(N - k) : R(0);
 		const R xlk = ld(L - k);
@@ -319,6 +326,12 @@ DSP_HD void row_load01(const PassArgsT<R> &a, cx<R> *buf, long long bin, int tid
 		buf[k * C + s] = cconj(cadd(S, Q));
 		if (k > 0) buf[(L - k) * C + s] = csub(S, Q);
 	}
+}
+
+template <class R>
+DSP_HD void row_load01(const PassArgsT<R> &a, cx<R> *buf, long long bin, int tid, int nthr)
+{
+	if (a.mask) row_load01_m<true>(a, buf, bin, tid, nthr); else row_load01_m<false>(a, buf, bin, tid, nthr);
 }
 
 // REDFT01: FFT output -> time samples in memory order
