@@ -778,7 +778,14 @@ int roundtrip_core(dspfft_plan fwd, dspfft_plan inv, const float *d_in, float *d
 		}
 		if (int rc = run_pass<float>(inv, P, (const float *)d_out, d_out, i + 1 == ni, stream)) return rc;
 	}
-	if (d_out8 && be_f32_to_u8(d_out8, d_out, mul8, (uint64_t)span, stream)) return fail(-4, "launch failed");
+	if (d_out8) {
+		// no planar specialised row pass at the end: one sweep over the whole span, which must then hold nothing but samples
+		long long dense = 1;
+		for (int a = 0; a < fwd->rank; a++) dense *= fwd->n[a];
+		for (const Dim &b : fwd->batches) dense *= b.n;
+		if (dense != span) return fail(-2, "8-bit output without a planar specialised row pass needs a dense work layout");
+		if (be_f32_to_u8(d_out8, d_out, mul8, (uint64_t)span, stream)) return fail(-4, "launch failed");
+	}
 	return 0;
 }
 }  // namespace
