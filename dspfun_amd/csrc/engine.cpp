@@ -740,6 +740,13 @@ int roundtrip_core(dspfft_plan fwd, dspfft_plan inv, const float *d_in, float *d
 		long long ispan = 1;
 		for (int a = 0; a < fwd->rank; a++) ispan += (long long)(fwd->n[a] - 1) * fwd->axes[a].is;
 		for (const Dim &b : fwd->batches) ispan += (long long)(b.n - 1) * b.is;
+		if (d_out8 && !pass_has_u8(inv->passes[ni - 1])) {
+			// the output conversion will be one sweep over the whole span, which must then hold nothing but samples
+			long long dense = 1;
+			for (int a = 0; a < fwd->rank; a++) dense *= fwd->n[a];
+			for (const Dim &b : fwd->batches) dense *= b.n;
+			if (dense != span) return fail(-2, "8-bit output without a planar specialised row pass needs a dense work layout");
+		}
 		if (d_in8 && !pass_has_u8(fwd->passes[0])) {
 			if (ispan != span) return fail(-2, "8-bit input without a planar specialised row pass needs identical input and work layouts");
 			if (be_u8_to_f32(d_out, d_in8, (uint64_t)span, stream)) return fail(-4, "launch failed");
@@ -778,14 +785,7 @@ int roundtrip_core(dspfft_plan fwd, dspfft_plan inv, const float *d_in, float *d
 		}
 		if (int rc = run_pass<float>(inv, P, (const float *)d_out, d_out, i + 1 == ni, stream)) return rc;
 	}
-	if (d_out8) {
-		// no planar specialised row pass at the end: one sweep over the whole span, which must then hold nothing but samples
-		long long dense = 1;
-		for (int a = 0; a < fwd->rank; a++) dense *= fwd->n[a];
-		for (const Dim &b : fwd->batches) dense *= b.n;
-		if (dense != span) return fail(-2, "8-bit output without a planar specialised row pass needs a dense work layout");
-		if (be_f32_to_u8(d_out8, d_out, mul8, (uint64_t)span, stream)) return fail(-4, "launch failed");
-	}
+	if (d_out8 && be_f32_to_u8(d_out8, d_out, mul8, (uint64_t)span, stream)) return fail(-4, "launch failed");    // no fused store: one sweep
 	return 0;
 }
 }  // namespace
