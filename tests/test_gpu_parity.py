@@ -726,6 +726,44 @@ def test_guru_blocks_of_a_volume(gpu, block, dtype):
         check(gb, ref, tol=1e-13 if f64 else TOL)
 
 
+@pytest.mark.parametrize("seed", range(40))
+def test_random_advanced_interface_geometries(gpu, seed):
+    """random rank / n / howmany / stride / dist / embed, in and out of place, f32 and f64, against the definition"""
+    from dspfun_amd import Plan
+    import test_kernel_logic_cpu as tk
+    rng = np.random.default_rng(5000 + seed)
+    rank, n, howmany, embed, stride, dist, total, kinds = tk._random_case(rng)
+    f64 = bool(seed % 3 == 0)
+    oop = bool(rng.integers(0, 2))
+    x = ol.synth_f32(seed + 1, total)
+    x = x.astype(np.float64) if f64 else x
+    ref_full = ol.r2r_many(x.astype(np.float64), n, kinds, howmany=howmany, inembed=embed, istride=stride, idist=dist,
+                           onembed=embed, ostride=stride, odist=dist)
+    p = Plan.many_r2r(n, kinds, howmany=howmany, inembed=embed, istride=stride, idist=dist, onembed=embed, ostride=stride, odist=dist,
+                      dtype="f64" if f64 else "f32")
+    src = gpu.from_numpy(x.copy()).to("cuda:0")
+    if oop:
+        out = gpu.full((total,), 7.0, dtype=src.dtype, device="cuda:0")
+        p.execute(src.data_ptr(), out.data_ptr())
+        gpu.cuda.synchronize()
+        assert np.array_equal(src.cpu().numpy(), x)
+        got, ref = out.cpu().numpy(), np.full(total, 7.0)
+    else:
+        p.execute(src.data_ptr())
+        gpu.cuda.synchronize()
+        got, ref = src.cpu().numpy(), x.astype(np.float64).copy()
+    idx = np.zeros(1, dtype=np.int64)
+    mult = stride
+    for a in range(rank - 1, -1, -1):
+        idx = (idx[None, :] + (np.arange(n[a]) * mult)[:, None]).ravel()
+        mult *= embed[a]
+    idx = (idx[None, :] + (np.arange(howmany) * dist)[:, None]).ravel()
+    ref[idx] = ref_full[idx]
+    tol = 5e-13 if f64 else 3e-6
+    scale = max(np.abs(ref_full[idx]).max(), 1e-30)
+    assert np.abs(got.astype(np.float64) - ref).max() <= tol * scale, (n, howmany, embed, stride, dist, kinds, oop, p.describe())
+
+
 def test_scan_pruned_idct_path(gpu):
     """scan.c:20-41,449: few coefficients per frame -> direct rank-1 sums; against the restatement and against the
     transform path (dspfft_execute_masked_accumulate) on the same frames"""

@@ -622,3 +622,61 @@ def test_tiny_packed_lines_many_chunks(N, lines):
         ref = ol.r2r_many(buf[r, :N * lines].astype(np.float64).copy(), [N], [REDFT10], howmany=lines, idist=N, odist=N)
         assert relerr(got[r, :N * lines], ref) < 1e-6
         assert np.array_equal(got[r, N * lines:], buf[r, N * lines:])
+
+
+# ---- randomised geometries: FFTW's advanced interface (rank, n, howmany, stride, dist, embed; in or out of place) ----
+def _random_case(rng):
+    rank = int(rng.integers(1, 4))
+    n = [int(rng.choice([1, 2, 3, 4, 5, 6, 8, 9, 12, 16, 17, 20, 33, 34, 36, 37, 40, 48, 74])) for _ in range(rank)]
+    while np.prod(n) > 40000:
+        n[int(rng.integers(0, rank))] = int(rng.choice([2, 3, 4, 6, 8]))
+    layout = rng.choice(["planar", "interleaved"])
+    howmany = int(rng.choice([1, 2, 3, 4, 5]))
+    embed = [v + int(rng.choice([0, 0, 1, 3])) for v in n]
+    embed[0] = n[0]                                            # FFTW ignores embed[0] beyond sizing
+    if layout == "interleaved":
+        stride, dist = howmany, 1
+        total = int(np.prod(embed)) * howmany
+    else:
+        stride = 1
+        dist = int(np.prod(embed)) + int(rng.choice([0, 0, 5]))
+        total = dist * howmany
+    kinds = [int(rng.choice([REDFT10, REDFT01])) for _ in range(rank)]
+    return rank, n, howmany, embed, stride, dist, total, kinds
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_advanced_interface_geometries(seed):
+    rng = np.random.default_rng(1000 + seed)
+    rank, n, howmany, embed, stride, dist, total, kinds = _random_case(rng)
+    f64 = bool(seed % 3 == 0)
+    oop = bool(rng.integers(0, 2))
+    x = ol.synth_f32(seed + 1, total)
+    x = x.astype(np.float64) if f64 else x
+    ref_full = ol.r2r_many(x.astype(np.float64), n, kinds, howmany=howmany, inembed=embed, istride=stride, idist=dist,
+                           onembed=embed, ostride=stride, odist=dist)
+    p = Plan.many_r2r(n, kinds, howmany=howmany, inembed=embed, istride=stride, idist=dist, onembed=embed, ostride=stride, odist=dist,
+                      lib=emul(), dtype="f64" if f64 else "f32")
+    if oop:
+        out = np.full(total, 7.0, dtype=x.dtype)
+        src = x.copy()
+        p.execute(src.ctypes.data, out.ctypes.data)
+        assert np.array_equal(src, x), p.describe()
+        got = out
+        # positions the transform does not own keep the output buffer's previous content
+        ref = np.full(total, 7.0)
+    else:
+        got = x.copy()
+        p.execute(got.ctypes.data)
+        ref = x.astype(np.float64).copy()
+    # element offsets the plan owns
+    idx = np.zeros(1, dtype=np.int64)
+    mult = stride
+    for a in range(rank - 1, -1, -1):
+        idx = (idx[None, :] + (np.arange(n[a]) * mult)[:, None]).ravel()
+        mult *= embed[a]
+    idx = (idx[None, :] + (np.arange(howmany) * dist)[:, None]).ravel()
+    ref[idx] = ref_full[idx]
+    tol = 5e-13 if f64 else 3e-6
+    scale = max(np.abs(ref_full[idx]).max(), 1e-30)
+    assert np.abs(got.astype(np.float64) - ref).max() <= tol * scale, (n, howmany, embed, stride, dist, kinds, oop, p.describe())
