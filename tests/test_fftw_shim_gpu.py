@@ -262,3 +262,47 @@ def test_scan_harness_other_methods(tmp_path, method, step):
     _write_ppm(ppm, img)
     subprocess.run([os.path.join(ROOT, "host", "scan_gpu"), str(ppm), str(out), str(step), method], stderr=subprocess.PIPE, check=True)
     assert np.abs(_read_pf(out) - img.astype(np.float64) / 255.0).max() <= 5e-6
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_geometries_on_host_pointers(fftw, seed):
+    """random advanced-interface geometries through fftwf_/fftw_plan_many_r2r on pinned host arrays: the owned elements
+    match the definition, everything else in the arrays is left as it was"""
+    import test_kernel_logic_cpu as tk
+    rng = np.random.default_rng(7000 + seed)
+    rank, n, howmany, embed, stride, dist, total, kinds = tk._random_case(rng)
+    f64 = bool(seed % 2)
+    oop = bool(rng.integers(0, 2))
+    dt = np.float64 if f64 else np.float32
+    alloc, free_ = (fftw.fftw_alloc_real, fftw.fftw_free) if f64 else (fftw.fftwf_alloc_real, fftw.fftwf_free)
+    mk, ex, kill = (fftw.fftw_plan_many_r2r, fftw.fftw_execute, fftw.fftw_destroy_plan) if f64 else (fftw.fftwf_plan_many_r2r, fftw.fftwf_execute, fftw.fftwf_destroy_plan)
+    x = ol.synth_f32(seed + 11, total).astype(dt)
+    pin = alloc(total)
+    a = _host_array(pin, total, dt)
+    a[:] = x
+    if oop:
+        pout = alloc(total)
+        b = _host_array(pout, total, dt)
+        b[:] = 7
+    else:
+        pout, b = pin, a
+    plan = mk(rank, _ia(n), howmany, pin, _ia(embed), stride, dist, pout, _ia(embed), stride, dist, _ia(kinds), 1 << 6)
+    assert plan
+    ex(plan)
+    ref_full = ol.r2r_many(x.astype(np.float64), n, kinds, howmany=howmany, inembed=embed, istride=stride, idist=dist, onembed=embed, ostride=stride, odist=dist)
+    idx = np.zeros(1, dtype=np.int64)
+    mult = stride
+    for ax in range(rank - 1, -1, -1):
+        idx = (idx[None, :] + (np.arange(n[ax]) * mult)[:, None]).ravel()
+        mult *= embed[ax]
+    idx = (idx[None, :] + (np.arange(howmany) * dist)[:, None]).ravel()
+    ref = np.full(total, 7.0) if oop else x.astype(np.float64).copy()
+    ref[idx] = ref_full[idx]
+    if oop:
+        assert np.array_equal(a, x)
+    scale = max(np.abs(ref_full[idx]).max(), 1e-30)
+    assert np.abs(b.astype(np.float64) - ref).max() <= (5e-13 if f64 else 3e-6) * scale, (n, howmany, embed, stride, dist, kinds, oop)
+    kill(plan)
+    free_(pin)
+    if oop:
+        free_(pout)

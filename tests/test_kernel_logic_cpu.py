@@ -680,3 +680,39 @@ def test_random_advanced_interface_geometries(seed):
     tol = 5e-13 if f64 else 3e-6
     scale = max(np.abs(ref_full[idx]).max(), 1e-30)
     assert np.abs(got.astype(np.float64) - ref).max() <= tol * scale, (n, howmany, embed, stride, dist, kinds, oop, p.describe())
+
+
+def _oracle_along_axis(arr, axis, kind):
+    """the definition along one axis of a dense float64 array"""
+    moved = np.ascontiguousarray(np.moveaxis(arr, axis, -1))
+    n = moved.shape[-1]
+    lines = moved.reshape(-1, n)
+    out = ol.r2r_many(lines.ravel(), [n], [kind], howmany=lines.shape[0], idist=n, odist=n).reshape(moved.shape)
+    return np.moveaxis(out, -1, axis)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_guru_geometries(seed):
+    """guru-shaped plans on a dense array: a random subset of 1..3 axes is transformed, the rest are batch dimensions"""
+    rng = np.random.default_rng(9000 + seed)
+    nd = int(rng.integers(2, 6))
+    shape = [int(rng.choice([1, 2, 3, 4, 5, 6, 8, 12, 16, 20, 33, 37])) for _ in range(nd)]
+    while np.prod(shape) > 30000:
+        shape[int(rng.integers(0, nd))] = int(rng.choice([2, 3, 4]))
+    strides = [int(np.prod(shape[i + 1:])) for i in range(nd)]
+    rank = int(rng.integers(1, min(3, nd) + 1))
+    taxes = sorted(rng.choice(nd, size=rank, replace=False).tolist())
+    kinds = [int(rng.choice([REDFT10, REDFT01])) for _ in range(rank)]
+    dims = [(shape[a], strides[a], strides[a]) for a in taxes]
+    how = [(shape[a], strides[a], strides[a]) for a in range(nd) if a not in taxes]
+    rng.shuffle(how)
+    f64 = bool(seed % 2)
+    x = ol.synth_f32(seed + 3, int(np.prod(shape))).reshape(shape)
+    x = x.astype(np.float64) if f64 else x
+    p = Plan.guru(dims, how, kinds, lib=emul(), dtype="f64" if f64 else "f32")
+    got = x.copy()
+    p.execute(got.ctypes.data)
+    ref = x.astype(np.float64)
+    for a, k in zip(taxes, kinds):
+        ref = _oracle_along_axis(ref, a, k)
+    assert relerr(got, ref) < (5e-13 if f64 else 3e-6), (shape, taxes, kinds, p.describe())
