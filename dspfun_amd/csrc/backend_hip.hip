@@ -34,19 +34,20 @@ template <int KIND, class R, int MAXT>
 __global__ void __launch_bounds__(MAXT) row_kernel(const PassArgsT<R> a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+	__shared__ long long bases[2 * 16];
 	cx<R> *buf = reinterpret_cast<cx<R> *>(lds);
-	const int tid = threadIdx.x, nthr = blockDim.x, L = a.N / 2;
-	long long bin, bout;
-	row_base(a, blockIdx.x, bin, bout);
-	if (KIND == KIND_REDFT10) row_load10(a, buf, bin, tid, nthr);
-	else row_load01(a, buf, bin, tid, nthr);
+	const int tid = threadIdx.x, nthr = blockDim.x, L = a.N / 2, B = a.C * a.LPW;
+	const int cnt = row_bases(a, blockIdx.x, bases, tid);
+	__syncthreads();
+	if (KIND == KIND_REDFT10) row_load10(a, buf, bases, cnt, tid, nthr);
+	else row_load01(a, buf, bases, cnt, tid, nthr);
 	__syncthreads();
 	for (int s = 0; s < a.fft.ns; s++) {
-		fft_stage(buf, L, a.fft.st[s], a.C, a.divB, a.W, tid, nthr);
+		fft_stage(buf, L, a.fft.st[s], B, a.divB, a.W, tid, nthr);
 		__syncthreads();
 	}
-	if (KIND == KIND_REDFT10) row_post10(a, buf, bout, tid, nthr);
-	else row_store01(a, buf, bout, tid, nthr);
+	if (KIND == KIND_REDFT10) row_post10(a, buf, bases, cnt, tid, nthr);
+	else row_store01(a, buf, bases, cnt, tid, nthr);
 }
 
 template <int KIND, class R, int MAXT>

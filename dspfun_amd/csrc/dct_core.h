@@ -75,6 +75,8 @@ struct PassGeom {
 	int kind;         // KIND_*
 	// ROW
 	int C;            // interleaved signals per line
+	int LPW;          // lines per workgroup (generic ROW kernel; the specialised kernels take one)
+	FastDiv divC, divNC, divKC;   // ROW: divide by C, by N*C (samples per line), by (N/4+1)*C (output pairs per line)
 	// COL
 	int K;            // tile width in samples (even)
 	int B;            // complex columns per tile = K/2
@@ -92,7 +94,7 @@ struct PassGeom {
 	FastDiv mask_div;     // elements per owner id (32-bit offsets: masked runs are limited to 2^32 / d elements)
 	int accumulate;
 	FftDesc fft;
-	FastDiv divB;         // divide by (ROW: C, COL: B)
+	FastDiv divB;         // divide by the number of signals in the LDS buffer (ROW: C*LPW, COL: B)
 };
 
 template <class R>
@@ -224,9 +226,11 @@ DSP_HD void fft_stage_inv(C *buf, int L, const StageDesc &S, int B, FastDiv divB
 }
 
 // ------------------------------------------------------------------------------------------------
-// ROW pass.  LDS: buf[L*C] complex, L = N/2, channel s of packed sample m at buf[m*C + s].  The line goes from global
-// memory straight into the packed FFT input and from the FFT output straight back (no staging copy of the line), so
-// all loads of a line happen before its first store: in place is safe.
+// ROW pass.  A workgroup owns LPW consecutive lines (1 for long lines; several short ones so that it still has a few
+// thousand samples).  LDS: buf[L*B] complex, L = N/2, B = C*LPW signals, channel s of line l of packed sample m at
+// buf[m*B + l*C + s]; bases[2l], bases[2l+1] = input / output element offset of line l (filled by row_bases).  The
+// lines go from global memory straight into the packed FFT input and from the FFT output straight back (no staging
+// copy), so all loads of a line happen before its first store: in place is safe.
 // index of sample v[n] of the even/odd-reordered signal inside the original signal
 DSP_HD int makhoul_src(int n, int N) { return 2 * n < N ? 2 * n : 2 * (N - 1 - n) + 1; }
 DSP_HD int makhoul_dst(int y, int N) { return (y & 1) ? N - 1 - (y >> 1) : (y >> 1); }
@@ -237,6 +241,15 @@ DSP_HD void row_base(const PassGeom &a, int line, long long &bin, long long &bou
 	bin = i0 * a.sb0_in + i1 * a.sb1_in;
 	bout = i0 * a.sb0_out + i1 * a.sb1_out;
 }
+// lines of workgroup `wg`: returns how many (the last workgroup may hold fewer than LPW) and fills bases[]
+DSP_HD int row_bases(const PassGeom &a, int wg, long long *bases, int tid)
+{
+	const long long nlines = (long long)a.nb0 * a.nb1;
+	long long cnt = nlines - (long long)wg * a.LPW;
+	if (cnt > a.LPW) cnt = a.LPW;
+	if (tid < (int)cnt) row_base(a, wg * a.LPW + tid, bases[2 * tid], bases[2 * tid + 1]);
+	return (int)cnt;
+}
 
 template <class R>
 DSP_HD void row_put(const PassArgsT<R> &a, long long off, R v)
@@ -246,37 +259,39 @@ DSP_HD void row_put(const PassArgsT<R> &a, long long off, R v)
 
 // REDFT10: pixels in memory order -> even/odd reordered, packed two reals per complex slot
 template <bool MASKED, class R>
-DSP_HD void row_load10_m(const PassArgsT<R> &a, cx<R> *buf, long long bin, int tid, int nthr)
+DSP_HD void row_load10_m(const PassArgsT<R> &a, cx<R> *buf, const long long *bases, int cnt, int tid, int nthr)
 {
-	const int N = a.N, C = a.C;
+	const int N = a.N, C = a.C, B = a.C * a.LPW;
 	R *bf = reinterpret_cast<R *>(buf);
-	for (int it = tid; it < N * C; it += nthr) {
-		const int x = (int)a.divB.div((uint32_t)it), s = it - x * C;
-		R v = load_masked<MASKED>(a, bin + it);
+	for (int it = tid; it < cnt * N * C; it += nthr) {
+		const int l = (int)a.divNC.div((uint32_t)it), e = it - l * N * C;
+		const int x = (int)a.divC.div((uint32_t)e), s = e - x * C;
+		R v = load_masked<MASKED>(a, bases[2 * l] + e);
 		if (x == 0) v *= a.in_scale0;
 		const int n = makhoul_dst(x, N);
-		bf[2 * ((n >> 1) * C + s) + (n & 1)] = v;
+		bf[2 * ((n >> 1) * B + l * C + s) + (n & 1)] = v;
 	}
 }
 
 template <class R>
-DSP_HD void row_load10(const PassArgsT<R> &a, cx<R> *buf, long long bin, int tid, int nthr)
+DSP_HD void row_load10(const PassArgsT<R> &a, cx<R> *buf, const long long *bases, int cnt, int tid, int nthr)
 {
-	if (a.mask) row_load10_m<true>(a, buf, bin, tid, nthr); else row_load10_m<false>(a, buf, bin, tid, nthr);
+	if (a.mask) row_load10_m<true>(a, buf, bases, cnt, tid, nthr); else row_load10_m<false>(a, buf, bases, cnt, tid, nthr);
 }
 
 // REDFT10: FFT output -> 4 real outputs per (k, L-k) pair, stored
 template <class R>
-DSP_HD void row_post10(const PassArgsT<R> &a, const cx<R> *buf, long long bout, int tid, int nthr)
+DSP_HD void row_post10(const PassArgsT<R> &a, const cx<R> *buf, const long long *bases, int cnt, int tid, int nthr)
 {
 	typedef cx<R> C_;
-	const int L = a.N / 2, C = a.C, N = a.N;
+	const int L = a.N / 2, C = a.C, N = a.N, B = a.C * a.LPW;
 	const int nk = L / 2 + 1;
-	for (int it = tid; it < nk * C; it += nthr) {
-		const int k = (int)a.divB.div((uint32_t)it), s = it - k * C;
+	for (int it = tid; it < cnt * nk * C; it += nthr) {
+		const int l = (int)a.divKC.div((uint32_t)it), e = it - l * nk * C;
+		const int k = (int)a.divC.div((uint32_t)e), s = e - k * C;
 		const int km = k ? L - k : 0;
-		const C_ zk = buf[a.pos[k] * C + s];
-		const C_ zm = cconj(buf[a.pos[km] * C + s]);
+		const C_ zk = buf[a.pos[k] * B + l * C + s];
+		const C_ zm = cconj(buf[a.pos[km] * B + l * C + s]);
 		const C_ E = cscale(cadd(zk, zm), R(0.5));
 		const C_ Dh = cscale(csub(zk, zm), R(0.5));
 		const C_ D = cmul_mi(Dh);                 // (zk - conj zm) / (2i)
@@ -290,7 +305,7 @@ DSP_HD void row_post10(const PassArgsT<R> &a, const cx<R> *buf, long long bout, 
 		const C_ Vm = cconj(csub(E, P));          // V[L-k]
 		const C_ wk = cmul(tk, Vk);
 		const C_ wm = cmul(tlk, Vm);
-		const long long o = bout + s;
+		const long long o = bases[2 * l + 1] + s;
 		const R sc = a.scale;
 		row_put(a, o + (long long)k * C, R(2) * wk.x * sc * (k == 0 ? a.out_scale0 : R(1)));
 		if (k > 0) row_put(a, o + (long long)(N - k) * C, R(-2) * wk.y * sc);
@@ -301,14 +316,15 @@ DSP_HD void row_post10(const PassArgsT<R> &a, const cx<R> *buf, long long bout, 
 
 // REDFT01: natural-order input -> conj of the half-length spectrum in buf
 template <bool MASKED, class R>
-DSP_HD void row_load01_m(const PassArgsT<R> &a, cx<R> *buf, long long bin, int tid, int nthr)
+DSP_HD void row_load01_m(const PassArgsT<R> &a, cx<R> *buf, const long long *bases, int cnt, int tid, int nthr)
 {
 	typedef cx<R> C_;
-	const int L = a.N / 2, C = a.C, N = a.N;
+	const int L = a.N / 2, C = a.C, N = a.N, B = a.C * a.LPW;
 	const int nk = L / 2 + 1;
-	for (int it = tid; it < nk * C; it += nthr) {
-		const int k = (int)a.divB.div((uint32_t)it), s = it - k * C;
-		const long long o = bin + s;
+	for (int it = tid; it < cnt * nk * C; it += nthr) {
+		const int l = (int)a.divKC.div((uint32_t)it), e = it - l * nk * C;
+		const int k = (int)a.divC.div((uint32_t)e), s = e - k * C;
+		const long long o = bases[2 * l] + s;
 		auto ld = [&](int px) { return load_masked<MASKED>(a, o + (long long)px * C); };
 		const R xk = ld(k) * (k == 0 ? a.in_scale0 : R(1));
 		const R xnk = k ? ld(N - k) : R(0);
@@ -323,29 +339,30 @@ DSP_HD void row_load01_m(const PassArgsT<R> &a, cx<R> *buf, long long bin, int t
 		const C_ S = cadd(Vk, cconj(Vm));
 		const C_ D = csub(Vk, cconj(Vm));
 		const C_ Q = cmul_pi(cmulc(D, t4));                    // i * conj(t1[k]) * D
-		buf[k * C + s] = cconj(cadd(S, Q));
-		if (k > 0) buf[(L - k) * C + s] = csub(S, Q);
+		buf[k * B + l * C + s] = cconj(cadd(S, Q));
+		if (k > 0) buf[(L - k) * B + l * C + s] = csub(S, Q);
 	}
 }
 
 template <class R>
-DSP_HD void row_load01(const PassArgsT<R> &a, cx<R> *buf, long long bin, int tid, int nthr)
+DSP_HD void row_load01(const PassArgsT<R> &a, cx<R> *buf, const long long *bases, int cnt, int tid, int nthr)
 {
-	if (a.mask) row_load01_m<true>(a, buf, bin, tid, nthr); else row_load01_m<false>(a, buf, bin, tid, nthr);
+	if (a.mask) row_load01_m<true>(a, buf, bases, cnt, tid, nthr); else row_load01_m<false>(a, buf, bases, cnt, tid, nthr);
 }
 
 // REDFT01: FFT output -> time samples in memory order
 template <class R>
-DSP_HD void row_store01(const PassArgsT<R> &a, const cx<R> *buf, long long bout, int tid, int nthr)
+DSP_HD void row_store01(const PassArgsT<R> &a, const cx<R> *buf, const long long *bases, int cnt, int tid, int nthr)
 {
-	const int N = a.N, C = a.C;
+	const int N = a.N, C = a.C, B = a.C * a.LPW;
 	const R *bf = reinterpret_cast<const R *>(buf);
-	for (int it = tid; it < N * C; it += nthr) {
-		const int x = (int)a.divB.div((uint32_t)it), s = it - x * C;
+	for (int it = tid; it < cnt * N * C; it += nthr) {
+		const int l = (int)a.divNC.div((uint32_t)it), e = it - l * N * C;
+		const int x = (int)a.divC.div((uint32_t)e), s = e - x * C;
 		const int n = makhoul_dst(x, N);
-		const R f = bf[2 * (a.pos[n >> 1] * C + s) + (n & 1)];
+		const R f = bf[2 * (a.pos[n >> 1] * B + l * C + s) + (n & 1)];
 		const R sc = (x == 0) ? a.scale * a.out_scale0 : a.scale;
-		row_put(a, bout + it, ((n & 1) ? -f : f) * sc);
+		row_put(a, bases[2 * l + 1] + e, ((n & 1) ? -f : f) * sc);
 	}
 }
 

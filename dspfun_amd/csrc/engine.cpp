@@ -322,26 +322,33 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 				for (size_t i = 0; i < others.size(); i++) if ((int)i != cdim) lines.push_back(others[i]);
 				merge_dims(lines);
 				PassGeom &pa = P.pa;
-				pa.N = N; pa.kind = kind; pa.C = C; pa.fft = F; pa.divB = make_div((uint32_t)C);
+				pa.N = N; pa.kind = kind; pa.C = C; pa.fft = F;
 				pa.nb0 = lines.size() > 0 ? lines[0].n : 1; pa.sb0_in = lines.size() > 0 ? lines[0].is : 0; pa.sb0_out = lines.size() > 0 ? lines[0].os : 0;
 				pa.nb1 = lines.size() > 1 ? lines[1].n : 1; pa.sb1_in = lines.size() > 1 ? lines[1].is : 0; pa.sb1_out = lines.size() > 1 ? lines[1].os : 0;
 				for (size_t i = 2; i < lines.size(); i++) P.hostloop.push_back(lines[i]);
 				P.type = Pass::ROW;
-				if ((long long)pa.nb0 * pa.nb1 > 0x7fffffffLL) return fail(-2, "too many lines for one launch");
-				P.g.nwg = pa.nb0 * pa.nb1; P.g.lds_bytes = (size_t)L * C * 2 * es;
+				const long long nlines = (long long)pa.nb0 * pa.nb1;
+				if (nlines > 0x7fffffffLL) return fail(-2, "too many lines for one launch");
+				// short lines: several per workgroup (about 2048 samples), as long as the launch keeps well over a workgroup per CU
+				int LPW = 1;
+				while (LPW < 16 && (long long)N * C * LPW < 2048 && nlines / (2 * LPW) >= 1024 && (size_t)L * C * 2 * LPW * 2 * es <= maxlds) LPW *= 2;
+				if (env_int("DSPFFT_ROW_LPW")) LPW = std::min(16, std::max(1, env_int("DSPFFT_ROW_LPW")));
+				pa.LPW = LPW; pa.divB = make_div((uint32_t)(C * LPW)); pa.divC = make_div((uint32_t)C);
+				pa.divNC = make_div((uint32_t)(N * C)); pa.divKC = make_div((uint32_t)((L / 2 + 1) * C));
+				P.g.nwg = (int)((nlines + LPW - 1) / LPW); P.g.lds_bytes = (size_t)L * C * LPW * 2 * es;
 				// about 16 waves per CU: one big-LDS workgroup of 1024 threads, two of 512, otherwise 256 (measured, tools/sweep_generic.py)
 				P.g.nthr = P.g.lds_bytes > 80 * 1024 ? 1024 : P.g.lds_bytes > 24 * 1024 ? 512 : 256;
 				if (env_int("DSPFFT_ROW_THREADS")) P.g.nthr = env_int("DSPFFT_ROW_THREADS");
 				if (upload_tables(P, pl->f64, N, L, pos)) return fail(-3, "table upload failed");
-				snprintf(buf, sizeof buf, "axis %d: ROW%s  N=%d C=%d fft=%d(%s) lines=%d lds=%zu", a, tag, N, C, L, radix_string(F).c_str(), P.g.nwg, P.g.lds_bytes);
+				snprintf(buf, sizeof buf, "axis %d: ROW%s  N=%d C=%d fft=%d(%s) lines=%lld x%d lds=%zu", a, tag, N, C, L, radix_string(F).c_str(), nlines, LPW, P.g.lds_bytes);
 				P.desc = buf;
 				// vector pixel access needs the line starts aligned to the pixel vector (C=2: 8 B, C=4: 16 B)
 				const int al = (C == 2 || C == 4) ? C : 1;
 				bool aligned = true;
 				for (const Dim &d : lines) aligned = aligned && (d.is % al == 0) && (d.os % al == 0);
 				if (!pl->f64 && aligned && be_find_spec(0, N, C, &P.spec)) {
-					P.has_spec = true; P.spa = pa; P.spec_nwg = P.g.nwg;
-					snprintf(buf, sizeof buf, "axis %d: ROW* N=%d C=%d spec#%d threads=%d lines=%d lds=%zu", a, N, C, P.spec.id, P.spec.nthr, P.g.nwg, P.spec.lds);
+					P.has_spec = true; P.spa = pa; P.spec_nwg = (int)nlines;
+					snprintf(buf, sizeof buf, "axis %d: ROW* N=%d C=%d spec#%d threads=%d lines=%lld lds=%zu", a, N, C, P.spec.id, P.spec.nthr, nlines, P.spec.lds);
 					P.desc = buf;
 				}
 				return 0;
@@ -370,7 +377,14 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 			}
 			merge_dims(rest);
 			const size_t rows = direct ? (size_t)N : (size_t)M;           // complex LDS rows per tile column pair
-			int K = std::min(env_int("DSPFFT_COL_K") ? env_int("DSPFFT_COL_K") : 16, (inner.n + 1) & ~1);
+			// tile width: 16 floats (64 B row segments); short axes take wider tiles so a workgroup still owns a few
+			// thousand samples (a 64-row tile of width 16 is 1024 samples for 256 threads)
+			int Kwant = 16;
+			long long nbatch = 1;
+			for (const Dim &d : rest) nbatch *= d.n;
+			// ... as long as the launch still has well over a workgroup per CU (a single small frame keeps its narrow tiles)
+			while (Kwant < 64 && (long long)rows * Kwant < 4096 && ((inner.n + 2 * Kwant - 1) / (2 * Kwant)) * nbatch >= 1024) Kwant *= 2;
+			int K = std::min(env_int("DSPFFT_COL_K") ? env_int("DSPFFT_COL_K") : Kwant, (inner.n + 1) & ~1);
 			while (K >= 2 && rows * (K / 2) * 2 * es > maxlds) K -= 2;
 			if (K >= 2) {
 				PassGeom &pa = P.pa;

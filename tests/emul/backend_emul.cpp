@@ -29,15 +29,16 @@ static int emul_row(const PassArgsT<R> &a, const LaunchGeom &g)
 {
 	std::vector<unsigned char> lds(g.lds_bytes + 32);
 	cx<R> *buf = (cx<R> *)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
-	const int nthr = g.nthr, L = a.N / 2;
+	long long bases[2 * 16];
+	const int nthr = g.nthr, L = a.N / 2, B = a.C * a.LPW;
 	for (int wg = 0; wg < g.nwg; wg++) {
-		long long bin, bout;
-		row_base(a, wg, bin, bout);
-		if (a.kind == KIND_REDFT10) { PHASE(row_load10(a, buf, bin, tid, nthr)); }
-		else { PHASE(row_load01(a, buf, bin, tid, nthr)); }
-		for (int s = 0; s < a.fft.ns; s++) PHASE(fft_stage(buf, L, a.fft.st[s], a.C, a.divB, a.W, tid, nthr));
-		if (a.kind == KIND_REDFT10) { PHASE(row_post10(a, buf, bout, tid, nthr)); }
-		else { PHASE(row_store01(a, buf, bout, tid, nthr)); }
+		int cnt = 0;
+		PHASE(cnt = row_bases(a, wg, bases, tid));
+		if (a.kind == KIND_REDFT10) { PHASE(row_load10(a, buf, bases, cnt, tid, nthr)); }
+		else { PHASE(row_load01(a, buf, bases, cnt, tid, nthr)); }
+		for (int s = 0; s < a.fft.ns; s++) PHASE(fft_stage(buf, L, a.fft.st[s], B, a.divB, a.W, tid, nthr));
+		if (a.kind == KIND_REDFT10) { PHASE(row_post10(a, buf, bases, cnt, tid, nthr)); }
+		else { PHASE(row_store01(a, buf, bases, cnt, tid, nthr)); }
 	}
 	return 0;
 }

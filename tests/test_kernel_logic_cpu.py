@@ -716,3 +716,36 @@ def test_random_guru_geometries(seed):
     for a, k in zip(taxes, kinds):
         ref = _oracle_along_axis(ref, a, k)
     assert relerr(got, ref) < (5e-13 if f64 else 3e-6), (shape, taxes, kinds, p.describe())
+
+
+@pytest.mark.parametrize("lpw", [2, 4, 16])
+def test_generic_row_pass_with_several_lines_per_workgroup(lpw):
+    """short lines share a workgroup (the planner does this for big batches of short lines; forced here), with a ragged last group"""
+    os.environ["DSPFFT_ROW_LPW"] = str(lpw)
+    os.environ["DSPFFT_NO_TINY"] = "1"
+    try:
+        for (h, w, c) in [(37, 64, 3), (5, 36, 1), (21, 40, 2)]:
+            x = ol.synth_f32(h + w, h * w * c).reshape(h, w, c)
+            for kind in (REDFT10, REDFT01):
+                p = Plan.image(h, w, c, kind, lib=emul())
+                assert f"x{lpw}" in p.describe().splitlines()[1], p.describe()
+                ref = ol.dct2d_interleaved(x.astype(np.float64), kind, impl="port")
+                assert relerr(run(p, x.copy()), ref) < TOL, (h, w, c, kind, p.describe())
+                p64 = Plan.image(h, w, c, kind, lib=emul(), dtype="f64")
+                assert relerr(run64(p64, x.astype(np.float64)), ref) < 5e-13
+        # fused scan step through it
+        h, w, c = 37, 64, 3
+        L = emul()
+        x = ol.synth_f32(2, h * w * c).reshape(h, w, c)
+        coeffs = x.copy()
+        Plan.image(h, w, c, REDFT10, lib=L).set_scale(1.0 / (4 * w * h)).execute(coeffs.ctypes.data)
+        ids = np.zeros(h * w, dtype=np.uint32)
+        assert L.dspfft_scan_zigzag_frame_ids(ids.ctypes.data, w, h, (h * w + 2) // 3, None) == 0
+        inv = Plan.image(h, w, c, REDFT01, lib=L)
+        acc = np.ascontiguousarray(np.broadcast_to(coeffs[0, 0], (h, w, c)).copy())
+        work = np.zeros_like(acc)
+        for f in range(3):
+            inv.execute_masked_accumulate(coeffs.ctypes.data, work.ctypes.data, acc.ctypes.data, ids.ctypes.data, f, c)
+        assert np.abs(acc - x).max() < 1e-5
+    finally:
+        del os.environ["DSPFFT_ROW_LPW"], os.environ["DSPFFT_NO_TINY"]
