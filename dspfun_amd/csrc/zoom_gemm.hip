@@ -19,18 +19,23 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, LDP = BM + 4;   // LDS tiles are [k][row], padded
+constexpr int BM = 128, BN = 128;
 
 // C[m*ldc + n*cs] = alpha * sum_k A[m*lda + k] * B[n*ldb + k];  batch b offsets: sa, sb, sc
 // 128 x 128 x BK block tile, 256 threads = 2 x 2 waves of 64 x 64, each 2 x 2 MFMA 32x32x2 tiles;
 // global -> registers -> LDS double buffer (the next K-tile's loads are in flight during the MFMAs).
+// LDS tiles are [row][k] with k contiguous: a thread's float4 along K goes in with ONE ds_write_b128 (no transposing
+// scalar writes) and every lane takes its MFMA operands for four k-steps with ONE ds_read_b128.  The two k-slots of
+// an MFMA need not be adjacent in memory, only the same for A and B: lane half lk owns k = 4 lk .. 4 lk + 3 of each
+// group of eight.  Row pitch BK + 4 floats keeps the b128 accesses of a wave spread over the banks.
 template <int BK>
 __global__ void __launch_bounds__(256) gemm_nt_f32_mfma(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
                                                         int M, int N, int K, long long lda, long long ldb, long long ldc, int cs,
                                                         long long sa, long long sb, long long sc, float alpha)
 {
-	__shared__ float As[2][BK][LDP];
-	__shared__ float Bs[2][BK][LDP];
+	constexpr int PITCH = BK + 4;
+	__shared__ __attribute__((aligned(16))) float As[2][BM][PITCH];
+	__shared__ __attribute__((aligned(16))) float Bs[2][BN][PITCH];
 	constexpr int NV = BK / 8;                               // float4 per thread per operand per K-tile
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int wm = wave >> 1, wn = wave & 1;                 // 2 x 2 waves, each 64 x 64
@@ -62,9 +67,8 @@ __global__ void __launch_bounds__(256) gemm_nt_f32_mfma(const float *__restrict_
 	auto stash = [&](int buf) {
 #pragma unroll
 		for (int v = 0; v < NV; v++) {
-			const int k = sk + 8 * v;
-			As[buf][k + 0][srow] = ra[v].x; As[buf][k + 1][srow] = ra[v].y; As[buf][k + 2][srow] = ra[v].z; As[buf][k + 3][srow] = ra[v].w;
-			Bs[buf][k + 0][srow] = rb[v].x; Bs[buf][k + 1][srow] = rb[v].y; Bs[buf][k + 2][srow] = rb[v].z; Bs[buf][k + 3][srow] = rb[v].w;
+			*reinterpret_cast<float4 *>(&As[buf][srow][sk + 8 * v]) = ra[v];
+			*reinterpret_cast<float4 *>(&Bs[buf][srow][sk + 8 * v]) = rb[v];
 		}
 	};
 
@@ -80,13 +84,20 @@ __global__ void __launch_bounds__(256) gemm_nt_f32_mfma(const float *__restrict_
 		const int cur = kt & 1;
 		if (kt + 1 < nk) fetch_tile((kt + 1) * BK);
 #pragma unroll
-		for (int s = 0; s < BK / 2; s++) {
-			const float a0 = As[cur][2 * s + lk][wm * 64 + li], a1 = As[cur][2 * s + lk][wm * 64 + 32 + li];
-			const float b0 = Bs[cur][2 * s + lk][wn * 64 + li], b1 = Bs[cur][2 * s + lk][wn * 64 + 32 + li];
-			acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-			acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-			acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-			acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+		for (int g = 0; g < BK / 8; g++) {
+			const float4 a0 = *reinterpret_cast<const float4 *>(&As[cur][wm * 64 + li][8 * g + 4 * lk]);
+			const float4 a1 = *reinterpret_cast<const float4 *>(&As[cur][wm * 64 + 32 + li][8 * g + 4 * lk]);
+			const float4 b0 = *reinterpret_cast<const float4 *>(&Bs[cur][wn * 64 + li][8 * g + 4 * lk]);
+			const float4 b1 = *reinterpret_cast<const float4 *>(&Bs[cur][wn * 64 + 32 + li][8 * g + 4 * lk]);
+			const float a0v[4] = {a0.x, a0.y, a0.z, a0.w}, a1v[4] = {a1.x, a1.y, a1.z, a1.w};
+			const float b0v[4] = {b0.x, b0.y, b0.z, b0.w}, b1v[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+			for (int s = 0; s < 4; s++) {
+				acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[s], b0v[s], acc[0][0], 0, 0, 0);
+				acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[s], b1v[s], acc[0][1], 0, 0, 0);
+				acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[s], b0v[s], acc[1][0], 0, 0, 0);
+				acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[s], b1v[s], acc[1][1], 0, 0, 0);
+			}
 		}
 		if (kt + 1 < nk) stash(cur ^ 1);
 		__syncthreads();
