@@ -61,7 +61,7 @@ if dist is not None:
 err = max(int((p["dst"].int() - p["src"].int()).abs().max()) for p in planes)
 if rank == 0:
     samples = FRAMES * (1080 * 1920 + 2 * 540 * 960)
-    print(json.dumps({"workload": "motion yuv420p 1920x1080x256, per-frame blocks, quantiser 3, u8 in -> u8 out", "n_gpus": world, "frames_per_rank": nf,
+    print(json.dumps({"workload": "motion yuv420p 1920x1080x256, per-frame blocks, --quant 20, u8 in -> u8 out", "n_gpus": world, "frames_per_rank": nf,
                       "ms_per_clip": round(dt * 1e3, 3), "frames_per_s": round(FRAMES / dt), "Msamples_per_s": round(samples / dt / 1e6),
                       "algorithmic_GBps_per_gpu": round(samples * 18 / dt / 1e9 / world, 1), "max_abs_u8_change": err,
                       "parallelism": f"frame-sharded x{world}, no collective"}))
