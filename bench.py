@@ -63,7 +63,7 @@ def cpu_baseline(max_seconds=30.0):
         b = ol.r2r_many(f, n, kinds3, howmany=C, istride=C, idist=1, ostride=C, odist=1, impl="port", threads=threads)
         reps += 1
         el = time.perf_counter() - t0
-        if el > 10.0 or el * (reps + 1) / reps > max_seconds or reps >= 8:
+        if el > 10.0 or el * (reps + 1) / reps > max_seconds or reps >= 64:
             break
     err = float(np.abs(b / np.float32(4.0 * W * H) - x).max())
     return {"value": round(reps * H * W / 1e6 / el, 3), "unit": "Mpixels/s", "cores": threads, "kind": "port",
