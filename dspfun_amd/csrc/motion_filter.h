@@ -17,6 +17,7 @@ struct MotionFilter {
 	FastDiv div_mw, div_mh, div_bd;
 	int bd;                                  // frames per block as laid out (the embedding depth; 1 = every frame its own block)
 	int enabled;
+	int quant_only;                          // nothing but the quantiser acts (no damp/boost/threshold/DC rule): positions are not needed
 };
 
 inline FastDiv motion_filter_div(uint32_t d)
@@ -26,6 +27,7 @@ inline FastDiv motion_filter_div(uint32_t d)
 inline void motion_filter_set_divs(MotionFilter &p, int block_depth)
 {
 	p.bd = block_depth;
+	p.quant_only = p.quantizer > 0.f && p.damp == 1.f && p.boost == 1.f && !(p.thr_hi > 0.f) && (p.preserve_dc == 0 || !(p.b0d || p.b0h || p.b0w));
 	p.div_mw = motion_filter_div((uint32_t)p.mw); p.div_mh = motion_filter_div((uint32_t)p.mh); p.div_bd = motion_filter_div((uint32_t)block_depth);
 }
 
@@ -61,6 +63,16 @@ DSP_HD float motion_filter_elem(const MotionFilter &p, uint32_t e, float v, unsi
 // four consecutive elements starting at element offset e (< 2^31) of the working buffer
 DSP_HD float4 motion_filter4(const MotionFilter &p, uint32_t e, float4 v, unsigned long long &coded)
 {
+	if (p.quant_only) {
+		float r[4] = {v.x, v.y, v.z, v.w};
+		for (int q = 0; q < 4; q++) {
+			r[q] = (float)(round((double)r[q] / p.quantizer) * p.quantizer);                 // motion.c:740-744
+			coded += (r[q] != 0.f);
+			DSP_SCHED_FENCE();
+		}
+		float4 o; o.x = r[0]; o.y = r[1]; o.z = r[2]; o.w = r[3];
+		return o;
+	}
 	const uint32_t row = p.div_mw.div_exact(e);
 	int x = (int)(e - row * (uint32_t)p.mw);
 	const uint32_t pl = p.div_mh.div_exact(row);
