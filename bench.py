@@ -183,6 +183,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # clocks and caches settle over a few tens of milliseconds: whatever --warmup says, run at least that much untimed work
+    # first (a short --steps run is otherwise timed on a GPU that is still ramping up)
+    for _ in range(max(0, 60 - args.warmup)):
+        step()
     for _ in range(args.warmup):
         step()
     barrier()
