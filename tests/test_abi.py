@@ -54,3 +54,17 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_bench_and_smoke_fail_loudly_without_a_gpu():
+    """no CPU path hides behind the entry points the driver runs: bench.py exits with an error, smoke() asserts"""
+    import subprocess, sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True)
+    assert r.returncode == 2 and "no GPU" in r.stderr, (r.returncode, r.stderr[-200:])
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    with pytest.raises(AssertionError, match="needs a GPU"):
+        g.smoke()
