@@ -71,6 +71,21 @@ def cpu_baseline(max_seconds=30.0):
                       f"(roundtrip max abs err {err:.1e})"}
 
 
+def self_launch(ngpus):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+    as a child (one rank per GPU, RCCL rendezvous on 127.0.0.1) and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,12 +97,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # called directly as `python bench.py --gpus N`: start the N ranks ourselves, as a CHILD process of a parent
+        # that has not imported torch or touched the GPU (a process that has initialised the GPU must never exec)
+        sys.exit(self_launch(args.gpus))
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})", file=sys.stderr)
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch {args.gpus} ranks", file=sys.stderr)
         sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible", file=sys.stderr)

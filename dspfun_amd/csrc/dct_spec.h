@@ -15,6 +15,14 @@
 #include "dct_core.h"
 #include "elementwise_core.h"
 
+// LDS pad (elements / rows per first-stage sub-block); overridable for experiments (tools/sbench.hip)
+#ifndef DSP_ROW_PADC
+#define DSP_ROW_PADC 1
+#endif
+#ifndef DSP_COL_PADC
+#define DSP_COL_PADC 1
+#endif
+
 namespace dspfft {
 
 template <int I, int... Rs> constexpr int pack_get() { constexpr int a[] = {Rs..., 1}; return a[I]; }
@@ -147,7 +155,7 @@ struct RowSpec {
 	// SB = first-stage sub-block; the pad de-phases the SB-strided accesses of the digit-reversed
 	// gather in the last stage.  After the last stage the plane is in natural order (no pad).
 	static constexpr int R0 = pack_get<0, Rs...>(), RL = pack_get<NS - 1, Rs...>();
-	static constexpr int SB = L / R0, PADC = (NS >= 2) ? 1 : 0;
+	static constexpr int SB = L / R0, PADC = (NS >= 2) ? DSP_ROW_PADC : 0;
 	static constexpr int PL = L + R0 * PADC;           // plane pitch (complex)
 	static constexpr size_t LDS = (size_t)C * PL * 8;
 	static constexpr int NBL = L / RL;                 // butterflies of the last stage per channel
@@ -399,7 +407,7 @@ struct ColSpec {
 	// rows of the tile are padded by one row per first-stage sub-block while the DIF stages run
 	// (see RowSpec); natural order, unpadded, after the last stage.
 	static constexpr int R0 = pack_get<0, Rs...>(), RL = pack_get<NS - 1, Rs...>();
-	static constexpr int SB = N / R0, PADC = (NS >= 2) ? 1 : 0;
+	static constexpr int SB = N / R0, PADC = (NS >= 2) ? DSP_COL_PADC : 0;
 	static constexpr int ROWS = N + R0 * PADC;
 	static constexpr size_t LDS = (size_t)ROWS * B * 8;
 	static constexpr int NBL = N / RL;

@@ -68,3 +68,18 @@ def test_bench_and_smoke_fail_loudly_without_a_gpu():
     import __graft_entry__ as g
     with pytest.raises(AssertionError, match="needs a GPU"):
         g.smoke()
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` called directly (no torchrun) starts two ranks as a child process; without a GPU each
+    rank stops with "no GPU visible" and the parent returns non-zero"""
+    import subprocess, sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert r.stderr.count("no GPU visible") == 2, r.stderr[-600:]
+

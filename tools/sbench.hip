@@ -1,0 +1,180 @@
+// sbench.hip -- schedule experiments for the 4K roundtrip (not part of the product): the four specialised passes
+// (ROW10, COL10, COL01, ROW01) of 4 frames, launched under different multi-stream schedules, all in ONE process with
+// interleaved rounds (cdna_hip_programming.md rule 24).
+//   single      one stream, frame after frame
+//   aligned     two streams, one frame each, streams re-synchronised every step (bench.py's default)
+//   free        two streams, free running
+//   lagK        two streams, stream B's frame starts when stream A has finished K passes of its frame (K = 1, 2)
+//   lockstep    two streams, re-synchronised before every pass (same pass shape always co-runs)
+//   batch2      one stream, two frames per launch
+//   batch4      one stream, four frames per launch
+// Build: hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -Idspfun_amd/csrc tools/sbench.hip -o tools/sbench
+//        (add -DDSP_COL_PADC=0 / -DDSP_ROW_PADC=0 for the no-pad LDS layouts: 54 / 36 allocation granules of 1280 B)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+#include <string>
+#include <algorithm>
+#include "dct_spec.h"
+using namespace dspfft;
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+template <class S, int KIND, bool ROWK>
+__global__ void __launch_bounds__(S::T, S::WPE) pass_k(const PassArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+	const int tid = threadIdx.x;
+	typename S::template State<KIND> st;
+	long long bin, bout;
+	if constexpr (ROWK) row_base(a, blockIdx.x, bin, bout); else S::base(a, blockIdx.x, bin, bout);
+	auto *buf = reinterpret_cast<std::conditional_t<ROWK, cf, float4> *>(lds);
+	S::template prefetch<KIND>(a, bin, tid, st);
+	S::template phase<KIND, 0>(a, buf, bout, tid, st);
+	__syncthreads();
+	static_for<1, S::NPH>([&](auto ph) {
+		S::template phase<KIND, ph>(a, buf, bout, tid, st);
+		if constexpr (ph + 1 < S::NPH) __syncthreads();
+	});
+}
+
+static const int H = 2160, W = 3840, C = 3;
+static const size_t NF = (size_t)H * W * C;
+static const int NFR = 4;
+static float *g_buf;
+
+typedef RowSpec<3840, 3, 512, 12, 10, 16> RS;
+typedef ColSpec<2160, 8, 512, 12, 12, 15> CS;
+
+struct Tables { cf *T, *Wt; };
+static Tables make_tables(int N, int L)
+{
+	std::vector<cf> T(N + 1), Wv(L);
+	for (int j = 0; j <= N; j++) T[j] = cmk((float)cos(M_PI * j / (2.0 * N)), (float)-sin(M_PI * j / (2.0 * N)));
+	for (int t = 0; t < L; t++) Wv[t] = cmk((float)cos(2 * M_PI * t / L), (float)-sin(2 * M_PI * t / L));
+	Tables r;
+	CHK(hipMalloc(&r.T, T.size() * 8)); CHK(hipMalloc(&r.Wt, Wv.size() * 8));
+	CHK(hipMemcpy(r.T, T.data(), T.size() * 8, hipMemcpyHostToDevice)); CHK(hipMemcpy(r.Wt, Wv.data(), Wv.size() * 8, hipMemcpyHostToDevice));
+	return r;
+}
+static Tables g_trow, g_tcol;
+
+// pass p (0 ROW10, 1 COL10, 2 COL01, 3 ROW01) over `nfr` consecutive frames starting at frame f0
+static void launch_pass(int p, int f0, int nfr, hipStream_t s)
+{
+	PassArgs a; memset((void *)&a, 0, sizeof a);
+	a.in = a.out = g_buf + (size_t)f0 * NF;
+	a.in_scale0 = a.out_scale0 = 1.f;
+	const bool row = (p == 0 || p == 3);
+	a.kind = (p <= 1) ? KIND_REDFT10 : KIND_REDFT01;
+	a.scale = (p <= 1) ? 1.f : (row ? 1.f / (2.f * W) : 1.f / (2.f * H));
+	if (row) {
+		a.N = W; a.C = C; a.nb0 = H; a.nb1 = nfr; a.sb0_in = a.sb0_out = (long long)W * C; a.sb1_in = a.sb1_out = (long long)NF;
+		a.T = g_trow.T; a.W = g_trow.Wt;
+		if (p == 0) hipLaunchKernelGGL((pass_k<RS, KIND_REDFT10, true>), dim3(H * nfr), dim3(RS::T), RS::LDS, s, a);
+		else hipLaunchKernelGGL((pass_k<RS, KIND_REDFT01, true>), dim3(H * nfr), dim3(RS::T), RS::LDS, s, a);
+	} else {
+		a.N = H; a.K = CS::K; a.B = CS::B; a.ninner = W * C; a.ntiles = W * C / CS::K; a.es_in = a.es_out = (long long)W * C;
+		a.nb0 = nfr; a.nb1 = 1; a.sb0_in = a.sb0_out = (long long)NF;
+		a.T = g_tcol.T; a.W = g_tcol.Wt;
+		if (p == 1) hipLaunchKernelGGL((pass_k<CS, KIND_REDFT10, false>), dim3(a.ntiles * nfr), dim3(CS::T), CS::LDS, s, a);
+		else hipLaunchKernelGGL((pass_k<CS, KIND_REDFT01, false>), dim3(a.ntiles * nfr), dim3(CS::T), CS::LDS, s, a);
+	}
+}
+
+static hipStream_t sA, sB;
+static hipEvent_t evA[8], evB[8], evStepA, evStepB;
+
+static void step(const std::string &mode)
+{
+	if (mode == "single") {
+		for (int f = 0; f < NFR; f++) for (int p = 0; p < 4; p++) launch_pass(p, f, 1, sA);
+	} else if (mode == "batch2") {
+		for (int f = 0; f < NFR; f += 2) for (int p = 0; p < 4; p++) launch_pass(p, f, 2, sA);
+	} else if (mode == "batch4") {
+		for (int p = 0; p < 4; p++) launch_pass(p, 0, 4, sA);
+	} else if (mode == "free") {
+		for (int f = 0; f < NFR; f++) for (int p = 0; p < 4; p++) launch_pass(p, f, 1, (f & 1) ? sB : sA);
+	} else if (mode == "aligned") {
+		CHK(hipStreamWaitEvent(sA, evStepB, 0)); CHK(hipStreamWaitEvent(sB, evStepA, 0));
+		for (int f = 0; f < NFR; f++) for (int p = 0; p < 4; p++) launch_pass(p, f, 1, (f & 1) ? sB : sA);
+		CHK(hipEventRecord(evStepA, sA)); CHK(hipEventRecord(evStepB, sB));
+	} else if (mode == "lockstep") {
+		for (int f = 0; f < NFR; f += 2)
+			for (int p = 0; p < 4; p++) {
+				CHK(hipStreamWaitEvent(sA, evStepB, 0)); CHK(hipStreamWaitEvent(sB, evStepA, 0));
+				launch_pass(p, f, 1, sA); launch_pass(p, f + 1, 1, sB);
+				CHK(hipEventRecord(evStepA, sA)); CHK(hipEventRecord(evStepB, sB));
+			}
+	} else if (mode == "lag1" || mode == "lag2") {
+		const int lag = mode == "lag1" ? 1 : 2;
+		// stream A: frames 0, 2; stream B: frames 1, 3; B's first frame of the step starts after A has done `lag` passes
+		for (int f = 0; f < NFR; f += 2) {
+			for (int p = 0; p < 4; p++) {
+				launch_pass(p, f, 1, sA);
+				if (f == 0 && p == lag - 1) CHK(hipEventRecord(evA[0], sA));
+			}
+		}
+		CHK(hipStreamWaitEvent(sB, evA[0], 0));
+		for (int f = 1; f < NFR; f += 2) for (int p = 0; p < 4; p++) launch_pass(p, f, 1, sB);
+		// the next step's stream A waits for B to be `lag` passes from finishing its last frame: keep it simple -- A runs free
+	} else if (mode == "pipe") {
+		// strict complementary pipeline: B's pass p of frame f+1 starts when A's pass p of frame f is done, and vice versa
+		for (int f = 0; f < NFR; f += 2)
+			for (int p = 0; p < 4; p++) {
+				CHK(hipStreamWaitEvent(sA, evB[p], 0));
+				launch_pass(p, f, 1, sA);
+				CHK(hipEventRecord(evA[p], sA));
+				CHK(hipStreamWaitEvent(sB, evA[p], 0));
+				launch_pass(p, f + 1, 1, sB);
+				CHK(hipEventRecord(evB[(p + 1) & 3], sB));
+			}
+	}
+}
+
+static double run_mode(const std::string &mode, int steps)
+{
+	for (int i = 0; i < 3; i++) step(mode);
+	CHK(hipDeviceSynchronize());
+	hipEvent_t a, b; CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
+	CHK(hipEventRecord(a, sA));
+	CHK(hipStreamWaitEvent(sB, a, 0));
+	for (int i = 0; i < steps; i++) step(mode);
+	CHK(hipEventRecord(evStepB, sB)); CHK(hipStreamWaitEvent(sA, evStepB, 0));
+	CHK(hipEventRecord(b, sA)); CHK(hipEventSynchronize(b));
+	float ms; CHK(hipEventElapsedTime(&ms, a, b));
+	CHK(hipGetLastError());
+	CHK(hipDeviceSynchronize());
+	CHK(hipEventDestroy(a)); CHK(hipEventDestroy(b));
+	return (double)steps * NFR * H * W / 1e6 / (ms * 1e-3);
+}
+
+int main(int argc, char **argv)
+{
+	const int steps = argc > 1 ? atoi(argv[1]) : 100;
+	CHK(hipMalloc(&g_buf, NF * 4 * NFR));
+	{
+		std::vector<float> h(NF);
+		for (size_t i = 0; i < h.size(); i++) h[i] = (float)((i * 2654435761u) % 1000) / 1000.f;
+		for (int f = 0; f < NFR; f++) CHK(hipMemcpy(g_buf + (size_t)f * NF, h.data(), NF * 4, hipMemcpyHostToDevice));
+	}
+	g_trow = make_tables(W, W / 2); g_tcol = make_tables(H, H);
+	CHK(hipStreamCreateWithFlags(&sA, hipStreamNonBlocking)); CHK(hipStreamCreateWithFlags(&sB, hipStreamNonBlocking));
+	for (int i = 0; i < 8; i++) { CHK(hipEventCreateWithFlags(&evA[i], hipEventDisableTiming)); CHK(hipEventCreateWithFlags(&evB[i], hipEventDisableTiming)); CHK(hipEventRecord(evA[i], sA)); CHK(hipEventRecord(evB[i], sB)); }
+	CHK(hipEventCreateWithFlags(&evStepA, hipEventDisableTiming)); CHK(hipEventCreateWithFlags(&evStepB, hipEventDisableTiming));
+	CHK(hipEventRecord(evStepA, sA)); CHK(hipEventRecord(evStepB, sB));
+	CHK(hipFuncSetAttribute((const void *)pass_k<RS, KIND_REDFT10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RS::LDS));
+	CHK(hipFuncSetAttribute((const void *)pass_k<RS, KIND_REDFT01, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RS::LDS));
+	CHK(hipFuncSetAttribute((const void *)pass_k<CS, KIND_REDFT10, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CS::LDS));
+	CHK(hipFuncSetAttribute((const void *)pass_k<CS, KIND_REDFT01, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CS::LDS));
+	printf("ROW LDS %zu B (%.2f granules of 1280), COL LDS %zu B (%.2f granules); %d steps of %d frames\n", (size_t)RS::LDS, RS::LDS / 1280.0, (size_t)CS::LDS, CS::LDS / 1280.0, steps, NFR);
+	const char *modes[] = {"single", "aligned", "free", "lag1", "lag2", "lockstep", "pipe", "batch2", "batch4"};
+	for (int round = 0; round < 3; round++) {
+		printf("round %d:", round);
+		for (const char *m : modes) { double v = run_mode(m, steps); printf(" %s=%.0f", m, v); fflush(stdout); }
+		printf("  (Mpix/s)\n");
+	}
+	return 0;
+}
