@@ -45,6 +45,13 @@ int be_launch_spec_u8(int row_spec_id, const PassArgs &a, const U8IO &io, int nw
 // fused column roundtrip: REDFT10 along the tile axis (af), pointwise filter, REDFT01 (ai); both passes share spec `id`
 int be_launch_roundtrip(int id, const PassArgs &af, const PassArgs &ai, const MotionFilter &filt, unsigned long long *coded, int nwg, void *stream);
 
+// outer-radix-2 split of a long column axis (dct_spec.h ColHalfSpec): half-tile column kernels for length N whose inner extent is
+// a multiple of the tile width, and the paired row kernel of row spec (N, C); be_find_row_pair returns an id or -1
+bool be_find_half_spec(int N, int inner, SpecInfo *info);
+int be_find_row_pair(int N, int C);
+int be_launch_col_half(int id, const PassArgs &a, int nwg, void *stream);
+int be_launch_row_pair(int id, const PassArgs &a, int npairs, void *stream);
+
 // motion's filter over every active element of a buffer of `span` elements (the unfused form of the roundtrip's middle step)
 int be_motion_filter(float *buf, const MotionFilter &filt, uint64_t span, unsigned long long *coded, void *stream);
 

@@ -24,8 +24,16 @@ namespace dspfft {
 	extern template int launch_col_spec<ColSpec<N, K, T, __VA_ARGS__>, 0>(const PassArgs &, int, void *); \
 	extern template int launch_col_spec<ColSpec<N, K, T, __VA_ARGS__>, 1>(const PassArgs &, int, void *); \
 	extern template int launch_col_roundtrip<ColSpec<N, K, T, __VA_ARGS__>>(const PassArgs &, const PassArgs &, const MotionFilter &, unsigned long long *, int, void *);
+#define DSP_EXTERN_HALF(N, K, T, ...) \
+	extern template int launch_col_half<ColHalfSpec<N, K, T, __VA_ARGS__>, 0>(const PassArgs &, int, void *); \
+	extern template int launch_col_half<ColHalfSpec<N, K, T, __VA_ARGS__>, 1>(const PassArgs &, int, void *);
+#define DSP_EXTERN_PAIR(N, C, T, ...) \
+	extern template int launch_row_pair<RowSpec<N, C, T, __VA_ARGS__>, 0>(const PassArgs &, int, void *); \
+	extern template int launch_row_pair<RowSpec<N, C, T, __VA_ARGS__>, 1>(const PassArgs &, int, void *);
 DSPFFT_ROW_SPECS(DSP_EXTERN_ROW)
 DSPFFT_COL_SPECS(DSP_EXTERN_COL)
+DSPFFT_COL_HALF_SPECS(DSP_EXTERN_HALF)
+DSPFFT_ROW_PAIR_SPECS(DSP_EXTERN_PAIR)
 
 // ---------------------------------------------------------------------------------------------
 // MAXT: the largest workgroup the instantiation is launched with (512 leaves the register allocator 256 VGPRs, which

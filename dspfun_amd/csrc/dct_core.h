@@ -104,6 +104,7 @@ struct PassArgsT : PassGeom {
 	// tables (device memory)
 	const cx<R> *T;       // T[j] = exp(-i pi j / (2N)), j in [0, N]
 	const cx<R> *W;       // W[t] = exp(-2 pi i t / L),  t in [0, L)
+	const cx<R> *H;       // half-tile column passes (dct_spec.h ColHalfSpec) only: H[n] = exp(-2 pi i n / N), n in [0, N/2)
 	R scale;              // every output is multiplied by scale ...
 	R out_scale0;         // ... and output index 0 of this axis additionally by out_scale0
 	R in_scale0;          // input index 0 of this axis is multiplied by in_scale0 before transforming

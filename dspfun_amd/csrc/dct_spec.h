@@ -69,6 +69,15 @@ DSP_HD void twiddle_chain(cf *x, cf w1)
 	static_for<1, R>([&](auto r) { x[r] = cmul(x[r], w[r]); });
 }
 
+// the same with the powers built one after another (w^r = w^(r-1) w1): a longer dependency chain but two twiddle values
+// live instead of R - 1.  Used where registers are scarcer than latency (row_pair_kernel).
+template <int R>
+DSP_HD void twiddle_chain_seq(cf *x, cf w1)
+{
+	cf w = w1;
+	static_for<1, R>([&](auto r) { x[r] = cmul(x[r], w); if constexpr (r + 1 < R) w = cmul(w, w1); });
+}
+
 // ---- pixel (C floats) global access ------------------------------------------------------------
 template <int C> struct Pix { float v[C]; };
 
@@ -222,7 +231,7 @@ struct RowSpec {
 	static DSP_HD int padded(int p) { return p + (p / SB) * PADC; }
 
 	// stages 0 .. NS-2 (in place, padded layout)
-	template <int I>
+	template <int I, bool SEQTW = false>
 	static DSP_HD void stage(const PassArgs &a, cf *planes, int tid)
 	{
 		constexpr int R = pack_get<I, Rs...>(), Lc = pack_lc<I, Rs...>(), M1 = Lc / R, NB = L / R, TW = L / Lc;
@@ -236,7 +245,7 @@ struct RowSpec {
 			cf x[R];
 			static_for<0, R>([&](auto r) { x[r] = p[r * stride]; });
 			Dft<R>::run(x);
-			if constexpr (M1 > 1) twiddle_chain<R>(x, a.W[m * TW]);
+			if constexpr (M1 > 1) { if constexpr (SEQTW) twiddle_chain_seq<R>(x, a.W[m * TW]); else twiddle_chain<R>(x, a.W[m * TW]); }
 			static_for<0, R>([&](auto r) { p[r * stride] = x[r]; });
 		});
 	}
@@ -272,7 +281,7 @@ struct RowSpec {
 	}
 
 	// phase 0 consumes the prefetched registers; phases 1.. work on LDS; the last one stores to `bout`
-	template <int KIND, int PH, class ST>
+	template <int KIND, int PH, class ST, bool SEQTW = false>
 	static DSP_HD void phase(const PassArgs &a, cf *planes, long long bout, int tid, ST &st, const U8IO *io = nullptr)
 	{
 		float *pf = reinterpret_cast<float *>(planes);
@@ -323,7 +332,7 @@ struct RowSpec {
 				});
 			}
 		} else if constexpr (PH < NS) {
-			stage<PH - 1>(a, planes, tid);
+			stage<PH - 1, SEQTW>(a, planes, tid);
 		} else if constexpr (PH == NS) {
 			last_read(planes, st, tid);
 		} else if constexpr (PH == NS + 1) {
@@ -651,6 +660,158 @@ struct ColSpec {
 					const float sc = (y == 0) ? a.scale * a.out_scale0 : a.scale;
 					float4 r; r.x = F.x * sc; r.y = -F.y * sc; r.z = F.z * sc; r.w = -F.w * sc;
 					store4_a(a, bout + (long long)y * a.es_out + 4 * jp, r);
+				});
+			}
+		}
+	}
+};
+
+// =================================================================================================
+// Column pass split by an OUTER RADIX 2 across two kernels, so that a long column (2160, 4320 rows) is transformed on
+// tiles of N/2 rows x twice the width: 64-B row segments instead of 32-B ones for the same LDS footprint (measured with
+// no arithmetic on MI355X, tools/membench2: 2160x8 tiles 38.0 us per 4K frame, 1080x16 tiles 32.8 us, linear copy 29.5 us).
+//
+// With M = N/2, w = exp(-2 pi i / N) and v[] the even/odd ("Makhoul") reordered column, v[n] = x[2n], v[n+M] = x[N-1-2n]:
+//   REDFT10  (decimation in frequency)  F[2q] = FFT_M(v[n] + v[n+M])[q],  F[2q+1] = FFT_M((v[n] - v[n+M]) w^n)[q]
+//   REDFT01  (decimation in time)       v[n] = E[n] + conj(w)^n O[n],  v[n+M] = E[n] - conj(w)^n O[n],
+//                                        E, O = inverse M-point transforms of the even / odd coefficients
+// The butterfly v[n] +- v[n+M] pairs image rows y1 = 2n and y2 = N-1-2n.  It commutes with the transform along the other
+// axis, so the ROW pass does it on its INPUT: one workgroup loads both rows, transforms (r1 + r2) into row y1 and
+// (r1 - r2) into row y2 (row_pair_kernel).  The column pass then works on "half" tiles: half 0 = rows 2n (even rows),
+// half 1 = rows N-1-2n (odd rows, bottom up), each an M-point FFT with the twiddle w^n folded into its load (REDFT10)
+// or store (REDFT01).  Everything stays in place; the intermediate layout is internal to one execute().
+template <int N_, int K_, int T_, int... Rs>
+struct ColHalfSpec {
+	static constexpr int N = N_, M = N_ / 2, K = K_, T = T_, NP = K_ / 4;
+	typedef ColSpec<N_ / 2, K_, T_, Rs...> B;          // stages / last stage of the M-point FFT are the plain column pass's
+	static constexpr int NS = B::NS, NPH = B::NPH, WPE = 1;
+	static constexpr size_t LDS = B::LDS;
+	static constexpr int Y_ROUNDS = B::Y_ROUNDS, Q_ROUNDS = B::K_ROUNDS, NQ = (M / 2 + 1) * NP;
+	static_assert(N_ % 4 == 0, "half tiles need N divisible by 4");
+	template <int KIND> using State = typename B::template State<KIND>;
+
+	// image row of tile row n in half h
+	static DSP_HD int row_of(int n, int h) { return h ? N - 1 - 2 * n : 2 * n; }
+	// FFT slot of the partner F[N-k] of coefficient k = 2q + h
+	static DSP_HD int partner(int q, int h) { return h ? M - 1 - q : (q ? M - q : 0); }
+
+	static DSP_HD void base(const PassArgs &a, int work, long long &bin, long long &bout, int &h)
+	{
+		const int per = 2 * a.ntiles;
+		const int bt = work / per, t0 = work - bt * per;
+		const int t1 = xcd_remap(t0, per);
+		h = t1 / a.ntiles;
+		const int t = t1 - h * a.ntiles;
+		const int i1 = bt / a.nb0, i0 = bt - i1 * a.nb0;
+		bin = i0 * a.sb0_in + i1 * a.sb1_in + (long long)t * K;
+		bout = i0 * a.sb0_out + i1 * a.sb1_out + (long long)t * K;
+	}
+
+	template <int KIND, class ST>
+	static DSP_HD void prefetch(const PassArgs &a, long long bin, int h, int tid, ST &st)
+	{
+		if constexpr (KIND == KIND_REDFT10) {
+			static_for<0, Y_ROUNDS>([&](auto i) {
+				const int it = tid + i * T;
+				if ((i + 1) * T <= M * NP || it < M * NP) {
+					const int n = it / NP, jp = it - n * NP;
+					st.pre[i] = *reinterpret_cast<const float4 *>(a.in + bin + (long long)row_of(n, h) * a.es_in + 4 * jp);
+				}
+			});
+		} else {
+			static_for<0, Q_ROUNDS>([&](auto i) {
+				const int it = tid + i * T;
+				if ((i + 1) * T <= NQ || it < NQ) {
+					const int q = it / NP, jp = it - q * NP;
+					if (h && q >= M / 2) return;
+					const int k = 2 * q + h, km = k ? N - k : 0;
+					st.tw[i] = a.T[k];
+					const long long p = bin + 4 * jp;
+					st.pre[2 * i] = *reinterpret_cast<const float4 *>(a.in + p + (long long)k * a.es_in);
+					st.pre[2 * i + 1] = *reinterpret_cast<const float4 *>(a.in + p + (long long)km * a.es_in);
+				}
+			});
+		}
+	}
+
+	static DSP_HD float4 mul_h(float4 v, cf w)
+	{
+		float4 r;
+		r.x = v.x * w.x - v.y * w.y; r.y = v.x * w.y + v.y * w.x;
+		r.z = v.z * w.x - v.w * w.y; r.w = v.z * w.y + v.w * w.x;
+		return r;
+	}
+
+	template <int KIND, int PH, class ST>
+	static DSP_HD void phase(const PassArgs &a, float4 *buf, long long bout, int h, int tid, ST &st)
+	{
+		if constexpr (PH == 0) {
+			if constexpr (KIND == KIND_REDFT10) {
+				static_for<0, Y_ROUNDS>([&](auto i) {
+					const int it = tid + i * T;
+					if ((i + 1) * T <= M * NP || it < M * NP) {
+						const int n = it / NP, jp = it - n * NP;
+						float4 v = st.pre[i];
+						if (h) v = mul_h(v, a.H[n]);
+						buf[B::padded(n) * NP + jp] = v;
+					}
+				});
+			} else {
+				static_for<0, Q_ROUNDS>([&](auto i) {
+					const int it = tid + i * T;
+					if ((i + 1) * T <= NQ || it < NQ) {
+						const int q = it / NP, jp = it - q * NP;
+						if (h && q >= M / 2) return;
+						const int k = 2 * q + h, qm = partner(q, h);
+						float4 xk = st.pre[2 * i], xm = st.pre[2 * i + 1];
+						if (k == 0) { xk.x *= a.in_scale0; xk.y *= a.in_scale0; xk.z *= a.in_scale0; xk.w *= a.in_scale0; xm.x = xm.y = xm.z = xm.w = 0.f; }
+						const cf t = st.tw[i];
+						const cf Va0 = cmulc(cmk(xk.x, -xm.x), t), Vb0 = cmulc(cmk(xk.y, -xm.y), t);
+						const cf Va1 = cmulc(cmk(xk.z, -xm.z), t), Vb1 = cmulc(cmk(xk.w, -xm.w), t);
+						float4 lo, hi;
+						lo.x = Va0.x - Vb0.y; lo.y = -Va0.y - Vb0.x; lo.z = Va1.x - Vb1.y; lo.w = -Va1.y - Vb1.x;
+						hi.x = Va0.x + Vb0.y; hi.y = Va0.y - Vb0.x; hi.z = Va1.x + Vb1.y; hi.w = Va1.y - Vb1.x;
+						buf[B::padded(q) * NP + jp] = lo;
+						if (k > 0) buf[B::padded(qm) * NP + jp] = hi;
+					}
+				});
+			}
+		} else if constexpr (PH < NS) {
+			B::template stage<PH - 1>(a, buf, tid);
+		} else if constexpr (PH == NS) {
+			B::last_read(buf, st, tid);
+		} else if constexpr (PH == NS + 1) {
+			B::last_write(buf, st, tid);
+		} else {
+			if constexpr (KIND == KIND_REDFT10) {
+				static_for<0, Q_ROUNDS>([&](auto ri) {
+					const int it = tid + ri * T;
+					if (!((ri + 1) * T <= NQ || it < NQ)) return;
+					const int q = it / NP, jp = it - q * NP;
+					if (h && q >= M / 2) return;
+					const int k = 2 * q + h, km = k ? N - k : 0, qm = partner(q, h);
+					const float4 zk = buf[q * NP + jp], zm = buf[qm * NP + jp];
+					const cf t = a.T[k];
+					const cf A0 = cmk(zk.x + zm.x, zk.y - zm.y), B0 = cmul_mi(cmk(zk.x - zm.x, zk.y + zm.y));
+					const cf A1 = cmk(zk.z + zm.z, zk.w - zm.w), B1 = cmul_mi(cmk(zk.z - zm.z, zk.w + zm.w));
+					const cf wa0 = cmul(t, A0), wb0 = cmul(t, B0), wa1 = cmul(t, A1), wb1 = cmul(t, B1);
+					const float sc = a.scale, s0 = (k == 0) ? sc * a.out_scale0 : sc;
+					const long long o = bout + 4 * jp;
+					float4 r0; r0.x = wa0.x * s0; r0.y = wb0.x * s0; r0.z = wa1.x * s0; r0.w = wb1.x * s0;
+					*reinterpret_cast<float4 *>(a.out + o + (long long)k * a.es_out) = r0;
+					if (k > 0 && km != k) {
+						float4 r1; r1.x = -wa0.y * sc; r1.y = -wb0.y * sc; r1.z = -wa1.y * sc; r1.w = -wb1.y * sc;
+						*reinterpret_cast<float4 *>(a.out + o + (long long)km * a.es_out) = r1;
+					}
+				});
+			} else {
+				tloop<M * NP, T>(tid, [&](int it) {
+					const int n = it / NP, jp = it - n * NP;
+					float4 F = buf[n * NP + jp];
+					if (h) F = mul_h(F, a.H[n]);           // conj(w)^n O[n] = conj(w^n conj(O[n])); the conjugation is the sign below
+					const float sc = a.scale;
+					float4 r; r.x = F.x * sc; r.y = -F.y * sc; r.z = F.z * sc; r.w = -F.w * sc;
+					*reinterpret_cast<float4 *>(a.out + bout + (long long)row_of(n, h) * a.es_out + 4 * jp) = r;
 				});
 			}
 		}

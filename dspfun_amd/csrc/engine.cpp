@@ -84,10 +84,11 @@ int env_int(const char *name) { const char *e = getenv(name); return e ? atoi(e)
 struct Tables {
 	void *T = nullptr, *W = nullptr, *pos = nullptr, *cosTab = nullptr;
 	void *WM = nullptr, *chirp = nullptr, *Bhat = nullptr;     // Bluestein (BLUE passes)
+	void *H = nullptr;                                         // half-tile column passes: exp(-2 pi i n / N), n < N/2
 	void release()
 	{
-		be_free(T); be_free(W); be_free(pos); be_free(cosTab); be_free(WM); be_free(chirp); be_free(Bhat);
-		T = W = pos = cosTab = WM = chirp = Bhat = nullptr;
+		be_free(T); be_free(W); be_free(pos); be_free(cosTab); be_free(WM); be_free(chirp); be_free(Bhat); be_free(H);
+		T = W = pos = cosTab = WM = chirp = Bhat = H = nullptr;
 	}
 };
 
@@ -130,6 +131,12 @@ struct Pass {
 	PassGeom spa;              // ... with this geometry (used when the buffers are 16-B aligned)
 	SpecInfo spec;
 	int spec_nwg = 0;
+	// outer-radix-2 split of a long column axis (dct_spec.h ColHalfSpec): the row pass works on row pairs, the column pass on half tiles
+	bool pair = false, half = false;
+	int pair_id = -1;
+	SpecInfo hspec;
+	PassGeom hpa;
+	int half_nwg = 0;
 	std::vector<Dim> hostloop;
 	Tables tab;
 	std::string desc;
@@ -145,6 +152,8 @@ struct dspfft_plan_s {
 	bool f64;                  // samples are double (dspfft_plan_many_r2r_f64): generic kernels, double tables
 	double scale, in0[3], out0[3];
 	std::vector<Pass> passes;
+	std::vector<Pass> split;   // alternative pass list of dspfft_execute / dspfft_execute_pass (build_split); empty when not applicable
+	int split_col_axis = -1;
 	size_t alg_bytes;
 };
 
@@ -467,7 +476,7 @@ template <class R>
 void fill_args(PassArgsT<R> &a, const PassGeom &g, const dspfft_plan_s *pl, const Pass &P, const R *in, R *out, double scale, const Fuse &fz)
 {
 	static_cast<PassGeom &>(a) = g;
-	a.in = in; a.out = out; a.T = (const cx<R> *)P.tab.T; a.W = (const cx<R> *)P.tab.W;
+	a.in = in; a.out = out; a.T = (const cx<R> *)P.tab.T; a.W = (const cx<R> *)P.tab.W; a.H = (const cx<R> *)P.tab.H;
 	a.scale = (R)scale; a.in_scale0 = (R)pl->in0[P.axis]; a.out_scale0 = (R)pl->out0[P.axis];
 	a.mask = fz.mask; a.mask_id = fz.id; a.mask_div = make_div((uint32_t)fz.div); a.accumulate = fz.accumulate;
 }
@@ -499,6 +508,13 @@ int run_pass(const dspfft_plan_s *pl, const Pass &P, const R *in, R *out, bool l
 		} else {
 			bool use_spec = false;
 			if constexpr (std::is_same<R, float>::value) {
+				if (P.pair || P.half) {          // only reached through pick_passes(), which has checked alignment and scales
+					PassArgs a;
+					fill_args(a, P.pair ? P.spa : P.hpa, pl, P, in + oin, out + oout, scale, fz);
+					rc = P.pair ? be_launch_row_pair(P.pair_id, a, P.spec_nwg / 2, stream) : be_launch_col_half(P.hspec.id, a, P.half_nwg, stream);
+					if (rc) return fail(-4, "kernel launch failed (%s): backend code %d", P.desc.c_str(), rc);
+					return 0;
+				}
 				const bool ptr_ok = P.type == Pass::ROW
 					? ((P.pa.C == 2 ? 7u : P.pa.C == 4 ? 15u : 3u) & ((uintptr_t)(in + oin) | (uintptr_t)(out + oout))) == 0
 					: (15u & ((uintptr_t)(in + oin) | (uintptr_t)(out + oout))) == 0;
@@ -531,6 +547,75 @@ int run_pass(const dspfft_plan_s *pl, const Pass &P, const R *in, R *out, bool l
 
 }  // namespace
 
+namespace {
+// Outer radix-2 split of a long column axis for 2-D f32 plans whose two passes both have specialised kernels: the row pass
+// butterflies row pairs on its input, the column pass transforms half tiles of N/2 rows and twice the width (dct_spec.h,
+// ColHalfSpec).  REDFT10 along the columns runs row pass -> column pass (decimation in frequency), REDFT01 column pass ->
+// row pass (decimation in time), whatever order the plain plan uses.  DSPFFT_NO_SPLIT=1 disables it; DSPFFT_FORCE_SPLIT=1
+// applies it wherever the kernels exist (tests on small frames).
+void build_split(dspfft_plan_s *pl)
+{
+	if (pl->f64 || pl->rank != 2 || pl->passes.size() != 2 || env_int("DSPFFT_NO_SPLIT") == 1) return;
+	const Pass *R = nullptr, *Cc = nullptr;
+	for (const Pass &P : pl->passes) {
+		if (!P.has_spec || !P.hostloop.empty()) return;
+		if (P.type == Pass::ROW) R = &P; else if (P.type == Pass::COL) Cc = &P;
+	}
+	if (!R || !Cc) return;
+	const int N = Cc->pa.N, ca = Cc->axis, ra = R->axis;
+	const bool force = env_int("DSPFFT_FORCE_SPLIT") == 1;
+	if (N % 4 || (!force && Cc->spec.P >= 16)) return;
+	SpecInfo hs;
+	if (!be_find_half_spec(N, Cc->pa.ninner, &hs)) return;
+	// worth it when the half tiles are wider (64-B instead of 32-B row segments), or as wide in half the LDS (8K: two
+	// 69 KB workgroups per CU instead of one of 138 KB)
+	if (!force && !(hs.P > Cc->spec.P || 2 * hs.lds <= Cc->spec.lds + 4096)) return;
+	const int pid = be_find_row_pair(R->pa.N, R->pa.C);
+	if (pid < 0) return;
+	const bool col_first = pl->kinds[ca] == DSPFFT_REDFT01;
+	std::vector<Pass> sp(2);
+	Pass &PR = sp[col_first ? 1 : 0], &PC = sp[col_first ? 0 : 1];
+	auto drop = [&]() { for (Pass &P : sp) P.tab.release(); };
+	if (build_pass(pl, ra, !col_first, PR) || build_pass(pl, ca, col_first, PC)) { drop(); return; }
+	// the row pass's first batch dimension must be the split axis, line for line
+	const long long cis = col_first ? pl->axes[ca].os : pl->axes[ca].is, cos_ = pl->axes[ca].os;
+	if (PR.type != Pass::ROW || !PR.has_spec || !PR.hostloop.empty() || PR.spa.nb0 != N || PR.spa.sb0_in != cis || PR.spa.sb0_out != cos_ ||
+	    PC.type != Pass::COL || !PC.has_spec || !PC.hostloop.empty()) { drop(); return; }
+	char buf[256];
+	PR.pair = true; PR.pair_id = pid;
+	snprintf(buf, sizeof buf, "axis %d: ROW*2 N=%d C=%d row pairs of axis %d, spec#%d threads=%d pairs=%d lds=%zu", ra, PR.pa.N, PR.pa.C, ca, PR.spec.id, PR.spec.nthr, PR.spec_nwg / 2, PR.spec.lds);
+	PR.desc = buf;
+	// column pass: FFT of length N/2; T stays the table of the full length, W becomes the half length's, H = exp(-2 pi i n / N)
+	const int M = N / 2;
+	{
+		const long double pi = 3.14159265358979323846264338327950288L;
+		std::vector<cf> W(M), H(M);
+		for (int t = 0; t < M; t++) { W[t] = cmk<float>((float)cosl(2 * pi * t / M), (float)-sinl(2 * pi * t / M)); H[t] = cmk<float>((float)cosl(2 * pi * t / N), (float)-sinl(2 * pi * t / N)); }
+		be_free(PC.tab.W);
+		PC.tab.W = be_alloc(W.size() * sizeof(cf)); PC.tab.H = be_alloc(H.size() * sizeof(cf));
+		if (!PC.tab.W || !PC.tab.H || be_upload(PC.tab.W, W.data(), W.size() * sizeof(cf)) || be_upload(PC.tab.H, H.data(), H.size() * sizeof(cf))) { drop(); return; }
+	}
+	PC.half = true; PC.hspec = hs; PC.hpa = PC.spa;
+	PC.hpa.K = hs.P; PC.hpa.B = hs.P / 2; PC.hpa.ntiles = PC.pa.ninner / hs.P;
+	PC.half_nwg = 2 * PC.hpa.ntiles * PC.pa.nb0 * PC.pa.nb1;
+	snprintf(buf, sizeof buf, "axis %d: COL*/2 N=%d as 2 x %d, K=%d half#%d threads=%d inner=%d tiles=%d wgs=%d lds=%zu", ca, N, M, hs.P, hs.id, hs.nthr, PC.pa.ninner, 2 * PC.hpa.ntiles, PC.half_nwg, hs.lds);
+	PC.desc = buf;
+	pl->split = std::move(sp);
+	pl->split_col_axis = ca;
+}
+
+// which pass list an execution uses: the split one unless the buffers or the plan's per-index scales rule it out
+const std::vector<Pass> &pick_passes(const dspfft_plan_s *pl, const void *in, const void *out)
+{
+	if (pl->split.empty()) return pl->passes;
+	if (15u & ((uintptr_t)in | (uintptr_t)out)) return pl->passes;
+	const int ca = pl->split_col_axis;
+	// the row-pair butterfly mixes index 0 of the split axis with index N-1: scales on that index need the plain passes
+	if (pl->kinds[ca] == DSPFFT_REDFT10 ? pl->in0[ca] != 1.0 : pl->out0[ca] != 1.0) return pl->passes;
+	return pl->split;
+}
+}  // namespace
+
 static int plan_finish(dspfft_plan_s *pl, dspfft_plan *plan, bool first_axis_first)
 {
 	size_t samples = 1;
@@ -546,6 +631,7 @@ static int plan_finish(dspfft_plan_s *pl, dspfft_plan *plan, bool first_axis_fir
 		if (rc) { dspfft_destroy_plan(pl); return rc; }
 		first = false;
 	}
+	build_split(pl);
 	*plan = pl;
 	return 0;
 }
@@ -653,9 +739,10 @@ int execute_t(dspfft_plan pl, const R *d_in, R *d_out, void *stream)
 {
 	if (!pl || !d_in || !d_out) return fail(-1, "null plan or buffer");
 	if (pl->f64 != std::is_same<R, double>::value) return fail(-1, "plan and buffers differ in sample type (f32 plan <-> dspfft_execute, f64 plan <-> dspfft_execute_f64)");
-	for (size_t i = 0; i < pl->passes.size(); i++) {
-		const Pass &P = pl->passes[i];
-		int rc = run_pass<R>(pl, P, P.first ? d_in : d_out, d_out, i + 1 == pl->passes.size(), stream);
+	const std::vector<Pass> &passes = pick_passes(pl, d_in, d_out);
+	for (size_t i = 0; i < passes.size(); i++) {
+		const Pass &P = passes[i];
+		int rc = run_pass<R>(pl, P, P.first ? d_in : d_out, d_out, i + 1 == passes.size(), stream);
 		if (rc) return rc;
 	}
 	return 0;
@@ -831,14 +918,16 @@ extern "C" int dspfft_execute_pass(dspfft_plan pl, int index, const float *d_in,
 {
 	if (!pl || !d_in || !d_out || index < 0 || index >= (int)pl->passes.size()) return fail(-1, "bad plan, buffer or pass index");
 	if (pl->f64) return fail(-1, "dspfft_execute_pass takes f32 plans");
-	const Pass &P = pl->passes[index];
-	return run_pass<float>(pl, P, P.first ? d_in : d_out, d_out, index + 1 == (int)pl->passes.size(), stream);
+	const std::vector<Pass> &passes = pick_passes(pl, d_in, d_out);
+	const Pass &P = passes[index];
+	return run_pass<float>(pl, P, P.first ? d_in : d_out, d_out, index + 1 == (int)passes.size(), stream);
 }
 
 extern "C" void dspfft_destroy_plan(dspfft_plan pl)
 {
 	if (!pl) return;
 	for (Pass &P : pl->passes) P.tab.release();
+	for (Pass &P : pl->split) P.tab.release();
 	delete pl;
 }
 
@@ -846,7 +935,9 @@ extern "C" int dspfft_plan_describe(dspfft_plan pl, char *buf, size_t buflen)
 {
 	if (!pl || !buf || !buflen) return fail(-1, "bad arguments");
 	std::string s = std::string("backend ") + be_name() + "\n";
-	for (const Pass &P : pl->passes) { s += P.desc; if (!P.hostloop.empty()) s += " +hostloop"; s += "\n"; }
+	// a split plan lists the passes dspfft_execute runs; the plain ones (masked / fused executions, unaligned buffers) follow
+	for (const Pass &P : pl->split) { s += P.desc; s += "\n"; }
+	for (const Pass &P : pl->passes) { if (!pl->split.empty()) s += "plain "; s += P.desc; if (!P.hostloop.empty()) s += " +hostloop"; s += "\n"; }
 	snprintf(buf, buflen, "%s", s.c_str());
 	return 0;
 }

@@ -83,6 +83,72 @@ __global__ void __launch_bounds__(S::T, S::WPE) col_spec_kernel(const PassArgs a
 	});
 }
 
+// ---- outer radix-2 split of the column axis (dct_spec.h, ColHalfSpec) ----
+// ROW side: one workgroup per row PAIR (y1 = 2n, y2 = N-1-2n of the split axis, which is the row pass's batch dimension 0):
+// loads both lines, transforms (r1 + r2) into line y1 and (r1 - r2) into line y2.  The second line's samples wait in
+// registers while the first is transformed.
+// waves per SIMD to ask of the register allocator: as many workgroups as the line's LDS allows, capped at 6 (80 VGPRs) -- left
+// alone the allocator spends 115 VGPRs on the 3840-pixel pair kernel (plain: 56) and a third workgroup no longer fits a CU
+#ifndef DSP_PAIR_WPE_MAX
+#define DSP_PAIR_WPE_MAX 6
+#endif
+template <class S> constexpr int pair_waves_per_simd()
+{
+	const int wgs = (int)((160 * 1024) / S::LDS), w = wgs * S::T / 256;
+	return w < 1 ? 1 : w > DSP_PAIR_WPE_MAX ? DSP_PAIR_WPE_MAX : w;
+}
+template <class S, int KIND>
+__global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_kernel(const PassArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+	cf *planes = reinterpret_cast<cf *>(lds);
+	const int tid = threadIdx.x;
+	typename S::template State<KIND> st, st2;
+	const int pairs = a.nb0 >> 1;
+	const int i1 = blockIdx.x / pairs, n = blockIdx.x - i1 * pairs;
+	const int y1 = 2 * n, y2 = a.nb0 - 1 - 2 * n;
+	const long long bin1 = y1 * a.sb0_in + i1 * a.sb1_in, bin2 = y2 * a.sb0_in + i1 * a.sb1_in;
+	const long long bout1 = y1 * a.sb0_out + i1 * a.sb1_out, bout2 = y2 * a.sb0_out + i1 * a.sb1_out;
+	S::template prefetch_m<KIND, false>(a, bin1, tid, st, nullptr);
+	S::template prefetch_m<KIND, false>(a, bin2, tid, st2, nullptr);
+	constexpr int NPRE = (int)(sizeof(st.pre) / sizeof(float));
+	float cur[NPRE], diff[NPRE];
+	static_for<0, NPRE>([&](auto i) { const float p = st.pre[i], q = st2.pre[i]; cur[i] = p + q; diff[i] = p - q; });
+	// a real loop (not two copies of the phases) whose only loop-carried values are the waiting line's samples: the compiler
+	// otherwise hoists the second transform's index arithmetic and twiddle loads above the first, or carries the last stage's
+	// butterfly registers around the loop, and keeps them live across every barrier (133 / 115 VGPRs: a resident workgroup fewer)
+#pragma nounroll
+	for (int rep = 0; rep < 2; rep++) {
+		const long long bout = rep ? bout2 : bout1;
+		int t = tid; asm volatile("" : "+v"(t));
+		typename S::template State<KIND> w;
+		static_for<0, NPRE>([&](auto i) { w.pre[i] = cur[i]; });
+		static_for<0, S::NPH>([&](auto ph) {
+			S::template phase<KIND, ph, decltype(w), true>(a, planes, bout, t, w);
+			__syncthreads();
+		});
+		static_for<0, NPRE>([&](auto i) { cur[i] = diff[i]; });
+	}
+}
+
+// COL side: one workgroup per half tile (N/2 rows x K floats)
+template <class S, int KIND>
+__global__ void __launch_bounds__(S::T, S::WPE) col_half_kernel(const PassArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+	float4 *buf = reinterpret_cast<float4 *>(lds);
+	const int tid = threadIdx.x;
+	typename S::template State<KIND> st;
+	long long bin, bout;
+	int h;
+	S::base(a, blockIdx.x, bin, bout, h);
+	S::template prefetch<KIND>(a, bin, h, tid, st);
+	static_for<0, S::NPH>([&](auto ph) {
+		S::template phase<KIND, ph>(a, buf, bout, h, tid, st);
+		if constexpr (ph + 1 < S::NPH) __syncthreads();
+	});
+}
+
 // forward REDFT10 -> motion filter -> inverse REDFT01 along the tile's axis in one launch: the tile is read once and
 // written once instead of three times each (forward store + filter read/write + inverse load saved)
 struct FilterOp {
@@ -161,6 +227,24 @@ int launch_col_spec(const PassArgs &a, int nwork, void *stream)
 	static int lds_ok = allow_lds(col_spec_kernel<S, KIND>, S::LDS);
 	if (lds_ok) return lds_ok;
 	hipLaunchKernelGGL((col_spec_kernel<S, KIND>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+template <class S, int KIND>
+int launch_row_pair(const PassArgs &a, int npairs, void *stream)
+{
+	static int lds_ok = allow_lds(row_pair_kernel<S, KIND>, S::LDS);
+	if (lds_ok) return lds_ok;
+	hipLaunchKernelGGL((row_pair_kernel<S, KIND>), dim3(npairs), dim3(S::T), S::LDS, (hipStream_t)stream, a);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+template <class S, int KIND>
+int launch_col_half(const PassArgs &a, int nwork, void *stream)
+{
+	static int lds_ok = allow_lds(col_half_kernel<S, KIND>, S::LDS);
+	if (lds_ok) return lds_ok;
+	hipLaunchKernelGGL((col_half_kernel<S, KIND>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a);
 	HIPCHK(hipGetLastError());
 	return 0;
 }

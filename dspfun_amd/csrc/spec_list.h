@@ -48,3 +48,19 @@
 	X(480, 16, 256, 4, 8, 15)
 
 #define DSPFFT_COL_SPECS(X) DSPFFT_COL_SPECS_A(X) DSPFFT_COL_SPECS_B(X)
+
+// Column passes split by an outer radix 2 (ColHalfSpec): X(N, K, THREADS, radices of N/2 ...).  A plan uses them (with the
+// paired row pass) when the full-length tile would have to be narrower than 16 floats; the entries marked "forced only"
+// exist for the CPU/GPU tests of the mechanism on small frames (DSPFFT_FORCE_SPLIT=1).
+#define DSPFFT_COL_HALF_SPECS(X) \
+	X(2160, 16, 512, 8, 9, 15) \
+	X(4320, 8, 512, 12, 12, 15) \
+	X(1080, 16, 256, 4, 9, 15)   /* forced only */ \
+	X(512, 16, 256, 4, 4, 16)    /* forced only */
+
+// row specs (N, C) that also get the paired kernel
+#define DSPFFT_ROW_PAIR_SPECS(X) \
+	X(3840, 3, 512, 12, 10, 16) \
+	X(7680, 3, 1024, 16, 15, 16) \
+	X(1920, 3, 256, 4, 15, 16) \
+	X(512, 3, 64, 16, 16)

@@ -189,6 +189,46 @@ int launch_row_spec_u8(const PassArgs &a, const U8IO &io, int nwork, void *)
 	}
 	return 0;
 }
+template <class S, int KIND>
+int launch_row_pair(const PassArgs &a, int npairs, void *)
+{
+	std::vector<unsigned char> lds(S::LDS + 16);
+	cf *planes = (cf *)lds.data();
+	const int pairs = a.nb0 >> 1;
+	for (int wg = 0; wg < npairs; wg++) {
+		std::vector<typename S::template State<KIND>> st(S::T), st2(S::T);
+		const int i1 = wg / pairs, n = wg - i1 * pairs;
+		const int y1 = 2 * n, y2 = a.nb0 - 1 - 2 * n;
+		const long long bin1 = y1 * a.sb0_in + i1 * a.sb1_in, bin2 = y2 * a.sb0_in + i1 * a.sb1_in;
+		const long long bout1 = y1 * a.sb0_out + i1 * a.sb1_out, bout2 = y2 * a.sb0_out + i1 * a.sb1_out;
+		constexpr int NPRE = (int)(sizeof(st[0].pre) / sizeof(float));
+		for (int tid = 0; tid < S::T; tid++) {
+			for (int i = 0; i < NPRE; i++) st[tid].pre[i] = st2[tid].pre[i] = 0.f;
+			S::template prefetch_m<KIND, false>(a, bin1, tid, st[tid], nullptr);
+			S::template prefetch_m<KIND, false>(a, bin2, tid, st2[tid], nullptr);
+			for (int i = 0; i < NPRE; i++) { const float p = st[tid].pre[i], q = st2[tid].pre[i]; st[tid].pre[i] = p + q; st2[tid].pre[i] = p - q; }
+		}
+		typedef typename S::template State<KIND> ST;
+		static_for<0, S::NPH>([&](auto ph) { for (int tid = 0; tid < S::T; tid++) S::template phase<KIND, ph, ST, true>(a, planes, bout1, tid, st[tid]); });
+		for (int tid = 0; tid < S::T; tid++) for (int i = 0; i < NPRE; i++) st[tid].pre[i] = st2[tid].pre[i];
+		static_for<0, S::NPH>([&](auto ph) { for (int tid = 0; tid < S::T; tid++) S::template phase<KIND, ph, ST, true>(a, planes, bout2, tid, st[tid]); });
+	}
+	return 0;
+}
+template <class S, int KIND>
+int launch_col_half(const PassArgs &a, int nwork, void *)
+{
+	std::vector<unsigned char> lds(S::LDS + 32);
+	float4 *buf = (float4 *)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
+	for (int wg = 0; wg < nwork; wg++) {
+		std::vector<typename S::template State<KIND>> st(S::T);
+		long long bin, bout; int h;
+		S::base(a, wg, bin, bout, h);
+		for (int tid = 0; tid < S::T; tid++) S::template prefetch<KIND>(a, bin, h, tid, st[tid]);
+		static_for<0, S::NPH>([&](auto ph) { for (int tid = 0; tid < S::T; tid++) S::template phase<KIND, ph>(a, buf, bout, h, tid, st[tid]); });
+	}
+	return 0;
+}
 struct FilterOp {
 	MotionFilter p;
 	float4 operator()(long long e, float4 v, unsigned long long &coded) const { return p.enabled ? motion_filter4(p, (uint32_t)e, v, coded) : v; }

@@ -1,0 +1,88 @@
+"""CPU: the outer-radix-2 split of a long column axis (dct_spec.h ColHalfSpec + row_pair_kernel; engine.cpp build_split) on the
+test-only emulation backend, against the oracle.  DSPFFT_FORCE_SPLIT=1 applies the split wherever the kernels exist, so the
+mechanism is checked on frames small enough for the emulation; the natural case (3840x2160, 7680x4320) runs in the GPU tests."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from dspfun_amd.engine import Plan, REDFT10, REDFT01
+from emul_lib import emul
+
+TOL = 2e-6
+
+
+@pytest.fixture()
+def forced():
+    os.environ["DSPFFT_FORCE_SPLIT"] = "1"
+    yield
+    del os.environ["DSPFFT_FORCE_SPLIT"]
+
+
+def relerr(got, ref):
+    return np.abs(got.astype(np.float64) - ref).max() / np.abs(ref).max()
+
+
+@pytest.mark.parametrize("h,w", [(512, 512), (1080, 1920)])
+def test_forced_split_forward_inverse_vs_oracle(forced, h, w):
+    c = 3
+    x = ol.synth_f32(0xD5F0002, h * w * c).reshape(h, w, c)
+    fwd = Plan.image(h, w, c, REDFT10, lib=emul())
+    inv = Plan.image(h, w, c, REDFT01, lib=emul()).set_scale(1.0 / (4 * w * h))
+    df, di = fwd.describe().splitlines(), inv.describe().splitlines()
+    # REDFT10 runs row pairs first, REDFT01 half tiles first; the plain passes stay available
+    assert df[1].startswith("axis 1: ROW*2") and df[2].startswith("axis 0: COL*/2") and df[3].startswith("plain axis 1"), df
+    assert di[1].startswith("axis 0: COL*/2") and di[2].startswith("axis 1: ROW*2"), di
+    ref = ol.dct2d_interleaved(x.astype(np.float64), REDFT10, impl="port", threads=4)
+    d = x.copy()
+    fwd.execute(d.ctypes.data)
+    assert relerr(d, ref) < TOL
+    inv.execute(d.ctypes.data)
+    assert np.abs(d - x).max() < 5e-6
+    # the inverse alone on the oracle's coefficients, out of place
+    co = ref.astype(np.float32)
+    out = np.zeros_like(co)
+    keep = co.copy()
+    inv.execute(co.ctypes.data, out.ctypes.data)
+    assert np.abs(out - x).max() < 5e-6 and np.array_equal(co, keep)
+
+
+def test_split_and_plain_agree_and_fallbacks(forced):
+    h, w, c = 512, 512, 3
+    x = ol.synth_f32(7, h * w * c).reshape(h, w, c)
+    sp = Plan.image(h, w, c, REDFT10, lib=emul())
+    os.environ["DSPFFT_NO_SPLIT"] = "1"
+    try:
+        pl = Plan.image(h, w, c, REDFT10, lib=emul())
+    finally:
+        del os.environ["DSPFFT_NO_SPLIT"]
+    assert "COL*/2" in sp.describe() and "COL*/2" not in pl.describe()
+    a, b = x.copy(), x.copy()
+    sp.execute(a.ctypes.data)
+    pl.execute(b.ctypes.data)
+    assert np.abs(a - b).max() / np.abs(b).max() < 1e-6
+    # a scale on index 0 of the split axis' INPUT (REDFT10) cannot ride on the row-pair butterfly: the plain passes run
+    sp.set_axis_scale0(0, 0.5, 1.0)
+    pl.set_axis_scale0(0, 0.5, 1.0)
+    a, b = x.copy(), x.copy()
+    sp.execute(a.ctypes.data)
+    pl.execute(b.ctypes.data)
+    assert np.array_equal(a, b)
+    # per-pass execution walks the same list as execute()
+    sp.set_axis_scale0(0, 1.0, 0.25)
+    pl.set_axis_scale0(0, 1.0, 0.25)
+    a, b = x.copy(), x.copy()
+    for i in range(sp.num_passes):
+        sp.execute_pass(i, a.ctypes.data)
+    pl.execute(b.ctypes.data)
+    assert np.abs(a - b).max() / np.abs(b).max() < 1e-6
+
+
+def test_split_is_not_used_where_it_does_not_apply():
+    # default policy: only when the full-length column tile would be narrower than 16 floats (here it is not)
+    assert "COL*/2" not in Plan.image(512, 512, 3, REDFT10, lib=emul()).describe()
+    d = Plan.image(2160, 3840, 3, REDFT10, lib=emul()).describe()
+    assert "ROW*2 N=3840" in d and "COL*/2 N=2160 as 2 x 1080, K=16" in d
+    d = Plan.image(4320, 7680, 3, REDFT01, lib=emul()).describe()
+    assert d.splitlines()[1].startswith("axis 0: COL*/2 N=4320 as 2 x 2160, K=8")

@@ -40,6 +40,14 @@ __global__ void __launch_bounds__(S::T, S::WPE) pass_k(const PassArgs a)
 	});
 }
 
+#ifdef SPLIT
+#include <hip/hip_runtime.h>
+#include "backend.h"
+#include "spec_list.h"
+#include "spec_kernels.h"
+typedef ColHalfSpec<2160, 16, 512, 8, 9, 15> HS;
+static cf *g_WM, *g_Hh;
+#endif
 static const int H = 2160, W = 3840, C = 3;
 static const size_t NF = (size_t)H * W * C;
 static const int NFR = 4;
@@ -70,6 +78,21 @@ static void launch_pass(int p, int f0, int nfr, hipStream_t s)
 	const bool row = (p == 0 || p == 3);
 	a.kind = (p <= 1) ? KIND_REDFT10 : KIND_REDFT01;
 	a.scale = (p <= 1) ? 1.f : (row ? 1.f / (2.f * W) : 1.f / (2.f * H));
+#ifdef SPLIT
+	if (row) {
+		a.N = W; a.C = C; a.nb0 = H; a.nb1 = nfr; a.sb0_in = a.sb0_out = (long long)W * C; a.sb1_in = a.sb1_out = (long long)NF;
+		a.T = g_trow.T; a.W = g_trow.Wt;
+		if (p == 0) hipLaunchKernelGGL((row_pair_kernel<RS, KIND_REDFT10>), dim3(H / 2 * nfr), dim3(RS::T), RS::LDS, s, a);
+		else hipLaunchKernelGGL((row_pair_kernel<RS, KIND_REDFT01>), dim3(H / 2 * nfr), dim3(RS::T), RS::LDS, s, a);
+	} else {
+		a.N = H; a.K = HS::K; a.B = HS::K / 2; a.ninner = W * C; a.ntiles = W * C / HS::K; a.es_in = a.es_out = (long long)W * C;
+		a.nb0 = nfr; a.nb1 = 1; a.sb0_in = a.sb0_out = (long long)NF;
+		a.T = g_tcol.T; a.W = g_WM; a.H = g_Hh;
+		if (p == 1) hipLaunchKernelGGL((col_half_kernel<HS, KIND_REDFT10>), dim3(2 * a.ntiles * nfr), dim3(HS::T), HS::LDS, s, a);
+		else hipLaunchKernelGGL((col_half_kernel<HS, KIND_REDFT01>), dim3(2 * a.ntiles * nfr), dim3(HS::T), HS::LDS, s, a);
+	}
+	return;
+#endif
 	if (row) {
 		a.N = W; a.C = C; a.nb0 = H; a.nb1 = nfr; a.sb0_in = a.sb0_out = (long long)W * C; a.sb1_in = a.sb1_out = (long long)NF;
 		a.T = g_trow.T; a.W = g_trow.Wt;
@@ -161,6 +184,20 @@ int main(int argc, char **argv)
 		for (int f = 0; f < NFR; f++) CHK(hipMemcpy(g_buf + (size_t)f * NF, h.data(), NF * 4, hipMemcpyHostToDevice));
 	}
 	g_trow = make_tables(W, W / 2); g_tcol = make_tables(H, H);
+#ifdef SPLIT
+	{
+		const int M = H / 2;
+		std::vector<cf> Wv(M), Hv(M);
+		for (int t = 0; t < M; t++) { Wv[t] = cmk((float)cos(2 * M_PI * t / M), (float)-sin(2 * M_PI * t / M)); Hv[t] = cmk((float)cos(2 * M_PI * t / H), (float)-sin(2 * M_PI * t / H)); }
+		CHK(hipMalloc(&g_WM, M * 8)); CHK(hipMalloc(&g_Hh, M * 8));
+		CHK(hipMemcpy(g_WM, Wv.data(), M * 8, hipMemcpyHostToDevice)); CHK(hipMemcpy(g_Hh, Hv.data(), M * 8, hipMemcpyHostToDevice));
+		CHK(hipFuncSetAttribute((const void *)row_pair_kernel<RS, KIND_REDFT10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RS::LDS));
+		CHK(hipFuncSetAttribute((const void *)row_pair_kernel<RS, KIND_REDFT01>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RS::LDS));
+		CHK(hipFuncSetAttribute((const void *)col_half_kernel<HS, KIND_REDFT10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HS::LDS));
+		CHK(hipFuncSetAttribute((const void *)col_half_kernel<HS, KIND_REDFT01>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HS::LDS));
+		printf("SPLIT build: row pairs + half tiles %dx%d (LDS %zu B)\n", HS::M, HS::K, (size_t)HS::LDS);
+	}
+#endif
 	CHK(hipStreamCreateWithFlags(&sA, hipStreamNonBlocking)); CHK(hipStreamCreateWithFlags(&sB, hipStreamNonBlocking));
 	for (int i = 0; i < 8; i++) { CHK(hipEventCreateWithFlags(&evA[i], hipEventDisableTiming)); CHK(hipEventCreateWithFlags(&evB[i], hipEventDisableTiming)); CHK(hipEventRecord(evA[i], sA)); CHK(hipEventRecord(evB[i], sB)); }
 	CHK(hipEventCreateWithFlags(&evStepA, hipEventDisableTiming)); CHK(hipEventCreateWithFlags(&evStepB, hipEventDisableTiming));
@@ -170,6 +207,17 @@ int main(int argc, char **argv)
 	CHK(hipFuncSetAttribute((const void *)pass_k<CS, KIND_REDFT10, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CS::LDS));
 	CHK(hipFuncSetAttribute((const void *)pass_k<CS, KIND_REDFT01, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CS::LDS));
 	printf("ROW LDS %zu B (%.2f granules of 1280), COL LDS %zu B (%.2f granules); %d steps of %d frames\n", (size_t)RS::LDS, RS::LDS / 1280.0, (size_t)CS::LDS, CS::LDS / 1280.0, steps, NFR);
+	{	// each pass alone, one frame (cache-resident)
+		for (int p = 0; p < 4; p++) {
+			for (int i = 0; i < 3; i++) launch_pass(p, 0, 1, sA);
+			hipEvent_t a, b; CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
+			CHK(hipEventRecord(a, sA));
+			for (int i = 0; i < 30; i++) launch_pass(p, 0, 1, sA);
+			CHK(hipEventRecord(b, sA)); CHK(hipEventSynchronize(b));
+			float ms; CHK(hipEventElapsedTime(&ms, a, b));
+			printf("pass %d alone: %.1f us\n", p, ms * 1000 / 30);
+		}
+	}
 	const char *modes[] = {"single", "aligned", "free", "lag1", "lag2", "lockstep", "pipe", "batch2", "batch4"};
 	for (int round = 0; round < 3; round++) {
 		printf("round %d:", round);
