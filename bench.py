@@ -28,6 +28,7 @@ H, W, C = 2160, 3840, 3
 ALG_BYTES_PER_PIXEL = 48.0        # 16 B/sample roundtrip = 48 B/pixel
 HBM_PEAK = 8.0e12                 # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy ceiling)
 SEED = 0xD5F0002
+DRIFT_BOUND = 1e-3                # |frame - input| after every roundtrip of the run (one roundtrip: <= 5e-6, tests/test_gpu_parity.py)
 
 
 def synth_frames(torch, nframes, device):
@@ -93,7 +94,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--frames", type=int, default=4, help="independent frames per GPU per step")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("BENCH_STREAMS", "2")), help="HIP streams the independent frames are spread over")
-    ap.add_argument("--schedule", choices=["auto", "free", "aligned"], default="aligned", help="how two streams interleave their frames (see step())")
+    ap.add_argument("--schedule", choices=["auto", "free", "aligned"], default="free", help="how two streams interleave their frames (see step())")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -135,41 +136,34 @@ def main():
     side = [torch.cuda.Stream(device=dev) for _ in range(nstreams)] if nstreams > 1 else []
     handles = [s_.cuda_stream for s_ in side] if side else [stream]
 
-    passes = [(fwd, i) for i in range(fwd.num_passes)] + [(inv, i) for i in range(inv.num_passes)]
-    npass = len(passes)
-    # HIP events bracket the launches of ONE frame per step inside the timed region (on the stream the kernel is
-    # launched on), rotating through the frames of the step, so the in-region average per kernel samples every
-    # position in the step -- the population rocprofv3 averages -- at a quarter of the event traffic (events on every
-    # launch were measured to cost 7 % of the throughput)
-    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(npass)] for _ in range(args.steps)]
-    tstreams = side if side else [torch.cuda.current_stream()]
+    from dspfun_amd.engine import Batch, Events
+    npass = fwd.num_passes + inv.num_passes
+    # One step = ONE call into the library (dspfft_execute_many: frame f -> forward plan, inverse plan, on stream f mod nstreams), so
+    # the Python binding costs one ctypes call per step instead of one per pass (measured: 16 ctypes calls + 8 torch event records
+    # per 290-us step left the GPU waiting for the host -- the same launches from C ran 3-5 % faster, tools/sbench.hip).
+    # Events of the library bracket the passes of ONE frame per step inside the timed region (on the stream the kernels are launched
+    # on), rotating through the frames, so the in-region average per kernel samples every position in the step -- the population
+    # rocprofv3 averages -- at a quarter of the event traffic.
+    batch = Batch([(pl_, p, None, handles[i % len(handles)]) for i, p in enumerate(ptrs) for pl_ in (fwd, inv)])
+    events = Events(2 * npass * args.steps)
 
-    # Two schedules for the frames of a step on two streams.  "free": each stream runs its frames back to back.
-    # "aligned" (default): the streams start every STEP together (each waits for the other's previous step), which
-    # keeps kernels of the same pass shape overlapping.  Measured on this pool's MI355X boxes: free-running reaches
-    # 53-54K Mpix/s while the two streams sit in a favourable interleave, but falls to 42-44K (no better than one
-    # stream) when they drift into an unfavourable one -- per box, per process and sometimes within a run; aligned
-    # gives 50-51K every time.  "auto" times both for a moment (untimed) and keeps the faster.
+    # Schedules of the frames of a step on two streams.  "free" (default): each stream runs its frames back to back, so one
+    # stream's kernel tails and ramps are filled by the other stream's kernels (58-59K Mpix/s from C, steady over rounds).
+    # "aligned": the streams start every STEP together (each waits for the other's previous step), which keeps kernels of the
+    # same pass shape overlapping (56-57K).  Round 1 preferred "aligned" because "free" was erratic (42-54K) -- that was the
+    # host: with a ctypes call per pass the streams ran dry at random moments.  "auto" times both for a moment and keeps the faster.
     sched = {"aligned": False, "last": [None] * max(1, nstreams)}
 
     def step(k=None):
         if sched["aligned"]:
-            # the streams start the step together: each waits for the others' work of the previous step
             for a_ in range(len(side)):
                 for b_ in range(len(side)):
                     if a_ != b_ and sched["last"][b_] is not None:
                         side[a_].wait_event(sched["last"][b_])
-        for i, p in enumerate(ptrs):
-            h_ = handles[i % len(handles)]
-            if k is None or i != k % len(ptrs):
-                fwd.execute(p, stream=h_)
-                inv.execute(p, stream=h_)
-            else:
-                ts = tstreams[i % len(tstreams)]
-                for j, (plan, idx) in enumerate(passes):
-                    ev[k][j][0].record(ts)
-                    plan.execute_pass(idx, p, stream=h_)
-                    ev[k][j][1].record(ts)
+        if k is None:
+            batch.run()
+        else:
+            batch.run(timed_item=2 * (k % len(ptrs)), timed_count=2, events=events, event_offset=2 * npass * k)
         if sched["aligned"]:
             for a_ in range(len(side)):
                 e_ = torch.cuda.Event()
@@ -219,7 +213,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    in_region_ms = [sum(ev[k][j][0].elapsed_time(ev[k][j][1]) for k in range(args.steps)) / args.steps for j in range(npass)]
+    in_region_ms = [sum(events.elapsed_ms(2 * npass * k + 2 * j, 2 * npass * k + 2 * j + 1) for k in range(args.steps)) / args.steps for j in range(npass)]
 
     # sanity of what was timed: after (warmup+steps) consecutive in-place roundtrips the frame is still the input
     # (single-roundtrip accuracy is what tests/test_gpu_parity.py pins: <= 5e-6)
@@ -247,15 +241,22 @@ def main():
         # algorithmic bytes of ONE launch: the 48 B/pixel roundtrip figure is 4 axis passes of 12 B/pixel each
         alg = H * W * ALG_BYTES_PER_PIXEL / 4.0
         achieved = alg / (in_region_ms[k] * 1e-3)
-        traffic = None
+        # PMC traffic is not measured by this run (rocprofv3 --pmc needs its own passes: tools/pmc_traffic.sh); it is looked up
+        # in profiles/traffic.json by the KIND of the dominant pass and dropped when that file does not describe the kernels this
+        # plan runs (its "plan" field must equal the forward plan's description)
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("dominant_kernel_hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                key = ("row" if " ROW" in names[k] else "col") + "_" + names[k].split()[0]
+                if tj.get("plan") == [ln.strip() for ln in fwd.describe().splitlines() if ln.startswith("axis")]:
+                    traffic = tj.get("hbm_bytes_per_launch", {}).get(key)
+                    traffic_source = f"profiles/traffic.json ({tj.get('round', '?')}), key {key}"
             except Exception:
                 traffic = None
         roof = {"bound": "hbm", "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": names[k], "kernel_ms": round(in_region_ms[k], 5),
                 "all_kernels_ms": {names[i]: round(in_region_ms[i], 5) for i in range(npass)},
                 "algorithmic_bytes_per_launch": alg,
@@ -282,10 +283,25 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
+        # a run whose frames no longer equal the input after all the roundtrips did not time the transform: no headline number
+        bad = not (drift <= DRIFT_BOUND)
+        if bad:
+            line["value"] = None
+            line["error"] = f"max_abs_drift_after_all_roundtrips {drift} exceeds {DRIFT_BOUND}"
         print(json.dumps(line), flush=True)
+        status = 1 if bad else 0
+    else:
+        status = 0
+    if dist is not None:
+        st_ = torch.tensor([status], dtype=torch.int32, device=dev)
+        dist.broadcast(st_, src=0)
+        status = int(st_.item())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if status:
+        print("bench.py: the frames drifted from the input; see the JSON line", file=sys.stderr)
+        sys.exit(1)
 
 
 if __name__ == "__main__":

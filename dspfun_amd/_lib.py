@@ -17,6 +17,7 @@ SYMBOLS = [
     "dspfft_plan_many_r2r_f64", "dspfft_plan_set_scale_f64", "dspfft_plan_set_axis_scale0_f64", "dspfft_execute_f64", "dspfft_execute_masked_accumulate_f64",
     "dspfft_plan_many_r2r_ordered", "dspfft_plan_guru_r2r", "dspfft_execute_roundtrip", "dspfft_execute_roundtrip_u8",
     "dspfft_execute", "dspfft_plan_num_passes", "dspfft_execute_pass", "dspfft_destroy_plan", "dspfft_plan_describe", "dspfft_plan_algorithmic_bytes",
+    "dspfft_execute_many", "dspfft_event_create", "dspfft_event_destroy", "dspfft_event_synchronize", "dspfft_event_elapsed_ms",
     "dspfft_last_error", "dspfft_version",
     "dspfft_scan_zigzag", "dspfft_scan_zigzag_frame_ids", "dspfft_execute_masked_accumulate", "dspfft_scan_scatter", "dspfft_accumulate", "dspfft_broadcast_dc",
     "dspfft_u8_to_f32", "dspfft_f32_to_u8",
@@ -49,6 +50,13 @@ def bind(lib):
     lib.dspfft_plan_set_scale.argtypes = [vp, C.c_float]
     lib.dspfft_plan_set_axis_scale0.argtypes = [vp, C.c_int, C.c_float, C.c_float]
     lib.dspfft_execute.argtypes = [vp, vp, vp, vp]
+    lib.dspfft_execute_many.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.POINTER(vp)]
+    lib.dspfft_event_create.restype = vp
+    lib.dspfft_event_create.argtypes = []
+    lib.dspfft_event_destroy.argtypes = [vp]
+    lib.dspfft_event_destroy.restype = None
+    lib.dspfft_event_synchronize.argtypes = [vp]
+    lib.dspfft_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(C.c_float)]
     lib.dspfft_plan_many_r2r_f64.argtypes = lib.dspfft_plan_many_r2r.argtypes
     lib.dspfft_plan_many_r2r_ordered.argtypes = lib.dspfft_plan_many_r2r.argtypes + [C.c_int]
     lib.dspfft_plan_guru_r2r.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(IoDim), C.c_int, C.POINTER(IoDim), ip, C.c_int]

@@ -45,6 +45,13 @@ int be_launch_spec_u8(int row_spec_id, const PassArgs &a, const U8IO &io, int nw
 // fused column roundtrip: REDFT10 along the tile axis (af), pointwise filter, REDFT01 (ai); both passes share spec `id`
 int be_launch_roundtrip(int id, const PassArgs &af, const PassArgs &ai, const MotionFilter &filt, unsigned long long *coded, int nwg, void *stream);
 
+// timing events on a stream (dspfft_execute_many's profiling aid); the emulation backend has none (elapsed = 0)
+void *be_event_create();
+void be_event_destroy(void *e);
+int be_event_record(void *e, void *stream);
+int be_event_synchronize(void *e);
+int be_event_elapsed_ms(void *a, void *b, float *ms);
+
 // outer-radix-2 split of a long column axis (dct_spec.h ColHalfSpec): half-tile column kernels for length N whose inner extent is
 // a multiple of the tile width, and the paired row kernel of row spec (N, C); be_find_row_pair returns an id or -1
 bool be_find_half_spec(int N, int inner, SpecInfo *info);

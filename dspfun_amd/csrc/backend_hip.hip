@@ -191,6 +191,11 @@ __global__ void f32_to_u8_kernel(uint8_t *d, const float *s, double mul, uint64_
 void *be_alloc(size_t bytes) { void *p = nullptr; if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return nullptr; return p; }
 void be_free(void *p) { if (p) (void)hipFree(p); }
 int be_upload(void *dst, const void *src, size_t bytes) { HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return 0; }
+void *be_event_create() { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return nullptr; return (void *)e; }
+void be_event_destroy(void *e) { if (e) (void)hipEventDestroy((hipEvent_t)e); }
+int be_event_record(void *e, void *stream) { HIPCHK(hipEventRecord((hipEvent_t)e, (hipStream_t)stream)); return 0; }
+int be_event_synchronize(void *e) { HIPCHK(hipEventSynchronize((hipEvent_t)e)); return 0; }
+int be_event_elapsed_ms(void *a, void *b, float *ms) { HIPCHK(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b)); return 0; }
 size_t be_max_lds() { return 160 * 1024; }
 const char *be_name() { return "hip-gfx950"; }
 

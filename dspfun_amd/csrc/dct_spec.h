@@ -688,7 +688,9 @@ struct ColHalfSpec {
 	static constexpr size_t LDS = B::LDS;
 	static constexpr int Y_ROUNDS = B::Y_ROUNDS, Q_ROUNDS = B::K_ROUNDS, NQ = (M / 2 + 1) * NP;
 	static_assert(N_ % 4 == 0, "half tiles need N divisible by 4");
-	template <int KIND> using State = typename B::template State<KIND>;
+	template <int KIND> struct State : B::template State<KIND> {
+		cf hw[KIND == KIND_REDFT10 ? Y_ROUNDS : 1];       // REDFT10, half 1: w^n of this thread's rows
+	};
 
 	// image row of tile row n in half h
 	static DSP_HD int row_of(int n, int h) { return h ? N - 1 - 2 * n : 2 * n; }
@@ -717,6 +719,12 @@ struct ColHalfSpec {
 					const int n = it / NP, jp = it - n * NP;
 					st.pre[i] = *reinterpret_cast<const float4 *>(a.in + bin + (long long)row_of(n, h) * a.es_in + 4 * jp);
 				}
+			});
+			// half 1: the twiddles w^n of this thread's rows, fetched behind the data so their latency hides under it (rows n .. n + T/NP
+			// apart share nothing, but the 8.6 KB table stays in L1/L2)
+			if (h) static_for<0, Y_ROUNDS>([&](auto i) {
+				const int it = tid + i * T;
+				if ((i + 1) * T <= M * NP || it < M * NP) st.hw[i] = a.H[it / NP];
 			});
 		} else {
 			static_for<0, Q_ROUNDS>([&](auto i) {
@@ -752,7 +760,7 @@ struct ColHalfSpec {
 					if ((i + 1) * T <= M * NP || it < M * NP) {
 						const int n = it / NP, jp = it - n * NP;
 						float4 v = st.pre[i];
-						if (h) v = mul_h(v, a.H[n]);
+						if (h) v = mul_h(v, st.hw[i]);
 						buf[B::padded(n) * NP + jp] = v;
 					}
 				});

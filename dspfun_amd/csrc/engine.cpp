@@ -564,12 +564,15 @@ void build_split(dspfft_plan_s *pl)
 	if (!R || !Cc) return;
 	const int N = Cc->pa.N, ca = Cc->axis, ra = R->axis;
 	const bool force = env_int("DSPFFT_FORCE_SPLIT") == 1;
-	if (N % 4 || (!force && Cc->spec.P >= 16)) return;
+	if (N % 4) return;
 	SpecInfo hs;
 	if (!be_find_half_spec(N, Cc->pa.ninner, &hs)) return;
-	// worth it when the half tiles are wider (64-B instead of 32-B row segments), or as wide in half the LDS (8K: two
-	// 69 KB workgroups per CU instead of one of 138 KB)
-	if (!force && !(hs.P > Cc->spec.P || 2 * hs.lds <= Cc->spec.lds + 4096)) return;
+	// Used when the full-length tile fills a CU's LDS on its own (8K: 4320 rows x 8 floats = 138 KB, one workgroup per CU) and the
+	// half tiles fit twice: measured 935 vs 1027 us per 7680x4320x3 roundtrip.  At 3840x2160 the half tiles are wider instead
+	// (1080 x 16 floats, 64-B row segments: column passes 42-45 us instead of 46-49) but the paired row pass loses more than that
+	// (2 rows per workgroup in sequence, 2 workgroups per CU: 52-55 us instead of 37-39) -- 58.3K vs 58.6K Mpix/s on two streams,
+	// 41.4K vs 48.9K on one (tools/sbench.hip, tools/bench_8k_split.py; profiles/r02_split.txt) -- so 4K keeps the plain passes.
+	if (!force && !(Cc->spec.lds > 80 * 1024 && 2 * hs.lds <= Cc->spec.lds + 4096)) return;
 	const int pid = be_find_row_pair(R->pa.N, R->pa.C);
 	if (pid < 0) return;
 	const bool col_first = pl->kinds[ca] == DSPFFT_REDFT01;
@@ -921,6 +924,37 @@ extern "C" int dspfft_execute_pass(dspfft_plan pl, int index, const float *d_in,
 	const std::vector<Pass> &passes = pick_passes(pl, d_in, d_out);
 	const Pass &P = passes[index];
 	return run_pass<float>(pl, P, P.first ? d_in : d_out, d_out, index + 1 == (int)passes.size(), stream);
+}
+
+extern "C" int dspfft_execute_many(int count, const dspfft_plan *plans, const float *const *d_in, float *const *d_out, void *const *streams,
+                                   int timed_item, int timed_count, void *const *pass_events)
+{
+	if (count < 0 || (count && (!plans || !d_in || !d_out))) return fail(-1, "bad arguments");
+	int ev = 0;
+	for (int i = 0; i < count; i++) {
+		dspfft_plan pl = plans[i];
+		void *st = streams ? streams[i] : nullptr;
+		if (!pl || !d_in[i] || !d_out[i]) return fail(-1, "item %d: null plan or buffer", i);
+		if (pl->f64) return fail(-1, "dspfft_execute_many takes f32 plans");
+		const bool timed = pass_events && i >= timed_item && i < timed_item + timed_count;
+		if (!timed) { if (int rc = execute_t<float>(pl, d_in[i], d_out[i], st)) return rc; continue; }
+		const std::vector<Pass> &passes = pick_passes(pl, d_in[i], d_out[i]);
+		for (size_t p = 0; p < passes.size(); p++) {
+			const Pass &P = passes[p];
+			if (be_event_record(pass_events[ev++], st)) return fail(-4, "event record failed");
+			if (int rc = run_pass<float>(pl, P, P.first ? d_in[i] : d_out[i], d_out[i], p + 1 == passes.size(), st)) return rc;
+			if (be_event_record(pass_events[ev++], st)) return fail(-4, "event record failed");
+		}
+	}
+	return 0;
+}
+extern "C" void *dspfft_event_create(void) { return be_event_create(); }
+extern "C" void dspfft_event_destroy(void *e) { be_event_destroy(e); }
+extern "C" int dspfft_event_synchronize(void *e) { return e && !be_event_synchronize(e) ? 0 : fail(-4, "event synchronise failed"); }
+extern "C" int dspfft_event_elapsed_ms(void *a, void *b, float *ms)
+{
+	if (!a || !b || !ms) return fail(-1, "bad arguments");
+	return be_event_elapsed_ms(a, b, ms) ? fail(-4, "event query failed") : 0;
 }
 
 extern "C" void dspfft_destroy_plan(dspfft_plan pl)

@@ -170,3 +170,51 @@ class Plan:
     def _check(self, rc):
         if rc:
             raise DspfftError(self._lib.dspfft_last_error().decode())
+
+
+class Events:
+    """n timing events of the library (dspfft_event_create): recorded by Batch.run on the streams of the bracketed items"""
+
+    def __init__(self, n, lib=None):
+        self._lib = lib or _lib.load()
+        self.handles = (C.c_void_p * n)(*[self._lib.dspfft_event_create() for _ in range(n)])
+        if any(h is None for h in self.handles):
+            raise DspfftError("event creation failed")
+
+    def elapsed_ms(self, i, j):
+        ms = C.c_float()
+        if self._lib.dspfft_event_elapsed_ms(self.handles[i], self.handles[j], C.byref(ms)):
+            raise DspfftError(self._lib.dspfft_last_error().decode())
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            for h in self.handles:
+                self._lib.dspfft_event_destroy(h)
+        except Exception:
+            pass
+
+
+class Batch:
+    """A fixed list of executions -- (plan, d_in, d_out, stream) per item -- enqueued by ONE call of dspfft_execute_many: the
+    per-frame loop of motion (motion/motion.c:613-753) or of a clip of spec/ispec frames, without a binding-layer call per frame."""
+
+    def __init__(self, items, lib=None):
+        items = list(items)
+        self._lib = lib or _lib.load()
+        self._keep = [it[0] for it in items]
+        n = len(items)
+        self.n = n
+        self._plans = (C.c_void_p * n)(*[it[0]._h for it in items])
+        self._in = (C.c_void_p * n)(*[it[1] for it in items])
+        self._out = (C.c_void_p * n)(*[(it[1] if it[2] is None else it[2]) for it in items])
+        self._streams = (C.c_void_p * n)(*[(it[3] or None) for it in items])
+
+    def run(self, timed_item=0, timed_count=0, events=None, event_offset=0):
+        ev = None
+        if events is not None and timed_count:
+            ev = C.cast(C.byref(events.handles, event_offset * C.sizeof(C.c_void_p)), C.POINTER(C.c_void_p))
+        rc = self._lib.dspfft_execute_many(self.n, self._plans, self._in, self._out, self._streams, timed_item, timed_count if ev is not None else 0, ev)
+        if rc:
+            raise DspfftError(self._lib.dspfft_last_error().decode())
+

@@ -56,6 +56,19 @@ int dspfft_execute(dspfft_plan plan, const float *d_in, float *d_out, void *hip_
 int dspfft_plan_num_passes(dspfft_plan plan);
 int dspfft_execute_pass(dspfft_plan plan, int index, const float *d_in, float *d_out, void *hip_stream);
 
+/* Many executions with one call: item i runs plans[i] on (d_in[i], d_out[i]) on hip_streams[i] (f32 plans), in order.  This is what
+ * a tool that loops fftw(execute) over the frames of a clip (motion/motion.c:613-753, scan/scan.c:447) calls once per batch, so a
+ * binding layer (cgo, ctypes ...) pays its per-call cost once per batch instead of once per frame and pass.
+ * Profiling aid: with pass_events non-NULL, every pass of items [timed_item, timed_item + timed_count) is bracketed by events
+ * recorded on that item's stream: the j-th bracketed pass between pass_events[2j] and pass_events[2j+1] (handles from
+ * dspfft_event_create; read with dspfft_event_elapsed_ms after dspfft_event_synchronize or a stream/device synchronise). */
+int dspfft_execute_many(int count, const dspfft_plan *plans, const float *const *d_in, float *const *d_out, void *const *hip_streams,
+                        int timed_item, int timed_count, void *const *pass_events);
+void *dspfft_event_create(void);
+void dspfft_event_destroy(void *event);
+int dspfft_event_synchronize(void *event);
+int dspfft_event_elapsed_ms(void *start, void *stop, float *ms);
+
 /* Double-precision samples: the fftw_ (no suffix) API that spec, zoom and applybasis use in their default
  * build (COEFF_PRECISION ?= D: spec/Makefile:1, applybasis/Makefile:1; include/precision.h:50-53,66-72).
  * Same geometry and call-site contract as above with `double` buffers; arithmetic, twiddle tables and the

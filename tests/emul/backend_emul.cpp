@@ -21,6 +21,11 @@ void be_free(void *p) { free(p); }
 int be_upload(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
 size_t be_max_lds() { const char *e = getenv("DSPFFT_EMUL_LDS"); return e ? (size_t)atol(e) : 160 * 1024; }
 const char *be_name() { return "cpu-emulation (tests only)"; }
+void *be_event_create() { return malloc(1); }
+void be_event_destroy(void *e) { free(e); }
+int be_event_record(void *, void *) { return 0; }
+int be_event_synchronize(void *) { return 0; }
+int be_event_elapsed_ms(void *, void *, float *ms) { *ms = 0.f; return 0; }
 
 #define PHASE(stmt) for (int tid = 0; tid < nthr; tid++) { stmt; }
 

@@ -58,12 +58,12 @@ def test_forced_split_vs_oracle(gpu, h, w):
     assert np.abs(out.cpu().numpy() - x).max() <= 5e-6
 
 
-def test_4k_split_is_default_and_matches_plain_and_oracle(gpu):
+def test_4k_forced_split_matches_plain_and_oracle(gpu):
     h, w, c = 2160, 3840, 3
     x = ol.synth_f32(0xD5F0002, h * w * c).reshape(h, w, c)
-    fwd, inv = plans(h, w, c)
-    pf, pi = plans(h, w, c, {"DSPFFT_NO_SPLIT": "1"})
-    assert "COL*/2 N=2160 as 2 x 1080, K=16" in fwd.describe() and "COL*/2" not in pf.describe()
+    fwd, inv = plans(h, w, c, {"DSPFFT_FORCE_SPLIT": "1"})
+    pf, pi = plans(h, w, c)
+    assert "COL*/2 N=2160 as 2 x 1080, K=16" in fwd.describe() and "COL*/2" not in pf.describe()   # 4K keeps the plain passes by default
     a, b = dev(gpu, x), dev(gpu, x)
     fwd.execute(a.data_ptr())
     pf.execute(b.data_ptr())

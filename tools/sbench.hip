@@ -53,7 +53,11 @@ static const size_t NF = (size_t)H * W * C;
 static const int NFR = 4;
 static float *g_buf;
 
+#ifdef PAIR768
+typedef RowSpec<3840, 3, 768, 12, 10, 16> RS;
+#else
 typedef RowSpec<3840, 3, 512, 12, 10, 16> RS;
+#endif
 typedef ColSpec<2160, 8, 512, 12, 12, 15> CS;
 
 struct Tables { cf *T, *Wt; };
