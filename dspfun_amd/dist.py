@@ -8,10 +8,12 @@ Two regimes:
   data path (bench.py uses this: weak scaling).
 
 * one 3-D block spanning the whole clip (`-b 0x0x0`, motion/motion.c:535-552: REDFT10^3 / REDFT01^3 on a
-  {d,h,w} block): `SlabDCT3D`.  Each rank owns d/G consecutive frames.  Forward = local 2-D passes
-  (x, y) -> ONE all-to-all that re-slabs the volume by rows (each rank then owns h/G rows of ALL
+  {d,h,w} block): `SlabDCT3D`.  Each rank owns a block of consecutive frames.  Forward = local y and x
+  passes -> all-to-all that re-slabs the volume by rows (each rank then owns a block of rows of ALL
   frames) -> local z pass.  The coefficients stay in the z-local layout, where motion's filters
-  (elementwise, motion.c:650-744) can run; inverse = z pass -> all-to-all back -> 2-D passes.
+  (elementwise, motion.c:650-744) can run; inverse = z pass -> all-to-all back -> x and y passes.
+  The x pass writes / reads the exchange buffers itself (no pack or unpack sweep), the exchange is cut into
+  pieces that overlap the neighbouring pieces' passes, and d, h need not divide by the number of ranks.
   No all-reduce anywhere; xGMI is point-to-point and an all-to-all uses all 7 links at once.
 """
 import math
@@ -29,73 +31,178 @@ def shard_range(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-class SlabDCT3D:
-    """Distributed 3-D DCT-II / DCT-III of a {d,h,w} f32 volume, slab-decomposed over the ranks of
-    `group`.  `uniform=True` fuses motion's uniform-range scaling (motion.c:644-647 forward,
-    :748-751 inverse) into the passes; the inverse additionally applies 1/(8 d h w)."""
+def block_range(n, rank, world):
+    """[lo, hi) of rank's block when n units are dealt in EQUAL blocks of ceil(n / world) (the last blocks may be short or
+    empty): the layout SlabDCT3D uses for frames and for rows, because equal blocks make every exchange buffer an affine
+    array (no gaps to pack around) whatever n % world is"""
+    per = -(-n // world)
+    return min(n, rank * per), min(n, (rank + 1) * per)
 
-    def __init__(self, d, h, w, group=None, uniform=True, lib=None):
+
+class SlabDCT3D:
+    """Distributed 3-D DCT-II / DCT-III of a {d,h,w} f32 volume (motion -b 0x0x0, motion/motion.c:535-552,641,753), slab-decomposed
+    over the ranks of `group`.  `uniform=True` fuses motion's uniform-range scaling (motion.c:644-647 forward, :748-751 inverse)
+    into the passes; the inverse additionally applies 1/(8 d h w).
+
+    Layout.  Rank r owns frames block_range(d, r, G) of the clip ([dl, h, w], all rows) before the forward transform and rows
+    block_range(h, r, G) of the coefficients afterwards ([d, hl, w], all frames).  d and h need NOT divide by G (BASELINE config 5's
+    chroma planes are 960 x 540: 540 = 7 x 68 + 64 on 8 ranks): blocks are ceil-sized, the last one short.
+
+    No pack / unpack sweeps.  The x pass is the LAST local pass of the forward transform and the FIRST after the inverse
+    exchange, and it is separable by lines, so it writes (reads) the exchange buffers directly through its batch strides:
+      forward   y pass in place on [dl, h, w]  ->  x pass of rows [r*hp + c0, ...) of every frame, straight into
+                send[r] = [dlp, ch, w]  ->  all_to_all_single  ->  recv = [G*dlp, ch, w] = every frame, my rows  ->  z pass from
+                recv (frame stride ch*w) into coeffs [d, hl, w]
+      inverse   z pass from coeffs into send = [G*dlp, ch, w]  ->  all_to_all_single  ->  x pass from recv[s] = [dlp, ch, w]
+                straight into rows [s*hp + c0, ...) of [dl, h, w]  ->  y pass in place
+    Pipelined: the rows of a block are cut into `chunks` pieces; the exchange of piece p (RCCL, its own stream) runs while the x pass
+    of piece p+1 and the z pass of piece p-1 run on the compute stream.  Two all-to-alls per roundtrip, no all-reduce; xGMI is
+    point-to-point and an all-to-all uses all 7 links at once."""
+
+    def __init__(self, d, h, w, group=None, uniform=True, lib=None, chunks=None):
         self.group = group
         self.G = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        if d % self.G or h % self.G:
-            raise ValueError(f"d={d} and h={h} must be divisible by the number of ranks ({self.G})")
+        G = self.G
         self.d, self.h, self.w = d, h, w
-        self.dl, self.hl = d // self.G, h // self.G
+        self.dlp, self.hp = -(-d // G), -(-h // G)               # block sizes (frames, rows)
+        self.f_lo, self.f_hi = block_range(d, self.rank, G)
+        self.y_lo, self.y_hi = block_range(h, self.rank, G)
+        self.dl, self.hl = self.f_hi - self.f_lo, self.y_hi - self.y_lo
+        if chunks is None:
+            chunks = 1 if G == 1 else 4
+        self.ch = -(-self.hp // max(1, min(chunks, self.hp)))    # rows per piece
+        self.P = -(-self.hp // self.ch)
+        self.lib = lib
+        self.uniform = uniform
+        self._plans = {}
+        self._bufs = {}
         r2 = math.sqrt(2.0)
-        # local 2-D passes over this rank's frames: rank 2 {h,w}, howmany = frames, dist = h*w
-        self.fwd_yx = Plan.many_r2r([h, w], [REDFT10] * 2, howmany=self.dl, idist=h * w, odist=h * w, lib=lib)
-        self.inv_yx = Plan.many_r2r([h, w], [REDFT01] * 2, howmany=self.dl, idist=h * w, odist=h * w, lib=lib)
-        # z pass in the re-slabbed layout [d][hl*w]: rank 1 {d}, howmany = hl*w columns, stride = hl*w, dist = 1
-        cols = self.hl * w
-        self.fwd_z = Plan.many_r2r([d], [REDFT10], howmany=cols, istride=cols, idist=1, ostride=cols, odist=1, lib=lib)
-        self.inv_z = Plan.many_r2r([d], [REDFT01], howmany=cols, istride=cols, idist=1, ostride=cols, odist=1, lib=lib)
-        if uniform:
-            for a in (0, 1):
-                self.fwd_yx.set_axis_scale0(a, 1.0, 1.0 / r2)
-                self.inv_yx.set_axis_scale0(a, r2, 1.0)
-            self.fwd_z.set_axis_scale0(0, 1.0, 1.0 / r2).set_scale(2.0 * r2)
-            self.inv_z.set_axis_scale0(0, r2, 1.0).set_scale(1.0 / (2.0 * r2))
-        self.inv_yx.set_scale(1.0 / (8.0 * d * h * w))
+        u = (lambda p, fwd: p.set_axis_scale0(0, 1.0, 1.0 / r2) if fwd else p.set_axis_scale0(0, r2, 1.0)) if uniform else (lambda p, fwd: p)
+        self._u = u
+        dl, hl = self.dl, self.hl
+        # y pass, in place on my frames: transform dim (h, stride w), batch (w, 1) x (dl, h*w)
+        self.fwd_y = self.inv_y = None
+        if dl:
+            self.fwd_y = u(Plan.guru([(h, w, w)], [(w, 1, 1), (dl, h * w, h * w)], [REDFT10], lib=lib), True)
+            self.inv_y = u(Plan.guru([(h, w, w)], [(w, 1, 1), (dl, h * w, h * w)], [REDFT01], lib=lib), False).set_scale(1.0 / (8.0 * d * h * w))
+
+    # ---- plans that depend on a piece's row count (cached: at most three distinct counts occur) ----
+    def _plan_x(self, nrows, fwd):
+        """x pass over `nrows` rows of every one of my frames, between the frame layout [dl, h, w] and a block [dlp, ch, w] of
+        an exchange buffer"""
+        key = ("x", nrows, fwd)
+        if key not in self._plans:
+            w, h, ch = self.w, self.h, self.ch
+            if fwd:
+                p = Plan.guru([(w, 1, 1)], [(nrows, w, w), (self.dl, h * w, ch * w)], [REDFT10], lib=self.lib)
+            else:
+                p = Plan.guru([(w, 1, 1)], [(nrows, w, w), (self.dl, ch * w, h * w)], [REDFT01], lib=self.lib)
+            self._plans[key] = self._u(p, fwd)
+        return self._plans[key]
+
+    def _plan_z(self, nrows, fwd):
+        """z pass over the columns of `nrows` of my rows, between a received piece [G*dlp, ch, w] and coeffs [d, hl, w]"""
+        key = ("z", nrows, fwd)
+        if key not in self._plans:
+            w, ch, hl, d = self.w, self.ch, self.hl, self.d
+            r2 = math.sqrt(2.0)
+            if fwd:
+                p = Plan.guru([(d, ch * w, hl * w)], [(nrows * w, 1, 1)], [REDFT10], lib=self.lib)
+                p = self._u(p, True)
+                if self.uniform:
+                    p.set_scale(2.0 * r2)
+            else:
+                p = Plan.guru([(d, hl * w, ch * w)], [(nrows * w, 1, 1)], [REDFT01], lib=self.lib)
+                p = self._u(p, False)
+                if self.uniform:
+                    p.set_scale(1.0 / (2.0 * r2))
+            self._plans[key] = p
+        return self._plans[key]
+
+    def _buf(self, name, like):
+        n = self.P * self.G * self.dlp * self.ch * self.w
+        b = self._bufs.get(name)
+        if b is None or b.device != like.device:
+            b = torch.zeros(n, dtype=torch.float32, device=like.device)
+            self._bufs[name] = b
+        return b.view(self.P, self.G, self.dlp, self.ch, self.w)
 
     @staticmethod
     def _stream(t):
         return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
 
-    def _to_rows(self, x):
-        """[dl, h, w] (my frames, all rows) -> [d, hl, w] (all frames, my rows): one all-to-all"""
-        if self.G == 1:
-            return x
-        send = x.view(self.dl, self.G, self.hl, self.w).permute(1, 0, 2, 3).contiguous()
-        recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=self.group)
-        return recv.view(self.d, self.hl, self.w)
+    def _rows_of(self, r, p):
+        """image rows of block r that fall into piece p: [y0, y1)"""
+        lo, hi = block_range(self.h, r, self.G)
+        y0 = min(hi, lo + p * self.ch)
+        return y0, min(hi, y0 + self.ch)
 
-    def _to_frames(self, c):
-        """[d, hl, w] -> [dl, h, w]: the inverse exchange"""
+    def _exchange(self, send, recv):
         if self.G == 1:
-            return c
-        send = c.view(self.G, self.dl, self.hl, self.w).contiguous()
-        recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=self.group)
-        return recv.permute(1, 0, 2, 3).contiguous().view(self.dl, self.h, self.w)
+            return None                             # one rank: forward() / inverse() alias recv to send
+        return dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group, async_op=True)
 
     def forward(self, frames):
-        """frames: [d/G, h, w] f32 (this rank's frames; overwritten).  Returns [d, h/G, w] coefficients
-        of REDFT10^3 (uniform range if requested) for this rank's row slab."""
-        assert frames.shape == (self.dl, self.h, self.w) and frames.dtype == torch.float32 and frames.is_contiguous()
-        self.fwd_yx.execute(frames.data_ptr(), stream=self._stream(frames))
-        c = self._to_rows(frames)
-        self.fwd_z.execute(c.data_ptr(), stream=self._stream(c))
-        return c
+        """frames: [dl, h, w] f32 (this rank's frames, block_range(d, rank, G); overwritten).  Returns [d, hl, w] coefficients of
+        REDFT10^3 (uniform range if requested) for this rank's rows block_range(h, rank, G)."""
+        assert tuple(frames.shape) == (self.dl, self.h, self.w) and frames.dtype == torch.float32 and frames.is_contiguous()
+        st = self._stream(frames)
+        send = self._buf("send", frames)
+        recv = send if self.G == 1 else self._buf("recv", frames)
+        coeffs = torch.empty((self.d, self.hl, self.w), dtype=torch.float32, device=frames.device)
+        if self.dl:
+            self.fwd_y.execute(frames.data_ptr(), stream=st)
+        es = 4
+        work = [None] * self.P
+
+        def zpass(p):
+            if work[p] is not None:
+                work[p].wait()                      # RCCL: the compute stream waits for the collective; gloo: the host does
+            y0, y1 = self._rows_of(self.rank, p)
+            if y1 > y0:
+                self._plan_z(y1 - y0, True).execute(recv[p].data_ptr(), coeffs.data_ptr() + (y0 - self.y_lo) * self.w * es, stream=st)
+
+        for p in range(self.P):
+            for r in range(self.G):
+                y0, y1 = self._rows_of(r, p)
+                if y1 > y0 and self.dl:
+                    self._plan_x(y1 - y0, True).execute(frames.data_ptr() + y0 * self.w * es, send[p, r].data_ptr(), stream=st)
+            work[p] = self._exchange(send[p], recv[p])
+            if p > 0:
+                zpass(p - 1)
+        zpass(self.P - 1)
+        return coeffs
 
     def inverse(self, coeffs):
-        """coeffs: [d, h/G, w] (overwritten).  Returns this rank's [d/G, h, w] frames, scaled by 1/(8dhw)."""
-        assert coeffs.shape == (self.d, self.hl, self.w) and coeffs.is_contiguous()
-        self.inv_z.execute(coeffs.data_ptr(), stream=self._stream(coeffs))
-        x = self._to_frames(coeffs)
-        self.inv_yx.execute(x.data_ptr(), stream=self._stream(x))
-        return x
+        """coeffs: [d, hl, w] (this rank's rows; not modified).  Returns this rank's [dl, h, w] frames, scaled by 1/(8dhw)."""
+        assert tuple(coeffs.shape) == (self.d, self.hl, self.w) and coeffs.is_contiguous()
+        st = self._stream(coeffs)
+        send = self._buf("send", coeffs)
+        recv = send if self.G == 1 else self._buf("recv", coeffs)
+        frames = torch.empty((self.dl, self.h, self.w), dtype=torch.float32, device=coeffs.device)
+        es = 4
+        work = [None] * self.P
+
+        def xpass(p):
+            if work[p] is not None:
+                work[p].wait()
+            for s in range(self.G):
+                y0, y1 = self._rows_of(s, p)
+                if y1 > y0 and self.dl:
+                    self._plan_x(y1 - y0, False).execute(recv[p, s].data_ptr(), frames.data_ptr() + y0 * self.w * es, stream=st)
+
+        for p in range(self.P):
+            y0, y1 = self._rows_of(self.rank, p)
+            if y1 > y0:
+                self._plan_z(y1 - y0, False).execute(coeffs.data_ptr() + (y0 - self.y_lo) * self.w * es, send[p].data_ptr(), stream=st)
+            work[p] = self._exchange(send[p], recv[p])
+            if p > 0:
+                xpass(p - 1)
+        xpass(self.P - 1)
+        if self.dl:
+            self.inv_y.execute(frames.data_ptr(), stream=st)
+        return frames
 
 
 class ChannelShardedScan:
@@ -122,13 +229,14 @@ class ChannelShardedScan:
         self.fwd = Plan.many_r2r([self.h, self.w], [REDFT10] * 2, lib=lib).set_scale(1.0 / (4.0 * self.w * self.h))
         self.inv = Plan.many_r2r([self.h, self.w], [REDFT01] * 2, lib=lib)
         self.ids = torch.zeros(self.w * self.h, dtype=torch.int32, device=dev)
-        self._check(self.lib.dspfft_scan_zigzag_frame_ids(self.ids.data_ptr(), self.w, self.h, self.step, None))
+        st = SlabDCT3D._stream(image_hwc) or None     # every helper on torch's current stream, like the transforms
+        self._check(self.lib.dspfft_scan_zigzag_frame_ids(self.ids.data_ptr(), self.w, self.h, self.step, st))
         self.work = torch.empty((self.h, self.w), dtype=torch.float32, device=dev)
         self.sums = []
         for cz in self.coeffs:
             self.fwd.execute(cz.data_ptr(), stream=SlabDCT3D._stream(cz))
             s = torch.empty_like(cz)
-            self._check(self.lib.dspfft_broadcast_dc(s.data_ptr(), cz.data_ptr(), self.w * self.h, 1, None))   # scan.c:377-383
+            self._check(self.lib.dspfft_broadcast_dc(s.data_ptr(), cz.data_ptr(), self.w * self.h, 1, st))   # scan.c:377-383
             self.sums.append(s)
         self.frame = 0
 

@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, d, h, w, q):
+def _worker(rank, world, port, d, h, w, chunks, q):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -29,43 +29,63 @@ def _worker(rank, world, port, d, h, w, q):
     try:
         import oracle_lib as ol
         from emul_lib import emul
-        from dspfun_amd.dist import SlabDCT3D, shard_range
+        from dspfun_amd.dist import SlabDCT3D, block_range
         vol = ol.synth_u8(0xD5F0005, d * h * w).astype(np.float32).reshape(d, h, w)
-        lo, hi = shard_range(d, rank, world)
-        eng = SlabDCT3D(d, h, w, lib=emul())
+        lo, hi = block_range(d, rank, world)
+        ylo, yhi = block_range(h, rank, world)
+        eng = SlabDCT3D(d, h, w, lib=emul(), chunks=chunks)
+        assert (eng.f_lo, eng.f_hi, eng.y_lo, eng.y_hi) == (lo, hi, ylo, yhi)
         mine = torch.from_numpy(vol[lo:hi].copy())
         c = eng.forward(mine)
+        assert tuple(c.shape) == (d, yhi - ylo, w)
         # reference: REDFT10^3 with motion's uniform scaling, rows of my slab
         ref = ol.r2r_many(vol.astype(np.float64), [d, h, w], [ol.REDFT10] * 3, impl="port")
         ol.lib().oracle_motion_uniform_f64(ref.ctypes.data, d, h, w, h, w, 1)
         ref = ref.reshape(d, h, w)
-        hl = h // world
-        err_f = np.abs(c.numpy() - ref[:, rank * hl:(rank + 1) * hl, :]).max() / np.abs(ref).max()
+        err_f = np.abs(c.numpy() - ref[:, ylo:yhi, :]).max() / np.abs(ref).max() if yhi > ylo else 0.0
+        keep = c.clone()
         back = eng.inverse(c)
-        err_b = np.abs(back.numpy() - vol[lo:hi]).max()
+        assert torch.equal(c, keep)                      # the coefficients are not consumed
+        err_b = np.abs(back.numpy() - vol[lo:hi]).max() if hi > lo else 0.0
+        # a second roundtrip through the same (reused) exchange buffers
+        back2 = eng.inverse(eng.forward(torch.from_numpy(vol[lo:hi].copy())))
+        err_b = max(err_b, float(np.abs(back2.numpy() - vol[lo:hi]).max()) if hi > lo else 0.0)
         q.put((rank, float(err_f), float(err_b)))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("d,h,w", [(8, 12, 10), (16, 30, 24)])
-def test_slab_dct3d_world2(d, h, w):
+# (d, h, w, world, chunks): even splits; h % G != 0 and d % G != 0 (BASELINE config 5's chroma planes: 540 rows on 8 ranks);
+# a rank with no rows at all; one piece and more pieces than rows
+@pytest.mark.parametrize("d,h,w,world,chunks", [(8, 12, 10, 2, 1), (16, 30, 24, 2, 4), (6, 27, 10, 2, 3), (7, 10, 12, 3, 2), (4, 5, 8, 3, 8), (9, 2, 8, 3, 1)])
+def test_slab_dct3d_gloo(d, h, w, world, chunks):
     import subprocess
     subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "emul")])
     subprocess.check_call(["make", "-s", "-C", os.path.join(os.path.dirname(HERE), "oracle"), "liboracle.so"])
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, d, h, w, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, d, h, w, chunks, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=180) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     for rank, err_f, err_b in res:
         assert err_f < 1e-5, (rank, err_f)
         assert err_b < 2e-3, (rank, err_b)       # pixel domain 0..255: far below half an LSB
+
+
+def test_block_range_is_equal_blocks():
+    from dspfun_amd.dist import block_range
+    for n, world in ((540, 8), (256, 8), (10, 8), (1, 3), (7, 2)):
+        spans = [block_range(n, r, world) for r in range(world)]
+        per = -(-n // world)
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        assert all(b - a == per for a, b in spans if b < n)
+    assert block_range(540, 7, 8) == (476, 540) and block_range(10, 6, 8) == (10, 10)
 
 
 def test_shard_range_covers_everything():

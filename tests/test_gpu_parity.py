@@ -482,6 +482,13 @@ def test_slab_dct3d_single_rank_matches_rank3_plan(gpu):
     back = eng.inverse(b_)
     gpu.cuda.synchronize()
     assert float((back - x).abs().max()) < 1e-3
+    # the same through five row pieces (the pipelined exchange's layout; one rank, so the exchange itself is a no-op)
+    eng5 = SlabDCT3D(d_, h, w, chunks=5)
+    assert eng5.P == 5
+    c5 = eng5.forward(x.clone())
+    gpu.cuda.synchronize()
+    assert float((a_ - c5).abs().max() / a_.abs().max()) < 2e-6
+    assert float((eng5.inverse(c5) - x).abs().max()) < 1e-3
 
 
 def test_channel_sharded_scan_single_rank(gpu):

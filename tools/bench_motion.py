@@ -5,6 +5,9 @@ dspfft_execute_roundtrip_u8.  Frames are independent: no collective on the data 
 
     python tools/bench_motion.py                                   # one GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/bench_motion.py
+    ... tools/bench_motion.py volume     # `-b 0x0x0`: ONE 3-D block over the whole clip per plane (dspfun_amd.dist.SlabDCT3D: local y, x
+                                         # passes, all-to-all over RCCL/xGMI in row pieces that overlap the passes, local z pass; float
+                                         # forward + inverse, motion.c:535-552,641,753).  Unmeasured on more than one GPU until a SCALE record exists.
 Prints one JSON line on rank 0."""
 import json, math, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,6 +25,50 @@ if world > 1:
     dist.init_process_group("nccl", device_id=dev)
 
 FRAMES, QUANT, REPS = 256, 20.0, 5      # motion --quant 20 (motion/README.md)
+if len(sys.argv) > 1 and sys.argv[1] == "volume":
+    from dspfun_amd.dist import SlabDCT3D
+    chunks = int(os.environ.get("SLAB_CHUNKS", "4"))
+    engs, vols = [], []
+    for (h, w) in ((1080, 1920), (540, 960), (540, 960)):
+        e = SlabDCT3D(FRAMES, h, w, chunks=chunks)
+        engs.append(e)
+        vols.append((torch.rand(e.dl, h, w, device=dev) * 255).floor())
+
+    def clip3d():
+        errs = []
+        for e, v in zip(engs, vols):
+            back = e.inverse(e.forward(v.clone()))
+            errs.append(back)
+        return errs
+
+    def barrier3d():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    clip3d()
+    barrier3d()
+    t0 = time.perf_counter()
+    for _ in range(REPS):
+        outs = clip3d()
+    barrier3d()
+    dt = (time.perf_counter() - t0) / REPS
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    err = max(float((o - v).abs().max()) for o, v in zip(outs, vols) if v.numel())
+    if rank == 0:
+        samples = FRAMES * (1080 * 1920 + 2 * 540 * 960)
+        print(json.dumps({"workload": "motion yuv420p 1920x1080x256, one 3-D block per plane (-b 0x0x0), float forward + inverse (incl. a clone of the input per plane)",
+                          "n_gpus": world, "frames_per_rank": engs[0].dl, "row_pieces": engs[0].P, "ms_per_clip": round(dt * 1e3, 3),
+                          "Msamples_per_s": round(samples / dt / 1e6), "algorithmic_GBps_per_gpu": round(samples * 16 / dt / 1e9 / world, 1),
+                          "max_abs_roundtrip_error_0_255": err, "parallelism": f"slab x{world}: 2 all-to-alls per roundtrip (RCCL), pipelined in {engs[0].P} row pieces"}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    sys.exit(0)
 lo, hi = shard_range(FRAMES, rank, world)
 nf = hi - lo
 r2 = math.sqrt(2.0)
