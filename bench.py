@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--frames", type=int, default=4, help="independent frames per GPU per step")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("BENCH_STREAMS", "2")), help="HIP streams the independent frames are spread over")
     ap.add_argument("--schedule", choices=["auto", "free", "aligned"], default="free", help="how two streams interleave their frames (see step())")
+    ap.add_argument("--event-every", type=int, default=4, help="bracket the passes of one frame with events every N-th step (events between "
+                    "dependent launches cost throughput: every step -3 %%, every launch -7 %%)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -145,7 +147,9 @@ def main():
     # on), rotating through the frames, so the in-region average per kernel samples every position in the step -- the population
     # rocprofv3 averages -- at a quarter of the event traffic.
     batch = Batch([(pl_, p, None, handles[i % len(handles)]) for i, p in enumerate(ptrs) for pl_ in (fwd, inv)])
-    events = Events(2 * npass * args.steps)
+    every = max(1, args.event_every)
+    timed_steps = [k for k in range(args.steps) if k % every == 0]
+    events = Events(2 * npass * len(timed_steps))
 
     # Schedules of the frames of a step on two streams.  "free" (default): each stream runs its frames back to back, so one
     # stream's kernel tails and ramps are filled by the other stream's kernels (58-59K Mpix/s from C, steady over rounds).
@@ -160,10 +164,11 @@ def main():
                 for b_ in range(len(side)):
                     if a_ != b_ and sched["last"][b_] is not None:
                         side[a_].wait_event(sched["last"][b_])
-        if k is None:
+        if k is None or k % every:
             batch.run()
         else:
-            batch.run(timed_item=2 * (k % len(ptrs)), timed_count=2, events=events, event_offset=2 * npass * k)
+            j = k // every
+            batch.run(timed_item=2 * (j % len(ptrs)), timed_count=2, events=events, event_offset=2 * npass * j)
         if sched["aligned"]:
             for a_ in range(len(side)):
                 e_ = torch.cuda.Event()
@@ -213,7 +218,8 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    in_region_ms = [sum(events.elapsed_ms(2 * npass * k + 2 * j, 2 * npass * k + 2 * j + 1) for k in range(args.steps)) / args.steps for j in range(npass)]
+    nt = len(timed_steps)
+    in_region_ms = [sum(events.elapsed_ms(2 * npass * t + 2 * j, 2 * npass * t + 2 * j + 1) for t in range(nt)) / nt for j in range(npass)]
 
     # sanity of what was timed: after (warmup+steps) consecutive in-place roundtrips the frame is still the input
     # (single-roundtrip accuracy is what tests/test_gpu_parity.py pins: <= 5e-6)
@@ -259,7 +265,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": names[k], "kernel_ms": round(in_region_ms[k], 5),
                 "all_kernels_ms": {names[i]: round(in_region_ms[i], 5) for i in range(npass)},
-                "algorithmic_bytes_per_launch": alg,
+                "algorithmic_bytes_per_launch": alg, "launches_timed_in_region_per_kernel": nt,
                 "note": ("durations are HIP-event averages over the timed region; with hip_streams > 1 the kernels of two frames "
                          "share the CUs, so a launch lasts longer than when it runs alone (isolated_*)") if nstreams > 1 else
                         "durations are HIP-event averages over the timed region",
