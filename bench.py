@@ -94,7 +94,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--frames", type=int, default=4, help="independent frames per GPU per step")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("BENCH_STREAMS", "2")), help="HIP streams the independent frames are spread over")
-    ap.add_argument("--schedule", choices=["auto", "free", "aligned"], default="free", help="how two streams interleave their frames (see step())")
+    ap.add_argument("--realign", type=int, default=8, help="with --schedule realign: re-join the streams every N steps")
+    ap.add_argument("--schedule", choices=["free", "aligned", "realign"], default="realign", help="how two streams interleave their frames (see step())")
     ap.add_argument("--event-every", type=int, default=4, help="bracket the passes of one frame with events every N-th step (events between "
                     "dependent launches cost throughput: every step -3 %%, every launch -7 %%)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -149,17 +150,20 @@ def main():
     batch = Batch([(pl_, p, None, handles[i % len(handles)]) for i, p in enumerate(ptrs) for pl_ in (fwd, inv)])
     every = max(1, args.event_every)
     timed_steps = [k for k in range(args.steps) if k % every == 0]
-    events = Events(2 * npass * len(timed_steps))
+    nper = min(2, len(ptrs)) if nstreams >= 2 else 1          # frames bracketed per timed step: one per stream
+    events = Events(2 * npass * nper * len(timed_steps))
 
-    # Schedules of the frames of a step on two streams.  "free" (default): each stream runs its frames back to back, so one
-    # stream's kernel tails and ramps are filled by the other stream's kernels (58-59K Mpix/s from C, steady over rounds).
-    # "aligned": the streams start every STEP together (each waits for the other's previous step), which keeps kernels of the
-    # same pass shape overlapping (56-57K).  Round 1 preferred "aligned" because "free" was erratic (42-54K) -- that was the
-    # host: with a ctypes call per pass the streams ran dry at random moments.  "auto" times both for a moment and keeps the faster.
-    sched = {"aligned": False, "last": [None] * max(1, nstreams)}
+    # Schedules of the frames of a step on two streams (frame f on stream f mod 2).  Left alone ("free") the streams keep whatever
+    # relative phase they happen to have: 58-59K Mpix/s while kernels of the same pass shape overlap (tools/sbench.hip, both boxes
+    # seen), 45K when a stream's row passes run beside the other's column passes (mixed workgroup shapes leave LDS unused; forced:
+    # "pipe" 35-39K) -- and anything that delays one stream (the timing events below, a colder frame) moves the phase.  Re-joining
+    # the streams at EVERY step ("aligned", round 1's default) is steady but idles the faster stream at each join (55-56K).
+    # Default: re-join every `--realign` steps (8): the phase cannot wander, the joins are rare.  The timing events bracket one
+    # frame on EACH stream in the same step, so they delay both streams alike.
+    sched = {"every": 0, "count": 0, "last": [None] * max(1, nstreams)}
 
     def step(k=None):
-        if sched["aligned"]:
+        if sched["every"] and sched["count"] % sched["every"] == 0:
             for a_ in range(len(side)):
                 for b_ in range(len(side)):
                     if a_ != b_ and sched["last"][b_] is not None:
@@ -168,33 +172,22 @@ def main():
             batch.run()
         else:
             j = k // every
-            batch.run(timed_item=2 * (j % len(ptrs)), timed_count=2, events=events, event_offset=2 * npass * j)
-        if sched["aligned"]:
+            first = (2 * j) % len(ptrs) if len(ptrs) >= 2 else 0
+            batch.run(timed_item=2 * first, timed_count=2 * nper, events=events, event_offset=2 * npass * nper * j)
+        sched["count"] += 1
+        if sched["every"] and sched["count"] % sched["every"] == 0:
             for a_ in range(len(side)):
                 e_ = torch.cuda.Event()
                 e_.record(side[a_])
                 sched["last"][a_] = e_
 
     schedule = "single stream" if nstreams == 1 else "free"
-    if nstreams == 2 and args.schedule == "auto":
-        def trial(aligned, reps=40):
-            sched["aligned"] = aligned
-            sched["last"] = [None] * nstreams
-            for _ in range(5):
-                step()
-            torch.cuda.synchronize()
-            t_ = time.perf_counter()
-            for _ in range(reps):
-                step()
-            torch.cuda.synchronize()
-            return time.perf_counter() - t_
-        t_free, t_al = min(trial(False), trial(False)), min(trial(True), trial(True))
-        sched["aligned"] = t_al < t_free
-        sched["last"] = [None] * nstreams
-        schedule = "step-aligned" if sched["aligned"] else "free"
-    elif nstreams >= 2 and args.schedule == "aligned":
-        sched["aligned"] = True
+    if nstreams >= 2 and args.schedule == "aligned":
+        sched["every"] = 1
         schedule = "step-aligned"
+    elif nstreams >= 2 and args.schedule == "realign":
+        sched["every"] = max(1, args.realign)
+        schedule = f"free, streams re-joined every {sched['every']} steps"
 
     def barrier():
         torch.cuda.synchronize()
@@ -218,7 +211,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    nt = len(timed_steps)
+    nt = len(timed_steps) * nper
     in_region_ms = [sum(events.elapsed_ms(2 * npass * t + 2 * j, 2 * npass * t + 2 * j + 1) for t in range(nt)) / nt for j in range(npass)]
 
     # sanity of what was timed: after (warmup+steps) consecutive in-place roundtrips the frame is still the input

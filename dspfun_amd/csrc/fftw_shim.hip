@@ -57,6 +57,7 @@ struct Shim {
 	dspfft_plan plan = nullptr;
 	void *h_in = nullptr, *h_out = nullptr;
 	size_t in_len = 0, out_len = 0;          // elements
+	bool out_dense = false;                  // the transform writes every element of [0, out_len): `out` needs no upload
 	size_t es = 4;                           // bytes per element: 4 (fftwf_) or 8 (fftw_)
 	void *d_in = nullptr, *d_out = nullptr;  // d_out == d_in when in-place
 	hipStream_t stream = nullptr;
@@ -77,6 +78,11 @@ Shim *make_plan(int rank, const int *n, int howmany, void *in, const int *inembe
 	}
 	s->in_len = span(rank, n, inembed, istride, idist, howmany);
 	s->out_len = span(rank, n, onembed, ostride, odist, howmany);
+	size_t written = (size_t)howmany;
+	for (int a = 0; a < rank; a++) written *= (size_t)n[a];
+	s->out_dense = written == s->out_len;     // as many outputs as the span holds: no embedding gaps (scan/scan.c:359: onembed == NULL)
+	// in place: ONE device buffer that covers both layouts (they may differ: inembed != onembed on the same array)
+	if (in == out) { const size_t both = s->in_len > s->out_len ? s->in_len : s->out_len; s->in_len = both; if (!s->out_dense) s->out_len = both; }
 	bool ok = hipMalloc(&s->d_in, s->in_len * s->es) == hipSuccess;
 	if (in == out) s->d_out = s->d_in;
 	else ok = ok && hipMalloc(&s->d_out, s->out_len * s->es) == hipSuccess;
@@ -93,8 +99,9 @@ void run(Shim *s)
 {
 	if (!s) { fprintf(stderr, "dspfft: execute on a NULL plan\n"); return; }
 	bool ok = hipMemcpyAsync(s->d_in, s->h_in, s->in_len * s->es, hipMemcpyHostToDevice, s->stream) == hipSuccess;
-	// out-of-place with embedding gaps: elements the transform does not write must survive in `out`
-	if (s->d_out != s->d_in) ok = ok && hipMemcpyAsync(s->d_out, s->h_out, s->out_len * s->es, hipMemcpyHostToDevice, s->stream) == hipSuccess;
+	// out-of-place with embedding gaps: elements the transform does not write must survive in `out`, so the host's `out` goes up
+	// first.  A dense output (scan's per-frame plan, scan/scan.c:359,447) is overwritten whole: two transfers per execute, not three.
+	if (s->d_out != s->d_in && !s->out_dense) ok = ok && hipMemcpyAsync(s->d_out, s->h_out, s->out_len * s->es, hipMemcpyHostToDevice, s->stream) == hipSuccess;
 	if (ok) {
 		const int rc = s->es == 8 ? dspfft_execute_f64(s->plan, (const double *)s->d_in, (double *)s->d_out, s->stream)
 		                          : dspfft_execute(s->plan, (const float *)s->d_in, (float *)s->d_out, s->stream);

@@ -82,6 +82,28 @@ void fftw_cleanup_threads(void);
 int fftw_import_wisdom_from_filename(const char *filename);
 int fftw_export_wisdom_to_filename(const char *filename);
 
+/* ---------------- long double: COEFF_PRECISION=L (include/precision.h:73-79) ----------------
+ * The GPU has no long double.  SURVEY.md 8b allows a CPU-only implementation for this precision: these entry points run a
+ * plain host path (dspfun_amd/csrc/fftwl_cpu.cpp: recursive mixed-radix FFT in long double, single thread, any length) on ordinary
+ * host memory.  Same call-site contract as above (plan captures the pointers and never touches the arrays; execute is repeatable). */
+typedef fftw_r2r_kind fftwl_r2r_kind;
+typedef struct fftwl_plan_s *fftwl_plan;
+long double *fftwl_alloc_real(size_t n);
+void fftwl_free(void *p);
+fftwl_plan fftwl_plan_many_r2r(int rank, const int *n, int howmany,
+                               long double *in, const int *inembed, int istride, int idist,
+                               long double *out, const int *onembed, int ostride, int odist,
+                               const fftwl_r2r_kind *kind, unsigned flags);
+fftwl_plan fftwl_plan_r2r_2d(int n0, int n1, long double *in, long double *out, fftwl_r2r_kind kind0, fftwl_r2r_kind kind1, unsigned flags);
+void fftwl_execute(const fftwl_plan p);
+void fftwl_destroy_plan(fftwl_plan p);
+void fftwl_cleanup(void);
+int fftwl_init_threads(void);
+void fftwl_plan_with_nthreads(int nthreads);
+void fftwl_cleanup_threads(void);
+int fftwl_import_wisdom_from_filename(const char *filename);
+int fftwl_export_wisdom_to_filename(const char *filename);
+
 #ifdef __cplusplus
 }
 #endif

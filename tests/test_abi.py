@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared(header):
     txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b((?:dspfft|fftwf?)_[a-z0-9_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b((?:dspfft|fftw[fl]?)_[a-z0-9_]+)\s*\(", txt)))
 
 
 def test_header_symbols_match_binding_list():
@@ -32,11 +32,11 @@ def test_product_library_exports_every_declared_symbol():
 
 
 def test_product_library_exports_the_fftw_named_boundary():
-    """every function include/fftw3.h declares (the FFTW functions the tools use, x {fftwf_, fftw_})"""
+    """every function include/fftw3.h declares (the FFTW functions the tools use, x {fftwf_, fftw_, fftwl_})"""
     from dspfun_amd import _lib
     lib = C.CDLL(_lib.LIB_PATH)
     names = declared("fftw3.h")
-    assert len(names) == 24, names      # 12 functions x {fftwf_, fftw_}
+    assert len(names) == 36, names      # 12 functions x {fftwf_, fftw_, fftwl_}
     for name in names:
         assert hasattr(lib, name), name
 

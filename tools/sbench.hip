@@ -111,6 +111,13 @@ static void launch_pass(int p, int f0, int nfr, hipStream_t s)
 	}
 }
 
+// spins for about `us` microseconds (s_memrealtime counts at 100 MHz): one wave, used to stagger stream B behind stream A
+__global__ void delay_k(int us)
+{
+	const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+	while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)us * 100) __builtin_amdgcn_s_sleep(32);
+}
+static int g_lag_us = 20, g_join_every = 8, g_stepno = 0;
 static hipStream_t sA, sB;
 static hipEvent_t evA[8], evB[8], evStepA, evStepB;
 
@@ -128,6 +135,15 @@ static void step(const std::string &mode)
 		CHK(hipStreamWaitEvent(sA, evStepB, 0)); CHK(hipStreamWaitEvent(sB, evStepA, 0));
 		for (int f = 0; f < NFR; f++) for (int p = 0; p < 4; p++) launch_pass(p, f, 1, (f & 1) ? sB : sA);
 		CHK(hipEventRecord(evStepA, sA)); CHK(hipEventRecord(evStepB, sB));
+	} else if (mode == "stagger") {
+		// streams re-joined every g_join_every steps; after a join stream B starts g_lag_us behind stream A
+		if (g_stepno % g_join_every == 0) {
+			CHK(hipStreamWaitEvent(sA, evStepB, 0)); CHK(hipStreamWaitEvent(sB, evStepA, 0));
+			if (g_lag_us > 0) hipLaunchKernelGGL(delay_k, dim3(1), dim3(64), 0, sB, g_lag_us);
+		}
+		for (int f = 0; f < NFR; f++) for (int p = 0; p < 4; p++) launch_pass(p, f, 1, (f & 1) ? sB : sA);
+		g_stepno++;
+		if (g_stepno % g_join_every == 0) { CHK(hipEventRecord(evStepA, sA)); CHK(hipEventRecord(evStepB, sB)); }
 	} else if (mode == "lockstep") {
 		for (int f = 0; f < NFR; f += 2)
 			for (int p = 0; p < 4; p++) {
@@ -221,6 +237,19 @@ int main(int argc, char **argv)
 			float ms; CHK(hipEventElapsedTime(&ms, a, b));
 			printf("pass %d alone: %.1f us\n", p, ms * 1000 / 30);
 		}
+	}
+	if (argc > 2 && !strcmp(argv[2], "stagger")) {
+		// does a free-running pair of streams keep its phase?  and which lag behind stream A is best for stream B?
+		for (int round = 0; round < 2; round++) {
+			printf("round %d: aligned=%.0f free(%d steps)=%.0f free(%d steps)=%.0f", round, run_mode("aligned", steps), steps, run_mode("free", steps), 10 * steps, run_mode("free", 10 * steps));
+			for (int je : {1, 8, 64})
+				for (int lag : {0, 5, 10, 15, 20, 25, 30, 40, 60}) {
+					g_join_every = je; g_lag_us = lag; g_stepno = 0;
+					printf(" j%d/lag%d=%.0f", je, lag, run_mode("stagger", 4 * steps)); fflush(stdout);
+				}
+			printf("\n");
+		}
+		return 0;
 	}
 	const char *modes[] = {"single", "aligned", "free", "lag1", "lag2", "lockstep", "pipe", "batch2", "batch4"};
 	for (int round = 0; round < 3; round++) {
