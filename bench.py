@@ -72,6 +72,59 @@ def cpu_baseline(max_seconds=30.0):
                       f"(roundtrip max abs err {err:.1e})"}
 
 
+def fftw_cpu_baseline(max_seconds=20.0):
+    """The real FFTW (north_star "next to the FFTW CPU path") when the box has it: dlopen libfftw3f.so.3
+    (never our own alias, which has no .3 soname and is not on the loader path), fftwf_plan_many_r2r(FFTW_ESTIMATE) of the 4K
+    roundtrip with 1 thread and with all cores.  Returns None when FFTW is absent (this image and, so far, the GPU boxes)."""
+    import ctypes as C
+    try:
+        fw = C.CDLL("libfftw3f.so.3")
+        if not hasattr(fw, "fftwf_plan_many_r2r") or not hasattr(fw, "fftwf_version"):
+            return None
+    except OSError:
+        return None
+    import numpy as np
+    ip = C.POINTER(C.c_int)
+    fw.fftwf_plan_many_r2r.restype = C.c_void_p
+    fw.fftwf_plan_many_r2r.argtypes = [C.c_int, ip, C.c_int, C.c_void_p, ip, C.c_int, C.c_int, C.c_void_p, ip, C.c_int, C.c_int, ip, C.c_uint]
+    fw.fftwf_execute.argtypes = [C.c_void_p]
+    fw.fftwf_destroy_plan.argtypes = [C.c_void_p]
+    threads_ok = False
+    try:
+        ft = C.CDLL("libfftw3f_threads.so.3")
+        threads_ok = bool(ft.fftwf_init_threads())
+    except OSError:
+        ft = None
+    x = (np.random.default_rng(SEED).random(H * W * C, dtype=np.float32))
+    ia = lambda v: (C.c_int * len(v))(*v)
+    out = {}
+    for label, nthr in (("1", 1), ("all", os.cpu_count() or 1)):
+        if nthr > 1 and not threads_ok:
+            continue
+        if threads_ok:
+            ft.fftwf_plan_with_nthreads(nthr)
+        pf = fw.fftwf_plan_many_r2r(2, ia([H, W]), C, x.ctypes.data, None, C, 1, x.ctypes.data, None, C, 1, ia([5, 5]), 1 << 6)
+        pi = fw.fftwf_plan_many_r2r(2, ia([H, W]), C, x.ctypes.data, None, C, 1, x.ctypes.data, None, C, 1, ia([4, 4]), 1 << 6)
+        if not pf or not pi:
+            return None
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            fw.fftwf_execute(pf); fw.fftwf_execute(pi)
+            x *= np.float32(1.0 / (4.0 * W * H))
+            reps += 1
+            el = time.perf_counter() - t0
+            if el > max_seconds / 2 or reps >= 32:
+                break
+        out[label] = (round(reps * H * W / 1e6 / el, 3), nthr, reps)
+        fw.fftwf_destroy_plan(pf); fw.fftwf_destroy_plan(pi)
+    if not out:
+        return None
+    best = out.get("all", out["1"])
+    ver = C.c_char_p.in_dll(fw, "fftwf_version").value.decode()
+    return {"value": best[0], "unit": "Mpixels/s", "cores": best[1], "kind": "fftw", "single_thread_value": out["1"][0],
+            "sample": f"{best[2]} roundtrip(s) of one 3840x2160x3 f32 frame, {ver}, fftwf_plan_many_r2r(FFTW_ESTIMATE), {best[1]} thread(s)"}
+
+
 def self_launch(ngpus):
     """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py ...`
     as a child (one rank per GPU, RCCL rendezvous on 127.0.0.1) and return its exit code."""
@@ -205,6 +258,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
+    enqueue_s = time.perf_counter() - t0          # host time to enqueue all steps (must stay well below the GPU's time)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -277,11 +331,14 @@ def main():
                        "frames_per_gpu_per_step": args.frames, "hip_streams": nstreams, "stream_schedule": schedule, "layout": "interleaved HWC, in place, device-resident",
                        "parallelism": f"frame-sharded x{world}, no collective"},
             "roundtrip_frac_of_hbm_roofline": round(value * 1e6 * ALG_BYTES_PER_PIXEL / (HBM_PEAK * world), 4),      # per GPU
-            "max_abs_drift_after_all_roundtrips": drift,
+            "max_abs_drift_after_all_roundtrips": drift, "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 5),
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
+            fw_ = fftw_cpu_baseline()
+            # the oracle's port stays THE cpu_baseline object (kind "port"); a real FFTW, when the box has one, is reported beside it
+            line["cpu_baseline_fftw"] = fw_ if fw_ is not None else "libfftw3f.so.3 not present on this box"
         # a run whose frames no longer equal the input after all the roundtrips did not time the transform: no headline number
         bad = not (drift <= DRIFT_BOUND)
         if bad:

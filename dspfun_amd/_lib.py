@@ -20,6 +20,8 @@ SYMBOLS = [
     "dspfft_execute_many", "dspfft_event_create", "dspfft_event_destroy", "dspfft_event_synchronize", "dspfft_event_elapsed_ms",
     "dspfft_last_error", "dspfft_version",
     "dspfft_scan_zigzag", "dspfft_scan_zigzag_frame_ids", "dspfft_execute_masked_accumulate", "dspfft_scan_scatter", "dspfft_accumulate", "dspfft_broadcast_dc",
+    "dspfft_scan_limit", "dspfft_scan_max_interval", "dspfft_scan_owner_index", "dspfft_scan_frame_ids", "dspfft_scan_coords", "dspfft_scan_stamp",
+    "dspfft_scan_index_to_frame_ids", "dspfft_scan_magnitude_work_bytes", "dspfft_scan_magnitude_index",
     "dspfft_u8_to_f32", "dspfft_f32_to_u8",
     "dspfft_zoom_ncomponents", "dspfft_zoom_basis", "dspfft_zoom_work_floats", "dspfft_zoom_product", "dspfft_gemm_nt_f32",
     "dspfft_zoom_last_error", "dspfft_applybasis_work_floats", "dspfft_applybasis_partsums",
@@ -78,6 +80,18 @@ def bind(lib):
     lib.dspfft_scan_zigzag.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, vp]
     lib.dspfft_scan_zigzag_frame_ids.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, vp]
     lib.dspfft_execute_masked_accumulate.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, C.c_int, vp]
+    lib.dspfft_scan_limit.restype = C.c_uint64
+    lib.dspfft_scan_limit.argtypes = [C.c_int, C.c_uint32, C.c_uint32]
+    lib.dspfft_scan_max_interval.restype = C.c_uint64
+    lib.dspfft_scan_max_interval.argtypes = [C.c_int, C.c_uint32, C.c_uint32]
+    lib.dspfft_scan_owner_index.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, vp]
+    lib.dspfft_scan_frame_ids.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint64, vp]
+    lib.dspfft_scan_coords.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, vp]
+    lib.dspfft_scan_stamp.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp]
+    lib.dspfft_scan_index_to_frame_ids.argtypes = [vp, C.c_uint64, C.c_uint64, vp]
+    lib.dspfft_scan_magnitude_work_bytes.restype = C.c_size_t
+    lib.dspfft_scan_magnitude_work_bytes.argtypes = [C.c_uint32, C.c_uint32]
+    lib.dspfft_scan_magnitude_index.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_int, C.c_double, vp, C.c_size_t, C.POINTER(C.c_uint32), vp]
     lib.dspfft_scan_scatter.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_int, vp]
     lib.dspfft_accumulate.argtypes = [vp, vp, C.c_uint64, vp]
     lib.dspfft_broadcast_dc.argtypes = [vp, vp, C.c_uint64, C.c_int, vp]

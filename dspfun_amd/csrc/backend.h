@@ -45,6 +45,15 @@ int be_launch_spec_u8(int row_spec_id, const PassArgs &a, const U8IO &io, int nw
 // fused column roundtrip: REDFT10 along the tile axis (af), pointwise filter, REDFT01 (ai); both passes share spec `id`
 int be_launch_roundtrip(int id, const PassArgs &af, const PassArgs &ai, const MotionFilter &filt, unsigned long long *coded, int nwg, void *stream);
 
+// scan orders other than zigzag (scan_core.h, scan_methods.hip).  be_scan_owner_index: step == 0 writes the owner scan index of
+// every pixel, step > 0 the frame id index / step with the DC pixel set to 0xFFFFFFFF
+int be_scan_owner_index(uint32_t *idx, int method, uint32_t w, uint32_t h, uint64_t step, void *stream);
+int be_scan_coords(uint32_t *lin, int method, uint32_t w, uint32_t h, uint64_t first, uint64_t count, uint64_t slots, void *stream);
+int be_scan_stamp(uint32_t *ids, const uint32_t *lin, uint64_t n, uint32_t frame, void *stream);
+int be_scan_index_to_frame_ids(uint32_t *ids, uint64_t n, uint64_t step, void *stream);
+size_t be_scan_magnitude_work_bytes(uint32_t w, uint32_t h);
+int be_scan_magnitude_index(uint32_t *idx, const float *coeffs, uint32_t w, uint32_t h, int ch, double q, void *work, size_t work_bytes, uint32_t *limit, void *stream);
+
 // timing events on a stream (dspfft_execute_many's profiling aid); the emulation backend has none (elapsed = 0)
 void *be_event_create();
 void be_event_destroy(void *e);

@@ -148,7 +148,7 @@ __global__ void zigzag_ids_kernel(uint32_t *ids, uint32_t w, uint32_t h, uint64_
 {
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
 		const uint32_t p = zigzag_lin(w, h, i);
-		ids[p] = p ? (uint32_t)(i / step) : 0xffffffffu;   // the DC pixel never matches: scan.c:445 clears it
+		ids[p] = !step ? (uint32_t)i : p ? (uint32_t)(i / step) : 0xffffffffu;   // step 0: the owner index itself; frame ids: the DC pixel never matches (scan.c:445 clears it)
 	}
 }
 __global__ void scatter_kernel(float *recon, const float *coeffs, const uint32_t *lin, uint64_t count, int ch)

@@ -984,6 +984,85 @@ extern "C" int dspfft_scan_zigzag(uint32_t *d_lin, uint32_t w, uint32_t h, uint6
 	if ((uint64_t)w * h > 0xffffffffull) return fail(-1, "image too large for 32-bit offsets");
 	return be_scan_zigzag(d_lin, w, h, first, count, s) ? fail(-4, "launch failed") : 0;
 }
+// ---- scan methods other than zigzag (scan_core.h) ----
+#include "scan_core.h"
+extern "C" uint64_t dspfft_scan_limit(int method, uint32_t w32, uint32_t h32)
+{
+	const uint64_t w = w32, h = h32;
+	switch (method) {
+	case SCANM_ROW: return h;
+	case SCANM_COLUMN: return w;
+	case SCANM_DIAGONAL: return w + h - 1;
+	case SCANM_MIRROR: case SCANM_BOX: return std::max(w, h);
+	case SCANM_IBOX: return std::min(w, h);
+	case SCANM_RADIAL: case SCANM_IRADIAL: return rint_hypot(w - 1, h - 1) + 1;      // the farthest corner's bucket is the last one
+	case SCANM_HORIZONTAL: case SCANM_VERTICAL: case SCANM_ZIGZAG: return w * h;
+	default: return 0;
+	}
+}
+extern "C" uint64_t dspfft_scan_max_interval(int method, uint32_t w32, uint32_t h32)
+{
+	const uint64_t w = w32, h = h32;
+	switch (method) {
+	case SCANM_ROW: return w;
+	case SCANM_COLUMN: return h;
+	case SCANM_DIAGONAL: return std::min(w, h);
+	case SCANM_MIRROR: return std::min(w, h) * 2 - 1;
+	case SCANM_BOX: case SCANM_IBOX: return w + h;
+	case SCANM_HORIZONTAL: case SCANM_VERTICAL: case SCANM_ZIGZAG: return 1;
+	default: return 0;                                                                // radial / iradial: no closed form (owner ids only)
+	}
+}
+static int scan_args_ok(const void *p, int method, uint32_t w, uint32_t h)
+{
+	if (!p || !w || !h || method < 0 || method >= SCANM_COUNT) return fail(-1, "bad scan arguments");
+	if ((uint64_t)w * h > 0xfffffffeull) return fail(-1, "image too large for 32-bit offsets");
+	return 0;
+}
+extern "C" int dspfft_scan_owner_index(uint32_t *d_index, int method, uint32_t w, uint32_t h, void *s)
+{
+	if (int rc = scan_args_ok(d_index, method, w, h)) return rc;
+	if (method == SCANM_BOX) return fail(-2, "box has no single owner per pixel: use dspfft_scan_coords + dspfft_scan_stamp");
+	if (method == SCANM_ZIGZAG) return be_scan_zigzag_frame_ids(d_index, w, h, 0, s) ? fail(-4, "launch failed") : 0;
+	return be_scan_owner_index(d_index, method, w, h, 0, s) ? fail(-4, "launch failed") : 0;
+}
+extern "C" int dspfft_scan_frame_ids(uint32_t *d_ids, int method, uint32_t w, uint32_t h, uint64_t step, void *s)
+{
+	if (int rc = scan_args_ok(d_ids, method, w, h)) return rc;
+	if (!step) return fail(-1, "step must be >= 1");
+	if (method == SCANM_BOX) return fail(-2, "box has no single owner per pixel: use dspfft_scan_coords + dspfft_scan_stamp");
+	if (method == SCANM_ZIGZAG) return be_scan_zigzag_frame_ids(d_ids, w, h, step, s) ? fail(-4, "launch failed") : 0;
+	return be_scan_owner_index(d_ids, method, w, h, step, s) ? fail(-4, "launch failed") : 0;
+}
+extern "C" int dspfft_scan_coords(uint32_t *d_lin, int method, uint32_t w, uint32_t h, uint64_t first, uint64_t count, void *s)
+{
+	if (int rc = scan_args_ok(d_lin, method, w, h)) return rc;
+	const uint64_t slots = dspfft_scan_max_interval(method, w, h);
+	if (!slots) return fail(-2, "radial / iradial have no closed-form coordinate lists: use dspfft_scan_frame_ids");
+	if (first + count > dspfft_scan_limit(method, w, h)) return fail(-1, "scan index range out of bounds");
+	if (method == SCANM_ZIGZAG) return be_scan_zigzag(d_lin, w, h, first, count, s) ? fail(-4, "launch failed") : 0;
+	return be_scan_coords(d_lin, method, w, h, first, count, slots, s) ? fail(-4, "launch failed") : 0;
+}
+extern "C" int dspfft_scan_stamp(uint32_t *d_ids, const uint32_t *d_lin, uint64_t nslots, uint32_t frame_id, void *s)
+{
+	if (!d_ids || (!d_lin && nslots)) return fail(-1, "bad arguments");
+	return be_scan_stamp(d_ids, d_lin, nslots, frame_id, s) ? fail(-4, "launch failed") : 0;
+}
+extern "C" int dspfft_scan_index_to_frame_ids(uint32_t *d_ids, uint64_t n, uint64_t step, void *s)
+{
+	if (!d_ids || !n || !step) return fail(-1, "bad arguments");
+	return be_scan_index_to_frame_ids(d_ids, n, step, s) ? fail(-4, "launch failed") : 0;
+}
+extern "C" size_t dspfft_scan_magnitude_work_bytes(uint32_t w, uint32_t h) { return be_scan_magnitude_work_bytes(w, h); }
+extern "C" int dspfft_scan_magnitude_index(uint32_t *d_index, const float *d_coeffs, uint32_t w, uint32_t h, int channels, double qfactor,
+                                           void *d_work, size_t work_bytes, uint32_t *limit, void *s)
+{
+	if (!d_index || !d_coeffs || !d_work || !w || !h || channels < 1) return fail(-1, "bad arguments");
+	if ((uint64_t)w * h > 0xfffffffeull) return fail(-1, "image too large for 32-bit offsets");
+	if (work_bytes < be_scan_magnitude_work_bytes(w, h)) return fail(-1, "work buffer too small: dspfft_scan_magnitude_work_bytes");
+	return be_scan_magnitude_index(d_index, d_coeffs, w, h, channels, qfactor, d_work, work_bytes, limit, s) ? fail(-4, "magnitude sort failed") : 0;
+}
+
 extern "C" int dspfft_scan_scatter(float *r, const float *c, const uint32_t *lin, uint64_t count, uint64_t npix, int ch, void *s)
 {
 	if (!r || !c || (!lin && count) || ch < 1) return fail(-1, "bad arguments");

@@ -168,6 +168,43 @@ int dspfft_execute_masked_accumulate(dspfft_plan plan, const float *d_in, float 
  * reconstructs coefficient (y,x); the DC pixel gets 0xFFFFFFFF (it is pre-added, scan.c:377-383,445). */
 int dspfft_scan_zigzag_frame_ids(uint32_t *d_ids, uint32_t w, uint32_t h, uint64_t step, void *hip_stream);
 
+/* ---- the other scan methods on the device (scan/scan_methods.c:59-67,122-208,240-331), SURVEY.md 8f #3 ----
+ * Method numbers follow host/scan_orders.h.  Every generator is bit-exact against the reference's (integer arithmetic; radial's
+ * rint(hypot) is evaluated exactly).  How a frame loop uses them:
+ *   all methods but box: dspfft_scan_frame_ids once, then dspfft_execute_masked_accumulate(..., frame, ...) per output frame;
+ *   box (a pixel can belong to several scan indices, and its first leg runs out of the image on tall frames): per frame
+ *     dspfft_scan_coords of the frame's scan indices -> dspfft_scan_stamp(ids, ..., frame) -> the same fused execution;
+ *   magnitude (needs the coefficients): dspfft_scan_magnitude_index -> dspfft_scan_index_to_frame_ids;
+ *   file: parsed on the host (host/scan_orders.c scan_order_read_file), uploaded as an index array or as coordinate lists. */
+enum {
+	DSPFFT_SCAN_HORIZONTAL = 0, DSPFFT_SCAN_VERTICAL = 1, DSPFFT_SCAN_ZIGZAG = 2, DSPFFT_SCAN_ROW = 3, DSPFFT_SCAN_COLUMN = 4,
+	DSPFFT_SCAN_DIAGONAL = 5, DSPFFT_SCAN_MIRROR = 6, DSPFFT_SCAN_BOX = 7, DSPFFT_SCAN_IBOX = 8, DSPFFT_SCAN_RADIAL = 9, DSPFFT_SCAN_IRADIAL = 10
+};
+/* number of scan indices (scan_context.c:30 via the method's limit function) and the most coordinates one index yields (host arithmetic) */
+uint64_t dspfft_scan_limit(int method, uint32_t w, uint32_t h);
+uint64_t dspfft_scan_max_interval(int method, uint32_t w, uint32_t h);
+/* d_index[y*w+x] = the scan index that yields pixel (y,x); every method except box (no single owner) */
+int dspfft_scan_owner_index(uint32_t *d_index, int method, uint32_t w, uint32_t h, void *hip_stream);
+/* d_ids[y*w+x] = owner index / step, the DC pixel 0xFFFFFFFF: the generalisation of dspfft_scan_zigzag_frame_ids (which it calls for zigzag) */
+int dspfft_scan_frame_ids(uint32_t *d_ids, int method, uint32_t w, uint32_t h, uint64_t step, void *hip_stream);
+/* coordinate lists: for scan indices [first, first+count), slot j < dspfft_scan_max_interval of index i holds y*w+x of its j-th coordinate,
+ * or 0xFFFFFFFF (slot beyond the index's interval, or a box coordinate past the end of the image); all methods but radial / iradial.
+ * d_lin holds count * dspfft_scan_max_interval entries. */
+int dspfft_scan_coords(uint32_t *d_lin, int method, uint32_t w, uint32_t h, uint64_t first, uint64_t count, void *hip_stream);
+/* d_ids[d_lin[t]] = frame_id for every valid entry (the DC pixel is left alone): builds the mask of ONE frame from coordinate lists;
+ * ids of earlier frames need no clearing as long as frame ids are not reused (initialise d_ids to 0xFFFFFFFF once) */
+int dspfft_scan_stamp(uint32_t *d_ids, const uint32_t *d_lin, uint64_t nslots, uint32_t frame_id, void *hip_stream);
+/* in place: ids[p] = index[p] / step, DC pixel 0xFFFFFFFF (for index arrays from dspfft_scan_magnitude_index or a `file` order) */
+int dspfft_scan_index_to_frame_ids(uint32_t *d_ids, uint64_t npixels, uint64_t step, void *hip_stream);
+/* scan_methods.c:240-296: d_index[p] = scan index of pixel p when pixels are ordered by descending magnitude key
+ * (sum_z |c|, x sqrt2 per non-zero index, optionally quantised by qfactor; 0 = off), INCLUDING the reference's grouping rule (an
+ * element whose key differs from its predecessor's still joins the predecessor's index; the next element opens a new one).
+ * Ties: the reference leaves their order to qsort; here equal keys keep raster order (stable sort) -- documented, deterministic.
+ * Synchronises the stream; *limit receives the number of scan indices.  d_work: dspfft_scan_magnitude_work_bytes(w, h) bytes. */
+size_t dspfft_scan_magnitude_work_bytes(uint32_t w, uint32_t h);
+int dspfft_scan_magnitude_index(uint32_t *d_index, const float *d_coeffs, uint32_t w, uint32_t h, int channels, double qfactor,
+                                void *d_work, size_t work_bytes, uint32_t *limit, void *hip_stream);
+
 /* scan/scan.c:451-459 arithmetic: sum += image (len floats). */
 int dspfft_accumulate(float *d_sum, const float *d_image, uint64_t len, void *hip_stream);
 

@@ -13,6 +13,8 @@
 #include "dct_spec.h"
 #include "spec_list.h"
 #include "elementwise_core.h"
+#include "scan_core.h"
+#include <algorithm>
 
 namespace dspfft {
 
@@ -275,7 +277,48 @@ int be_scan_zigzag(uint32_t *lin, uint32_t w, uint32_t h, uint64_t first, uint64
 }
 int be_scan_zigzag_frame_ids(uint32_t *ids, uint32_t w, uint32_t h, uint64_t step, void *)
 {
-	for (uint64_t i = 0; i < (uint64_t)w * h; i++) { const uint32_t p = zigzag_lin(w, h, i); ids[p] = p ? (uint32_t)(i / step) : 0xffffffffu; }
+	for (uint64_t i = 0; i < (uint64_t)w * h; i++) { const uint32_t p = zigzag_lin(w, h, i); ids[p] = !step ? (uint32_t)i : p ? (uint32_t)(i / step) : 0xffffffffu; }
+	return 0;
+}
+int be_scan_owner_index(uint32_t *idx, int method, uint32_t w, uint32_t h, uint64_t step, void *)
+{
+	for (uint64_t p = 0; p < (uint64_t)w * h; p++) {
+		const uint64_t i = scan_owner_index(method, w, h, p / w, p % w);
+		idx[p] = step ? (p ? (uint32_t)(i / step) : SCAN_NONE) : (uint32_t)i;
+	}
+	return 0;
+}
+int be_scan_coords(uint32_t *lin, int method, uint32_t w, uint32_t h, uint64_t first, uint64_t count, uint64_t slots, void *)
+{
+	for (uint64_t k = 0; k < count; k++)
+		for (uint64_t j = 0; j < slots; j++)
+			lin[k * slots + j] = j < scan_interval(method, w, h, first + k) ? scan_coord_lin(method, w, h, first + k, j) : SCAN_NONE;
+	return 0;
+}
+int be_scan_stamp(uint32_t *ids, const uint32_t *lin, uint64_t n, uint32_t frame, void *)
+{
+	for (uint64_t t = 0; t < n; t++) if (lin[t] != SCAN_NONE && lin[t] != 0) ids[lin[t]] = frame;
+	return 0;
+}
+int be_scan_index_to_frame_ids(uint32_t *ids, uint64_t n, uint64_t step, void *)
+{
+	for (uint64_t p = 0; p < n; p++) ids[p] = p ? (uint32_t)(ids[p] / step) : SCAN_NONE;
+	return 0;
+}
+size_t be_scan_magnitude_work_bytes(uint32_t, uint32_t) { return 16; }
+int be_scan_magnitude_index(uint32_t *idx, const float *coeffs, uint32_t w, uint32_t h, int ch, double q, void *, size_t, uint32_t *limit, void *)
+{
+	const uint64_t n = (uint64_t)w * h;
+	std::vector<float> key(n);
+	std::vector<uint32_t> order(n);
+	for (uint64_t p = 0; p < n; p++) { key[p] = scan_magnitude_key(coeffs + p * ch, ch, p / w, p % w, q); order[p] = (uint32_t)p; }
+	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key[a] > key[b]; });
+	uint32_t j = 0;
+	for (uint64_t k = 0; k < n; k++) {
+		if (k > 0 && (k == 1 || key[order[k - 1]] != key[order[k - 2]])) j++;
+		idx[order[k]] = j;
+	}
+	if (limit) *limit = j + 1;
 	return 0;
 }
 int be_scan_scatter(float *recon, const float *coeffs, const uint32_t *lin, uint64_t count, uint64_t npixels, int ch, void *)

@@ -1,0 +1,116 @@
+"""Shared body of the scan-method generator checks: the same assertions run against the CPU emulation of the device functions
+(tests/test_scan_methods_cpu.py) and against the HIP library on the GPU (tests/test_scan_methods_gpu.py).  The yardstick is the
+harness-side host library host/scan_orders.c (itself checked against the oracle restatements and the reference's known answers in
+tests/test_scan_orders_cpu.py, and against the compiled reference by the round-1 judge)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+METHODS = ["horizontal", "vertical", "zigzag", "row", "column", "diagonal", "mirror", "box", "ibox", "radial", "iradial"]
+NONE = 0xFFFFFFFF
+SIZES = [(8, 8), (16, 9), (9, 16), (7, 5), (5, 12), (1, 6), (6, 1), (33, 20)]
+
+
+def host_lib():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host"), "libscanorders.so"])
+    lib = C.CDLL(os.path.join(ROOT, "host", "libscanorders.so"))
+    lib.scan_order_limit.restype = C.c_size_t
+    lib.scan_order_limit.argtypes = [C.c_int, C.c_size_t, C.c_size_t]
+    lib.scan_order_max_interval.restype = C.c_size_t
+    lib.scan_order_max_interval.argtypes = [C.c_int, C.c_size_t, C.c_size_t]
+    lib.scan_order_coords.restype = C.c_size_t
+    lib.scan_order_coords.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
+    return lib
+
+
+def host_orders(so, m, w, h):
+    buf = np.zeros((so.scan_order_max_interval(m, w, h) + 1, 2), dtype=np.uint64)
+    out = []
+    for i in range(so.scan_order_limit(m, w, h)):
+        n = so.scan_order_coords(m, w, h, i, buf.ctypes.data)
+        out.append([(int(buf[j, 0]), int(buf[j, 1])) for j in range(n)])
+    return out
+
+
+def check_method(L, so, m, w, h, alloc, fetch):
+    """alloc(n_uint32) -> (handle, device pointer); fetch(handle) -> numpy uint32 array"""
+    ref = host_orders(so, m, w, h)
+    assert L.dspfft_scan_limit(m, w, h) == len(ref), (METHODS[m], w, h)
+    name = METHODS[m]
+    # ---- owner index / frame ids (every method but box) ----
+    if name != "box":
+        want = np.full(w * h, -1, dtype=np.int64)
+        for i, cs in enumerate(ref):
+            for (y, x) in cs:
+                assert want[y * w + x] in (-1, i)            # ibox emits its corner twice, in the same index
+                want[y * w + x] = i
+        assert (want >= 0).all()
+        hnd, ptr = alloc(w * h)
+        assert L.dspfft_scan_owner_index(ptr, m, w, h, None) == 0
+        assert np.array_equal(fetch(hnd).astype(np.int64), want), (name, w, h)
+        for step in (1, 3, max(1, len(ref) // 4)):
+            assert L.dspfft_scan_frame_ids(ptr, m, w, h, step, None) == 0
+            got = fetch(hnd).astype(np.int64)
+            exp = want // step
+            exp[0] = NONE
+            assert np.array_equal(got, exp), (name, w, h, step)
+    else:
+        hnd, ptr = alloc(w * h)
+        assert L.dspfft_scan_owner_index(ptr, m, w, h, None) != 0      # refused: no single owner
+    # ---- coordinate lists (every method but radial / iradial) ----
+    slots = L.dspfft_scan_max_interval(m, w, h)
+    if name in ("radial", "iradial"):
+        assert slots == 0
+        return
+    assert slots >= max(len(c) for c in ref)
+    first, count = (len(ref) // 3, len(ref) - len(ref) // 3)
+    hnd, ptr = alloc(count * slots)
+    assert L.dspfft_scan_coords(ptr, m, w, h, first, count, None) == 0
+    got = fetch(hnd).reshape(count, slots)
+    for k in range(count):
+        cs = ref[first + k]
+        exp = [(y * w + x if y * w + x < w * h else NONE) for (y, x) in cs] + [NONE] * (slots - len(cs))
+        assert list(got[k]) == exp, (name, w, h, first + k)
+    # ---- stamps: the mask of one frame from its coordinate lists == the set the host loop scatters (scan.c:430-432) ----
+    ids_h, ids_p = alloc(w * h)
+    L.dspfft_scan_index_to_frame_ids(ids_p, w * h, 1, None)       # any content; then mark everything "no frame"
+    hnd2, ptr2 = alloc(w * h)
+    full_h, full_p = alloc(len(ref) * slots)
+    assert L.dspfft_scan_coords(full_p, m, w, h, 0, len(ref), None) == 0
+    step = max(1, len(ref) // 3)
+    return_masks = []
+    for f in range((len(ref) + step - 1) // step):
+        lo, hi = f * step, min(len(ref), (f + 1) * step)
+        assert L.dspfft_scan_stamp(ids_p, full_p + 4 * lo * slots, (hi - lo) * slots, 1000 + f, None) == 0
+        mask = fetch(ids_h) == 1000 + f
+        exp = np.zeros(w * h, dtype=bool)
+        for i in range(lo, hi):
+            for (y, x) in ref[i]:
+                if y * w + x < w * h:
+                    exp[y * w + x] = True
+        exp[0] = False
+        assert np.array_equal(mask, exp), (name, w, h, f)
+        return_masks.append(mask)
+    return return_masks
+
+
+def magnitude_reference(coeffs, w, h, ch, q):
+    """scan_methods.c:240-296 in numpy with the documented tie rule (stable: equal keys in raster order)"""
+    c = coeffs.reshape(h * w, ch).astype(np.float32)
+    s = np.zeros(h * w, dtype=np.float64)
+    for z in range(ch):
+        s += np.abs(c[:, z]).astype(np.float64)
+    ys, xs = np.divmod(np.arange(h * w), w)
+    norm = np.where(xs > 0, np.sqrt(2.0), 1.0) * np.where(ys > 0, np.sqrt(2.0), 1.0)
+    val = (np.rint(s * norm * q / ch) if q else s * norm).astype(np.float32)
+    order = np.argsort(-val.astype(np.float64), kind="stable")
+    sv = val[order]
+    a = np.ones(h * w, dtype=np.int64)
+    a[1:] = (sv[1:] != sv[:-1])
+    j = np.concatenate([[0], np.cumsum(a)[:-1]])
+    idx = np.empty(h * w, dtype=np.int64)
+    idx[order] = j
+    return idx, int(j[-1]) + 1
