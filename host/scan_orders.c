@@ -164,3 +164,78 @@ int scan_order_serialize_index(int method, size_t w, size_t h, FILE *f)
 	free(index); free(yx);
 	return err;
 }
+
+/* ---- the `file` method: scan_precomputed.c:24-120 ---- */
+struct pre { size_t limit, *intervals; size_t (**scans)[2]; };
+
+static int pre_add(struct pre *p, size_t index, size_t x, size_t y)                   /* scan_precomputed.c:24-49 */
+{
+	if (index >= p->limit) {
+		size_t *iv = realloc(p->intervals, sizeof(*iv) * (index + 1));
+		if (!iv) return 0;
+		p->intervals = iv;
+		size_t (**sc)[2] = realloc(p->scans, sizeof(*sc) * (index + 1));
+		if (!sc) return 0;
+		p->scans = sc;
+		for (size_t i = p->limit; i <= index; i++) { p->intervals[i] = 0; p->scans[i] = NULL; }
+		p->limit = index + 1;
+	}
+	size_t (*s)[2] = realloc(p->scans[index], sizeof(*s) * (p->intervals[index] + 1));
+	if (!s) return 0;
+	p->scans[index] = s;
+	s[p->intervals[index]][0] = y; s[p->intervals[index]][1] = x;
+	p->intervals[index]++;
+	return 1;
+}
+static void pre_free(struct pre *p)
+{
+	for (size_t i = 0; i < p->limit; i++) free(p->scans[i]);
+	free(p->scans); free(p->intervals);
+	memset(p, 0, sizeof *p);
+}
+
+int scan_order_read_file(FILE *f, size_t w, size_t h, struct scan_order_list *out)
+{
+	memset(out, 0, sizeof *out);
+	struct pre p = {0, NULL, NULL};
+	char *line = NULL;
+	size_t cap = 0;
+	int ok = 0;
+	if (getline(&line, &cap, f) <= 0) { free(line); return 1; }
+	const int coordinate = strchr(line, ',') || *line == '\n';                         /* scan_precomputed.c:108 */
+	size_t row = 0;
+	do {
+		if (!coordinate && *line == '\n') continue;                                    /* :84-85: blank lines of an index grid */
+		char *string = line, *token;
+		size_t col = 0;
+		while ((token = strsep(&string, " ")) && *token != '\n') {
+			if (!*token) continue;
+			size_t a, b;
+			if (coordinate) { if (sscanf(token, "%zu,%zu", &a, &b) != 2 || !pre_add(&p, row, a, b)) goto done; }           /* x,y of index `row` */
+			else { if (sscanf(token, "%zu", &a) != 1 || !pre_add(&p, a, col, row)) goto done; col++; }                     /* index of pixel (col, row) */
+		}
+		row++;
+	} while (getline(&line, &cap, f) > 0);
+	if (!feof(f) || !p.limit) goto done;
+	for (size_t i = 0; i < p.limit; i++)                                               /* scan_methods.c:401-407 */
+		for (size_t j = 0; j < p.intervals[i]; j++)
+			if (p.scans[i][j][1] >= w || p.scans[i][j][0] >= h) goto done;
+	out->limit = p.limit;
+	out->offset = malloc(sizeof(size_t) * (p.limit + 1));
+	for (size_t i = 0; i < p.limit; i++) { out->offset[i] = out->total; out->total += p.intervals[i]; out->max_interval = umax(out->max_interval, p.intervals[i]); }
+	out->offset[p.limit] = out->total;
+	out->yx = malloc(sizeof(*out->yx) * (out->total + 1));
+	for (size_t i = 0; i < p.limit; i++) memcpy(out->yx + out->offset[i], p.scans[i], sizeof(*out->yx) * p.intervals[i]);
+	ok = 1;
+done:
+	free(line);
+	pre_free(&p);
+	return ok ? 0 : 1;
+}
+
+void scan_order_list_free(struct scan_order_list *l)
+{
+	free(l->offset); free(l->yx);
+	memset(l, 0, sizeof *l);
+}
+

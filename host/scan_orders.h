@@ -25,6 +25,14 @@ size_t scan_order_max_interval(int method, size_t w, size_t h);          /* most
 /* coordinates of scan index i into yx[][2] (room for scan_order_max_interval entries); returns how many */
 size_t scan_order_coords(int method, size_t w, size_t h, size_t i, size_t (*yx)[2]);
 
+/* The `file` method (scan_methods.c:393-410 + scan_precomputed.c:24-120): reads either plaintext serialisation -- coordinate
+ * lists ("x,y x,y ..." per scan index, one index per line; detected by a ',' or an empty first line) or an index grid (one scan
+ * index per pixel, row by row; blank lines skipped) -- and rejects coordinates outside w x h, as init_file does.
+ * On success returns 0 and fills *out (free with scan_order_list_free): coordinates of index i are yx[offset[i] .. offset[i+1]). */
+struct scan_order_list { size_t limit, max_interval, total; size_t *offset; size_t (*yx)[2]; };
+int scan_order_read_file(FILE *f, size_t w, size_t h, struct scan_order_list *out);
+void scan_order_list_free(struct scan_order_list *l);
+
 /* scan_precomputed.c:122-153.  Return 0 on success. */
 int scan_order_serialize_coordinate(int method, size_t w, size_t h, FILE *f);
 int scan_order_serialize_index(int method, size_t w, size_t h, FILE *f);

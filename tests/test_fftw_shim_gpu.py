@@ -306,3 +306,46 @@ def test_random_geometries_on_host_pointers(fftw, seed):
     free_(pin)
     if oop:
         free_(pout)
+
+
+@pytest.mark.parametrize("method", ["horizontal", "vertical", "zigzag", "row", "column", "diagonal", "mirror", "box", "ibox", "radial", "iradial",
+                                    "magnitude", "magnitude:200", "file:coordinate", "file:index", "file:box"])
+def test_scan_device_resident_harness_every_method(tmp_path, method):
+    """host/scan_dev.c: scan's loop with every buffer and every scan order on the GPU.  The final sum equals
+    the input for every method that visits each pixel once; box (shared pixels are added once per frame they appear in) is checked
+    against the host-pointer harness scan_gpu, which runs the reference's own loop shape."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    w, h = 80, 48
+    img = ol.synth_u8(31, w * h * 3).reshape(h, w, 3)
+    ppm, out = tmp_path / "in.ppm", tmp_path / "sum.pf"
+    _write_ppm(ppm, img)
+    arg, step = method, "7"
+    if method.startswith("file:"):
+        kind = method.split(":")[1]
+        import ctypes as C
+        so = C.CDLL(os.path.join(ROOT, "host", "libscanorders.so"))
+        libc = C.CDLL(None)
+        libc.fopen.restype = C.c_void_p
+        libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+        libc.fclose.argtypes = [C.c_void_p]
+        so.scan_order_serialize_coordinate.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_void_p]
+        so.scan_order_serialize_index.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_void_p]
+        path = tmp_path / "order.txt"
+        f = libc.fopen(str(path).encode(), b"w")
+        if kind == "box":        # wide frame: in range, but pixels shared between indices -> per-frame lists + stamps
+            assert so.scan_order_serialize_coordinate(7, w, h, f) == 0
+        elif kind == "coordinate":
+            assert so.scan_order_serialize_coordinate(6, w, h, f) == 0        # mirror
+        else:
+            assert so.scan_order_serialize_index(5, w, h, f) == 0             # diagonal
+        libc.fclose(f)
+        arg = "file:" + str(path)
+    r = subprocess.run([os.path.join(ROOT, "host", "scan_dev"), str(ppm), str(out), step, arg], stderr=subprocess.PIPE, check=True)
+    assert b"device-resident" in r.stderr
+    got = _read_pf(out)
+    if method in ("box", "file:box"):
+        ref_out = tmp_path / "ref.pf"
+        subprocess.run([os.path.join(ROOT, "host", "scan_gpu"), str(ppm), str(ref_out), step, "box"], stderr=subprocess.PIPE, check=True)
+        assert np.abs(got - _read_pf(ref_out)).max() <= 5e-6
+    else:
+        assert np.abs(got - img.astype(np.float64) / 255.0).max() <= 5e-6

@@ -112,3 +112,71 @@ def test_permutation_methods_cover_every_pixel_once(so, method):
     w, h = 12, 7
     flat = [c for idx in product_orders(so, method, w, h) for c in idx]
     assert sorted(flat) == [(y, x) for y in range(h) for x in range(w)]
+
+
+class _OrderList(C.Structure):
+    _fields_ = [("limit", C.c_size_t), ("max_interval", C.c_size_t), ("total", C.c_size_t), ("offset", C.POINTER(C.c_size_t)), ("yx", C.POINTER(C.c_size_t * 2))]
+
+
+class _Precomputed(C.Structure):          # scan/scan_precomputed.h:12-16
+    _fields_ = [("limit", C.c_size_t), ("intervals", C.POINTER(C.c_size_t)), ("scans", C.POINTER(C.POINTER(C.c_size_t * 2)))]
+
+
+@pytest.mark.parametrize("method,w,h", [("diagonal", 8, 8), ("box", 16, 9), ("ibox", 9, 16), ("mirror", 7, 5), ("zigzag", 6, 4), ("radial", 10, 6)])
+@pytest.mark.parametrize("fmt", ["coordinate", "index"])
+def test_file_method_reader_roundtrips_and_matches_the_reference_deserialiser(so, method, w, h, fmt):
+    """`file` (scan_methods.c:393-410): host/scan_orders.c scan_order_read_file on both plaintext serialisations, against the
+    generator that wrote the file and against the REFERENCE's own scan_precomputed_unserialize (oracle/_ref)."""
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    so.scan_order_read_file.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(_OrderList)]
+    so.scan_order_list_free.argtypes = [C.POINTER(_OrderList)]
+    m = METHODS.index(method)
+    orders = product_orders(so, method, w, h)
+    if method == "box":
+        if fmt == "index":
+            pytest.skip("an index grid holds one scan index per pixel: box's shared pixels do not survive it")
+        w_file = max(x for cs in orders for (_, x) in cs) + 1       # box on tall frames runs past the width: the file is wider
+    else:
+        w_file = w
+    with tempfile.NamedTemporaryFile(suffix=".txt", delete=False) as tf:
+        path = tf.name
+    f = libc.fopen(path.encode(), b"w")
+    assert (so.scan_order_serialize_coordinate if fmt == "coordinate" else so.scan_order_serialize_index)(m, w, h, f) == 0
+    libc.fclose(f)
+    lst = _OrderList()
+    f = libc.fopen(path.encode(), b"r")
+    assert so.scan_order_read_file(f, max(w, w_file), h, C.byref(lst)) == 0
+    libc.fclose(f)
+    got = [[(lst.yx[k][0], lst.yx[k][1]) for k in range(lst.offset[i], lst.offset[i + 1])] for i in range(lst.limit)]
+    if fmt == "coordinate":
+        assert got == orders
+    else:        # the grid stores, per pixel, the LAST index that emitted it, listed in raster order
+        owner = {}
+        for i, cs in enumerate(orders):
+            for c in cs:
+                owner[c] = i
+        want = [[] for _ in range(len(orders))]
+        for y in range(h):
+            for x in range(w):
+                want[owner[(y, x)]].append((y, x))
+        assert got == want
+    # the reference's deserialiser on the same file
+    r = ol.ref()
+    if r is not None:
+        r.scan_precomputed_unserialize.restype = C.POINTER(_Precomputed)
+        r.scan_precomputed_unserialize.argtypes = [C.c_void_p]
+        f = libc.fopen(path.encode(), b"r")
+        p = r.scan_precomputed_unserialize(f)
+        libc.fclose(f)
+        assert p and p.contents.limit == lst.limit
+        refl = [[(p.contents.scans[i][j][0], p.contents.scans[i][j][1]) for j in range(p.contents.intervals[i])] for i in range(p.contents.limit)]
+        assert refl == got
+    so.scan_order_list_free(C.byref(lst))
+    # out-of-range coordinates are rejected like init_file does
+    f = libc.fopen(path.encode(), b"r")
+    assert so.scan_order_read_file(f, max(1, w - 1), h, C.byref(lst)) != 0
+    libc.fclose(f)
+    os.unlink(path)
