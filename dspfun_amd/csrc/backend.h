@@ -45,6 +45,12 @@ int be_launch_spec_u8(int row_spec_id, const PassArgs &a, const U8IO &io, int nw
 // fused column roundtrip: REDFT10 along the tile axis (af), pointwise filter, REDFT01 (ai); both passes share spec `id`
 int be_launch_roundtrip(int id, const PassArgs &af, const PassArgs &ai, const MotionFilter &filt, unsigned long long *coded, int nwg, void *stream);
 
+// strided 3-D regions between an 8-bit buffer and a float buffer (motion's block / scaled regions inside a larger embedding,
+// motion/motion.c:617-640,756-776), and zeroing (motion.c:619 memset before a block is loaded)
+int be_zero(void *p, size_t bytes, void *stream);
+int be_region_u8_to_f32(float *dst, const uint8_t *src, const int n[3], const long long sdst[3], const long long ssrc[3], void *stream);
+int be_region_f32_to_u8(uint8_t *dst, const float *src, double mul, const int n[3], const long long sdst[3], const long long ssrc[3], void *stream);
+
 // scan orders other than zigzag (scan_core.h, scan_methods.hip).  be_scan_owner_index: step == 0 writes the owner scan index of
 // every pixel, step > 0 the frame id index / step with the DC pixel set to 0xFFFFFFFF
 int be_scan_owner_index(uint32_t *idx, int method, uint32_t w, uint32_t h, uint64_t step, void *stream);

@@ -187,6 +187,24 @@ __global__ void f32_to_u8_kernel(uint8_t *d, const float *s, double mul, uint64_
 	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < len; i += (uint64_t)gridDim.x * blockDim.x) d[i] = quantise_u8((double)s[i] * mul);
 }
 
+struct Region3 { int n[3]; long long sd[3], ss[3]; };
+__global__ void region_u8_to_f32_kernel(float *d, const uint8_t *s, Region3 r)
+{
+	const uint64_t total = (uint64_t)r.n[0] * r.n[1] * r.n[2];
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t x = i % r.n[2], y = (i / r.n[2]) % r.n[1], z = i / ((uint64_t)r.n[2] * r.n[1]);
+		d[z * r.sd[0] + y * r.sd[1] + x * r.sd[2]] = (float)s[z * r.ss[0] + y * r.ss[1] + x * r.ss[2]];
+	}
+}
+__global__ void region_f32_to_u8_kernel(uint8_t *d, const float *s, double mul, Region3 r)
+{
+	const uint64_t total = (uint64_t)r.n[0] * r.n[1] * r.n[2];
+	for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t x = i % r.n[2], y = (i / r.n[2]) % r.n[1], z = i / ((uint64_t)r.n[2] * r.n[1]);
+		d[z * r.sd[0] + y * r.sd[1] + x * r.sd[2]] = quantise_u8((double)s[z * r.ss[0] + y * r.ss[1] + x * r.ss[2]] * mul);
+	}
+}
+
 // ---------------------------------------------------------------------------------------------
 void *be_alloc(size_t bytes) { void *p = nullptr; if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return nullptr; return p; }
 void be_free(void *p) { if (p) (void)hipFree(p); }
@@ -348,6 +366,29 @@ int be_u8_to_f32(float *d, const uint8_t *s, uint64_t len, void *stream)
 {
 	if (!len) return 0;
 	hipLaunchKernelGGL(u8_to_f32_kernel, dim3(ew_grid(len)), dim3(256), 0, (hipStream_t)stream, d, s, len);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+int be_zero(void *p, size_t bytes, void *stream) { HIPCHK(hipMemsetAsync(p, 0, bytes, (hipStream_t)stream)); return 0; }
+static Region3 make_region(const int n[3], const long long sd[3], const long long ss[3])
+{
+	Region3 r;
+	for (int a = 0; a < 3; a++) { r.n[a] = n[a]; r.sd[a] = sd[a]; r.ss[a] = ss[a]; }
+	return r;
+}
+int be_region_u8_to_f32(float *dst, const uint8_t *src, const int n[3], const long long sdst[3], const long long ssrc[3], void *stream)
+{
+	const uint64_t total = (uint64_t)n[0] * n[1] * n[2];
+	if (!total) return 0;
+	hipLaunchKernelGGL(region_u8_to_f32_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dst, src, make_region(n, sdst, ssrc));
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+int be_region_f32_to_u8(uint8_t *dst, const float *src, double mul, const int n[3], const long long sdst[3], const long long ssrc[3], void *stream)
+{
+	const uint64_t total = (uint64_t)n[0] * n[1] * n[2];
+	if (!total) return 0;
+	hipLaunchKernelGGL(region_f32_to_u8_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dst, src, mul, make_region(n, sdst, ssrc));
 	HIPCHK(hipGetLastError());
 	return 0;
 }

@@ -814,11 +814,22 @@ int roundtrip_core(dspfft_plan fwd, dspfft_plan inv, const float *d_in, float *d
 	if (fwd->f64 || inv->f64) return fail(-1, "the fused roundtrip takes f32 plans");
 	const size_t nf = fwd->passes.size(), ni = inv->passes.size();
 	const Pass &F = fwd->passes[nf - 1], &I = inv->passes[0];
-	if (F.axis != I.axis || fwd->rank != inv->rank || fwd->howmany != inv->howmany)
+	bool differs = fwd->rank != inv->rank;
+	for (int a = 0; !differs && a < fwd->rank; a++) differs = fwd->n[a] != inv->n[a];
+	if (fwd->rank != inv->rank || fwd->howmany != inv->howmany || (!differs && F.axis != I.axis))
 		return fail(-1, "the forward plan's last pass and the inverse plan's first pass must run along the same axis (create the inverse with dspfft_plan_many_r2r_ordered(..., 1))");
-	for (int a = 0; a < fwd->rank; a++)
-		if (fwd->n[a] != inv->n[a] || fwd->axes[a].os != inv->axes[a].is || inv->axes[a].is != inv->axes[a].os || fwd->kinds[a] != DSPFFT_REDFT10 || inv->kinds[a] != DSPFFT_REDFT01)
+	// motion's `scaled != block` (motion.c:535-552): the inverse runs over DIFFERENT extents inside the same embedding -- larger:
+	// the spectrum is zero-padded (band-limited upscale), smaller: truncated (downscale)
+	bool rescale = false;
+	for (int a = 0; a < fwd->rank; a++) {
+		if (fwd->axes[a].os != inv->axes[a].is || inv->axes[a].is != inv->axes[a].os || fwd->kinds[a] != DSPFFT_REDFT10 || inv->kinds[a] != DSPFFT_REDFT01)
 			return fail(-1, "roundtrip: the inverse must be REDFT01, in place, on the forward (REDFT10) plan's output layout");
+		rescale = rescale || fwd->n[a] != inv->n[a];
+	}
+	if (rescale && (!fwd->batches.empty() || !inv->batches.empty())) return fail(-2, "roundtrip with different forward / inverse extents takes one block per call (howmany = 1)");
+	if (rescale)
+		for (int a = 0; a < fwd->rank; a++)
+			if (fwd->axes[a].is != fwd->axes[a].os) return fail(-2, "roundtrip with different forward / inverse extents needs ONE embedding for input, work and output (motion.c:535-552)");
 	if (fwd->batches.size() != inv->batches.size()) return fail(-1, "roundtrip: batch layouts differ");
 	for (size_t b = 0; b < fwd->batches.size(); b++)
 		if (fwd->batches[b].n != inv->batches[b].n || fwd->batches[b].os != inv->batches[b].is || inv->batches[b].is != inv->batches[b].os) return fail(-1, "roundtrip: batch layouts differ");
@@ -835,9 +846,35 @@ int roundtrip_core(dspfft_plan fwd, dspfft_plan inv, const float *d_in, float *d
 	}
 	// extent of the working buffer in elements (the filter addresses it with 32-bit offsets)
 	long long span = 1;
-	for (int a = 0; a < fwd->rank; a++) span += (long long)(fwd->n[a] - 1) * fwd->axes[a].os;
+	for (int a = 0; a < fwd->rank; a++) span += (long long)(std::max(fwd->n[a], inv->n[a]) - 1) * fwd->axes[a].os;
 	for (const Dim &b : fwd->batches) span += (long long)(b.n - 1) * b.os;
 	if (fp && span >= (1ll << 31)) return fail(-2, "filtered roundtrip addresses the buffer with 31-bit offsets: buffer too large");
+	// region geometry of the two ends (rank padded to 3 with unit extents)
+	int nf3[3] = {1, 1, 1}, ni3[3] = {1, 1, 1};
+	long long sw3[3] = {0, 0, 0}, si3[3] = {0, 0, 0};
+	for (int a = 0; a < fwd->rank; a++) {
+		const int k = 3 - fwd->rank + a;
+		nf3[k] = fwd->n[a]; ni3[k] = inv->n[a]; sw3[k] = fwd->axes[a].os; si3[k] = fwd->axes[a].is;
+	}
+	if (rescale) {
+		// one block, unfused: zero the working buffer (motion.c:619), load the block region, forward, filter, inverse over the
+		// scaled region, store it.  In place on a float buffer the caller has zeroed everything outside the block itself.
+		if (d_in8) {
+			if (be_zero(d_out, (size_t)span * sizeof(float), stream) || be_region_u8_to_f32(d_out, d_in8, nf3, sw3, si3, stream)) return fail(-4, "launch failed");
+			d_in = d_out;
+		} else if (d_in != d_out) {
+			if (be_zero(d_out, (size_t)span * sizeof(float), stream)) return fail(-4, "launch failed");
+		}
+		for (size_t i = 0; i < nf; i++) {
+			const Pass &P = fwd->passes[i];
+			if (int rc = run_pass<float>(fwd, P, (P.first && !d_in8) ? d_in : d_out, d_out, i + 1 == nf, stream)) return rc;
+		}
+		if (fp && be_motion_filter(d_out, mf, (uint64_t)span, d_coeffs_coded, stream)) return fail(-4, "filter launch failed");
+		for (size_t i = 0; i < ni; i++)
+			if (int rc = run_pass<float>(inv, inv->passes[i], (const float *)d_out, d_out, i + 1 == ni, stream)) return rc;
+		if (d_out8 && be_region_f32_to_u8(d_out8, d_out, mul8, ni3, sw3, sw3, stream)) return fail(-4, "launch failed");
+		return 0;
+	}
 	if (d_in8 || d_out8) {
 		// the 8-bit buffers share the plans' element layout; the unfused conversions below walk whole spans
 		if (nf < 2 || ni < 2) return fail(-2, "8-bit roundtrip needs at least two transformed axes");

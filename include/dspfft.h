@@ -122,6 +122,11 @@ typedef struct {
 int dspfft_execute_roundtrip(dspfft_plan fwd, dspfft_plan inv, const float *d_in, float *d_out,
                              const dspfft_motion_filter_params *filter, unsigned long long *d_coeffs_coded, void *hip_stream);
 
+/* `scaled != block` (motion/motion.c:535-552,566,644-647,748-759): `inv` may be planned over DIFFERENT extents than `fwd` inside the
+ * same embedding (same strides; howmany = 1).  Larger extents zero-pad the spectrum (band-limited upscale), smaller ones truncate
+ * it (downscale); the filter's `active` is min(block, scaled) per axis.  The transforms then run unfused.  The work buffer is
+ * zeroed first (motion.c:619) except in place on a float buffer, where the caller has zeroed everything outside the block. */
+
 /* The same with motion's 8-bit samples at both ends (motion/motion.c:617-640 load, :760-776 store): d_in and d_out
  * hold uint8 samples in the plans' input / output element layout, d_work is a float buffer in the plans' working
  * layout.  When the first forward pass and the last inverse pass are planar specialised row passes they read the
@@ -204,6 +209,22 @@ int dspfft_scan_index_to_frame_ids(uint32_t *d_ids, uint64_t npixels, uint64_t s
 size_t dspfft_scan_magnitude_work_bytes(uint32_t w, uint32_t h);
 int dspfft_scan_magnitude_index(uint32_t *d_index, const float *d_coeffs, uint32_t w, uint32_t h, int channels, double qfactor,
                                 void *d_work, size_t work_bytes, uint32_t *limit, void *hip_stream);
+
+/* ---- the rest of motion's block loop (motion/motion.c), HIP-only entry points ---- */
+enum { DSPFFT_MOTION_NONE = 0, DSPFFT_MOTION_ABS = 1, DSPFFT_MOTION_SHIFT = 2, DSPFFT_MOTION_FLAT = 3, DSPFFT_MOTION_COPY = 4 };
+/* motion.c:617-640: the {n[0],n[1],n[2]} corner of an 8-bit buffer -> float, both laid out as planes of minbuf_hw[0] x minbuf_hw[1];
+ * ispec_mode decodes an input spectrogram (--ispec: shift uses ic = 127.5 / log1p(N normalization 255 8), :568,626-628) */
+int dspfft_motion_load_u8(float *d_coeffs, const uint8_t *d_pix, const int n[3], const int minbuf_hw[2], int ispec_mode, double ic, double normalization, void *hip_stream);
+/* motion.c:756-776: pel = coeff * scalefactor * normalization, then the --spec encode (abs / shift with constant c, :755,762-763; flat :764)
+ * or * normalization again (none / copy, :767), clamp and lround to 8 bits */
+int dspfft_motion_store_u8(uint8_t *d_pix, const float *d_coeffs, const int n[3], const int minbuf_hw[2], int spec_mode,
+                           double scalefactor, double normalization, double c, void *hip_stream);
+/* motion.c:652-668 (--coeff-limit): keep the `keep` coefficients of largest magnitude among d_coeffs[0 .. count), zero the rest.
+ * Radix select on the device (four histogram passes over the bits of |c|, no sort).  Ties at the threshold: the reference's choice
+ * depends on qsort; here the earliest in buffer order are kept -- documented, deterministic. */
+size_t dspfft_motion_topn_work_bytes(size_t count);
+int dspfft_motion_topn(float *d_coeffs, size_t count, size_t keep, void *d_work, size_t work_bytes, void *hip_stream);
+const char *dspfft_motion_last_error(void);
 
 /* scan/scan.c:451-459 arithmetic: sum += image (len floats). */
 int dspfft_accumulate(float *d_sum, const float *d_image, uint64_t len, void *hip_stream);

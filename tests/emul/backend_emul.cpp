@@ -329,6 +329,19 @@ int be_scan_scatter(float *recon, const float *coeffs, const uint32_t *lin, uint
 }
 int be_accumulate(float *sum, const float *img, uint64_t len, void *) { for (uint64_t i = 0; i < len; i++) sum[i] += img[i]; return 0; }
 int be_broadcast_dc(float *sum, const float *c, uint64_t npix, int ch, void *) { for (uint64_t p = 0; p < npix; p++) for (int z = 0; z < ch; z++) sum[p * ch + z] = c[z]; return 0; }
+int be_zero(void *p, size_t bytes, void *) { memset(p, 0, bytes); return 0; }
+int be_region_u8_to_f32(float *dst, const uint8_t *src, const int n[3], const long long sd[3], const long long ss[3], void *)
+{
+	for (long long z = 0; z < n[0]; z++) for (long long y = 0; y < n[1]; y++) for (long long x = 0; x < n[2]; x++)
+		dst[z * sd[0] + y * sd[1] + x * sd[2]] = (float)src[z * ss[0] + y * ss[1] + x * ss[2]];
+	return 0;
+}
+int be_region_f32_to_u8(uint8_t *dst, const float *src, double mul, const int n[3], const long long sd[3], const long long ss[3], void *)
+{
+	for (long long z = 0; z < n[0]; z++) for (long long y = 0; y < n[1]; y++) for (long long x = 0; x < n[2]; x++)
+		dst[z * sd[0] + y * sd[1] + x * sd[2]] = quantise_u8((double)src[z * ss[0] + y * ss[1] + x * ss[2]] * mul);
+	return 0;
+}
 int be_u8_to_f32(float *d, const uint8_t *s, uint64_t len, void *) { for (uint64_t i = 0; i < len; i++) d[i] = (float)s[i]; return 0; }
 int be_f32_to_u8(uint8_t *d, const float *s, double mul, uint64_t len, void *) { for (uint64_t i = 0; i < len; i++) d[i] = quantise_u8((double)s[i] * mul); return 0; }
 
