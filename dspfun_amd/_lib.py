@@ -25,6 +25,7 @@ SYMBOLS = [
     "dspfft_u8_to_f32", "dspfft_f32_to_u8",
     "dspfft_zoom_ncomponents", "dspfft_zoom_basis", "dspfft_zoom_work_floats", "dspfft_zoom_product", "dspfft_gemm_nt_f32",
     "dspfft_zoom_last_error", "dspfft_applybasis_work_floats", "dspfft_applybasis_partsums",
+    "dspfft_applybasis_work_floats_ex", "dspfft_applybasis_partsums_ex", "dspfft_applybasis_render",
     "dspfft_motion_load_u8", "dspfft_motion_store_u8", "dspfft_motion_topn_work_bytes", "dspfft_motion_topn", "dspfft_motion_last_error",
     "dspfft_spec_encode", "dspfft_ispec_decode", "dspfft_motion_filter", "dspfft_scan_pruned_accumulate", "dspfft_pointwise_last_error",
 ]
@@ -121,6 +122,10 @@ def bind(lib):
         lib.dspfft_scan_pruned_accumulate.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
         lib.dspfft_applybasis_work_floats.restype = C.c_size_t
         lib.dspfft_applybasis_work_floats.argtypes = [C.c_int] * 7
+        lib.dspfft_applybasis_work_floats_ex.restype = C.c_size_t
+        lib.dspfft_applybasis_work_floats_ex.argtypes = [C.c_int] * 7
+        lib.dspfft_applybasis_partsums_ex.argtypes = [vp, vp, vp] + [C.c_int] * 10 + [C.c_longlong, C.c_longlong, vp, vp]
+        lib.dspfft_applybasis_render.argtypes = [vp, vp] + [C.c_int] * 11 + [C.c_double, C.c_double, C.POINTER(C.c_float), vp]
         lib.dspfft_applybasis_partsums.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_longlong, vp, vp]
     return lib
 

@@ -26,3 +26,69 @@ def partsums(torch, pixels_hwc, function="dft", orthogonal=False, terms=None, pa
     if rc:
         raise DspfftError(lib.dspfft_zoom_last_error().decode())
     return torch.view_as_complex(out)
+
+
+def partsums_ex(torch, pix_re, pix_im=None, function="dft", orthogonal=False, K=None, N=None, partsum=(1, 1), offset=(0, 0)):
+    """The general form (dspfft_applybasis_partsums_ex): K = (Kw, Kh) basis functions, N = (Nw, Nh) blocks of `partsum` pixels;
+    --inverse is K = image size, N = terms / partsum (applybasis.c:378-389); pix_im: the imaginary part of a .coeff input."""
+    lib = _lib.load()
+    h, w, c = pix_re.shape
+    assert c == 3 and pix_re.dtype == torch.float32 and pix_re.is_contiguous()
+    func = FUNCTIONS.index(function)
+    pw, ph = partsum
+    kw, kh = K if K else (w, h)
+    nw, nh = N if N else (w // pw, h // ph)
+    out = torch.empty((kh, kw, nh, nw, 3, 2), dtype=torch.float32, device=pix_re.device)
+    work = torch.empty(lib.dspfft_applybasis_work_floats_ex(w, h, kw, kh, nw, nh, func), dtype=torch.float32, device=pix_re.device)
+    rc = lib.dspfft_applybasis_partsums_ex(out.data_ptr(), pix_re.data_ptr(), pix_im.data_ptr() if pix_im is not None else None, w, h, func, int(orthogonal),
+                                           kw, kh, nw, nh, pw, ph, offset[0], offset[1], work.data_ptr(), None)
+    if rc:
+        raise DspfftError(lib.dspfft_zoom_last_error().decode())
+    return torch.view_as_complex(out)
+
+
+PLANES = ("real", "imaginary", "magnitude", "phase")
+RESCALES = ("linear", "log", "gain", "level")
+RANGES = ("shift", "abs", "invert", "hue")
+
+
+def render(torch, parts, inverse=False, scale=1, padding=1, plane="real", rescale=("linear",), range_="shift", coeff_scale=1.0, insize_wh=1.0,
+           padcolor=(0.0, 0.0, 0.0, 1.0)):
+    """applybasis.c:392-442: RGBA float frame of the partial sums `parts` (complex [Kh, Kw, Nh, Nw, 3])"""
+    lib = _lib.load()
+    kh, kw, nh, nw, _ = parts.shape
+    tw, th = (nw, nh) if inverse else (kw, kh)
+    fw, fh = kw * nw * scale + padding * tw + padding, kh * nh * scale + padding * th + padding
+    frame = torch.empty((fh, fw, 4), dtype=torch.float32, device=parts.device)
+    pc = (C.c_float * 4)(*padcolor)
+    r0 = RESCALES.index(rescale[0])
+    r1 = RESCALES.index(rescale[1]) if len(rescale) > 1 else -1
+    rc = lib.dspfft_applybasis_render(frame.data_ptr(), torch.view_as_real(parts).data_ptr(), kw, kh, nw, nh, int(inverse), scale, padding,
+                                      PLANES.index(plane), r0, r1, RANGES.index(range_), float(coeff_scale), float(insize_wh), pc, None)
+    if rc:
+        raise DspfftError(lib.dspfft_zoom_last_error().decode())
+    return frame
+
+
+# ---- the `.coeff` file (applybasis.c:383-390 header, :443 body; read back at :319-338) ----
+# coords {unsigned long long w, h} followed by w*h*3 `complex intermediate` values in the loop order of :410-413 (k_h, k_w, n_h, n_w, channel).
+# `intermediate` depends on the build; this reader / writer uses double (INTERMEDIATE_PRECISION=D): 16 bytes per value.
+def write_coeff(path, parts_np):
+    import numpy as np
+    kh, kw, nh, nw, c = parts_np.shape
+    assert c == 3
+    with open(path, "wb") as f:
+        np.array([nw * kw, nh * kh], dtype=np.uint64).tofile(f)          # dumpsize = {N.w K.w, N.h K.h}
+        np.ascontiguousarray(parts_np, dtype=np.complex128).tofile(f)
+
+
+def read_coeff(path):
+    """-> complex128 array [h][w][3] exactly as applybasis reads it back: `pixels[(y * insize.w + x) * 3 + j]`"""
+    import numpy as np
+    with open(path, "rb") as f:
+        w, h = (int(v) for v in np.fromfile(f, dtype=np.uint64, count=2))
+        data = np.fromfile(f, dtype=np.complex128, count=w * h * 3)
+    if data.size != w * h * 3:
+        raise ValueError("short .coeff file")
+    return data.reshape(h, w, 3)
+

@@ -31,7 +31,8 @@ constexpr int BM = 128, BN = 128;
 template <int BK>
 __global__ void __launch_bounds__(256) gemm_nt_f32_mfma(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
                                                         int M, int N, int K, long long lda, long long ldb, long long ldc, int cs,
-                                                        long long sa, long long sb, long long sc, float alpha)
+                                                        long long sa, long long sb, long long sc, float alpha,
+                                                        int nb1 = 0, long long sa2 = 0, long long sb2 = 0, long long sc2 = 0)
 {
 	constexpr int PITCH = BK + 4;
 	__shared__ __attribute__((aligned(16))) float As[2][BM][PITCH];
@@ -40,14 +41,17 @@ __global__ void __launch_bounds__(256) gemm_nt_f32_mfma(const float *__restrict_
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int wm = wave >> 1, wn = wave & 1;                 // 2 x 2 waves, each 64 x 64
 	const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
-	A += (long long)blockIdx.z * sa; B += (long long)blockIdx.z * sb; C += (long long)blockIdx.z * sc;
+	{	// blockIdx.z = b1 + nb1 * b2: two batch levels (e.g. partial-sum block and colour channel), nb1 = 0: one level
+		const int b2 = nb1 ? (int)blockIdx.z / nb1 : 0, b1 = (int)blockIdx.z - b2 * nb1;
+		A += (long long)b1 * sa + (long long)b2 * sa2; B += (long long)b1 * sb + (long long)b2 * sb2; C += (long long)b1 * sc + (long long)b2 * sc2;
+	}
 
 	// staging: thread -> (row = tid / 2, k4 = (tid % 2) * 4 + 8 v): float4 along K
 	const int srow = tid >> 1, sk = (tid & 1) * 4;
 	const bool a_ok = bm + srow < M, b_ok = bn + srow < N;
 	const float *ap = A + (long long)(bm + srow) * lda + sk;
 	const float *bp = B + (long long)(bn + srow) * ldb + sk;
-	const bool vec = ((lda | ldb | sa | sb) & 3) == 0 && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0;
+	const bool vec = ((lda | ldb | sa | sb | sa2 | sb2) & 3) == 0 && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0;
 
 	auto fetch = [&](const float *p, bool ok, int k0) -> float4 {
 		float4 v; v.x = v.y = v.z = v.w = 0.f;
@@ -172,24 +176,6 @@ __global__ void ab_basis_kernel(float *re, float *im, int func, int ortho, long 
 		re[i] = (float)r; if (im) im[i] = (float)m;
 	}
 }
-// out[kh][kw][nh][nw][j] (re, im)  <-  P[c][kh][nh][kw*Nw+nw] products (see dspfft_applybasis_partsums)
-__global__ void ab_combine_kernel(float *out, const float *P, int cplx, int Kh, int Kw, int Nh, int Nw)
-{
-	const size_t per = (size_t)Kh * Nh * Kw * Nw, total = per * 3;
-	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-		const size_t j = i / per, r = i - j * per;               // channel-major temp
-		const size_t kh = r / ((size_t)Nh * Kw * Nw), r2 = r - kh * ((size_t)Nh * Kw * Nw);
-		const size_t nh = r2 / ((size_t)Kw * Nw), r3 = r2 - nh * ((size_t)Kw * Nw);
-		const size_t kw = r3 / Nw, nw = r3 - kw * Nw;
-		const size_t o = ((((kh * Kw + kw) * Nh + nh) * Nw + nw) * 3 + j) * 2;
-		if (cplx) {
-			// P blocks: 0 = Fh_re.T_re, 1 = Fh_im.T_im, 2 = Fh_re.T_im, 3 = Fh_im.T_re   (each 3*per floats)
-			out[o] = P[i] - P[3 * per + i];
-			out[o + 1] = P[2 * 3 * per + i] + P[3 * 3 * per + i];
-		} else { out[o] = P[i]; out[o + 1] = 0.f; }
-	}
-}
-
 thread_local char g_zerr[256] = "";
 
 }  // namespace
@@ -226,6 +212,16 @@ extern "C" int dspfft_gemm_nt_f32(const float *A, const float *B, float *C, int 
 	return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
+// the same product over TWO batch levels in one launch: batch index (b1, b2), offsets b1 * s?1 + b2 * s?2
+static int gemm_nt_f32_batch2(const float *A, const float *B, float *C, int M, int N, int K, long long lda, long long ldb, long long ldc,
+                              int nb1, long long sa1, long long sb1, long long sc1, int nb2, long long sa2, long long sb2, long long sc2, void *stream)
+{
+	dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, nb1 * nb2);
+	if (K >= 16) hipLaunchKernelGGL(gemm_nt_f32_mfma<16>, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, 1, sa1, sb1, sc1, 1.f, nb1, sa2, sb2, sc2);
+	else hipLaunchKernelGGL(gemm_nt_f32_mfma<8>, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, 1, sa1, sb1, sc1, 1.f, nb1, sa2, sb2, sc2);
+	return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
 extern "C" size_t dspfft_zoom_work_floats(int w, int h, size_t ch, int vw)
 {
 	return (size_t)3 * w * h + (size_t)3 * vw * ch;      // planar copy of the coefficients + Tt for 3 channels
@@ -245,55 +241,151 @@ extern "C" int dspfft_zoom_product(const float *d_coeffs, int w, int h, const fl
 	return dspfft_gemm_nt_f32(d_yb, Tt, d_out, vh, vw, (int)ch, (long long)ch, (long long)ch, (long long)vw * 3, 3, 3, 0, (long long)vw * ch, 1, 1.f / ((float)w * (float)h), stream);
 }
 
-// ---- applybasis' forward partial sums (applybasis/applybasis.c:410-431) as batched NT GEMMs ----
+// ---- applybasis' partial sums (applybasis/applybasis.c:410-431) as TWO batched NT GEMM launches ----
+// out[kh][kw][nh][nw][j] = sum_{sh, sw} f_h(kh + offh, nh Ph + sh) f_w(kw + offw, nw Pw + sw) pix_j[nh Ph + sh][nw Pw + sw]
+// Forward (K = terms, N = image / partsum) and --inverse (K = image size, N = terms / partsum, applybasis.c:378-389) are the
+// same sums with different (K, N); pixels may be complex (a .coeff input, applybasis.c:319-338).
+//   step 1  Tt[j][(part, kw)][nw][y]            = sum_sw Fw[(part, kw)][nw Pw + sw] pix_j[y][nw Pw + sw]        batch (nw, j)
+//   step 2  P[j][(hp, kh)][nh][(tp, kw, nw)]    = sum_sh Fh[(hp, kh)][nh Ph + sh] Tt[j][(tp, kw)][nw][nh Ph + sh]  batch (nh, j)
+// with the real and imaginary basis parts stacked as extra rows, so each step is ONE launch whatever the function
+// (round 1: 6 to 24 launches from a host loop, MfmaUtil 0.02 on a 512 x 512 image).
+__global__ void ab_combine2_kernel(float *out, const float *P, int cplx, int Kh, int Kw, int Nh, int Nw, int accumulate_as_imag)
+{
+	const int C = cplx ? 2 : 1;
+	const size_t row = (size_t)C * Kw * Nw;                     // floats per (hp, kh, nh)
+	const size_t perj = (size_t)C * Kh * Nh * row;
+	const size_t total = (size_t)Kh * Kw * Nh * Nw * 3;
+	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+		const size_t j = i % 3, t = i / 3;
+		const size_t nw = t % Nw, nh = (t / Nw) % Nh, kw = (t / ((size_t)Nw * Nh)) % Kw, kh = t / ((size_t)Nw * Nh * Kw);
+		auto at = [&](int hp, int tp) { return P[j * perj + (((size_t)hp * Kh + kh) * Nh + nh) * row + ((size_t)tp * Kw + kw) * Nw + nw]; };
+		float re, im;
+		if (cplx) { re = at(0, 0) - at(1, 1); im = at(0, 1) + at(1, 0); } else { re = at(0, 0); im = 0.f; }
+		float *o = out + i * 2;
+		if (accumulate_as_imag) { o[0] -= im; o[1] += re; }       // + i * (re + i im): the imaginary part of complex pixels
+		else { o[0] = re; o[1] = im; }
+	}
+}
+
+extern "C" size_t dspfft_applybasis_work_floats_ex(int w, int h, int Kw, int Kh, int Nw, int Nh, int func)
+{
+	const size_t C = func <= 1 ? 2 : 1;
+	return (size_t)3 * w * h + C * ((size_t)Kw * w + (size_t)Kh * h) + C * 3 * (size_t)Kw * Nw * h + C * C * 3 * (size_t)Kh * Nh * Kw * Nw;
+}
 extern "C" size_t dspfft_applybasis_work_floats(int w, int h, int Kw, int Kh, int Pw, int Ph, int func)
 {
-	const size_t Nw = (size_t)w / Pw, Nh = (size_t)h / Ph, cplx = func <= 1 ? 2 : 1;
-	return (size_t)3 * w * h                       /* planar pixels */
-	     + cplx * ((size_t)Kw * w + (size_t)Kh * h) /* basis matrices */
-	     + cplx * 3 * (size_t)Kw * Nw * h           /* Tt */
-	     + cplx * cplx * 3 * (size_t)Kh * Nh * Kw * Nw; /* products */
+	return dspfft_applybasis_work_floats_ex(w, h, Kw, Kh, w / Pw, h / Ph, func);
+}
+
+static int applybasis_core(float *d_out, const float *d_pixels, int w, int h, int func, int ortho, int Kw, int Kh, int Nw, int Nh, int Pw, int Ph,
+                           long long offw, long long offh, float *d_work, int as_imag, hipStream_t s)
+{
+	const int cplx = func <= 1, C = cplx ? 2 : 1;
+	const size_t npix = (size_t)w * h;
+	float *planes = d_work;
+	float *Fw = planes + 3 * npix, *Fh = Fw + (size_t)C * Kw * w;               // [(part, k)][n]: imaginary rows stacked under the real ones
+	float *Tt = Fh + (size_t)C * Kh * h;                                         // [j][(part, kw)][nw][y]
+	float *P = Tt + (size_t)3 * C * Kw * Nw * h;                                 // [j][(hp, kh)][nh][(tp, kw, nw)]
+	hipLaunchKernelGGL(deinterleave3_kernel, dim3(1024), dim3(256), 0, s, planes, d_pixels, npix);
+	hipLaunchKernelGGL(ab_basis_kernel, dim3(512), dim3(256), 0, s, Fw, cplx ? Fw + (size_t)Kw * w : nullptr, func, ortho, (long long)Kw, offw, (unsigned long long)w);
+	hipLaunchKernelGGL(ab_basis_kernel, dim3(512), dim3(256), 0, s, Fh, cplx ? Fh + (size_t)Kh * h : nullptr, func, ortho, (long long)Kh, offh, (unsigned long long)h);
+	int rc = gemm_nt_f32_batch2(Fw, planes, Tt, C * Kw, h, Pw, w, w, (long long)Nw * h,
+	                            Nw, Pw, Pw, h, 3, 0, (long long)npix, (long long)C * Kw * Nw * h, s);
+	if (rc) return rc;
+	const long long row = (long long)C * Kw * Nw;
+	rc = gemm_nt_f32_batch2(Fh, Tt, P, C * Kh, (int)row, Ph, h, h, (long long)Nh * row,
+	                        Nh, Ph, Ph, row, 3, 0, (long long)C * Kw * Nw * h, (long long)C * Kh * Nh * row, s);
+	if (rc) return rc;
+	hipLaunchKernelGGL(ab_combine2_kernel, dim3(1024), dim3(256), 0, s, d_out, P, cplx, Kh, Kw, Nh, Nw, as_imag);
+	return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+extern "C" int dspfft_applybasis_partsums_ex(float *d_out, const float *d_pix_re, const float *d_pix_im, int w, int h, int func, int ortho,
+                                             int Kw, int Kh, int Nw, int Nh, int Pw, int Ph, long long offw, long long offh, float *d_work, void *stream)
+{
+	if (!d_out || !d_pix_re || !d_work || func < 0 || func > 11 || Kw < 1 || Kh < 1 || Nw < 1 || Nh < 1 || Pw < 1 || Ph < 1 ||
+	    (long long)Nw * Pw > w || (long long)Nh * Ph > h) {
+		snprintf(g_zerr, sizeof g_zerr, "bad arguments (the partial-sum blocks N x P must fit in the image)"); return -1;
+	}
+	hipStream_t s = (hipStream_t)stream;
+	int rc = applybasis_core(d_out, d_pix_re, w, h, func, ortho, Kw, Kh, Nw, Nh, Pw, Ph, offw, offh, d_work, 0, s);
+	if (!rc && d_pix_im) rc = applybasis_core(d_out, d_pix_im, w, h, func, ortho, Kw, Kh, Nw, Nh, Pw, Ph, offw, offh, d_work, 1, s);
+	return rc;
 }
 
 extern "C" int dspfft_applybasis_partsums(float *d_out, const float *d_pixels, int w, int h, int func, int ortho,
                                           int Kw, int Kh, int Pw, int Ph, long long offw, long long offh,
                                           float *d_work, void *stream)
 {
-	if (!d_out || !d_pixels || !d_work || func < 0 || func > 11 || Kw < 1 || Kh < 1 || Pw < 1 || Ph < 1 || w % Pw || h % Ph) {
-		snprintf(g_zerr, sizeof g_zerr, "bad arguments (the partial-sum block must divide the image)"); return -1;
-	}
-	hipStream_t s = (hipStream_t)stream;
-	const int Nw = w / Pw, Nh = h / Ph, cplx = func <= 1;
-	const size_t npix = (size_t)w * h;
-	float *planes = d_work;
-	float *Fw_re = planes + 3 * npix, *Fw_im = cplx ? Fw_re + (size_t)Kw * w : nullptr;
-	float *Fh_re = Fw_re + (cplx ? 2 : 1) * (size_t)Kw * w, *Fh_im = cplx ? Fh_re + (size_t)Kh * h : nullptr;
-	float *Tt = Fh_re + (cplx ? 2 : 1) * (size_t)Kh * h;                       // [c?][3][Kw][Nw][h]
-	const size_t tsz = (size_t)3 * Kw * Nw * h;
-	float *P = Tt + (cplx ? 2 : 1) * tsz;                                       // [blocks][3][Kh][Nh][Kw*Nw]
-	const size_t per = (size_t)Kh * Nh * Kw * Nw, psz = 3 * per;
-	hipLaunchKernelGGL(deinterleave3_kernel, dim3(1024), dim3(256), 0, s, planes, d_pixels, npix);
-	hipLaunchKernelGGL(ab_basis_kernel, dim3(512), dim3(256), 0, s, Fw_re, Fw_im, func, ortho, (long long)Kw, offw, (unsigned long long)w);
-	hipLaunchKernelGGL(ab_basis_kernel, dim3(512), dim3(256), 0, s, Fh_re, Fh_im, func, ortho, (long long)Kh, offh, (unsigned long long)h);
-	// step 1: Tt[j][kw][nw][y] = sum_{sw} Fw[kw][nw Pw + sw] pix_j[y][nw Pw + sw]      (batch over nw, per channel)
-	for (int part = 0; part < (cplx ? 2 : 1); part++)
-		for (int j = 0; j < 3; j++) {
-			int rc = dspfft_gemm_nt_f32(part ? Fw_im : Fw_re, planes + j * npix, Tt + part * tsz + (size_t)j * Kw * Nw * h,
-			                            Kw, h, Pw, w, w, (long long)Nw * h, 1, Nw, Pw, Pw, h, 1.f, stream);
-			if (rc) return rc;
-		}
-	// step 2: P[j][kh][nh][kw*Nw+nw] = sum_{sh} Fh[kh][nh Ph + sh] Tt[j][kw][nw][nh Ph + sh]   (batch over nh, per channel)
-	for (int hp = 0; hp < (cplx ? 2 : 1); hp++)        // Fh part
-		for (int tp = 0; tp < (cplx ? 2 : 1); tp++) {  // Tt part
-			// block order expected by ab_combine_kernel: 0 re.re, 1 im.im, 2 re.im, 3 im.re
-			const int slot = cplx ? (hp == 0 && tp == 0 ? 0 : hp == 1 && tp == 1 ? 1 : hp == 0 ? 2 : 3) : 0;
-			for (int j = 0; j < 3; j++) {
-				int rc = dspfft_gemm_nt_f32(hp ? Fh_im : Fh_re, Tt + tp * tsz + (size_t)j * Kw * Nw * h, P + slot * psz + (size_t)j * per,
-				                            Kh, Kw * Nw, Ph, h, h, (long long)Nh * Kw * Nw, 1, Nh, Ph, Ph, (long long)Kw * Nw, 1.f, stream);
-				if (rc) return rc;
-			}
+	if (Pw < 1 || Ph < 1 || w % Pw || h % Ph) { snprintf(g_zerr, sizeof g_zerr, "bad arguments (the partial-sum block must divide the image)"); return -1; }
+	return dspfft_applybasis_partsums_ex(d_out, d_pixels, nullptr, w, h, func, ortho, Kw, Kh, w / Pw, h / Ph, Pw, Ph, offw, offh, d_work, stream);
+}
 
+// ---- the rendered frame (applybasis.c:392-442): realize -> rescale (one type, or two interpolated) -> range -> cells of
+// scale x scale pixels at INDEX(d) = ((size.d * bi.d + i.d) * scale + padding * bi.d + padding), alpha = 1 ----
+__device__ inline double ab_rescale(int type, double c, double scale)
+{
+	switch (type) {
+	case 1: return copysign(log1p(fabs(c)) / log1p(scale), c);                                         // logscale
+	case 2: { const double r = sqrt(scale); c /= r; return copysign(log1p(fabs(c)) / log1p(r), c); }  // gain
+	case 3: c /= scale; return copysign(log1p(fabs(c)) / log1p(1.0), c);                               // loglevel
+	default: return c / scale;                                                                         // linear
+	}
+}
+__global__ void ab_render_kernel(float *frame, const float *part, int Kw, int Kh, int Nw, int Nh, int inverse, int scale, int padding,
+                                 int plane, int rescale0, int rescale1, int range, double coeff_scale, double insize_wh, long long fw)
+{
+	const size_t total = (size_t)Kh * Kw * Nh * Nw;
+	for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+		const size_t nw = t % Nw, nh = (t / Nw) % Nh, kw = (t / ((size_t)Nw * Nh)) % Kw, kh = t / ((size_t)Nw * Nh * Kw);
+		double v[3];
+		for (int j = 0; j < 3; j++) {
+			const double re = part[(t * 3 + j) * 2], im = part[(t * 3 + j) * 2 + 1];
+			double r = plane == 1 ? im : plane == 2 ? hypot(re, im) : plane == 3 ? atan2(im + 2.220446049250313e-16, re) / 3.14159265358979323846 : re;
+			double c0 = ab_rescale(rescale0, r, coeff_scale);
+			if (rescale1 >= 0) {
+				const double c1 = ab_rescale(rescale1, r, coeff_scale), NN = sqrt(insize_wh) - 1, nn = sqrt(coeff_scale) - 1;
+				c0 = ((NN - nn) * c0 + nn * c1) / NN;
+			}
+			v[j] = c0;
 		}
-	hipLaunchKernelGGL(ab_combine_kernel, dim3(1024), dim3(256), 0, s, d_out, P, cplx, Kh, Kw, Nh, Nw);
+		if (range == 0) for (int j = 0; j < 3; j++) v[j] = (v[j] + 1) / 2;                 // shift and shift2 (the latter's pre-mapping is the caller's)
+		else if (range == 1) for (int j = 0; j < 3; j++) v[j] = fabs(v[j]);              // abs
+		else if (range == 2) for (int j = 0; j < 3; j++) v[j] += v[j] < 0;               // invert
+		else if (!(v[0] >= 0 && v[1] >= 0 && v[2] >= 0)) {                               // hue
+			const double a = fabs(v[0]), b = fabs(v[1]), c = fabs(v[2]);
+			v[0] = (-a + 2 * b + 2 * c) / 3; v[1] = (2 * a - b + 2 * c) / 3; v[2] = (2 * a + 2 * b - c) / 3;
+		}
+		// forward: bi = k (terms), i = n, size = N;  --inverse: bi = n, i = k, size = K (applybasis.c:378-389)
+		const size_t bw = inverse ? nw : kw, bh = inverse ? nh : kh, iw = inverse ? kw : nw, ih = inverse ? kh : nh;
+		const size_t sw_ = inverse ? (size_t)Kw : (size_t)Nw, sh_ = inverse ? (size_t)Kh : (size_t)Nh;
+		const size_t x0 = (sw_ * bw + iw) * scale + (size_t)padding * bw + padding, y0 = (sh_ * bh + ih) * scale + (size_t)padding * bh + padding;
+		for (int ys = 0; ys < scale; ys++)
+			for (int xs = 0; xs < scale; xs++) {
+				float *o = frame + ((y0 + ys) * (size_t)fw + x0 + xs) * 4;
+				o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = 1.f;
+			}
+	}
+}
+__global__ void ab_fill_kernel(float *frame, size_t npix, float r, float g, float b, float a)
+{
+	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
+		frame[4 * i] = r; frame[4 * i + 1] = g; frame[4 * i + 2] = b; frame[4 * i + 3] = a;
+	}
+}
+
+extern "C" int dspfft_applybasis_render(float *d_frame, const float *d_partsums, int Kw, int Kh, int Nw, int Nh, int inverse, int scale, int padding,
+                                        int plane, int rescale0, int rescale1, int range, double coeff_scale, double insize_wh,
+                                        const float padcolor[4], void *stream)
+{
+	if (!d_frame || !d_partsums || Kw < 1 || Kh < 1 || Nw < 1 || Nh < 1 || scale < 1 || padding < 0 || plane < 0 || plane > 3 ||
+	    rescale0 < 0 || rescale0 > 3 || rescale1 > 3 || range < 0 || range > 3 || !padcolor) { snprintf(g_zerr, sizeof g_zerr, "bad arguments"); return -1; }
+	// framesize = size * terms * scale + padding * terms + padding with (size, terms) = (N, K) forward, (K, N) inverse: the same product
+	const long long tw = inverse ? Nw : Kw, th = inverse ? Nh : Kh;
+	const long long fw = (long long)Kw * Nw * scale + (long long)padding * tw + padding, fh = (long long)Kh * Nh * scale + (long long)padding * th + padding;
+	hipStream_t s = (hipStream_t)stream;
+	hipLaunchKernelGGL(ab_fill_kernel, dim3(1024), dim3(256), 0, s, d_frame, (size_t)fw * fh, padcolor[0], padcolor[1], padcolor[2], padcolor[3]);
+	hipLaunchKernelGGL(ab_render_kernel, dim3(1024), dim3(256), 0, s, d_frame, d_partsums, Kw, Kh, Nw, Nh, inverse, scale, padding, plane, rescale0, rescale1, range,
+	                   coeff_scale, insize_wh, fw);
 	return hipGetLastError() == hipSuccess ? 0 : -4;
 }

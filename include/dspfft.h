@@ -273,6 +273,23 @@ int dspfft_applybasis_partsums(float *d_out, const float *d_pixels, int w, int h
                                int Kw, int Kh, int Pw, int Ph, long long offw, long long offh,
                                float *d_work, void *hip_stream);
 
+/* The general form: N partial-sum blocks of P pixels per axis chosen freely (N x P <= image), real or complex pixels.
+ *   forward  (applybasis.c:378-389 with !inverse):  K = terms,       N = image size / partsum
+ *   --inverse                                    :  K = image size,  N = terms / partsum
+ *   .coeff input (applybasis.c:319-338): complex pixels -- d_pix_im non-NULL (planes h x w x 3, like d_pix_re)
+ * Each call is two batched GEMM launches (three basis / layout kernels around them), whatever the function. */
+size_t dspfft_applybasis_work_floats_ex(int w, int h, int Kw, int Kh, int Nw, int Nh, int func);
+int dspfft_applybasis_partsums_ex(float *d_out, const float *d_pix_re, const float *d_pix_im, int w, int h, int func, int ortho,
+                                  int Kw, int Kh, int Nw, int Nh, int Pw, int Ph, long long offw, long long offh, float *d_work, void *hip_stream);
+/* applybasis.c:392-442: the rendered frame from the partial sums.  d_frame: fh x fw x 4 floats (RGBA) with
+ * fw = Kw Nw scale + padding T_w + padding (T = K forward, N with --inverse), same for fh; filled with padcolor first.
+ * plane: 0 real 1 imaginary 2 magnitude 3 phase (:20-31); rescale0 / rescale1: 0 linear 1 log 2 gain 3 level, rescale1 = -1 for a
+ * single type, else the two are interpolated as :433-438 does; range: 0 shift / shift2, 1 abs, 2 invert, 3 hue (:46-76);
+ * coeff_scale as :399-407; insize_wh = input width x height. */
+int dspfft_applybasis_render(float *d_frame, const float *d_partsums, int Kw, int Kh, int Nw, int Nh, int inverse, int scale, int padding,
+                             int plane, int rescale0, int rescale1, int range, double coeff_scale, double insize_wh,
+                             const float padcolor[4], void *hip_stream);
+
 /* ---- elementwise stages either side of the transform, on the device ---- */
 
 /* spec/spec.c:81-139 on uniform-range coefficients (after the fused normalisation): f *= gain; divisor per channel

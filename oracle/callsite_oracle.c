@@ -175,6 +175,73 @@ void oracle_applybasis_partsums_f64(double *out /* [Kh][Kw][Nh][Nw][3][2] */, co
 				}
 }
 
+/* the general loop of applybasis.c:378-431: K basis functions x N blocks of P pixels per axis (forward: K = terms, N = size / P;
+ * --inverse: K = size, N = terms / P), complex pixels (a .coeff input; pix_im may be NULL) */
+void oracle_applybasis_partsums_ex_f64(double *out /* [Kh][Kw][Nh][Nw][3][2] */, const double *pix_re, const double *pix_im, int w, int h, int func, int ortho,
+                                       int Kw, int Kh, int Nw, int Nh, int Pw, int Ph, long long offw, long long offh)
+{
+	for (int kh = 0; kh < Kh; kh++)
+		for (int kw = 0; kw < Kw; kw++)
+			for (int nh = 0; nh < Nh; nh++)
+				for (int nw = 0; nw < Nw; nw++) {
+					double complex ps[3] = {0, 0, 0};
+					for (int sh = 0; sh < Ph; sh++)
+						for (int sw = 0; sw < Pw; sw++) {
+							double complex comp = ab_basis(func, kw + offw, (long long)nw * Pw + sw, (unsigned long long)w, ortho) *
+							                      ab_basis(func, kh + offh, (long long)nh * Ph + sh, (unsigned long long)h, ortho);
+							const size_t p = ((size_t)(nh * Ph + sh) * w + (size_t)nw * Pw + sw) * 3;
+							for (int j = 0; j < 3; j++) ps[j] += comp * (pix_re[p + j] + (pix_im ? I * pix_im[p + j] : 0));
+						}
+					double *o = out + ((((size_t)kh * Kw + kw) * Nh + nh) * Nw + nw) * 6;
+					for (int j = 0; j < 3; j++) { o[2 * j] = creal(ps[j]); o[2 * j + 1] = cimag(ps[j]); }
+				}
+}
+
+/* applybasis.c:20-76 (realize / rescale / range) and :392-442 (the rendered frame) */
+static double ab_rescale_f64(int type, double c, double scale)
+{
+	switch (type) {
+	case 1: return copysign(log1p(fabs(c)) / log1p(scale), c);
+	case 2: { double r = sqrt(scale); c /= r; return copysign(log1p(fabs(c)) / log1p(r), c); }
+	case 3: c /= scale; return copysign(log1p(fabs(c)) / log1p(1.0), c);
+	default: return c / scale;
+	}
+}
+void oracle_applybasis_render_f64(double *frame /* fh x fw x 4, pre-filled by the caller */, const double *parts, int Kw, int Kh, int Nw, int Nh, int inverse,
+                                  int scale, int padding, int plane, int rescale0, int rescale1, int range, double coeff_scale, double insize_wh)
+{
+	const long long tw = inverse ? Nw : Kw;
+	const long long fw = (long long)Kw * Nw * scale + (long long)padding * tw + padding;
+	for (int kh = 0; kh < Kh; kh++) for (int kw = 0; kw < Kw; kw++) for (int nh = 0; nh < Nh; nh++) for (int nw = 0; nw < Nw; nw++) {
+		const double *p = parts + ((((size_t)kh * Kw + kw) * Nh + nh) * Nw + nw) * 6;
+		double v[3];
+		for (int j = 0; j < 3; j++) {
+			double complex z = p[2 * j] + I * p[2 * j + 1];
+			double r = plane == 1 ? cimag(z) : plane == 2 ? cabs(z) : plane == 3 ? carg(z + I * 2.220446049250313e-16) / M_PI : creal(z);
+			double c0 = ab_rescale_f64(rescale0, r, coeff_scale);
+			if (rescale1 >= 0) {
+				double c1 = ab_rescale_f64(rescale1, r, coeff_scale), NN = sqrt(insize_wh) - 1, nn = sqrt(coeff_scale) - 1;
+				c0 = ((NN - nn) * c0 + nn * c1) / NN;
+			}
+			v[j] = c0;
+		}
+		if (range == 0) for (int j = 0; j < 3; j++) v[j] = (v[j] + 1) / 2;
+		else if (range == 1) for (int j = 0; j < 3; j++) v[j] = fabs(v[j]);
+		else if (range == 2) for (int j = 0; j < 3; j++) v[j] += v[j] < 0;
+		else if (!(v[0] >= 0 && v[1] >= 0 && v[2] >= 0)) {
+			double a = fabs(v[0]), b = fabs(v[1]), c = fabs(v[2]);
+			v[0] = (-a + 2 * b + 2 * c) / 3; v[1] = (2 * a - b + 2 * c) / 3; v[2] = (2 * a + 2 * b - c) / 3;
+		}
+		const size_t bw = inverse ? nw : kw, bh = inverse ? nh : kh, iw = inverse ? kw : nw, ih = inverse ? kh : nh;
+		const size_t sw_ = inverse ? Kw : Nw, sh_ = inverse ? Kh : Nh;
+		const size_t x0 = (sw_ * bw + iw) * scale + (size_t)padding * bw + padding, y0 = (sh_ * bh + ih) * scale + (size_t)padding * bh + padding;
+		for (int ys = 0; ys < scale; ys++) for (int xs = 0; xs < scale; xs++) {
+			double *o = frame + ((y0 + ys) * (size_t)fw + x0 + xs) * 4;
+			o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = 1;
+		}
+	}
+}
+
 /* ---- spectrogram encoding / decoding and motion's coefficient filters, as the reference computes them with
  * COEFF_PRECISION=F, INTERMEDIATE_PRECISION=D (coeff = float, intermediate = double) ------------------------- */
 
