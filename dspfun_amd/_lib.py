@@ -27,7 +27,7 @@ SYMBOLS = [
     "dspfft_zoom_last_error", "dspfft_applybasis_work_floats", "dspfft_applybasis_partsums",
     "dspfft_applybasis_work_floats_ex", "dspfft_applybasis_partsums_ex", "dspfft_applybasis_render",
     "dspfft_motion_load_u8", "dspfft_motion_store_u8", "dspfft_motion_topn_work_bytes", "dspfft_motion_topn", "dspfft_motion_last_error",
-    "dspfft_spec_encode", "dspfft_ispec_decode", "dspfft_motion_filter", "dspfft_scan_pruned_accumulate", "dspfft_pointwise_last_error",
+    "dspfft_spec_encode", "dspfft_ispec_decode", "dspfft_ispec_signmap", "dspfft_motion_filter", "dspfft_scan_pruned_accumulate", "dspfft_pointwise_last_error",
 ]
 
 class IoDim(C.Structure):
@@ -113,6 +113,7 @@ def bind(lib):
         lib.dspfft_ispec_decode.argtypes = [vp, C.c_size_t, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, vp]
         lib.dspfft_motion_filter.argtypes = [vp, ip, ip, ip, ip, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, vp, vp]
         lib.dspfft_pointwise_last_error.restype = C.c_char_p
+        lib.dspfft_ispec_signmap.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]
         lib.dspfft_motion_load_u8.argtypes = [vp, vp, ip, ip, C.c_int, C.c_double, C.c_double, vp]
         lib.dspfft_motion_store_u8.argtypes = [vp, vp, ip, ip, C.c_int, C.c_double, C.c_double, C.c_double, vp]
         lib.dspfft_motion_topn_work_bytes.restype = C.c_size_t

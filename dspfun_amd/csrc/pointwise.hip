@@ -62,6 +62,14 @@ __global__ void ispec_decode_kernel(float *f, size_t len, int d, double gain, do
 	}
 }
 
+// spec/ispec.c:91-99: signs of an `abs` spectrogram from its companion sign-map image (8 bits per sample, what spec's
+// `saturate` sign type writes): f[i] = copysign(f[i], map[i] - 128) for every sample but the first pixel's
+__global__ void ispec_signmap_kernel(float *f, const uint8_t *map, size_t len, int d)
+{
+	for (size_t i = (size_t)d + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x)
+		f[i] = copysignf(f[i], (float)((int)map[i] - 128));
+}
+
 __global__ void motion_filter_kernel(float *c, dspfft::MotionFilter p, unsigned long long *coded)
 {
 	const size_t total = (size_t)p.ad * p.ah * p.aw;
@@ -147,6 +155,15 @@ extern "C" int dspfft_ispec_decode(float *d_f, size_t npixels, int channels, dou
 	const size_t len = npixels * channels;
 	hipLaunchKernelGGL(ispec_decode_kernel, dim3(grid_for(len)), dim3(256), 0, (hipStream_t)stream, d_f, len, channels, gain,
 	                   mx[0], mx[1], mx[2], mx[3], scaletype, signtype, restore_dc, d4[0], d4[1], d4[2], d4[3]);
+	return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+extern "C" int dspfft_ispec_signmap(float *d_f, const uint8_t *d_map, size_t npixels, int channels, void *stream)
+{
+	if (!d_f || !d_map || channels < 1) return bad("bad arguments");
+	const size_t len = npixels * channels;
+	if (len <= (size_t)channels) return 0;
+	hipLaunchKernelGGL(ispec_signmap_kernel, dim3(grid_for(len - channels)), dim3(256), 0, (hipStream_t)stream, d_f, d_map, len, channels);
 	return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

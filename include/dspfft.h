@@ -302,6 +302,10 @@ int dspfft_spec_encode(float *d_f, size_t npixels, int channels, double gain, in
  * from the spectrogram's "DC" property (host memory; needed for rangetype dc/dcs and for restore_dc, ispec.c:161-163). */
 int dspfft_ispec_decode(float *d_f, size_t npixels, int channels, double gain, int rangetype, int scaletype, int signtype,
                         const double *dc, int restore_dc, void *hip_stream);
+/* spec/ispec.c:91-99, run BEFORE dspfft_ispec_decode of an `abs` spectrogram that comes with a sign-map image (-m): every sample but
+ * the first pixel's takes the sign of (map - 128); the first pixel of the map carries the DC terms instead (DC[z] = map[z] / 255,
+ * host arithmetic on channels bytes -- pass them to dspfft_ispec_decode as `dc`). */
+int dspfft_ispec_signmap(float *d_f, const uint8_t *d_map, size_t npixels, int channels, void *hip_stream);
 
 /* motion/motion.c:683-744 on one block of uniform-range coefficients embedded in {., minbuf_h, minbuf_w}: damp outside /
  * boost inside the band-pass box [band_begin, band_end), threshold on |c| (threshold_hi <= 0 disables; bounds already scaled

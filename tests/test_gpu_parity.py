@@ -803,3 +803,21 @@ def test_scan_pruned_idct_path(gpu):
         gpu.cuda.synchronize()
         assert np.abs(total.cpu().numpy() - ref).max() <= 2e-6
         assert float((total - total2).abs().max()) <= 5e-6
+
+
+def test_ispec_signmap_restores_the_signs_of_an_abs_spectrogram(gpu):
+    """spec/ispec.c:91-99: an `abs` spectrogram plus the `saturate` sign image spec writes beside it decode back to the signed
+    coefficients (every sample but the first pixel, whose map bytes carry the DC terms)"""
+    from dspfun_amd import _lib
+    L = _lib.load()
+    h, w, d = 20, 24, 3
+    c = (ol.synth_f32(8, h * w * d).reshape(h, w, d) - 0.5).astype(np.float32)
+    mag = np.abs(c)
+    sat = (~np.signbit(c)).astype(np.uint8) * 255                    # spec.c:134-136 as an 8-bit image
+    f = dev(gpu, mag)
+    m = gpu.from_numpy(sat).to("cuda:0")
+    assert L.dspfft_ispec_signmap(f.data_ptr(), m.data_ptr(), h * w, d, None) == 0
+    gpu.cuda.synchronize()
+    got = f.cpu().numpy()
+    assert np.array_equal(got.reshape(-1, d)[1:], c.reshape(-1, d)[1:])
+    assert np.array_equal(got.reshape(-1, d)[0], mag.reshape(-1, d)[0])
