@@ -27,7 +27,16 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 # gfx950: FETCH_SIZE reports half of the bytes of wide (12-16 B/lane) streaming reads -> x2; WRITE_SIZE exact
 tot = {k: (2 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024 for k, v in raw.items()}
 dom = max(tot, key=tot.get)
-out = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over tools/prof_passes.py, one 3840x2160x3 frame (tools/pmc_traffic.sh)",
+import sys
+sys.path.insert(0, R)
+plan_lines = None
+try:
+    import subprocess
+    plan_lines = subprocess.check_output([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from dspfun_amd import Plan, REDFT10; print(Plan.image(2160, 3840, 3, REDFT10).describe())" % R]).decode().splitlines()
+    plan_lines = [ln.strip() for ln in plan_lines if ln.startswith("axis")]
+except Exception as e:
+    print("could not record the plan description:", e)
+out = {"round": os.environ.get("ROUND", "r02"), "plan": plan_lines, "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over tools/prof_passes.py, one 3840x2160x3 frame (tools/pmc_traffic.sh)",
        "raw_KB_per_dispatch": raw,
        "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide (12-16 B/lane) streaming reads -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact",
        "hbm_bytes_per_launch": {k: int(v) for k, v in tot.items()},
