@@ -27,7 +27,7 @@ SYMBOLS = [
     "dspfft_zoom_last_error", "dspfft_applybasis_work_floats", "dspfft_applybasis_partsums",
     "dspfft_applybasis_work_floats_ex", "dspfft_applybasis_partsums_ex", "dspfft_applybasis_render",
     "dspfft_motion_load_u8", "dspfft_motion_store_u8", "dspfft_motion_topn_work_bytes", "dspfft_motion_topn", "dspfft_motion_last_error",
-    "dspfft_spec_encode", "dspfft_ispec_decode", "dspfft_ispec_signmap", "dspfft_motion_filter", "dspfft_scan_pruned_accumulate", "dspfft_pointwise_last_error",
+    "dspfft_spec_encode", "dspfft_ispec_decode", "dspfft_ispec_signmap", "dspfft_motion_filter", "dspfft_scan_pruned_accumulate", "dspfft_scan_pruned_work_floats", "dspfft_scan_pruned_accumulate_ws", "dspfft_pointwise_last_error",
 ]
 
 class IoDim(C.Structure):
@@ -121,6 +121,9 @@ def bind(lib):
         lib.dspfft_motion_topn.argtypes = [vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, vp]
         lib.dspfft_motion_last_error.restype = C.c_char_p
         lib.dspfft_scan_pruned_accumulate.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+        lib.dspfft_scan_pruned_work_floats.restype = C.c_size_t
+        lib.dspfft_scan_pruned_work_floats.argtypes = [C.c_int, C.c_int, C.c_int]
+        lib.dspfft_scan_pruned_accumulate_ws.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
         lib.dspfft_applybasis_work_floats.restype = C.c_size_t
         lib.dspfft_applybasis_work_floats.argtypes = [C.c_int] * 7
         lib.dspfft_applybasis_work_floats_ex.restype = C.c_size_t

@@ -17,10 +17,9 @@ enum { RANGE_ONE = 0, RANGE_DC = 1, RANGE_DCS = 2 };
 enum { SCALE_LOG = 0, SCALE_LINEAR = 1 };
 enum { SIGN_ABS = 0, SIGN_SHIFT = 1, SIGN_SATURATE = 2, SIGN_RETAIN = 3 };
 
-// spec.c:92-110 (+ :115 log1p): per-channel divisor from the (gain-multiplied) DC terms
-__global__ void spec_max_kernel(double *mx, const float *f, int d, double gain, int rangetype, int scaletype)
+// spec.c:92-110 (+ :115 log1p): per-channel divisor from the (gain-multiplied) DC terms of the FIRST pixel
+__device__ inline void spec_divisors(double *mx, const float *f, int d, double gain, int rangetype, int scaletype)
 {
-	if (threadIdx.x || blockIdx.x) return;
 	float m[8];
 	if (rangetype == RANGE_ONE) for (int z = 0; z < d; z++) m[z] = (float)gain;
 	else if (rangetype == RANGE_DC) {
@@ -30,19 +29,31 @@ __global__ void spec_max_kernel(double *mx, const float *f, int d, double gain, 
 	} else for (int z = 0; z < d; z++) m[z] = (float)(f[z] * gain);
 	for (int z = 0; z < d; z++) mx[z] = scaletype == SCALE_LOG ? (double)log1pf(m[z]) : (double)m[z];   // mc(log1p) on coeff max[] (spec.c:115)
 }
-
-__global__ void spec_encode_kernel(float *f, size_t len, int d, double gain, const double *mx, int scaletype, int signtype)
+__device__ inline float spec_encode_one(float fi, size_t i, int d, double gain, const double *mx, int scaletype, int signtype)
 {
-	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x) {
-		float v = (float)(f[i] * gain);                                                   // spec.c:88-89
-		const float m = (float)mx[i % d];
-		if (scaletype == SCALE_LOG) v = (float)(copysign(log1p((double)fabsf(v)), (double)v) / m);   // :117
-		else v = v / m;                                                                     // :121
-		if (signtype == SIGN_ABS) v = fabsf(v);                                             // :128
-		else if (signtype == SIGN_SHIFT) v = (float)(((double)v / 2. + 0.5) * 254 / 255);   // :132
-		else if (signtype == SIGN_SATURATE) { if (i >= (size_t)d) v = !signbit(v); }        // :135-136
-		f[i] = v;
+	float v = (float)(fi * gain);                                                       // spec.c:88-89
+	const float m = (float)mx[i % d];
+	if (scaletype == SCALE_LOG) v = (float)(copysign(log1p((double)fabsf(v)), (double)v) / m);   // :117
+	else v = v / m;                                                                     // :121
+	if (signtype == SIGN_ABS) v = fabsf(v);                                             // :128
+	else if (signtype == SIGN_SHIFT) v = (float)(((double)v / 2. + 0.5) * 254 / 255);   // :132
+	else if (signtype == SIGN_SATURATE) { if (i >= (size_t)d) v = !signbit(v); }        // :135-136
+	return v;
+}
+// FIRST = 0: every sample but the first pixel's (which this launch only reads, so every thread can derive the divisors from
+// it -- no device scratch, no allocation: the call can sit in a captured graph); FIRST = 1: one block, the first pixel itself
+template <int FIRST>
+__global__ void spec_encode_kernel(float *f, size_t len, int d, double gain, int rangetype, int scaletype, int signtype)
+{
+	double mx[8];
+	spec_divisors(mx, f, d, gain, rangetype, scaletype);
+	if (FIRST) {
+		__syncthreads();                                    // all threads of the single block have read the DC terms
+		if ((int)threadIdx.x < d) f[threadIdx.x] = spec_encode_one(f[threadIdx.x], threadIdx.x, d, gain, mx, scaletype, signtype);
+		return;
 	}
+	for (size_t i = (size_t)d + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < len; i += (size_t)gridDim.x * blockDim.x)
+		f[i] = spec_encode_one(f[i], i, d, gain, mx, scaletype, signtype);
 }
 
 __global__ void ispec_decode_kernel(float *f, size_t len, int d, double gain, double m0, double m1, double m2, double m3,
@@ -127,12 +138,10 @@ extern "C" int dspfft_spec_encode(float *d_f, size_t npixels, int channels, doub
 {
 	if (!d_f || channels < 1 || channels > 8 || rangetype < 0 || rangetype > 2 || scaletype < 0 || scaletype > 1 || signtype < 0 || signtype > 3) return bad("bad arguments");
 	hipStream_t s = (hipStream_t)stream;
-	double *mx = nullptr;
-	if (hipMallocAsync((void **)&mx, sizeof(double) * 8, s) != hipSuccess) return bad("hipMallocAsync failed");
-	hipLaunchKernelGGL(spec_max_kernel, dim3(1), dim3(64), 0, s, mx, d_f, channels, gain, rangetype, scaletype);
 	const size_t len = npixels * channels;
-	hipLaunchKernelGGL(spec_encode_kernel, dim3(grid_for(len)), dim3(256), 0, s, d_f, len, channels, gain, mx, scaletype, signtype);
-	(void)hipFreeAsync(mx, s);
+	if (len > (size_t)channels)
+		hipLaunchKernelGGL(spec_encode_kernel<0>, dim3(grid_for(len - channels)), dim3(256), 0, s, d_f, len, channels, gain, rangetype, scaletype, signtype);
+	hipLaunchKernelGGL(spec_encode_kernel<1>, dim3(1), dim3(64), 0, s, d_f, len, channels, gain, rangetype, scaletype, signtype);
 	return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
@@ -185,6 +194,21 @@ extern "C" int dspfft_motion_filter(float *d_coeffs, const int active[3], const 
 
 /* scan's pruned inverse (scan/scan.c:20-41,449): for frames that add only a few coefficients, the direct sum of
  * rank-1 basis products replaces the two-pass REDFT01 -- one read + one write of `sum`, no intermediate. */
+extern "C" size_t dspfft_scan_pruned_work_floats(int ncoords, int w, int h) { return (size_t)(ncoords > 0 ? ncoords : 0) * ((size_t)w + h); }
+
+/* the same with the basis table in a caller-provided buffer: no allocation, so a scan loop on the pruned path can be captured */
+extern "C" int dspfft_scan_pruned_accumulate_ws(float *d_sum, const float *d_coeffs, const uint32_t *d_lin, int ncoords,
+                                                int w, int h, int channels, float *d_work, void *stream)
+{
+	if (!d_sum || !d_coeffs || (!d_lin && ncoords) || ncoords < 0 || w < 1 || h < 1 || channels < 1 || (!d_work && ncoords)) return bad("bad arguments");
+	if (!ncoords) return 0;
+	hipStream_t s = (hipStream_t)stream;
+	float *by = d_work, *bx = d_work + (size_t)ncoords * h;
+	hipLaunchKernelGGL(pruned_basis_kernel, dim3(grid_for((size_t)ncoords * (w + h))), dim3(256), 0, s, by, bx, d_lin, ncoords, w, h);
+	hipLaunchKernelGGL(pruned_accumulate_kernel, dim3(grid_for((size_t)w * h * channels)), dim3(256), 0, s, d_sum, d_coeffs, d_lin, by, bx, ncoords, w, h, channels);
+	return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
 extern "C" int dspfft_scan_pruned_accumulate(float *d_sum, const float *d_coeffs, const uint32_t *d_lin, int ncoords,
                                              int w, int h, int channels, void *stream)
 {

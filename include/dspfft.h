@@ -321,6 +321,11 @@ int dspfft_motion_filter(float *d_coeffs, const int active[3], const int minbuf_
  * when step * max_interval <= log2(w*h) (scan.c:349-350).  The caller leaves the DC pixel out of the list (scan.c:445). */
 int dspfft_scan_pruned_accumulate(float *d_sum, const float *d_coeffs, const uint32_t *d_lin, int ncoords,
                                   int w, int h, int channels, void *hip_stream);
+/* the same with its basis table in a caller-provided buffer of dspfft_scan_pruned_work_floats(ncoords, w, h) floats: no allocation
+ * inside the call, so a scan loop on the pruned path can be captured into a hipGraph (dspfft_scan_pruned_accumulate allocates per call) */
+size_t dspfft_scan_pruned_work_floats(int ncoords, int w, int h);
+int dspfft_scan_pruned_accumulate_ws(float *d_sum, const float *d_coeffs, const uint32_t *d_lin, int ncoords,
+                                     int w, int h, int channels, float *d_work, void *hip_stream);
 const char *dspfft_pointwise_last_error(void);
 
 #ifdef __cplusplus

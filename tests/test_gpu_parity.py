@@ -803,6 +803,21 @@ def test_scan_pruned_idct_path(gpu):
         gpu.cuda.synchronize()
         assert np.abs(total.cpu().numpy() - ref).max() <= 2e-6
         assert float((total - total2).abs().max()) <= 5e-6
+    # the workspace variant (no allocation inside the call): the same frames inside a captured hipGraph
+    total3 = gpu.zeros_like(coeffs)
+    wsf = gpu.empty(L.dspfft_scan_pruned_work_floats(step, w, h), dtype=gpu.float32, device="cuda:0")
+    g = gpu.cuda.CUDAGraph()
+    s_ = gpu.cuda.Stream()
+    with gpu.cuda.stream(s_):
+        with gpu.cuda.graph(g, stream=s_):
+            for f in range(6):
+                first = f * step + (1 if f == 0 else 0)
+                cnt = (f + 1) * step - first
+                assert L.dspfft_scan_pruned_accumulate_ws(total3.data_ptr(), coeffs.data_ptr(), order.data_ptr() + 4 * first, cnt, w, h, c, wsf.data_ptr(),
+                                                          gpu.cuda.current_stream().cuda_stream) == 0
+    g.replay()
+    gpu.cuda.synchronize()
+    assert float((total3 - total).abs().max()) == 0.0
 
 
 def test_ispec_signmap_restores_the_signs_of_an_abs_spectrogram(gpu):
