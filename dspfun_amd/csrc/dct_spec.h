@@ -709,15 +709,21 @@ struct ColHalfSpec {
 		bout = i0 * a.sb0_out + i1 * a.sb1_out + (long long)t * K;
 	}
 
+	// the fused scan step masks the first pass's loads (load4_m) and adds in the last pass's stores (store4_a), as in ColSpec
 	template <int KIND, class ST>
 	static DSP_HD void prefetch(const PassArgs &a, long long bin, int h, int tid, ST &st)
+	{
+		if (a.mask) prefetch_m<KIND, true>(a, bin, h, tid, st); else prefetch_m<KIND, false>(a, bin, h, tid, st);
+	}
+	template <int KIND, bool MASKED, class ST>
+	static DSP_HD void prefetch_m(const PassArgs &a, long long bin, int h, int tid, ST &st)
 	{
 		if constexpr (KIND == KIND_REDFT10) {
 			static_for<0, Y_ROUNDS>([&](auto i) {
 				const int it = tid + i * T;
 				if ((i + 1) * T <= M * NP || it < M * NP) {
 					const int n = it / NP, jp = it - n * NP;
-					st.pre[i] = *reinterpret_cast<const float4 *>(a.in + bin + (long long)row_of(n, h) * a.es_in + 4 * jp);
+					st.pre[i] = load4_m<MASKED>(a, bin + (long long)row_of(n, h) * a.es_in + 4 * jp);
 				}
 			});
 			// half 1: the twiddles w^n of this thread's rows, fetched behind the data so their latency hides under it (rows n .. n + T/NP
@@ -735,8 +741,8 @@ struct ColHalfSpec {
 					const int k = 2 * q + h, km = k ? N - k : 0;
 					st.tw[i] = a.T[k];
 					const long long p = bin + 4 * jp;
-					st.pre[2 * i] = *reinterpret_cast<const float4 *>(a.in + p + (long long)k * a.es_in);
-					st.pre[2 * i + 1] = *reinterpret_cast<const float4 *>(a.in + p + (long long)km * a.es_in);
+					st.pre[2 * i] = load4_m<MASKED>(a, p + (long long)k * a.es_in);
+					st.pre[2 * i + 1] = load4_m<MASKED>(a, p + (long long)km * a.es_in);
 				}
 			});
 		}
@@ -806,10 +812,10 @@ struct ColHalfSpec {
 					const float sc = a.scale, s0 = (k == 0) ? sc * a.out_scale0 : sc;
 					const long long o = bout + 4 * jp;
 					float4 r0; r0.x = wa0.x * s0; r0.y = wb0.x * s0; r0.z = wa1.x * s0; r0.w = wb1.x * s0;
-					*reinterpret_cast<float4 *>(a.out + o + (long long)k * a.es_out) = r0;
+					store4_a(a, o + (long long)k * a.es_out, r0);
 					if (k > 0 && km != k) {
 						float4 r1; r1.x = -wa0.y * sc; r1.y = -wb0.y * sc; r1.z = -wa1.y * sc; r1.w = -wb1.y * sc;
-						*reinterpret_cast<float4 *>(a.out + o + (long long)km * a.es_out) = r1;
+						store4_a(a, o + (long long)km * a.es_out, r1);
 					}
 				});
 			} else {
@@ -819,7 +825,7 @@ struct ColHalfSpec {
 					if (h) F = mul_h(F, a.H[n]);           // conj(w)^n O[n] = conj(w^n conj(O[n])); the conjugation is the sign below
 					const float sc = a.scale;
 					float4 r; r.x = F.x * sc; r.y = -F.y * sc; r.z = F.z * sc; r.w = -F.w * sc;
-					*reinterpret_cast<float4 *>(a.out + bout + (long long)row_of(n, h) * a.es_out + 4 * jp) = r;
+					store4_a(a, bout + (long long)row_of(n, h) * a.es_out + 4 * jp, r);
 				});
 			}
 		}

@@ -776,11 +776,15 @@ int execute_masked_accumulate_t(dspfft_plan pl, const R *d_in, R *d_work, R *d_a
 	if (d_ids && elems_per_id < 1) return fail(-1, "elems_per_id must be >= 1");
 	if (d_ids && (unsigned long long)pl->alg_bytes / (2 * sizeof(R)) * (unsigned)elems_per_id >= (1ull << 32))
 		return fail(-2, "masked execution addresses elements with 32-bit offsets: plan too large");
-	const size_t np = pl->passes.size();
-	for (const Pass &P : pl->passes)
+	// the split passes (row pairs + half tiles) carry the mask and the accumulation like the plain ones: the row-pair butterfly
+	// runs on the masked inputs, which is what masking the coefficients first means
+	const bool split_ok = !pl->split.empty() && !(15u & ((uintptr_t)d_in | (uintptr_t)d_work | (uintptr_t)d_acc)) && &pick_passes(pl, d_in, d_acc) == &pl->split;
+	const std::vector<Pass> &passes = split_ok ? pl->split : pl->passes;
+	const size_t np = passes.size();
+	for (const Pass &P : passes)
 		if (!P.hostloop.empty()) return fail(-2, "masked/accumulating execution is not available for plans that need a host-side batch loop");
 	for (size_t i = 0; i < np; i++) {
-		const Pass &P = pl->passes[i];
+		const Pass &P = passes[i];
 		const bool firstp = i == 0, lastp = i + 1 == np;
 		Fuse fz;
 		if (firstp && d_ids) { fz.mask = d_ids; fz.id = id; fz.div = elems_per_id; }

@@ -109,8 +109,8 @@ __global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_kerne
 	const int y1 = 2 * n, y2 = a.nb0 - 1 - 2 * n;
 	const long long bin1 = y1 * a.sb0_in + i1 * a.sb1_in, bin2 = y2 * a.sb0_in + i1 * a.sb1_in;
 	const long long bout1 = y1 * a.sb0_out + i1 * a.sb1_out, bout2 = y2 * a.sb0_out + i1 * a.sb1_out;
-	S::template prefetch_m<KIND, false>(a, bin1, tid, st, nullptr);
-	S::template prefetch_m<KIND, false>(a, bin2, tid, st2, nullptr);
+	S::template prefetch<KIND>(a, bin1, tid, st);              // masked loads when this is the first pass of a fused scan step
+	S::template prefetch<KIND>(a, bin2, tid, st2);
 	constexpr int NPRE = (int)(sizeof(st.pre) / sizeof(float));
 	float cur[NPRE], diff[NPRE];
 	static_for<0, NPRE>([&](auto i) { const float p = st.pre[i], q = st2.pre[i]; cur[i] = p + q; diff[i] = p - q; });

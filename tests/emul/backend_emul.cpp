@@ -211,8 +211,8 @@ int launch_row_pair(const PassArgs &a, int npairs, void *)
 		constexpr int NPRE = (int)(sizeof(st[0].pre) / sizeof(float));
 		for (int tid = 0; tid < S::T; tid++) {
 			for (int i = 0; i < NPRE; i++) st[tid].pre[i] = st2[tid].pre[i] = 0.f;
-			S::template prefetch_m<KIND, false>(a, bin1, tid, st[tid], nullptr);
-			S::template prefetch_m<KIND, false>(a, bin2, tid, st2[tid], nullptr);
+			S::template prefetch<KIND>(a, bin1, tid, st[tid]);
+			S::template prefetch<KIND>(a, bin2, tid, st2[tid]);
 			for (int i = 0; i < NPRE; i++) { const float p = st[tid].pre[i], q = st2[tid].pre[i]; st[tid].pre[i] = p + q; st2[tid].pre[i] = p - q; }
 		}
 		typedef typename S::template State<KIND> ST;

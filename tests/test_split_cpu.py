@@ -86,3 +86,32 @@ def test_split_is_not_used_where_it_does_not_apply():
     assert "COL*/2" not in Plan.image(2160, 3840, 3, REDFT10, lib=emul()).describe()
     d = Plan.image(4320, 7680, 3, REDFT01, lib=emul()).describe()
     assert d.splitlines()[1].startswith("axis 0: COL*/2 N=4320 as 2 x 2160, K=8")
+
+
+def test_forced_split_carries_the_fused_scan_step(forced):
+    """scan/scan.c:429-459 through the split passes: mask on the half-tile column pass's loads, accumulation in the row-pair pass's
+    stores -- the same sums as the plain passes and as the f64 restatement"""
+    h, w, c = 512, 512, 3
+    x = ol.synth_f32(0xD5F0004, h * w * c).reshape(h, w, c)
+    fwd = Plan.image(h, w, c, REDFT10, lib=emul()).set_scale(1.0 / (4 * w * h))
+    inv = Plan.image(h, w, c, REDFT01, lib=emul())
+    assert "COL*/2" in inv.describe()
+    os.environ["DSPFFT_NO_SPLIT"] = "1"
+    try:
+        inv_plain = Plan.image(h, w, c, REDFT01, lib=emul())
+    finally:
+        del os.environ["DSPFFT_NO_SPLIT"]
+    coeffs = x.copy()
+    fwd.execute(coeffs.ctypes.data)
+    L = emul()
+    step = (w * h + 3) // 4
+    ids = np.zeros(w * h, dtype=np.uint32)
+    assert L.dspfft_scan_zigzag_frame_ids(ids.ctypes.data, w, h, step, None) == 0
+    acc = np.zeros_like(x); acc2 = np.zeros_like(x); work = np.zeros_like(x)
+    assert L.dspfft_broadcast_dc(acc.ctypes.data, coeffs.ctypes.data, w * h, c, None) == 0
+    acc2[...] = acc
+    for f in range(4):
+        inv.execute_masked_accumulate(coeffs.ctypes.data, work.ctypes.data, acc.ctypes.data, ids.ctypes.data, f, c)
+        inv_plain.execute_masked_accumulate(coeffs.ctypes.data, work.ctypes.data, acc2.ctypes.data, ids.ctypes.data, f, c)
+        assert np.abs(acc - acc2).max() < 2e-6, f
+    assert np.abs(acc - x).max() <= 5e-6
