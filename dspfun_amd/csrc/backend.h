@@ -39,6 +39,9 @@ int be_launch_blue(const BlueArgsD &a, const LaunchGeom &g, void *stream);
 struct SpecInfo { int id, nthr, P; size_t lds; };   // P = C (ROW) or K (COL)
 bool be_find_spec(int is_col, int N, int P, SpecInfo *info);
 int be_launch_spec(int is_col, int id, const PassArgs &a, int nwg, void *stream);
+// the same for double samples (spec_list.h DSPFFT_*_SPECS_F64): plain passes only
+bool be_find_spec_f64(int is_col, int N, int P, SpecInfo *info);
+int be_launch_spec(int is_col, int id, const PassArgsD &a, int nwg, void *stream);
 // planar row pass reading u8 (REDFT10) or writing quantised u8 (REDFT01); only specs with C == 1 have it
 bool be_spec_has_u8(int row_spec_id);
 int be_launch_spec_u8(int row_spec_id, const PassArgs &a, const U8IO &io, int nwg, void *stream);

@@ -30,6 +30,14 @@ namespace dspfft {
 #define DSP_EXTERN_PAIR(N, C, T, ...) \
 	extern template int launch_row_pair<RowSpec<N, C, T, __VA_ARGS__>, 0>(const PassArgs &, int, void *); \
 	extern template int launch_row_pair<RowSpec<N, C, T, __VA_ARGS__>, 1>(const PassArgs &, int, void *);
+#define DSP_EXTERN_ROW_D(N, C, T, ...) \
+	extern template int launch_row_spec<RowSpecT<double, N, C, T, __VA_ARGS__>, 0>(const PassArgsD &, int, void *); \
+	extern template int launch_row_spec<RowSpecT<double, N, C, T, __VA_ARGS__>, 1>(const PassArgsD &, int, void *);
+#define DSP_EXTERN_COL_D(N, K, T, ...) \
+	extern template int launch_col_spec<ColSpecT<double, N, K, T, __VA_ARGS__>, 0>(const PassArgsD &, int, void *); \
+	extern template int launch_col_spec<ColSpecT<double, N, K, T, __VA_ARGS__>, 1>(const PassArgsD &, int, void *);
+DSPFFT_ROW_SPECS_F64(DSP_EXTERN_ROW_D)
+DSPFFT_COL_SPECS_F64(DSP_EXTERN_COL_D)
 DSPFFT_ROW_SPECS(DSP_EXTERN_ROW)
 DSPFFT_COL_SPECS(DSP_EXTERN_COL)
 DSPFFT_COL_HALF_SPECS(DSP_EXTERN_HALF)

@@ -56,14 +56,14 @@ DSP_HD void tloop(int tid, F &&f)
 	if constexpr (REM > 0) { if (tid < REM) f(tid + FULL * T); }
 }
 
-DSP_HD cf csqr(cf a) { return cmk(a.x * a.x - a.y * a.y, 2.f * a.x * a.y); }
+template <class Re> DSP_HD cx<Re> csqr(cx<Re> a) { return cmk<Re>(a.x * a.x - a.y * a.y, (Re)2 * a.x * a.y); }
 
 // x[r] *= w1^r, r = 1..R-1, powers built by a balanced product tree (depth log2 R) from ONE table
 // value, so a butterfly costs one twiddle load instead of R-1.
-template <int R>
-DSP_HD void twiddle_chain(cf *x, cf w1)
+template <int R, class CX>
+DSP_HD void twiddle_chain(CX *x, CX w1)
 {
-	cf w[R > 1 ? R : 2];
+	CX w[R > 1 ? R : 2];
 	w[1] = w1;
 	static_for<2, R>([&](auto r) { if constexpr (r % 2 == 0) w[r] = csqr(w[r / 2]); else w[r] = cmul(w[r / 2], w[r - r / 2]); });
 	static_for<1, R>([&](auto r) { x[r] = cmul(x[r], w[r]); });
@@ -71,40 +71,47 @@ DSP_HD void twiddle_chain(cf *x, cf w1)
 
 // the same with the powers built one after another (w^r = w^(r-1) w1): a longer dependency chain but two twiddle values
 // live instead of R - 1.  Used where registers are scarcer than latency (row_pair_kernel).
-template <int R>
-DSP_HD void twiddle_chain_seq(cf *x, cf w1)
+template <int R, class CX>
+DSP_HD void twiddle_chain_seq(CX *x, CX w1)
 {
-	cf w = w1;
+	CX w = w1;
 	static_for<1, R>([&](auto r) { x[r] = cmul(x[r], w); if constexpr (r + 1 < R) w = cmul(w, w1); });
 }
 
-// ---- pixel (C floats) global access ------------------------------------------------------------
-template <int C> struct Pix { float v[C]; };
+// ---- pixel (C samples) global access ------------------------------------------------------------
+// Re = float (the tuned image path) or double (the fftw_ API: spec / zoom's default build)
+// What one lane of a column pass moves: 16 bytes = NCS complex signals = 2 NCS adjacent real columns (float: two signals = four
+// columns, double: one signal = two columns).  s[i].x is column 2i, s[i].y column 2i + 1: two real columns ride through the complex
+// FFT as one signal.  One global_load_dwordx4 / ds_read_b128 either way.
+template <class Re, int NCS_> struct alignas(16) SigVec { cx<Re> s[NCS_]; };
+template <class Re> struct sig_of { static constexpr int NCS = 16 / (2 * (int)sizeof(Re)); typedef SigVec<Re, NCS> type; };
 
-template <int C> DSP_HD Pix<C> load_pix(const float *p)
+template <int C, class Re = float> struct Pix { Re v[C]; };
+
+template <int C, class Re> DSP_HD Pix<C, Re> load_pix(const Re *p)
 {
-	Pix<C> r;
+	Pix<C, Re> r;
 #if defined(__HIP_DEVICE_COMPILE__)
-	if constexpr (C == 3) { typedef float f3 __attribute__((ext_vector_type(3))); f3 t; __builtin_memcpy(&t, p, 12); r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; return r; }
-	if constexpr (C == 4) { const float4 t = *reinterpret_cast<const float4 *>(p); r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; return r; }
-	if constexpr (C == 2) { const float2 t = *reinterpret_cast<const float2 *>(p); r.v[0] = t.x; r.v[1] = t.y; return r; }
+	if constexpr (C == 3) { typedef Re r3 __attribute__((ext_vector_type(3))); r3 t; __builtin_memcpy(&t, p, 3 * sizeof(Re)); r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; return r; }
+	if constexpr (C == 4) { typedef Re r4 __attribute__((ext_vector_type(4))); const r4 t = *reinterpret_cast<const r4 *>(p); r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; return r; }
+	if constexpr (C == 2) { typedef Re r2 __attribute__((ext_vector_type(2))); const r2 t = *reinterpret_cast<const r2 *>(p); r.v[0] = t.x; r.v[1] = t.y; return r; }
 #endif
 	static_for<0, C>([&](auto c) { r.v[c] = p[c]; });
 	return r;
 }
-template <int C> DSP_HD void store_pix(float *p, const Pix<C> &r)
+template <int C, class Re> DSP_HD void store_pix(Re *p, const Pix<C, Re> &r)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-	if constexpr (C == 3) { typedef float f3 __attribute__((ext_vector_type(3))); f3 t; t.x = r.v[0]; t.y = r.v[1]; t.z = r.v[2]; __builtin_memcpy(p, &t, 12); return; }
-	if constexpr (C == 4) { float4 t; t.x = r.v[0]; t.y = r.v[1]; t.z = r.v[2]; t.w = r.v[3]; *reinterpret_cast<float4 *>(p) = t; return; }
-	if constexpr (C == 2) { float2 t; t.x = r.v[0]; t.y = r.v[1]; *reinterpret_cast<float2 *>(p) = t; return; }
+	if constexpr (C == 3) { typedef Re r3 __attribute__((ext_vector_type(3))); r3 t; t.x = r.v[0]; t.y = r.v[1]; t.z = r.v[2]; __builtin_memcpy(p, &t, 3 * sizeof(Re)); return; }
+	if constexpr (C == 4) { typedef Re r4 __attribute__((ext_vector_type(4))); r4 t; t.x = r.v[0]; t.y = r.v[1]; t.z = r.v[2]; t.w = r.v[3]; *reinterpret_cast<r4 *>(p) = t; return; }
+	if constexpr (C == 2) { typedef Re r2 __attribute__((ext_vector_type(2))); r2 t; t.x = r.v[0]; t.y = r.v[1]; *reinterpret_cast<r2 *>(p) = t; return; }
 #endif
 	static_for<0, C>([&](auto c) { p[c] = r.v[c]; });
 }
 
 // MASKED is decided once per prefetch (a.mask is uniform), not per load: a branch around every load would make each
 // load wait for its own data before the next is issued (measured: 8K row pass 208 -> 257 us)
-template <int C, bool MASKED> DSP_HD Pix<C> load_pix_m(const PassArgs &a, long long off)
+template <int C, bool MASKED, class Re> DSP_HD Pix<C, Re> load_pix_m(const PassArgsT<Re> &a, long long off)
 {
 	if constexpr (MASKED) {
 		// fused scan step: look at the owner ids first and do not fetch coefficients that are masked out
@@ -112,39 +119,41 @@ template <int C, bool MASKED> DSP_HD Pix<C> load_pix_m(const PassArgs &a, long l
 		uint32_t id[C];
 		bool any = false;
 		static_for<0, C>([&](auto c) { id[c] = a.mask[a.mask_div.div((uint32_t)(off + c))]; any = any || id[c] == a.mask_id; });
-		Pix<C> v;
-		if (!any) { static_for<0, C>([&](auto c) { v.v[c] = 0.f; }); return v; }
-		v = load_pix<C>(a.in + off);
-		static_for<0, C>([&](auto c) { if (id[c] != a.mask_id) v.v[c] = 0.f; });
+		Pix<C, Re> v;
+		if (!any) { static_for<0, C>([&](auto c) { v.v[c] = (Re)0; }); return v; }
+		v = load_pix<C, Re>(a.in + off);
+		static_for<0, C>([&](auto c) { if (id[c] != a.mask_id) v.v[c] = (Re)0; });
 		return v;
 	}
-	return load_pix<C>(a.in + off);
+	return load_pix<C, Re>(a.in + off);
 }
-template <int C> DSP_HD void store_pix_a(const PassArgs &a, long long off, Pix<C> r)
+template <int C, class Re> DSP_HD void store_pix_a(const PassArgsT<Re> &a, long long off, Pix<C, Re> r)
 {
-	if (a.accumulate) { const Pix<C> o = load_pix<C>(a.out + off); static_for<0, C>([&](auto c) { r.v[c] += o.v[c]; }); }
-	store_pix<C>(a.out + off, r);
+	if (a.accumulate) { const Pix<C, Re> o = load_pix<C, Re>(a.out + off); static_for<0, C>([&](auto c) { r.v[c] += o.v[c]; }); }
+	store_pix<C, Re>(a.out + off, r);
 }
-template <bool MASKED> DSP_HD float4 load4_m(const PassArgs &a, long long off)
+template <bool MASKED, class Re> DSP_HD typename sig_of<Re>::type loadv_m(const PassArgsT<Re> &a, long long off)
 {
+	typedef typename sig_of<Re>::type V;
+	constexpr int NCS = sig_of<Re>::NCS;
 	if constexpr (MASKED) {
-		const uint32_t i0 = a.mask[a.mask_div.div((uint32_t)off)], i1 = a.mask[a.mask_div.div((uint32_t)off + 1)];
-		const uint32_t i2 = a.mask[a.mask_div.div((uint32_t)off + 2)], i3 = a.mask[a.mask_div.div((uint32_t)off + 3)];
-		float4 v; v.x = v.y = v.z = v.w = 0.f;
-		if (i0 != a.mask_id && i1 != a.mask_id && i2 != a.mask_id && i3 != a.mask_id) return v;
-		v = *reinterpret_cast<const float4 *>(a.in + off);
-		if (i0 != a.mask_id) v.x = 0.f;
-		if (i1 != a.mask_id) v.y = 0.f;
-		if (i2 != a.mask_id) v.z = 0.f;
-		if (i3 != a.mask_id) v.w = 0.f;
+		uint32_t id[2 * NCS];
+		bool any = false;
+		static_for<0, 2 * NCS>([&](auto c) { id[c] = a.mask[a.mask_div.div((uint32_t)off + c)]; any = any || id[c] == a.mask_id; });
+		V v;
+		static_for<0, NCS>([&](auto i) { v.s[i].x = v.s[i].y = (Re)0; });
+		if (!any) return v;
+		v = *reinterpret_cast<const V *>(a.in + off);
+		static_for<0, NCS>([&](auto i) { if (id[2 * i] != a.mask_id) v.s[i].x = (Re)0; if (id[2 * i + 1] != a.mask_id) v.s[i].y = (Re)0; });
 		return v;
 	}
-	return *reinterpret_cast<const float4 *>(a.in + off);
+	return *reinterpret_cast<const V *>(a.in + off);
 }
-DSP_HD void store4_a(const PassArgs &a, long long off, float4 r)
+template <class Re> DSP_HD void storev_a(const PassArgsT<Re> &a, long long off, typename sig_of<Re>::type r)
 {
-	float4 *p = reinterpret_cast<float4 *>(a.out + off);
-	if (a.accumulate) { const float4 o = *p; r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
+	typedef typename sig_of<Re>::type V;
+	V *p = reinterpret_cast<V *>(a.out + off);
+	if (a.accumulate) { const V o = *p; static_for<0, sig_of<Re>::NCS>([&](auto i) { r.s[i].x += o.s[i].x; r.s[i].y += o.s[i].y; }); }
 	*p = r;
 }
 
@@ -154,10 +163,16 @@ DSP_HD void store4_a(const PassArgs &a, long long off, float4 r)
 struct U8IO { const uint8_t *in; uint8_t *out; double mul; };
 
 // =================================================================================================
-template <int N_, int C_, int T_, int... Rs>
-struct RowSpec {
+template <class Re_, int N_, int C_, int T_, int... Rs>
+struct RowSpecT {
+	typedef Re_ Re;                                    // sample type
+	typedef cx<Re_> CX;
+	typedef PassArgsT<Re_> PA;
 	static constexpr int N = N_, C = C_, T = T_, L = N_ / 2, NS = (int)sizeof...(Rs), NPH = NS + 3;
-	static constexpr int WPE = 1;                      // min waves per SIMD asked of the register allocator
+	// min waves per SIMD asked of the register allocator.  double: as many workgroups as the line's LDS allows, capped at 4 (128 VGPRs);
+	// left alone the allocator spends 140+ on the double kernels and a second workgroup no longer fits a CU
+	static constexpr int WPE_D = (int)((160 * 1024) / ((size_t)C_ * (N_ / 2 + 16) * sizeof(CX))) * T_ / 256;
+	static constexpr int WPE = std::is_same<Re, double>::value ? (WPE_D < 1 ? 1 : WPE_D > 4 ? 4 : WPE_D) : 1;
 	static_assert((1 * ... * Rs) == L, "radices must multiply to N/2");
 	static_assert(N % 2 == 0 && NS >= 1, "ROW needs even N");
 	// LDS layout of one channel plane while the DIF stages run: slot p lives at p + (p / SB) * PADC,
@@ -166,29 +181,29 @@ struct RowSpec {
 	static constexpr int R0 = pack_get<0, Rs...>(), RL = pack_get<NS - 1, Rs...>();
 	static constexpr int SB = L / R0, PADC = (NS >= 2) ? DSP_ROW_PADC : 0;
 	static constexpr int PL = L + R0 * PADC;           // plane pitch (complex)
-	static constexpr size_t LDS = (size_t)C * PL * 8;
+	static constexpr size_t LDS = (size_t)C * PL * sizeof(CX);
 	static constexpr int NBL = L / RL;                 // butterflies of the last stage per channel
 	static constexpr int LAST_ROUNDS = (C * NBL + T - 1) / T;
 	static constexpr int PIX_ROUNDS = (N + T - 1) / T;           // REDFT10: pixels per thread
 	static constexpr int K_ROUNDS = (L / 2 + 1 + T - 1) / T;     // REDFT01: (k, L-k) pairs per thread
 	// 8-bit ends (U8IO, planar rows): a thread moves FOUR consecutive pixels as one dword, x = 4 (tid + i T) + q
 	static constexpr int U8_ROUNDS = (N / 4 + T - 1) / T;
-	static constexpr bool U8_OK = (C == 1) && (N % 4 == 0);
+	static constexpr bool U8_OK = (C == 1) && (N % 4 == 0) && std::is_same<Re, float>::value;
 	// per-thread registers that live across barriers: the last stage's butterflies and the
 	// line's global data, loaded before the first LDS phase
 	template <int KIND> struct State {
-		cf x[LAST_ROUNDS * RL];
-		float pre[(KIND == KIND_REDFT10 ? (U8_OK && 4 * U8_ROUNDS > PIX_ROUNDS ? 4 * U8_ROUNDS : PIX_ROUNDS) : 4 * K_ROUNDS) * C];
+		CX x[LAST_ROUNDS * RL];
+		Re pre[(KIND == KIND_REDFT10 ? (U8_OK && 4 * U8_ROUNDS > PIX_ROUNDS ? 4 * U8_ROUNDS : PIX_ROUNDS) : 4 * K_ROUNDS) * C];
 	};
 
 	// issue the global loads of one line into registers (no LDS access, no waiting)
 	template <int KIND, class ST>
-	static DSP_HD void prefetch(const PassArgs &a, long long bin, int tid, ST &st, const U8IO *io = nullptr)
+	static DSP_HD void prefetch(const PA &a, long long bin, int tid, ST &st, const U8IO *io = nullptr)
 	{
 		if (a.mask) prefetch_m<KIND, true>(a, bin, tid, st, io); else prefetch_m<KIND, false>(a, bin, tid, st, io);
 	}
 	template <int KIND, bool MASKED, class ST>
-	static DSP_HD void prefetch_m(const PassArgs &a, long long bin, int tid, ST &st, const U8IO *io)
+	static DSP_HD void prefetch_m(const PA &a, long long bin, int tid, ST &st, const U8IO *io)
 	{
 		if constexpr (KIND == KIND_REDFT10 && U8_OK) {
 			if (io && io->in) {
@@ -197,7 +212,7 @@ struct RowSpec {
 					if ((i + 1) * T <= N / 4 || g < N / 4) {
 						uint32_t w4;
 						__builtin_memcpy(&w4, io->in + bin + 4 * g, 4);
-						static_for<0, 4>([&](auto q) { st.pre[i * 4 + q] = (float)((w4 >> (8 * q)) & 0xffu); });
+						static_for<0, 4>([&](auto q) { st.pre[i * 4 + q] = (Re)((w4 >> (8 * q)) & 0xffu); });
 					}
 				});
 				return;
@@ -207,7 +222,7 @@ struct RowSpec {
 			static_for<0, PIX_ROUNDS>([&](auto i) {
 				const int x = tid + i * T;
 				if ((i + 1) * T <= N || x < N) {
-					const Pix<C> v = load_pix_m<C, MASKED>(a, bin + (long long)x * C);
+					const Pix<C, Re> v = load_pix_m<C, MASKED, Re>(a, bin + (long long)x * C);
 					static_for<0, C>([&](auto c) { st.pre[i * C + c] = v.v[c]; });
 				}
 			});
@@ -215,10 +230,10 @@ struct RowSpec {
 			static_for<0, K_ROUNDS>([&](auto i) {
 				const int k = tid + i * T;
 				if ((i + 1) * T <= L / 2 + 1 || k <= L / 2) {
-					const Pix<C> p0 = load_pix_m<C, MASKED>(a, bin + (long long)k * C);
-					const Pix<C> p1 = load_pix_m<C, MASKED>(a, bin + (long long)(k ? N - k : 0) * C);
-					const Pix<C> p2 = load_pix_m<C, MASKED>(a, bin + (long long)(L - k) * C);
-					const Pix<C> p3 = load_pix_m<C, MASKED>(a, bin + (long long)(L + k) * C);
+					const Pix<C, Re> p0 = load_pix_m<C, MASKED, Re>(a, bin + (long long)k * C);
+					const Pix<C, Re> p1 = load_pix_m<C, MASKED, Re>(a, bin + (long long)(k ? N - k : 0) * C);
+					const Pix<C, Re> p2 = load_pix_m<C, MASKED, Re>(a, bin + (long long)(L - k) * C);
+					const Pix<C, Re> p3 = load_pix_m<C, MASKED, Re>(a, bin + (long long)(L + k) * C);
 					static_for<0, C>([&](auto c) {
 						st.pre[(i * 4 + 0) * C + c] = p0.v[c]; st.pre[(i * 4 + 1) * C + c] = p1.v[c];
 						st.pre[(i * 4 + 2) * C + c] = p2.v[c]; st.pre[(i * 4 + 3) * C + c] = p3.v[c];
@@ -232,27 +247,27 @@ struct RowSpec {
 
 	// stages 0 .. NS-2 (in place, padded layout)
 	template <int I, bool SEQTW = false>
-	static DSP_HD void stage(const PassArgs &a, cf *planes, int tid)
+	static DSP_HD void stage(const PA &a, CX *planes, int tid)
 	{
 		constexpr int R = pack_get<I, Rs...>(), Lc = pack_lc<I, Rs...>(), M1 = Lc / R, NB = L / R, TW = L / Lc;
 		tloop<C * NB, T>(tid, [&](int it) {
 			const int c = it / NB, q = it - c * NB;
 			const int blk = q / M1, m = q - blk * M1;
-			cf *p;
+			CX *p;
 			int stride;
 			if constexpr (I == 0) { p = planes + c * PL + m; stride = SB + PADC; }
 			else { p = planes + c * PL + padded(blk * Lc) + m; stride = M1; }
-			cf x[R];
+			CX x[R];
 			static_for<0, R>([&](auto r) { x[r] = p[r * stride]; });
 			Dft<R>::run(x);
-			if constexpr (M1 > 1) { if constexpr (SEQTW) twiddle_chain_seq<R>(x, a.W[m * TW]); else twiddle_chain<R>(x, a.W[m * TW]); }
+			if constexpr (M1 > 1) { if constexpr (SEQTW) twiddle_chain_seq<R, CX>(x, a.W[m * TW]); else twiddle_chain<R, CX>(x, a.W[m * TW]); }
 			static_for<0, R>([&](auto r) { p[r * stride] = x[r]; });
 		});
 	}
 
 	// last stage, part 1: gather (digit-reversed) + butterfly into registers
 	template <class ST>
-	static DSP_HD void last_read(cf *planes, ST &st, int tid)
+	static DSP_HD void last_read(CX *planes, ST &st, int tid)
 	{
 		static_for<0, LAST_ROUNDS>([&](auto i) {
 			const int it = tid + i * T;
@@ -260,7 +275,7 @@ struct RowSpec {
 				const int c = it / NBL, kb = it - c * NBL;
 				int blk;
 				if constexpr (NS >= 2) blk = PosCalcFirst<NBL, NS - 1, Rs..., 1>::run(kb); else blk = 0;
-				const cf *p = planes + c * PL + (NS >= 2 ? padded(blk * RL) : 0);
+				const CX *p = planes + c * PL + (NS >= 2 ? padded(blk * RL) : 0);
 				static_for<0, RL>([&](auto r) { st.x[i * RL + r] = p[r]; });
 				Dft<RL>::run(&st.x[i * RL]);
 			}
@@ -268,13 +283,13 @@ struct RowSpec {
 	}
 	// last stage, part 2 (after a barrier): natural-order write  k = kb + NBL * r
 	template <class ST>
-	static DSP_HD void last_write(cf *planes, const ST &st, int tid)
+	static DSP_HD void last_write(CX *planes, const ST &st, int tid)
 	{
 		static_for<0, LAST_ROUNDS>([&](auto i) {
 			const int it = tid + i * T;
 			if (it < C * NBL) {
 				const int c = it / NBL, kb = it - c * NBL;
-				cf *p = planes + c * PL + kb;
+				CX *p = planes + c * PL + kb;
 				static_for<0, RL>([&](auto r) { p[r * NBL] = st.x[i * RL + r]; });
 			}
 		});
@@ -282,9 +297,9 @@ struct RowSpec {
 
 	// phase 0 consumes the prefetched registers; phases 1.. work on LDS; the last one stores to `bout`
 	template <int KIND, int PH, class ST, bool SEQTW = false>
-	static DSP_HD void phase(const PassArgs &a, cf *planes, long long bout, int tid, ST &st, const U8IO *io = nullptr)
+	static DSP_HD void phase(const PA &a, CX *planes, long long bout, int tid, ST &st, const U8IO *io = nullptr)
 	{
-		float *pf = reinterpret_cast<float *>(planes);
+		Re *pf = reinterpret_cast<Re *>(planes);
 		if constexpr (PH == 0) {
 			if constexpr (KIND == KIND_REDFT10 && U8_OK) {
 				if (io && io->in) {       // the prefetch took four consecutive pixels per round
@@ -293,7 +308,7 @@ struct RowSpec {
 						if ((i + 1) * T <= N / 4 || g < N / 4)
 							static_for<0, 4>([&](auto q) {
 								const int x = 4 * g + q, n = makhoul_dst(x, N);
-								const float v = st.pre[i * 4 + q];
+								const Re v = st.pre[i * 4 + q];
 								pf[2 * padded(n >> 1) + (n & 1)] = (x == 0) ? v * a.in_scale0 : v;
 							});
 					});
@@ -301,30 +316,30 @@ struct RowSpec {
 				}
 			}
 			if constexpr (KIND == KIND_REDFT10) {
-				// pixel x -> reordered sample n; float index inside the (padded) channel plane
+				// pixel x -> reordered sample n; Re index inside the (padded) channel plane
 				static_for<0, PIX_ROUNDS>([&](auto i) {
 					const int x = tid + i * T;
 					if ((i + 1) * T <= N || x < N) {
 						const int n = makhoul_dst(x, N);
 						const int f = 2 * padded(n >> 1) + (n & 1);
-						static_for<0, C>([&](auto c) { const float v = st.pre[i * C + c]; pf[c * (2 * PL) + f] = (x == 0) ? v * a.in_scale0 : v; });
+						static_for<0, C>([&](auto c) { const Re v = st.pre[i * C + c]; pf[c * (2 * PL) + f] = (x == 0) ? v * a.in_scale0 : v; });
 					}
 				});
 			} else {
 				static_for<0, K_ROUNDS>([&](auto i) {
 					const int k = tid + i * T;
 					if ((i + 1) * T <= L / 2 + 1 || k <= L / 2) {
-						const cf tk = a.T[k];
-						const cf tlk = cmul(cconj(tk), cmk(0.70710678118654752f, -0.70710678118654752f));   // T[L-k]
-						const cf t1 = csqr(csqr(tk));                                                      // T[4k]
+						const CX tk = a.T[k];
+						const CX tlk = cmul(cconj(tk), cmk<Re>((Re)0.70710678118654752440, (Re)-0.70710678118654752440));   // T[L-k]
+						const CX t1 = csqr(csqr(tk));                                                      // T[4k]
 						static_for<0, C>([&](auto c) {
-							const float xk = st.pre[(i * 4 + 0) * C + c], xnk = st.pre[(i * 4 + 1) * C + c];
-							const float xlk = st.pre[(i * 4 + 2) * C + c], xlpk = st.pre[(i * 4 + 3) * C + c];
-							const float x0 = (k == 0) ? xk * a.in_scale0 : xk;
-							const cf Vk = cmulc(cmk(x0, k ? -xnk : 0.f), tk);
-							const cf Vm = cmulc(cmk(xlk, -xlpk), tlk);
-							const cf S = cadd(Vk, cconj(Vm)), D = csub(Vk, cconj(Vm));
-							const cf Q = cmul_pi(cmulc(D, t1));
+							const Re xk = st.pre[(i * 4 + 0) * C + c], xnk = st.pre[(i * 4 + 1) * C + c];
+							const Re xlk = st.pre[(i * 4 + 2) * C + c], xlpk = st.pre[(i * 4 + 3) * C + c];
+							const Re x0 = (k == 0) ? xk * a.in_scale0 : xk;
+							const CX Vk = cmulc(cmk<Re>(x0, k ? -xnk : (Re)0), tk);
+							const CX Vm = cmulc(cmk<Re>(xlk, -xlpk), tlk);
+							const CX S = cadd(Vk, cconj(Vm)), D = csub(Vk, cconj(Vm));
+							const CX Q = cmul_pi(cmulc(D, t1));
 							planes[c * PL + padded(k)] = cconj(cadd(S, Q));
 							if (k > 0) planes[c * PL + padded(L - k)] = csub(S, Q);
 						});
@@ -343,28 +358,28 @@ struct RowSpec {
 					const int k = tid + ri * T;
 					if (!((ri + 1) * T <= L / 2 + 1 || k <= L / 2)) return;
 					const int km = k ? L - k : 0;
-					const cf tk = a.T[k];
-					const cf tlk = cmul(cconj(tk), cmk(0.70710678118654752f, -0.70710678118654752f));
-					const cf t1 = csqr(csqr(tk));
-					Pix<C> o0, o1, o2, o3;
+					const CX tk = a.T[k];
+					const CX tlk = cmul(cconj(tk), cmk<Re>((Re)0.70710678118654752440, (Re)-0.70710678118654752440));
+					const CX t1 = csqr(csqr(tk));
+					Pix<C, Re> o0, o1, o2, o3;
 					static_for<0, C>([&](auto c) {
-						const cf zk = planes[c * PL + k];
-						const cf zm = cconj(planes[c * PL + km]);
-						const cf E = cadd(zk, zm);                  // 2E
-						const cf D = cmul_mi(csub(zk, zm));         // 2D
-						const cf P = cmul(t1, D);
-						const cf wk = cmul(tk, cadd(E, P));         // 2 * T[k] V[k]
-						const cf wm = cmul(tlk, cconj(csub(E, P))); // 2 * T[L-k] V[L-k]
-						const float sc = a.scale;
+						const CX zk = planes[c * PL + k];
+						const CX zm = cconj(planes[c * PL + km]);
+						const CX E = cadd(zk, zm);                  // 2E
+						const CX D = cmul_mi(csub(zk, zm));         // 2D
+						const CX P = cmul(t1, D);
+						const CX wk = cmul(tk, cadd(E, P));         // 2 * T[k] V[k]
+						const CX wm = cmul(tlk, cconj(csub(E, P))); // 2 * T[L-k] V[L-k]
+						const Re sc = a.scale;
 						o0.v[c] = wk.x * (k == 0 ? sc * a.out_scale0 : sc);
 						o1.v[c] = -wk.y * sc;
 						o2.v[c] = wm.x * sc;
 						o3.v[c] = -wm.y * sc;
 					});
-					store_pix_a<C>(a, bout + (long long)k * C, o0);
-					if (k > 0) store_pix_a<C>(a, bout + (long long)(N - k) * C, o1);
-					if (L - k != k) store_pix_a<C>(a, bout + (long long)(L - k) * C, o2);
-					if (k > 0 && L + k != N - k) store_pix_a<C>(a, bout + (long long)(L + k) * C, o3);
+					store_pix_a<C, Re>(a, bout + (long long)k * C, o0);
+					if (k > 0) store_pix_a<C, Re>(a, bout + (long long)(N - k) * C, o1);
+					if (L - k != k) store_pix_a<C, Re>(a, bout + (long long)(L - k) * C, o2);
+					if (k > 0 && L + k != N - k) store_pix_a<C, Re>(a, bout + (long long)(L + k) * C, o3);
 				});
 			} else {
 				if constexpr (U8_OK) {
@@ -373,8 +388,8 @@ struct RowSpec {
 							uint32_t w4 = 0;
 							static_for<0, 4>([&](auto q) {
 								const int x = 4 * g + q, n = makhoul_dst(x, N);
-								const float sc = (x == 0) ? a.scale * a.out_scale0 : a.scale;
-								const float f = pf[n];
+								const Re sc = (x == 0) ? a.scale * a.out_scale0 : a.scale;
+								const Re f = pf[n];
 								w4 |= (uint32_t)quantise_u8((double)(((n & 1) ? -f : f) * sc) * io->mul) << (8 * q);
 							});
 							__builtin_memcpy(io->out + bout + 4 * g, &w4, 4);
@@ -384,18 +399,20 @@ struct RowSpec {
 				}
 				tloop<N, T>(tid, [&](int x) {
 					const int n = makhoul_dst(x, N);
-					Pix<C> o;
-					const float sc = (x == 0) ? a.scale * a.out_scale0 : a.scale;
+					Pix<C, Re> o;
+					const Re sc = (x == 0) ? a.scale * a.out_scale0 : a.scale;
 					static_for<0, C>([&](auto c) {
-						const float f = pf[c * (2 * PL) + n];
+						const Re f = pf[c * (2 * PL) + n];
 						o.v[c] = ((n & 1) ? -f : f) * sc;
 					});
-					store_pix_a<C>(a, bout + (long long)x * C, o);
+					store_pix_a<C, Re>(a, bout + (long long)x * C, o);
 				});
 			}
 		}
 	}
 };
+
+template <int N_, int C_, int T_, int... Rs> using RowSpec = RowSpecT<float, N_, C_, T_, Rs...>;
 
 // =================================================================================================
 DSP_HD int xcd_remap(int bid, int n)
@@ -407,36 +424,65 @@ DSP_HD int xcd_remap(int bid, int n)
 	return (bid & 7) * per + (bid >> 3);
 }
 
-template <int N_, int K_, int T_, int... Rs>
-struct ColSpec {
-	static constexpr int N = N_, K = K_, T = T_, B = K_ / 2, NP = K_ / 4, NS = (int)sizeof...(Rs), NPH = NS + 3;
-	static constexpr int WPE = 1;
+template <class Re_, int N_, int K_, int T_, int... Rs>
+struct ColSpecT {
+	typedef Re_ Re;
+	typedef cx<Re_> CX;
+	typedef PassArgsT<Re_> PA;
+	typedef typename sig_of<Re_>::type V;            // NCS complex signals = VW real columns (16 bytes)
+	static constexpr int NCS = sig_of<Re_>::NCS, VW = 2 * NCS;
+	static constexpr int N = N_, K = K_, T = T_, B = K_ / 2, NP = K_ / VW, NS = (int)sizeof...(Rs), NPH = NS + 3;
+	static constexpr int WPE_D = (int)((160 * 1024) / ((size_t)(N_ + 16) * (K_ / 2) * sizeof(CX))) * T_ / 256;
+	static constexpr int WPE = std::is_same<Re, double>::value ? (WPE_D < 1 ? 1 : WPE_D > 4 ? 4 : WPE_D) : 1;   // see RowSpecT
 	static_assert((1 * ... * Rs) == N, "radices must multiply to N");
-	static_assert(K % 4 == 0 && NS >= 1, "tile width must be a multiple of 4 floats");
+	static_assert(K % VW == 0 && NS >= 1, "tile width must be a multiple of the lane vector (4 floats / 2 doubles)");
 	// rows of the tile are padded by one row per first-stage sub-block while the DIF stages run
 	// (see RowSpec); natural order, unpadded, after the last stage.
 	static constexpr int R0 = pack_get<0, Rs...>(), RL = pack_get<NS - 1, Rs...>();
 	static constexpr int SB = N / R0, PADC = (NS >= 2) ? DSP_COL_PADC : 0;
 	static constexpr int ROWS = N + R0 * PADC;
-	static constexpr size_t LDS = (size_t)ROWS * B * 8;
+	static constexpr size_t LDS = (size_t)ROWS * B * sizeof(CX);
 	static constexpr int NBL = N / RL;
 	static constexpr int LAST_ROUNDS = (NBL * NP + T - 1) / T;
-	static constexpr int Y_ROUNDS = (N * NP + T - 1) / T;              // REDFT10: (row, column-pair) items per thread
-	static constexpr int K_ROUNDS = ((N / 2 + 1) * NP + T - 1) / T;    // REDFT01: (k, column-pair) items per thread
+	static constexpr int Y_ROUNDS = (N * NP + T - 1) / T;              // REDFT10: (row, lane vector) items per thread
+	static constexpr int K_ROUNDS = ((N / 2 + 1) * NP + T - 1) / T;    // REDFT01: (k, lane vector) items per thread
 	template <int KIND> struct State {
-		cf xa[LAST_ROUNDS * RL], xb[LAST_ROUNDS * RL];
-		float4 pre[KIND == KIND_REDFT10 ? Y_ROUNDS : 2 * K_ROUNDS];
-		cf tw[KIND == KIND_REDFT01 ? K_ROUNDS : 1];   // REDFT01: T[k] of this thread's items, fetched with the data (measured: -5 us);
+		CX x[NCS][LAST_ROUNDS * RL];
+		V pre[KIND == KIND_REDFT10 ? Y_ROUNDS : 2 * K_ROUNDS];
+		CX tw[KIND == KIND_REDFT01 ? K_ROUNDS : 1];   // REDFT01: T[k] of this thread's items, fetched with the data (measured: -5 us);
 		                                              // REDFT10 loads T[k] where it is used (prefetching it there measured slower)
 	};
 
+	static DSP_HD V vscale(V v, Re f) { static_for<0, NCS>([&](auto i) { v.s[i].x *= f; v.s[i].y *= f; }); return v; }
+	static DSP_HD V vzero() { V v; static_for<0, NCS>([&](auto i) { v.s[i].x = v.s[i].y = (Re)0; }); return v; }
+
+	// REDFT10's last step for FFT outputs zk = Z[k], zm = Z[N-k] of one lane: coefficient rows k (r0) and N-k (r1), unscaled by out_scale0
+	static DSP_HD void post10(V zk, V zm, CX t, Re s0, Re sc, V &r0, V &r1)
+	{
+		static_for<0, NCS>([&](auto i) {
+			const CX A = cmk<Re>(zk.s[i].x + zm.s[i].x, zk.s[i].y - zm.s[i].y), Bq = cmul_mi(cmk<Re>(zk.s[i].x - zm.s[i].x, zk.s[i].y + zm.s[i].y));
+			const CX wa = cmul(t, A), wb = cmul(t, Bq);
+			r0.s[i].x = wa.x * s0; r0.s[i].y = wb.x * s0;
+			r1.s[i].x = -wa.y * sc; r1.s[i].y = -wb.y * sc;
+		});
+	}
+	// REDFT01's first step for coefficient rows xk (k) and xm (N-k): FFT inputs at slots k (lo) and N-k (hi)
+	static DSP_HD void pre01(V xk, V xm, CX t, V &lo, V &hi)
+	{
+		static_for<0, NCS>([&](auto i) {
+			const CX Va = cmulc(cmk<Re>(xk.s[i].x, -xm.s[i].x), t), Vb = cmulc(cmk<Re>(xk.s[i].y, -xm.s[i].y), t);
+			lo.s[i].x = Va.x - Vb.y; lo.s[i].y = -Va.y - Vb.x;
+			hi.s[i].x = Va.x + Vb.y; hi.s[i].y = Va.y - Vb.x;
+		});
+	}
+
 	template <int KIND, class ST>
-	static DSP_HD void prefetch(const PassArgs &a, long long bin, int tid, ST &st)
+	static DSP_HD void prefetch(const PA &a, long long bin, int tid, ST &st)
 	{
 		if (a.mask) prefetch_m<KIND, true>(a, bin, tid, st); else prefetch_m<KIND, false>(a, bin, tid, st);
 	}
 	template <int KIND, bool MASKED, class ST>
-	static DSP_HD void prefetch_m(const PassArgs &a, long long bin, int tid, ST &st)
+	static DSP_HD void prefetch_m(const PA &a, long long bin, int tid, ST &st)
 	{
 		if constexpr (KIND == KIND_REDFT01)
 			static_for<0, K_ROUNDS>([&](auto i) {
@@ -448,7 +494,7 @@ struct ColSpec {
 				const int it = tid + i * T;
 				if ((i + 1) * T <= N * NP || it < N * NP) {
 					const int y = it / NP, jp = it - y * NP;
-					st.pre[i] = load4_m<MASKED>(a, bin + (long long)y * a.es_in + 4 * jp);
+					st.pre[i] = loadv_m<MASKED, Re>(a, bin + (long long)y * a.es_in + VW * jp);
 				}
 			});
 		} else {
@@ -457,9 +503,9 @@ struct ColSpec {
 				if ((i + 1) * T <= (N / 2 + 1) * NP || it < (N / 2 + 1) * NP) {
 					const int k = it / NP, jp = it - k * NP;
 					const int km = k ? N - k : 0;
-					const long long p = bin + 4 * jp;
-					st.pre[2 * i] = load4_m<MASKED>(a, p + (long long)k * a.es_in);
-					st.pre[2 * i + 1] = load4_m<MASKED>(a, p + (long long)km * a.es_in);
+					const long long p = bin + VW * jp;
+					st.pre[2 * i] = loadv_m<MASKED, Re>(a, p + (long long)k * a.es_in);
+					st.pre[2 * i + 1] = loadv_m<MASKED, Re>(a, p + (long long)km * a.es_in);
 				}
 			});
 		}
@@ -467,7 +513,7 @@ struct ColSpec {
 
 	static DSP_HD int padded(int n) { return n + (n / SB) * PADC; }
 
-	static DSP_HD void base(const PassArgs &a, int work, long long &bin, long long &bout)
+	static DSP_HD void base(const PA &a, int work, long long &bin, long long &bout)
 	{
 		const int bt = work / a.ntiles, t0 = work - bt * a.ntiles;
 		const int t = xcd_remap(t0, a.ntiles);
@@ -477,32 +523,31 @@ struct ColSpec {
 	}
 
 	template <int I>
-	static DSP_HD void stage(const PassArgs &a, float4 *buf, int tid)
+	static DSP_HD void stage(const PA &a, V *buf, int tid)
 	{
 		constexpr int R = pack_get<I, Rs...>(), Lc = pack_lc<I, Rs...>(), M1 = Lc / R, NB = N / R, TW = N / Lc;
 		tloop<NB * NP, T>(tid, [&](int it) {
 			const int q = it / NP, jp = it - q * NP;
 			const int blk = q / M1, m = q - blk * M1;
-			float4 *p;
+			V *p;
 			int stride;
 			if constexpr (I == 0) { p = buf + m * NP + jp; stride = (SB + PADC) * NP; }
 			else { p = buf + (padded(blk * Lc) + m) * NP + jp; stride = M1 * NP; }
-			cf xa[R], xb[R];
-			static_for<0, R>([&](auto r) { const float4 v = p[r * stride]; xa[r] = cmk(v.x, v.y); xb[r] = cmk(v.z, v.w); });
-			Dft<R>::run(xa);
-			Dft<R>::run(xb);
+			CX x[NCS][R];
+			static_for<0, R>([&](auto r) { const V v = p[r * stride]; static_for<0, NCS>([&](auto i) { x[i][r] = v.s[i]; }); });
+			static_for<0, NCS>([&](auto i) { Dft<R>::run(x[i]); });
 			if constexpr (M1 > 1) {
-				cf w[R];
+				CX w[R];
 				w[1] = a.W[m * TW];
 				static_for<2, R>([&](auto r) { if constexpr (r % 2 == 0) w[r] = csqr(w[r / 2]); else w[r] = cmul(w[r / 2], w[r - r / 2]); });
-				static_for<1, R>([&](auto r) { xa[r] = cmul(xa[r], w[r]); xb[r] = cmul(xb[r], w[r]); });
+				static_for<1, R>([&](auto r) { static_for<0, NCS>([&](auto i) { x[i][r] = cmul(x[i][r], w[r]); }); });
 			}
-			static_for<0, R>([&](auto r) { float4 v; v.x = xa[r].x; v.y = xa[r].y; v.z = xb[r].x; v.w = xb[r].y; p[r * stride] = v; });
+			static_for<0, R>([&](auto r) { V v; static_for<0, NCS>([&](auto i) { v.s[i] = x[i][r]; }); p[r * stride] = v; });
 		});
 	}
 
 	template <class ST>
-	static DSP_HD void last_read(const float4 *buf, ST &st, int tid)
+	static DSP_HD void last_read(const V *buf, ST &st, int tid)
 	{
 		static_for<0, LAST_ROUNDS>([&](auto i) {
 			const int it = tid + i * T;
@@ -510,23 +555,22 @@ struct ColSpec {
 				const int kb = it / NP, jp = it - kb * NP;
 				int blk;
 				if constexpr (NS >= 2) blk = PosCalcFirst<NBL, NS - 1, Rs..., 1>::run(kb); else blk = 0;
-				const float4 *p = buf + (NS >= 2 ? padded(blk * RL) : 0) * NP + jp;
-				static_for<0, RL>([&](auto r) { const float4 v = p[r * NP]; st.xa[i * RL + r] = cmk(v.x, v.y); st.xb[i * RL + r] = cmk(v.z, v.w); });
-				Dft<RL>::run(&st.xa[i * RL]);
-				Dft<RL>::run(&st.xb[i * RL]);
+				const V *p = buf + (NS >= 2 ? padded(blk * RL) : 0) * NP + jp;
+				static_for<0, RL>([&](auto r) { const V v = p[r * NP]; static_for<0, NCS>([&](auto c) { st.x[c][i * RL + r] = v.s[c]; }); });
+				static_for<0, NCS>([&](auto c) { Dft<RL>::run(&st.x[c][i * RL]); });
 			}
 		});
 	}
 	template <class ST>
-	static DSP_HD void last_write(float4 *buf, const ST &st, int tid)
+	static DSP_HD void last_write(V *buf, const ST &st, int tid)
 	{
 		static_for<0, LAST_ROUNDS>([&](auto i) {
 			const int it = tid + i * T;
 			if (it < NBL * NP) {
 				const int kb = it / NP, jp = it - kb * NP;
-				float4 *p = buf + kb * NP + jp;
+				V *p = buf + kb * NP + jp;
 				static_for<0, RL>([&](auto r) {
-					float4 v; v.x = st.xa[i * RL + r].x; v.y = st.xa[i * RL + r].y; v.z = st.xb[i * RL + r].x; v.w = st.xb[i * RL + r].y;
+					V v; static_for<0, NCS>([&](auto c) { v.s[c] = st.x[c][i * RL + r]; });
 					p[r * NBL * NP] = v;
 				});
 			}
@@ -539,28 +583,24 @@ struct ColSpec {
 	// the results wait in registers across one barrier because the inverse's padded layout overlaps slots other
 	// threads still have to read.
 	struct StateRT {
-		cf xa[LAST_ROUNDS * RL], xb[LAST_ROUNDS * RL];
-		float4 pre[(Y_ROUNDS > 2 * K_ROUNDS) ? Y_ROUNDS : 2 * K_ROUNDS];
-		cf tw[1];
+		CX x[NCS][LAST_ROUNDS * RL];
+		V pre[(Y_ROUNDS > 2 * K_ROUNDS) ? Y_ROUNDS : 2 * K_ROUNDS];
+		CX tw[1];
 	};
 	template <class ST, class F>
-	static DSP_HD void mid_read(const PassArgs &af, const PassArgs &ai, const float4 *buf, long long bout, int tid, ST &st, const F &filt, unsigned long long &coded)
+	static DSP_HD void mid_read(const PA &af, const PA &ai, const V *buf, long long bout, int tid, ST &st, const F &filt, unsigned long long &coded)
 	{
 		static_for<0, K_ROUNDS>([&](auto ri) {
 			const int it = tid + ri * T;
 			if (!((ri + 1) * T <= (N / 2 + 1) * NP || it < (N / 2 + 1) * NP)) return;
 			const int k = it / NP, jp = it - k * NP;
 			const int km = k ? N - k : 0;
-			const float4 zk = buf[k * NP + jp], zm = buf[km * NP + jp];
-			const cf t = af.T[k];
-			const cf A0 = cmk(zk.x + zm.x, zk.y - zm.y), B0 = cmul_mi(cmk(zk.x - zm.x, zk.y + zm.y));
-			const cf A1 = cmk(zk.z + zm.z, zk.w - zm.w), B1 = cmul_mi(cmk(zk.z - zm.z, zk.w + zm.w));
-			const cf wa0 = cmul(t, A0), wb0 = cmul(t, B0), wa1 = cmul(t, A1), wb1 = cmul(t, B1);
-			const float sc = af.scale, s0 = (k == 0) ? sc * af.out_scale0 : sc;
-			const long long o = bout + 4 * jp;
-			float4 xk, xm;
-			xk.x = wa0.x * s0; xk.y = wb0.x * s0; xk.z = wa1.x * s0; xk.w = wb1.x * s0;          // coefficient row k
-			xm.x = -wa0.y * sc; xm.y = -wb0.y * sc; xm.z = -wa1.y * sc; xm.w = -wb1.y * sc;      // coefficient row N-k
+			const V zk = buf[k * NP + jp], zm = buf[km * NP + jp];
+			const CX t = af.T[k];
+			const Re sc = af.scale, s0 = (k == 0) ? sc * af.out_scale0 : sc;
+			const long long o = bout + VW * jp;
+			V xk, xm;
+			post10(zk, zm, t, s0, sc, xk, xm);                                   // coefficient rows k and N-k
 			DSP_SCHED_FENCE();
 			xk = filt(o + (long long)k * af.es_out, xk, coded);
 			DSP_SCHED_FENCE();
@@ -568,18 +608,15 @@ struct ColSpec {
 			else if (km == k && k > 0) xm = xk;
 			DSP_SCHED_FENCE();                                                   // k = N/2: the same row
 			// REDFT01's first phase on rows k and N-k (ColSpec::phase<KIND_REDFT01, 0>)
-			if (k == 0) { xk.x *= ai.in_scale0; xk.y *= ai.in_scale0; xk.z *= ai.in_scale0; xk.w *= ai.in_scale0; xm.x = xm.y = xm.z = xm.w = 0.f; }
-			const cf Va0 = cmulc(cmk(xk.x, -xm.x), t), Vb0 = cmulc(cmk(xk.y, -xm.y), t);
-			const cf Va1 = cmulc(cmk(xk.z, -xm.z), t), Vb1 = cmulc(cmk(xk.w, -xm.w), t);
-			float4 lo, hi;
-			lo.x = Va0.x - Vb0.y; lo.y = -Va0.y - Vb0.x; lo.z = Va1.x - Vb1.y; lo.w = -Va1.y - Vb1.x;
-			hi.x = Va0.x + Vb0.y; hi.y = Va0.y - Vb0.x; hi.z = Va1.x + Vb1.y; hi.w = Va1.y - Vb1.x;
+			if (k == 0) { xk = vscale(xk, ai.in_scale0); xm = vzero(); }
+			V lo, hi;
+			pre01(xk, xm, t, lo, hi);
 			st.pre[2 * ri] = lo; st.pre[2 * ri + 1] = hi;
 			DSP_SCHED_FENCE();
 		});
 	}
 	template <class ST>
-	static DSP_HD void mid_write(float4 *buf, int tid, const ST &st)
+	static DSP_HD void mid_write(V *buf, int tid, const ST &st)
 	{
 		static_for<0, K_ROUNDS>([&](auto ri) {
 			const int it = tid + ri * T;
@@ -592,7 +629,7 @@ struct ColSpec {
 	}
 
 	template <int KIND, int PH, class ST>
-	static DSP_HD void phase(const PassArgs &a, float4 *buf, long long bout, int tid, ST &st)
+	static DSP_HD void phase(const PA &a, V *buf, long long bout, int tid, ST &st)
 	{
 		if constexpr (PH == 0) {
 			if constexpr (KIND == KIND_REDFT10) {
@@ -600,8 +637,8 @@ struct ColSpec {
 					const int it = tid + i * T;
 					if ((i + 1) * T <= N * NP || it < N * NP) {
 						const int y = it / NP, jp = it - y * NP;
-						float4 v = st.pre[i];
-						if (y == 0) { v.x *= a.in_scale0; v.y *= a.in_scale0; v.z *= a.in_scale0; v.w *= a.in_scale0; }
+						V v = st.pre[i];
+						if (y == 0) v = vscale(v, a.in_scale0);
 						buf[padded(makhoul_dst(y, N)) * NP + jp] = v;
 					}
 				});
@@ -611,14 +648,10 @@ struct ColSpec {
 					if ((i + 1) * T <= (N / 2 + 1) * NP || it < (N / 2 + 1) * NP) {
 						const int k = it / NP, jp = it - k * NP;
 						const int km = k ? N - k : 0;
-						float4 xk = st.pre[2 * i], xm = st.pre[2 * i + 1];
-						if (k == 0) { xk.x *= a.in_scale0; xk.y *= a.in_scale0; xk.z *= a.in_scale0; xk.w *= a.in_scale0; xm.x = xm.y = xm.z = xm.w = 0.f; }
-						const cf t = st.tw[i];
-						const cf Va0 = cmulc(cmk(xk.x, -xm.x), t), Vb0 = cmulc(cmk(xk.y, -xm.y), t);
-						const cf Va1 = cmulc(cmk(xk.z, -xm.z), t), Vb1 = cmulc(cmk(xk.w, -xm.w), t);
-						float4 lo, hi;
-						lo.x = Va0.x - Vb0.y; lo.y = -Va0.y - Vb0.x; lo.z = Va1.x - Vb1.y; lo.w = -Va1.y - Vb1.x;
-						hi.x = Va0.x + Vb0.y; hi.y = Va0.y - Vb0.x; hi.z = Va1.x + Vb1.y; hi.w = Va1.y - Vb1.x;
+						V xk = st.pre[2 * i], xm = st.pre[2 * i + 1];
+						if (k == 0) { xk = vscale(xk, a.in_scale0); xm = vzero(); }
+						V lo, hi;
+						pre01(xk, xm, st.tw[i], lo, hi);
 						buf[padded(k) * NP + jp] = lo;
 						if (k > 0) buf[padded(km) * NP + jp] = hi;
 					}
@@ -637,34 +670,29 @@ struct ColSpec {
 					if (!((ri + 1) * T <= (N / 2 + 1) * NP || it < (N / 2 + 1) * NP)) return;
 					const int k = it / NP, jp = it - k * NP;
 					const int km = k ? N - k : 0;
-					const float4 zk = buf[k * NP + jp], zm = buf[km * NP + jp];
-					const cf t = a.T[k];
-					// column 0: (zk.x, zk.y) & conj(zm.x, zm.y); column 1: (.z, .w)
-					const cf A0 = cmk(zk.x + zm.x, zk.y - zm.y), B0 = cmul_mi(cmk(zk.x - zm.x, zk.y + zm.y));
-					const cf A1 = cmk(zk.z + zm.z, zk.w - zm.w), B1 = cmul_mi(cmk(zk.z - zm.z, zk.w + zm.w));
-					const cf wa0 = cmul(t, A0), wb0 = cmul(t, B0), wa1 = cmul(t, A1), wb1 = cmul(t, B1);
-					const float sc = a.scale, s0 = (k == 0) ? sc * a.out_scale0 : sc;
-					const long long o = bout + 4 * jp;
-					float4 r0; r0.x = wa0.x * s0; r0.y = wb0.x * s0; r0.z = wa1.x * s0; r0.w = wb1.x * s0;
-					store4_a(a, o + (long long)k * a.es_out, r0);
-					if (k > 0 && km != k) {
-						float4 r1; r1.x = -wa0.y * sc; r1.y = -wb0.y * sc; r1.z = -wa1.y * sc; r1.w = -wb1.y * sc;
-						store4_a(a, o + (long long)km * a.es_out, r1);
-					}
+					const V zk = buf[k * NP + jp], zm = buf[km * NP + jp];
+					const Re sc = a.scale, s0 = (k == 0) ? sc * a.out_scale0 : sc;
+					const long long o = bout + VW * jp;
+					V r0, r1;
+					post10(zk, zm, a.T[k], s0, sc, r0, r1);
+					storev_a<Re>(a, o + (long long)k * a.es_out, r0);
+					if (k > 0 && km != k) storev_a<Re>(a, o + (long long)km * a.es_out, r1);
 				});
 			} else {
 				tloop<N * NP, T>(tid, [&](int it) {
 					const int n = it / NP, jp = it - n * NP;
-					const float4 F = buf[n * NP + jp];
+					const V F = buf[n * NP + jp];
 					const int y = makhoul_src(n, N);
-					const float sc = (y == 0) ? a.scale * a.out_scale0 : a.scale;
-					float4 r; r.x = F.x * sc; r.y = -F.y * sc; r.z = F.z * sc; r.w = -F.w * sc;
-					store4_a(a, bout + (long long)y * a.es_out + 4 * jp, r);
+					const Re sc = (y == 0) ? a.scale * a.out_scale0 : a.scale;
+					V r; static_for<0, NCS>([&](auto i) { r.s[i].x = F.s[i].x * sc; r.s[i].y = -F.s[i].y * sc; });
+					storev_a<Re>(a, bout + (long long)y * a.es_out + VW * jp, r);
 				});
 			}
 		}
 	}
 };
+
+template <int N_, int K_, int T_, int... Rs> using ColSpec = ColSpecT<float, N_, K_, T_, Rs...>;
 
 // =================================================================================================
 // Column pass split by an OUTER RADIX 2 across two kernels, so that a long column (2160, 4320 rows) is transformed on
@@ -680,16 +708,21 @@ struct ColSpec {
 // (r1 - r2) into row y2 (row_pair_kernel).  The column pass then works on "half" tiles: half 0 = rows 2n (even rows),
 // half 1 = rows N-1-2n (odd rows, bottom up), each an M-point FFT with the twiddle w^n folded into its load (REDFT10)
 // or store (REDFT01).  Everything stays in place; the intermediate layout is internal to one execute().
-template <int N_, int K_, int T_, int... Rs>
-struct ColHalfSpec {
-	static constexpr int N = N_, M = N_ / 2, K = K_, T = T_, NP = K_ / 4;
-	typedef ColSpec<N_ / 2, K_, T_, Rs...> B;          // stages / last stage of the M-point FFT are the plain column pass's
+template <class Re_, int N_, int K_, int T_, int... Rs>
+struct ColHalfSpecT {
+	typedef Re_ Re;
+	typedef cx<Re_> CX;
+	typedef PassArgsT<Re_> PA;
+	typedef ColSpecT<Re_, N_ / 2, K_, T_, Rs...> B;          // stages / last stage of the M-point FFT are the plain column pass's
+	typedef typename B::V V;
+	static constexpr int NCS = B::NCS, VW = B::VW;
+	static constexpr int N = N_, M = N_ / 2, K = K_, T = T_, NP = B::NP;
 	static constexpr int NS = B::NS, NPH = B::NPH, WPE = 1;
 	static constexpr size_t LDS = B::LDS;
 	static constexpr int Y_ROUNDS = B::Y_ROUNDS, Q_ROUNDS = B::K_ROUNDS, NQ = (M / 2 + 1) * NP;
 	static_assert(N_ % 4 == 0, "half tiles need N divisible by 4");
 	template <int KIND> struct State : B::template State<KIND> {
-		cf hw[KIND == KIND_REDFT10 ? Y_ROUNDS : 1];       // REDFT10, half 1: w^n of this thread's rows
+		CX hw[KIND == KIND_REDFT10 ? Y_ROUNDS : 1];       // REDFT10, half 1: w^n of this thread's rows
 	};
 
 	// image row of tile row n in half h
@@ -697,7 +730,7 @@ struct ColHalfSpec {
 	// FFT slot of the partner F[N-k] of coefficient k = 2q + h
 	static DSP_HD int partner(int q, int h) { return h ? M - 1 - q : (q ? M - q : 0); }
 
-	static DSP_HD void base(const PassArgs &a, int work, long long &bin, long long &bout, int &h)
+	static DSP_HD void base(const PA &a, int work, long long &bin, long long &bout, int &h)
 	{
 		const int per = 2 * a.ntiles;
 		const int bt = work / per, t0 = work - bt * per;
@@ -709,21 +742,21 @@ struct ColHalfSpec {
 		bout = i0 * a.sb0_out + i1 * a.sb1_out + (long long)t * K;
 	}
 
-	// the fused scan step masks the first pass's loads (load4_m) and adds in the last pass's stores (store4_a), as in ColSpec
+	// the fused scan step masks the first pass's loads (loadv_m) and adds in the last pass's stores (storev_a), as in ColSpec
 	template <int KIND, class ST>
-	static DSP_HD void prefetch(const PassArgs &a, long long bin, int h, int tid, ST &st)
+	static DSP_HD void prefetch(const PA &a, long long bin, int h, int tid, ST &st)
 	{
 		if (a.mask) prefetch_m<KIND, true>(a, bin, h, tid, st); else prefetch_m<KIND, false>(a, bin, h, tid, st);
 	}
 	template <int KIND, bool MASKED, class ST>
-	static DSP_HD void prefetch_m(const PassArgs &a, long long bin, int h, int tid, ST &st)
+	static DSP_HD void prefetch_m(const PA &a, long long bin, int h, int tid, ST &st)
 	{
 		if constexpr (KIND == KIND_REDFT10) {
 			static_for<0, Y_ROUNDS>([&](auto i) {
 				const int it = tid + i * T;
 				if ((i + 1) * T <= M * NP || it < M * NP) {
 					const int n = it / NP, jp = it - n * NP;
-					st.pre[i] = load4_m<MASKED>(a, bin + (long long)row_of(n, h) * a.es_in + 4 * jp);
+					st.pre[i] = loadv_m<MASKED, Re>(a, bin + (long long)row_of(n, h) * a.es_in + VW * jp);
 				}
 			});
 			// half 1: the twiddles w^n of this thread's rows, fetched behind the data so their latency hides under it (rows n .. n + T/NP
@@ -740,24 +773,23 @@ struct ColHalfSpec {
 					if (h && q >= M / 2) return;
 					const int k = 2 * q + h, km = k ? N - k : 0;
 					st.tw[i] = a.T[k];
-					const long long p = bin + 4 * jp;
-					st.pre[2 * i] = load4_m<MASKED>(a, p + (long long)k * a.es_in);
-					st.pre[2 * i + 1] = load4_m<MASKED>(a, p + (long long)km * a.es_in);
+					const long long p = bin + VW * jp;
+					st.pre[2 * i] = loadv_m<MASKED, Re>(a, p + (long long)k * a.es_in);
+					st.pre[2 * i + 1] = loadv_m<MASKED, Re>(a, p + (long long)km * a.es_in);
 				}
 			});
 		}
 	}
 
-	static DSP_HD float4 mul_h(float4 v, cf w)
+	static DSP_HD V mul_h(V v, CX w)
 	{
-		float4 r;
-		r.x = v.x * w.x - v.y * w.y; r.y = v.x * w.y + v.y * w.x;
-		r.z = v.z * w.x - v.w * w.y; r.w = v.z * w.y + v.w * w.x;
+		V r;
+		static_for<0, NCS>([&](auto i) { r.s[i].x = v.s[i].x * w.x - v.s[i].y * w.y; r.s[i].y = v.s[i].x * w.y + v.s[i].y * w.x; });
 		return r;
 	}
 
 	template <int KIND, int PH, class ST>
-	static DSP_HD void phase(const PassArgs &a, float4 *buf, long long bout, int h, int tid, ST &st)
+	static DSP_HD void phase(const PA &a, V *buf, long long bout, int h, int tid, ST &st)
 	{
 		if constexpr (PH == 0) {
 			if constexpr (KIND == KIND_REDFT10) {
@@ -765,7 +797,7 @@ struct ColHalfSpec {
 					const int it = tid + i * T;
 					if ((i + 1) * T <= M * NP || it < M * NP) {
 						const int n = it / NP, jp = it - n * NP;
-						float4 v = st.pre[i];
+						V v = st.pre[i];
 						if (h) v = mul_h(v, st.hw[i]);
 						buf[B::padded(n) * NP + jp] = v;
 					}
@@ -777,14 +809,10 @@ struct ColHalfSpec {
 						const int q = it / NP, jp = it - q * NP;
 						if (h && q >= M / 2) return;
 						const int k = 2 * q + h, qm = partner(q, h);
-						float4 xk = st.pre[2 * i], xm = st.pre[2 * i + 1];
-						if (k == 0) { xk.x *= a.in_scale0; xk.y *= a.in_scale0; xk.z *= a.in_scale0; xk.w *= a.in_scale0; xm.x = xm.y = xm.z = xm.w = 0.f; }
-						const cf t = st.tw[i];
-						const cf Va0 = cmulc(cmk(xk.x, -xm.x), t), Vb0 = cmulc(cmk(xk.y, -xm.y), t);
-						const cf Va1 = cmulc(cmk(xk.z, -xm.z), t), Vb1 = cmulc(cmk(xk.w, -xm.w), t);
-						float4 lo, hi;
-						lo.x = Va0.x - Vb0.y; lo.y = -Va0.y - Vb0.x; lo.z = Va1.x - Vb1.y; lo.w = -Va1.y - Vb1.x;
-						hi.x = Va0.x + Vb0.y; hi.y = Va0.y - Vb0.x; hi.z = Va1.x + Vb1.y; hi.w = Va1.y - Vb1.x;
+						V xk = st.pre[2 * i], xm = st.pre[2 * i + 1];
+						if (k == 0) { xk = B::vscale(xk, a.in_scale0); xm = B::vzero(); }
+						V lo, hi;
+						B::pre01(xk, xm, st.tw[i], lo, hi);
 						buf[B::padded(q) * NP + jp] = lo;
 						if (k > 0) buf[B::padded(qm) * NP + jp] = hi;
 					}
@@ -804,32 +832,28 @@ struct ColHalfSpec {
 					const int q = it / NP, jp = it - q * NP;
 					if (h && q >= M / 2) return;
 					const int k = 2 * q + h, km = k ? N - k : 0, qm = partner(q, h);
-					const float4 zk = buf[q * NP + jp], zm = buf[qm * NP + jp];
-					const cf t = a.T[k];
-					const cf A0 = cmk(zk.x + zm.x, zk.y - zm.y), B0 = cmul_mi(cmk(zk.x - zm.x, zk.y + zm.y));
-					const cf A1 = cmk(zk.z + zm.z, zk.w - zm.w), B1 = cmul_mi(cmk(zk.z - zm.z, zk.w + zm.w));
-					const cf wa0 = cmul(t, A0), wb0 = cmul(t, B0), wa1 = cmul(t, A1), wb1 = cmul(t, B1);
-					const float sc = a.scale, s0 = (k == 0) ? sc * a.out_scale0 : sc;
-					const long long o = bout + 4 * jp;
-					float4 r0; r0.x = wa0.x * s0; r0.y = wb0.x * s0; r0.z = wa1.x * s0; r0.w = wb1.x * s0;
-					store4_a(a, o + (long long)k * a.es_out, r0);
-					if (k > 0 && km != k) {
-						float4 r1; r1.x = -wa0.y * sc; r1.y = -wb0.y * sc; r1.z = -wa1.y * sc; r1.w = -wb1.y * sc;
-						store4_a(a, o + (long long)km * a.es_out, r1);
-					}
+					const V zk = buf[q * NP + jp], zm = buf[qm * NP + jp];
+					const Re sc = a.scale, s0 = (k == 0) ? sc * a.out_scale0 : sc;
+					const long long o = bout + VW * jp;
+					V r0, r1;
+					B::post10(zk, zm, a.T[k], s0, sc, r0, r1);
+					storev_a<Re>(a, o + (long long)k * a.es_out, r0);
+					if (k > 0 && km != k) storev_a<Re>(a, o + (long long)km * a.es_out, r1);
 				});
 			} else {
 				tloop<M * NP, T>(tid, [&](int it) {
 					const int n = it / NP, jp = it - n * NP;
-					float4 F = buf[n * NP + jp];
+					V F = buf[n * NP + jp];
 					if (h) F = mul_h(F, a.H[n]);           // conj(w)^n O[n] = conj(w^n conj(O[n])); the conjugation is the sign below
-					const float sc = a.scale;
-					float4 r; r.x = F.x * sc; r.y = -F.y * sc; r.z = F.z * sc; r.w = -F.w * sc;
-					store4_a(a, bout + (long long)row_of(n, h) * a.es_out + 4 * jp, r);
+					const Re sc = a.scale;
+					V r; static_for<0, NCS>([&](auto i) { r.s[i].x = F.s[i].x * sc; r.s[i].y = -F.s[i].y * sc; });
+					storev_a<Re>(a, bout + (long long)row_of(n, h) * a.es_out + VW * jp, r);
 				});
 			}
 		}
 	}
 };
+
+template <int N_, int K_, int T_, int... Rs> using ColHalfSpec = ColHalfSpecT<float, N_, K_, T_, Rs...>;
 
 }  // namespace dspfft

@@ -149,7 +149,7 @@ struct dspfft_plan_s {
 	int n[3], kinds[3];
 	Dim axes[3];
 	std::vector<Dim> batches;  // howmany/dist (one entry) or the guru interface's howmany_dims
-	bool f64;                  // samples are double (dspfft_plan_many_r2r_f64): generic kernels, double tables
+	bool f64;                  // samples are double (dspfft_plan_many_r2r_f64): double tables; specialised kernels for the sizes of DSPFFT_*_SPECS_F64
 	double scale, in0[3], out0[3];
 	std::vector<Pass> passes;
 	std::vector<Pass> split;   // alternative pass list of dspfft_execute / dspfft_execute_pass (build_split); empty when not applicable
@@ -355,9 +355,9 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 				const int al = (C == 2 || C == 4) ? C : 1;
 				bool aligned = true;
 				for (const Dim &d : lines) aligned = aligned && (d.is % al == 0) && (d.os % al == 0);
-				if (!pl->f64 && aligned && be_find_spec(0, N, C, &P.spec)) {
+				if (aligned && (pl->f64 ? be_find_spec_f64(0, N, C, &P.spec) : be_find_spec(0, N, C, &P.spec))) {
 					P.has_spec = true; P.spa = pa; P.spec_nwg = (int)nlines;
-					snprintf(buf, sizeof buf, "axis %d: ROW* N=%d C=%d spec#%d threads=%d lines=%lld lds=%zu", a, N, C, P.spec.id, P.spec.nthr, nlines, P.spec.lds);
+					snprintf(buf, sizeof buf, "axis %d: ROW*%s N=%d C=%d spec#%d threads=%d lines=%lld lds=%zu", a, tag, N, C, P.spec.id, P.spec.nthr, nlines, P.spec.lds);
 					P.desc = buf;
 				}
 				return 0;
@@ -424,11 +424,11 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 				// float4 tile rows: every stride that positions a tile must keep 16-B alignment
 				bool aligned = (ax.is % 4 == 0) && (ax.os % 4 == 0);
 				for (const Dim &d : rest) aligned = aligned && (d.is % 4 == 0) && (d.os % 4 == 0);
-				if (!pl->f64 && aligned && be_find_spec(1, N, inner.n, &P.spec)) {
+				if (aligned && (pl->f64 ? be_find_spec_f64(1, N, inner.n, &P.spec) : be_find_spec(1, N, inner.n, &P.spec))) {
 					P.has_spec = true; P.spa = pa;
 					P.spa.K = P.spec.P; P.spa.B = P.spec.P / 2; P.spa.ntiles = inner.n / P.spec.P;
 					P.spec_nwg = P.spa.ntiles * pa.nb0 * pa.nb1;
-					snprintf(buf, sizeof buf, "axis %d: COL* N=%d K=%d spec#%d threads=%d inner=%d tiles=%d wgs=%d lds=%zu (generic fallback: K=%d)", a, N, P.spec.P, P.spec.id, P.spec.nthr, inner.n, P.spa.ntiles, P.spec_nwg, P.spec.lds, K);
+					snprintf(buf, sizeof buf, "axis %d: COL*%s N=%d K=%d spec#%d threads=%d inner=%d tiles=%d wgs=%d lds=%zu (generic fallback: K=%d)", a, tag, N, P.spec.P, P.spec.id, P.spec.nthr, inner.n, P.spa.ntiles, P.spec_nwg, P.spec.lds, K);
 					P.desc = buf;
 				}
 				return 0;
@@ -515,12 +515,14 @@ int run_pass(const dspfft_plan_s *pl, const Pass &P, const R *in, R *out, bool l
 					if (rc) return fail(-4, "kernel launch failed (%s): backend code %d", P.desc.c_str(), rc);
 					return 0;
 				}
-				const bool ptr_ok = P.type == Pass::ROW
-					? ((P.pa.C == 2 ? 7u : P.pa.C == 4 ? 15u : 3u) & ((uintptr_t)(in + oin) | (uintptr_t)(out + oout))) == 0
-					: (15u & ((uintptr_t)(in + oin) | (uintptr_t)(out + oout))) == 0;
+			}
+			{
+				// the specialised kernels move whole pixels (ROW: C samples) or four samples (COL) per access
+				const uintptr_t al = sizeof(R) * (P.type == Pass::ROW ? (P.pa.C == 2 || P.pa.C == 4 ? P.pa.C : 1) : 4);
+				const bool ptr_ok = ((al - 1) & ((uintptr_t)(in + oin) | (uintptr_t)(out + oout))) == 0;
 				use_spec = P.has_spec && ptr_ok;
 				if (use_spec) {
-					PassArgs a;
+					PassArgsT<R> a;
 					fill_args(a, P.spa, pl, P, in + oin, out + oout, scale, fz);
 					rc = be_launch_spec(P.type == Pass::COL, P.spec.id, a, P.spec_nwg, stream);
 				}

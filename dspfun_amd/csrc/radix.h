@@ -19,6 +19,7 @@
 struct float2 { float x, y; };
 struct alignas(16) float4 { float x, y, z, w; };
 struct alignas(16) double2 { double x, y; };
+struct alignas(32) double4 { double x, y, z, w; };
 #endif
 
 namespace dspfft {

@@ -23,10 +23,10 @@ static int allow_lds(K kernel, size_t bytes)
 // registers was measured slower on MI355X: the extra ~60 VGPRs cost a resident workgroup per CU,
 // and co-resident workgroups already overlap each other's memory and LDS phases.)
 template <class S, int KIND>
-__global__ void __launch_bounds__(S::T, S::WPE) row_spec_kernel(const PassArgs a)
+__global__ void __launch_bounds__(S::T, S::WPE) row_spec_kernel(const typename S::PA a)
 {
-	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-	cf *planes = reinterpret_cast<cf *>(lds);
+	extern __shared__ __attribute__((aligned(32))) unsigned char lds[];
+	typename S::CX *planes = reinterpret_cast<typename S::CX *>(lds);
 	const int tid = threadIdx.x;
 	typename S::template State<KIND> st;
 	long long bin, bout;
@@ -44,10 +44,10 @@ __global__ void __launch_bounds__(S::T, S::WPE) row_spec_kernel(const PassArgs a
 
 // the same with 8-bit input (REDFT10) or quantised 8-bit output (REDFT01): planar rows only
 template <class S, int KIND>
-__global__ void __launch_bounds__(S::T, S::WPE) row_spec_u8_kernel(const PassArgs a, const U8IO io)
+__global__ void __launch_bounds__(S::T, S::WPE) row_spec_u8_kernel(const typename S::PA a, const U8IO io)
 {
-	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-	cf *planes = reinterpret_cast<cf *>(lds);
+	extern __shared__ __attribute__((aligned(32))) unsigned char lds[];
+	typename S::CX *planes = reinterpret_cast<typename S::CX *>(lds);
 	const int tid = threadIdx.x;
 	typename S::template State<KIND> st;
 	long long bin, bout;
@@ -64,10 +64,10 @@ __global__ void __launch_bounds__(S::T, S::WPE) row_spec_u8_kernel(const PassArg
 }
 
 template <class S, int KIND>
-__global__ void __launch_bounds__(S::T, S::WPE) col_spec_kernel(const PassArgs a)
+__global__ void __launch_bounds__(S::T, S::WPE) col_spec_kernel(const typename S::PA a)
 {
-	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-	float4 *buf = reinterpret_cast<float4 *>(lds);
+	extern __shared__ __attribute__((aligned(32))) unsigned char lds[];
+	typename S::V *buf = reinterpret_cast<typename S::V *>(lds);
 	const int tid = threadIdx.x;
 	typename S::template State<KIND> st;
 	long long bin, bout;
@@ -98,10 +98,10 @@ template <class S> constexpr int pair_waves_per_simd()
 	return w < 1 ? 1 : w > DSP_PAIR_WPE_MAX ? DSP_PAIR_WPE_MAX : w;
 }
 template <class S, int KIND>
-__global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_kernel(const PassArgs a)
+__global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_kernel(const typename S::PA a)
 {
-	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-	cf *planes = reinterpret_cast<cf *>(lds);
+	extern __shared__ __attribute__((aligned(32))) unsigned char lds[];
+	typename S::CX *planes = reinterpret_cast<typename S::CX *>(lds);
 	const int tid = threadIdx.x;
 	typename S::template State<KIND> st, st2;
 	const int pairs = a.nb0 >> 1;
@@ -111,9 +111,10 @@ __global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_kerne
 	const long long bout1 = y1 * a.sb0_out + i1 * a.sb1_out, bout2 = y2 * a.sb0_out + i1 * a.sb1_out;
 	S::template prefetch<KIND>(a, bin1, tid, st);              // masked loads when this is the first pass of a fused scan step
 	S::template prefetch<KIND>(a, bin2, tid, st2);
-	constexpr int NPRE = (int)(sizeof(st.pre) / sizeof(float));
-	float cur[NPRE], diff[NPRE];
-	static_for<0, NPRE>([&](auto i) { const float p = st.pre[i], q = st2.pre[i]; cur[i] = p + q; diff[i] = p - q; });
+	typedef typename S::Re Re;
+	constexpr int NPRE = (int)(sizeof(st.pre) / sizeof(Re));
+	Re cur[NPRE], diff[NPRE];
+	static_for<0, NPRE>([&](auto i) { const Re p = st.pre[i], q = st2.pre[i]; cur[i] = p + q; diff[i] = p - q; });
 	// a real loop (not two copies of the phases) whose only loop-carried values are the waiting line's samples: the compiler
 	// otherwise hoists the second transform's index arithmetic and twiddle loads above the first, or carries the last stage's
 	// butterfly registers around the loop, and keeps them live across every barrier (133 / 115 VGPRs: a resident workgroup fewer)
@@ -133,10 +134,10 @@ __global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_kerne
 
 // COL side: one workgroup per half tile (N/2 rows x K floats)
 template <class S, int KIND>
-__global__ void __launch_bounds__(S::T, S::WPE) col_half_kernel(const PassArgs a)
+__global__ void __launch_bounds__(S::T, S::WPE) col_half_kernel(const typename S::PA a)
 {
-	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-	float4 *buf = reinterpret_cast<float4 *>(lds);
+	extern __shared__ __attribute__((aligned(32))) unsigned char lds[];
+	typename S::V *buf = reinterpret_cast<typename S::V *>(lds);
 	const int tid = threadIdx.x;
 	typename S::template State<KIND> st;
 	long long bin, bout;
@@ -153,9 +154,13 @@ __global__ void __launch_bounds__(S::T, S::WPE) col_half_kernel(const PassArgs a
 // written once instead of three times each (forward store + filter read/write + inverse load saved)
 struct FilterOp {
 	MotionFilter p;
-	__device__ float4 operator()(long long e, float4 v, unsigned long long &coded) const
+	__device__ SigVec<float, 2> operator()(long long e, SigVec<float, 2> v, unsigned long long &coded) const
 	{
-		return p.enabled ? motion_filter4(p, (uint32_t)e, v, coded) : v;
+		if (!p.enabled) return v;
+		float4 f; f.x = v.s[0].x; f.y = v.s[0].y; f.z = v.s[1].x; f.w = v.s[1].y;
+		f = motion_filter4(p, (uint32_t)e, f, coded);
+		v.s[0].x = f.x; v.s[0].y = f.y; v.s[1].x = f.z; v.s[1].y = f.w;
+		return v;
 	}
 };
 
@@ -168,11 +173,11 @@ template <class S> constexpr int rt_waves_per_simd()
 }
 
 template <class S>
-__global__ void __launch_bounds__(S::T, rt_waves_per_simd<S>()) col_roundtrip_kernel(const PassArgs af, const PassArgs ai, const FilterOp filt, unsigned long long *coded)
+__global__ void __launch_bounds__(S::T, rt_waves_per_simd<S>()) col_roundtrip_kernel(const typename S::PA af, const typename S::PA ai, const FilterOp filt, unsigned long long *coded)
 {
-	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+	extern __shared__ __attribute__((aligned(32))) unsigned char lds[];
 	__shared__ unsigned int wg_coded;       // non-zero quantised coefficients of this tile (one global atomic per workgroup)
-	float4 *buf = reinterpret_cast<float4 *>(lds);
+	typename S::V *buf = reinterpret_cast<typename S::V *>(lds);
 	const int tid = threadIdx.x;
 	if (tid == 0) wg_coded = 0;
 	typename S::StateRT st;
@@ -202,7 +207,7 @@ __global__ void __launch_bounds__(S::T, rt_waves_per_simd<S>()) col_roundtrip_ke
 	asm volatile("" : "+v"(t));
 	S::mid_write(buf, t, st);
 	__syncthreads();
-	PassArgs a2 = ai;
+	typename S::PA a2 = ai;
 	asm volatile("" : "+s"(a2.W), "+s"(a2.T), "+s"(a2.out));
 	static_for<1, S::NPH>([&](auto ph) {
 		asm volatile("" : "+v"(t));
@@ -213,7 +218,7 @@ __global__ void __launch_bounds__(S::T, rt_waves_per_simd<S>()) col_roundtrip_ke
 
 
 template <class S, int KIND>
-int launch_row_spec(const PassArgs &a, int nwork, void *stream)
+int launch_row_spec(const typename S::PA &a, int nwork, void *stream)
 {
 	static int lds_ok = allow_lds(row_spec_kernel<S, KIND>, S::LDS);
 	if (lds_ok) return lds_ok;
@@ -222,7 +227,7 @@ int launch_row_spec(const PassArgs &a, int nwork, void *stream)
 	return 0;
 }
 template <class S, int KIND>
-int launch_col_spec(const PassArgs &a, int nwork, void *stream)
+int launch_col_spec(const typename S::PA &a, int nwork, void *stream)
 {
 	static int lds_ok = allow_lds(col_spec_kernel<S, KIND>, S::LDS);
 	if (lds_ok) return lds_ok;
@@ -231,7 +236,7 @@ int launch_col_spec(const PassArgs &a, int nwork, void *stream)
 	return 0;
 }
 template <class S, int KIND>
-int launch_row_pair(const PassArgs &a, int npairs, void *stream)
+int launch_row_pair(const typename S::PA &a, int npairs, void *stream)
 {
 	static int lds_ok = allow_lds(row_pair_kernel<S, KIND>, S::LDS);
 	if (lds_ok) return lds_ok;
@@ -240,7 +245,7 @@ int launch_row_pair(const PassArgs &a, int npairs, void *stream)
 	return 0;
 }
 template <class S, int KIND>
-int launch_col_half(const PassArgs &a, int nwork, void *stream)
+int launch_col_half(const typename S::PA &a, int nwork, void *stream)
 {
 	static int lds_ok = allow_lds(col_half_kernel<S, KIND>, S::LDS);
 	if (lds_ok) return lds_ok;
@@ -249,7 +254,7 @@ int launch_col_half(const PassArgs &a, int nwork, void *stream)
 	return 0;
 }
 template <class S, int KIND>
-int launch_row_spec_u8(const PassArgs &a, const U8IO &io, int nwork, void *stream)
+int launch_row_spec_u8(const typename S::PA &a, const U8IO &io, int nwork, void *stream)
 {
 	static int lds_ok = allow_lds(row_spec_u8_kernel<S, KIND>, S::LDS);
 	if (lds_ok) return lds_ok;
@@ -258,7 +263,7 @@ int launch_row_spec_u8(const PassArgs &a, const U8IO &io, int nwork, void *strea
 	return 0;
 }
 template <class S>
-int launch_col_roundtrip(const PassArgs &af, const PassArgs &ai, const MotionFilter &filt, unsigned long long *coded, int nwork, void *stream)
+int launch_col_roundtrip(const typename S::PA &af, const typename S::PA &ai, const MotionFilter &filt, unsigned long long *coded, int nwork, void *stream)
 {
 	static int lds_ok = allow_lds(col_roundtrip_kernel<S>, S::LDS);
 	if (lds_ok) return lds_ok;

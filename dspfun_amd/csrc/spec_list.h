@@ -64,3 +64,31 @@
 	X(7680, 3, 1024, 16, 15, 16) \
 	X(1920, 3, 256, 4, 15, 16) \
 	X(512, 3, 64, 16, 16)
+
+// ---- double precision (the fftw_ API: spec and zoom's default COEFF_PRECISION=D build) ----
+// Same structures over double samples: X(N, C | K, THREADS, radices ...).  A slot is 16 bytes, so a 3840 x 3 line needs 92 KB of
+// LDS (one workgroup per CU) and column tiles are K = 4 doubles wide = the same 32-B row segments / 69 KB as the float K = 8 tile.
+#define DSPFFT_ROW_SPECS_F64(X)      \
+	X(3840, 3, 1024, 12, 10, 16)     \
+	X(1920, 3, 512, 4, 15, 16)       \
+	X(960, 3, 256, 2, 16, 15)        \
+	X(3840, 1, 256, 12, 10, 16)      \
+	X(1920, 1, 128, 4, 16, 15)       \
+	X(512, 3, 128, 16, 16)           \
+	X(4096, 3, 1024, 8, 16, 16)      \
+	X(2560, 3, 512, 8, 10, 16)       \
+	X(2048, 3, 512, 4, 16, 16)       \
+	X(1280, 3, 256, 4, 10, 16)       \
+	X(1024, 3, 256, 4, 8, 16)        \
+	X(1280, 1, 128, 4, 10, 16)
+
+#define DSPFFT_COL_SPECS_F64(X)      \
+	X(2160, 4, 512, 12, 12, 15)      \
+	X(1080, 8, 512, 8, 9, 15)        \
+	X(540, 8, 256, 4, 9, 15)         \
+	X(512, 8, 256, 4, 8, 16)         \
+	X(4096, 4, 1024, 16, 16, 16)     \
+	X(2048, 4, 512, 8, 16, 16)       \
+	X(1440, 4, 512, 8, 12, 15)       \
+	X(1024, 8, 512, 4, 16, 16)       \
+	X(720, 8, 256, 6, 8, 15)

@@ -63,8 +63,8 @@ int fftwf_export_wisdom_to_filename(const char *filename);     /* motion.c:557 *
 /* ---------------- double precision: COEFF_PRECISION=D (spec/Makefile, zoom/Makefile default) ----------------
  * Same engine with double buffers, double arithmetic and double tables on the device
  * (dspfft_plan_many_r2r_f64 / dspfft_execute_f64): results agree with a double FFTW to ~1e-14 of max|coeff|.
- * These plans run the runtime-geometry kernels; the tuned kernels are single precision, so build the tools
- * with COEFF_PRECISION=F when f32 accuracy is enough. */
+ * The common frame sizes (spec_list.h DSPFFT_*_SPECS_F64: 4K, 1080p, 720p, powers of two) run compile-time-specialised double
+ * kernels (3840x2160 RGB roundtrip 383 us = 26 % of the 96 B/pixel roofline); other sizes run the runtime-geometry kernels. */
 typedef struct fftw_plan_s *fftw_plan;
 double *fftw_alloc_real(size_t n);
 void fftw_free(void *p);

@@ -155,10 +155,10 @@ int be_launch_dense(const DenseArgsD &a, const LaunchGeom &g, void *) { return e
 // one "workgroup" per line / tile, as in backend_hip.hip: prefetch (global loads into the per-thread State),
 // then the barrier-separated phases
 template <class S, int KIND>
-int launch_row_spec(const PassArgs &a, int nwork, void *)
+int launch_row_spec(const typename S::PA &a, int nwork, void *)
 {
-	std::vector<unsigned char> lds(S::LDS + 16);
-	cf *planes = (cf *)lds.data();
+	std::vector<unsigned char> lds(S::LDS + 32);
+	typename S::CX *planes = (typename S::CX *)(((uintptr_t)lds.data() + 31) & ~(uintptr_t)31);
 	for (int wg = 0; wg < nwork; wg++) {
 		std::vector<typename S::template State<KIND>> st(S::T);
 		long long bin, bout;
@@ -169,10 +169,10 @@ int launch_row_spec(const PassArgs &a, int nwork, void *)
 	return 0;
 }
 template <class S, int KIND>
-int launch_col_spec(const PassArgs &a, int nwork, void *)
+int launch_col_spec(const typename S::PA &a, int nwork, void *)
 {
-	std::vector<unsigned char> lds(S::LDS + 32);
-	float4 *buf = (float4 *)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
+	std::vector<unsigned char> lds(S::LDS + 64);
+	typename S::V *buf = (typename S::V *)(((uintptr_t)lds.data() + 31) & ~(uintptr_t)31);
 	for (int wg = 0; wg < nwork; wg++) {
 		std::vector<typename S::template State<KIND>> st(S::T);
 		long long bin, bout;
@@ -226,7 +226,7 @@ template <class S, int KIND>
 int launch_col_half(const PassArgs &a, int nwork, void *)
 {
 	std::vector<unsigned char> lds(S::LDS + 32);
-	float4 *buf = (float4 *)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
+	typename S::V *buf = (typename S::V *)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
 	for (int wg = 0; wg < nwork; wg++) {
 		std::vector<typename S::template State<KIND>> st(S::T);
 		long long bin, bout; int h;
@@ -238,13 +238,20 @@ int launch_col_half(const PassArgs &a, int nwork, void *)
 }
 struct FilterOp {
 	MotionFilter p;
-	float4 operator()(long long e, float4 v, unsigned long long &coded) const { return p.enabled ? motion_filter4(p, (uint32_t)e, v, coded) : v; }
+	SigVec<float, 2> operator()(long long e, SigVec<float, 2> v, unsigned long long &coded) const
+	{
+		if (!p.enabled) return v;
+		float4 f; f.x = v.s[0].x; f.y = v.s[0].y; f.z = v.s[1].x; f.w = v.s[1].y;
+		f = motion_filter4(p, (uint32_t)e, f, coded);
+		v.s[0].x = f.x; v.s[0].y = f.y; v.s[1].x = f.z; v.s[1].y = f.w;
+		return v;
+	}
 };
 template <class S>
 int launch_col_roundtrip(const PassArgs &af, const PassArgs &ai, const MotionFilter &filt, unsigned long long *coded, int nwork, void *)
 {
 	std::vector<unsigned char> lds(S::LDS + 32);
-	float4 *buf = (float4 *)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
+	typename S::V *buf = (typename S::V *)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
 	FilterOp f; f.p = filt;
 	unsigned long long mine = 0;
 	for (int wg = 0; wg < nwork; wg++) {

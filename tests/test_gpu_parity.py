@@ -331,6 +331,26 @@ def test_f64_plan_vs_oracle(gpu, h, w, c, kind):
     check(d.cpu().numpy(), ref, tol=TOL64)
 
 
+@pytest.mark.parametrize("h,w,c", [(512, 512, 3), (540, 960, 3), (1080, 1920, 3), (1080, 1920, 1), (2160, 3840, 1), (720, 1280, 3), (1440, 2560, 3), (2048, 2048, 3),
+                                   (1024, 1024, 3), (4096, 4096, 3), (720, 1280, 1)])
+@pytest.mark.parametrize("kind", [5, 4])
+def test_f64_specialised_kernels_vs_port(gpu, h, w, c, kind):
+    """spec_list.h DSPFFT_*_SPECS_F64 (RowSpecT<double> / ColSpecT<double>): against the f64 port, in place and out of place,
+    and the same to rounding as the generic double kernels"""
+    from dspfun_amd import Plan
+    x = ol.synth_f32(h * 3 + w, h * w * c).astype(np.float64).reshape(h, w, c) * (1 + 2.0 ** -31)
+    p = Plan.image(h, w, c, kind, dtype="f64")
+    assert "ROW* f64" in p.describe() and "COL* f64" in p.describe(), p.describe()
+    ref = ol.dct2d_interleaved(x, kind, impl="port", threads=8)
+    d = gpu.from_numpy(x.copy()).to("cuda:0")
+    o = gpu.empty_like(d)
+    p.execute(d.data_ptr(), o.data_ptr())
+    p.execute(d.data_ptr())
+    gpu.cuda.synchronize()
+    check(d.cpu().numpy(), ref, tol=TOL64)
+    check(o.cpu().numpy(), ref, tol=TOL64)
+
+
 def test_f64_c2_frame_roundtrip_with_spec_normalisation(gpu):
     """3840x2160x3 in double: spec.c:63-78 then ispec.c:153-167, normalisation fused, against the f64 port and
     by the round trip"""

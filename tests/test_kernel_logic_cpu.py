@@ -749,3 +749,44 @@ def test_generic_row_pass_with_several_lines_per_workgroup(lpw):
         assert np.abs(acc - x).max() < 1e-5
     finally:
         del os.environ["DSPFFT_ROW_LPW"], os.environ["DSPFFT_NO_TINY"]
+
+
+# ---- double-precision specialised kernels (spec_list.h DSPFFT_*_SPECS_F64: RowSpecT<double> / ColSpecT<double>) ----
+@pytest.mark.parametrize("h,w,c", [(512, 512, 3), (540, 960, 3), (720, 1280, 3), (1024, 1024, 3), (720, 1280, 1)])
+@pytest.mark.parametrize("kind", [REDFT10, REDFT01])
+def test_f64_specialised_sizes(h, w, c, kind):
+    x = ol.synth_f32(h + w, h * w * c).astype(np.float64).reshape(h, w, c) * (1 + 2.0 ** -30)
+    p = Plan.image(h, w, c, kind, lib=emul(), dtype="f64")
+    d = p.describe()
+    assert "ROW* f64" in d and "COL* f64" in d, d
+    ref = ol.dct2d_interleaved(x, kind, impl="port", threads=8)
+    assert relerr(run64(p, x.copy()), ref) < 1e-13, d
+    # out of place, and the generic kernels give the same answer to rounding
+    out = np.empty_like(x)
+    assert relerr(run64(p, x.copy(), out), ref) < 1e-13
+    os.environ["DSPFFT_NO_SPEC"] = "1"
+    try:
+        pg = Plan.image(h, w, c, kind, lib=emul(), dtype="f64")
+    finally:
+        del os.environ["DSPFFT_NO_SPEC"]
+    assert "*" not in pg.describe()
+    assert relerr(run64(pg, x.copy()), ref) < 1e-13
+
+
+def test_f64_specialised_fused_scan_step():
+    """masked loads + accumulate stores in the double kernels (scan.c:421-459 with COEFF_PRECISION=D)"""
+    h, w, c = 512, 512, 3
+    L = emul()
+    x = ol.synth_f32(77, h * w * c).astype(np.float64).reshape(h, w, c)
+    coeffs = x.copy()
+    Plan.image(h, w, c, REDFT10, lib=L, dtype="f64").set_scale(1.0 / (4 * w * h)).execute(coeffs.ctypes.data)
+    inv = Plan.image(h, w, c, REDFT01, lib=L, dtype="f64")
+    assert "ROW* f64" in inv.describe() and "COL* f64" in inv.describe()
+    ids = np.zeros(h * w, dtype=np.uint32)
+    nframes = 3
+    assert L.dspfft_scan_zigzag_frame_ids(ids.ctypes.data, w, h, (h * w + nframes - 1) // nframes, None) == 0
+    acc = np.ascontiguousarray(np.broadcast_to(coeffs[0, 0], (h, w, c)).copy())
+    work = np.zeros_like(acc)
+    for f in range(nframes):
+        inv.execute_masked_accumulate(coeffs.ctypes.data, work.ctypes.data, acc.ctypes.data, ids.ctypes.data, f, c)
+    assert np.abs(acc - x).max() < 1e-12

@@ -37,7 +37,7 @@ template <class S, int KIND, int ABL, int WPE>
 __global__ void __launch_bounds__(S::T, WPE) col_k(const PassArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-	float4 *buf = reinterpret_cast<float4 *>(lds);
+	typename S::V *buf = reinterpret_cast<typename S::V *>(lds);
 	const int tid = threadIdx.x;
 	typename S::template State<KIND> st;
 	long long bin, bout;

@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(S::T, S::WPE) pass_k(const PassArgs a, WgStamp
 	unsigned long long ts[MAXST] = {}, r0 = 0, r1 = 0;
 	if constexpr (STAMPS) { RSTAMP(r0); STAMP(ts[0]); }
 	if constexpr (ROWK) row_base(a, blockIdx.x, bin, bout); else S::base(a, blockIdx.x, bin, bout);
-	auto *buf = reinterpret_cast<std::conditional_t<ROWK, cf, float4> *>(lds);
+	auto *buf = reinterpret_cast<std::conditional_t<ROWK, cf, SigVec<float, 2>> *>(lds);
 	S::template prefetch<KIND>(a, bin, tid, st);
 	if constexpr (STAMPS) STAMP(ts[1]);
 	S::template phase<KIND, 0>(a, buf, bout, tid, st);

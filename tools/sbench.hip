@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(S::T, S::WPE) pass_k(const PassArgs a)
 	typename S::template State<KIND> st;
 	long long bin, bout;
 	if constexpr (ROWK) row_base(a, blockIdx.x, bin, bout); else S::base(a, blockIdx.x, bin, bout);
-	auto *buf = reinterpret_cast<std::conditional_t<ROWK, cf, float4> *>(lds);
+	auto *buf = reinterpret_cast<std::conditional_t<ROWK, cf, SigVec<float, 2>> *>(lds);
 	S::template prefetch<KIND>(a, bin, tid, st);
 	S::template phase<KIND, 0>(a, buf, bout, tid, st);
 	__syncthreads();
@@ -50,7 +50,8 @@ static cf *g_WM, *g_Hh;
 #endif
 static const int H = 2160, W = 3840, C = 3;
 static const size_t NF = (size_t)H * W * C;
-static const int NFR = 4;
+static int NFR = 4;            // frames per step (6 for the three-stream experiment)
+static const int NFR_MAX = 6;
 static float *g_buf;
 
 #ifdef PAIR768
@@ -135,6 +136,12 @@ static void step(const std::string &mode)
 		CHK(hipStreamWaitEvent(sA, evStepB, 0)); CHK(hipStreamWaitEvent(sB, evStepA, 0));
 		for (int f = 0; f < NFR; f++) for (int p = 0; p < 4; p++) launch_pass(p, f, 1, (f & 1) ? sB : sA);
 		CHK(hipEventRecord(evStepA, sA)); CHK(hipEventRecord(evStepB, sB));
+	} else if (mode == "free3") {
+		// three streams, one frame each in flight: 298 MB hot, more than the 256 MB Infinity Cache holds
+		static hipStream_t sC = nullptr;
+		if (!sC) CHK(hipStreamCreateWithFlags(&sC, hipStreamNonBlocking));
+		for (int f = 0; f < NFR; f++) for (int p = 0; p < 4; p++) launch_pass(p, f, 1, f % 3 == 0 ? sA : f % 3 == 1 ? sB : sC);
+		if (g_stepno++ % 8 == 7) { CHK(hipEventRecord(evA[7], sC)); CHK(hipStreamWaitEvent(sA, evA[7], 0)); }
 	} else if (mode == "stagger") {
 		// streams re-joined every g_join_every steps; after a join stream B starts g_lag_us behind stream A
 		if (g_stepno % g_join_every == 0) {
@@ -197,11 +204,11 @@ static double run_mode(const std::string &mode, int steps)
 int main(int argc, char **argv)
 {
 	const int steps = argc > 1 ? atoi(argv[1]) : 100;
-	CHK(hipMalloc(&g_buf, NF * 4 * NFR));
+	CHK(hipMalloc(&g_buf, NF * 4 * NFR_MAX));
 	{
 		std::vector<float> h(NF);
 		for (size_t i = 0; i < h.size(); i++) h[i] = (float)((i * 2654435761u) % 1000) / 1000.f;
-		for (int f = 0; f < NFR; f++) CHK(hipMemcpy(g_buf + (size_t)f * NF, h.data(), NF * 4, hipMemcpyHostToDevice));
+		for (int f = 0; f < NFR_MAX; f++) CHK(hipMemcpy(g_buf + (size_t)f * NF, h.data(), NF * 4, hipMemcpyHostToDevice));
 	}
 	g_trow = make_tables(W, W / 2); g_tcol = make_tables(H, H);
 #ifdef SPLIT
@@ -237,6 +244,16 @@ int main(int argc, char **argv)
 			float ms; CHK(hipEventElapsedTime(&ms, a, b));
 			printf("pass %d alone: %.1f us\n", p, ms * 1000 / 30);
 		}
+	}
+	if (argc > 2 && !strcmp(argv[2], "three")) {
+		for (int round = 0; round < 3; round++) {
+			NFR = 4; const double f2 = run_mode("free", steps);
+			NFR = 6; const double f2b = run_mode("free", steps); g_stepno = 0; const double f3 = run_mode("free3", steps);
+			NFR = 2; const double f2c = run_mode("free", 2 * steps);
+			NFR = 4;
+			printf("round %d: two streams 4 frames/step %.0f, 6 frames/step %.0f, 2 frames/step (all cache-resident) %.0f; three streams 6 frames/step %.0f\n", round, f2, f2b, f2c, f3);
+		}
+		return 0;
 	}
 	if (argc > 2 && !strcmp(argv[2], "stagger")) {
 		// does a free-running pair of streams keep its phase?  and which lag behind stream A is best for stream B?
