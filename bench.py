@@ -172,7 +172,8 @@ def main():
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    # DSPFFT_BENCH_FORCE_DIST=1 runs the RCCL path (init, barriers, max-over-ranks) with a single rank: the one way to exercise it on a 1-GPU box
+    if world > 1 or (os.environ.get("DSPFFT_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)

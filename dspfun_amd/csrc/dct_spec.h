@@ -424,12 +424,20 @@ DSP_HD int xcd_remap(int bid, int n)
 	return (bid & 7) * per + (bid >> 3);
 }
 
+// What a lane of a column pass computes with: the NCS complex signals of its 16 bytes as ONE complex number over a "lane real" --
+// float: Pk2 (both signals side by side: every butterfly instruction is a packed one), double: the scalar itself.
+template <class Re> struct lane_of;
+template <> struct lane_of<float> { typedef Pk2 LR; };
+template <> struct lane_of<double> { typedef double LR; };
+
 template <class Re_, int N_, int K_, int T_, int... Rs>
 struct ColSpecT {
 	typedef Re_ Re;
 	typedef cx<Re_> CX;
 	typedef PassArgsT<Re_> PA;
 	typedef typename sig_of<Re_>::type V;            // NCS complex signals = VW real columns (16 bytes)
+	typedef typename lane_of<Re_>::LR LR;
+	typedef cx<LR> LC;                               // the lane's signals as one complex number
 	static constexpr int NCS = sig_of<Re_>::NCS, VW = 2 * NCS;
 	static constexpr int N = N_, K = K_, T = T_, B = K_ / 2, NP = K_ / VW, NS = (int)sizeof...(Rs), NPH = NS + 3;
 	static constexpr int WPE_D = (int)((160 * 1024) / ((size_t)(N_ + 16) * (K_ / 2) * sizeof(CX))) * T_ / 256;
@@ -447,33 +455,56 @@ struct ColSpecT {
 	static constexpr int Y_ROUNDS = (N * NP + T - 1) / T;              // REDFT10: (row, lane vector) items per thread
 	static constexpr int K_ROUNDS = ((N / 2 + 1) * NP + T - 1) / T;    // REDFT01: (k, lane vector) items per thread
 	template <int KIND> struct State {
-		CX x[NCS][LAST_ROUNDS * RL];
-		V pre[KIND == KIND_REDFT10 ? Y_ROUNDS : 2 * K_ROUNDS];
+		LC x[LAST_ROUNDS * RL];
+		LC pre[KIND == KIND_REDFT10 ? Y_ROUNDS : 2 * K_ROUNDS];   // the loaded rows, column order (g_get)
 		CX tw[KIND == KIND_REDFT01 ? K_ROUNDS : 1];   // REDFT01: T[k] of this thread's items, fetched with the data (measured: -5 us);
 		                                              // REDFT10 loads T[k] where it is used (prefetching it there measured slower)
 	};
 
-	static DSP_HD V vscale(V v, Re f) { static_for<0, NCS>([&](auto i) { v.s[i].x *= f; v.s[i].y *= f; }); return v; }
-	static DSP_HD V vzero() { V v; static_for<0, NCS>([&](auto i) { v.s[i].x = v.s[i].y = (Re)0; }); return v; }
-
-	// REDFT10's last step for FFT outputs zk = Z[k], zm = Z[N-k] of one lane: coefficient rows k (r0) and N-k (r1), unscaled by out_scale0
-	static DSP_HD void post10(V zk, V zm, CX t, Re s0, Re sc, V &r0, V &r1)
+	// ---- lane vector <-> lane complex ----
+	// Global memory order is column order: (c0, c1 | c2, c3), signal i = c(2i) + j c(2i+1).  g_get gives x = the first column of each
+	// signal, y = the second.  In LDS a float lane keeps (re_a, re_b, im_a, im_b) so that l_get / l_put are register-pair moves and
+	// the swap happens once, where the tile meets global memory.
+	static DSP_HD LC g_get(V v)
 	{
-		static_for<0, NCS>([&](auto i) {
-			const CX A = cmk<Re>(zk.s[i].x + zm.s[i].x, zk.s[i].y - zm.s[i].y), Bq = cmul_mi(cmk<Re>(zk.s[i].x - zm.s[i].x, zk.s[i].y + zm.s[i].y));
-			const CX wa = cmul(t, A), wb = cmul(t, Bq);
-			r0.s[i].x = wa.x * s0; r0.s[i].y = wb.x * s0;
-			r1.s[i].x = -wa.y * sc; r1.s[i].y = -wb.y * sc;
-		});
+		if constexpr (NCS == 2) return cmk<LR>(pk2(v.s[0].x, v.s[1].x), pk2(v.s[0].y, v.s[1].y)); else return cmk<LR>(v.s[0].x, v.s[0].y);
 	}
-	// REDFT01's first step for coefficient rows xk (k) and xm (N-k): FFT inputs at slots k (lo) and N-k (hi)
-	static DSP_HD void pre01(V xk, V xm, CX t, V &lo, V &hi)
+	static DSP_HD V g_put(LC c)
 	{
-		static_for<0, NCS>([&](auto i) {
-			const CX Va = cmulc(cmk<Re>(xk.s[i].x, -xm.s[i].x), t), Vb = cmulc(cmk<Re>(xk.s[i].y, -xm.s[i].y), t);
-			lo.s[i].x = Va.x - Vb.y; lo.s[i].y = -Va.y - Vb.x;
-			hi.s[i].x = Va.x + Vb.y; hi.s[i].y = Va.y - Vb.x;
-		});
+		V v;
+		if constexpr (NCS == 2) { v.s[0].x = c.x.x; v.s[0].y = c.y.x; v.s[1].x = c.x.y; v.s[1].y = c.y.y; } else { v.s[0].x = c.x; v.s[0].y = c.y; }
+		return v;
+	}
+	static DSP_HD LC l_get(V v)
+	{
+		if constexpr (NCS == 2) return cmk<LR>(pk2(v.s[0].x, v.s[0].y), pk2(v.s[1].x, v.s[1].y)); else return cmk<LR>(v.s[0].x, v.s[0].y);
+	}
+	static DSP_HD V l_put(LC c)
+	{
+		V v;
+		if constexpr (NCS == 2) { v.s[0].x = c.x.x; v.s[0].y = c.x.y; v.s[1].x = c.y.x; v.s[1].y = c.y.y; } else { v.s[0].x = c.x; v.s[0].y = c.y; }
+		return v;
+	}
+	// lane complex times a scalar complex (the same twiddle for every signal of the lane)
+	static DSP_HD LC lmul(LC a, CX w) { return cmk<LR>(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
+	static DSP_HD LC lmulc(LC a, CX w) { return cmk<LR>(a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y); }   // a * conj(w)
+	static DSP_HD LC lscale(LC a, Re f) { return cmk<LR>(a.x * f, a.y * f); }
+	static DSP_HD LC lzero() { return cmk<LR>((LR)(Re)0, (LR)(Re)0); }
+
+	// REDFT10's last step for FFT outputs zk = Z[k], zm = Z[N-k] of one lane: coefficient rows k (r0) and N-k (r1), column order
+	static DSP_HD void post10(LC zk, LC zm, CX t, Re s0, Re sc, LC &r0, LC &r1)
+	{
+		const LC A = cmk<LR>(zk.x + zm.x, zk.y - zm.y), Bq = cmul_mi(cmk<LR>(zk.x - zm.x, zk.y + zm.y));
+		const LC wa = lmul(A, t), wb = lmul(Bq, t);
+		r0 = cmk<LR>(wa.x * s0, wb.x * s0);
+		r1 = cmk<LR>(-wa.y * sc, -wb.y * sc);
+	}
+	// REDFT01's first step for coefficient rows xk (k) and xm (N-k), column order: FFT inputs at slots k (lo) and N-k (hi)
+	static DSP_HD void pre01(LC xk, LC xm, CX t, LC &lo, LC &hi)
+	{
+		const LC Va = lmulc(cmk<LR>(xk.x, -xm.x), t), Vb = lmulc(cmk<LR>(xk.y, -xm.y), t);
+		lo = cmk<LR>(Va.x - Vb.y, -Va.y - Vb.x);
+		hi = cmk<LR>(Va.x + Vb.y, Va.y - Vb.x);
 	}
 
 	template <int KIND, class ST>
@@ -494,7 +525,7 @@ struct ColSpecT {
 				const int it = tid + i * T;
 				if ((i + 1) * T <= N * NP || it < N * NP) {
 					const int y = it / NP, jp = it - y * NP;
-					st.pre[i] = loadv_m<MASKED, Re>(a, bin + (long long)y * a.es_in + VW * jp);
+					st.pre[i] = g_get(loadv_m<MASKED, Re>(a, bin + (long long)y * a.es_in + VW * jp));
 				}
 			});
 		} else {
@@ -504,8 +535,8 @@ struct ColSpecT {
 					const int k = it / NP, jp = it - k * NP;
 					const int km = k ? N - k : 0;
 					const long long p = bin + VW * jp;
-					st.pre[2 * i] = loadv_m<MASKED, Re>(a, p + (long long)k * a.es_in);
-					st.pre[2 * i + 1] = loadv_m<MASKED, Re>(a, p + (long long)km * a.es_in);
+					st.pre[2 * i] = g_get(loadv_m<MASKED, Re>(a, p + (long long)k * a.es_in));
+					st.pre[2 * i + 1] = g_get(loadv_m<MASKED, Re>(a, p + (long long)km * a.es_in));
 				}
 			});
 		}
@@ -533,16 +564,16 @@ struct ColSpecT {
 			int stride;
 			if constexpr (I == 0) { p = buf + m * NP + jp; stride = (SB + PADC) * NP; }
 			else { p = buf + (padded(blk * Lc) + m) * NP + jp; stride = M1 * NP; }
-			CX x[NCS][R];
-			static_for<0, R>([&](auto r) { const V v = p[r * stride]; static_for<0, NCS>([&](auto i) { x[i][r] = v.s[i]; }); });
-			static_for<0, NCS>([&](auto i) { Dft<R>::run(x[i]); });
+			LC x[R];
+			static_for<0, R>([&](auto r) { x[r] = l_get(p[r * stride]); });
+			Dft<R>::run(x);
 			if constexpr (M1 > 1) {
 				CX w[R];
 				w[1] = a.W[m * TW];
 				static_for<2, R>([&](auto r) { if constexpr (r % 2 == 0) w[r] = csqr(w[r / 2]); else w[r] = cmul(w[r / 2], w[r - r / 2]); });
-				static_for<1, R>([&](auto r) { static_for<0, NCS>([&](auto i) { x[i][r] = cmul(x[i][r], w[r]); }); });
+				static_for<1, R>([&](auto r) { x[r] = lmul(x[r], w[r]); });
 			}
-			static_for<0, R>([&](auto r) { V v; static_for<0, NCS>([&](auto i) { v.s[i] = x[i][r]; }); p[r * stride] = v; });
+			static_for<0, R>([&](auto r) { p[r * stride] = l_put(x[r]); });
 		});
 	}
 
@@ -556,8 +587,8 @@ struct ColSpecT {
 				int blk;
 				if constexpr (NS >= 2) blk = PosCalcFirst<NBL, NS - 1, Rs..., 1>::run(kb); else blk = 0;
 				const V *p = buf + (NS >= 2 ? padded(blk * RL) : 0) * NP + jp;
-				static_for<0, RL>([&](auto r) { const V v = p[r * NP]; static_for<0, NCS>([&](auto c) { st.x[c][i * RL + r] = v.s[c]; }); });
-				static_for<0, NCS>([&](auto c) { Dft<RL>::run(&st.x[c][i * RL]); });
+				static_for<0, RL>([&](auto r) { st.x[i * RL + r] = l_get(p[r * NP]); });
+				Dft<RL>::run(&st.x[i * RL]);
 			}
 		});
 	}
@@ -569,10 +600,7 @@ struct ColSpecT {
 			if (it < NBL * NP) {
 				const int kb = it / NP, jp = it - kb * NP;
 				V *p = buf + kb * NP + jp;
-				static_for<0, RL>([&](auto r) {
-					V v; static_for<0, NCS>([&](auto c) { v.s[c] = st.x[c][i * RL + r]; });
-					p[r * NBL * NP] = v;
-				});
+				static_for<0, RL>([&](auto r) { p[r * NBL * NP] = l_put(st.x[i * RL + r]); });
 			}
 		});
 	}
@@ -583,8 +611,8 @@ struct ColSpecT {
 	// the results wait in registers across one barrier because the inverse's padded layout overlaps slots other
 	// threads still have to read.
 	struct StateRT {
-		CX x[NCS][LAST_ROUNDS * RL];
-		V pre[(Y_ROUNDS > 2 * K_ROUNDS) ? Y_ROUNDS : 2 * K_ROUNDS];
+		LC x[LAST_ROUNDS * RL];
+		LC pre[(Y_ROUNDS > 2 * K_ROUNDS) ? Y_ROUNDS : 2 * K_ROUNDS];
 		CX tw[1];
 	};
 	template <class ST, class F>
@@ -595,12 +623,13 @@ struct ColSpecT {
 			if (!((ri + 1) * T <= (N / 2 + 1) * NP || it < (N / 2 + 1) * NP)) return;
 			const int k = it / NP, jp = it - k * NP;
 			const int km = k ? N - k : 0;
-			const V zk = buf[k * NP + jp], zm = buf[km * NP + jp];
+			const LC zk = l_get(buf[k * NP + jp]), zm = l_get(buf[km * NP + jp]);
 			const CX t = af.T[k];
 			const Re sc = af.scale, s0 = (k == 0) ? sc * af.out_scale0 : sc;
 			const long long o = bout + VW * jp;
-			V xk, xm;
-			post10(zk, zm, t, s0, sc, xk, xm);                                   // coefficient rows k and N-k
+			LC r0, r1;
+			post10(zk, zm, t, s0, sc, r0, r1);                                   // coefficient rows k and N-k
+			V xk = g_put(r0), xm = g_put(r1);
 			DSP_SCHED_FENCE();
 			xk = filt(o + (long long)k * af.es_out, xk, coded);
 			DSP_SCHED_FENCE();
@@ -608,9 +637,10 @@ struct ColSpecT {
 			else if (km == k && k > 0) xm = xk;
 			DSP_SCHED_FENCE();                                                   // k = N/2: the same row
 			// REDFT01's first phase on rows k and N-k (ColSpec::phase<KIND_REDFT01, 0>)
-			if (k == 0) { xk = vscale(xk, ai.in_scale0); xm = vzero(); }
-			V lo, hi;
-			pre01(xk, xm, t, lo, hi);
+			LC ck = g_get(xk), cm = g_get(xm);
+			if (k == 0) { ck = lscale(ck, ai.in_scale0); cm = lzero(); }
+			LC lo, hi;
+			pre01(ck, cm, t, lo, hi);
 			st.pre[2 * ri] = lo; st.pre[2 * ri + 1] = hi;
 			DSP_SCHED_FENCE();
 		});
@@ -623,8 +653,8 @@ struct ColSpecT {
 			if (!((ri + 1) * T <= (N / 2 + 1) * NP || it < (N / 2 + 1) * NP)) return;
 			const int k = it / NP, jp = it - k * NP;
 			const int km = k ? N - k : 0;
-			buf[padded(k) * NP + jp] = st.pre[2 * ri];
-			if (k > 0) buf[padded(km) * NP + jp] = st.pre[2 * ri + 1];
+			buf[padded(k) * NP + jp] = l_put(st.pre[2 * ri]);
+			if (k > 0) buf[padded(km) * NP + jp] = l_put(st.pre[2 * ri + 1]);
 		});
 	}
 
@@ -637,9 +667,9 @@ struct ColSpecT {
 					const int it = tid + i * T;
 					if ((i + 1) * T <= N * NP || it < N * NP) {
 						const int y = it / NP, jp = it - y * NP;
-						V v = st.pre[i];
-						if (y == 0) v = vscale(v, a.in_scale0);
-						buf[padded(makhoul_dst(y, N)) * NP + jp] = v;
+						LC v = st.pre[i];
+						if (y == 0) v = lscale(v, a.in_scale0);
+						buf[padded(makhoul_dst(y, N)) * NP + jp] = l_put(v);
 					}
 				});
 			} else {
@@ -648,12 +678,12 @@ struct ColSpecT {
 					if ((i + 1) * T <= (N / 2 + 1) * NP || it < (N / 2 + 1) * NP) {
 						const int k = it / NP, jp = it - k * NP;
 						const int km = k ? N - k : 0;
-						V xk = st.pre[2 * i], xm = st.pre[2 * i + 1];
-						if (k == 0) { xk = vscale(xk, a.in_scale0); xm = vzero(); }
-						V lo, hi;
+						LC xk = st.pre[2 * i], xm = st.pre[2 * i + 1];
+						if (k == 0) { xk = lscale(xk, a.in_scale0); xm = lzero(); }
+						LC lo, hi;
 						pre01(xk, xm, st.tw[i], lo, hi);
-						buf[padded(k) * NP + jp] = lo;
-						if (k > 0) buf[padded(km) * NP + jp] = hi;
+						buf[padded(k) * NP + jp] = l_put(lo);
+						if (k > 0) buf[padded(km) * NP + jp] = l_put(hi);
 					}
 				});
 			}
@@ -670,22 +700,21 @@ struct ColSpecT {
 					if (!((ri + 1) * T <= (N / 2 + 1) * NP || it < (N / 2 + 1) * NP)) return;
 					const int k = it / NP, jp = it - k * NP;
 					const int km = k ? N - k : 0;
-					const V zk = buf[k * NP + jp], zm = buf[km * NP + jp];
+					const LC zk = l_get(buf[k * NP + jp]), zm = l_get(buf[km * NP + jp]);
 					const Re sc = a.scale, s0 = (k == 0) ? sc * a.out_scale0 : sc;
 					const long long o = bout + VW * jp;
-					V r0, r1;
+					LC r0, r1;
 					post10(zk, zm, a.T[k], s0, sc, r0, r1);
-					storev_a<Re>(a, o + (long long)k * a.es_out, r0);
-					if (k > 0 && km != k) storev_a<Re>(a, o + (long long)km * a.es_out, r1);
+					storev_a<Re>(a, o + (long long)k * a.es_out, g_put(r0));
+					if (k > 0 && km != k) storev_a<Re>(a, o + (long long)km * a.es_out, g_put(r1));
 				});
 			} else {
 				tloop<N * NP, T>(tid, [&](int it) {
 					const int n = it / NP, jp = it - n * NP;
-					const V F = buf[n * NP + jp];
+					const LC F = l_get(buf[n * NP + jp]);
 					const int y = makhoul_src(n, N);
 					const Re sc = (y == 0) ? a.scale * a.out_scale0 : a.scale;
-					V r; static_for<0, NCS>([&](auto i) { r.s[i].x = F.s[i].x * sc; r.s[i].y = -F.s[i].y * sc; });
-					storev_a<Re>(a, bout + (long long)y * a.es_out + VW * jp, r);
+					storev_a<Re>(a, bout + (long long)y * a.es_out + VW * jp, g_put(cmk<LR>(F.x * sc, -F.y * sc)));
 				});
 			}
 		}
@@ -715,6 +744,8 @@ struct ColHalfSpecT {
 	typedef PassArgsT<Re_> PA;
 	typedef ColSpecT<Re_, N_ / 2, K_, T_, Rs...> B;          // stages / last stage of the M-point FFT are the plain column pass's
 	typedef typename B::V V;
+	typedef typename B::LC LC;
+	typedef typename B::LR LR;
 	static constexpr int NCS = B::NCS, VW = B::VW;
 	static constexpr int N = N_, M = N_ / 2, K = K_, T = T_, NP = B::NP;
 	static constexpr int NS = B::NS, NPH = B::NPH, WPE = 1;
@@ -756,7 +787,7 @@ struct ColHalfSpecT {
 				const int it = tid + i * T;
 				if ((i + 1) * T <= M * NP || it < M * NP) {
 					const int n = it / NP, jp = it - n * NP;
-					st.pre[i] = loadv_m<MASKED, Re>(a, bin + (long long)row_of(n, h) * a.es_in + VW * jp);
+					st.pre[i] = B::g_get(loadv_m<MASKED, Re>(a, bin + (long long)row_of(n, h) * a.es_in + VW * jp));
 				}
 			});
 			// half 1: the twiddles w^n of this thread's rows, fetched behind the data so their latency hides under it (rows n .. n + T/NP
@@ -774,18 +805,11 @@ struct ColHalfSpecT {
 					const int k = 2 * q + h, km = k ? N - k : 0;
 					st.tw[i] = a.T[k];
 					const long long p = bin + VW * jp;
-					st.pre[2 * i] = loadv_m<MASKED, Re>(a, p + (long long)k * a.es_in);
-					st.pre[2 * i + 1] = loadv_m<MASKED, Re>(a, p + (long long)km * a.es_in);
+					st.pre[2 * i] = B::g_get(loadv_m<MASKED, Re>(a, p + (long long)k * a.es_in));
+					st.pre[2 * i + 1] = B::g_get(loadv_m<MASKED, Re>(a, p + (long long)km * a.es_in));
 				}
 			});
 		}
-	}
-
-	static DSP_HD V mul_h(V v, CX w)
-	{
-		V r;
-		static_for<0, NCS>([&](auto i) { r.s[i].x = v.s[i].x * w.x - v.s[i].y * w.y; r.s[i].y = v.s[i].x * w.y + v.s[i].y * w.x; });
-		return r;
 	}
 
 	template <int KIND, int PH, class ST>
@@ -797,9 +821,9 @@ struct ColHalfSpecT {
 					const int it = tid + i * T;
 					if ((i + 1) * T <= M * NP || it < M * NP) {
 						const int n = it / NP, jp = it - n * NP;
-						V v = st.pre[i];
-						if (h) v = mul_h(v, st.hw[i]);
-						buf[B::padded(n) * NP + jp] = v;
+						LC v = st.pre[i];
+						if (h) v = B::lmul(v, st.hw[i]);
+						buf[B::padded(n) * NP + jp] = B::l_put(v);
 					}
 				});
 			} else {
@@ -809,12 +833,12 @@ struct ColHalfSpecT {
 						const int q = it / NP, jp = it - q * NP;
 						if (h && q >= M / 2) return;
 						const int k = 2 * q + h, qm = partner(q, h);
-						V xk = st.pre[2 * i], xm = st.pre[2 * i + 1];
-						if (k == 0) { xk = B::vscale(xk, a.in_scale0); xm = B::vzero(); }
-						V lo, hi;
+						LC xk = st.pre[2 * i], xm = st.pre[2 * i + 1];
+						if (k == 0) { xk = B::lscale(xk, a.in_scale0); xm = B::lzero(); }
+						LC lo, hi;
 						B::pre01(xk, xm, st.tw[i], lo, hi);
-						buf[B::padded(q) * NP + jp] = lo;
-						if (k > 0) buf[B::padded(qm) * NP + jp] = hi;
+						buf[B::padded(q) * NP + jp] = B::l_put(lo);
+						if (k > 0) buf[B::padded(qm) * NP + jp] = B::l_put(hi);
 					}
 				});
 			}
@@ -832,22 +856,21 @@ struct ColHalfSpecT {
 					const int q = it / NP, jp = it - q * NP;
 					if (h && q >= M / 2) return;
 					const int k = 2 * q + h, km = k ? N - k : 0, qm = partner(q, h);
-					const V zk = buf[q * NP + jp], zm = buf[qm * NP + jp];
+					const LC zk = B::l_get(buf[q * NP + jp]), zm = B::l_get(buf[qm * NP + jp]);
 					const Re sc = a.scale, s0 = (k == 0) ? sc * a.out_scale0 : sc;
 					const long long o = bout + VW * jp;
-					V r0, r1;
+					LC r0, r1;
 					B::post10(zk, zm, a.T[k], s0, sc, r0, r1);
-					storev_a<Re>(a, o + (long long)k * a.es_out, r0);
-					if (k > 0 && km != k) storev_a<Re>(a, o + (long long)km * a.es_out, r1);
+					storev_a<Re>(a, o + (long long)k * a.es_out, B::g_put(r0));
+					if (k > 0 && km != k) storev_a<Re>(a, o + (long long)km * a.es_out, B::g_put(r1));
 				});
 			} else {
 				tloop<M * NP, T>(tid, [&](int it) {
 					const int n = it / NP, jp = it - n * NP;
-					V F = buf[n * NP + jp];
-					if (h) F = mul_h(F, a.H[n]);           // conj(w)^n O[n] = conj(w^n conj(O[n])); the conjugation is the sign below
+					LC F = B::l_get(buf[n * NP + jp]);
+					if (h) F = B::lmul(F, a.H[n]);         // conj(w)^n O[n] = conj(w^n conj(O[n])); the conjugation is the sign below
 					const Re sc = a.scale;
-					V r; static_for<0, NCS>([&](auto i) { r.s[i].x = F.s[i].x * sc; r.s[i].y = -F.s[i].y * sc; });
-					storev_a<Re>(a, bout + (long long)row_of(n, h) * a.es_out + VW * jp, r);
+					storev_a<Re>(a, bout + (long long)row_of(n, h) * a.es_out + VW * jp, B::g_put(cmk<LR>(F.x * sc, -F.y * sc)));
 				});
 			}
 		}

@@ -24,6 +24,28 @@ struct alignas(32) double4 { double x, y, z, w; };
 
 namespace dspfft {
 
+// Two floats that go through every operation together.  On gfx950 a 2 x float vector maps onto the packed FP32 instructions
+// (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two results per lane per issue), which is how the column kernels carry the two
+// complex signals of a lane through the butterflies at half the instruction count.  The host (g++ emulation) stand-in does the same
+// arithmetic element by element.
+#if defined(__clang__)
+typedef float Pk2 __attribute__((ext_vector_type(2)));
+DSP_HD Pk2 pk2(float a, float b) { Pk2 r; r.x = a; r.y = b; return r; }
+#else
+struct Pk2 {
+	float x, y;
+	constexpr Pk2() : x(0), y(0) {}
+	constexpr Pk2(float s) : x(s), y(s) {}
+	constexpr Pk2(float a, float b) : x(a), y(b) {}
+	Pk2 &operator+=(Pk2 o) { x += o.x; y += o.y; return *this; }
+};
+constexpr Pk2 operator+(Pk2 a, Pk2 b) { return Pk2(a.x + b.x, a.y + b.y); }
+constexpr Pk2 operator-(Pk2 a, Pk2 b) { return Pk2(a.x - b.x, a.y - b.y); }
+constexpr Pk2 operator*(Pk2 a, Pk2 b) { return Pk2(a.x * b.x, a.y * b.y); }
+constexpr Pk2 operator-(Pk2 a) { return Pk2(-a.x, -a.y); }
+DSP_HD Pk2 pk2(float a, float b) { return Pk2(a, b); }
+#endif
+
 // complex number over float (the tuned path; 8 bytes, same layout as float2) or double (the fftw_ double API)
 template <class R> struct cx { typedef R real; R x, y; };
 typedef cx<float> cf;

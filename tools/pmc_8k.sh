@@ -13,7 +13,7 @@ for c in ("FETCH_SIZE","WRITE_SIZE"):
     f=glob.glob(f"{R}/gpurun_out/pmc8k_{c}/*counter_collection.csv")[0]
     acc=collections.defaultdict(list)
     for row in csv.DictReader(open(f)):
-        if row["Counter_Name"]==c and "spec_kernel" in row["Kernel_Name"]:
-            acc[row["Kernel_Name"][:70]].append(float(row["Counter_Value"]))
+        if row["Counter_Name"]==c and "dspfft::" in row["Kernel_Name"]:
+            acc[row["Kernel_Name"][:90]].append(float(row["Counter_Value"]))
     for k,v in acc.items(): print(c, k, round(sum(v)/len(v)/1024,1), "MB per dispatch (raw KB counter)")
 PY
