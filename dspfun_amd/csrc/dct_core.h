@@ -93,6 +93,14 @@ struct PassGeom {
 	uint32_t mask_id;
 	FastDiv mask_div;     // elements per owner id (32-bit offsets: masked runs are limited to 2^32 / d elements)
 	int accumulate;
+	// sparse scan frames (specialised kernels, dct_spec.h): a masked COL first pass records per tile whether any coefficient was
+	// selected (zflags[tile] = 0 / 1) and skips the tiles with none; the ROW pass that follows reads zeros for those tiles, not `in`
+	uint8_t *zflags;      // null: off.  COL side writes (when mask is set), ROW side reads
+	int zshift;           // ROW side: log2 of the column pass's tile width in samples
+	int zhalf;            // ROW side: the flags of odd lines start at zflags + zhalf (split column passes: half 1), else 0
+	const void *zpage;    // ROW side: 64 zero bytes to load from in place of a skipped tile
+	const uint32_t *zranges;   // COL side, optional: (min, max) owner id of every tile (dspfft_plan_scan_prepare): a tile whose range
+	                           // excludes mask_id is skipped without reading its owner ids
 	FftDesc fft;
 	FastDiv divB;         // divide by the number of signals in the LDS buffer (ROW: C*LPW, COL: B)
 };

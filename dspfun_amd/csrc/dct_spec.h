@@ -127,22 +127,43 @@ template <int C, bool MASKED, class Re> DSP_HD Pix<C, Re> load_pix_m(const PassA
 	}
 	return load_pix<C, Re>(a.in + off);
 }
+// ROW pass behind a masked COL pass that skipped its empty tiles (PassGeom::zflags): o = offset of the pixel within its line.
+// No branch around the load (see load_pix_m): a pixel whose tiles were all skipped loads from the zero page instead.
+template <int C, class Re> DSP_HD Pix<C, Re> load_pix_z(const PassArgsT<Re> &a, const uint8_t *zf, int o, long long off)
+{
+	const int t0 = o >> a.zshift, tl = (o + C - 1) >> a.zshift;
+	const uint8_t f0 = zf[t0], fl = zf[tl];
+	const Re *p = (f0 | fl) ? a.in + off : reinterpret_cast<const Re *>(a.zpage);
+	Pix<C, Re> v = load_pix<C, Re>(p);
+	static_for<0, C>([&](auto c) { const uint8_t nz = (((o + c) >> a.zshift) == t0) ? f0 : fl; if (!nz) v.v[c] = (Re)0; });
+	return v;
+}
 template <int C, class Re> DSP_HD void store_pix_a(const PassArgsT<Re> &a, long long off, Pix<C, Re> r)
 {
 	if (a.accumulate) { const Pix<C, Re> o = load_pix<C, Re>(a.out + off); static_for<0, C>([&](auto c) { r.v[c] += o.v[c]; }); }
 	store_pix<C, Re>(a.out + off, r);
 }
-template <bool MASKED, class Re> DSP_HD typename sig_of<Re>::type loadv_m(const PassArgsT<Re> &a, long long off)
+template <bool MASKED, class Re> DSP_HD typename sig_of<Re>::type loadv_m(const PassArgsT<Re> &a, long long off, bool &hit)
 {
 	typedef typename sig_of<Re>::type V;
 	constexpr int NCS = sig_of<Re>::NCS;
 	if constexpr (MASKED) {
-		uint32_t id[2 * NCS];
+		// owner ids of the lane's 2 NCS consecutive elements: when they span at most two owners (three or more elements per owner:
+		// RGB pixels) two loads serve all of them
+		uint32_t id[2 * NCS], own[2 * NCS];
+		static_for<0, 2 * NCS>([&](auto c) { own[c] = a.mask_div.div((uint32_t)off + c); });
+		if (own[2 * NCS - 1] - own[0] <= 1) {
+			const uint32_t ia = a.mask[own[0]], ib = a.mask[own[2 * NCS - 1]];
+			static_for<0, 2 * NCS>([&](auto c) { id[c] = own[c] == own[0] ? ia : ib; });
+		} else {
+			static_for<0, 2 * NCS>([&](auto c) { id[c] = a.mask[own[c]]; });
+		}
 		bool any = false;
-		static_for<0, 2 * NCS>([&](auto c) { id[c] = a.mask[a.mask_div.div((uint32_t)off + c)]; any = any || id[c] == a.mask_id; });
+		static_for<0, 2 * NCS>([&](auto c) { any = any || id[c] == a.mask_id; });
 		V v;
 		static_for<0, NCS>([&](auto i) { v.s[i].x = v.s[i].y = (Re)0; });
 		if (!any) return v;
+		hit = true;                  // this thread selected at least one coefficient (sparse scan frames: see PassGeom::zflags)
 		v = *reinterpret_cast<const V *>(a.in + off);
 		static_for<0, NCS>([&](auto i) { if (id[2 * i] != a.mask_id) v.s[i].x = (Re)0; if (id[2 * i + 1] != a.mask_id) v.s[i].y = (Re)0; });
 		return v;
@@ -198,13 +219,19 @@ struct RowSpecT {
 
 	// issue the global loads of one line into registers (no LDS access, no waiting)
 	template <int KIND, class ST>
-	static DSP_HD void prefetch(const PA &a, long long bin, int tid, ST &st, const U8IO *io = nullptr)
+	static DSP_HD void prefetch(const PA &a, long long bin, int tid, ST &st, const U8IO *io = nullptr, const uint8_t *zf = nullptr)
 	{
-		if (a.mask) prefetch_m<KIND, true>(a, bin, tid, st, io); else prefetch_m<KIND, false>(a, bin, tid, st, io);
+		if (a.mask) prefetch_m<KIND, true, false>(a, bin, tid, st, io, nullptr);
+		else if (zf) prefetch_m<KIND, false, true>(a, bin, tid, st, io, zf);       // zf: this line's tile flags (PassGeom::zflags)
+		else prefetch_m<KIND, false, false>(a, bin, tid, st, io, nullptr);
 	}
-	template <int KIND, bool MASKED, class ST>
-	static DSP_HD void prefetch_m(const PA &a, long long bin, int tid, ST &st, const U8IO *io)
+	template <int KIND, bool MASKED, bool FLAGGED, class ST>
+	static DSP_HD void prefetch_m(const PA &a, long long bin, int tid, ST &st, const U8IO *io, const uint8_t *zf)
 	{
+		auto ld = [&](int x) {
+			if constexpr (FLAGGED) return load_pix_z<C, Re>(a, zf, x * C, bin + (long long)x * C);
+			else return load_pix_m<C, MASKED, Re>(a, bin + (long long)x * C);
+		};
 		if constexpr (KIND == KIND_REDFT10 && U8_OK) {
 			if (io && io->in) {
 				static_for<0, U8_ROUNDS>([&](auto i) {
@@ -222,7 +249,7 @@ struct RowSpecT {
 			static_for<0, PIX_ROUNDS>([&](auto i) {
 				const int x = tid + i * T;
 				if ((i + 1) * T <= N || x < N) {
-					const Pix<C, Re> v = load_pix_m<C, MASKED, Re>(a, bin + (long long)x * C);
+					const Pix<C, Re> v = ld(x);
 					static_for<0, C>([&](auto c) { st.pre[i * C + c] = v.v[c]; });
 				}
 			});
@@ -230,10 +257,7 @@ struct RowSpecT {
 			static_for<0, K_ROUNDS>([&](auto i) {
 				const int k = tid + i * T;
 				if ((i + 1) * T <= L / 2 + 1 || k <= L / 2) {
-					const Pix<C, Re> p0 = load_pix_m<C, MASKED, Re>(a, bin + (long long)k * C);
-					const Pix<C, Re> p1 = load_pix_m<C, MASKED, Re>(a, bin + (long long)(k ? N - k : 0) * C);
-					const Pix<C, Re> p2 = load_pix_m<C, MASKED, Re>(a, bin + (long long)(L - k) * C);
-					const Pix<C, Re> p3 = load_pix_m<C, MASKED, Re>(a, bin + (long long)(L + k) * C);
+					const Pix<C, Re> p0 = ld(k), p1 = ld(k ? N - k : 0), p2 = ld(L - k), p3 = ld(L + k);
 					static_for<0, C>([&](auto c) {
 						st.pre[(i * 4 + 0) * C + c] = p0.v[c]; st.pre[(i * 4 + 1) * C + c] = p1.v[c];
 						st.pre[(i * 4 + 2) * C + c] = p2.v[c]; st.pre[(i * 4 + 3) * C + c] = p3.v[c];
@@ -508,12 +532,15 @@ struct ColSpecT {
 	}
 
 	template <int KIND, class ST>
-	static DSP_HD void prefetch(const PA &a, long long bin, int tid, ST &st)
+	static DSP_HD void prefetch(const PA &a, long long bin, int tid, ST &st) { bool hit = false; prefetch<KIND>(a, bin, tid, st, hit); }
+	// hit (masked runs): set when this thread selected at least one coefficient
+	template <int KIND, class ST>
+	static DSP_HD void prefetch(const PA &a, long long bin, int tid, ST &st, bool &hit)
 	{
-		if (a.mask) prefetch_m<KIND, true>(a, bin, tid, st); else prefetch_m<KIND, false>(a, bin, tid, st);
+		if (a.mask) prefetch_m<KIND, true>(a, bin, tid, st, hit); else prefetch_m<KIND, false>(a, bin, tid, st, hit);
 	}
 	template <int KIND, bool MASKED, class ST>
-	static DSP_HD void prefetch_m(const PA &a, long long bin, int tid, ST &st)
+	static DSP_HD void prefetch_m(const PA &a, long long bin, int tid, ST &st, bool &hit)
 	{
 		if constexpr (KIND == KIND_REDFT01)
 			static_for<0, K_ROUNDS>([&](auto i) {
@@ -525,7 +552,7 @@ struct ColSpecT {
 				const int it = tid + i * T;
 				if ((i + 1) * T <= N * NP || it < N * NP) {
 					const int y = it / NP, jp = it - y * NP;
-					st.pre[i] = g_get(loadv_m<MASKED, Re>(a, bin + (long long)y * a.es_in + VW * jp));
+					st.pre[i] = g_get(loadv_m<MASKED, Re>(a, bin + (long long)y * a.es_in + VW * jp, hit));
 				}
 			});
 		} else {
@@ -535,8 +562,8 @@ struct ColSpecT {
 					const int k = it / NP, jp = it - k * NP;
 					const int km = k ? N - k : 0;
 					const long long p = bin + VW * jp;
-					st.pre[2 * i] = g_get(loadv_m<MASKED, Re>(a, p + (long long)k * a.es_in));
-					st.pre[2 * i + 1] = g_get(loadv_m<MASKED, Re>(a, p + (long long)km * a.es_in));
+					st.pre[2 * i] = g_get(loadv_m<MASKED, Re>(a, p + (long long)k * a.es_in, hit));
+					st.pre[2 * i + 1] = g_get(loadv_m<MASKED, Re>(a, p + (long long)km * a.es_in, hit));
 				}
 			});
 		}
@@ -544,10 +571,14 @@ struct ColSpecT {
 
 	static DSP_HD int padded(int n) { return n + (n / SB) * PADC; }
 
-	static DSP_HD void base(const PA &a, int work, long long &bin, long long &bout)
+	static DSP_HD void base(const PA &a, int work, long long &bin, long long &bout) { int tile; base(a, work, bin, bout, tile); }
+	// tile = index of the tile among all tiles of the launch (what PassGeom::zflags is indexed by)
+	static DSP_HD void base(const PA &a, int work, long long &bin, long long &bout, int &tile)
 	{
 		const int bt = work / a.ntiles, t0 = work - bt * a.ntiles;
-		const int t = xcd_remap(t0, a.ntiles);
+		// sparse scan frames keep a contiguous run of tiles and skip the rest: leave those runs spread over the XCDs
+		const int t = (a.zflags && a.mask) ? t0 : xcd_remap(t0, a.ntiles);
+		tile = bt * a.ntiles + t;
 		const int i1 = bt / a.nb0, i0 = bt - i1 * a.nb0;
 		bin = i0 * a.sb0_in + i1 * a.sb1_in + (long long)t * K;
 		bout = i0 * a.sb0_out + i1 * a.sb1_out + (long long)t * K;
@@ -761,11 +792,14 @@ struct ColHalfSpecT {
 	// FFT slot of the partner F[N-k] of coefficient k = 2q + h
 	static DSP_HD int partner(int q, int h) { return h ? M - 1 - q : (q ? M - q : 0); }
 
-	static DSP_HD void base(const PA &a, int work, long long &bin, long long &bout, int &h)
+	static DSP_HD void base(const PA &a, int work, long long &bin, long long &bout, int &h) { int tile; base(a, work, bin, bout, h, tile); }
+	// tile = half * ntiles + tile of the row (PassGeom::zflags, zhalf = ntiles), per batch
+	static DSP_HD void base(const PA &a, int work, long long &bin, long long &bout, int &h, int &tile)
 	{
 		const int per = 2 * a.ntiles;
 		const int bt = work / per, t0 = work - bt * per;
-		const int t1 = xcd_remap(t0, per);
+		const int t1 = (a.zflags && a.mask) ? t0 : xcd_remap(t0, per);     // see ColSpecT::base
+		tile = bt * per + t1;
 		h = t1 / a.ntiles;
 		const int t = t1 - h * a.ntiles;
 		const int i1 = bt / a.nb0, i0 = bt - i1 * a.nb0;
@@ -775,19 +809,19 @@ struct ColHalfSpecT {
 
 	// the fused scan step masks the first pass's loads (loadv_m) and adds in the last pass's stores (storev_a), as in ColSpec
 	template <int KIND, class ST>
-	static DSP_HD void prefetch(const PA &a, long long bin, int h, int tid, ST &st)
+	static DSP_HD void prefetch(const PA &a, long long bin, int h, int tid, ST &st, bool &hit)
 	{
-		if (a.mask) prefetch_m<KIND, true>(a, bin, h, tid, st); else prefetch_m<KIND, false>(a, bin, h, tid, st);
+		if (a.mask) prefetch_m<KIND, true>(a, bin, h, tid, st, hit); else prefetch_m<KIND, false>(a, bin, h, tid, st, hit);
 	}
 	template <int KIND, bool MASKED, class ST>
-	static DSP_HD void prefetch_m(const PA &a, long long bin, int h, int tid, ST &st)
+	static DSP_HD void prefetch_m(const PA &a, long long bin, int h, int tid, ST &st, bool &hit)
 	{
 		if constexpr (KIND == KIND_REDFT10) {
 			static_for<0, Y_ROUNDS>([&](auto i) {
 				const int it = tid + i * T;
 				if ((i + 1) * T <= M * NP || it < M * NP) {
 					const int n = it / NP, jp = it - n * NP;
-					st.pre[i] = B::g_get(loadv_m<MASKED, Re>(a, bin + (long long)row_of(n, h) * a.es_in + VW * jp));
+					st.pre[i] = B::g_get(loadv_m<MASKED, Re>(a, bin + (long long)row_of(n, h) * a.es_in + VW * jp, hit));
 				}
 			});
 			// half 1: the twiddles w^n of this thread's rows, fetched behind the data so their latency hides under it (rows n .. n + T/NP
@@ -805,8 +839,8 @@ struct ColHalfSpecT {
 					const int k = 2 * q + h, km = k ? N - k : 0;
 					st.tw[i] = a.T[k];
 					const long long p = bin + VW * jp;
-					st.pre[2 * i] = B::g_get(loadv_m<MASKED, Re>(a, p + (long long)k * a.es_in));
-					st.pre[2 * i + 1] = B::g_get(loadv_m<MASKED, Re>(a, p + (long long)km * a.es_in));
+					st.pre[2 * i] = B::g_get(loadv_m<MASKED, Re>(a, p + (long long)k * a.es_in, hit));
+					st.pre[2 * i + 1] = B::g_get(loadv_m<MASKED, Re>(a, p + (long long)km * a.es_in, hit));
 				}
 			});
 		}

@@ -155,6 +155,17 @@ struct dspfft_plan_s {
 	std::vector<Pass> split;   // alternative pass list of dspfft_execute / dspfft_execute_pass (build_split); empty when not applicable
 	int split_col_axis = -1;
 	size_t alg_bytes;
+	// sparse scan frames (PassGeom::zflags): per-tile flags of the masked column pass + a page of zeros, allocated on first use
+	void *zflags = nullptr;
+	size_t zflags_bytes = 0;
+	void *zpage = nullptr;
+	// dspfft_plan_scan_prepare: (min, max) owner id per column tile for the owner-id array `zr_ids` (elements per id zr_div), laid out
+	// for the split passes (zr_split) or the plain ones
+	void *zranges = nullptr;
+	size_t zranges_bytes = 0;
+	const void *zr_ids = nullptr;
+	int zr_div = 0;
+	bool zr_split = false;
 };
 
 namespace {
@@ -469,7 +480,7 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 	}
 }
 
-struct Fuse { const uint32_t *mask = nullptr; uint32_t id = 0; int div = 1; bool accumulate = false; };
+struct Fuse { const uint32_t *mask = nullptr; uint32_t id = 0; int div = 1; bool accumulate = false; uint8_t *zflags = nullptr; int zshift = 0, zhalf = 0; const void *zpage = nullptr; const uint32_t *zranges = nullptr; };
 FastDiv make_div(uint32_t d);
 
 template <class R>
@@ -479,6 +490,7 @@ void fill_args(PassArgsT<R> &a, const PassGeom &g, const dspfft_plan_s *pl, cons
 	a.in = in; a.out = out; a.T = (const cx<R> *)P.tab.T; a.W = (const cx<R> *)P.tab.W; a.H = (const cx<R> *)P.tab.H;
 	a.scale = (R)scale; a.in_scale0 = (R)pl->in0[P.axis]; a.out_scale0 = (R)pl->out0[P.axis];
 	a.mask = fz.mask; a.mask_id = fz.id; a.mask_div = make_div((uint32_t)fz.div); a.accumulate = fz.accumulate;
+	a.zflags = fz.zflags; a.zshift = fz.zshift; a.zhalf = fz.zhalf; a.zpage = fz.zpage; a.zranges = fz.zranges;
 }
 
 template <class R>
@@ -770,6 +782,58 @@ extern "C" int dspfft_execute_masked_accumulate_f64(dspfft_plan pl, const double
 }
 
 namespace {
+// Sparse frames of the fused scan step: one image, a specialised column pass first and a specialised row pass over the same dense rows
+// second.  The column pass flags the tiles none of whose coefficients belongs to the frame and leaves them alone; the row pass reads
+// zeros there.  At BASELINE config 4 (zigzag, 32 frames) a frame touches about half of the columns.  The 1-D passes commute; a plain
+// plan lists ROW before COL, and a frame of a wide image is sparser in columns than in rows, so the column pass goes first when input
+// and output strides agree (a pass's geometry is built for its place in the list).  Returns false when the plan does not qualify.
+bool sparse_order(const dspfft_plan_s *pl, const std::vector<Pass> &passes, bool split, size_t order[2])
+{
+	order[0] = 0; order[1] = 1;
+	if (passes.size() != 2 || env_int("DSPFFT_NO_ZSKIP") == 1) return false;
+	// measured (tools/bench_scan_step.py): 7680x4320x3 on the split passes 630 -> 513 us per frame; 3840x2160x3 on the plain passes
+	// 119 -> 122 us (the frame lives in the Infinity Cache and the flag lookups cost what the skipped reads save), so plain plans
+	// take part only on request (DSPFFT_ZSKIP=1: the tests of the mechanism on small frames)
+	if (!split && env_int("DSPFFT_ZSKIP") != 1) return false;
+	if (!split && passes[0].type == Pass::ROW && passes[1].type == Pass::COL) {
+		bool same = true;
+		for (int b = 0; b < pl->rank; b++) same = same && pl->axes[b].is == pl->axes[b].os;
+		for (const Dim &b : pl->batches) same = same && b.is == b.os;
+		if (same) { order[0] = 1; order[1] = 0; }
+	}
+	const Pass &PC = passes[order[0]], &PR = passes[order[1]];
+	const bool col_ok = PC.type == Pass::COL && (split ? PC.half : PC.has_spec), row_ok = PR.type == Pass::ROW && (split ? PR.pair : PR.has_spec);
+	const PassGeom &gc = split ? PC.hpa : PC.spa, &gr = PR.spa;
+	const bool ok = col_ok && row_ok && PC.hostloop.empty() && PR.hostloop.empty() && gc.nb0 == 1 && gc.nb1 == 1 && gr.nb1 == 1 && gr.nb0 == gc.N &&
+	                gr.N * gr.C == gc.ninner && gr.sb0_in == gc.ninner && gc.es_in == gc.ninner && gc.es_out == gc.ninner && gc.ninner % gc.K == 0 && (gc.K & (gc.K - 1)) == 0;
+	if (!ok) { order[0] = 0; order[1] = 1; }
+	return ok;
+}
+}  // namespace
+
+extern "C" int dspfft_plan_scan_prepare(dspfft_plan pl, const uint32_t *d_ids, int elems_per_id, void *stream)
+{
+	if (!pl) return fail(-1, "null plan");
+	pl->zr_ids = nullptr;                       // forget what was prepared before
+	if (!d_ids) return 0;
+	if (elems_per_id < 1) return fail(-1, "elems_per_id must be >= 1");
+	const bool split = !pl->split.empty();
+	const std::vector<Pass> &passes = split ? pl->split : pl->passes;
+	size_t order[2];
+	if (!sparse_order(pl, passes, split, order)) return 0;      // nothing to prepare for this plan: executes read every owner id
+	const PassGeom &gc = split ? passes[order[0]].hpa : passes[order[0]].spa;
+	const int halves = split ? 2 : 1;
+	const size_t need = (size_t)2 * halves * gc.ntiles * sizeof(uint32_t);
+	if (pl->zranges_bytes < need) { be_free(pl->zranges); pl->zranges = be_alloc(need); pl->zranges_bytes = pl->zranges ? need : 0; }
+	if (!pl->zranges) return fail(-3, "allocation failed");
+	TileRangeGeom g;
+	g.K = gc.K; g.ntiles = gc.ntiles; g.nrows = gc.N / halves; g.row_start = 0; g.row_step = 1; g.es = gc.es_in; g.div = make_div((uint32_t)elems_per_id);
+	if (be_scan_tile_ranges((uint32_t *)pl->zranges, d_ids, g, halves, stream)) return fail(-4, "launch failed");
+	pl->zr_ids = d_ids; pl->zr_div = elems_per_id; pl->zr_split = split;
+	return 0;
+}
+
+namespace {
 template <class R>
 int execute_masked_accumulate_t(dspfft_plan pl, const R *d_in, R *d_work, R *d_acc, const uint32_t *d_ids, uint32_t id, int elems_per_id, void *stream)
 {
@@ -785,12 +849,35 @@ int execute_masked_accumulate_t(dspfft_plan pl, const R *d_in, R *d_work, R *d_a
 	const size_t np = passes.size();
 	for (const Pass &P : passes)
 		if (!P.hostloop.empty()) return fail(-2, "masked/accumulating execution is not available for plans that need a host-side batch loop");
+	// Sparse frames: one image, a specialised column pass first and a specialised row pass over the same dense rows second.  The
+	// column pass flags the tiles none of whose coefficients belongs to this frame and leaves them alone; the row pass reads zeros
+	// there.  At BASELINE config 4 (zigzag, 32 frames) a frame touches about half of the columns.
+	uint8_t *zflags = nullptr;
+	int zshift = 0, zhalf = 0;
+	const uint32_t *zranges = nullptr;
+	size_t order[2] = {0, 1};
+	if (d_ids && np == 2 && sparse_order(pl, passes, split_ok, order)) {
+		const PassGeom &gc = split_ok ? passes[order[0]].hpa : passes[order[0]].spa;
+		const size_t al = sizeof(R) * 4;
+		if (!((al - 1) & ((uintptr_t)d_in | (uintptr_t)d_work | (uintptr_t)d_acc))) {
+			const size_t need = (size_t)2 * gc.ntiles;
+			if (pl->zflags_bytes < need) { be_free(pl->zflags); pl->zflags = be_alloc(need); pl->zflags_bytes = pl->zflags ? need : 0; }
+			if (!pl->zpage) { pl->zpage = be_alloc(64); if (pl->zpage) { const char z[64] = {0}; if (be_upload(pl->zpage, z, 64)) { be_free(pl->zpage); pl->zpage = nullptr; } } }
+			if (pl->zflags && pl->zpage) {
+				zflags = (uint8_t *)pl->zflags; zhalf = split_ok ? gc.ntiles : 0;
+				while ((1 << zshift) < gc.K) zshift++;
+				if (pl->zranges && pl->zr_ids == (const void *)d_ids && pl->zr_div == elems_per_id && pl->zr_split == split_ok) zranges = (const uint32_t *)pl->zranges;
+			}
+		}
+	}
+	if (!zflags) { order[0] = 0; order[1] = 1; }
 	for (size_t i = 0; i < np; i++) {
-		const Pass &P = passes[i];
+		const Pass &P = passes[np == 2 ? order[i] : i];
 		const bool firstp = i == 0, lastp = i + 1 == np;
 		Fuse fz;
 		if (firstp && d_ids) { fz.mask = d_ids; fz.id = id; fz.div = elems_per_id; }
 		fz.accumulate = lastp;
+		fz.zflags = zflags; fz.zshift = zshift; fz.zhalf = zhalf; fz.zpage = pl->zpage; fz.zranges = zranges;
 		const R *src = firstp ? d_in : d_work;
 		R *dst = lastp ? d_acc : d_work;
 		int rc = run_pass<R>(pl, P, src, dst, lastp, stream, fz);
@@ -1005,6 +1092,7 @@ extern "C" void dspfft_destroy_plan(dspfft_plan pl)
 	if (!pl) return;
 	for (Pass &P : pl->passes) P.tab.release();
 	for (Pass &P : pl->split) P.tab.release();
+	be_free(pl->zflags); be_free(pl->zpage); be_free(pl->zranges);
 	delete pl;
 }
 

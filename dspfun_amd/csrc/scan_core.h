@@ -12,6 +12,7 @@
 #include <math.h>
 #include <stdint.h>
 #include "radix.h"
+#include "dct_core.h"
 
 namespace dspfft {
 
@@ -109,6 +110,17 @@ DSP_HD float scan_magnitude_key(const float *c, int channels, uint64_t y, uint64
 	const double P = 1.41421356237309504880;          // M_SQRT2 = precision.h:130 P_SQRT2i for intermediate = double
 	const double norm = (x ? P : 1.0) * (y ? P : 1.0);
 	return (float)(qfactor != 0.0 ? rint(sum * norm * qfactor / channels) : sum * norm);
+}
+
+// (min, max) owner id over the elements of one column tile (sparse scan frames, PassGeom::zranges); ids of 0xFFFFFFFF (the DC pixel,
+// scan.c:377-383) are no frame's.  Rows row_start, row_start + row_step, ...: a half tile of a split column pass takes every other row.
+struct TileRangeGeom { int K, ntiles, nrows, row_start, row_step; long long es; FastDiv div; };
+DSP_HD void tile_range_item(const TileRangeGeom &g, const uint32_t *ids, int tile, long long item, uint32_t &lo, uint32_t &hi)
+{
+	const long long r = item / g.K;
+	const int j = (int)(item - r * g.K);
+	const uint32_t id = ids[g.div.div((uint32_t)((g.row_start + r * g.row_step) * g.es + (long long)tile * g.K + j))];
+	if (id != 0xFFFFFFFFu) { lo = id < lo ? id : lo; hi = id > hi ? id : hi; }
 }
 
 }  // namespace dspfft

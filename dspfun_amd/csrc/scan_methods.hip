@@ -90,6 +90,32 @@ int be_scan_stamp(uint32_t *ids, const uint32_t *lin, uint64_t n, uint32_t frame
 	HIPCHK(hipGetLastError());
 	return 0;
 }
+__global__ void __launch_bounds__(256) tile_ranges_kernel(uint32_t *ranges, const uint32_t *ids, const TileRangeGeom g0, int halves)
+{
+	TileRangeGeom g = g0;
+	const int half = blockIdx.x / g.ntiles, tile = blockIdx.x - half * g.ntiles;
+	if (halves == 2) { g.row_start = half; g.row_step = 2; }
+	uint32_t lo = 0xFFFFFFFFu, hi = 0;
+	const long long items = (long long)g.nrows * g.K;
+	for (long long it = threadIdx.x; it < items; it += 256) tile_range_item(g, ids, tile, it, lo, hi);
+	for (int off = 32; off > 0; off >>= 1) {
+		const uint32_t l2 = __shfl_xor(lo, off), h2 = __shfl_xor(hi, off);
+		lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi;
+	}
+	__shared__ uint32_t sl[4], sh[4];
+	if ((threadIdx.x & 63) == 0) { sl[threadIdx.x >> 6] = lo; sh[threadIdx.x >> 6] = hi; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		for (int i = 1; i < 4; i++) { lo = sl[i] < lo ? sl[i] : lo; hi = sh[i] > hi ? sh[i] : hi; }
+		ranges[2 * blockIdx.x] = lo; ranges[2 * blockIdx.x + 1] = hi;
+	}
+}
+int be_scan_tile_ranges(uint32_t *ranges, const uint32_t *ids, TileRangeGeom g, int halves, void *stream)
+{
+	hipLaunchKernelGGL(tile_ranges_kernel, dim3(g.ntiles * halves), dim3(256), 0, (hipStream_t)stream, ranges, ids, g, halves);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
 int be_scan_index_to_frame_ids(uint32_t *ids, uint64_t n, uint64_t step, void *stream)
 {
 	hipLaunchKernelGGL(index_to_frame_kernel, dim3(sgrid(n)), dim3(256), 0, (hipStream_t)stream, ids, n, step);

@@ -31,7 +31,9 @@ __global__ void __launch_bounds__(S::T, S::WPE) row_spec_kernel(const typename S
 	typename S::template State<KIND> st;
 	long long bin, bout;
 	row_base(a, blockIdx.x, bin, bout);
-	S::template prefetch<KIND>(a, bin, tid, st);
+	// behind a masked column pass that skipped its empty tiles: this line's tile flags (PassGeom::zflags; one image: line = row)
+	const uint8_t *zf = a.zflags ? a.zflags + (blockIdx.x & 1) * a.zhalf : nullptr;
+	S::template prefetch<KIND>(a, bin, tid, st, nullptr, zf);
 	S::template phase<KIND, 0>(a, planes, bout, tid, st);
 	__syncthreads();
 	static_for<1, S::NPH>([&](auto ph) {
@@ -71,8 +73,21 @@ __global__ void __launch_bounds__(S::T, S::WPE) col_spec_kernel(const typename S
 	const int tid = threadIdx.x;
 	typename S::template State<KIND> st;
 	long long bin, bout;
-	S::base(a, blockIdx.x, bin, bout);
-	S::template prefetch<KIND>(a, bin, tid, st);
+	int tile;
+	bool hit = false;
+	S::base(a, blockIdx.x, bin, bout, tile);
+	// sparse scan frames, prepared owner ids: this frame lies outside the tile's id range -- nothing to read at all
+	if (a.zflags && a.mask && a.zranges && (a.mask_id < a.zranges[2 * tile] || a.mask_id > a.zranges[2 * tile + 1])) {
+		if (tid == 0) a.zflags[tile] = 0;
+		return;
+	}
+	S::template prefetch<KIND>(a, bin, tid, st, hit);
+	// a tile none of whose coefficients belongs to this frame transforms to zeros -- say so and stop
+	if (a.zflags && a.mask) {
+		const int nz = __syncthreads_or(hit);
+		if (tid == 0) a.zflags[tile] = (uint8_t)(nz != 0);
+		if (!nz) return;
+	}
 	S::template phase<KIND, 0>(a, buf, bout, tid, st);
 	__syncthreads();
 	static_for<1, S::NPH>([&](auto ph) {
@@ -109,8 +124,8 @@ __global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_kerne
 	const int y1 = 2 * n, y2 = a.nb0 - 1 - 2 * n;
 	const long long bin1 = y1 * a.sb0_in + i1 * a.sb1_in, bin2 = y2 * a.sb0_in + i1 * a.sb1_in;
 	const long long bout1 = y1 * a.sb0_out + i1 * a.sb1_out, bout2 = y2 * a.sb0_out + i1 * a.sb1_out;
-	S::template prefetch<KIND>(a, bin1, tid, st);              // masked loads when this is the first pass of a fused scan step
-	S::template prefetch<KIND>(a, bin2, tid, st2);
+	S::template prefetch<KIND>(a, bin1, tid, st, nullptr, a.zflags);              // masked loads when this is the first pass of a fused scan step,
+	S::template prefetch<KIND>(a, bin2, tid, st2, nullptr, a.zflags ? a.zflags + a.zhalf : nullptr);   // tile flags when it follows a masked half-tile pass
 	typedef typename S::Re Re;
 	constexpr int NPRE = (int)(sizeof(st.pre) / sizeof(Re));
 	Re cur[NPRE], diff[NPRE];
@@ -141,9 +156,19 @@ __global__ void __launch_bounds__(S::T, S::WPE) col_half_kernel(const typename S
 	const int tid = threadIdx.x;
 	typename S::template State<KIND> st;
 	long long bin, bout;
-	int h;
-	S::base(a, blockIdx.x, bin, bout, h);
-	S::template prefetch<KIND>(a, bin, h, tid, st);
+	int h, tile;
+	bool hit = false;
+	S::base(a, blockIdx.x, bin, bout, h, tile);
+	if (a.zflags && a.mask && a.zranges && (a.mask_id < a.zranges[2 * tile] || a.mask_id > a.zranges[2 * tile + 1])) {   // see col_spec_kernel
+		if (tid == 0) a.zflags[tile] = 0;
+		return;
+	}
+	S::template prefetch<KIND>(a, bin, h, tid, st, hit);
+	if (a.zflags && a.mask) {
+		const int nz = __syncthreads_or(hit);
+		if (tid == 0) a.zflags[tile] = (uint8_t)(nz != 0);
+		if (!nz) return;
+	}
 	static_for<0, S::NPH>([&](auto ph) {
 		S::template phase<KIND, ph>(a, buf, bout, h, tid, st);
 		if constexpr (ph + 1 < S::NPH) __syncthreads();
@@ -183,7 +208,8 @@ __global__ void __launch_bounds__(S::T, rt_waves_per_simd<S>()) col_roundtrip_ke
 	typename S::StateRT st;
 	long long bin, bout;
 	S::base(af, blockIdx.x, bin, bout);
-	S::template prefetch<KIND_REDFT10>(af, bin, tid, st);
+	bool hit = false;
+	S::template prefetch<KIND_REDFT10>(af, bin, tid, st, hit);
 	S::template phase<KIND_REDFT10, 0>(af, buf, bout, tid, st);
 	__syncthreads();
 	// The empty asm statements make the thread index (and, below, the inverse plan's table pointers) opaque at each

@@ -119,6 +119,12 @@ class Plan:
         self._check(run(
             self._h, C.c_void_p(d_in), C.c_void_p(d_work), C.c_void_p(d_acc), C.c_void_p(d_ids or None), frame_id, elems_per_id, C.c_void_p(stream)))
 
+    def scan_prepare(self, d_ids=0, elems_per_id=1, stream=0):
+        """owner ids that stay the same over a scan's frames: record each column tile's id range so that the fused step skips a tile
+        outside the frame without reading its ids (dspfft_plan_scan_prepare); d_ids = 0 forgets"""
+        self._check(self._lib.dspfft_plan_scan_prepare(self._h, C.c_void_p(d_ids or None), elems_per_id, C.c_void_p(stream)))
+        return self
+
     @staticmethod
     def _filter_params(filter):
         if filter is None:

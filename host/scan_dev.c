@@ -95,6 +95,8 @@ int main(int argc, char *argv[])
 		HIP(hipMemset(d_ids, 0xff, npix * 4));
 	} else if (method >= 0) DSP(dspfft_scan_frame_ids(d_ids, method, w, h, step, NULL));
 	else DSP(dspfft_scan_index_to_frame_ids(d_ids, npix, step, NULL));                            /* magnitude / file: index -> frame */
+	/* owner ids that stay put over the frames: let the fused step skip the column tiles a frame does not touch (box restamps its ids) */
+	if (!per_frame_lists) DSP(dspfft_plan_scan_prepare(inv, d_ids, channels, NULL));
 
 	DSP(dspfft_broadcast_dc(d_sum, d_coeffs, npix, channels, NULL));                              /* scan.c:377-383 */
 	uint32_t *h_lin = per_frame_lists && method < 0 ? malloc((size_t)step * (slots ? slots : 1) * 4) : NULL;

@@ -81,6 +81,11 @@ int dspfft_plan_many_r2r_f64(dspfft_plan *plan, int rank, const int *n, int howm
 int dspfft_plan_set_scale_f64(dspfft_plan plan, double scale);
 int dspfft_plan_set_axis_scale0_f64(dspfft_plan plan, int axis, double in_scale0, double out_scale0);
 int dspfft_execute_f64(dspfft_plan plan, const double *d_in, double *d_out, void *hip_stream);
+/* Optional, for owner ids that stay the same over the frames of a scan (every method but box, whose ids are stamped per frame):
+ * records the (min, max) owner id of every column tile of `plan`, so that a later dspfft_execute_masked_accumulate with the SAME
+ * d_ids pointer and elems_per_id leaves a tile alone -- without reading its owner ids -- when `id` lies outside its range.  Call it
+ * again after rewriting the ids; d_ids = NULL forgets.  Results are the same with or without it. */
+int dspfft_plan_scan_prepare(dspfft_plan plan, const uint32_t *d_ids, int elems_per_id, void *hip_stream);
 int dspfft_execute_masked_accumulate_f64(dspfft_plan plan, const double *d_in, double *d_work, double *d_acc,
                                          const uint32_t *d_ids, uint32_t id, int elems_per_id, void *hip_stream);
 

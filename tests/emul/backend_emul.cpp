@@ -163,7 +163,8 @@ int launch_row_spec(const typename S::PA &a, int nwork, void *)
 		std::vector<typename S::template State<KIND>> st(S::T);
 		long long bin, bout;
 		row_base(a, wg, bin, bout);
-		for (int tid = 0; tid < S::T; tid++) S::template prefetch<KIND>(a, bin, tid, st[tid]);
+		const uint8_t *zf = a.zflags ? a.zflags + (wg & 1) * a.zhalf : nullptr;
+		for (int tid = 0; tid < S::T; tid++) S::template prefetch<KIND>(a, bin, tid, st[tid], nullptr, zf);
 		static_for<0, S::NPH>([&](auto ph) { for (int tid = 0; tid < S::T; tid++) S::template phase<KIND, ph>(a, planes, bout, tid, st[tid]); });
 	}
 	return 0;
@@ -176,8 +177,12 @@ int launch_col_spec(const typename S::PA &a, int nwork, void *)
 	for (int wg = 0; wg < nwork; wg++) {
 		std::vector<typename S::template State<KIND>> st(S::T);
 		long long bin, bout;
-		S::base(a, wg, bin, bout);
-		for (int tid = 0; tid < S::T; tid++) S::template prefetch<KIND>(a, bin, tid, st[tid]);
+		int tile;
+		bool hit = false;
+		S::base(a, wg, bin, bout, tile);
+		if (a.zflags && a.mask && a.zranges && (a.mask_id < a.zranges[2 * tile] || a.mask_id > a.zranges[2 * tile + 1])) { a.zflags[tile] = 0; continue; }
+		for (int tid = 0; tid < S::T; tid++) S::template prefetch<KIND>(a, bin, tid, st[tid], hit);
+		if (a.zflags && a.mask) { a.zflags[tile] = hit; if (!hit) continue; }
 		static_for<0, S::NPH>([&](auto ph) { for (int tid = 0; tid < S::T; tid++) S::template phase<KIND, ph>(a, buf, bout, tid, st[tid]); });
 	}
 	return 0;
@@ -211,8 +216,8 @@ int launch_row_pair(const PassArgs &a, int npairs, void *)
 		constexpr int NPRE = (int)(sizeof(st[0].pre) / sizeof(float));
 		for (int tid = 0; tid < S::T; tid++) {
 			for (int i = 0; i < NPRE; i++) st[tid].pre[i] = st2[tid].pre[i] = 0.f;
-			S::template prefetch<KIND>(a, bin1, tid, st[tid]);
-			S::template prefetch<KIND>(a, bin2, tid, st2[tid]);
+			S::template prefetch<KIND>(a, bin1, tid, st[tid], nullptr, a.zflags);
+			S::template prefetch<KIND>(a, bin2, tid, st2[tid], nullptr, a.zflags ? a.zflags + a.zhalf : nullptr);
 			for (int i = 0; i < NPRE; i++) { const float p = st[tid].pre[i], q = st2[tid].pre[i]; st[tid].pre[i] = p + q; st2[tid].pre[i] = p - q; }
 		}
 		typedef typename S::template State<KIND> ST;
@@ -229,9 +234,12 @@ int launch_col_half(const PassArgs &a, int nwork, void *)
 	typename S::V *buf = (typename S::V *)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
 	for (int wg = 0; wg < nwork; wg++) {
 		std::vector<typename S::template State<KIND>> st(S::T);
-		long long bin, bout; int h;
-		S::base(a, wg, bin, bout, h);
-		for (int tid = 0; tid < S::T; tid++) S::template prefetch<KIND>(a, bin, h, tid, st[tid]);
+		long long bin, bout; int h, tile;
+		bool hit = false;
+		S::base(a, wg, bin, bout, h, tile);
+		if (a.zflags && a.mask && a.zranges && (a.mask_id < a.zranges[2 * tile] || a.mask_id > a.zranges[2 * tile + 1])) { a.zflags[tile] = 0; continue; }
+		for (int tid = 0; tid < S::T; tid++) S::template prefetch<KIND>(a, bin, h, tid, st[tid], hit);
+		if (a.zflags && a.mask) { a.zflags[tile] = hit; if (!hit) continue; }
 		static_for<0, S::NPH>([&](auto ph) { for (int tid = 0; tid < S::T; tid++) S::template phase<KIND, ph>(a, buf, bout, h, tid, st[tid]); });
 	}
 	return 0;
@@ -305,6 +313,18 @@ int be_scan_coords(uint32_t *lin, int method, uint32_t w, uint32_t h, uint64_t f
 int be_scan_stamp(uint32_t *ids, const uint32_t *lin, uint64_t n, uint32_t frame, void *)
 {
 	for (uint64_t t = 0; t < n; t++) if (lin[t] != SCAN_NONE && lin[t] != 0) ids[lin[t]] = frame;
+	return 0;
+}
+int be_scan_tile_ranges(uint32_t *ranges, const uint32_t *ids, TileRangeGeom g0, int halves, void *)
+{
+	for (int b = 0; b < g0.ntiles * halves; b++) {
+		TileRangeGeom g = g0;
+		const int half = b / g.ntiles, tile = b - half * g.ntiles;
+		if (halves == 2) { g.row_start = half; g.row_step = 2; }
+		uint32_t lo = 0xFFFFFFFFu, hi = 0;
+		for (long long it = 0; it < (long long)g.nrows * g.K; it++) tile_range_item(g, ids, tile, it, lo, hi);
+		ranges[2 * b] = lo; ranges[2 * b + 1] = hi;
+	}
 	return 0;
 }
 int be_scan_index_to_frame_ids(uint32_t *ids, uint64_t n, uint64_t step, void *)

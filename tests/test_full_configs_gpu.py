@@ -69,8 +69,12 @@ def test_c4_full_workload_8k_step_2pow20(gpu):
     assert np.abs(got - cf64).max() <= 1e-5 * np.abs(cf64).max()
     del got
     ref = np.ascontiguousarray(np.broadcast_to(cf64[0, 0], (h, w, c)).copy())
+    inv.scan_prepare(ids.data_ptr(), c)
+    skipped = []
     for f in range(nframes):
+        work.fill_(float("nan"))       # tiles the masked column pass skips (no coefficient of this frame) must not be read back
         inv.execute_masked_accumulate(coeffs.data_ptr(), work.data_ptr(), acc.data_ptr(), ids.data_ptr(), f, c)
+        skipped.append(float(gpu.isnan(work).float().mean()))
         if f < 2:
             rec = np.where((frame_of.reshape(h, w) == f)[:, :, None], cf64, 0.0)
             ref += ol.dct2d_interleaved(rec, REDFT01, impl="port", threads=thr)
@@ -79,6 +83,44 @@ def test_c4_full_workload_8k_step_2pow20(gpu):
             assert np.abs(acc.cpu().numpy() - ref).max() < 5e-6, f
     gpu.cuda.synchronize()
     assert float((acc.cpu() - gpu.from_numpy(x)).abs().max()) <= 5e-6
+    # zigzag frames of a 16:9 image: the first touches 19 % of the columns, the middle ones 59 %
+    assert skipped[0] > 0.7 and 0.3 < float(np.mean(skipped)) < 0.7, skipped
+
+
+@pytest.mark.parametrize("w,h", [(3840, 2160), (1920, 1080)])
+def test_sparse_frames_skip_matches_dense(gpu, w, h, monkeypatch):
+    """the fused scan step with and without the empty-tile skip (DSPFFT_NO_ZSKIP=1), zigzag, 9 frames"""
+    from dspfun_amd import Plan, _lib, REDFT10, REDFT01
+    L = _lib.load()
+    monkeypatch.setenv("DSPFFT_ZSKIP", "1")           # plain plans (no column split at these sizes) take part on request only
+    c, nframes = 3, 9
+    x = ol.synth_f32(w + h, w * h * c).reshape(h, w, c)
+    coeffs = gpu.from_numpy(x).to("cuda:0")
+    Plan.image(h, w, c, REDFT10).set_scale(1.0 / (4.0 * w * h)).execute(coeffs.data_ptr())
+    ids = gpu.zeros(w * h, dtype=gpu.int32, device="cuda:0")
+    assert L.dspfft_scan_zigzag_frame_ids(ids.data_ptr(), w, h, (w * h + nframes - 1) // nframes, None) == 0
+    inv = Plan.image(h, w, c, REDFT01)
+    out = {}
+    for skip in (True, False, "prepared"):
+        if skip:
+            monkeypatch.delenv("DSPFFT_NO_ZSKIP", raising=False)
+        else:
+            monkeypatch.setenv("DSPFFT_NO_ZSKIP", "1")
+        inv.scan_prepare(ids.data_ptr() if skip == "prepared" else 0, c)
+        acc = gpu.empty_like(coeffs); work = gpu.empty_like(coeffs)
+        assert L.dspfft_broadcast_dc(acc.data_ptr(), coeffs.data_ptr(), w * h, c, None) == 0
+        sums = []
+        for f in range(nframes):
+            work.fill_(float("nan"))
+            inv.execute_masked_accumulate(coeffs.data_ptr(), work.data_ptr(), acc.data_ptr(), ids.data_ptr(), f, c)
+            sums.append(acc.clone())
+        out[skip] = sums
+        gpu.cuda.synchronize()
+        assert (float(gpu.isnan(work).float().mean()) > 0.2) == bool(skip)     # the last frame: the far corner of the spectrum
+    for a, b, p in zip(out[True], out[False], out["prepared"]):
+        assert float((a - b).abs().max()) < 2e-6
+        assert gpu.equal(a, p)
+    assert float((out[True][-1].cpu() - gpu.from_numpy(x)).abs().max()) <= 5e-6
 
 
 def _plans3d(d, h, w):

@@ -115,3 +115,62 @@ def test_forced_split_carries_the_fused_scan_step(forced):
         inv_plain.execute_masked_accumulate(coeffs.ctypes.data, work.ctypes.data, acc2.ctypes.data, ids.ctypes.data, f, c)
         assert np.abs(acc - acc2).max() < 2e-6, f
     assert np.abs(acc - x).max() <= 5e-6
+
+
+# ---- sparse scan frames: the masked column pass skips tiles without selected coefficients, the row pass reads zeros there ----
+@pytest.mark.parametrize("force_split", [False, True])
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_masked_accumulate_skips_empty_tiles(force_split, dtype, monkeypatch):
+    import ctypes as C
+    h, w, c = 512, 512, 3
+    if force_split and dtype == "f64":
+        pytest.skip("double plans have no column split")
+    if force_split:
+        monkeypatch.setenv("DSPFFT_FORCE_SPLIT", "1")
+    else:
+        monkeypatch.setenv("DSPFFT_ZSKIP", "1")       # plain plans take part on request only
+    L = emul()
+    npdt = np.float32 if dtype == "f32" else np.float64
+    x = ol.synth_f32(4242, h * w * c).astype(npdt).reshape(h, w, c)
+    coeffs = x.copy()
+    Plan.image(h, w, c, REDFT10, lib=L, dtype=dtype).set_scale(1.0 / (4 * w * h)).execute(coeffs.ctypes.data)
+    nframes = 7
+    ids = np.zeros(h * w, dtype=np.uint32)
+    assert L.dspfft_scan_zigzag_frame_ids(ids.ctypes.data, w, h, (h * w + nframes - 1) // nframes, None) == 0
+
+    def aligned(shape):          # the double kernels move 32-byte lane vectors
+        raw = np.empty(int(np.prod(shape)) * np.dtype(npdt).itemsize + 64, dtype=np.uint8)
+        o = (-raw.ctypes.data) % 64
+        return raw[o:o + int(np.prod(shape)) * np.dtype(npdt).itemsize].view(npdt).reshape(shape)
+    cal = aligned(coeffs.shape); cal[...] = coeffs; coeffs = cal
+
+    def run(skip, prepare=False):
+        if skip:
+            monkeypatch.delenv("DSPFFT_NO_ZSKIP", raising=False)
+        else:
+            monkeypatch.setenv("DSPFFT_NO_ZSKIP", "1")
+        inv = Plan.image(h, w, c, REDFT01, lib=L, dtype=dtype)
+        if prepare:
+            inv.scan_prepare(ids.ctypes.data, c)
+        assert ("ROW*2" in inv.describe()) == force_split
+        acc = aligned((h, w, c)); acc[...] = coeffs[0, 0]
+        work = aligned((h, w, c))
+        sums = []
+        for f in range(nframes):
+            work[...] = np.nan            # a skipped tile must not be read back
+            inv.execute_masked_accumulate(coeffs.ctypes.data, work.ctypes.data, acc.ctypes.data, ids.ctypes.data, f, c)
+            sums.append(acc.copy())
+            if skip and f in (0, nframes - 1):
+                # the first and the last zigzag frame touch a corner of the spectrum only: most column tiles stayed untouched
+                assert np.isnan(work).mean() > 0.3
+        return sums
+    a, b, p = run(True), run(False), run(True, prepare=True)
+    for sa, sp in zip(a, p):
+        assert np.array_equal(sa, sp)              # prepared id ranges only decide earlier what the kernel finds out anyway
+    for sa, sb in zip(a, b):
+        if force_split:
+            assert np.array_equal(sa, sb)          # same passes in the same order: skipping a tile of zeros changes nothing
+        else:
+            # the plain plan runs its column pass first when it skips (the passes commute): equal to rounding
+            assert np.abs(sa - sb).max() < (2e-6 if dtype == "f32" else 1e-14)
+    assert np.abs(a[-1] - x).max() < (2e-5 if dtype == "f32" else 1e-12)

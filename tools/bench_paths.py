@@ -41,6 +41,7 @@ ids = torch.zeros(w * h, dtype=torch.int32, device=dev)
 step = 1 << 20
 nframes = (w * h + step - 1) // step
 L.dspfft_scan_zigzag_frame_ids(ids.data_ptr(), w, h, step, None)
+inv.scan_prepare(ids.data_ptr(), c)          # as host/scan_dev.c does for owner ids that stay the same over the frames
 acc = torch.empty_like(coeffs); work = torch.empty_like(coeffs); recon = torch.empty_like(coeffs); image = torch.empty_like(coeffs)
 order = torch.zeros(w * h, dtype=torch.int32, device=dev)
 L.dspfft_scan_zigzag(order.data_ptr(), w, h, 0, w * h, None)

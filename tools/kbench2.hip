@@ -18,6 +18,12 @@ using namespace dspfft;
 #define STAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define RSTAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
+// -DNOSYNC drops the barriers between the LDS phases (wrong results): an upper bound on what decoupling the waves of a workgroup could buy
+#ifdef NOSYNC
+#define STAGE_SYNC() ((void)0)
+#else
+#define STAGE_SYNC() __syncthreads()
+#endif
 constexpr int MAXST = 12;
 struct WgStamps { unsigned long long t[MAXST]; unsigned long long r0, r1; unsigned xcc, cu; };
 
@@ -39,7 +45,7 @@ __global__ void __launch_bounds__(S::T, S::WPE) pass_k(const PassArgs a, WgStamp
 	if constexpr (STAMPS) STAMP(ts[2]);
 	static_for<1, S::NPH>([&](auto ph) {
 		S::template phase<KIND, ph>(a, buf, bout, tid, st);
-		if constexpr (ph + 1 < S::NPH) __syncthreads();
+		if constexpr (ph + 1 < S::NPH) STAGE_SYNC();
 		if constexpr (STAMPS) STAMP(ts[2 + ph]);
 	});
 	if constexpr (STAMPS) {
