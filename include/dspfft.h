@@ -170,7 +170,10 @@ int dspfft_scan_scatter(float *d_recon, const float *d_coeffs, const uint32_t *d
  * The first pass masks while loading (no zeroed `reconstruction` buffer, no scatter), the last pass
  * adds into d_acc while storing (no `image` buffer, no separate sum pass): 21.3 B/sample of traffic for
  * a 3-channel image instead of 32.  d_work: scratch with the plan's output layout.  d_ids == NULL
- * disables masking.  elems_per_id = channels for the image tools' interleaved buffers. */
+ * disables masking.  elems_per_id = channels for the image tools' interleaved buffers.
+ * Plans with split column passes (8K-class frames) skip the column tiles none of whose coefficients belongs to `id` and keep
+ * per-tile flags for the row pass in scratch owned by the plan: run one fused step per plan at a time (concurrent streams take
+ * one plan each); d_work then holds garbage in the skipped tiles, as scratch may. */
 int dspfft_execute_masked_accumulate(dspfft_plan plan, const float *d_in, float *d_work, float *d_acc,
                                      const uint32_t *d_ids, uint32_t id, int elems_per_id, void *hip_stream);
 
