@@ -169,6 +169,28 @@ static void run(const char *name)
 		for (int i = 0; i < q; i++) { s0 += v[i].second; s1 += v[q + i].second; s2 += v[2 * q + i].second; s3 += v[3 * q + i].second; }
 		printf("    mean life by start-time quartile: %.2f %.2f %.2f %.2f us\n", s0 / q, s1 / q, s2 / q, s3 / q);
 	}
+	// XCD placement (dct_spec.h xcd_remap assumes workgroups b and b + 8 share an XCD): alone, and with the same kernel running on a
+	// second stream at the same time
+	{
+		auto consistent = [&](const std::vector<WgStamps> &v) { int ok = 0; for (int b = 0; b < nwork; b++) ok += v[b].xcc == v[b & 7].xcc; return 100.0 * ok / nwork; };
+		printf("    XCC of workgroups 0..7: %u %u %u %u %u %u %u %u; workgroups on the XCC of (id mod 8): alone %.1f %%", h[0].xcc, h[1].xcc, h[2].xcc, h[3].xcc, h[4].xcc, h[5].xcc, h[6].xcc, h[7].xcc, consistent(h));
+		static hipStream_t s1 = nullptr, s2 = nullptr;
+		if (!s1) { CHK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)); CHK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking)); }
+		PassArgs b2 = a; b2.in = b2.out = g_buf + NF;
+		CHK(hipDeviceSynchronize());
+		for (int i = 0; i < 2; i++) {
+			hipLaunchKernelGGL(kern_s, dim3(nwork), dim3(S::T), S::LDS, s1, a, g_dbg);
+			hipLaunchKernelGGL(kern_s, dim3(nwork), dim3(S::T), S::LDS, s2, b2, g_dbg + 4096);
+		}
+		CHK(hipDeviceSynchronize());
+		std::vector<WgStamps> ha(nwork), hb(nwork);
+		CHK(hipMemcpy(ha.data(), g_dbg, sizeof(WgStamps) * nwork, hipMemcpyDeviceToHost));
+		CHK(hipMemcpy(hb.data(), g_dbg + 4096, sizeof(WgStamps) * nwork, hipMemcpyDeviceToHost));
+		unsigned long long a0 = ~0ull, a1 = 0, b0 = ~0ull, b1 = 0;
+		for (int i = 0; i < nwork; i++) { a0 = std::min(a0, ha[i].r0); a1 = std::max(a1, ha[i].r1); b0 = std::min(b0, hb[i].r0); b1 = std::max(b1, hb[i].r1); }
+		const double ov = ((double)std::min(a1, b1) - (double)std::max(a0, b0)) / 100.0;
+		printf(", two streams (overlapping %.0f of %.0f us) %.1f %% and %.1f %%\n", ov > 0 ? ov : 0.0, (double)(a1 - a0) / 100.0, consistent(ha), consistent(hb));
+	}
 	fflush(stdout);
 }
 
