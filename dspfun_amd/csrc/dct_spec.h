@@ -807,13 +807,35 @@ struct ColHalfSpecT {
 		bout = i0 * a.sb0_out + i1 * a.sb1_out + (long long)t * K;
 	}
 
+	template <int KIND, class ST>
+	static DSP_HD void prefetch_tw(const PA &a, int h, int tid, ST &st)
+	{
+		if constexpr (KIND == KIND_REDFT10) {
+			if (h) static_for<0, Y_ROUNDS>([&](auto i) {
+				const int it = tid + i * T;
+				if ((i + 1) * T <= M * NP || it < M * NP) st.hw[i] = a.H[it / NP];
+			});
+		} else {
+			static_for<0, Q_ROUNDS>([&](auto i) {
+				const int it = tid + i * T;
+				if ((i + 1) * T <= NQ || it < NQ) {
+					const int q = it / NP;
+					if (h && q >= M / 2) return;
+					st.tw[i] = a.T[2 * q + h];
+				}
+			});
+		}
+	}
+
 	// the fused scan step masks the first pass's loads (loadv_m) and adds in the last pass's stores (storev_a), as in ColSpec
 	template <int KIND, class ST>
 	static DSP_HD void prefetch(const PA &a, long long bin, int h, int tid, ST &st, bool &hit)
 	{
 		if (a.mask) prefetch_m<KIND, true>(a, bin, h, tid, st, hit); else prefetch_m<KIND, false>(a, bin, h, tid, st, hit);
 	}
-	template <int KIND, bool MASKED, class ST>
+	// WITH_TW = false leaves the twiddles of the tile (hw / tw) to prefetch_tw: the persistent kernel fetches them late, so that only
+	// the rows of the next tile occupy registers during the butterfly stages
+	template <int KIND, bool MASKED, class ST, bool WITH_TW = true>
 	static DSP_HD void prefetch_m(const PA &a, long long bin, int h, int tid, ST &st, bool &hit)
 	{
 		if constexpr (KIND == KIND_REDFT10) {
@@ -826,10 +848,7 @@ struct ColHalfSpecT {
 			});
 			// half 1: the twiddles w^n of this thread's rows, fetched behind the data so their latency hides under it (rows n .. n + T/NP
 			// apart share nothing, but the 8.6 KB table stays in L1/L2)
-			if (h) static_for<0, Y_ROUNDS>([&](auto i) {
-				const int it = tid + i * T;
-				if ((i + 1) * T <= M * NP || it < M * NP) st.hw[i] = a.H[it / NP];
-			});
+			if constexpr (WITH_TW) prefetch_tw<KIND>(a, h, tid, st);
 		} else {
 			static_for<0, Q_ROUNDS>([&](auto i) {
 				const int it = tid + i * T;
@@ -837,7 +856,7 @@ struct ColHalfSpecT {
 					const int q = it / NP, jp = it - q * NP;
 					if (h && q >= M / 2) return;
 					const int k = 2 * q + h, km = k ? N - k : 0;
-					st.tw[i] = a.T[k];
+					if constexpr (WITH_TW) st.tw[i] = a.T[k];
 					const long long p = bin + VW * jp;
 					st.pre[2 * i] = B::g_get(loadv_m<MASKED, Re>(a, p + (long long)k * a.es_in, hit));
 					st.pre[2 * i + 1] = B::g_get(loadv_m<MASKED, Re>(a, p + (long long)km * a.es_in, hit));

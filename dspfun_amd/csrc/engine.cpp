@@ -586,7 +586,9 @@ void build_split(dspfft_plan_s *pl)
 	// (1080 x 16 floats, 64-B row segments: column passes 42-45 us instead of 46-49) but the paired row pass loses more than that
 	// (2 rows per workgroup in sequence, 2 workgroups per CU: 52-55 us instead of 37-39) -- 58.3K vs 58.6K Mpix/s on two streams,
 	// 41.4K vs 48.9K on one (tools/sbench.hip, tools/bench_8k_split.py; profiles/r02_split.txt) -- so 4K keeps the plain passes.
-	if (!force && !(Cc->spec.lds > 80 * 1024 && 2 * hs.lds <= Cc->spec.lds + 4096)) return;
+	// The half tile may also take the whole LDS again with twice the width (4320: 2160 rows x 16 floats): an 8K frame does not fit the
+	// Infinity Cache, and HBM serves 64-byte row segments so much better than 32-byte ones that one workgroup per CU wins (882 vs 922 us).
+	if (!force && !(Cc->spec.lds > 80 * 1024 && hs.lds <= Cc->spec.lds + 4096)) return;
 	const int pid = be_find_row_pair(R->pa.N, R->pa.C);
 	if (pid < 0) return;
 	const bool col_first = pl->kinds[ca] == DSPFFT_REDFT01;

@@ -54,6 +54,7 @@
 // exist for the CPU/GPU tests of the mechanism on small frames (DSPFFT_FORCE_SPLIT=1).
 #define DSPFFT_COL_HALF_SPECS(X) \
 	X(2160, 16, 512, 8, 9, 15) \
+	X(4320, 16, 1024, 12, 12, 15) /* an 8K frame lives in HBM, where 64-byte row segments beat two workgroups per CU: 882 vs 922 us per roundtrip */ \
 	X(4320, 8, 512, 12, 12, 15) \
 	X(1080, 16, 256, 4, 9, 15)   /* forced only */ \
 	X(512, 16, 256, 4, 4, 16)    /* forced only */

@@ -85,7 +85,7 @@ def test_split_is_not_used_where_it_does_not_apply():
     # 4K: wider half tiles exist but measured no faster with the paired row pass (engine.cpp build_split): plain passes
     assert "COL*/2" not in Plan.image(2160, 3840, 3, REDFT10, lib=emul()).describe()
     d = Plan.image(4320, 7680, 3, REDFT01, lib=emul()).describe()
-    assert d.splitlines()[1].startswith("axis 0: COL*/2 N=4320 as 2 x 2160, K=8")
+    assert d.splitlines()[1].startswith("axis 0: COL*/2 N=4320 as 2 x 2160, K=16")
 
 
 def test_forced_split_carries_the_fused_scan_step(forced):

@@ -94,7 +94,7 @@ def test_8k_split_roundtrip_and_plain_agreement(gpu):
     x = ol.synth_f32(0xD5F0004, h * w * c).reshape(h, w, c)
     fwd, inv = plans(h, w, c)
     pf, _ = plans(h, w, c, {"DSPFFT_NO_SPLIT": "1"})
-    assert "COL*/2 N=4320 as 2 x 2160, K=8" in fwd.describe()
+    assert "COL*/2 N=4320 as 2 x 2160, K=16" in fwd.describe()
     a, b = dev(gpu, x), dev(gpu, x)
     fwd.execute(a.data_ptr())
     pf.execute(b.data_ptr())
