@@ -7,9 +7,11 @@
 //        lane, e.g. global_load_dwordx3 for the image tools' RGB buffers: 64 lanes x 12 B = 768 B
 //        contiguous per wave instruction); there is no raw staging copy of the line, so a
 //        3840x3 line needs 46 KB of LDS instead of 92 KB and three workgroups fit on a CU.
-//   COL  each lane moves float4 = two complex columns; LDS rows are [n][K/2] complex; the last radix
-//        is odd so the final stage's strided ds_read_b128 are bank-conflict free; workgroup -> tile
-//        mapping is XCD-aware (tiles that share 128-B lines run on the same XCD's L2).
+//   COL  each lane moves 16 bytes = four adjacent float columns = two complex signals (double: two columns, one signal) and
+//        carries the pair through the butterflies as ONE complex number over Pk2 (packed FP32: v_pk_fma_f32 ...); LDS rows
+//        are [n][K/2] complex; the last radix is odd so the final stage's strided ds_read_b128 are bank-conflict free;
+//        workgroup -> tile mapping is XCD-aware (tiles that share 128-B lines run on the same XCD's L2).
+// Everything is a template over the sample type: float (the image tools) and double (the fftw_ API of spec / zoom's default build).
 // Phases are barrier-separated and numbered 0 .. NS+1 (load/pre, NS FFT stages, post/unpack).
 #pragma once
 #include "dct_core.h"
