@@ -7,6 +7,7 @@
 #include "motion_filter.h"
 #include "dct_spec.h"
 #include "scan_core.h"
+#include "block_core.h"
 
 namespace dspfft {
 
@@ -35,6 +36,12 @@ int be_launch_tiny(const TinyArgsD &a, void *stream);
 // COL pass with the tile's DFT done by Bluestein's convolution (lengths with prime factors > 13)
 int be_launch_blue(const BlueArgs &a, const LaunchGeom &g, void *stream);
 int be_launch_blue(const BlueArgsD &a, const LaunchGeom &g, void *stream);
+
+// small blocks transformed along all their axes in one pass (block_core.h); nwg workgroups of BLOCK_THREADS, `lds` bytes each
+bool be_block_supported(int nx, int ny, int nz);
+int be_launch_block(const BlockArgs &a, int nwg, size_t lds, void *stream);
+// forward -> filter -> inverse of every block in one pass, float or 8-bit samples at either end
+int be_launch_block_roundtrip(const BlockRtArgs &a, int nwg, size_t lds, void *stream);
 
 // compile-time-specialised kernels (dct_spec.h / spec_list.h)
 struct SpecInfo { int id, nthr, P; size_t lds; };   // P = C (ROW) or K (COL)

@@ -154,6 +154,14 @@ struct dspfft_plan_s {
 	std::vector<Pass> passes;
 	std::vector<Pass> split;   // alternative pass list of dspfft_execute / dspfft_execute_pass (build_split); empty when not applicable
 	int split_col_axis = -1;
+	// small blocks: all axes in one pass (block_core.h, build_block); used by dspfft_execute on 16-byte aligned buffers
+	bool has_block = false;
+	BlockGeom blk;
+	int blk_kind = 0;
+	int blk_axis[3];           // plan axis behind the block's x, y, z
+	int blk_nwg = 0;
+	size_t blk_lds = 0;
+	std::string blk_desc;
 	size_t alg_bytes;
 	// sparse scan frames (PassGeom::zflags): per-tile flags of the masked column pass + a page of zeros, allocated on first use
 	void *zflags = nullptr;
@@ -624,6 +632,92 @@ void build_split(dspfft_plan_s *pl)
 }
 
 // which pass list an execution uses: the split one unless the buffers or the plan's per-index scales rule it out
+// Blocks of 4, 8 or 16 samples a side (motion's --blocksize 8x8x8 and the like): one pass over the data instead of one per axis
+// (block_core.h).  Needs the x axis contiguous, a batch dimension to take a workgroup's blocks from (the blocks of a row of blocks in
+// a [D][H][W] volume, or whole blocks of a block-major stack) and 16-byte aligned strides.
+void build_block(dspfft_plan_s *pl)
+{
+	if (pl->f64 || pl->rank < 2 || env_int("DSPFFT_NO_BLOCK") == 1) return;
+	for (const Pass &P : pl->passes) if (P.type != Pass::TINY || !P.hostloop.empty()) return;
+	for (int a = 1; a < pl->rank; a++) if (pl->kinds[a] != pl->kinds[0]) return;
+	int ax = -1;
+	for (int a = 0; a < pl->rank; a++) if (pl->axes[a].is == 1 && pl->axes[a].os == 1) ax = a;
+	if (ax < 0) return;
+	std::vector<int> rest;
+	for (int a = 0; a < pl->rank; a++) if (a != ax) rest.push_back(a);
+	std::sort(rest.begin(), rest.end(), [&](int p, int q) { return pl->axes[p].is < pl->axes[q].is; });
+	const int ay = rest[0], az = rest.size() > 1 ? rest[1] : -1;
+	const int nx = pl->n[ax], ny = pl->n[ay], nz = az >= 0 ? pl->n[az] : 1;
+	if (!be_block_supported(nx, ny, nz)) return;
+	// the dimension a workgroup takes its G blocks from: the batch dimension of smallest stride
+	std::vector<Dim> dims;
+	for (const Dim &b : pl->batches) if (b.n > 1) dims.push_back(b);
+	if (dims.empty()) return;
+	size_t gi = 0;
+	for (size_t i = 1; i < dims.size(); i++) if (dims[i].is < dims[gi].is) gi = i;
+	const Dim grp = dims[gi];
+	dims.erase(dims.begin() + gi);
+	merge_dims(dims);
+	if (dims.size() > BLOCK_MAX_DIMS) return;
+	bool aligned = grp.is % 4 == 0 && grp.os % 4 == 0 && pl->axes[ay].is % 4 == 0 && pl->axes[ay].os % 4 == 0 &&
+	               (az < 0 || (pl->axes[az].is % 4 == 0 && pl->axes[az].os % 4 == 0));
+	long long nrest = 1;
+	for (const Dim &d : dims) { aligned = aligned && d.is % 4 == 0 && d.os % 4 == 0; nrest *= d.n; }
+	if (!aligned) return;
+	BlockGeom &g = pl->blk;
+	memset(&g, 0, sizeof g);
+	g.nx = nx; g.ny = ny; g.nz = nz; pl->blk_kind = pl->kinds[0] == DSPFFT_REDFT10 ? KIND_REDFT10 : KIND_REDFT01;
+	g.sy_in = pl->axes[ay].is; g.sy_out = pl->axes[ay].os; g.sz_in = az >= 0 ? pl->axes[az].is : 0; g.sz_out = az >= 0 ? pl->axes[az].os : 0;
+	g.sxb_in = grp.is; g.sxb_out = grp.os;
+	g.rows_fast = !(grp.is == nx && grp.os == nx);
+	// tiles of about 4096 samples = 16 KB (measured on 1920x1080x256, tools/bench_blocks.py: 8x8x8 blocks 2.44 ms per roundtrip with 64 KB
+	// tiles, 1.77 ms with 16 KB ones -- eight and more workgroups per CU), rows of at most 1 KB
+	int G = std::min(256 / nx, 4096 / (nx * ny * nz));
+	if (env_int("DSPFFT_BLOCK_G")) G = env_int("DSPFFT_BLOCK_G");      // experiments (tools/bench_blocks.py)
+	G = std::max(1, std::min(G, grp.n));
+	if ((size_t)nz * ny * G * nx * sizeof(float) > 64 * 1024) return;
+	g.G = G; g.nxb = grp.n; g.ngroups = (grp.n + G - 1) / G; g.pitch = G * nx; g.gdiv = make_div((uint32_t)g.ngroups);
+	g.nd = (int)dims.size();
+	for (int d = 0; d < g.nd; d++) { g.bn[d] = dims[d].n; g.bis[d] = dims[d].is; g.bos[d] = dims[d].os; g.bdiv[d] = make_div((uint32_t)dims[d].n); }
+	const long long nwg = (long long)g.ngroups * nrest;
+	if (nwg > 0x7fffffffLL) return;
+	pl->blk_nwg = (int)nwg; pl->blk_lds = (size_t)nz * ny * g.pitch * sizeof(float);
+	pl->blk_axis[0] = ax; pl->blk_axis[1] = ay; pl->blk_axis[2] = az;
+	char buf[256];
+	snprintf(buf, sizeof buf, "axes %d,%d%s: BLOCK %dx%dx%d (x,y,z) all axes in one pass, %d blocks per workgroup (%s), wgs=%d lds=%zu",
+	         ax, ay, az >= 0 ? (std::string(",") + std::to_string(az)).c_str() : "", nx, ny, nz, G, g.rows_fast ? "block-major" : "side by side along x", pl->blk_nwg, pl->blk_lds);
+	pl->blk_desc = buf;
+	pl->has_block = true;
+}
+
+void block_scales(const dspfft_plan_s *pl, BlockScales &s)
+{
+	s.scale = (float)pl->scale;
+	for (int i = 0; i < 3; i++) { const int ax = pl->blk_axis[i]; s.in0[i] = ax >= 0 ? (float)pl->in0[ax] : 1.f; s.out0[i] = ax >= 0 ? (float)pl->out0[ax] : 1.f; }
+}
+
+int run_block(const dspfft_plan_s *pl, const float *in, float *out, void *stream)
+{
+	BlockArgs a;
+	static_cast<BlockGeom &>(a) = pl->blk;
+	a.kind = pl->blk_kind; a.in = in; a.out = out;
+	block_scales(pl, a.s);
+	if (int rc = be_launch_block(a, pl->blk_nwg, pl->blk_lds, stream)) return fail(-4, "kernel launch failed (%s): backend code %d", pl->blk_desc.c_str(), rc);
+	return 0;
+}
+
+// motion's per-block pipeline as one pass (block_core.h): both plans fuse their blocks the same way
+bool block_roundtrip_ok(const dspfft_plan_s *f, const dspfft_plan_s *i)
+{
+	if (!f->has_block || !i->has_block || f->blk_kind != KIND_REDFT10 || i->blk_kind != KIND_REDFT01) return false;
+	const BlockGeom &a = f->blk, &b = i->blk;
+	bool ok = a.nx == b.nx && a.ny == b.ny && a.nz == b.nz && a.G == b.G && a.nxb == b.nxb && a.nd == b.nd && a.rows_fast == b.rows_fast &&
+	          a.sy_out == b.sy_in && a.sz_out == b.sz_in && a.sxb_out == b.sxb_in && f->blk_nwg == i->blk_nwg;
+	for (int k = 0; k < 3; k++) ok = ok && f->blk_axis[k] == i->blk_axis[k];
+	for (int d = 0; ok && d < a.nd; d++) ok = a.bn[d] == b.bn[d] && a.bos[d] == b.bis[d];
+	return ok;
+}
+
 const std::vector<Pass> &pick_passes(const dspfft_plan_s *pl, const void *in, const void *out)
 {
 	if (pl->split.empty()) return pl->passes;
@@ -651,6 +745,7 @@ static int plan_finish(dspfft_plan_s *pl, dspfft_plan *plan, bool first_axis_fir
 		first = false;
 	}
 	build_split(pl);
+	build_block(pl);
 	*plan = pl;
 	return 0;
 }
@@ -758,6 +853,9 @@ int execute_t(dspfft_plan pl, const R *d_in, R *d_out, void *stream)
 {
 	if (!pl || !d_in || !d_out) return fail(-1, "null plan or buffer");
 	if (pl->f64 != std::is_same<R, double>::value) return fail(-1, "plan and buffers differ in sample type (f32 plan <-> dspfft_execute, f64 plan <-> dspfft_execute_f64)");
+	if constexpr (std::is_same<R, float>::value) {
+		if (pl->has_block && !(15u & ((uintptr_t)d_in | (uintptr_t)d_out))) return run_block(pl, d_in, d_out, stream);
+	}
 	const std::vector<Pass> &passes = pick_passes(pl, d_in, d_out);
 	for (size_t i = 0; i < passes.size(); i++) {
 		const Pass &P = passes[i];
@@ -911,7 +1009,8 @@ int roundtrip_core(dspfft_plan fwd, dspfft_plan inv, const float *d_in, float *d
 	const Pass &F = fwd->passes[nf - 1], &I = inv->passes[0];
 	bool differs = fwd->rank != inv->rank;
 	for (int a = 0; !differs && a < fwd->rank; a++) differs = fwd->n[a] != inv->n[a];
-	if (fwd->rank != inv->rank || fwd->howmany != inv->howmany || (!differs && F.axis != I.axis))
+	// (plans whose blocks go through the fused block pass have no pass order to agree on)
+	if (fwd->rank != inv->rank || fwd->howmany != inv->howmany || (!differs && F.axis != I.axis && !block_roundtrip_ok(fwd, inv)))
 		return fail(-1, "the forward plan's last pass and the inverse plan's first pass must run along the same axis (create the inverse with dspfft_plan_many_r2r_ordered(..., 1))");
 	// motion's `scaled != block` (motion.c:535-552): the inverse runs over DIFFERENT extents inside the same embedding -- larger:
 	// the spectrum is zero-padded (band-limited upscale), smaller: truncated (downscale)
@@ -951,6 +1050,26 @@ int roundtrip_core(dspfft_plan fwd, dspfft_plan inv, const float *d_in, float *d
 		const int k = 3 - fwd->rank + a;
 		nf3[k] = fwd->n[a]; ni3[k] = inv->n[a]; sw3[k] = fwd->axes[a].os; si3[k] = fwd->axes[a].is;
 	}
+	// small blocks: everything in one pass over the data
+	if (!rescale && block_roundtrip_ok(fwd, inv)) {
+		const uintptr_t pin = d_in8 ? (uintptr_t)d_in8 : (uintptr_t)d_in, pout = d_out8 ? (uintptr_t)d_out8 : (uintptr_t)d_out;
+		if (!((d_in8 ? 3u : 15u) & pin) && !((d_out8 ? 3u : 15u) & pout)) {
+			BlockRtArgs a;
+			static_cast<BlockGeom &>(a) = fwd->blk;
+			const BlockGeom &o = inv->blk;
+			a.sy_out = o.sy_out; a.sz_out = o.sz_out; a.sxb_out = o.sxb_out;
+			for (int d = 0; d < o.nd; d++) a.bos[d] = o.bos[d];
+			a.in = d_in8 ? nullptr : d_in; a.out = d_out8 ? nullptr : d_out; a.in8 = d_in8; a.out8 = d_out8; a.mul8 = mul8;
+			block_scales(fwd, a.f); block_scales(inv, a.i);
+			a.filt = mf; a.coded = d_coeffs_coded;
+			if (int rc = be_launch_block_roundtrip(a, fwd->blk_nwg, fwd->blk_lds, stream)) return fail(-4, "kernel launch failed (fused block roundtrip): backend code %d", rc);
+			return 0;
+		}
+	}
+	// the standalone filter finds a coefficient's position from its offset in a block-major embedding (minbuf_hw, block_depth); the
+	// blocks of a volume lying side by side are filtered by the fused block pass only, which knows each block's own coordinates
+	if (fp && fwd->has_block && !fwd->blk.rows_fast)
+		return fail(-2, "filtered roundtrip over the blocks of a volume needs the fused block pass: matching forward / inverse plans and 16-byte (8-bit: 4-byte) aligned buffers");
 	if (rescale) {
 		// one block, unfused: zero the working buffer (motion.c:619), load the block region, forward, filter, inverse over the
 		// scaled region, store it.  In place on a float buffer the caller has zeroed everything outside the block itself.
@@ -1104,7 +1223,8 @@ extern "C" int dspfft_plan_describe(dspfft_plan pl, char *buf, size_t buflen)
 	std::string s = std::string("backend ") + be_name() + "\n";
 	// a split plan lists the passes dspfft_execute runs; the plain ones (masked / fused executions, unaligned buffers) follow
 	for (const Pass &P : pl->split) { s += P.desc; s += "\n"; }
-	for (const Pass &P : pl->passes) { if (!pl->split.empty()) s += "plain "; s += P.desc; if (!P.hostloop.empty()) s += " +hostloop"; s += "\n"; }
+	if (pl->has_block) { s += pl->blk_desc; s += "\n"; }
+	for (const Pass &P : pl->passes) { if (!pl->split.empty() || pl->has_block) s += "plain "; s += P.desc; if (!P.hostloop.empty()) s += " +hostloop"; s += "\n"; }
 	snprintf(buf, buflen, "%s", s.c_str());
 	return 0;
 }

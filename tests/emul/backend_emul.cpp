@@ -315,6 +315,68 @@ int be_scan_stamp(uint32_t *ids, const uint32_t *lin, uint64_t n, uint32_t frame
 	for (uint64_t t = 0; t < n; t++) if (lin[t] != SCAN_NONE && lin[t] != 0) ids[lin[t]] = frame;
 	return 0;
 }
+bool be_block_supported(int nx, int ny, int nz)
+{
+#define DSP_BLOCK_HAS(X_, Y_, Z_) if (nx == X_ && ny == Y_ && nz == Z_) return true;
+	DSPFFT_BLOCK_SHAPES(DSP_BLOCK_HAS)
+#undef DSP_BLOCK_HAS
+	return false;
+}
+template <int NX, int NY, int NZ, int KIND>
+static int emul_block(const BlockArgs &a, int nwg, size_t lds_bytes)
+{
+	std::vector<unsigned char> raw(lds_bytes + 32);
+	float *lds = (float *)(((uintptr_t)raw.data() + 15) & ~(uintptr_t)15);
+	for (int wg = 0; wg < nwg; wg++) {
+		long long bin, bout; int cnt;
+		block_base(a, (uint32_t)wg, bin, bout, cnt);
+		for (int tid = 0; tid < BLOCK_THREADS; tid++) block_load_x<NX, NY, NZ, KIND, false>(a, block_axis_args(a.s, 0, NY == 1 && NZ == 1), a.in, nullptr, lds, bin, cnt, tid);
+		for (int tid = 0; tid < BLOCK_THREADS; tid++) block_lines_y<NX, NY, NZ, KIND>(a, block_axis_args(a.s, 1, NZ == 1), lds, cnt, tid);
+		for (int tid = 0; tid < BLOCK_THREADS; tid++) block_lines_z<NX, NY, NZ, KIND>(a, block_axis_args(a.s, 2, true), lds, cnt, tid);
+		for (int tid = 0; tid < BLOCK_THREADS; tid++) block_store_rows<NX, NY, NZ>(a, a.out, lds, bout, cnt, tid);
+	}
+	return 0;
+}
+int be_launch_block(const BlockArgs &a, int nwg, size_t lds, void *)
+{
+#define DSP_BLOCK_CASE(X_, Y_, Z_) \
+	if (a.nx == X_ && a.ny == Y_ && a.nz == Z_) \
+		return a.kind == KIND_REDFT10 ? emul_block<X_, Y_, Z_, KIND_REDFT10>(a, nwg, lds) : emul_block<X_, Y_, Z_, KIND_REDFT01>(a, nwg, lds);
+	DSPFFT_BLOCK_SHAPES(DSP_BLOCK_CASE)
+#undef DSP_BLOCK_CASE
+	return -1;
+}
+template <int NX, int NY, int NZ, bool IN8, bool OUT8>
+static int emul_block_rt(const BlockRtArgs &a, int nwg, size_t lds_bytes)
+{
+	std::vector<unsigned char> raw(lds_bytes + 32);
+	float *lds = (float *)(((uintptr_t)raw.data() + 15) & ~(uintptr_t)15);
+	unsigned long long mine = 0;
+	for (int wg = 0; wg < nwg; wg++) {
+		long long bin, bout; int cnt;
+		block_base(a, (uint32_t)wg, bin, bout, cnt);
+		for (int tid = 0; tid < BLOCK_THREADS; tid++) block_load_x<NX, NY, NZ, KIND_REDFT10, IN8>(a, block_axis_args(a.f, 0, NY == 1 && NZ == 1), a.in, a.in8, lds, bin, cnt, tid);
+		for (int tid = 0; tid < BLOCK_THREADS; tid++) block_lines_y<NX, NY, NZ, KIND_REDFT10>(a, block_axis_args(a.f, 1, NZ == 1), lds, cnt, tid);
+		for (int tid = 0; tid < BLOCK_THREADS; tid++) block_lines_z<NX, NY, NZ, KIND_REDFT10>(a, block_axis_args(a.f, 2, true), lds, cnt, tid);
+		if (a.filt.enabled) for (int tid = 0; tid < BLOCK_THREADS; tid++) block_filter<NX, NY, NZ>(a, a.filt, lds, cnt, tid, mine);
+		for (int tid = 0; tid < BLOCK_THREADS; tid++) block_lines_z<NX, NY, NZ, KIND_REDFT01>(a, block_axis_args(a.i, 2, false), lds, cnt, tid);
+		for (int tid = 0; tid < BLOCK_THREADS; tid++) block_lines_y<NX, NY, NZ, KIND_REDFT01>(a, block_axis_args(a.i, 1, false), lds, cnt, tid);
+		for (int tid = 0; tid < BLOCK_THREADS; tid++) block_store_x<NX, NY, NZ, KIND_REDFT01, OUT8>(a, block_axis_args(a.i, 0, true), a.out, a.out8, a.mul8, lds, bout, cnt, tid);
+	}
+	if (a.coded) *a.coded += mine;
+	return 0;
+}
+int be_launch_block_roundtrip(const BlockRtArgs &a, int nwg, size_t lds, void *)
+{
+#define DSP_BLOCK_CASE(X_, Y_, Z_) \
+	if (a.nx == X_ && a.ny == Y_ && a.nz == Z_) { \
+		if (a.in8) return a.out8 ? emul_block_rt<X_, Y_, Z_, true, true>(a, nwg, lds) : emul_block_rt<X_, Y_, Z_, true, false>(a, nwg, lds); \
+		return a.out8 ? emul_block_rt<X_, Y_, Z_, false, true>(a, nwg, lds) : emul_block_rt<X_, Y_, Z_, false, false>(a, nwg, lds); \
+	}
+	DSPFFT_BLOCK_SHAPES(DSP_BLOCK_CASE)
+#undef DSP_BLOCK_CASE
+	return -1;
+}
 int be_scan_tile_ranges(uint32_t *ranges, const uint32_t *ids, TileRangeGeom g0, int halves, void *)
 {
 	for (int b = 0; b < g0.ntiles * halves; b++) {

@@ -724,7 +724,7 @@ def test_roundtrip_u8_matches_float_path(gpu, case):
     assert np.abs(out.cpu().numpy().astype(np.float64) - np.clip(np.floor(u8 * mul + 0.5), 0, 255)).max() <= 6
 
 
-@pytest.mark.parametrize("block", [(8, 8, 8), (16, 16, 4), (5, 12, 15)])
+@pytest.mark.parametrize("block", [(8, 8, 8), (16, 16, 4), (5, 12, 15), (4, 4, 4), (16, 16, 16), (16, 8, 8), (8, 16, 8), (4, 16, 16)])
 @pytest.mark.parametrize("dtype", ["f32", "f64"])
 def test_guru_blocks_of_a_volume(gpu, block, dtype):
     """all blocks of a [D][H][W] volume in one plan (motion --blocksize: motion.c:591-615 walks them one by one); each block
@@ -740,6 +740,8 @@ def test_guru_blocks_of_a_volume(gpu, block, dtype):
     for kind in (5, 4):
         p = Plan.guru(dims, how, [kind] * 3, dtype=dtype)
         assert p.describe().count("TINY") == 3, p.describe()
+        # f32 blocks of 4 / 8 / 16 samples a side go through the one-pass kernel (block_core.h)
+        assert ("BLOCK" in p.describe()) == (dtype == "f32" and block != (5, 12, 15)), p.describe()
         d = gpu.from_numpy(x.copy()).to("cuda:0")
         p.execute(d.data_ptr())
         gpu.cuda.synchronize()
@@ -856,3 +858,49 @@ def test_ispec_signmap_restores_the_signs_of_an_abs_spectrogram(gpu):
     got = f.cpu().numpy()
     assert np.array_equal(got.reshape(-1, d)[1:], c.reshape(-1, d)[1:])
     assert np.array_equal(got.reshape(-1, d)[0], mag.reshape(-1, d)[0])
+
+
+# ---- small blocks: the one-pass kernels (block_core.h) ----
+@pytest.mark.parametrize("block", [(8, 8, 8), (4, 4, 4), (16, 16, 16), (1, 8, 8), (8, 16, 4)])
+def test_fused_block_roundtrip_gpu(gpu, block, monkeypatch):
+    """motion's per-block pipeline (8-bit load, REDFT10, filter + quantiser, REDFT01, 8-bit store) in one pass: block-major stack against
+    the unfused passes (DSPFFT_NO_BLOCK=1), and the blocks of a [D][H][W] volume against the same blocks rearranged block-major"""
+    from dspfun_amd import Plan
+    bd, bh, bw = block
+    D, H, W = 4 * bd, 6 * bh, 40 * bw
+    nb, vol = (D // bd) * (H // bh) * (W // bw), bd * bh * bw
+    n = [v for v in (bd, bh, bw) if v > 1]
+    rank = len(n)
+    nrm = 1.0 / np.prod([2.0 * v for v in n])
+    u8 = ol.synth_u8(11, D * H * W).reshape(D, H, W)
+    flt = dict(active=(bd, bh, bw), minbuf_hw=(bh, bw), block_depth=bd, band_begin=(0, 1, 0), band_end=(bd, bh, bw - 1), damp=0.5, boost=1.25, preserve_dc=1, quantizer=3.0)
+    bm = np.ascontiguousarray(u8.reshape(D // bd, bd, H // bh, bh, W // bw, bw).transpose(0, 2, 4, 1, 3, 5))
+    res = {}
+    for fused in (True, False):
+        if fused:
+            monkeypatch.delenv("DSPFFT_NO_BLOCK", raising=False)
+        else:
+            monkeypatch.setenv("DSPFFT_NO_BLOCK", "1")
+        fb = Plan.many_r2r(n, [5] * rank, howmany=nb, idist=vol, odist=vol)
+        ib = Plan.many_r2r(n, [4] * rank, howmany=nb, idist=vol, odist=vol, first_axis_first=True).set_scale(nrm)
+        assert ("BLOCK" in fb.describe()) == fused
+        din = gpu.from_numpy(bm.copy()).to("cuda:0"); dout = gpu.zeros_like(din); work = gpu.empty(nb * vol, dtype=gpu.float32, device="cuda:0")
+        coded = gpu.zeros(1, dtype=gpu.int64, device="cuda:0")
+        fb.roundtrip_u8(ib, din.data_ptr(), dout.data_ptr(), work.data_ptr(), 1.0, filter=flt, d_coded=coded.data_ptr())
+        gpu.cuda.synchronize()
+        res[fused] = (dout.cpu().numpy(), int(coded.item()))
+    a, b = res[True], res[False]
+    assert np.abs(a[0].astype(np.int32) - b[0].astype(np.int32)).max() <= 1 and (a[0] != b[0]).mean() < 1e-3
+    assert abs(a[1] - b[1]) <= max(4, b[1] // 10000) and b[1] > 0
+    monkeypatch.delenv("DSPFFT_NO_BLOCK", raising=False)
+    dims = [d for d in [(bd, H * W, H * W), (bh, W, W), (bw, 1, 1)] if d[0] > 1]
+    how = [(D // bd, bd * H * W, bd * H * W), (H // bh, bh * W, bh * W), (W // bw, bw, bw)]
+    fv = Plan.guru(dims, how, [5] * rank)
+    iv = Plan.guru(dims, how, [4] * rank).set_scale(nrm)
+    assert "side by side" in fv.describe()
+    din = gpu.from_numpy(u8.copy()).to("cuda:0"); dout = gpu.zeros_like(din); work = gpu.empty(D * H * W, dtype=gpu.float32, device="cuda:0")
+    coded = gpu.zeros(1, dtype=gpu.int64, device="cuda:0")
+    fv.roundtrip_u8(iv, din.data_ptr(), dout.data_ptr(), work.data_ptr(), 1.0, filter=flt, d_coded=coded.data_ptr())
+    gpu.cuda.synchronize()
+    back = a[0].reshape(D // bd, H // bh, W // bw, bd, bh, bw).transpose(0, 3, 1, 4, 2, 5).reshape(D, H, W)
+    assert np.array_equal(dout.cpu().numpy(), back) and int(coded.item()) == a[1]

@@ -790,3 +790,145 @@ def test_f64_specialised_fused_scan_step():
     for f in range(nframes):
         inv.execute_masked_accumulate(coeffs.ctypes.data, work.ctypes.data, acc.ctypes.data, ids.ctypes.data, f, c)
     assert np.abs(acc - x).max() < 1e-12
+
+
+# ---- small blocks: all axes in one pass (block_core.h) ----
+@pytest.mark.parametrize("block,vol", [((8, 8, 8), (16, 16, 8 * 37)), ((4, 4, 4), (8, 12, 4 * 70)), ((16, 16, 16), (16, 32, 16 * 5)), ((1, 8, 8), (3, 16, 8 * 33)),
+                                       ((1, 16, 16), (2, 16, 16 * 3)), ((8, 8, 16), (8, 16, 64)), ((4, 8, 8), (8, 8, 8 * 40)), ((8, 12, 8), (8, 24, 32))])
+def test_fused_block_pass(block, vol, monkeypatch):
+    """WxHxD blocks of a [D][H][W] volume (motion --blocksize): the one-pass kernel against the per-axis TINY passes and the oracle"""
+    bd, bh, bw = block
+    D, H, W = vol
+    x = ol.synth_f32(D + H + W, D * H * W).reshape(D, H, W)
+    dims = [(bd, H * W, H * W), (bh, W, W), (bw, 1, 1)]
+    how = [(D // bd, bd * H * W, bd * H * W), (H // bh, bh * W, bh * W), (W // bw, bw, bw)]
+    dims = [d for d in dims if d[0] > 1]
+    fusable = (bw, bh, bd) != (8, 12, 8)
+    for kind in (REDFT10, REDFT01):
+        p = Plan.guru(dims, how, [kind] * len(dims), lib=emul()).set_scale(0.37)
+        for a in range(len(dims)):
+            p.set_axis_scale0(a, 1.25 + a, 0.5 + 0.25 * a)
+        assert ("BLOCK" in p.describe()) == fusable, p.describe()
+        monkeypatch.setenv("DSPFFT_NO_BLOCK", "1")
+        q = Plan.guru(dims, how, [kind] * len(dims), lib=emul()).set_scale(0.37)
+        monkeypatch.delenv("DSPFFT_NO_BLOCK")
+        for a in range(len(dims)):
+            q.set_axis_scale0(a, 1.25 + a, 0.5 + 0.25 * a)
+        assert "BLOCK" not in q.describe()
+        got, ref = run(p, x.copy()), run(q, x.copy())
+        assert relerr(got, ref.astype(np.float64)) < 1e-6, (block, kind)
+        out = np.empty_like(x)
+        assert np.array_equal(run(p, x.copy(), out), got)               # out of place
+        # an unaligned buffer takes the per-axis passes
+        raw = np.empty(D * H * W + 1, dtype=np.float32)
+        u = raw[1:] if raw.ctypes.data % 16 == 0 else raw[:-1]
+        u[...] = x.ravel()
+        p.execute(u.ctypes.data)
+        assert relerr(u.reshape(D, H, W), ref.astype(np.float64)) < 1e-6
+    # one block against the definition
+    p = Plan.guru(dims, how, [REDFT10] * len(dims), lib=emul())
+    got = run(p, x.copy())
+    blk = np.ascontiguousarray(x[:bd, :bh, :bw]).astype(np.float64)
+    ref = ol.r2r_many(blk.ravel(), [v for v in (bd, bh, bw) if v > 1], [REDFT10] * len(dims)).reshape(bd, bh, bw)
+    assert relerr(got[:bd, :bh, :bw], ref) < TOL
+
+
+def _aligned_f32(n):
+    raw = np.empty(n * 4 + 64, dtype=np.uint8)
+    o = (-raw.ctypes.data) % 64
+    return raw[o:o + 4 * n].view(np.float32)
+
+
+@pytest.mark.parametrize("block,nblocks", [((8, 8, 8), 37), ((4, 4, 4), 130), ((1, 8, 8), 70), ((16, 16, 16), 3), ((8, 16, 4), 9)])
+@pytest.mark.parametrize("what", ["plain", "filter", "quant_u8"])
+def test_fused_block_roundtrip_block_major(block, nblocks, what, monkeypatch):
+    """motion's per-block pipeline on a block-major stack (the reference's per-block buffers, motion.c:591-776): one pass against the
+    unfused passes (DSPFFT_NO_BLOCK=1), 8-bit ends included"""
+    import ctypes as C
+    L = emul()
+    bd, bh, bw = block
+    vol = bd * bh * bw
+    n = [v for v in (bd, bh, bw) if v > 1]
+    rank = len(n)
+    r2 = float(np.sqrt(2.0))
+    nrm = 1.0 / np.prod([2.0 * v for v in n])
+    u8 = ol.synth_u8(nblocks + vol, nblocks * vol)
+    x = _aligned_f32(nblocks * vol); x[...] = u8.astype(np.float32)
+
+    def plans():
+        fwd = Plan.many_r2r(n, [REDFT10] * rank, howmany=nblocks, idist=vol, odist=vol, lib=L).set_scale(2 * r2)
+        inv = Plan.many_r2r(n, [REDFT01] * rank, howmany=nblocks, idist=vol, odist=vol, lib=L, first_axis_first=True).set_scale(nrm / (2 * r2))
+        for a in range(rank):
+            fwd.set_axis_scale0(a, 1.0, 1.0 / r2); inv.set_axis_scale0(a, r2, 1.0)
+        return fwd, inv
+    flt = None
+    if what == "filter":
+        flt = dict(active=(bd, bh, bw), minbuf_hw=(bh, bw), block_depth=bd, band_begin=(0, 1, 1), band_end=(bd, bh - 1, bw), damp=0.25, boost=1.5, preserve_dc=1)
+    elif what == "quant_u8":
+        flt = dict(active=(bd, bh, bw), minbuf_hw=(bh, bw), block_depth=bd, band_begin=(0, 0, 0), band_end=(bd, bh, bw), quantizer=6.0)
+    res = {}
+    for fused in (True, False):
+        if fused:
+            monkeypatch.delenv("DSPFFT_NO_BLOCK", raising=False)
+        else:
+            monkeypatch.setenv("DSPFFT_NO_BLOCK", "1")
+        fwd, inv = plans()
+        assert ("BLOCK" in fwd.describe()) == fused and ("block-major" in fwd.describe()) == fused, fwd.describe()
+        coded = np.zeros(1, dtype=np.uint64)
+        if what == "quant_u8":
+            inb = np.ascontiguousarray(u8); outb = np.zeros_like(u8); work = _aligned_f32(nblocks * vol)
+            fwd.roundtrip_u8(inv, inb.ctypes.data, outb.ctypes.data, work.ctypes.data, 1.0, filter=flt, d_coded=coded.ctypes.data)
+            res[fused] = (outb.copy(), int(coded[0]))
+        else:
+            buf = _aligned_f32(nblocks * vol); buf[...] = x
+            fwd.roundtrip(inv, buf.ctypes.data, filter=flt, d_coded=coded.ctypes.data if flt else 0)
+            res[fused] = (buf.copy(), int(coded[0]))
+    if what == "quant_u8":
+        assert np.abs(res[True][0].astype(np.int32) - res[False][0].astype(np.int32)).max() <= 1     # a value on a rounding edge may flip
+        assert (res[True][0] != res[False][0]).mean() < 1e-3
+        assert abs(res[True][1] - res[False][1]) <= max(4, res[False][1] // 10000) and res[False][1] > 0
+    else:
+        assert np.abs(res[True][0] - res[False][0]).max() < 2e-4 * 255
+        if what == "plain":
+            assert np.abs(res[True][0] - x).max() < 1e-3
+
+
+@pytest.mark.parametrize("block", [(8, 8, 8), (4, 16, 8), (1, 8, 8)])
+def test_fused_block_roundtrip_volume_layout(block):
+    """the blocks of a [D][H][W] volume where they lie (guru plans): the one-pass pipeline equals the block-major one on the rearranged data"""
+    L = emul()
+    bd, bh, bw = block
+    D, H, W = 2 * bd, 2 * bh, 9 * bw
+    nb = (D // bd) * (H // bh) * (W // bw)
+    vol = bd * bh * bw
+    n = [v for v in (bd, bh, bw) if v > 1]
+    rank = len(n)
+    u8 = ol.synth_u8(5, D * H * W).reshape(D, H, W)
+    dims = [d for d in [(bd, H * W, H * W), (bh, W, W), (bw, 1, 1)] if d[0] > 1]
+    how = [(D // bd, bd * H * W, bd * H * W), (H // bh, bh * W, bh * W), (W // bw, bw, bw)]
+    flt = dict(active=(bd, bh, bw), minbuf_hw=(bh, bw), block_depth=bd, band_begin=(0, 1, 0), band_end=(bd, bh, bw - 1), damp=0.5, boost=1.25, preserve_dc=1, quantizer=3.0)
+    nrm = 1.0 / np.prod([2.0 * v for v in n])
+    # volume layout
+    fv = Plan.guru(dims, how, [REDFT10] * rank, lib=L)
+    iv = Plan.guru(dims, how, [REDFT01] * rank, lib=L).set_scale(nrm)
+    assert "side by side" in fv.describe()
+    cv = np.zeros(1, dtype=np.uint64)
+    outv = np.zeros_like(u8); work = _aligned_f32(D * H * W)
+    fv.roundtrip_u8(iv, np.ascontiguousarray(u8).ctypes.data, outv.ctypes.data, work.ctypes.data, 1.0, filter=flt, d_coded=cv.ctypes.data)
+    # block-major layout of the same blocks
+    bm = np.ascontiguousarray(u8.reshape(D // bd, bd, H // bh, bh, W // bw, bw).transpose(0, 2, 4, 1, 3, 5))
+    fb = Plan.many_r2r(n, [REDFT10] * rank, howmany=nb, idist=vol, odist=vol, lib=L)
+    ib = Plan.many_r2r(n, [REDFT01] * rank, howmany=nb, idist=vol, odist=vol, lib=L, first_axis_first=True).set_scale(nrm)
+    cb = np.zeros(1, dtype=np.uint64)
+    outb = np.zeros_like(bm); workb = _aligned_f32(D * H * W)
+    fb.roundtrip_u8(ib, bm.ctypes.data, outb.ctypes.data, workb.ctypes.data, 1.0, filter=flt, d_coded=cb.ctypes.data)
+    back = outb.reshape(D // bd, H // bh, W // bw, bd, bh, bw).transpose(0, 3, 1, 4, 2, 5).reshape(D, H, W)
+    assert np.array_equal(outv, back) and int(cv[0]) == int(cb[0]) > 0
+    # float in place, and an unaligned buffer with a filter is refused rather than filtered at the wrong positions
+    buf = _aligned_f32(D * H * W); buf[...] = u8.ravel()
+    fv.roundtrip(iv, buf.ctypes.data, filter=flt)
+    assert np.abs(np.clip(np.floor(buf + 0.5), 0, 255).reshape(D, H, W) - outv).max() <= 1
+    raw = np.zeros(D * H * W + 1, dtype=np.float32)
+    u = raw[1:] if raw.ctypes.data % 16 == 0 else raw[:-1]
+    with pytest.raises(DspfftError):
+        fv.roundtrip(iv, u.ctypes.data, filter=flt)
