@@ -206,8 +206,9 @@ DSP_HD void block_filter(const BlockGeom &a, const MotionFilter &f, float *lds, 
 	}
 }
 
-// block extents with a fused kernel: X(NX, NY, NZ) -- 4, 8 or 16 samples a side, NZ = 1 for 2-D blocks
+// block extents with a fused kernel: X(NX, NY, NZ) -- 4, 8 or 16 samples a side (2-D blocks, NZ = 1: up to 32)
 #define DSPFFT_BLOCK_SHAPES(X) \
+	X(32, 32, 1) X(32, 16, 1) X(16, 32, 1) X(32, 8, 1) X(8, 32, 1) \
 	X(4, 4, 1) X(8, 4, 1) X(16, 4, 1) X(4, 8, 1) X(8, 8, 1) X(16, 8, 1) X(4, 16, 1) X(8, 16, 1) X(16, 16, 1) \
 	X(4, 4, 4) X(8, 4, 4) X(16, 4, 4) X(4, 8, 4) X(8, 8, 4) X(16, 8, 4) X(4, 16, 4) X(8, 16, 4) X(16, 16, 4) \
 	X(4, 4, 8) X(8, 4, 8) X(16, 4, 8) X(4, 8, 8) X(8, 8, 8) X(16, 8, 8) X(4, 16, 8) X(8, 16, 8) X(16, 16, 8) \

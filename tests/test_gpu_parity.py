@@ -861,7 +861,7 @@ def test_ispec_signmap_restores_the_signs_of_an_abs_spectrogram(gpu):
 
 
 # ---- small blocks: the one-pass kernels (block_core.h) ----
-@pytest.mark.parametrize("block", [(8, 8, 8), (4, 4, 4), (16, 16, 16), (1, 8, 8), (8, 16, 4)])
+@pytest.mark.parametrize("block", [(8, 8, 8), (4, 4, 4), (16, 16, 16), (1, 8, 8), (8, 16, 4), (1, 32, 32), (1, 8, 32)])
 def test_fused_block_roundtrip_gpu(gpu, block, monkeypatch):
     """motion's per-block pipeline (8-bit load, REDFT10, filter + quantiser, REDFT01, 8-bit store) in one pass: block-major stack against
     the unfused passes (DSPFFT_NO_BLOCK=1), and the blocks of a [D][H][W] volume against the same blocks rearranged block-major"""
