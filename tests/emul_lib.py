@@ -12,6 +12,10 @@ _emul = None
 def emul():
     global _emul
     if _emul is None:
-        subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "emul")], stdout=subprocess.DEVNULL)
+        # one build at a time: pytest-xdist workers would otherwise race on the same output file
+        import fcntl
+        with open(os.path.join(_HERE, "emul", ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "emul")], stdout=subprocess.DEVNULL)
         _emul = L.bind(C.CDLL(os.path.join(_HERE, "emul", "libdspfft_emul.so")))
     return _emul
