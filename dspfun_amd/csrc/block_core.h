@@ -177,6 +177,35 @@ DSP_HD void block_lines_z(const BlockGeom &a, const TinyArgs &tz, float *lds, in
 		}
 	}
 }
+// The middle of the roundtrip: the LAST forward axis (z, or y for 2-D blocks), motion's coefficient filter (motion.c:683-744,
+// positions are the block's own coordinates) and the same axis of the inverse on one line in registers -- one LDS round trip
+// instead of three.  ZAXIS: lines along z (stride NY * pitch), else along y (stride pitch).
+template <int NX, int NY, int NZ, bool ZAXIS>
+DSP_HD void block_lines_mid(const BlockGeom &a, const TinyArgs &tf, const TinyArgs &ti, const MotionFilter &f, float *lds, int cnt, int tid, unsigned long long &coded)
+{
+	constexpr int N = ZAXIS ? NZ : NY, OUTER = ZAXIS ? NY : NZ;
+	const int cols = cnt * NX;
+	const int stride = ZAXIS ? NY * a.pitch : a.pitch;
+	for (int l = tid; l < OUTER * cols; l += BLOCK_THREADS) {
+		const int o = l / cols, c = l - o * cols;
+		float *p = lds + (ZAXIS ? o * a.pitch : o * NY * a.pitch) + c;
+		float x[N], y[N];
+#pragma unroll
+		for (int j = 0; j < N; j++) x[j] = p[j * stride];
+		tiny_dct<N, KIND_REDFT10>(tf, x, y);
+		if (f.enabled) {
+			const int bx = c % NX;
+#pragma unroll
+			for (int j = 0; j < N; j++) {
+				const int bz = ZAXIS ? j : o, by = ZAXIS ? o : j;
+				if (bx < f.aw && by < f.ah && bz < f.ad) y[j] = motion_filter_at(f, bz, by, bx, y[j], coded);
+			}
+		}
+		tiny_dct<N, KIND_REDFT01>(ti, y, x);
+#pragma unroll
+		for (int j = 0; j < N; j++) p[j * stride] = x[j];
+	}
+}
 // rows of the tile back to global memory (four consecutive samples per lane; block extents are multiples of 4)
 template <int NX, int NY, int NZ>
 DSP_HD void block_store_rows(const BlockGeom &a, float *out, const float *lds, long long bout, int cnt, int tid)
@@ -192,20 +221,6 @@ DSP_HD void block_store_rows(const BlockGeom &a, float *out, const float *lds, l
 			*reinterpret_cast<const float4 *>(lds + row * a.pitch + g * NX + 4 * qx);
 	}
 }
-// motion's coefficient filter on the tile (motion.c:683-744): positions are the block's own coordinates
-template <int NX, int NY, int NZ>
-DSP_HD void block_filter(const BlockGeom &a, const MotionFilter &f, float *lds, int cnt, int tid, unsigned long long &coded)
-{
-	const int cols = cnt * NX;
-	for (int e = tid; e < NZ * NY * cols; e += BLOCK_THREADS) {
-		const int row = e / cols, c = e - row * cols;
-		const int z = row / NY, y = row - z * NY, x = c % NX;
-		if (x >= f.aw || y >= f.ah || z >= f.ad) continue;
-		float *p = lds + row * a.pitch + c;
-		*p = motion_filter_at(f, z, y, x, *p, coded);
-	}
-}
-
 // block extents with a fused kernel: X(NX, NY, NZ) -- 4, 8 or 16 samples a side (2-D blocks, NZ = 1: up to 32)
 #define DSPFFT_BLOCK_SHAPES(X) \
 	X(32, 32, 1) X(32, 16, 1) X(16, 32, 1) X(32, 8, 1) X(8, 32, 1) \

@@ -36,22 +36,25 @@ __global__ void __launch_bounds__(BLOCK_THREADS) block_roundtrip_kernel(const Bl
 	block_base(a, blockIdx.x, bin, bout, cnt);
 	block_load_x<NX, NY, NZ, KIND_REDFT10, IN8>(a, block_axis_args(a.f, 0, NY == 1 && NZ == 1), a.in, a.in8, lds, bin, cnt, tid);
 	__syncthreads();
-	if constexpr (NY > 1) { block_lines_y<NX, NY, NZ, KIND_REDFT10>(a, block_axis_args(a.f, 1, NZ == 1), lds, cnt, tid); __syncthreads(); }
-	if constexpr (NZ > 1) { block_lines_z<NX, NY, NZ, KIND_REDFT10>(a, block_axis_args(a.f, 2, true), lds, cnt, tid); __syncthreads(); }
-	if (a.filt.enabled) {
-		unsigned long long mine = 0;
-		block_filter<NX, NY, NZ>(a, a.filt, lds, cnt, tid, mine);
-		if (a.coded) {
-			unsigned int m = (unsigned int)mine;
-			for (int off = 32; off > 0; off >>= 1) m += __shfl_xor(m, off);
-			if ((tid & 63) == 0 && m) atomicAdd(&wg_coded, m);
-		}
+	// the last forward axis, the filter and the same axis of the inverse run on one line in registers (block_lines_mid)
+	unsigned long long mine = 0;
+	if constexpr (NZ > 1) {
+		if constexpr (NY > 1) { block_lines_y<NX, NY, NZ, KIND_REDFT10>(a, block_axis_args(a.f, 1, false), lds, cnt, tid); __syncthreads(); }
+		block_lines_mid<NX, NY, NZ, true>(a, block_axis_args(a.f, 2, true), block_axis_args(a.i, 2, false), a.filt, lds, cnt, tid, mine);
 		__syncthreads();
-		if (a.coded && tid == 0 && wg_coded) atomicAdd(a.coded, (unsigned long long)wg_coded);
+		if constexpr (NY > 1) { block_lines_y<NX, NY, NZ, KIND_REDFT01>(a, block_axis_args(a.i, 1, false), lds, cnt, tid); __syncthreads(); }
+	} else {
+		block_lines_mid<NX, NY, NZ, false>(a, block_axis_args(a.f, 1, true), block_axis_args(a.i, 1, false), a.filt, lds, cnt, tid, mine);
+		__syncthreads();
+	}
+	if (a.filt.enabled && a.coded) {
+		unsigned int m = (unsigned int)mine;
+		for (int off = 32; off > 0; off >>= 1) m += __shfl_xor(m, off);
+		if ((tid & 63) == 0 && m) atomicAdd(&wg_coded, m);
+		__syncthreads();
+		if (tid == 0 && wg_coded) atomicAdd(a.coded, (unsigned long long)wg_coded);
 	}
 	// the inverse's global scale rides on its x pass, the last one here
-	if constexpr (NZ > 1) { block_lines_z<NX, NY, NZ, KIND_REDFT01>(a, block_axis_args(a.i, 2, false), lds, cnt, tid); __syncthreads(); }
-	if constexpr (NY > 1) { block_lines_y<NX, NY, NZ, KIND_REDFT01>(a, block_axis_args(a.i, 1, false), lds, cnt, tid); __syncthreads(); }
 	block_store_x<NX, NY, NZ, KIND_REDFT01, OUT8>(a, block_axis_args(a.i, 0, true), a.out, a.out8, a.mul8, lds, bout, cnt, tid);
 }
 

@@ -360,11 +360,13 @@ static int emul_block_rt(const BlockRtArgs &a, int nwg, size_t lds_bytes)
 		long long bin, bout; int cnt;
 		block_base(a, (uint32_t)wg, bin, bout, cnt);
 		for (int tid = 0; tid < BLOCK_THREADS; tid++) block_load_x<NX, NY, NZ, KIND_REDFT10, IN8>(a, block_axis_args(a.f, 0, NY == 1 && NZ == 1), a.in, a.in8, lds, bin, cnt, tid);
-		for (int tid = 0; tid < BLOCK_THREADS; tid++) block_lines_y<NX, NY, NZ, KIND_REDFT10>(a, block_axis_args(a.f, 1, NZ == 1), lds, cnt, tid);
-		for (int tid = 0; tid < BLOCK_THREADS; tid++) block_lines_z<NX, NY, NZ, KIND_REDFT10>(a, block_axis_args(a.f, 2, true), lds, cnt, tid);
-		if (a.filt.enabled) for (int tid = 0; tid < BLOCK_THREADS; tid++) block_filter<NX, NY, NZ>(a, a.filt, lds, cnt, tid, mine);
-		for (int tid = 0; tid < BLOCK_THREADS; tid++) block_lines_z<NX, NY, NZ, KIND_REDFT01>(a, block_axis_args(a.i, 2, false), lds, cnt, tid);
-		for (int tid = 0; tid < BLOCK_THREADS; tid++) block_lines_y<NX, NY, NZ, KIND_REDFT01>(a, block_axis_args(a.i, 1, false), lds, cnt, tid);
+		if constexpr (NZ > 1) {
+			for (int tid = 0; tid < BLOCK_THREADS; tid++) block_lines_y<NX, NY, NZ, KIND_REDFT10>(a, block_axis_args(a.f, 1, false), lds, cnt, tid);
+			for (int tid = 0; tid < BLOCK_THREADS; tid++) block_lines_mid<NX, NY, NZ, true>(a, block_axis_args(a.f, 2, true), block_axis_args(a.i, 2, false), a.filt, lds, cnt, tid, mine);
+			for (int tid = 0; tid < BLOCK_THREADS; tid++) block_lines_y<NX, NY, NZ, KIND_REDFT01>(a, block_axis_args(a.i, 1, false), lds, cnt, tid);
+		} else {
+			for (int tid = 0; tid < BLOCK_THREADS; tid++) block_lines_mid<NX, NY, NZ, false>(a, block_axis_args(a.f, 1, true), block_axis_args(a.i, 1, false), a.filt, lds, cnt, tid, mine);
+		}
 		for (int tid = 0; tid < BLOCK_THREADS; tid++) block_store_x<NX, NY, NZ, KIND_REDFT01, OUT8>(a, block_axis_args(a.i, 0, true), a.out, a.out8, a.mul8, lds, bout, cnt, tid);
 	}
 	if (a.coded) *a.coded += mine;
