@@ -114,7 +114,13 @@ int dspfft_plan_many_r2r_ordered(dspfft_plan *plan, int rank, const int *n, int 
  * separately.  filter == NULL skips the filter.  The filter is motion.c:683-744 (see dspfft_motion_filter below):
  * positions are taken inside blocks of block_depth planes of minbuf_hw[0] x minbuf_hw[1] elements (block_depth =
  * the embedding depth for one 3-D block, 1 when every frame is its own block, motion's default -b 0x0x1);
- * d_coeffs_coded (device, may be NULL) is incremented by the number of non-zero quantised coefficients. */
+ * d_coeffs_coded (device, may be NULL) is incremented by the number of non-zero quantised coefficients.
+ * Small blocks (motion --blocksize 8x8x8 and the like: every extent 4, 8 or 16, 2-D blocks up to 32; f32; x contiguous; planned
+ * with dspfft_plan_many_r2r as a block-major stack or with dspfft_plan_guru_r2r where they lie in a volume): dspfft_execute runs all
+ * axes of a block in ONE pass, and this call -- the _u8 form included -- runs load, forward transform, filter (positions are the
+ * block's own coordinates), inverse transform and store as ONE kernel; the inverse plan needs no particular pass order then.
+ * Buffers must be 16-byte aligned (8-bit ones: 4-byte) for that path; a filtered roundtrip over the blocks of a volume has no
+ * other path and fails otherwise. */
 typedef struct {
 	int active[3];            /* block extent {d, h, w} actually transformed */
 	int minbuf_hw[2];         /* rows and row pitch of the buffer's planes */
