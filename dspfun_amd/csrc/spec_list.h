@@ -21,7 +21,18 @@
 	X(720, 3, 128, 4, 6, 15)           \
 	X(640, 3, 128, 4, 5, 16)           \
 	X(512, 3, 64, 16, 16)              \
-	X(1280, 1, 128, 4, 10, 16)
+	X(1280, 1, 128, 4, 10, 16)         \
+	X(5120, 3, 512, 10, 16, 16)        \
+	X(3200, 3, 512, 10, 10, 16)        \
+	X(2880, 3, 512, 6, 16, 15)         \
+	X(1600, 3, 256, 5, 10, 16)         \
+	X(1440, 3, 256, 3, 16, 15)         \
+	X(800, 3, 128, 5, 5, 16)           \
+	X(3840, 1, 256, 12, 10, 16)        \
+	X(2560, 1, 256, 8, 10, 16)         \
+	X(4096, 1, 256, 8, 16, 16)         \
+	X(2048, 1, 128, 4, 16, 16)         \
+	X(1024, 1, 64, 4, 8, 16)
 
 // (An outer radix-2 column split -- half of the tile parked in registers so 2160-row tiles could be K = 16 wide in
 // the same 69 KB -- was built and measured SLOWER at every size tried: 2160 (K=16): 57/68 us vs 49/53 us; 4320 (K=8):
@@ -45,7 +56,16 @@
 	X(1024, 16, 512, 4, 16, 16) \
 	X(720, 16, 256, 6, 8, 15) \
 	X(512, 16, 256, 4, 8, 16) \
-	X(480, 16, 256, 4, 8, 15)
+	X(480, 16, 256, 4, 8, 15) \
+	X(2880, 4, 512, 12, 16, 15) \
+	X(1800, 8, 512, 10, 12, 15) \
+	X(1600, 8, 512, 10, 10, 16) \
+	X(1200, 16, 512, 5, 16, 15) \
+	X(1152, 16, 512, 8, 9, 16) \
+	X(960, 16, 512, 4, 16, 15) \
+	X(900, 16, 512, 6, 10, 15) \
+	X(768, 16, 256, 16, 16, 3) \
+	X(600, 16, 256, 5, 8, 15)
 
 #define DSPFFT_COL_SPECS(X) DSPFFT_COL_SPECS_A(X) DSPFFT_COL_SPECS_B(X)
 

@@ -262,7 +262,8 @@ def test_generic_and_specialised_kernels_agree(gpu):
 
 
 @pytest.mark.parametrize("h,w,c", [(720, 1280, 3), (1440, 2560, 3), (480, 640, 3), (480, 720, 3), (512, 512, 3), (1024, 1024, 3), (2048, 2048, 3),
-                                    (2160, 4096, 3), (4096, 4096, 3), (720, 1280, 1), (4096, 4100, 1)])
+                                    (2160, 4096, 3), (4096, 4096, 3), (720, 1280, 1), (4096, 4100, 1), (600, 800, 3), (768, 1024, 3), (900, 1440, 3), (1200, 1600, 3),
+                                    (1600, 2560, 3), (1800, 3200, 3), (2880, 5120, 3), (960, 1280, 3), (1152, 2048, 1), (2160, 3840, 1), (2160, 4096, 1), (768, 1024, 1)])
 def test_common_resolutions_specialised_vs_oracle(gpu, h, w, c):
     """spec_list.h's entries for the common frame sizes: both transforms against the f64 port, and a roundtrip"""
     from dspfun_amd import REDFT10, REDFT01

@@ -180,7 +180,10 @@ def test_helpers_zigzag_and_scan_step():
 @pytest.mark.parametrize("h,w,c", [(4, 3840, 3), (3, 1920, 3), (2, 7680, 3), (5, 960, 3), (6, 256, 3), (4, 1920, 1), (4, 960, 1),
                                     (2160, 8, 3), (1080, 16, 3), (1080, 32, 1), (4320, 8, 1), (4320, 4, 3), (540, 16, 1), (256, 16, 3), (256, 256, 3),
                                     (2, 4096, 3), (3, 2560, 3), (2, 2048, 3), (3, 1280, 3), (3, 1024, 3), (5, 720, 3), (4, 640, 3), (4, 512, 3), (4, 1280, 1),
-                                    (4096, 8, 1), (4096, 4, 3), (2048, 8, 1), (1440, 8, 3), (1024, 16, 1), (720, 16, 3), (512, 16, 1), (480, 16, 3)])
+                                    (4096, 8, 1), (4096, 4, 3), (2048, 8, 1), (1440, 8, 3), (1024, 16, 1), (720, 16, 3), (512, 16, 1), (480, 16, 3),
+                                    (2, 5120, 3), (2, 3200, 3), (3, 2880, 3), (3, 1600, 3), (3, 1440, 3), (4, 800, 3), (3, 3840, 1), (3, 2560, 1), (3, 4096, 1),
+                                    (4, 2048, 1), (5, 1024, 1), (2880, 8, 1), (1800, 8, 1), (1600, 8, 3), (1200, 16, 1), (1152, 16, 3), (960, 16, 1), (900, 16, 3),
+                                    (768, 16, 1), (600, 16, 3)])
 @pytest.mark.parametrize("kind", [REDFT10, REDFT01])
 def test_specialised_kernels(h, w, c, kind):
     x = ol.synth_f32(h * 7 + w, h * w * c).reshape(h, w, c)

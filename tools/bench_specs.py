@@ -15,7 +15,11 @@ def t(fn, reps=20):
     return a.elapsed_time(b) / reps
 
 sizes = [(256, 256, 3), (480, 640, 3), (480, 720, 3), (512, 512, 3), (540, 960, 3), (720, 1280, 3), (1024, 1024, 3), (1080, 1920, 3), (1440, 2560, 3),
-         (2048, 2048, 3), (2160, 3840, 3), (2160, 4096, 3), (4096, 4096, 3), (4320, 7680, 3), (720, 1280, 1), (1080, 1920, 1)]
+         (2048, 2048, 3), (2160, 3840, 3), (2160, 4096, 3), (4096, 4096, 3), (4320, 7680, 3), (720, 1280, 1), (1080, 1920, 1),
+         (600, 800, 3), (768, 1024, 3), (900, 1440, 3), (900, 1600, 3), (960, 1280, 3), (1200, 1600, 3), (1200, 1920, 3), (1600, 2560, 3), (1800, 3200, 3),
+         (2880, 5120, 3), (2160, 3840, 1), (1440, 2560, 1), (2160, 4096, 1), (1080, 2048, 1), (768, 1024, 1)]
+if os.environ.get("SIZES") == "new":
+    sizes = sizes[16:]
 out = []
 for (h, w, c) in sizes:
     x = torch.rand(h, w, c, device="cuda:0")
