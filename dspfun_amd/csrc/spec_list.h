@@ -42,10 +42,10 @@
 // two groups, so the column kernels compile in two translation units (spec_inst_col_a/b.hip)
 #define DSPFFT_COL_SPECS_A(X) \
 	X(2160, 8, 512, 12, 12, 15) \
-	X(1080, 16, 512, 8, 9, 15) \
+	X(1080, 16, 512, 12, 10, 9) /* every stage within one round of 512 threads (8, 9, 15: 540 butterflies in the first): fused roundtrip 552 -> 460 us */ \
 	X(4320, 8, 1024, 2, 12, 12, 15) \
 	X(4320, 4, 512, 2, 12, 12, 15) \
-	X(540, 16, 256, 4, 9, 15) \
+	X(540, 16, 256, 12, 5, 9) \
 	X(256, 16, 256, 4, 4, 16) \
 	X(4096, 8, 1024, 16, 16, 16)
 
@@ -54,7 +54,7 @@
 	X(2048, 8, 512, 8, 16, 16) \
 	X(1440, 8, 512, 8, 12, 15) \
 	X(1024, 16, 512, 4, 16, 16) \
-	X(720, 16, 256, 6, 8, 15) \
+	X(720, 16, 512, 8, 10, 9) \
 	X(512, 16, 256, 4, 8, 16) \
 	X(480, 16, 256, 4, 8, 15) \
 	X(2880, 4, 512, 12, 16, 15) \
@@ -63,7 +63,7 @@
 	X(1200, 16, 512, 5, 16, 15) \
 	X(1152, 16, 512, 8, 9, 16) \
 	X(960, 16, 512, 4, 16, 15) \
-	X(900, 16, 512, 6, 10, 15) \
+	X(900, 16, 512, 10, 10, 9) \
 	X(768, 16, 256, 16, 16, 3) \
 	X(600, 16, 256, 5, 8, 15)
 
@@ -73,7 +73,7 @@
 // paired row pass) when the full-length tile would have to be narrower than 16 floats; the entries marked "forced only"
 // exist for the CPU/GPU tests of the mechanism on small frames (DSPFFT_FORCE_SPLIT=1).
 #define DSPFFT_COL_HALF_SPECS(X) \
-	X(2160, 16, 512, 8, 9, 15) \
+	X(2160, 16, 512, 12, 10, 9) \
 	X(4320, 16, 1024, 12, 12, 15) /* an 8K frame lives in HBM, where 64-byte row segments beat two workgroups per CU: 882 vs 922 us per roundtrip */ \
 	X(4320, 8, 512, 12, 12, 15) \
 	X(1080, 16, 256, 4, 9, 15)   /* forced only */ \
@@ -105,8 +105,8 @@
 
 #define DSPFFT_COL_SPECS_F64(X)      \
 	X(2160, 4, 512, 12, 12, 15)      \
-	X(1080, 8, 512, 8, 9, 15)        \
-	X(540, 8, 256, 4, 9, 15)         \
+	X(1080, 8, 512, 12, 10, 9)       \
+	X(540, 8, 256, 12, 5, 9)         \
 	X(512, 8, 256, 4, 8, 16)         \
 	X(4096, 4, 1024, 16, 16, 16)     \
 	X(2048, 4, 512, 8, 16, 16)       \

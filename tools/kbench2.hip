@@ -203,6 +203,16 @@ int main()
 		for (size_t i = 0; i < h.size(); i++) h[i] = (float)((i * 2654435761u) % 1000) / 1000.f;
 		for (int f = 0; f < NFR; f++) CHK(hipMemcpy(g_buf + (size_t)f * NF, h.data(), NF * 4, hipMemcpyHostToDevice));
 	}
+	if (getenv("KB_ROWT")) {
+		run<RowSpec<3840, 3, 576, 12, 10, 16>, KIND_REDFT10, true>("ROW 3840x3 T=576 12,10,16");
+		run<RowSpec<3840, 3, 576, 12, 10, 16>, KIND_REDFT01, true>("ROW 3840x3 T=576 12,10,16");
+		run<RowSpec<3840, 3, 640, 12, 10, 16>, KIND_REDFT10, true>("ROW 3840x3 T=640 12,10,16");
+		run<RowSpec<3840, 3, 640, 12, 10, 16>, KIND_REDFT01, true>("ROW 3840x3 T=640 12,10,16");
+		run<RowSpec<3840, 3, 576, 10, 12, 16>, KIND_REDFT10, true>("ROW 3840x3 T=576 10,12,16");
+		run<RowSpec<3840, 3, 576, 10, 12, 16>, KIND_REDFT01, true>("ROW 3840x3 T=576 10,12,16");
+		run<RowSpec<3840, 3, 384, 12, 10, 16>, KIND_REDFT10, true>("ROW 3840x3 T=384 12,10,16");
+		run<RowSpec<3840, 3, 384, 12, 10, 16>, KIND_REDFT01, true>("ROW 3840x3 T=384 12,10,16");
+	}
 	run<RowSpec<3840, 3, 512, 12, 10, 16>, KIND_REDFT10, true>("ROW 3840x3 T=512");
 	run<RowSpec<3840, 3, 512, 12, 10, 16>, KIND_REDFT01, true>("ROW 3840x3 T=512");
 	run<ColSpec<2160, 8, 512, 12, 12, 15>, KIND_REDFT10, false>("COL 2160 K=8 T=512");

@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(S::T, S::WPE) pass_k(const PassArgs a)
 #include "backend.h"
 #include "spec_list.h"
 #include "spec_kernels.h"
-typedef ColHalfSpec<2160, 16, 512, 8, 9, 15> HS;
+typedef ColHalfSpec<2160, 16, 512, 12, 10, 9> HS;
 static cf *g_WM, *g_Hh;
 #endif
 static const int H = 2160, W = 3840, C = 3;
