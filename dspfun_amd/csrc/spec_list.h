@@ -7,7 +7,7 @@
 
 #define DSPFFT_ROW_SPECS(X)            \
 	X(3840, 3, 512, 12, 10, 16)        \
-	X(1920, 3, 256, 4, 15, 16)         \
+	X(1920, 3, 256, 12, 5, 16)         \
 	X(7680, 3, 1024, 16, 15, 16)        \
 	X(960, 3, 192, 2, 16, 15)          \
 	X(256, 3, 192, 8, 16)              \
@@ -83,7 +83,7 @@
 #define DSPFFT_ROW_PAIR_SPECS(X) \
 	X(3840, 3, 512, 12, 10, 16) \
 	X(7680, 3, 1024, 16, 15, 16) \
-	X(1920, 3, 256, 4, 15, 16) \
+	X(1920, 3, 256, 12, 5, 16) \
 	X(512, 3, 64, 16, 16)
 
 // ---- double precision (the fftw_ API: spec and zoom's default COEFF_PRECISION=D build) ----

@@ -215,6 +215,16 @@ int main()
 	}
 	run<RowSpec<3840, 3, 512, 12, 10, 16>, KIND_REDFT10, true>("ROW 3840x3 T=512");
 	run<RowSpec<3840, 3, 512, 12, 10, 16>, KIND_REDFT01, true>("ROW 3840x3 T=512");
+	if (getenv("KB_COLT")) {
+		run<ColSpec<2160, 8, 384, 12, 12, 15>, KIND_REDFT10, false>("COL 2160 K=8 T=384 12,12,15");
+		run<ColSpec<2160, 8, 384, 12, 12, 15>, KIND_REDFT01, false>("COL 2160 K=8 T=384 12,12,15");
+		run<ColSpec<2160, 8, 320, 12, 12, 15>, KIND_REDFT10, false>("COL 2160 K=8 T=320 12,12,15");
+		run<ColSpec<2160, 8, 320, 12, 12, 15>, KIND_REDFT01, false>("COL 2160 K=8 T=320 12,12,15");
+		run<ColSpec<2160, 8, 512, 9, 16, 15>, KIND_REDFT10, false>("COL 2160 K=8 T=512 9,16,15");
+		run<ColSpec<2160, 8, 512, 9, 16, 15>, KIND_REDFT01, false>("COL 2160 K=8 T=512 9,16,15");
+		run<ColSpec<2160, 8, 512, 16, 15, 9>, KIND_REDFT10, false>("COL 2160 K=8 T=512 16,15,9");
+		run<ColSpec<2160, 8, 512, 16, 15, 9>, KIND_REDFT01, false>("COL 2160 K=8 T=512 16,15,9");
+	}
 	run<ColSpec<2160, 8, 512, 12, 12, 15>, KIND_REDFT10, false>("COL 2160 K=8 T=512");
 	run<ColSpec<2160, 8, 512, 12, 12, 15>, KIND_REDFT01, false>("COL 2160 K=8 T=512");
 	return 0;

@@ -39,9 +39,10 @@ template <class S, int KIND>
 static void run(const char *name)
 {
 	PassArgs a; memset((void *)&a, 0, sizeof a);
-	a.in = g_buf; a.out = g_buf; a.N = N; a.kind = KIND; a.C = 1;
+	a.in = g_buf; a.out = g_buf; a.N = N; a.kind = KIND; a.C = S::C;
 	a.T = g_T; a.W = g_W; a.scale = 1.f / 4000.f; a.in_scale0 = a.out_scale0 = 1.f;
-	a.nb0 = LINES; a.nb1 = 1; a.sb0_in = a.sb0_out = N; a.sb1_in = a.sb1_out = 0;
+	const int LINES = ::LINES / S::C;
+	a.nb0 = LINES; a.nb1 = 1; a.sb0_in = a.sb0_out = N * S::C; a.sb1_in = a.sb1_out = 0;
 	auto kern = row_k<S, KIND>;
 	CHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS));
 	int occ = 0; CHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)kern, S::T, S::LDS));
@@ -54,7 +55,7 @@ static void run(const char *name)
 		float ms; CHK(hipEventElapsedTime(&ms, e0, e1)); if (rep && ms < best) best = ms;
 	}
 	CHK(hipGetLastError());
-	const double bytes = 2.0 * LINES * N * 4;
+	const double bytes = 2.0 * LINES * N * S::C * 4;
 	printf("%-44s kind=%d workgroups/CU=%2d waves/CU=%2d lds=%5zu | %7.1f us = %5.2f TB/s (read + write)\n", name, KIND, occ, occ * S::T / 64, S::LDS, best * 1e3, bytes / best / 1e9);
 }
 
@@ -79,5 +80,14 @@ int main()
 	BOTH(64, 64, 15)
 	BOTH(128, 4, 16, 15)
 	BOTH(256, 4, 16, 15)
+	// RGB rows of 1920 pixels (zoom C3, 1080p frames): product = T 256, radices 4, 15, 16 (720 butterflies in the first stage: three rounds)
+#define BOTH3(T, ...) run<RowSpec<1920, 3, T, __VA_ARGS__>, KIND_REDFT10>("RGB T=" #T " radices " #__VA_ARGS__); run<RowSpec<1920, 3, T, __VA_ARGS__>, KIND_REDFT01>("RGB T=" #T " radices " #__VA_ARGS__);
+	BOTH3(256, 4, 15, 16)
+	BOTH3(384, 8, 8, 15)
+	BOTH3(256, 8, 8, 15)
+	BOTH3(384, 6, 10, 16)
+	BOTH3(256, 12, 5, 16)
+	BOTH3(256, 16, 4, 15)
+	BOTH3(512, 8, 8, 15)
 	return 0;
 }
