@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <complex>
+#include <dlfcn.h>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -137,6 +138,11 @@ struct Pass {
 	SpecInfo hspec;
 	PassGeom hpa;
 	int half_nwg = 0;
+	// a kernel compiled at plan time for this pass's geometry (jit_kernels.h; DSPFFT_JIT=1) where spec_list.h has no entry: spa /
+	// spec_nwg describe it like a listed one's, jit_fn is this pass's kind
+	bool jit = false;
+	void *jit_fn = nullptr;
+	int jit_nthr = 0;
 	std::vector<Dim> hostloop;
 	Tables tab;
 	std::string desc;
@@ -294,6 +300,83 @@ std::string radix_string(const FftDesc &F)
 }
 
 // Build the pass along transformed axis `a`.  `first` => reads the user's input strides.
+// ---- plan-time specialisation (DSPFFT_JIT=1) ----
+// Radix order and thread count for a length without an entry in spec_list.h, by the rules the listed entries came out of
+// (tools/kbench*, colbench, wavebench): largest radix first, an odd radix last when there is one (conflict-free last stage);
+// about 22 samples (ROW) / 34 samples (COL) of the tile per thread, rounded to a power of two.
+std::string jit_radices(const FftDesc &F)
+{
+	std::vector<int> r;
+	for (int i = 0; i < F.ns; i++) r.push_back(F.st[i].R);
+	std::sort(r.begin(), r.end(), [](int x, int y) { return x > y; });
+	int odd = -1;
+	for (int i = (int)r.size() - 1; i >= 0; i--) if (r[i] % 2) { odd = i; break; }
+	if (odd >= 0) { const int v = r[odd]; r.erase(r.begin() + odd); r.push_back(v); }
+	std::string s;
+	for (int v : r) s += ", " + std::to_string(v);
+	return s;
+}
+int jit_threads(double want)
+{
+	int t = 64;
+	while (t < 1024 && (double)t * 1.41 < want) t *= 2;
+	return t;
+}
+std::string library_dir()
+{
+	Dl_info info;
+	if (!dladdr((const void *)&library_dir, &info) || !info.dli_fname) return ".";
+	std::string p = info.dli_fname;
+	const size_t k = p.rfind('/');
+	return k == std::string::npos ? "." : p.substr(0, k);
+}
+// DSPFFT_JIT=1 forces it on, =2 off; otherwise the planning effort the caller asked for decides (dspfft_set_plan_effort: the FFTW
+// shim passes FFTW_MEASURE / PATIENT / EXHAUSTIVE on as "this plan will be executed many times", FFTW_ESTIMATE as "plan fast")
+int g_plan_effort = 0;
+bool jit_enabled()
+{
+	const int e = env_int("DSPFFT_JIT");
+	return be_jit_available() && (e == 1 || (e != 2 && g_plan_effort > 0));
+}
+
+// ROW: exact (N, C).  Returns true and fills P.jit* on success.
+bool jit_row(const dspfft_plan_s *pl, Pass &P, int N, int C, long long nlines, const FftDesc &F, int kind)
+{
+	const size_t es = pl->f64 ? 8 : 4;
+	const size_t lds = (size_t)C * (N / 2 + 16) * 2 * es;
+	if (F.ns < 1 || lds > be_max_lds()) return false;
+	const int T = jit_threads((double)N * C / 22.0);
+	const std::string type = std::string("RowSpecT<") + (pl->f64 ? "double" : "float") + ", " + std::to_string(N) + ", " + std::to_string(C) + ", " + std::to_string(T) + jit_radices(F) + ">";
+	void *fn[2];
+	char log[2048] = "";
+	if (be_jit_build(type.c_str(), 0, library_dir().c_str(), fn, log, sizeof log)) { fprintf(stderr, "dspfft: plan-time compilation of %s failed, using the runtime-geometry kernel\n%s\n", type.c_str(), log); return false; }
+	P.jit = true; P.jit_fn = fn[kind]; P.jit_nthr = T; P.spa = P.pa; P.spec_nwg = (int)nlines;
+	char buf[320];
+	snprintf(buf, sizeof buf, "axis %d: ROW+%s N=%d C=%d compiled at plan time: %s, lines=%lld", P.axis, pl->f64 ? " f64" : "", N, C, type.c_str(), nlines);
+	P.desc = buf;
+	return true;
+}
+// COL: tile width by the LDS it takes (16 samples up to 80 KB, then 8, then 4; doubles half of that), the inner extent a multiple of it
+bool jit_col(const dspfft_plan_s *pl, Pass &P, int N, int inner, const FftDesc &F, int kind)
+{
+	const size_t es = pl->f64 ? 8 : 4;
+	int K = pl->f64 ? 8 : 16;
+	while (K >= (pl->f64 ? 2 : 4) && ((size_t)(N + 16) * K * es > (K == (pl->f64 ? 8 : 16) ? 80u * 1024 : 150u * 1024) || inner % K)) K /= 2;
+	if (K < (pl->f64 ? 2 : 4) || F.ns < 1) return false;
+	const int T = jit_threads((double)N * K * (pl->f64 ? 2 : 1) / 34.0);
+	const std::string type = std::string("ColSpecT<") + (pl->f64 ? "double" : "float") + ", " + std::to_string(N) + ", " + std::to_string(K) + ", " + std::to_string(T) + jit_radices(F) + ">";
+	void *fn[2];
+	char log[2048] = "";
+	if (be_jit_build(type.c_str(), 1, library_dir().c_str(), fn, log, sizeof log)) { fprintf(stderr, "dspfft: plan-time compilation of %s failed, using the runtime-geometry kernel\n%s\n", type.c_str(), log); return false; }
+	P.jit = true; P.jit_fn = fn[kind]; P.jit_nthr = T; P.spa = P.pa;
+	P.spa.K = K; P.spa.B = K / 2; P.spa.ntiles = inner / K;
+	P.spec_nwg = P.spa.ntiles * P.pa.nb0 * P.pa.nb1;
+	char buf[320];
+	snprintf(buf, sizeof buf, "axis %d: COL+%s N=%d K=%d compiled at plan time: %s, tiles=%d wgs=%d", P.axis, pl->f64 ? " f64" : "", N, K, type.c_str(), P.spa.ntiles, P.spec_nwg);
+	P.desc = buf;
+	return true;
+}
+
 int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 {
 	memset(&P.pa, 0, sizeof P.pa); memset(&P.da, 0, sizeof P.da); memset(&P.g, 0, sizeof P.g);
@@ -378,6 +461,8 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 					P.has_spec = true; P.spa = pa; P.spec_nwg = (int)nlines;
 					snprintf(buf, sizeof buf, "axis %d: ROW*%s N=%d C=%d spec#%d threads=%d lines=%lld lds=%zu", a, tag, N, C, P.spec.id, P.spec.nthr, nlines, P.spec.lds);
 					P.desc = buf;
+				} else if (aligned && jit_enabled() && lines.size() <= 2) {
+					jit_row(pl, P, N, C, nlines, F, kind);
 				}
 				return 0;
 			}
@@ -449,6 +534,8 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 					P.spec_nwg = P.spa.ntiles * pa.nb0 * pa.nb1;
 					snprintf(buf, sizeof buf, "axis %d: COL*%s N=%d K=%d spec#%d threads=%d inner=%d tiles=%d wgs=%d lds=%zu (generic fallback: K=%d)", a, tag, N, P.spec.P, P.spec.id, P.spec.nthr, inner.n, P.spa.ntiles, P.spec_nwg, P.spec.lds, K);
 					P.desc = buf;
+				} else if (aligned && jit_enabled() && rest.size() <= 2) {
+					jit_col(pl, P, N, inner.n, F, kind);
 				}
 				return 0;
 			}
@@ -540,11 +627,11 @@ int run_pass(const dspfft_plan_s *pl, const Pass &P, const R *in, R *out, bool l
 				// the specialised kernels move whole pixels (ROW: C samples) or four samples (COL) per access
 				const uintptr_t al = sizeof(R) * (P.type == Pass::ROW ? (P.pa.C == 2 || P.pa.C == 4 ? P.pa.C : 1) : 4);
 				const bool ptr_ok = ((al - 1) & ((uintptr_t)(in + oin) | (uintptr_t)(out + oout))) == 0;
-				use_spec = P.has_spec && ptr_ok;
+				use_spec = (P.has_spec || P.jit) && ptr_ok;
 				if (use_spec) {
 					PassArgsT<R> a;
 					fill_args(a, P.spa, pl, P, in + oin, out + oout, scale, fz);
-					rc = be_launch_spec(P.type == Pass::COL, P.spec.id, a, P.spec_nwg, stream);
+					rc = P.jit ? be_jit_launch(P.jit_fn, &a, P.spec_nwg, P.jit_nthr, stream) : be_launch_spec(P.type == Pass::COL, P.spec.id, a, P.spec_nwg, stream);
 				}
 			}
 			if (P.type == Pass::BLUE) {
@@ -1230,6 +1317,7 @@ extern "C" int dspfft_plan_describe(dspfft_plan pl, char *buf, size_t buflen)
 }
 
 extern "C" size_t dspfft_plan_algorithmic_bytes(dspfft_plan pl) { return pl ? pl->alg_bytes : 0; }
+extern "C" void dspfft_set_plan_effort(int effort) { g_plan_effort = effort; }
 
 extern "C" int dspfft_scan_zigzag(uint32_t *d_lin, uint32_t w, uint32_t h, uint64_t first, uint64_t count, void *s)
 {

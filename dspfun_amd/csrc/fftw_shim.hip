@@ -64,14 +64,18 @@ struct Shim {
 };
 
 Shim *make_plan(int rank, const int *n, int howmany, void *in, const int *inembed, int istride, int idist,
-                void *out, const int *onembed, int ostride, int odist, const int *kinds, bool f64)
+                void *out, const int *onembed, int ostride, int odist, const int *kinds, bool f64, unsigned flags)
 {
 	if (!in || !out || !n || !kinds) { fprintf(stderr, "dspfft: plan_many_r2r: null argument\n"); return nullptr; }
 	Shim *s = new Shim();
 	s->es = f64 ? sizeof(double) : sizeof(float); s->h_in = in; s->h_out = out;
+	// FFTW_ESTIMATE = plan fast; FFTW_MEASURE / PATIENT / EXHAUSTIVE (scan.c:359, motion.c:93-103) = this plan will run many times:
+	// frame sizes without a listed specialised kernel get one compiled now (dspfft_set_plan_effort)
+	dspfft_set_plan_effort((flags & FFTW_ESTIMATE) ? 0 : 1);
 	// fftw_ (double) plans compute in double on the device, as the reference's default build does on the CPU
 	const int rc = f64 ? dspfft_plan_many_r2r_f64(&s->plan, rank, n, howmany, inembed, istride, idist, onembed, ostride, odist, kinds)
 	                   : dspfft_plan_many_r2r(&s->plan, rank, n, howmany, inembed, istride, idist, onembed, ostride, odist, kinds);
+	dspfft_set_plan_effort(0);
 	if (rc) {
 		fprintf(stderr, "dspfft: plan_many_r2r failed: %s\n", dspfft_last_error());
 		delete s; return nullptr;
@@ -129,17 +133,17 @@ extern "C" {
 float *fftwf_alloc_real(size_t n) { return (float *)pinned_alloc(n * sizeof(float)); }
 void fftwf_free(void *p) { pinned_free(p); }
 fftwf_plan fftwf_plan_many_r2r(int rank, const int *n, int howmany, float *in, const int *inembed, int istride, int idist,
-                               float *out, const int *onembed, int ostride, int odist, const fftwf_r2r_kind *kind, unsigned)
+                               float *out, const int *onembed, int ostride, int odist, const fftwf_r2r_kind *kind, unsigned flags)
 {
 	int k[3] = {0, 0, 0};
 	if (rank < 1 || rank > 3) { fprintf(stderr, "dspfft: rank %d unsupported\n", rank); return nullptr; }
 	for (int a = 0; a < rank; a++) k[a] = (int)kind[a];
-	return (fftwf_plan)make_plan(rank, n, howmany, in, inembed, istride, idist, out, onembed, ostride, odist, k, false);
+	return (fftwf_plan)make_plan(rank, n, howmany, in, inembed, istride, idist, out, onembed, ostride, odist, k, false, flags);
 }
-fftwf_plan fftwf_plan_r2r_2d(int n0, int n1, float *in, float *out, fftwf_r2r_kind k0, fftwf_r2r_kind k1, unsigned)
+fftwf_plan fftwf_plan_r2r_2d(int n0, int n1, float *in, float *out, fftwf_r2r_kind k0, fftwf_r2r_kind k1, unsigned flags)
 {
 	int n[2] = {n0, n1}, k[2] = {(int)k0, (int)k1};
-	return (fftwf_plan)make_plan(2, n, 1, in, nullptr, 1, 0, out, nullptr, 1, 0, k, false);
+	return (fftwf_plan)make_plan(2, n, 1, in, nullptr, 1, 0, out, nullptr, 1, 0, k, false, flags);
 }
 void fftwf_execute(const fftwf_plan p) { run((Shim *)p); }
 void fftwf_destroy_plan(fftwf_plan p) { destroy((Shim *)p); }
@@ -153,17 +157,17 @@ int fftwf_export_wisdom_to_filename(const char *f) { FILE *fp = f ? fopen(f, "w"
 double *fftw_alloc_real(size_t n) { return (double *)pinned_alloc(n * sizeof(double)); }
 void fftw_free(void *p) { pinned_free(p); }
 fftw_plan fftw_plan_many_r2r(int rank, const int *n, int howmany, double *in, const int *inembed, int istride, int idist,
-                             double *out, const int *onembed, int ostride, int odist, const fftw_r2r_kind *kind, unsigned)
+                             double *out, const int *onembed, int ostride, int odist, const fftw_r2r_kind *kind, unsigned flags)
 {
 	int k[3] = {0, 0, 0};
 	if (rank < 1 || rank > 3) { fprintf(stderr, "dspfft: rank %d unsupported\n", rank); return nullptr; }
 	for (int a = 0; a < rank; a++) k[a] = (int)kind[a];
-	return (fftw_plan)make_plan(rank, n, howmany, in, inembed, istride, idist, out, onembed, ostride, odist, k, true);
+	return (fftw_plan)make_plan(rank, n, howmany, in, inembed, istride, idist, out, onembed, ostride, odist, k, true, flags);
 }
-fftw_plan fftw_plan_r2r_2d(int n0, int n1, double *in, double *out, fftw_r2r_kind k0, fftw_r2r_kind k1, unsigned)
+fftw_plan fftw_plan_r2r_2d(int n0, int n1, double *in, double *out, fftw_r2r_kind k0, fftw_r2r_kind k1, unsigned flags)
 {
 	int n[2] = {n0, n1}, k[2] = {(int)k0, (int)k1};
-	return (fftw_plan)make_plan(2, n, 1, in, nullptr, 1, 0, out, nullptr, 1, 0, k, true);
+	return (fftw_plan)make_plan(2, n, 1, in, nullptr, 1, 0, out, nullptr, 1, 0, k, true, flags);
 }
 void fftw_execute(const fftw_plan p) { run((Shim *)p); }
 void fftw_destroy_plan(fftw_plan p) { destroy((Shim *)p); }

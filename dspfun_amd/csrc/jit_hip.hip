@@ -1,0 +1,161 @@
+// jit_hip.hip -- plan-time compilation of specialised kernels (jit_kernels.h) with hiprtc, for frame sizes without an entry in
+// spec_list.h.  One program per (RowSpecT | ColSpecT) instance holds both transform kinds; it is compiled once per process.
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+#include <glob.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "backend.h"
+
+namespace dspfft {
+
+namespace {
+struct Built { hipModule_t mod; hipFunction_t fn[2]; };
+std::mutex g_mu;
+std::map<std::string, Built> g_cache;        // key: the spec's type name
+
+std::string clang_resource_include()
+{
+	const char *root = getenv("ROCM_PATH");
+	const std::string pat = std::string(root && *root ? root : "/opt/rocm") + "/lib/llvm/lib/clang/*/include";
+	glob_t g;
+	std::string r;
+	if (glob(pat.c_str(), 0, nullptr, &g) == 0 && g.gl_pathc > 0) r = g.gl_pathv[g.gl_pathc - 1];
+	globfree(&g);
+	return r;
+}
+// Disk cache of compiled code objects: $DSPFFT_JIT_CACHE, else $XDG_CACHE_HOME/dspfft-jit, else $HOME/.cache/dspfft-jit.  The key
+// covers the spec and the library build (size + mtime of the headers' directory's library), so a rebuilt library recompiles.
+std::string cache_dir()
+{
+	const char *e = getenv("DSPFFT_JIT_CACHE");
+	std::string d;
+	if (e && *e) d = e;
+	else if ((e = getenv("XDG_CACHE_HOME")) && *e) d = std::string(e) + "/dspfft-jit";
+	else if ((e = getenv("HOME")) && *e) d = std::string(e) + "/.cache/dspfft-jit";
+	else return "";
+	for (size_t i = 1; i <= d.size(); i++) if (i == d.size() || d[i] == '/') { const std::string p = d.substr(0, i); mkdir(p.c_str(), 0755); }
+	return d;
+}
+std::string cache_file(const std::string &spec, const char *incdir)
+{
+	const std::string d = cache_dir();
+	if (d.empty()) return "";
+	struct stat st;
+	std::string key = spec + "|";
+	if (stat((std::string(incdir) + "/libdspfft_hip.so").c_str(), &st) == 0) key += std::to_string((long long)st.st_size) + "." + std::to_string((long long)st.st_mtime);
+	unsigned long long h = 1469598103934665603ull;
+	for (unsigned char ch : key) { h ^= ch; h *= 1099511628211ull; }
+	char name[64];
+	snprintf(name, sizeof name, "/%016llx.co", h);
+	return d + name;
+}
+// file: "DSPJIT1\n", lowered name 0, "\n", lowered name 1, "\n", code object
+bool cache_load(const std::string &path, std::string lowered[2], std::vector<char> &code)
+{
+	FILE *f = path.empty() ? nullptr : fopen(path.c_str(), "rb");
+	if (!f) return false;
+	std::vector<char> all;
+	char buf[65536];
+	size_t n;
+	while ((n = fread(buf, 1, sizeof buf, f)) > 0) all.insert(all.end(), buf, buf + n);
+	fclose(f);
+	const char *p = all.data(), *end = p + all.size();
+	auto line = [&](std::string &out) { const char *q = (const char *)memchr(p, '\n', (size_t)(end - p)); if (!q) return false; out.assign(p, q); p = q + 1; return true; };
+	std::string magic;
+	if (!line(magic) || magic != "DSPJIT1" || !line(lowered[0]) || !line(lowered[1]) || p >= end) return false;
+	code.assign(p, end);
+	return true;
+}
+void cache_store(const std::string &path, const std::string lowered[2], const std::vector<char> &code)
+{
+	if (path.empty()) return;
+	const std::string tmp = path + "." + std::to_string((long long)getpid());
+	FILE *f = fopen(tmp.c_str(), "wb");
+	if (!f) return;
+	fprintf(f, "DSPJIT1\n%s\n%s\n", lowered[0].c_str(), lowered[1].c_str());
+	const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+	fclose(f);
+	if (ok) rename(tmp.c_str(), path.c_str()); else unlink(tmp.c_str());
+}
+}  // namespace
+
+bool be_jit_available() { return true; }
+
+// spec_type: e.g. "RowSpecT<float, 1000, 3, 128, 5, 10, 10>"; is_col picks jit_col / jit_row.  funcs[kind] receives the kernels.
+int be_jit_build(const char *spec_type, int is_col, const char *incdir, void **funcs, char *log, size_t loglen)
+{
+	std::lock_guard<std::mutex> lock(g_mu);
+	auto it = g_cache.find(spec_type);
+	if (it != g_cache.end()) { funcs[0] = it->second.fn[0]; funcs[1] = it->second.fn[1]; return 0; }
+	const std::string cpath = cache_file(spec_type, incdir);
+	{
+		std::string lowered[2];
+		std::vector<char> code;
+		Built b;
+		if (cache_load(cpath, lowered, code) && hipModuleLoadData(&b.mod, code.data()) == hipSuccess) {
+			if (hipModuleGetFunction(&b.fn[0], b.mod, lowered[0].c_str()) == hipSuccess && hipModuleGetFunction(&b.fn[1], b.mod, lowered[1].c_str()) == hipSuccess) {
+				g_cache[spec_type] = b;
+				funcs[0] = b.fn[0]; funcs[1] = b.fn[1];
+				return 0;
+			}
+			(void)hipModuleUnload(b.mod);
+		}
+	}
+	const std::string kern = is_col ? "jit_col" : "jit_row";
+	std::string names[2];
+	for (int k = 0; k < 2; k++) names[k] = "dspfft::" + kern + "<dspfft::" + spec_type + ", " + std::to_string(k) + ">";
+	std::string src = "#include \"jit_kernels.h\"\n";
+	hiprtcProgram prog;
+	if (hiprtcCreateProgram(&prog, src.c_str(), "dspfft_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return -1;
+	for (int k = 0; k < 2; k++) hiprtcAddNameExpression(prog, names[k].c_str());
+	const char *root = getenv("ROCM_PATH");
+	const std::string inc1 = std::string("-I") + incdir, inc2 = std::string("-I") + (root && *root ? root : "/opt/rocm") + "/include", inc3 = "-I" + clang_resource_include();
+	const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fno-slp-vectorize", inc1.c_str(), inc2.c_str(), inc3.c_str()};
+	const hiprtcResult rc = hiprtcCompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts);
+	if (rc != HIPRTC_SUCCESS) {
+		size_t ls = 0;
+		hiprtcGetProgramLogSize(prog, &ls);
+		std::string l(ls, 0);
+		if (ls) hiprtcGetProgramLog(prog, &l[0]);
+		if (log && loglen) snprintf(log, loglen, "%s", l.c_str());
+		hiprtcDestroyProgram(&prog);
+		return -2;
+	}
+	size_t cs = 0;
+	hiprtcGetCodeSize(prog, &cs);
+	std::vector<char> code(cs);
+	hiprtcGetCode(prog, code.data());
+	Built b;
+	if (hipModuleLoadData(&b.mod, code.data()) != hipSuccess) { hiprtcDestroyProgram(&prog); return -3; }
+	std::string low[2];
+	for (int k = 0; k < 2; k++) {
+		const char *lowered = nullptr;
+		if (hiprtcGetLoweredName(prog, names[k].c_str(), &lowered) != HIPRTC_SUCCESS || hipModuleGetFunction(&b.fn[k], b.mod, lowered) != hipSuccess) {
+			hiprtcDestroyProgram(&prog);
+			return -4;
+		}
+		low[k] = lowered;
+	}
+	hiprtcDestroyProgram(&prog);
+	cache_store(cpath, low, code);
+	g_cache[spec_type] = b;
+	funcs[0] = b.fn[0]; funcs[1] = b.fn[1];
+	return 0;
+}
+
+int be_jit_launch(void *func, const void *args, int nwg, int nthr, void *stream)
+{
+	void *params[1] = {const_cast<void *>(args)};
+	const hipError_t e = hipModuleLaunchKernel((hipFunction_t)func, (unsigned)nwg, 1, 1, (unsigned)nthr, 1, 1, 0, (hipStream_t)stream, params, nullptr);
+	return e == hipSuccess ? 0 : (int)e;
+}
+
+}  // namespace dspfft

@@ -1,6 +1,7 @@
 """GPU (-m gpu): parity of the HIP product library (through the C ABI of include/dspfft.h) against
 the oracle.  float tolerance from BASELINE.json north_star: max|gpu-ref| <= 1e-5 * max|ref| (and
 rms <= 1e-5 * rms(ref)); integer scan order bit-exact."""
+import os
 import numpy as np
 import pytest
 
@@ -905,3 +906,67 @@ def test_fused_block_roundtrip_gpu(gpu, block, monkeypatch):
     gpu.cuda.synchronize()
     back = a[0].reshape(D // bd, H // bh, W // bw, bd, bh, bw).transpose(0, 3, 1, 4, 2, 5).reshape(D, H, W)
     assert np.array_equal(dout.cpu().numpy(), back) and int(coded.item()) == a[1]
+
+
+# ---- plan-time specialisation (DSPFFT_JIT=1): frame sizes without an entry in spec_list.h get RowSpecT / ColSpecT kernels compiled with hiprtc ----
+@pytest.mark.parametrize("h,w,c,dtype", [(1000, 1500, 3, "f32"), (750, 1000, 3, "f32"), (1500, 2000, 1, "f32"), (1350, 2400, 3, "f32"), (750, 1000, 3, "f64")])
+def test_plan_time_specialisation(gpu, h, w, c, dtype, monkeypatch):
+    from dspfun_amd import Plan, REDFT10, REDFT01
+    monkeypatch.setenv("DSPFFT_JIT", "1")
+    f64 = dtype == "f64"
+    x = ol.synth_f32(h + 3 * w, h * w * c).reshape(h, w, c)
+    x = x.astype(np.float64) * (1 + 2.0 ** -31) if f64 else x
+    fwd = Plan.image(h, w, c, REDFT10, dtype=dtype)
+    inv = Plan.image(h, w, c, REDFT01, dtype=dtype).set_scale(1.0 / (4.0 * h * w))
+    assert fwd.describe().count("compiled at plan time") == 2 and inv.describe().count("compiled at plan time") == 2, fwd.describe()
+    d = gpu.from_numpy(x.copy()).to("cuda:0")
+    o = gpu.empty_like(d)
+    fwd.execute(d.data_ptr(), o.data_ptr())
+    gpu.cuda.synchronize()
+    ref = ol.dct2d_interleaved(x.astype(np.float64), REDFT10, impl="port", threads=8)
+    check(o.cpu().numpy(), ref, tol=1e-13 if f64 else TOL)
+    inv.execute(o.data_ptr())
+    gpu.cuda.synchronize()
+    assert np.abs(o.cpu().numpy() - x).max() <= (1e-13 if f64 else 2e-6)
+    # the fused scan step runs on the compiled kernels too (masked loads, accumulating stores)
+    if not f64:
+        from dspfun_amd import _lib
+        L = _lib.load()
+        coeffs = gpu.from_numpy(x.copy()).to("cuda:0")
+        Plan.image(h, w, c, REDFT10).set_scale(1.0 / (4.0 * h * w)).execute(coeffs.data_ptr())
+        ids = gpu.zeros(h * w, dtype=gpu.int32, device="cuda:0")
+        assert L.dspfft_scan_zigzag_frame_ids(ids.data_ptr(), w, h, (h * w + 4) // 5, None) == 0
+        acc = gpu.empty_like(coeffs); work = gpu.empty_like(coeffs)
+        assert L.dspfft_broadcast_dc(acc.data_ptr(), coeffs.data_ptr(), w * h, c, None) == 0
+        p01 = Plan.image(h, w, c, REDFT01)
+        for f in range(5):
+            p01.execute_masked_accumulate(coeffs.data_ptr(), work.data_ptr(), acc.data_ptr(), ids.data_ptr(), f, c)
+        gpu.cuda.synchronize()
+        assert float((acc.cpu() - gpu.from_numpy(x)).abs().max()) <= 5e-6
+
+
+def test_plan_effort_and_disk_cache(gpu, monkeypatch, tmp_path):
+    """dspfft_set_plan_effort(1) compiles the kernels of an unlisted size at plan time and leaves the code objects in the disk cache
+    ($DSPFFT_JIT_CACHE; a later process loads them in about a millisecond instead of compiling for a second or two); effort 0 keeps the
+    runtime-geometry kernels; DSPFFT_JIT=2 overrides"""
+    from dspfun_amd import Plan, _lib, REDFT10
+    L = _lib.load()
+    monkeypatch.delenv("DSPFFT_JIT", raising=False)
+    monkeypatch.setenv("DSPFFT_JIT_CACHE", str(tmp_path / "jit"))
+    h, w, c = 700, 900, 3
+    assert "compiled at plan time" not in Plan.image(h, w, c, REDFT10).describe()
+    L.dspfft_set_plan_effort(1)
+    try:
+        p = Plan.image(h, w, c, REDFT10)
+        assert p.describe().count("compiled at plan time") == 2, p.describe()
+        files = sorted(os.listdir(tmp_path / "jit"))
+        assert len(files) == 2 and all(f.endswith(".co") for f in files)
+        monkeypatch.setenv("DSPFFT_JIT", "2")
+        assert "compiled at plan time" not in Plan.image(h, w, c, REDFT10).describe()
+    finally:
+        L.dspfft_set_plan_effort(0)
+    x = ol.synth_f32(5, h * w * c).reshape(h, w, c)
+    d = gpu.from_numpy(x.copy()).to("cuda:0")
+    p.execute(d.data_ptr())
+    gpu.cuda.synchronize()
+    check(d.cpu().numpy(), ol.dct2d_interleaved(x.astype(np.float64), REDFT10, impl="port", threads=8))
