@@ -71,6 +71,8 @@ def bind(lib):
     lib.dspfft_execute_f64.argtypes = [vp, vp, vp, vp]
     lib.dspfft_execute_masked_accumulate_f64.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, C.c_int, vp]
     lib.dspfft_plan_scan_prepare.argtypes = [vp, vp, C.c_int, vp]
+    lib.dspfft_set_plan_effort.argtypes = [C.c_int]
+    lib.dspfft_set_plan_effort.restype = None
     lib.dspfft_plan_num_passes.argtypes = [vp]
     lib.dspfft_execute_pass.argtypes = [vp, C.c_int, vp, vp, vp]
     lib.dspfft_destroy_plan.argtypes = [vp]

@@ -24,6 +24,12 @@ def _ia(v):
     return None if v is None else (C.c_int * len(v))(*[int(x) for x in v])
 
 
+def set_plan_effort(effort, lib=None):
+    """dspfft_set_plan_effort: > 0 lets the plans made afterwards compile kernels for frame sizes spec_list.h does not list (FFTW_MEASURE's
+    meaning: the plan will run many times); 0 (default) plans at once on the runtime-geometry kernels"""
+    (lib or _lib.load()).dspfft_set_plan_effort(int(effort))
+
+
 class Plan:
     """dtype "f32" (default; the fftwf_ API, COEFF_PRECISION=F) or "f64" (the fftw_ API of spec's, zoom's and
     applybasis's default build, include/precision.h:50-53): buffers, arithmetic and fused scales in that type."""
