@@ -339,20 +339,87 @@ bool jit_enabled()
 	return be_jit_available() && (e == 1 || (e != 2 && g_plan_effort > 0));
 }
 
+// Planning effort 2 (FFTW_PATIENT / FFTW_EXHAUSTIVE, DSPFFT_JIT_TUNE=1): compile a handful of candidates -- the rule's choice, the
+// planner's own radix order, half and twice the threads, the next narrower column tile -- run each on a scratch buffer laid out like
+// the plan's data and keep the fastest.  Every candidate lands in the disk cache; only the timing (milliseconds) is repeated later.
+struct JitCand { std::string type; int T, K; };
+bool jit_tune() { return env_int("DSPFFT_JIT_TUNE") == 1 || (env_int("DSPFFT_JIT_TUNE") != 2 && g_plan_effort >= 2); }
+std::string planner_radices(const FftDesc &F)
+{
+	std::string s;
+	for (int i = 0; i < F.ns; i++) s += ", " + std::to_string(F.st[i].R);
+	return s;
+}
+size_t plan_span(const dspfft_plan_s *pl)
+{
+	long long span = 1;
+	for (int a = 0; a < pl->rank; a++) span += (long long)(pl->n[a] - 1) * std::max(pl->axes[a].is, pl->axes[a].os);
+	for (const Dim &b : pl->batches) span += (long long)(b.n - 1) * std::max(b.is, b.os);
+	return (size_t)span;
+}
+template <class R> void fill_args(PassArgsT<R> &a, const PassGeom &g, const dspfft_plan_s *pl, const Pass &P, const R *in, R *out, double scale, const struct Fuse &fz);
+template <class R>
+float jit_time_t(const dspfft_plan_s *pl, const Pass &P, const PassGeom &g, void *fn, int nwg, int nthr, void *scratch);
+
+// fills P.jit* with the (fastest) candidate that compiles; geometry of candidate i through `geom(i, g, nwg)`
+template <class G>
+bool jit_pick(const dspfft_plan_s *pl, Pass &P, int is_col, const std::vector<JitCand> &cands, int kind, G geom, JitCand &chosen)
+{
+	const std::string dir = library_dir();
+	const bool tune = jit_tune() && cands.size() > 1;
+	void *scratch = nullptr;
+	if (tune) {
+		const size_t bytes = plan_span(pl) * (pl->f64 ? 8 : 4);
+		scratch = be_alloc(bytes);
+		if (scratch && be_zero(scratch, bytes, nullptr)) { be_free(scratch); scratch = nullptr; }
+	}
+	float best = 0.f;
+	bool have = false;
+	for (size_t i = 0; i < cands.size(); i++) {
+		void *fn[2];
+		char log[2048] = "";
+		if (be_jit_build(cands[i].type.c_str(), is_col, dir.c_str(), fn, log, sizeof log)) {
+			if (i == 0) fprintf(stderr, "dspfft: plan-time compilation of %s failed\n%s\n", cands[i].type.c_str(), log);
+			continue;
+		}
+		PassGeom g = P.pa;
+		int nwg = 0;
+		geom(cands[i], g, nwg);
+		float ms = 0.f;
+		if (tune && scratch) {
+			ms = pl->f64 ? jit_time_t<double>(pl, P, g, fn[kind], nwg, cands[i].T, scratch) : jit_time_t<float>(pl, P, g, fn[kind], nwg, cands[i].T, scratch);
+			if (ms <= 0.f) continue;
+		}
+		if (!have || (tune && scratch && ms < best)) {
+			have = true; best = ms; chosen = cands[i];
+			P.jit = true; P.jit_fn = fn[kind]; P.jit_nthr = cands[i].T; P.spa = g; P.spec_nwg = nwg;
+		}
+		if (!(tune && scratch)) break;
+	}
+	be_free(scratch);
+	return have;
+}
+
 // ROW: exact (N, C).  Returns true and fills P.jit* on success.
 bool jit_row(const dspfft_plan_s *pl, Pass &P, int N, int C, long long nlines, const FftDesc &F, int kind)
 {
 	const size_t es = pl->f64 ? 8 : 4;
 	const size_t lds = (size_t)C * (N / 2 + 16) * 2 * es;
 	if (F.ns < 1 || lds > be_max_lds()) return false;
-	const int T = jit_threads((double)N * C / 22.0);
-	const std::string type = std::string("RowSpecT<") + (pl->f64 ? "double" : "float") + ", " + std::to_string(N) + ", " + std::to_string(C) + ", " + std::to_string(T) + jit_radices(F) + ">";
-	void *fn[2];
-	char log[2048] = "";
-	if (be_jit_build(type.c_str(), 0, library_dir().c_str(), fn, log, sizeof log)) { fprintf(stderr, "dspfft: plan-time compilation of %s failed, using the runtime-geometry kernel\n%s\n", type.c_str(), log); return false; }
-	P.jit = true; P.jit_fn = fn[kind]; P.jit_nthr = T; P.spa = P.pa; P.spec_nwg = (int)nlines;
+	const int T0 = jit_threads((double)N * C / 22.0);
+	const std::string head = std::string("RowSpecT<") + (pl->f64 ? "double" : "float") + ", " + std::to_string(N) + ", " + std::to_string(C) + ", ";
+	std::vector<JitCand> cands;
+	auto add = [&](int T, const std::string &rad) {
+		if (T < 64 || T > 1024) return;
+		JitCand c{head + std::to_string(T) + rad + ">", T, 0};
+		for (const JitCand &o : cands) if (o.type == c.type) return;
+		cands.push_back(c);
+	};
+	add(T0, jit_radices(F)); add(T0, planner_radices(F)); add(T0 * 2, jit_radices(F)); add(T0 / 2, jit_radices(F)); add(T0 * 2, planner_radices(F));
+	JitCand c;
+	if (!jit_pick(pl, P, 0, cands, kind, [&](const JitCand &, PassGeom &, int &nwg) { nwg = (int)nlines; }, c)) return false;
 	char buf[320];
-	snprintf(buf, sizeof buf, "axis %d: ROW+%s N=%d C=%d compiled at plan time: %s, lines=%lld", P.axis, pl->f64 ? " f64" : "", N, C, type.c_str(), nlines);
+	snprintf(buf, sizeof buf, "axis %d: ROW+%s N=%d C=%d compiled at plan time: %s, lines=%lld", P.axis, pl->f64 ? " f64" : "", N, C, c.type.c_str(), nlines);
 	P.desc = buf;
 	return true;
 }
@@ -360,19 +427,25 @@ bool jit_row(const dspfft_plan_s *pl, Pass &P, int N, int C, long long nlines, c
 bool jit_col(const dspfft_plan_s *pl, Pass &P, int N, int inner, const FftDesc &F, int kind)
 {
 	const size_t es = pl->f64 ? 8 : 4;
-	int K = pl->f64 ? 8 : 16;
-	while (K >= (pl->f64 ? 2 : 4) && ((size_t)(N + 16) * K * es > (K == (pl->f64 ? 8 : 16) ? 80u * 1024 : 150u * 1024) || inner % K)) K /= 2;
-	if (K < (pl->f64 ? 2 : 4) || F.ns < 1) return false;
-	const int T = jit_threads((double)N * K * (pl->f64 ? 2 : 1) / 34.0);
-	const std::string type = std::string("ColSpecT<") + (pl->f64 ? "double" : "float") + ", " + std::to_string(N) + ", " + std::to_string(K) + ", " + std::to_string(T) + jit_radices(F) + ">";
-	void *fn[2];
-	char log[2048] = "";
-	if (be_jit_build(type.c_str(), 1, library_dir().c_str(), fn, log, sizeof log)) { fprintf(stderr, "dspfft: plan-time compilation of %s failed, using the runtime-geometry kernel\n%s\n", type.c_str(), log); return false; }
-	P.jit = true; P.jit_fn = fn[kind]; P.jit_nthr = T; P.spa = P.pa;
-	P.spa.K = K; P.spa.B = K / 2; P.spa.ntiles = inner / K;
-	P.spec_nwg = P.spa.ntiles * P.pa.nb0 * P.pa.nb1;
+	const int Kmax = pl->f64 ? 8 : 16, Kmin = pl->f64 ? 2 : 4;
+	int K = Kmax;
+	while (K >= Kmin && ((size_t)(N + 16) * K * es > (K == Kmax ? 80u * 1024 : 150u * 1024) || inner % K)) K /= 2;
+	if (K < Kmin || F.ns < 1) return false;
+	const std::string head = std::string("ColSpecT<") + (pl->f64 ? "double" : "float") + ", " + std::to_string(N) + ", ";
+	std::vector<JitCand> cands;
+	auto add = [&](int k, int T, const std::string &rad) {
+		if (k < Kmin || inner % k || T < 64 || T > 1024 || (size_t)(N + 16) * k * es > 150u * 1024) return;
+		JitCand c{head + std::to_string(k) + ", " + std::to_string(T) + rad + ">", T, k};
+		for (const JitCand &o : cands) if (o.type == c.type) return;
+		cands.push_back(c);
+	};
+	auto threads = [&](int k) { return jit_threads((double)N * k * (pl->f64 ? 2 : 1) / 34.0); };
+	add(K, threads(K), jit_radices(F)); add(K, threads(K), planner_radices(F)); add(K, threads(K) * 2, jit_radices(F)); add(K, threads(K) / 2, jit_radices(F));
+	add(K / 2, threads(K / 2), jit_radices(F)); add(K * 2, threads(K * 2), jit_radices(F));
+	JitCand c;
+	if (!jit_pick(pl, P, 1, cands, kind, [&](const JitCand &cd, PassGeom &g, int &nwg) { g.K = cd.K; g.B = cd.K / 2; g.ntiles = inner / cd.K; nwg = g.ntiles * g.nb0 * g.nb1; }, c)) return false;
 	char buf[320];
-	snprintf(buf, sizeof buf, "axis %d: COL+%s N=%d K=%d compiled at plan time: %s, tiles=%d wgs=%d", P.axis, pl->f64 ? " f64" : "", N, K, type.c_str(), P.spa.ntiles, P.spec_nwg);
+	snprintf(buf, sizeof buf, "axis %d: COL+%s N=%d K=%d compiled at plan time: %s, tiles=%d wgs=%d", P.axis, pl->f64 ? " f64" : "", N, c.K, c.type.c_str(), P.spa.ntiles, P.spec_nwg);
 	P.desc = buf;
 	return true;
 }
@@ -587,6 +660,25 @@ void fill_args(PassArgsT<R> &a, const PassGeom &g, const dspfft_plan_s *pl, cons
 	a.mask = fz.mask; a.mask_id = fz.id; a.mask_div = make_div((uint32_t)fz.div); a.accumulate = fz.accumulate;
 	a.zflags = fz.zflags; a.zshift = fz.zshift; a.zhalf = fz.zhalf; a.zpage = fz.zpage; a.zranges = fz.zranges;
 }
+
+// one candidate of the planning-effort-2 search: mean of three launches on the scratch buffer, in milliseconds (<= 0: failed)
+template <class R>
+float jit_time_t(const dspfft_plan_s *pl, const Pass &P, const PassGeom &g, void *fn, int nwg, int nthr, void *scratch)
+{
+	PassArgsT<R> a;
+	fill_args(a, g, pl, P, (const R *)scratch, (R *)scratch, 1.0, Fuse());
+	void *e0 = be_event_create(), *e1 = be_event_create();
+	float ms = -1.f;
+	if (e0 && e1 && !be_jit_launch(fn, &a, nwg, nthr, nullptr) && !be_event_record(e0, nullptr)) {
+		bool ok = true;
+		for (int i = 0; i < 3 && ok; i++) ok = !be_jit_launch(fn, &a, nwg, nthr, nullptr);
+		if (ok && !be_event_record(e1, nullptr) && !be_event_synchronize(e1) && !be_event_elapsed_ms(e0, e1, &ms)) ms /= 3.f; else ms = -1.f;
+	}
+	be_event_destroy(e0); be_event_destroy(e1);
+	return ms;
+}
+template float jit_time_t<float>(const dspfft_plan_s *, const Pass &, const PassGeom &, void *, int, int, void *);
+template float jit_time_t<double>(const dspfft_plan_s *, const Pass &, const PassGeom &, void *, int, int, void *);
 
 template <class R>
 int run_pass(const dspfft_plan_s *pl, const Pass &P, const R *in, R *out, bool last, void *stream, const Fuse &fz = Fuse())

@@ -99,8 +99,11 @@ typedef struct { int n; int is; int os; } dspfft_iodim;
 /* Planning effort for the plans created after the call (per process, like fftw's planner state; plans already made keep theirs).
  * 0 (default): a frame size without a compile-time-specialised kernel (spec_list.h) runs on the runtime-geometry kernels.
  * > 0: such sizes get RowSpecT / ColSpecT kernels COMPILED AT PLAN TIME (hiprtc: about a second per new size, then cached in
- * $DSPFFT_JIT_CACHE or ~/.cache/dspfft-jit) and run 1.3-1.8x faster from then on.  The FFTW shim maps FFTW_ESTIMATE to 0 and
- * FFTW_MEASURE / FFTW_PATIENT / FFTW_EXHAUSTIVE (scan.c:359, motion.c:93-103) to 1.  DSPFFT_JIT=1 / 2 in the environment forces it on / off. */
+ * $DSPFFT_JIT_CACHE or ~/.cache/dspfft-jit) and run 1.3-1.8x faster from then on.
+ * >= 2: several candidates (radix orders, thread counts, column tile widths) are compiled and TIMED on a scratch buffer, the fastest
+ * is kept (the caller's arrays are never touched).  The FFTW shim maps FFTW_ESTIMATE to 0, FFTW_MEASURE (scan.c:359) to 1 and
+ * FFTW_PATIENT / FFTW_EXHAUSTIVE (motion.c:93-103) to 2.  DSPFFT_JIT=1 / 2 in the environment forces compilation on / off,
+ * DSPFFT_JIT_TUNE=1 / 2 the timed search. */
 void dspfft_set_plan_effort(int effort);
 int dspfft_plan_guru_r2r(dspfft_plan *plan, int rank, const dspfft_iodim *dims, int howmany_rank, const dspfft_iodim *howmany_dims,
                          const int *kinds, int f64);

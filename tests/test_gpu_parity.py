@@ -970,3 +970,29 @@ def test_plan_effort_and_disk_cache(gpu, monkeypatch, tmp_path):
     p.execute(d.data_ptr())
     gpu.cuda.synchronize()
     check(d.cpu().numpy(), ol.dct2d_interleaved(x.astype(np.float64), REDFT10, impl="port", threads=8))
+
+
+def test_plan_effort_2_times_candidates(gpu, monkeypatch, tmp_path):
+    """planning effort 2 (FFTW_PATIENT / FFTW_EXHAUSTIVE through the shim): several candidate kernels are compiled and timed on a scratch
+    buffer; the plan that comes out is a compiled one and correct, and the caller's arrays were never involved"""
+    from dspfun_amd import Plan, set_plan_effort, REDFT10, REDFT01
+    monkeypatch.delenv("DSPFFT_JIT", raising=False)
+    monkeypatch.delenv("DSPFFT_JIT_TUNE", raising=False)
+    monkeypatch.setenv("DSPFFT_JIT_CACHE", str(tmp_path / "jit"))
+    h, w, c = 600, 1100, 3
+    set_plan_effort(2)
+    try:
+        fwd = Plan.image(h, w, c, REDFT10)
+        inv = Plan.image(h, w, c, REDFT01).set_scale(1.0 / (4.0 * h * w))
+    finally:
+        set_plan_effort(0)
+    assert fwd.describe().count("compiled at plan time") == 2, fwd.describe()
+    assert len(os.listdir(tmp_path / "jit")) >= 4          # more than one candidate per pass went through the compiler
+    x = ol.synth_f32(8, h * w * c).reshape(h, w, c)
+    d = gpu.from_numpy(x.copy()).to("cuda:0")
+    fwd.execute(d.data_ptr())
+    gpu.cuda.synchronize()
+    check(d.cpu().numpy(), ol.dct2d_interleaved(x.astype(np.float64), REDFT10, impl="port", threads=8))
+    inv.execute(d.data_ptr())
+    gpu.cuda.synchronize()
+    assert np.abs(d.cpu().numpy() - x).max() <= 2e-6
