@@ -303,7 +303,7 @@ std::string radix_string(const FftDesc &F)
 // ---- plan-time specialisation (DSPFFT_JIT=1) ----
 // Radix order and thread count for a length without an entry in spec_list.h, by the rules the listed entries came out of
 // (tools/kbench*, colbench, wavebench): largest radix first, an odd radix last when there is one (conflict-free last stage);
-// about 22 samples (ROW) / 34 samples (COL) of the tile per thread, rounded to a power of two.
+// about 11 samples (ROW, at most 512 threads while two lines fit a CU) / 34 samples (COL) of the tile per thread, rounded to a power of two.
 std::string jit_radices(const FftDesc &F)
 {
 	std::vector<int> r;
@@ -406,7 +406,10 @@ bool jit_row(const dspfft_plan_s *pl, Pass &P, int N, int C, long long nlines, c
 	const size_t es = pl->f64 ? 8 : 4;
 	const size_t lds = (size_t)C * (N / 2 + 16) * 2 * es;
 	if (F.ns < 1 || lds > be_max_lds()) return false;
-	const int T0 = jit_threads((double)N * C / 22.0);
+	// (the timed search of planning effort 2 kept picking twice the threads of the first rule, N C / 22, for RGB rows of 1500-2400
+	// pixels and never more than 512 below 4000 pixels)
+	int T0 = jit_threads((double)N * C / 11.0);
+	if (T0 > 512 && lds <= 80 * 1024) T0 = 512;
 	const std::string head = std::string("RowSpecT<") + (pl->f64 ? "double" : "float") + ", " + std::to_string(N) + ", " + std::to_string(C) + ", ";
 	std::vector<JitCand> cands;
 	auto add = [&](int T, const std::string &rad) {
