@@ -40,8 +40,11 @@ int be_launch_blue(const BlueArgsD &a, const LaunchGeom &g, void *stream);
 // Plan-time compilation (hiprtc) of jit_kernels.h for a RowSpecT / ColSpecT instance named by its C++ type; incdir = where the
 // library's headers lie.  funcs[0 / 1] = the REDFT10 / REDFT01 kernel.  The emulation backend has none (be_jit_available() = false).
 bool be_jit_available();
-int be_jit_build(const char *spec_type, int is_col, const char *incdir, void **funcs, char *log, size_t loglen);
+// be_jit_build returns the number of kernels written to funcs (row: REDFT10, REDFT01 [, 8-bit REDFT10, 8-bit REDFT01 with extras];
+// column: REDFT10, REDFT01 [, fused roundtrip with extras]) or a negative error
+int be_jit_build(const char *spec_type, int is_col, int extras, const char *incdir, void **funcs, char *log, size_t loglen);
 int be_jit_launch(void *func, const void *args, int nwg, int nthr, void *stream);
+int be_jit_launch_n(void *func, void **args, int nwg, int nthr, void *stream);      // one pointer per kernel parameter
 
 // small blocks transformed along all their axes in one pass (block_core.h); nwg workgroups of BLOCK_THREADS, `lds` bytes each
 bool be_block_supported(int nx, int ny, int nz);

@@ -142,6 +142,9 @@ struct Pass {
 	// spec_nwg describe it like a listed one's, jit_fn is this pass's kind
 	bool jit = false;
 	void *jit_fn = nullptr;
+	void *jit_fn_u8 = nullptr;      // planar rows: the 8-bit variant of this pass's kind
+	void *jit_fn_rt = nullptr;      // columns: the fused forward -> filter -> inverse kernel
+	std::string jit_type;
 	int jit_nthr = 0;
 	std::vector<Dim> hostloop;
 	Tables tab;
@@ -375,10 +378,13 @@ bool jit_pick(const dspfft_plan_s *pl, Pass &P, int is_col, const std::vector<Ji
 	}
 	float best = 0.f;
 	bool have = false;
+	// single precision: columns also get the fused roundtrip, planar rows of a multiple of four samples the 8-bit variants
+	const int extras = !pl->f64 && (is_col || (P.pa.C == 1 && P.pa.N % 4 == 0));
 	for (size_t i = 0; i < cands.size(); i++) {
-		void *fn[2];
+		void *fn[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 		char log[2048] = "";
-		if (be_jit_build(cands[i].type.c_str(), is_col, dir.c_str(), fn, log, sizeof log)) {
+		const int nfn = be_jit_build(cands[i].type.c_str(), is_col, extras, dir.c_str(), fn, log, sizeof log);
+		if (nfn < 2) {
 			if (i == 0) fprintf(stderr, "dspfft: plan-time compilation of %s failed\n%s\n", cands[i].type.c_str(), log);
 			continue;
 		}
@@ -392,7 +398,9 @@ bool jit_pick(const dspfft_plan_s *pl, Pass &P, int is_col, const std::vector<Ji
 		}
 		if (!have || (tune && scratch && ms < best)) {
 			have = true; best = ms; chosen = cands[i];
-			P.jit = true; P.jit_fn = fn[kind]; P.jit_nthr = cands[i].T; P.spa = g; P.spec_nwg = nwg;
+			P.jit = true; P.jit_fn = fn[kind]; P.jit_nthr = cands[i].T; P.spa = g; P.spec_nwg = nwg; P.jit_type = cands[i].type;
+			P.jit_fn_u8 = (!is_col && nfn == 4) ? fn[2 + kind] : nullptr;
+			P.jit_fn_rt = (is_col && nfn == 3) ? fn[2] : nullptr;
 		}
 		if (!(tune && scratch)) break;
 	}
@@ -1171,12 +1179,22 @@ int execute_masked_accumulate_t(dspfft_plan pl, const R *d_in, R *d_work, R *d_a
 
 namespace {
 // a planar row pass that can take / produce 8-bit samples itself
-bool pass_has_u8(const Pass &P) { return P.type == Pass::ROW && P.has_spec && P.pa.C == 1 && P.hostloop.empty() && be_spec_has_u8(P.spec.id); }
+bool pass_has_u8(const Pass &P)
+{
+	if (P.type != Pass::ROW || P.pa.C != 1 || !P.hostloop.empty()) return false;
+	return (P.has_spec && be_spec_has_u8(P.spec.id)) || (P.jit && P.jit_fn_u8);
+}
 
 int run_pass_u8(const dspfft_plan_s *pl, const Pass &P, const float *in, float *out, bool last, const U8IO &io, void *stream)
 {
 	PassArgs a;
 	fill_args(a, P.spa, pl, P, in, out, last ? pl->scale : 1.0, Fuse());
+	if (P.jit && !P.has_spec) {
+		U8IO io2 = io;
+		void *args[2] = {&a, &io2};
+		if (int rc = be_jit_launch_n(P.jit_fn_u8, args, P.spec_nwg, P.jit_nthr, stream)) return fail(-4, "kernel launch failed (%s, u8): backend code %d", P.desc.c_str(), rc);
+		return 0;
+	}
 	if (int rc = be_launch_spec_u8(P.spec.id, a, io, P.spec_nwg, stream)) return fail(-4, "kernel launch failed (%s, u8): backend code %d", P.desc.c_str(), rc);
 	return 0;
 }
@@ -1300,14 +1318,20 @@ int roundtrip_core(dspfft_plan fwd, dspfft_plan inv, const float *d_in, float *d
 		if (int rc = run_pass<float>(fwd, P, P.first ? d_in : d_out, d_out, false, stream)) return rc;
 	}
 	const float *src = nf == 1 ? d_in : d_out;
-	const bool fusable = F.type == Pass::COL && I.type == Pass::COL && F.has_spec && I.has_spec && F.spec.id == I.spec.id && F.spec_nwg == I.spec_nwg &&
+	const bool listed = F.has_spec && I.has_spec && F.spec.id == I.spec.id;
+	const bool compiled = !listed && F.jit && I.jit && F.jit_fn_rt && F.jit_type == I.jit_type;      // kernels compiled at plan time (jit_kernels.h)
+	const bool fusable = F.type == Pass::COL && I.type == Pass::COL && (listed || compiled) && F.spec_nwg == I.spec_nwg &&
 	                     F.hostloop.empty() && I.hostloop.empty() && (15u & ((uintptr_t)src | (uintptr_t)d_out)) == 0 &&
 	                     !(getenv("DSPFFT_NO_FUSED_ROUNDTRIP") && *getenv("DSPFFT_NO_FUSED_ROUNDTRIP") == '1');
 	if (fusable) {
 		PassArgs af, ai;
 		fill_args(af, F.spa, fwd, F, src, d_out, fwd->scale, Fuse());
 		fill_args(ai, I.spa, inv, I, (const float *)d_out, d_out, ni == 1 ? inv->scale : 1.0, Fuse());
-		if (int rc = be_launch_roundtrip(F.spec.id, af, ai, mf, d_coeffs_coded, F.spec_nwg, stream)) return fail(-4, "kernel launch failed (fused roundtrip): backend code %d", rc);
+		if (compiled) {
+			// parameters: (PassArgs af, PassArgs ai, FilterOp filt, unsigned long long *coded); FilterOp is the MotionFilter, nothing else
+			void *args[4] = {&af, &ai, &mf, &d_coeffs_coded};
+			if (int rc = be_jit_launch_n(F.jit_fn_rt, args, F.spec_nwg, F.jit_nthr, stream)) return fail(-4, "kernel launch failed (fused roundtrip, compiled at plan time): backend code %d", rc);
+		} else if (int rc = be_launch_roundtrip(F.spec.id, af, ai, mf, d_coeffs_coded, F.spec_nwg, stream)) return fail(-4, "kernel launch failed (fused roundtrip): backend code %d", rc);
 	} else {
 		if (int rc = run_pass<float>(fwd, F, src, d_out, true, stream)) return rc;
 		if (fp && be_motion_filter(d_out, mf, (uint64_t)span, d_coeffs_coded, stream)) return fail(-4, "filter launch failed");

@@ -17,7 +17,8 @@
 namespace dspfft {
 
 namespace {
-struct Built { hipModule_t mod; hipFunction_t fn[2]; };
+enum { JIT_MAXFN = 5 };
+struct Built { hipModule_t mod; hipFunction_t fn[JIT_MAXFN]; int nfn; };
 std::mutex g_mu;
 std::map<std::string, Built> g_cache;        // key: the spec's type name
 
@@ -57,8 +58,8 @@ std::string cache_file(const std::string &spec, const char *incdir)
 	snprintf(name, sizeof name, "/%016llx.co", h);
 	return d + name;
 }
-// file: "DSPJIT1\n", lowered name 0, "\n", lowered name 1, "\n", code object
-bool cache_load(const std::string &path, std::string lowered[2], std::vector<char> &code)
+// file: "DSPJIT2\n", number of kernels, "\n", their lowered names one per line, code object
+bool cache_load(const std::string &path, std::vector<std::string> &lowered, std::vector<char> &code)
 {
 	FILE *f = path.empty() ? nullptr : fopen(path.c_str(), "rb");
 	if (!f) return false;
@@ -69,18 +70,24 @@ bool cache_load(const std::string &path, std::string lowered[2], std::vector<cha
 	fclose(f);
 	const char *p = all.data(), *end = p + all.size();
 	auto line = [&](std::string &out) { const char *q = (const char *)memchr(p, '\n', (size_t)(end - p)); if (!q) return false; out.assign(p, q); p = q + 1; return true; };
-	std::string magic;
-	if (!line(magic) || magic != "DSPJIT1" || !line(lowered[0]) || !line(lowered[1]) || p >= end) return false;
+	std::string magic, cnt;
+	if (!line(magic) || magic != "DSPJIT2" || !line(cnt)) return false;
+	const int nk = atoi(cnt.c_str());
+	if (nk < 1 || nk > JIT_MAXFN) return false;
+	lowered.resize((size_t)nk);
+	for (int i = 0; i < nk; i++) if (!line(lowered[(size_t)i])) return false;
+	if (p >= end) return false;
 	code.assign(p, end);
 	return true;
 }
-void cache_store(const std::string &path, const std::string lowered[2], const std::vector<char> &code)
+void cache_store(const std::string &path, const std::vector<std::string> &lowered, const std::vector<char> &code)
 {
 	if (path.empty()) return;
 	const std::string tmp = path + "." + std::to_string((long long)getpid());
 	FILE *f = fopen(tmp.c_str(), "wb");
 	if (!f) return;
-	fprintf(f, "DSPJIT1\n%s\n%s\n", lowered[0].c_str(), lowered[1].c_str());
+	fprintf(f, "DSPJIT2\n%d\n", (int)lowered.size());
+	for (const std::string &l : lowered) fprintf(f, "%s\n", l.c_str());
 	const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
 	fclose(f);
 	if (ok) rename(tmp.c_str(), path.c_str()); else unlink(tmp.c_str());
@@ -89,33 +96,41 @@ void cache_store(const std::string &path, const std::string lowered[2], const st
 
 bool be_jit_available() { return true; }
 
-// spec_type: e.g. "RowSpecT<float, 1000, 3, 128, 5, 10, 10>"; is_col picks jit_col / jit_row.  funcs[kind] receives the kernels.
-int be_jit_build(const char *spec_type, int is_col, const char *incdir, void **funcs, char *log, size_t loglen)
+// spec_type: e.g. "RowSpecT<float, 1000, 3, 128, 5, 10, 10>".  kind 0 (row): funcs = {REDFT10, REDFT01} and, with `extras`, the 8-bit
+// variants {u8 REDFT10, u8 REDFT01}; kind 1 (column): {REDFT10, REDFT01} and, with `extras`, the fused roundtrip.  Returns the number of
+// kernels written to funcs (2, 3 or 4) or a negative error.
+int be_jit_build(const char *spec_type, int is_col, int extras, const char *incdir, void **funcs, char *log, size_t loglen)
 {
 	std::lock_guard<std::mutex> lock(g_mu);
-	auto it = g_cache.find(spec_type);
-	if (it != g_cache.end()) { funcs[0] = it->second.fn[0]; funcs[1] = it->second.fn[1]; return 0; }
-	const std::string cpath = cache_file(spec_type, incdir);
+	const std::string key = std::string(spec_type) + (extras ? "+x" : "");
+	auto it = g_cache.find(key);
+	if (it != g_cache.end()) { for (int i = 0; i < it->second.nfn; i++) funcs[i] = it->second.fn[i]; return it->second.nfn; }
+	std::vector<std::string> names;
+	const std::string st = std::string("dspfft::") + spec_type;
+	for (int k = 0; k < 2; k++) names.push_back(std::string("dspfft::") + (is_col ? "jit_col" : "jit_row") + "<" + st + ", " + std::to_string(k) + ">");
+	if (extras && is_col) names.push_back("dspfft::jit_col_rt<" + st + ">");
+	if (extras && !is_col) for (int k = 0; k < 2; k++) names.push_back("dspfft::jit_row_u8<" + st + ", " + std::to_string(k) + ">");
+	Built b;
+	b.nfn = (int)names.size();
+	const std::string cpath = cache_file(key, incdir);
 	{
-		std::string lowered[2];
+		std::vector<std::string> lowered;
 		std::vector<char> code;
-		Built b;
-		if (cache_load(cpath, lowered, code) && hipModuleLoadData(&b.mod, code.data()) == hipSuccess) {
-			if (hipModuleGetFunction(&b.fn[0], b.mod, lowered[0].c_str()) == hipSuccess && hipModuleGetFunction(&b.fn[1], b.mod, lowered[1].c_str()) == hipSuccess) {
-				g_cache[spec_type] = b;
-				funcs[0] = b.fn[0]; funcs[1] = b.fn[1];
-				return 0;
+		if (cache_load(cpath, lowered, code) && (int)lowered.size() == b.nfn && hipModuleLoadData(&b.mod, code.data()) == hipSuccess) {
+			bool ok = true;
+			for (int i = 0; i < b.nfn && ok; i++) ok = hipModuleGetFunction(&b.fn[i], b.mod, lowered[(size_t)i].c_str()) == hipSuccess;
+			if (ok) {
+				g_cache[key] = b;
+				for (int i = 0; i < b.nfn; i++) funcs[i] = b.fn[i];
+				return b.nfn;
 			}
 			(void)hipModuleUnload(b.mod);
 		}
 	}
-	const std::string kern = is_col ? "jit_col" : "jit_row";
-	std::string names[2];
-	for (int k = 0; k < 2; k++) names[k] = "dspfft::" + kern + "<dspfft::" + spec_type + ", " + std::to_string(k) + ">";
 	std::string src = "#include \"jit_kernels.h\"\n";
 	hiprtcProgram prog;
 	if (hiprtcCreateProgram(&prog, src.c_str(), "dspfft_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return -1;
-	for (int k = 0; k < 2; k++) hiprtcAddNameExpression(prog, names[k].c_str());
+	for (const std::string &n : names) hiprtcAddNameExpression(prog, n.c_str());
 	const char *root = getenv("ROCM_PATH");
 	const std::string inc1 = std::string("-I") + incdir, inc2 = std::string("-I") + (root && *root ? root : "/opt/rocm") + "/include", inc3 = "-I" + clang_resource_include();
 	const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fno-slp-vectorize", inc1.c_str(), inc2.c_str(), inc3.c_str()};
@@ -133,24 +148,29 @@ int be_jit_build(const char *spec_type, int is_col, const char *incdir, void **f
 	hiprtcGetCodeSize(prog, &cs);
 	std::vector<char> code(cs);
 	hiprtcGetCode(prog, code.data());
-	Built b;
 	if (hipModuleLoadData(&b.mod, code.data()) != hipSuccess) { hiprtcDestroyProgram(&prog); return -3; }
-	std::string low[2];
-	for (int k = 0; k < 2; k++) {
+	std::vector<std::string> low;
+	for (int k = 0; k < b.nfn; k++) {
 		const char *lowered = nullptr;
-		if (hiprtcGetLoweredName(prog, names[k].c_str(), &lowered) != HIPRTC_SUCCESS || hipModuleGetFunction(&b.fn[k], b.mod, lowered) != hipSuccess) {
+		if (hiprtcGetLoweredName(prog, names[(size_t)k].c_str(), &lowered) != HIPRTC_SUCCESS || hipModuleGetFunction(&b.fn[k], b.mod, lowered) != hipSuccess) {
 			hiprtcDestroyProgram(&prog);
 			return -4;
 		}
-		low[k] = lowered;
+		low.push_back(lowered);
 	}
 	hiprtcDestroyProgram(&prog);
 	cache_store(cpath, low, code);
-	g_cache[spec_type] = b;
-	funcs[0] = b.fn[0]; funcs[1] = b.fn[1];
-	return 0;
+	g_cache[key] = b;
+	for (int i = 0; i < b.nfn; i++) funcs[i] = b.fn[i];
+	return b.nfn;
 }
 
+// args: one pointer per kernel parameter
+int be_jit_launch_n(void *func, void **args, int nwg, int nthr, void *stream)
+{
+	const hipError_t e = hipModuleLaunchKernel((hipFunction_t)func, (unsigned)nwg, 1, 1, (unsigned)nthr, 1, 1, 0, (hipStream_t)stream, args, nullptr);
+	return e == hipSuccess ? 0 : (int)e;
+}
 int be_jit_launch(void *func, const void *args, int nwg, int nthr, void *stream)
 {
 	void *params[1] = {const_cast<void *>(args)};

@@ -1,0 +1,77 @@
+// spec_fused.h -- device-side pieces of the fused column roundtrip shared by spec_kernels.h and jit_kernels.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dct_spec.h"
+#include "motion_filter.h"
+
+namespace dspfft {
+
+// forward REDFT10 -> motion filter -> inverse REDFT01 along the tile's axis in one launch: the tile is read once and
+// written once instead of three times each (forward store + filter read/write + inverse load saved)
+struct FilterOp {
+	MotionFilter p;
+	__device__ SigVec<float, 2> operator()(long long e, SigVec<float, 2> v, unsigned long long &coded) const
+	{
+		if (!p.enabled) return v;
+		float4 f; f.x = v.s[0].x; f.y = v.s[0].y; f.z = v.s[1].x; f.w = v.s[1].y;
+		f = motion_filter4(p, (uint32_t)e, f, coded);
+		v.s[0].x = f.x; v.s[0].y = f.y; v.s[1].x = f.z; v.s[1].y = f.w;
+		return v;
+	}
+};
+
+// waves per SIMD to ask of the register allocator so that as many workgroups stay resident as the tile's LDS allows
+// (capped at 4 = 128 VGPRs): without the cap the allocator spends the whole budget and one workgroup fills a CU
+template <class S> constexpr int rt_waves_per_simd()
+{
+	const int wgs = (int)((160 * 1024) / S::LDS), w = wgs * S::T / 256;
+	return w < 1 ? 1 : w > 4 ? 4 : w;
+}
+
+// the body of the fused column roundtrip, shared by the listed kernels (spec_kernels.h, dynamic LDS) and the ones compiled at plan
+// time (jit_kernels.h, static LDS)
+template <class S>
+__device__ __forceinline__ void col_roundtrip_body(unsigned char *lds, const typename S::PA &af, const typename S::PA &ai, const FilterOp &filt, unsigned long long *coded)
+{
+	__shared__ unsigned int wg_coded;       // non-zero quantised coefficients of this tile (one global atomic per workgroup)
+	typename S::V *buf = reinterpret_cast<typename S::V *>(lds);
+	const int tid = threadIdx.x;
+	if (tid == 0) wg_coded = 0;
+	typename S::StateRT st;
+	long long bin, bout;
+	S::base(af, blockIdx.x, bin, bout);
+	bool hit = false;
+	S::template prefetch<KIND_REDFT10>(af, bin, tid, st, hit);
+	S::template phase<KIND_REDFT10, 0>(af, buf, bout, tid, st);
+	__syncthreads();
+	// The empty asm statements make the thread index (and, below, the inverse plan's table pointers) opaque at each
+	// phase: otherwise index arithmetic and twiddle loads of LATER phases are hoisted to the top of the kernel and
+	// stay live across every barrier (measured: 176 VGPRs -> 1 workgroup per CU; with them: <= 128).
+	static_for<1, S::NS + 2>([&](auto ph) {
+		int t = tid; asm volatile("" : "+v"(t));
+		S::template phase<KIND_REDFT10, ph>(af, buf, bout, t, st);
+		__syncthreads();
+	});
+	unsigned long long mine = 0;
+	int t = tid; asm volatile("" : "+v"(t));
+	S::mid_read(af, ai, buf, bout, t, st, filt, mine);
+	if (coded) {
+		unsigned int m = (unsigned int)mine;
+		for (int off = 32; off > 0; off >>= 1) m += __shfl_xor(m, off);
+		if ((tid & 63) == 0 && m) atomicAdd(&wg_coded, m);
+	}
+	__syncthreads();
+	if (coded && tid == 0 && wg_coded) atomicAdd(coded, (unsigned long long)wg_coded);
+	asm volatile("" : "+v"(t));
+	S::mid_write(buf, t, st);
+	__syncthreads();
+	typename S::PA a2 = ai;
+	asm volatile("" : "+s"(a2.W), "+s"(a2.T), "+s"(a2.out));
+	static_for<1, S::NPH>([&](auto ph) {
+		asm volatile("" : "+v"(t));
+		S::template phase<KIND_REDFT01, ph>(a2, buf, bout, t, st);
+		if constexpr (ph + 1 < S::NPH) __syncthreads();
+	});
+}
+
+}  // namespace dspfft

@@ -320,8 +320,9 @@ int be_scan_stamp(uint32_t *ids, const uint32_t *lin, uint64_t n, uint32_t frame
 #undef DSPFFT_BLOCK_SHAPES
 #define DSPFFT_BLOCK_SHAPES(X) X(8, 8, 8) X(4, 4, 4) X(16, 16, 16) X(8, 8, 1) X(16, 16, 1) X(16, 8, 8) X(8, 8, 4) X(4, 16, 8) X(8, 16, 4)
 bool be_jit_available() { return false; }
-int be_jit_build(const char *, int, const char *, void **, char *, size_t) { return -1; }
+int be_jit_build(const char *, int, int, const char *, void **, char *, size_t) { return -1; }
 int be_jit_launch(void *, const void *, int, int, void *) { return -1; }
+int be_jit_launch_n(void *, void **, int, int, void *) { return -1; }
 
 bool be_block_supported(int nx, int ny, int nz)
 {

@@ -996,3 +996,29 @@ def test_plan_effort_2_times_candidates(gpu, monkeypatch, tmp_path):
     inv.execute(d.data_ptr())
     gpu.cuda.synchronize()
     assert np.abs(d.cpu().numpy() - x).max() <= 2e-6
+
+
+def test_plan_time_kernels_run_motions_fused_pipeline(gpu, monkeypatch, tmp_path):
+    """a frame size without listed kernels (1000x600 luma, 12 frames): with kernels compiled at plan time motion's per-frame pipeline
+    -- 8-bit in, REDFT10, quantiser, REDFT01, 8-bit out -- runs as three launches (8-bit row kernels + fused column roundtrip) and
+    matches the runtime-geometry path (DSPFFT_JIT=2)"""
+    from dspfun_amd import Plan, REDFT10, REDFT01
+    monkeypatch.setenv("DSPFFT_JIT_CACHE", str(tmp_path / "jit"))
+    d_, h, w = 12, 600, 1000
+    u8 = ol.synth_u8(3, d_ * h * w).reshape(d_, h, w)
+    flt = dict(active=(1, h, w), minbuf_hw=(h, w), block_depth=1, band_begin=(0, 0, 0), band_end=(1, h, w), quantizer=4.0)
+    res = {}
+    for jit in ("1", "2"):
+        monkeypatch.setenv("DSPFFT_JIT", jit)
+        f2 = Plan.many_r2r([h, w], [REDFT10] * 2, howmany=d_, idist=h * w, odist=h * w)
+        i2 = Plan.many_r2r([h, w], [REDFT01] * 2, howmany=d_, idist=h * w, odist=h * w, first_axis_first=True).set_scale(1.0 / (4.0 * h * w))
+        assert (f2.describe().count("compiled at plan time") == 2) == (jit == "1"), f2.describe()
+        din = gpu.from_numpy(u8.copy()).to("cuda:0"); dout = gpu.zeros_like(din); work = gpu.empty(d_ * h * w, dtype=gpu.float32, device="cuda:0")
+        coded = gpu.zeros(1, dtype=gpu.int64, device="cuda:0")
+        f2.roundtrip_u8(i2, din.data_ptr(), dout.data_ptr(), work.data_ptr(), 1.0, filter=flt, d_coded=coded.data_ptr())
+        gpu.cuda.synchronize()
+        res[jit] = (dout.cpu().numpy(), int(coded.item()))
+    a, b = res["1"], res["2"]
+    assert np.abs(a[0].astype(np.int32) - b[0].astype(np.int32)).max() <= 1 and (a[0] != b[0]).mean() < 1e-3
+    assert abs(a[1] - b[1]) <= max(4, b[1] // 10000) and b[1] > 0
+    assert np.abs(a[0].astype(np.int32) - u8).max() <= 6          # quantiser 4: a coarse but close copy
