@@ -1437,6 +1437,7 @@ extern "C" int dspfft_plan_describe(dspfft_plan pl, char *buf, size_t buflen)
 
 extern "C" size_t dspfft_plan_algorithmic_bytes(dspfft_plan pl) { return pl ? pl->alg_bytes : 0; }
 extern "C" void dspfft_set_plan_effort(int effort) { g_plan_effort = effort; }
+extern "C" int dspfft_get_plan_effort(void) { return g_plan_effort; }
 
 extern "C" int dspfft_scan_zigzag(uint32_t *d_lin, uint32_t w, uint32_t h, uint64_t first, uint64_t count, void *s)
 {

@@ -105,6 +105,7 @@ typedef struct { int n; int is; int os; } dspfft_iodim;
  * FFTW_PATIENT / FFTW_EXHAUSTIVE (motion.c:93-103) to 2.  DSPFFT_JIT=1 / 2 in the environment forces compilation on / off,
  * DSPFFT_JIT_TUNE=1 / 2 the timed search. */
 void dspfft_set_plan_effort(int effort);
+int dspfft_get_plan_effort(void);
 int dspfft_plan_guru_r2r(dspfft_plan *plan, int rank, const dspfft_iodim *dims, int howmany_rank, const dspfft_iodim *howmany_dims,
                          const int *kinds, int f64);
 
