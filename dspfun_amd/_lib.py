@@ -132,7 +132,7 @@ def bind(lib):
         lib.dspfft_applybasis_work_floats.argtypes = [C.c_int] * 7
         lib.dspfft_applybasis_work_floats_ex.restype = C.c_size_t
         lib.dspfft_applybasis_work_floats_ex.argtypes = [C.c_int] * 7
-        lib.dspfft_applybasis_partsums_ex.argtypes = [vp, vp, vp] + [C.c_int] * 10 + [C.c_longlong, C.c_longlong, vp, vp]
+        lib.dspfft_applybasis_partsums_ex.argtypes = [vp, vp, vp] + [C.c_int] * 10 + [C.c_longlong, C.c_longlong, C.c_int, vp, vp]
         lib.dspfft_applybasis_render.argtypes = [vp, vp] + [C.c_int] * 11 + [C.c_double, C.c_double, C.POINTER(C.c_float), vp]
         lib.dspfft_applybasis_partsums.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_longlong, vp, vp]
     return lib

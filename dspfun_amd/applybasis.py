@@ -28,9 +28,10 @@ def partsums(torch, pixels_hwc, function="dft", orthogonal=False, terms=None, pa
     return torch.view_as_complex(out)
 
 
-def partsums_ex(torch, pix_re, pix_im=None, function="dft", orthogonal=False, K=None, N=None, partsum=(1, 1), offset=(0, 0)):
+def partsums_ex(torch, pix_re, pix_im=None, function="dft", orthogonal=False, K=None, N=None, partsum=(1, 1), offset=(0, 0), inverse=False):
     """The general form (dspfft_applybasis_partsums_ex): K = (Kw, Kh) basis functions, N = (Nw, Nh) blocks of `partsum` pixels;
-    --inverse is K = image size, N = terms / partsum (applybasis.c:378-389); pix_im: the imaginary part of a .coeff input."""
+    --inverse is K = image size, N = terms / partsum (applybasis.c:372-380) and moves --offset from the basis index to the block index
+    (:416-420); pix_im: the imaginary part of a .coeff input."""
     lib = _lib.load()
     h, w, c = pix_re.shape
     assert c == 3 and pix_re.dtype == torch.float32 and pix_re.is_contiguous()
@@ -41,7 +42,7 @@ def partsums_ex(torch, pix_re, pix_im=None, function="dft", orthogonal=False, K=
     out = torch.empty((kh, kw, nh, nw, 3, 2), dtype=torch.float32, device=pix_re.device)
     work = torch.empty(lib.dspfft_applybasis_work_floats_ex(w, h, kw, kh, nw, nh, func), dtype=torch.float32, device=pix_re.device)
     rc = lib.dspfft_applybasis_partsums_ex(out.data_ptr(), pix_re.data_ptr(), pix_im.data_ptr() if pix_im is not None else None, w, h, func, int(orthogonal),
-                                           kw, kh, nw, nh, pw, ph, offset[0], offset[1], work.data_ptr(), None)
+                                           kw, kh, nw, nh, pw, ph, offset[0], offset[1], int(inverse), work.data_ptr(), None)
     if rc:
         raise DspfftError(lib.dspfft_zoom_last_error().decode())
     return torch.view_as_complex(out)

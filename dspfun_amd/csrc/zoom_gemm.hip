@@ -167,12 +167,14 @@ __device__ void ab_basis(int func, long long k, long long n, unsigned long long 
 	}
 	re = c;
 }
-__global__ void ab_basis_kernel(float *re, float *im, int func, int ortho, long long terms, long long offset, unsigned long long N)
+// koff shifts the basis index (forward: bi = k, applybasis.c:416-418); noff the sample index (--inverse: bi = n, so the function is
+// evaluated at (n + off) P + s while the pixel read stays at n P + s)
+__global__ void ab_basis_kernel(float *re, float *im, int func, int ortho, long long terms, long long koff, long long noff, unsigned long long N)
 {
 	const size_t total = (size_t)terms * N;
 	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
 		const long long k = (long long)(i / N), n = (long long)(i - (size_t)k * N);
-		double r, m; ab_basis(func, k + offset, n, N, ortho, r, m);
+		double r, m; ab_basis(func, k + koff, n + noff, N, ortho, r, m);
 		re[i] = (float)r; if (im) im[i] = (float)m;
 	}
 }
@@ -243,6 +245,7 @@ extern "C" int dspfft_zoom_product(const float *d_coeffs, int w, int h, const fl
 
 // ---- applybasis' partial sums (applybasis/applybasis.c:410-431) as TWO batched NT GEMM launches ----
 // out[kh][kw][nh][nw][j] = sum_{sh, sw} f_h(kh + offh, nh Ph + sh) f_w(kw + offw, nw Pw + sw) pix_j[nh Ph + sh][nw Pw + sw]
+// (--inverse: the offset belongs to the block index, f(k, (n + off) P + s), the pixel read does not move: applybasis.c:372-378,416-420)
 // Forward (K = terms, N = image / partsum) and --inverse (K = image size, N = terms / partsum, applybasis.c:378-389) are the
 // same sums with different (K, N); pixels may be complex (a .coeff input, applybasis.c:319-338).
 //   step 1  Tt[j][(part, kw)][nw][y]            = sum_sw Fw[(part, kw)][nw Pw + sw] pix_j[y][nw Pw + sw]        batch (nw, j)
@@ -278,8 +281,9 @@ extern "C" size_t dspfft_applybasis_work_floats(int w, int h, int Kw, int Kh, in
 }
 
 static int applybasis_core(float *d_out, const float *d_pixels, int w, int h, int func, int ortho, int Kw, int Kh, int Nw, int Nh, int Pw, int Ph,
-                           long long offw, long long offh, float *d_work, int as_imag, hipStream_t s)
+                           long long offw, long long offh, int inverse, float *d_work, int as_imag, hipStream_t s)
 {
+	const long long kow = inverse ? 0 : offw, koh = inverse ? 0 : offh, now = inverse ? offw * Pw : 0, noh = inverse ? offh * Ph : 0;
 	const int cplx = func <= 1, C = cplx ? 2 : 1;
 	const size_t npix = (size_t)w * h;
 	float *planes = d_work;
@@ -287,8 +291,8 @@ static int applybasis_core(float *d_out, const float *d_pixels, int w, int h, in
 	float *Tt = Fh + (size_t)C * Kh * h;                                         // [j][(part, kw)][nw][y]
 	float *P = Tt + (size_t)3 * C * Kw * Nw * h;                                 // [j][(hp, kh)][nh][(tp, kw, nw)]
 	hipLaunchKernelGGL(deinterleave3_kernel, dim3(1024), dim3(256), 0, s, planes, d_pixels, npix);
-	hipLaunchKernelGGL(ab_basis_kernel, dim3(512), dim3(256), 0, s, Fw, cplx ? Fw + (size_t)Kw * w : nullptr, func, ortho, (long long)Kw, offw, (unsigned long long)w);
-	hipLaunchKernelGGL(ab_basis_kernel, dim3(512), dim3(256), 0, s, Fh, cplx ? Fh + (size_t)Kh * h : nullptr, func, ortho, (long long)Kh, offh, (unsigned long long)h);
+	hipLaunchKernelGGL(ab_basis_kernel, dim3(512), dim3(256), 0, s, Fw, cplx ? Fw + (size_t)Kw * w : nullptr, func, ortho, (long long)Kw, kow, now, (unsigned long long)w);
+	hipLaunchKernelGGL(ab_basis_kernel, dim3(512), dim3(256), 0, s, Fh, cplx ? Fh + (size_t)Kh * h : nullptr, func, ortho, (long long)Kh, koh, noh, (unsigned long long)h);
 	int rc = gemm_nt_f32_batch2(Fw, planes, Tt, C * Kw, h, Pw, w, w, (long long)Nw * h,
 	                            Nw, Pw, Pw, h, 3, 0, (long long)npix, (long long)C * Kw * Nw * h, s);
 	if (rc) return rc;
@@ -301,15 +305,15 @@ static int applybasis_core(float *d_out, const float *d_pixels, int w, int h, in
 }
 
 extern "C" int dspfft_applybasis_partsums_ex(float *d_out, const float *d_pix_re, const float *d_pix_im, int w, int h, int func, int ortho,
-                                             int Kw, int Kh, int Nw, int Nh, int Pw, int Ph, long long offw, long long offh, float *d_work, void *stream)
+                                             int Kw, int Kh, int Nw, int Nh, int Pw, int Ph, long long offw, long long offh, int inverse, float *d_work, void *stream)
 {
 	if (!d_out || !d_pix_re || !d_work || func < 0 || func > 11 || Kw < 1 || Kh < 1 || Nw < 1 || Nh < 1 || Pw < 1 || Ph < 1 ||
 	    (long long)Nw * Pw > w || (long long)Nh * Ph > h) {
 		snprintf(g_zerr, sizeof g_zerr, "bad arguments (the partial-sum blocks N x P must fit in the image)"); return -1;
 	}
 	hipStream_t s = (hipStream_t)stream;
-	int rc = applybasis_core(d_out, d_pix_re, w, h, func, ortho, Kw, Kh, Nw, Nh, Pw, Ph, offw, offh, d_work, 0, s);
-	if (!rc && d_pix_im) rc = applybasis_core(d_out, d_pix_im, w, h, func, ortho, Kw, Kh, Nw, Nh, Pw, Ph, offw, offh, d_work, 1, s);
+	int rc = applybasis_core(d_out, d_pix_re, w, h, func, ortho, Kw, Kh, Nw, Nh, Pw, Ph, offw, offh, inverse, d_work, 0, s);
+	if (!rc && d_pix_im) rc = applybasis_core(d_out, d_pix_im, w, h, func, ortho, Kw, Kh, Nw, Nh, Pw, Ph, offw, offh, inverse, d_work, 1, s);
 	return rc;
 }
 
@@ -318,7 +322,7 @@ extern "C" int dspfft_applybasis_partsums(float *d_out, const float *d_pixels, i
                                           float *d_work, void *stream)
 {
 	if (Pw < 1 || Ph < 1 || w % Pw || h % Ph) { snprintf(g_zerr, sizeof g_zerr, "bad arguments (the partial-sum block must divide the image)"); return -1; }
-	return dspfft_applybasis_partsums_ex(d_out, d_pixels, nullptr, w, h, func, ortho, Kw, Kh, w / Pw, h / Ph, Pw, Ph, offw, offh, d_work, stream);
+	return dspfft_applybasis_partsums_ex(d_out, d_pixels, nullptr, w, h, func, ortho, Kw, Kh, w / Pw, h / Ph, Pw, Ph, offw, offh, 0, d_work, stream);
 }
 
 // ---- the rendered frame (applybasis.c:392-442): realize -> rescale (one type, or two interpolated) -> range -> cells of

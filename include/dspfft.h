@@ -301,10 +301,13 @@ int dspfft_applybasis_partsums(float *d_out, const float *d_pixels, int w, int h
  *   forward  (applybasis.c:378-389 with !inverse):  K = terms,       N = image size / partsum
  *   --inverse                                    :  K = image size,  N = terms / partsum
  *   .coeff input (applybasis.c:319-338): complex pixels -- d_pix_im non-NULL (planes h x w x 3, like d_pix_re)
+ * --offset (applybasis.c:416-420 adds it to `bi`): inverse = 0 -> f(k + off, n P + s); inverse = 1 (`n = &bi`, :372-378) ->
+ * f(k, (n + off) P + s) while the pixel read stays at n P + s.
  * Each call is two batched GEMM launches (three basis / layout kernels around them), whatever the function. */
 size_t dspfft_applybasis_work_floats_ex(int w, int h, int Kw, int Kh, int Nw, int Nh, int func);
 int dspfft_applybasis_partsums_ex(float *d_out, const float *d_pix_re, const float *d_pix_im, int w, int h, int func, int ortho,
-                                  int Kw, int Kh, int Nw, int Nh, int Pw, int Ph, long long offw, long long offh, float *d_work, void *hip_stream);
+                                  int Kw, int Kh, int Nw, int Nh, int Pw, int Ph, long long offw, long long offh, int inverse,
+                                  float *d_work, void *hip_stream);
 /* applybasis.c:392-442: the rendered frame from the partial sums.  d_frame: fh x fw x 4 floats (RGBA) with
  * fw = Kw Nw scale + padding T_w + padding (T = K forward, N with --inverse), same for fh; filled with padcolor first.
  * plane: 0 real 1 imaginary 2 magnitude 3 phase (:20-31); rescale0 / rescale1: 0 linear 1 log 2 gain 3 level, rescale1 = -1 for a

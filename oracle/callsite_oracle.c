@@ -175,11 +175,13 @@ void oracle_applybasis_partsums_f64(double *out /* [Kh][Kw][Nh][Nw][3][2] */, co
 				}
 }
 
-/* the general loop of applybasis.c:378-431: K basis functions x N blocks of P pixels per axis (forward: K = terms, N = size / P;
- * --inverse: K = size, N = terms / P), complex pixels (a .coeff input; pix_im may be NULL) */
+/* the general loop of applybasis.c:370-380,410-425: K basis functions x N blocks of P pixels per axis (forward: K = terms, N = size / P;
+ * --inverse: K = size, N = terms / P), complex pixels (a .coeff input; pix_im may be NULL).  The offset is added to `bi` around the
+ * function call (:416-420): forward k = &bi, --inverse n = &bi -- then the function sees (n + off) P + s, the pixel index does not. */
 void oracle_applybasis_partsums_ex_f64(double *out /* [Kh][Kw][Nh][Nw][3][2] */, const double *pix_re, const double *pix_im, int w, int h, int func, int ortho,
-                                       int Kw, int Kh, int Nw, int Nh, int Pw, int Ph, long long offw, long long offh)
+                                       int Kw, int Kh, int Nw, int Nh, int Pw, int Ph, long long offw, long long offh, int inverse)
 {
+	const long long kow = inverse ? 0 : offw, koh = inverse ? 0 : offh, now = inverse ? offw : 0, noh = inverse ? offh : 0;
 	for (int kh = 0; kh < Kh; kh++)
 		for (int kw = 0; kw < Kw; kw++)
 			for (int nh = 0; nh < Nh; nh++)
@@ -187,8 +189,8 @@ void oracle_applybasis_partsums_ex_f64(double *out /* [Kh][Kw][Nh][Nw][3][2] */,
 					double complex ps[3] = {0, 0, 0};
 					for (int sh = 0; sh < Ph; sh++)
 						for (int sw = 0; sw < Pw; sw++) {
-							double complex comp = ab_basis(func, kw + offw, (long long)nw * Pw + sw, (unsigned long long)w, ortho) *
-							                      ab_basis(func, kh + offh, (long long)nh * Ph + sh, (unsigned long long)h, ortho);
+							double complex comp = ab_basis(func, kw + kow, (long long)(nw + now) * Pw + sw, (unsigned long long)w, ortho) *
+							                      ab_basis(func, kh + koh, (long long)(nh + noh) * Ph + sh, (unsigned long long)h, ortho);
 							const size_t p = ((size_t)(nh * Ph + sh) * w + (size_t)nw * Pw + sw) * 3;
 							for (int j = 0; j < 3; j++) ps[j] += comp * (pix_re[p + j] + (pix_im ? I * pix_im[p + j] : 0));
 						}

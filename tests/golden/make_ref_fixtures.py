@@ -1,0 +1,271 @@
+"""Regenerates tests/golden/ref_direct.npz from the REFERENCE'S OWN direct-sum code.  Build container only
+(needs /root/reference and gcc); never on the GPU box.
+
+FFTW itself is not in /root/reference and was never run.  What the reference does hold is its own
+direct-sum statement of the same transforms, and this script compiles that code AS IT LIES:
+
+  scan/scan.c:20-41          generate_basis_matrix + pruned_idct  -- the code scan switches to instead of
+                             fftw(execute) on a speed heuristic (scan.c:349-350,446-449): the reference's own
+                             definition of the 2-D REDFT01 (summed over ALL coefficients it IS the transform)
+  zoom/zoom.c:22-26,34,36-68 scaling_type, min(), generate_scaled_basis
+  zoom/zoom.c:361-375        the separable basis x coefficient product (scale 1, offset 0 == REDFT01 / (4wh))
+  applybasis/applybasis.c:77-140   the twelve basis functions (dct2 == REDFT10's kernel, dct3 == REDFT01's)
+  applybasis/applybasis.c:146-147,370-380,410-425  coords/offsets, the forward / --inverse index aliasing, the
+                             partial-sum loops (with the --offset handling of :419-421)
+
+The text of those line ranges is read from /root/reference at generation time into a temporary translation unit
+that includes the reference's include/precision.h (COEFF_PRECISION=L, INTERMEDIATE_PRECISION=L: the tightest build
+the reference offers) and is compiled with plain gcc -- no stand-in headers; no reference text is written to the
+repository.  Only numbers (inputs and outputs) go into the fixture file.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("DSPFUN_REFERENCE", "/root/reference")
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle_lib import synth_f32, splitmix64_stream  # noqa: E402
+
+LD = np.longdouble
+FUNCS = ["dft", "idft", "dct1", "dct2", "dct3", "dct4", "dst1", "dst2", "dst3", "dst4", "wht", "dht"]
+
+
+def lines(path, a, b):
+    with open(os.path.join(REF, path)) as f:
+        src = f.read().split("\n")
+    return "\n".join(src[a - 1:b]) + "\n"
+
+
+def build_scan_zoom(tmp):
+    """scan.c:20-41 and zoom.c's basis + product in one TU (both only need precision.h and libm)."""
+    tu = "#include <stdlib.h>\n#include <stdbool.h>\n#include <math.h>\n#include \"precision.h\"\n"
+    tu += lines("scan/scan.c", 20, 41)
+    tu += lines("zoom/zoom.c", 22, 26) + lines("zoom/zoom.c", 34, 34) + lines("zoom/zoom.c", 36, 68)
+    # --- wrappers (this script's own code) -------------------------------------------------------------
+    tu += """
+void ref_pruned_idct(const long double *c, long double *img, const size_t *coords, size_t ncoords, size_t width, size_t height, size_t channels)
+{   /* scan.c:357-362,449 */
+	coeff *basis[2];
+	basis[0] = generate_basis_matrix(height);
+	basis[1] = width == height ? basis[0] : generate_basis_matrix(width);
+	pruned_idct(basis, (coeff *)c, img, (size_t (*)[2])coords, ncoords, width, height, channels);
+	free(basis[0]);
+	if (width != height) free(basis[1]);
+}
+size_t ref_zoom(const long double *coeffs, long double *icoeffs, int scaling_type_, long double xscale_num, long double xscale_den, long double yscale_num,
+                long double yscale_den, long double vx, long double vy, size_t vw, size_t vh, size_t width, size_t height, size_t *out_cheight)
+{   /* zoom.c:323-325,347-359 */
+	enum scaling_type scaling_type = scaling_type_;
+	coeff *xbasis = NULL, *ybuf = NULL;
+	intermediate *tmp = NULL;
+	size_t maxvectors = vh > vw ? vh : vw;
+	bool reuse_basis = width == height && vx == vy && xscale_num == yscale_num && xscale_den == yscale_den;
+	size_t cwidth = generate_scaled_basis(&xbasis,scaling_type,xscale_num,xscale_den,vx,(reuse_basis ? maxvectors : vw),width);
+	size_t cheight;
+	coeff* ybasis;
+	if(reuse_basis) {
+		cheight = cwidth;
+		ybasis = xbasis;
+	}
+	else {
+		cheight = generate_scaled_basis(&ybuf,scaling_type,yscale_num,yscale_den,vy,vh,height);
+		ybasis = ybuf;
+	}
+	tmp = realloc(tmp,sizeof(*tmp)*cheight);
+"""
+    tu += lines("zoom/zoom.c", 361, 375)
+    tu += """
+	free(xbasis); free(ybuf); free(tmp);
+	*out_cheight = cheight;
+	return cwidth;
+}
+"""
+    return compile_tu(tmp, "scanzoom", tu)
+
+
+def build_applybasis(tmp):
+    tu = "#include <stdlib.h>\n#include <string.h>\n#include <stdbool.h>\n#include <complex.h>\n#include <math.h>\n#include \"precision.h\"\n"
+    tu += "#ifndef I\n#define I _Complex_I\n#endif\n"
+    tu += lines("applybasis/applybasis.c", 77, 140)
+    tu += lines("applybasis/applybasis.c", 146, 147)
+    tu += "static complex_intermediate (*const table[12])(long long, long long, unsigned long long, bool) = {" + ",".join(FUNCS) + "};\n"
+    tu += """
+void ref_basis(int f, long long k, long long n, unsigned long long N, int ortho, long double *re, long double *im)
+{
+	complex_intermediate v = table[f](k, n, N, ortho);
+	*re = creall(v); *im = cimagl(v);
+}
+/* the partial sums of applybasis.c:370-380,410-425; out[term][3] complex, terms in loop order */
+void ref_partsums(int f, int orthogonal, int inverse, coords insize, coords terms, coords partsum, offsets offset, const long double *pixels_, long double *out)
+{
+	complex_intermediate (*function)(long long, long long, unsigned long long, bool) = table[f];
+	const intermediate *pixels = pixels_;
+	coords size = insize;
+	size_t term = 0;
+"""
+    tu += lines("applybasis/applybasis.c", 370, 380)
+    tu += lines("applybasis/applybasis.c", 410, 425)
+    tu += """
+					for (int j = 0; j < 3; j++) { out[(term * 3 + j) * 2] = creall(partsums[j]); out[(term * 3 + j) * 2 + 1] = cimagl(partsums[j]); }
+					term++;
+				}
+}
+"""
+    return compile_tu(tmp, "applybasis", tu)
+
+
+def compile_tu(tmp, name, text):
+    src = os.path.join(tmp, name + ".c")
+    so = os.path.join(tmp, name + ".so")
+    with open(src, "w") as f:
+        f.write(text)
+    subprocess.check_call(["gcc", "-std=c11", "-D_GNU_SOURCE", "-DCOEFF_PRECISION=L", "-DINTERMEDIATE_PRECISION=L", "-O2", "-fPIC", "-shared",
+                           "-I" + os.path.join(REF, "include"), src, "-o", so, "-lm"])
+    return C.CDLL(so)
+
+
+def rnd(seed, n):
+    """zero-mean values in [-1, 1) from the survey's splitmix64 stream"""
+    return synth_f32(seed, n).astype(np.float64) * 2 - 1
+
+
+def main():
+    assert os.path.isdir(REF), REF
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        sz = build_scan_zoom(tmp)
+        ab = build_applybasis(tmp)
+        vp = C.c_void_p
+        sz.ref_pruned_idct.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]
+        sz.ref_zoom.restype = C.c_size_t
+        sz.ref_zoom.argtypes = [vp, vp, C.c_int] + [C.c_longdouble] * 6 + [C.c_size_t] * 4 + [vp]
+        ab.ref_basis.argtypes = [C.c_int, C.c_longlong, C.c_longlong, C.c_ulonglong, C.c_int, vp, vp]
+
+        def pruned(c, coords):
+            h, w, ch = c.shape
+            cl = np.ascontiguousarray(c, dtype=LD)
+            img = np.zeros((h, w, ch), dtype=LD)
+            co = np.ascontiguousarray(coords, dtype=np.uint64)   # size_t [n][2] = (y, x)
+            sz.ref_pruned_idct(cl.ctypes.data, img.ctypes.data, co.ctypes.data, len(co), w, h, ch)
+            return img.astype(np.float64)
+
+        # --- (1) dense 2-D REDFT01 by scan's pruned_idct over ALL coefficients ------------------------------
+        dense = [(6, 8, 1), (12, 16, 3), (16, 9, 3), (9, 16, 2), (45, 30, 3), (48, 64, 3), (60, 135, 1), (96, 80, 3)]
+        out["dense_shapes"] = np.array(dense)
+        for i, (h, w, ch) in enumerate(dense):
+            c = rnd(0xD5F1000 + i, h * w * ch).reshape(h, w, ch)
+            coords = np.array([(y, x) for y in range(h) for x in range(w)], dtype=np.uint64)
+            # a non-raster visiting order: the sum must not depend on it beyond rounding
+            coords = coords[np.argsort(splitmix64_stream(0xD5F1100 + i, h * w), kind="stable")]
+            out[f"dense{i}_coeffs"] = c
+            out[f"dense{i}_image"] = pruned(c, coords)
+            print("dense", (h, w, ch))
+        # the whole operator at 6x8: image of every unit coefficient
+        h, w = 6, 8
+        op = np.zeros((h * w, h * w))
+        for j in range(h * w):
+            c = np.zeros((h, w, 1)); c.flat[j] = 1
+            op[:, j] = pruned(c, np.array([(j // w, j % w)], dtype=np.uint64)).ravel()
+        out["operator_6x8"] = op
+
+        # --- (2) sparse spectra at listed frame sizes, sampled output pixels --------------------------------
+        sparse = [(480, 640, 3, 512, 2048), (1080, 1920, 3, 96, 4096), (2160, 3840, 3, 48, 4096)]
+        out["sparse_shapes"] = np.array(sparse)
+        for i, (h, w, ch, ncoef, npix) in enumerate(sparse):
+            u = splitmix64_stream(0xD5F1200 + i, ncoef * 2)
+            cy = (u[0::2] % np.uint64(h)).astype(np.int64); cx = (u[1::2] % np.uint64(w)).astype(np.int64)
+            # a few low-frequency and edge coefficients always present
+            cy[:4] = [0, 0, 1, h - 1]; cx[:4] = [0, 1, 0, w - 1]
+            key = cy * w + cx
+            _, first = np.unique(key, return_index=True)
+            first.sort()
+            cy, cx = cy[first], cx[first]
+            vals = rnd(0xD5F1300 + i, len(cy) * ch).reshape(len(cy), ch)
+            c = np.zeros((h, w, ch)); c[cy, cx] = vals
+            img = pruned(c, np.stack([cy, cx], 1).astype(np.uint64))
+            p = splitmix64_stream(0xD5F1400 + i, npix * 2)
+            py = (p[0::2] % np.uint64(h)).astype(np.int64); px = (p[1::2] % np.uint64(w)).astype(np.int64)
+            py[:4] = [0, 0, h - 1, h - 1]; px[:4] = [0, w - 1, 0, w - 1]
+            out[f"sparse{i}_cy"], out[f"sparse{i}_cx"], out[f"sparse{i}_vals"] = cy, cx, vals
+            out[f"sparse{i}_py"], out[f"sparse{i}_px"], out[f"sparse{i}_image_at"] = py, px, img[py, px]
+            print("sparse", (h, w, ch), len(cy))
+
+        # --- (3) zoom: basis + product ------------------------------------------------------------------------
+        # (h, w, type, xnum, xden, ynum, yden, vx, vy)   type: 0 interpolated, 1 centered, 2 native (zoom.c:22-26)
+        zoom = [(12, 16, 0, 1, 1, 1, 1, 0, 0), (12, 16, 0, 2, 1, 2, 1, 0, 0), (12, 16, 0, 4, 1, 4, 1, 0, 0), (24, 32, 0, 4, 1, 4, 1, 0, 0),
+                (12, 16, 2, 2, 1, 2, 1, 0, 0), (12, 16, 2, 3, 1, 2, 1, 0, 0), (16, 16, 0, 3, 2, 3, 2, 2.5, 2.5), (12, 16, 1, 5, 2, 7, 3, 1.25, -3.5),
+                (20, 12, 0, 1, 2, 3, 4, 0, 0), (12, 16, 2, 1, 2, 1, 2, 0.5, 0), (15, 9, 0, 7, 3, 2, 1, -2, 4)]
+        out["zoom_cases"] = np.array(zoom, dtype=np.float64)
+        for i, (h, w, typ, xn, xd, yn, yd, vx, vy) in enumerate(zoom):
+            vw = int(w * xn / xd); vh = int(h * yn / yd)   # zoom.c:286-289
+            c = rnd(0xD5F1500 + i, h * w * 3).reshape(h, w, 3) * (4 * w * h)
+            cl = np.ascontiguousarray(c, dtype=LD)
+            ic = np.zeros((vh, vw, 3), dtype=LD)
+            chh = C.c_size_t(0)
+            cw = sz.ref_zoom(cl.ctypes.data, ic.ctypes.data, typ, xn, xd, yn, yd, vx, vy, vw, vh, w, h, C.addressof(chh))
+            out[f"zoom{i}_coeffs"] = c
+            out[f"zoom{i}_out"] = ic.astype(np.float64)
+            out[f"zoom{i}_ncomp"] = np.array([cw, chh.value])
+            print("zoom", zoom[i], (vh, vw), (cw, chh.value))
+
+        # --- (4) applybasis: basis tables and partial sums -----------------------------------------------------
+        def table(f, N, ortho, K=None, off=0):
+            K = N if K is None else K
+            t = np.zeros((K, N), dtype=np.complex128)
+            re = C.c_longdouble(); im = C.c_longdouble()
+            for k in range(K):
+                for n in range(N):
+                    ab.ref_basis(f, k + off, n, N, ortho, C.addressof(re), C.addressof(im))
+                    t[k, n] = complex(float(re.value), float(im.value))
+            return t
+        lens = [2, 3, 4, 5, 8, 15, 16, 27, 45, 48, 64, 100]
+        out["basis_lens"] = np.array(lens)
+        for N in lens:
+            out[f"dct2_{N}"] = table(3, N, 0).real      # REDFT10: Y_k = 2 sum_n x_n dct2(k, n)
+            out[f"dct3_{N}"] = table(4, N, 0).real      # REDFT01: Y_k = 2 sum_n X_n dct3(k, n)
+        for N in (4, 8, 16):
+            for ortho in (0, 1):
+                out[f"basis_all_{N}_{ortho}"] = np.stack([table(f, N, ortho) for f in range(12)])
+        for ortho in (0, 1):   # non power of two: every function but wht
+            out[f"basis_all_6_{ortho}"] = np.stack([table(f, 6, ortho) for f in range(12) if FUNCS[f] != "wht"])
+
+        class Coords(C.Union):
+            _fields_ = [("a", C.c_ulonglong * 2)]
+
+        class Offsets(C.Union):
+            _fields_ = [("a", C.c_longlong * 2)]
+        ab.ref_partsums.argtypes = [C.c_int, C.c_int, C.c_int, Coords, Coords, Coords, Offsets, vp, vp]
+
+        def co(w, h, T=Coords):
+            c = T(); c.a[0] = w; c.a[1] = h
+            return c
+        # (func, ortho, inverse, w, h, terms_w, terms_h, P_w, P_h, off_w, off_h)
+        parts = [(3, 0, 0, 8, 8, 8, 8, 1, 1, 0, 0), (3, 0, 0, 8, 8, 8, 8, 8, 8, 0, 0), (4, 0, 0, 8, 8, 8, 8, 8, 8, 0, 0), (0, 0, 0, 8, 8, 4, 4, 2, 2, 1, -1),
+                 (3, 1, 0, 12, 8, 6, 4, 3, 2, 2, 1), (8, 0, 0, 8, 8, 8, 8, 4, 4, 0, 0), (10, 0, 0, 8, 8, 8, 8, 2, 2, 0, 0), (11, 0, 0, 12, 8, 5, 3, 4, 2, 0, 2),
+                 (4, 1, 1, 8, 8, 8, 8, 2, 2, 0, 0), (4, 0, 1, 8, 8, 8, 8, 2, 2, 1, 2), (1, 0, 1, 12, 8, 12, 8, 3, 2, 2, -1), (3, 0, 1, 12, 8, 6, 4, 1, 1, 3, 1)]
+        out["parts_cases"] = np.array(parts)
+        for i, (f, ortho, inv, w, h, tw, th, pw, ph, ow, oh) in enumerate(parts):
+            pix = rnd(0xD5F1600 + i, h * w * 3).reshape(h, w, 3)
+            pl = np.ascontiguousarray(pix, dtype=LD)
+            # term counts as the loop of :410-413 runs them (after :379-380 divide N by the partial-sum block)
+            K = (tw, th) if not inv else (w, h)
+            N = ((w // pw), (h // ph)) if not inv else (tw // pw, th // ph)
+            nterm = K[0] * K[1] * N[0] * N[1]
+            o = np.zeros((nterm, 3, 2), dtype=LD)
+            ab.ref_partsums(f, ortho, inv, co(w, h), co(tw, th), co(pw, ph), co(ow, oh, Offsets), pl.ctypes.data, o.ctypes.data)
+            out[f"parts{i}_pix"] = pix
+            out[f"parts{i}_out"] = o.astype(np.float64).reshape(K[1], K[0], N[1], N[0], 3, 2)
+            print("partsums", parts[i])
+
+    path = os.path.join(HERE, "ref_direct.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path))
+
+
+if __name__ == "__main__":
+    main()

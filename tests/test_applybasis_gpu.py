@@ -20,20 +20,20 @@ def gpu():
     return torch
 
 
-def oracle_ex(pre, pim, func, ortho, K, N, P, off=(0, 0)):
+def oracle_ex(pre, pim, func, ortho, K, N, P, off=(0, 0), inverse=False):
     h, w, _ = pre.shape
     out = np.zeros((K[1], K[0], N[1], N[0], 3, 2))
     L = ol.lib()
-    L.oracle_applybasis_partsums_ex_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 10 + [C.c_longlong, C.c_longlong]
+    L.oracle_applybasis_partsums_ex_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 10 + [C.c_longlong, C.c_longlong, C.c_int]
     a = np.ascontiguousarray(pre, dtype=np.float64)
     b = np.ascontiguousarray(pim, dtype=np.float64) if pim is not None else None
     L.oracle_applybasis_partsums_ex_f64(out.ctypes.data, a.ctypes.data, b.ctypes.data if b is not None else None, w, h, FUNCS.index(func), int(ortho),
-                                        K[0], K[1], N[0], N[1], P[0], P[1], off[0], off[1])
+                                        K[0], K[1], N[0], N[1], P[0], P[1], off[0], off[1], int(inverse))
     return out[..., 0] + 1j * out[..., 1]
 
 
 @pytest.mark.parametrize("func", ["dft", "dct2", "dst3", "wht", "dht"])
-@pytest.mark.parametrize("case", ["forward_partial", "inverse_terms", "complex_input"])
+@pytest.mark.parametrize("case", ["forward_partial", "inverse_terms", "inverse_offset", "complex_input"])
 def test_partsums_general_form(gpu, func, case):
     from dspfun_amd import applybasis as ab
     w, h = 32, 16
@@ -43,12 +43,15 @@ def test_partsums_general_form(gpu, func, case):
         K, N, P, off = (5, 3), (w // 4, h // 2), (4, 2), (1, 2)
     elif case == "inverse_terms":          # --inverse -t 24x8 -u 3x2: K = image size, N = terms / partsum (blocks cover only part of the image)
         K, N, P, off = (w, h), (8, 4), (3, 2), (0, 0)
+    elif case == "inverse_offset":         # --inverse -O 2x-1: the offset moves the function's sample index, not the pixel read (applybasis.c:372-378,416-420)
+        K, N, P, off = (w, h), (8, 4), (3, 2), (2, -1)
     else:                                   # a .coeff read back: complex pixels, orthogonal bases, full sums
         pim = (ol.synth_f32(4, w * h * 3).reshape(h, w, 3) - 0.5).astype(np.float32)
         K, N, P, off = (w, h), (1, 1), (w, h), (0, 0)
     ortho = case == "complex_input"
-    got = ab.partsums_ex(gpu, gpu.from_numpy(pre).cuda(), gpu.from_numpy(pim).cuda() if pim is not None else None, func, ortho, K, N, P, off).cpu().numpy()
-    ref = oracle_ex(pre, pim, func, ortho, K, N, P, off)
+    inverse = case.startswith("inverse")
+    got = ab.partsums_ex(gpu, gpu.from_numpy(pre).cuda(), gpu.from_numpy(pim).cuda() if pim is not None else None, func, ortho, K, N, P, off, inverse).cpu().numpy()
+    ref = oracle_ex(pre, pim, func, ortho, K, N, P, off, inverse)
     assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
 
 
