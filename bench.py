@@ -203,8 +203,11 @@ def main():
     # rocprofv3 averages -- at a quarter of the event traffic.
     batch = Batch([(pl_, p, None, handles[i % len(handles)]) for i, p in enumerate(ptrs) for pl_ in (fwd, inv)])
     every = max(1, args.event_every)
-    timed_steps = [k for k in range(args.steps) if k % every == 0]
     nper = min(2, len(ptrs)) if nstreams >= 2 else 1          # frames bracketed per timed step: one per stream
+    if len(ptrs) % nper:
+        print(f"bench.py: --frames {len(ptrs)} must be a multiple of {nper} (the frames bracketed per timed step)", file=sys.stderr)
+        sys.exit(2)
+    timed_steps = [k for k in range(args.steps) if k % every == 0]
     events = Events(2 * npass * nper * len(timed_steps))
 
     # Schedules of the frames of a step on two streams (frame f on stream f mod 2).  Left alone ("free") the streams keep whatever
@@ -214,34 +217,15 @@ def main():
     # the streams at EVERY step ("aligned", round 1's default) is steady but idles the faster stream at each join (55-56K).
     # Default: re-join every `--realign` steps (8): the phase cannot wander, the joins are rare.  The timing events bracket one
     # frame on EACH stream in the same step, so they delay both streams alike.
-    sched = {"every": 0, "count": 0, "last": [None] * max(1, nstreams)}
-
-    def step(k=None):
-        if sched["every"] and sched["count"] % sched["every"] == 0:
-            for a_ in range(len(side)):
-                for b_ in range(len(side)):
-                    if a_ != b_ and sched["last"][b_] is not None:
-                        side[a_].wait_event(sched["last"][b_])
-        if k is None or k % every:
-            batch.run()
-        else:
-            j = k // every
-            first = (2 * j) % len(ptrs) if len(ptrs) >= 2 else 0
-            batch.run(timed_item=2 * first, timed_count=2 * nper, events=events, event_offset=2 * npass * nper * j)
-        sched["count"] += 1
-        if sched["every"] and sched["count"] % sched["every"] == 0:
-            for a_ in range(len(side)):
-                e_ = torch.cuda.Event()
-                e_.record(side[a_])
-                sched["last"][a_] = e_
-
+    # Round 3: the step loop itself is the library's (dspfft_execute_many_repeat: a clip's frame loop, K steps in ONE call), so no
+    # host-language code runs between two steps; the re-joins are the library's too.
+    rejoin = 0
     schedule = "single stream" if nstreams == 1 else "free"
     if nstreams >= 2 and args.schedule == "aligned":
-        sched["every"] = 1
-        schedule = "step-aligned"
+        rejoin, schedule = 1, "step-aligned"
     elif nstreams >= 2 and args.schedule == "realign":
-        sched["every"] = max(1, args.realign)
-        schedule = f"free, streams re-joined every {sched['every']} steps"
+        rejoin = max(1, args.realign)
+        schedule = f"free, streams re-joined every {rejoin} steps"
 
     def barrier():
         torch.cuda.synchronize()
@@ -251,14 +235,12 @@ def main():
 
     # clocks and caches settle over a few tens of milliseconds: whatever --warmup says, run at least that much untimed work
     # first (a short --steps run is otherwise timed on a GPU that is still ramping up)
-    for _ in range(max(0, 60 - args.warmup)):
-        step()
-    for _ in range(args.warmup):
-        step()
+    if args.warmup < 60:
+        batch.run_repeat(60 - args.warmup, rejoin)
+    batch.run_repeat(args.warmup, rejoin)
     barrier()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k)
+    batch.run_repeat(args.steps, rejoin, every, 2 * nper, events)      # EXACTLY --steps steps
     enqueue_s = time.perf_counter() - t0          # host time to enqueue all steps (must stay well below the GPU's time)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -329,7 +311,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (splitmix64 uniform [0,1), SURVEY.md 8d seed 0xD5F0002)",
             "config": {"workload": "spec + ispec roundtrip on 3840x2160 RGB float32 (BASELINE configs[1])",
-                       "frames_per_gpu_per_step": args.frames, "hip_streams": nstreams, "stream_schedule": schedule, "layout": "interleaved HWC, in place, device-resident",
+                       "frames_per_gpu_per_step": args.frames, "hip_streams": nstreams, "stream_schedule": schedule, "step_loop": "dspfft_execute_many_repeat (one library call for all steps)", "layout": "interleaved HWC, in place, device-resident",
                        "parallelism": f"frame-sharded x{world}, no collective"},
             "roundtrip_frac_of_hbm_roofline": round(value * 1e6 * ALG_BYTES_PER_PIXEL / (HBM_PEAK * world), 4),      # per GPU
             "max_abs_drift_after_all_roundtrips": drift, "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 5),

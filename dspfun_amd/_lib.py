@@ -17,10 +17,10 @@ SYMBOLS = [
     "dspfft_plan_many_r2r_f64", "dspfft_plan_set_scale_f64", "dspfft_plan_set_axis_scale0_f64", "dspfft_execute_f64", "dspfft_execute_masked_accumulate_f64", "dspfft_plan_scan_prepare", "dspfft_set_plan_effort", "dspfft_get_plan_effort",
     "dspfft_plan_many_r2r_ordered", "dspfft_plan_guru_r2r", "dspfft_execute_roundtrip", "dspfft_execute_roundtrip_u8",
     "dspfft_execute", "dspfft_plan_num_passes", "dspfft_execute_pass", "dspfft_destroy_plan", "dspfft_plan_describe", "dspfft_plan_algorithmic_bytes",
-    "dspfft_execute_many", "dspfft_event_create", "dspfft_event_destroy", "dspfft_event_synchronize", "dspfft_event_elapsed_ms",
+    "dspfft_execute_many", "dspfft_execute_many_repeat", "dspfft_event_create", "dspfft_event_destroy", "dspfft_event_synchronize", "dspfft_event_elapsed_ms",
     "dspfft_last_error", "dspfft_version",
     "dspfft_scan_zigzag", "dspfft_scan_zigzag_frame_ids", "dspfft_execute_masked_accumulate", "dspfft_scan_scatter", "dspfft_accumulate", "dspfft_broadcast_dc",
-    "dspfft_scan_limit", "dspfft_scan_max_interval", "dspfft_scan_owner_index", "dspfft_scan_frame_ids", "dspfft_scan_coords", "dspfft_scan_stamp",
+    "dspfft_scan_limit", "dspfft_scan_max_interval", "dspfft_scan_coord_slots", "dspfft_scan_owner_index", "dspfft_scan_frame_ids", "dspfft_scan_coords", "dspfft_scan_stamp",
     "dspfft_scan_index_to_frame_ids", "dspfft_scan_magnitude_work_bytes", "dspfft_scan_magnitude_index",
     "dspfft_u8_to_f32", "dspfft_f32_to_u8",
     "dspfft_zoom_ncomponents", "dspfft_zoom_basis", "dspfft_zoom_work_floats", "dspfft_zoom_product", "dspfft_gemm_nt_f32",
@@ -55,6 +55,7 @@ def bind(lib):
     lib.dspfft_plan_set_axis_scale0.argtypes = [vp, C.c_int, C.c_float, C.c_float]
     lib.dspfft_execute.argtypes = [vp, vp, vp, vp]
     lib.dspfft_execute_many.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.POINTER(vp)]
+    lib.dspfft_execute_many_repeat.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     lib.dspfft_event_create.restype = vp
     lib.dspfft_event_create.argtypes = []
     lib.dspfft_event_destroy.argtypes = [vp]
@@ -90,6 +91,8 @@ def bind(lib):
     lib.dspfft_scan_limit.argtypes = [C.c_int, C.c_uint32, C.c_uint32]
     lib.dspfft_scan_max_interval.restype = C.c_uint64
     lib.dspfft_scan_max_interval.argtypes = [C.c_int, C.c_uint32, C.c_uint32]
+    lib.dspfft_scan_coord_slots.restype = C.c_uint64
+    lib.dspfft_scan_coord_slots.argtypes = [C.c_int, C.c_uint32, C.c_uint32]
     lib.dspfft_scan_owner_index.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, vp]
     lib.dspfft_scan_frame_ids.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint64, vp]
     lib.dspfft_scan_coords.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, vp]

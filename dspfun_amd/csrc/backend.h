@@ -88,6 +88,9 @@ void be_event_destroy(void *e);
 int be_event_record(void *e, void *stream);
 int be_event_synchronize(void *e);
 int be_event_elapsed_ms(void *a, void *b, float *ms);
+// ordering-only events between streams (dspfft_execute_many_repeat re-joins its streams with them)
+void *be_order_event_create();
+int be_stream_wait_event(void *stream, void *e);
 
 // outer-radix-2 split of a long column axis (dct_spec.h ColHalfSpec): half-tile column kernels for length N whose inner extent is
 // a multiple of the tile width, and the paired row kernel of row spec (N, C); be_find_row_pair returns an id or -1

@@ -1383,16 +1383,14 @@ extern "C" int dspfft_execute_pass(dspfft_plan pl, int index, const float *d_in,
 	return run_pass<float>(pl, P, P.first ? d_in : d_out, d_out, index + 1 == (int)passes.size(), stream);
 }
 
-extern "C" int dspfft_execute_many(int count, const dspfft_plan *plans, const float *const *d_in, float *const *d_out, void *const *streams,
-                                   int timed_item, int timed_count, void *const *pass_events)
+// one pass over the items; items [timed_item, timed_item + timed_count) bracket each of their passes with pass_events (2 per pass)
+static int execute_many_once(int count, const dspfft_plan *plans, const float *const *d_in, float *const *d_out, void *const *streams,
+                             int timed_item, int timed_count, void *const *pass_events)
 {
-	if (count < 0 || (count && (!plans || !d_in || !d_out))) return fail(-1, "bad arguments");
 	int ev = 0;
 	for (int i = 0; i < count; i++) {
 		dspfft_plan pl = plans[i];
 		void *st = streams ? streams[i] : nullptr;
-		if (!pl || !d_in[i] || !d_out[i]) return fail(-1, "item %d: null plan or buffer", i);
-		if (pl->f64) return fail(-1, "dspfft_execute_many takes f32 plans");
 		const bool timed = pass_events && i >= timed_item && i < timed_item + timed_count;
 		if (!timed) { if (int rc = execute_t<float>(pl, d_in[i], d_out[i], st)) return rc; continue; }
 		const std::vector<Pass> &passes = pick_passes(pl, d_in[i], d_out[i]);
@@ -1404,6 +1402,65 @@ extern "C" int dspfft_execute_many(int count, const dspfft_plan *plans, const fl
 		}
 	}
 	return 0;
+}
+static int check_many(int count, const dspfft_plan *plans, const float *const *d_in, float *const *d_out, int timed_item, int timed_count, bool events)
+{
+	if (count < 0 || (count && (!plans || !d_in || !d_out))) return fail(-1, "bad arguments");
+	for (int i = 0; i < count; i++) {
+		if (!plans[i] || !d_in[i] || !d_out[i]) return fail(-1, "item %d: null plan or buffer", i);
+		if (plans[i]->f64) return fail(-1, "dspfft_execute_many takes f32 plans");
+	}
+	if (events) {
+		if (timed_item < 0 || timed_count < 0 || timed_item + timed_count > count) return fail(-1, "timed items [%d, %d) lie outside the batch of %d", timed_item, timed_item + timed_count, count);
+		// a one-pass small-block plan runs ONE fused kernel in dspfft_execute, not its axis passes: bracketing "passes" would time other kernels
+		for (int i = timed_item; i < timed_item + timed_count; i++)
+			if (plans[i]->has_block) return fail(-1, "item %d: per-pass events are not available for one-pass block plans", i);
+	}
+	return 0;
+}
+
+extern "C" int dspfft_execute_many(int count, const dspfft_plan *plans, const float *const *d_in, float *const *d_out, void *const *streams,
+                                   int timed_item, int timed_count, void *const *pass_events)
+{
+	if (int rc = check_many(count, plans, d_in, d_out, timed_item, timed_count, pass_events != nullptr)) return rc;
+	return execute_many_once(count, plans, d_in, d_out, streams, timed_item, timed_count, pass_events);
+}
+
+// The frame loop of a clip inside the library: the batch `repeats` times (motion/motion.c:613-753 runs its per-frame plans once per
+// frame of the clip, scan/scan.c:421-447 its inverse plan once per output frame).  See include/dspfft.h.
+extern "C" int dspfft_execute_many_repeat(int count, const dspfft_plan *plans, const float *const *d_in, float *const *d_out, void *const *streams,
+                                          int repeats, int rejoin_every, int timed_every, int timed_count, void *const *pass_events)
+{
+	if (repeats < 0 || rejoin_every < 0 || timed_every < 0) return fail(-1, "bad arguments");
+	const bool ev = pass_events && timed_every > 0 && timed_count > 0;
+	if (ev && count % timed_count) return fail(-1, "the timed window (%d items) must divide the batch (%d items)", timed_count, count);
+	if (int rc = check_many(count, plans, d_in, d_out, 0, ev ? count : 0, ev)) return rc;
+	// distinct streams of the batch, in order of first use
+	std::vector<void *> uniq;
+	for (int i = 0; i < count; i++) { void *st = streams ? streams[i] : nullptr; if (std::find(uniq.begin(), uniq.end(), st) == uniq.end()) uniq.push_back(st); }
+	std::vector<void *> join;
+	const bool rejoin = rejoin_every > 0 && uniq.size() > 1;
+	if (rejoin) for (size_t i = 0; i < uniq.size(); i++) { void *e = be_order_event_create(); if (!e) { for (void *x : join) be_event_destroy(x); return fail(-4, "event creation failed"); } join.push_back(e); }
+	int rc = 0, windows = 0;
+	size_t ev_off = 0;
+	for (int k = 0; k < repeats && !rc; k++) {
+		if (rejoin && k && k % rejoin_every == 0) {
+			// every stream waits for where every other stream stood at the end of the previous repeat: their relative phase cannot drift
+			for (size_t a = 0; a < uniq.size() && !rc; a++) if (be_event_record(join[a], uniq[a])) rc = fail(-4, "event record failed");
+			for (size_t a = 0; a < uniq.size() && !rc; a++)
+				for (size_t b = 0; b < uniq.size() && !rc; b++)
+					if (a != b && be_stream_wait_event(uniq[a], join[b])) rc = fail(-4, "stream wait failed");
+			if (rc) break;
+		}
+		if (ev && k % timed_every == 0) {
+			const int first = (int)(((long long)windows * timed_count) % count);
+			rc = execute_many_once(count, plans, d_in, d_out, streams, first, timed_count, pass_events + ev_off);
+			for (int i = first; i < first + timed_count; i++) ev_off += 2 * pick_passes(plans[i], d_in[i], d_out[i]).size();
+			windows++;
+		} else rc = execute_many_once(count, plans, d_in, d_out, streams, 0, 0, nullptr);
+	}
+	for (void *x : join) be_event_destroy(x);
+	return rc;
 }
 extern "C" void *dspfft_event_create(void) { return be_event_create(); }
 extern "C" void dspfft_event_destroy(void *e) { be_event_destroy(e); }
@@ -1469,10 +1526,17 @@ extern "C" uint64_t dspfft_scan_max_interval(int method, uint32_t w32, uint32_t 
 	case SCANM_COLUMN: return h;
 	case SCANM_DIAGONAL: return std::min(w, h);
 	case SCANM_MIRROR: return std::min(w, h) * 2 - 1;
-	case SCANM_BOX: case SCANM_IBOX: return w + h;
+	case SCANM_BOX: case SCANM_IBOX: return w + h - 1;                                // limit_sum (scan_methods.c:23,496,502)
 	case SCANM_HORIZONTAL: case SCANM_VERTICAL: case SCANM_ZIGZAG: return 1;
 	default: return 0;                                                                // radial / iradial: no closed form (owner ids only)
 	}
+}
+// entries per scan index in a coordinate list: max_interval, plus the one entry the reference's callers over-allocate (scan.c:346) and
+// ibox needs (index 0 emits its corner twice: w + h coordinates against max_interval = w + h - 1)
+extern "C" uint64_t dspfft_scan_coord_slots(int method, uint32_t w, uint32_t h)
+{
+	const uint64_t m = dspfft_scan_max_interval(method, w, h);
+	return (method == SCANM_BOX || method == SCANM_IBOX) ? m + 1 : m;
 }
 static int scan_args_ok(const void *p, int method, uint32_t w, uint32_t h)
 {
@@ -1498,7 +1562,7 @@ extern "C" int dspfft_scan_frame_ids(uint32_t *d_ids, int method, uint32_t w, ui
 extern "C" int dspfft_scan_coords(uint32_t *d_lin, int method, uint32_t w, uint32_t h, uint64_t first, uint64_t count, void *s)
 {
 	if (int rc = scan_args_ok(d_lin, method, w, h)) return rc;
-	const uint64_t slots = dspfft_scan_max_interval(method, w, h);
+	const uint64_t slots = dspfft_scan_coord_slots(method, w, h);
 	if (!slots) return fail(-2, "radial / iradial have no closed-form coordinate lists: use dspfft_scan_frame_ids");
 	if (first + count > dspfft_scan_limit(method, w, h)) return fail(-1, "scan index range out of bounds");
 	if (method == SCANM_ZIGZAG) return be_scan_zigzag(d_lin, w, h, first, count, s) ? fail(-4, "launch failed") : 0;

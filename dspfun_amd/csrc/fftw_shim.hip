@@ -110,7 +110,12 @@ void run(Shim *s)
 	if (ok) {
 		const int rc = s->es == 8 ? dspfft_execute_f64(s->plan, (const double *)s->d_in, (double *)s->d_out, s->stream)
 		                          : dspfft_execute(s->plan, (const float *)s->d_in, (float *)s->d_out, s->stream);
-		if (rc) { fprintf(stderr, "dspfft: execute failed: %s\n", dspfft_last_error()); return; }
+		if (rc) {
+			// the uploads (and whatever passes were enqueued) still read the caller's arrays: drain the stream before handing them back
+			fprintf(stderr, "dspfft: execute failed: %s\n", dspfft_last_error());
+			(void)hipStreamSynchronize(s->stream);
+			return;
+		}
 	}
 	ok = ok && hipMemcpyAsync(s->h_out, s->d_out, s->out_len * s->es, hipMemcpyDeviceToHost, s->stream) == hipSuccess;
 	ok = ok && hipStreamSynchronize(s->stream) == hipSuccess;

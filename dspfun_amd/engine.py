@@ -230,3 +230,15 @@ class Batch:
         if rc:
             raise DspfftError(self._lib.dspfft_last_error().decode())
 
+    def run_repeat(self, repeats, rejoin_every=0, timed_every=0, timed_count=0, events=None):
+        """dspfft_execute_many_repeat: the batch `repeats` times in one library call (the frame loop of a clip); the streams of the
+        batch are re-joined every `rejoin_every` repeats; every `timed_every`-th repeat brackets the passes of a rotating window of
+        `timed_count` items with `events` (2 per pass, in order)."""
+        ev = None
+        if events is not None and timed_every and timed_count:
+            ev = C.cast(events.handles, C.POINTER(C.c_void_p))
+        rc = self._lib.dspfft_execute_many_repeat(self.n, self._plans, self._in, self._out, self._streams, int(repeats), int(rejoin_every),
+                                                  int(timed_every) if ev is not None else 0, int(timed_count) if ev is not None else 0, ev)
+        if rc:
+            raise DspfftError(self._lib.dspfft_last_error().decode())
+

@@ -6,7 +6,8 @@
  *
  *   scan_dev in.{ppm,pf} out.pf [step] [method]
  *     method: a prefix of horizontal vertical zigzag row column diagonal mirror box ibox radial iradial (scan_methods.c:581-591),
- *             magnitude[:qfactor] (scan_methods.c:240-296), or file:<path> (scan_methods.c:393-410, either serialisation)
+ *             magnitude[:qfactor] (scan_methods.c:240-296), file:<path> (scan_methods.c:393-410, either serialisation), or
+ *             random[:seed] (scan_methods.c:210-228: the permutation is drawn on the host with libc rand(), as the tool draws it)
  * Output: the final `sum` image; on stderr the number of frames and max|sum - input| (0 up to rounding when the method visits
  * every pixel exactly once).
  */
@@ -15,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <dspfft.h>
 #include <hip/hip_runtime_api.h>
@@ -64,10 +66,15 @@ int main(int argc, char *argv[])
 		DSP(dspfft_scan_magnitude_index(d_ids, d_coeffs, w, h, channels, q, d_mw, wb, &lim32, NULL));
 		HIP(hipFree(d_mw));
 		limit = lim32;
-	} else if (!strncmp(mname, "file:", 5)) {
-		FILE *f = fopen(mname + 5, "r");
-		if (!f || scan_order_read_file(f, width, height, &fl)) { fprintf(stderr, "cannot read the scan order %s\n", mname + 5); return 1; }
-		fclose(f);
+	} else if (!strncmp(mname, "file:", 5) || !strncmp(mname, "random", 6)) {
+		if (mname[0] == 'r') {
+			const unsigned int seed = mname[6] == ':' ? (unsigned int)strtoul(mname + 7, NULL, 10) : (unsigned int)time(NULL);   /* scan_methods.c:216 */
+			if (scan_order_random(width, height, seed, &fl)) { fprintf(stderr, "cannot draw the random scan order\n"); return 1; }
+		} else {
+			FILE *f = fopen(mname + 5, "r");
+			if (!f || scan_order_read_file(f, width, height, &fl)) { fprintf(stderr, "cannot read the scan order %s\n", mname + 5); return 1; }
+			fclose(f);
+		}
 		limit = fl.limit; slots = fl.max_interval;
 		/* a pixel listed under several indices needs per-frame lists; otherwise one owner-index array does */
 		uint32_t *owner = malloc(npix * 4);
@@ -84,7 +91,7 @@ int main(int argc, char *argv[])
 		method = scan_order_find_prefix(mname);                                               /* scan.c:176 scan_method_find_prefix */
 		if (method < 0) { fprintf(stderr, "unknown scan method %s\n", mname); return 2; }
 		limit = dspfft_scan_limit(method, w, h);
-		slots = dspfft_scan_max_interval(method, w, h);
+		slots = dspfft_scan_coord_slots(method, w, h);
 		per_frame_lists = method == DSPFFT_SCAN_BOX;
 	}
 	size_t step = argc > 3 ? strtoul(argv[3], NULL, 10) : (limit + 31) / 32;

@@ -55,7 +55,8 @@ size_t scan_order_max_interval(int method, size_t w, size_t h)
 	case SCAN_COLUMN: return h;
 	case SCAN_DIAGONAL: return umin(w, h);                         /* limit_min */
 	case SCAN_MIRROR: return umin(w, h) * 2 - 1;                   /* limit_mirror */
-	case SCAN_BOX: case SCAN_IBOX: return w + h - 1 + 1;           /* limit_sum (+1: ibox emits its corner twice) */
+	case SCAN_BOX: case SCAN_IBOX: return w + h - 1;               /* limit_sum (scan_methods.c:23,496,502).  ibox index 0 emits its corner twice = w + h
+	                                                                * coordinates: callers allocate max_interval + 1 entries, as scan.c:346 does */
 	case SCAN_RADIAL: case SCAN_IRADIAL: {
 		size_t lim = scan_order_limit(method, w, h), best = 0;
 		size_t *cnt = calloc(lim, sizeof *cnt);
@@ -231,6 +232,31 @@ done:
 	free(line);
 	pre_free(&p);
 	return ok ? 0 : 1;
+}
+
+int scan_order_random(size_t w, size_t h, unsigned int seed, struct scan_order_list *out)
+{
+	memset(out, 0, sizeof *out);
+	const size_t len = w * h;
+	if (!len) return 1;
+	size_t *ctx = malloc(sizeof(size_t) * len);
+	out->offset = malloc(sizeof(size_t) * (len + 1));
+	out->yx = malloc(sizeof(*out->yx) * (len + 1));
+	if (!ctx || !out->offset || !out->yx) { free(ctx); scan_order_list_free(out); return 1; }
+	srand(seed);                                                                       /* scan_methods.c:217 */
+	for (size_t i = 0; i < len; i++) ctx[i] = i;
+	for (size_t i = len - 1; i > 1; i--) {                                             /* :220-225: the loop ends above index 1 */
+		const size_t j = (size_t)rand() % (i + 1);
+		const size_t tmp = ctx[j];
+		ctx[j] = ctx[i];
+		ctx[i] = tmp;
+	}
+	for (size_t i = 0; i < len; i++) { out->offset[i] = i; out->yx[i][0] = ctx[i] / w; out->yx[i][1] = ctx[i] % w; }   /* :117-120 */
+	out->offset[len] = len;
+	out->limit = out->total = len;
+	out->max_interval = 1;
+	free(ctx);
+	return 0;
 }
 
 void scan_order_list_free(struct scan_order_list *l)

@@ -33,6 +33,12 @@ struct scan_order_list { size_t limit, max_interval, total; size_t *offset; size
 int scan_order_read_file(FILE *f, size_t w, size_t h, struct scan_order_list *out);
 void scan_order_list_free(struct scan_order_list *l);
 
+/* The `random` method (scan_methods.c:210-228 init_random + :117-120 scan_ordered): a permutation of the pixels drawn with libc's
+ * srand(seed) / rand() exactly as the tool draws it (Fisher-Yates from the top that stops above index 1), one coordinate per scan
+ * index.  Reproducible for a given libc and seed; the tool's default seed is time(NULL).  Returns 0 and fills *out like
+ * scan_order_read_file. */
+int scan_order_random(size_t w, size_t h, unsigned int seed, struct scan_order_list *out);
+
 /* scan_precomputed.c:122-153.  Return 0 on success. */
 int scan_order_serialize_coordinate(int method, size_t w, size_t h, FILE *f);
 int scan_order_serialize_index(int method, size_t w, size_t h, FILE *f);

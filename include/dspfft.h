@@ -64,6 +64,16 @@ int dspfft_execute_pass(dspfft_plan plan, int index, const float *d_in, float *d
  * dspfft_event_create; read with dspfft_event_elapsed_ms after dspfft_event_synchronize or a stream/device synchronise). */
 int dspfft_execute_many(int count, const dspfft_plan *plans, const float *const *d_in, float *const *d_out, void *const *hip_streams,
                         int timed_item, int timed_count, void *const *pass_events);
+/* The same batch `repeats` times with ONE call: the frame loop of a clip inside the library (motion/motion.c:613-753 executes its
+ * per-frame plans once per frame, scan/scan.c:421-447 its inverse plan once per output frame), so nothing of the host language sits
+ * between two frames.  rejoin_every > 0 and more than one distinct stream in the batch: every rejoin_every repeats each stream waits
+ * for the point the others have reached (two free-running streams otherwise keep whatever relative phase the first repeat's host timing
+ * gave them, and that phase decides how well their kernels share the CUs).
+ * Profiling aid: with pass_events non-NULL and timed_every > 0, repeats 0, timed_every, 2 timed_every ... bracket every pass of a window
+ * of timed_count consecutive items (timed_count must divide count); the window advances by timed_count items (mod count) each time, and
+ * the events of the j-th bracketed pass overall are pass_events[2j], pass_events[2j+1].  One-pass block plans cannot be bracketed. */
+int dspfft_execute_many_repeat(int count, const dspfft_plan *plans, const float *const *d_in, float *const *d_out, void *const *hip_streams,
+                               int repeats, int rejoin_every, int timed_every, int timed_count, void *const *pass_events);
 void *dspfft_event_create(void);
 void dspfft_event_destroy(void *event);
 int dspfft_event_synchronize(void *event);
@@ -84,7 +94,10 @@ int dspfft_execute_f64(dspfft_plan plan, const double *d_in, double *d_out, void
 /* Optional, for owner ids that stay the same over the frames of a scan (every method but box, whose ids are stamped per frame):
  * records the (min, max) owner id of every column tile of `plan`, so that a later dspfft_execute_masked_accumulate with the SAME
  * d_ids pointer and elems_per_id leaves a tile alone -- without reading its owner ids -- when `id` lies outside its range.  Call it
- * again after rewriting the ids; d_ids = NULL forgets.  Results are the same with or without it. */
+ * again after rewriting the ids; d_ids = NULL forgets.  Results are the same with or without it.
+ * The library cannot see writes to the id array: rewriting it (dspfft_scan_stamp, dspfft_scan_frame_ids, dspfft_scan_index_to_frame_ids
+ * or your own kernel on the same buffer) WITHOUT preparing again makes later steps skip the wrong tiles.  The prepared ranges and the
+ * per-tile flags are scratch of the plan: masked executions of one plan must be serialised on one stream (one plan per stream otherwise). */
 int dspfft_plan_scan_prepare(dspfft_plan plan, const uint32_t *d_ids, int elems_per_id, void *hip_stream);
 int dspfft_execute_masked_accumulate_f64(dspfft_plan plan, const double *d_in, double *d_work, double *d_acc,
                                          const uint32_t *d_ids, uint32_t id, int elems_per_id, void *hip_stream);
@@ -212,13 +225,16 @@ enum {
 /* number of scan indices (scan_context.c:30 via the method's limit function) and the most coordinates one index yields (host arithmetic) */
 uint64_t dspfft_scan_limit(int method, uint32_t w, uint32_t h);
 uint64_t dspfft_scan_max_interval(int method, uint32_t w, uint32_t h);
+/* entries per scan index in the coordinate lists below: max_interval, + 1 for box / ibox (the entry scan.c:346 over-allocates; ibox's
+ * index 0 emits w + h coordinates against max_interval = w + h - 1, scan_methods.c:135-144,502) */
+uint64_t dspfft_scan_coord_slots(int method, uint32_t w, uint32_t h);
 /* d_index[y*w+x] = the scan index that yields pixel (y,x); every method except box (no single owner) */
 int dspfft_scan_owner_index(uint32_t *d_index, int method, uint32_t w, uint32_t h, void *hip_stream);
 /* d_ids[y*w+x] = owner index / step, the DC pixel 0xFFFFFFFF: the generalisation of dspfft_scan_zigzag_frame_ids (which it calls for zigzag) */
 int dspfft_scan_frame_ids(uint32_t *d_ids, int method, uint32_t w, uint32_t h, uint64_t step, void *hip_stream);
-/* coordinate lists: for scan indices [first, first+count), slot j < dspfft_scan_max_interval of index i holds y*w+x of its j-th coordinate,
+/* coordinate lists: for scan indices [first, first+count), slot j < dspfft_scan_coord_slots of index i holds y*w+x of its j-th coordinate,
  * or 0xFFFFFFFF (slot beyond the index's interval, or a box coordinate past the end of the image); all methods but radial / iradial.
- * d_lin holds count * dspfft_scan_max_interval entries. */
+ * d_lin holds count * dspfft_scan_coord_slots entries. */
 int dspfft_scan_coords(uint32_t *d_lin, int method, uint32_t w, uint32_t h, uint64_t first, uint64_t count, void *hip_stream);
 /* d_ids[d_lin[t]] = frame_id for every valid entry (the DC pixel is left alone): builds the mask of ONE frame from coordinate lists;
  * ids of earlier frames need no clearing as long as frame ids are not reused (initialise d_ids to 0xFFFFFFFF once) */

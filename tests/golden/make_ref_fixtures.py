@@ -12,6 +12,7 @@ direct-sum statement of the same transforms, and this script compiles that code 
   applybasis/applybasis.c:77-140   the twelve basis functions (dct2 == REDFT10's kernel, dct3 == REDFT01's)
   applybasis/applybasis.c:146-147,370-380,410-425  coords/offsets, the forward / --inverse index aliasing, the
                              partial-sum loops (with the --offset handling of :419-421)
+  scan/scan_methods.c:210-228  init_random: the `random` scan order as this image's libc rand() draws it
 
 The text of those line ranges is read from /root/reference at generation time into a temporary translation unit
 that includes the reference's include/precision.h (COEFF_PRECISION=L, INTERMEDIATE_PRECISION=L: the tightest build
@@ -117,6 +118,14 @@ void ref_partsums(int f, int orthogonal, int inverse, coords insize, coords term
 }
 """
     return compile_tu(tmp, "applybasis", tu)
+
+
+def build_random(tmp):
+    """scan_methods.c:210-228 init_random (libc srand / rand) as it lies"""
+    tu = "#include <stdlib.h>\n#include <time.h>\n#include \"precision.h\"\n"
+    tu += lines("scan/scan_methods.c", 210, 228)
+    tu += "size_t *ref_init_random(size_t w, size_t h, const char *args) { return init_random(w, h, 3, NULL, args); }\n"
+    return compile_tu(tmp, "random", tu)
 
 
 def compile_tu(tmp, name, text):
@@ -261,6 +270,17 @@ def main():
             out[f"parts{i}_pix"] = pix
             out[f"parts{i}_out"] = o.astype(np.float64).reshape(K[1], K[0], N[1], N[0], 3, 2)
             print("partsums", parts[i])
+
+        # --- (5) scan's `random` order: the permutation init_random draws with this libc's rand() ------------------------
+        rn = build_random(tmp)
+        rn.ref_init_random.restype = C.POINTER(C.c_size_t)
+        rn.ref_init_random.argtypes = [C.c_size_t, C.c_size_t, C.c_char_p]
+        rcases = [(16, 9, 42), (9, 16, 7), (64, 48, 123456789)]
+        out["random_cases"] = np.array(rcases)
+        for i, (w, h, seed) in enumerate(rcases):
+            ptr = rn.ref_init_random(w, h, str(seed).encode())
+            out[f"random{i}_perm"] = np.array(ptr[:w * h], dtype=np.uint64)
+            print("random", (w, h, seed))
 
     path = os.path.join(HERE, "ref_direct.npz")
     np.savez_compressed(path, **out)

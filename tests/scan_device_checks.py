@@ -61,7 +61,7 @@ def check_method(L, so, m, w, h, alloc, fetch):
         hnd, ptr = alloc(w * h)
         assert L.dspfft_scan_owner_index(ptr, m, w, h, None) != 0      # refused: no single owner
     # ---- coordinate lists (every method but radial / iradial) ----
-    slots = L.dspfft_scan_max_interval(m, w, h)
+    slots = L.dspfft_scan_coord_slots(m, w, h)
     if name in ("radial", "iradial"):
         assert slots == 0
         return

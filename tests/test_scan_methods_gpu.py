@@ -112,7 +112,7 @@ def test_device_resident_frame_loop(gpu, so, method):
     elif method != "box":
         assert L.dspfft_scan_frame_ids(ids.data_ptr(), m, w, h, step, None) == 0
     else:
-        slots = L.dspfft_scan_max_interval(m, w, h)
+        slots = L.dspfft_scan_coord_slots(m, w, h)
         lin = torch.zeros(step * slots, dtype=torch.int32, device="cuda:0")
     acc = torch.empty_like(coeffs)
     work2 = torch.empty_like(coeffs)

@@ -180,3 +180,31 @@ def test_file_method_reader_roundtrips_and_matches_the_reference_deserialiser(so
     assert so.scan_order_read_file(f, max(1, w - 1), h, C.byref(lst)) != 0
     libc.fclose(f)
     os.unlink(path)
+
+
+def test_box_ibox_max_interval_is_limit_sum(so):
+    """scan_methods.c:23,496,502: box and ibox report limit_sum = w + h - 1, although ibox's index 0 emits its corner twice (w + h
+    coordinates) -- the tool's buffer has one entry to spare (scan.c:346).  The value feeds scan.c:349-350's use_fftw selector."""
+    for (w, h) in ((16, 9), (9, 16), (8, 8), (1920, 1080)):
+        for name in ("box", "ibox"):
+            assert so.scan_order_max_interval(METHODS.index(name), w, h) == w + h - 1
+    buf = np.zeros((16 + 9 + 1, 2), dtype=np.uint64)
+    assert so.scan_order_coords(METHODS.index("ibox"), 16, 9, 0, buf.ctypes.data) == 16 + 9
+
+
+def test_random_order_is_the_references_permutation(so):
+    """scan_methods.c:210-228 init_random compiled as it lies (tests/golden/make_ref_fixtures.py) against host/scan_orders.c's
+    scan_order_random: same libc rand() stream, same Fisher-Yates loop (ends above index 1), coordinates ctx[i] / w, ctx[i] % w."""
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "ref_direct.npz"))
+    so.scan_order_random.argtypes = [C.c_size_t, C.c_size_t, C.c_uint, C.POINTER(_OrderList)]
+    so.scan_order_list_free.argtypes = [C.POINTER(_OrderList)]
+    for i, (w, h, seed) in enumerate(fx["random_cases"]):
+        w, h, seed = int(w), int(h), int(seed)
+        lst = _OrderList()
+        assert so.scan_order_random(w, h, seed, C.byref(lst)) == 0
+        assert lst.limit == w * h and lst.max_interval == 1 and lst.total == w * h
+        yx = np.array([[lst.yx[k][0], lst.yx[k][1]] for k in range(w * h)], dtype=np.uint64)
+        perm = fx[f"random{i}_perm"]
+        assert np.array_equal(yx[:, 0] * np.uint64(w) + yx[:, 1], perm)
+        assert sorted(perm.tolist()) == list(range(w * h))
+        so.scan_order_list_free(C.byref(lst))
