@@ -151,6 +151,7 @@ def main():
     ap.add_argument("--schedule", choices=["free", "aligned", "realign"], default="realign", help="how two streams interleave their frames (see step())")
     ap.add_argument("--event-every", type=int, default=4, help="bracket the passes of one frame with events every N-th step (events between "
                     "dependent launches cost throughput: every step -3 %%, every launch -7 %%)")
+    ap.add_argument("--inverse-order", choices=["columns-first", "rows-first"], default="columns-first", help="axis order of the REDFT01 plan")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -180,7 +181,11 @@ def main():
 
     from dspfun_amd import Plan, REDFT10, REDFT01
     fwd = Plan.image(H, W, C, REDFT10)
-    inv = Plan.image(H, W, C, REDFT01).set_scale(1.0 / (4.0 * W * H))
+    # the inverse plan runs its column pass first (dspfft_plan_many_r2r_ordered: the planner's choice of axis order, same results): a
+    # frame's four launches are then ROW, COL | COL, ROW and each stream changes workgroup shape twice per frame instead of four
+    # times, so the two streams overlap same-shaped kernels more of the time (+1 %, tools/cbench.c)
+    inv = Plan.many_r2r([H, W], [REDFT01] * 2, howmany=C, istride=C, idist=1, ostride=C, odist=1,
+                        first_axis_first=(args.inverse_order == "columns-first")).set_scale(1.0 / (4.0 * W * H))
     frames = synth_frames(torch, args.frames, dev)
     ref0 = frames[0].clone()
     torch.cuda.synchronize()          # the frames are used on other streams from here on
@@ -190,8 +195,11 @@ def main():
     # independent frames may run on separate HIP streams: kernels of different frames (and different
     # pass shapes) then share the CUs, so one frame's memory-bound phases overlap another's butterflies
     nstreams = max(1, min(args.streams, args.frames))
-    side = [torch.cuda.Stream(device=dev) for _ in range(nstreams)] if nstreams > 1 else []
-    handles = [s_.cuda_stream for s_ in side] if side else [stream]
+    # the streams are the library's own (dspfft_stream_create = hipStreamCreateWithFlags(hipStreamNonBlocking)): two streams from
+    # torch's pool were seen sharing a hardware queue, which serialises the frames they carry (tools/py_enqueue_probe.py: 48K vs 56K)
+    from dspfun_amd.engine import Stream
+    side = [Stream() for _ in range(nstreams)] if nstreams > 1 else []
+    handles = [s_.handle for s_ in side] if side else [stream]
 
     from dspfun_amd.engine import Batch, Events
     npass = fwd.num_passes + inv.num_passes
@@ -311,7 +319,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (splitmix64 uniform [0,1), SURVEY.md 8d seed 0xD5F0002)",
             "config": {"workload": "spec + ispec roundtrip on 3840x2160 RGB float32 (BASELINE configs[1])",
-                       "frames_per_gpu_per_step": args.frames, "hip_streams": nstreams, "stream_schedule": schedule, "step_loop": "dspfft_execute_many_repeat (one library call for all steps)", "layout": "interleaved HWC, in place, device-resident",
+                       "frames_per_gpu_per_step": args.frames, "hip_streams": nstreams, "stream_schedule": schedule, "step_loop": "dspfft_execute_many_repeat (one library call for all steps)", "inverse_plan_order": args.inverse_order, "layout": "interleaved HWC, in place, device-resident",
                        "parallelism": f"frame-sharded x{world}, no collective"},
             "roundtrip_frac_of_hbm_roofline": round(value * 1e6 * ALG_BYTES_PER_PIXEL / (HBM_PEAK * world), 4),      # per GPU
             "max_abs_drift_after_all_roundtrips": drift, "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 5),

@@ -88,6 +88,10 @@ void be_event_destroy(void *e);
 int be_event_record(void *e, void *stream);
 int be_event_synchronize(void *e);
 int be_event_elapsed_ms(void *a, void *b, float *ms);
+// streams of the library's own (dspfft_stream_create): plain non-blocking HIP streams
+void *be_stream_create();
+void be_stream_destroy(void *s);
+int be_stream_synchronize(void *s);
 // ordering-only events between streams (dspfft_execute_many_repeat re-joins its streams with them)
 void *be_order_event_create();
 int be_stream_wait_event(void *stream, void *e);

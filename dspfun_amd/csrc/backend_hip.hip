@@ -222,6 +222,9 @@ void be_event_destroy(void *e) { if (e) (void)hipEventDestroy((hipEvent_t)e); }
 int be_event_record(void *e, void *stream) { HIPCHK(hipEventRecord((hipEvent_t)e, (hipStream_t)stream)); return 0; }
 int be_event_synchronize(void *e) { HIPCHK(hipEventSynchronize((hipEvent_t)e)); return 0; }
 int be_event_elapsed_ms(void *a, void *b, float *ms) { HIPCHK(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b)); return 0; }
+void *be_stream_create() { hipStream_t s = nullptr; if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr; return (void *)s; }
+void be_stream_destroy(void *s) { if (s) (void)hipStreamDestroy((hipStream_t)s); }
+int be_stream_synchronize(void *s) { HIPCHK(hipStreamSynchronize((hipStream_t)s)); return 0; }
 void *be_order_event_create() { hipEvent_t e = nullptr; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr; return (void *)e; }
 int be_stream_wait_event(void *stream, void *e) { HIPCHK(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)e, 0)); return 0; }
 size_t be_max_lds() { return 160 * 1024; }

@@ -1462,6 +1462,9 @@ extern "C" int dspfft_execute_many_repeat(int count, const dspfft_plan *plans, c
 	for (void *x : join) be_event_destroy(x);
 	return rc;
 }
+extern "C" void *dspfft_stream_create(void) { return be_stream_create(); }
+extern "C" void dspfft_stream_destroy(void *s) { be_stream_destroy(s); }
+extern "C" int dspfft_stream_synchronize(void *s) { return be_stream_synchronize(s) ? fail(-4, "stream synchronise failed") : 0; }
 extern "C" void *dspfft_event_create(void) { return be_event_create(); }
 extern "C" void dspfft_event_destroy(void *e) { be_event_destroy(e); }
 extern "C" int dspfft_event_synchronize(void *e) { return e && !be_event_synchronize(e) ? 0 : fail(-4, "event synchronise failed"); }

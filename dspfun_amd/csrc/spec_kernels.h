@@ -23,9 +23,21 @@ static int allow_lds(K kernel, size_t bytes)
 // One workgroup per line / tile.  (A persistent variant that prefetched the next item into
 // registers was measured slower on MI355X: the extra ~60 VGPRs cost a resident workgroup per CU,
 // and co-resident workgroups already overlap each other's memory and LDS phases.)
-template <class S, int KIND>
-__global__ void __launch_bounds__(S::T, S::WPE) row_spec_kernel(const typename S::PA a)
+// PLAIN: the instantiation a plain dspfft_execute runs -- no owner-id mask, no tile flags, no accumulation.  The fused scan step's
+// fields are pinned to "off" on a local copy of the arguments, so every branch on them folds away after inlining (the fused code is a
+// third of the kernel's text; two such kernels sharing the CUs ran 1.5 % faster without it: tools/sbench.hip vs -DUSELIB)
+template <class PA> __device__ inline PA plain_args(const PA &a_)
 {
+	PA a = a_;
+	a.mask = nullptr; a.zflags = nullptr; a.zranges = nullptr; a.accumulate = 0;
+	return a;
+}
+template <class PA> static inline bool is_plain(const PA &a) { return !a.mask && !a.zflags && !a.accumulate; }
+
+template <class S, int KIND, bool PLAIN>
+__global__ void __launch_bounds__(S::T, S::WPE) row_spec_kernel(const typename S::PA a_)
+{
+	const typename S::PA a = PLAIN ? plain_args(a_) : a_;
 	extern __shared__ __attribute__((aligned(32))) unsigned char lds[];
 	typename S::CX *planes = reinterpret_cast<typename S::CX *>(lds);
 	const int tid = threadIdx.x;
@@ -66,9 +78,10 @@ __global__ void __launch_bounds__(S::T, S::WPE) row_spec_u8_kernel(const typenam
 	});
 }
 
-template <class S, int KIND>
-__global__ void __launch_bounds__(S::T, S::WPE) col_spec_kernel(const typename S::PA a)
+template <class S, int KIND, bool PLAIN>
+__global__ void __launch_bounds__(S::T, S::WPE) col_spec_kernel(const typename S::PA a_)
 {
+	const typename S::PA a = PLAIN ? plain_args(a_) : a_;
 	extern __shared__ __attribute__((aligned(32))) unsigned char lds[];
 	typename S::V *buf = reinterpret_cast<typename S::V *>(lds);
 	const int tid = threadIdx.x;
@@ -188,18 +201,20 @@ __global__ void __launch_bounds__(S::T, rt_waves_per_simd<S>()) col_roundtrip_ke
 template <class S, int KIND>
 int launch_row_spec(const typename S::PA &a, int nwork, void *stream)
 {
-	static int lds_ok = allow_lds(row_spec_kernel<S, KIND>, S::LDS);
+	static int lds_ok = allow_lds(row_spec_kernel<S, KIND, false>, S::LDS) | allow_lds(row_spec_kernel<S, KIND, true>, S::LDS);
 	if (lds_ok) return lds_ok;
-	hipLaunchKernelGGL((row_spec_kernel<S, KIND>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a);
+	if (is_plain(a)) hipLaunchKernelGGL((row_spec_kernel<S, KIND, true>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a);
+	else hipLaunchKernelGGL((row_spec_kernel<S, KIND, false>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a);
 	HIPCHK(hipGetLastError());
 	return 0;
 }
 template <class S, int KIND>
 int launch_col_spec(const typename S::PA &a, int nwork, void *stream)
 {
-	static int lds_ok = allow_lds(col_spec_kernel<S, KIND>, S::LDS);
+	static int lds_ok = allow_lds(col_spec_kernel<S, KIND, false>, S::LDS) | allow_lds(col_spec_kernel<S, KIND, true>, S::LDS);
 	if (lds_ok) return lds_ok;
-	hipLaunchKernelGGL((col_spec_kernel<S, KIND>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a);
+	if (is_plain(a)) hipLaunchKernelGGL((col_spec_kernel<S, KIND, true>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a);
+	else hipLaunchKernelGGL((col_spec_kernel<S, KIND, false>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a);
 	HIPCHK(hipGetLastError());
 	return 0;
 }

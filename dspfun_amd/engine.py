@@ -184,6 +184,26 @@ class Plan:
             raise DspfftError(self._lib.dspfft_last_error().decode())
 
 
+class Stream:
+    """A HIP stream of the library's own (dspfft_stream_create: hipStreamNonBlocking).  `handle` is what execute / Batch take."""
+
+    def __init__(self, lib=None):
+        self._lib = lib or _lib.load()
+        self.handle = self._lib.dspfft_stream_create()
+        if not self.handle:
+            raise DspfftError("stream creation failed")
+
+    def synchronize(self):
+        if self._lib.dspfft_stream_synchronize(self.handle):
+            raise DspfftError(self._lib.dspfft_last_error().decode())
+
+    def __del__(self):
+        try:
+            self._lib.dspfft_stream_destroy(self.handle)
+        except Exception:
+            pass
+
+
 class Events:
     """n timing events of the library (dspfft_event_create): recorded by Batch.run on the streams of the bracketed items"""
 

@@ -74,6 +74,13 @@ int dspfft_execute_many(int count, const dspfft_plan *plans, const float *const 
  * the events of the j-th bracketed pass overall are pass_events[2j], pass_events[2j+1].  One-pass block plans cannot be bracketed. */
 int dspfft_execute_many_repeat(int count, const dspfft_plan *plans, const float *const *d_in, float *const *d_out, void *const *hip_streams,
                                int repeats, int rejoin_every, int timed_every, int timed_count, void *const *pass_events);
+/* Streams of the library's own for the calls above: plain non-blocking HIP streams (hipStreamCreateWithFlags(hipStreamNonBlocking)),
+ * for hosts without a HIP binding of their own (cgo, ctypes ...) and for hosts whose framework hands out streams from a pool:
+ * two streams of torch's pool were seen sharing a hardware queue, which serialises the two frames they carry (48K instead of 56K
+ * Mpix/s on the 4K roundtrip, tools/py_enqueue_probe.py).  NULL on failure. */
+void *dspfft_stream_create(void);
+void dspfft_stream_destroy(void *stream);
+int dspfft_stream_synchronize(void *stream);
 void *dspfft_event_create(void);
 void dspfft_event_destroy(void *event);
 int dspfft_event_synchronize(void *event);

@@ -28,6 +28,9 @@ void be_event_destroy(void *e) { free(e); }
 int be_event_record(void *, void *) { return 0; }
 int be_event_synchronize(void *) { return 0; }
 int be_event_elapsed_ms(void *, void *, float *ms) { *ms = 0.f; return 0; }
+void *be_stream_create() { return malloc(1); }
+void be_stream_destroy(void *s) { free(s); }
+int be_stream_synchronize(void *) { return 0; }
 void *be_order_event_create() { return malloc(1); }
 int be_stream_wait_event(void *, void *) { return 0; }
 

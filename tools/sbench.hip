@@ -74,9 +74,26 @@ static Tables make_tables(int N, int L)
 }
 static Tables g_trow, g_tcol;
 
+#ifdef USELIB
+// -DUSELIB (link with -ldspfft_hip): the same schedules with the LIBRARY's launches (dspfft_execute_pass) instead of this file's kernels
+#include "../include/dspfft.h"
+static dspfft_plan g_fwd, g_inv;
+#endif
 // pass p (0 ROW10, 1 COL10, 2 COL01, 3 ROW01) over `nfr` consecutive frames starting at frame f0
 static void launch_pass(int p, int f0, int nfr, hipStream_t s)
 {
+#ifdef USELIB
+	if (nfr == 1) {
+		if (!g_fwd) {
+			const int dims[2] = {H, W}, k10[2] = {DSPFFT_REDFT10, DSPFFT_REDFT10}, k01[2] = {DSPFFT_REDFT01, DSPFFT_REDFT01};
+			if (dspfft_plan_many_r2r(&g_fwd, 2, dims, C, NULL, C, 1, NULL, C, 1, k10) || dspfft_plan_many_r2r_ordered(&g_inv, 2, dims, C, NULL, C, 1, NULL, C, 1, k01, 1)) { printf("plan failed\n"); exit(1); }
+			dspfft_plan_set_scale(g_inv, 1.0f / (4.0f * W * H));
+		}
+		float *b = g_buf + (size_t)f0 * NF;
+		if (dspfft_execute_pass(p <= 1 ? g_fwd : g_inv, p & 1, b, b, s)) { printf("execute_pass failed: %s\n", dspfft_last_error()); exit(1); }
+		return;
+	}
+#endif
 	PassArgs a; memset((void *)&a, 0, sizeof a);
 	a.in = a.out = g_buf + (size_t)f0 * NF;
 	a.in_scale0 = a.out_scale0 = 1.f;
