@@ -153,6 +153,7 @@ def main():
                     "dependent launches cost throughput: every step -3 %%, every launch -7 %%)")
     ap.add_argument("--inverse-order", choices=["columns-first", "rows-first"], default="columns-first", help="axis order of the REDFT01 plan")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-motion", action="store_true", help="skip the motion_c5 object (BASELINE configs[4]: per-frame blocks and the RCCL slab volume)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -310,6 +311,17 @@ def main():
                 "isolated_kernel_ms": {names[i]: round(iso[i], 5) for i in range(npass)},
                 "isolated_frac_dominant": round(alg / (max(iso) * 1e-3) / HBM_PEAK, 4)}
 
+    # BASELINE configs[4] beside the headline: motion's per-frame blocks (frame-sharded, no collective; strong and
+    # weak) and its one-3-D-block mode through SlabDCT3D -- the one path that exercises RCCL all-to-all -- so that a SCALE record at
+    # N = 2, 4, 8 carries the curve north_star asks for.  Every rank takes part; its own barriers and max-over-ranks timing.
+    motion = None
+    if not args.no_motion:
+        del frames, ref0
+        torch.cuda.empty_cache()
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from bench_motion import motion_c5
+        motion = motion_c5(torch, dist, dev, rank, world)
+
     if rank == 0:
         pixels = args.steps * args.frames * world * H * W
         value = pixels / 1e6 / elapsed
@@ -325,6 +337,8 @@ def main():
             "max_abs_drift_after_all_roundtrips": drift, "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 5),
             "roofline": roof,
         }
+        if motion is not None:
+            line["motion_c5"] = motion
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
             fw_ = fftw_cpu_baseline()

@@ -57,7 +57,9 @@ def _worker(rank, world, port, d, h, w, chunks, q):
 
 # (d, h, w, world, chunks): even splits; h % G != 0 and d % G != 0 (BASELINE config 5's chroma planes: 540 rows on 8 ranks);
 # a rank with no rows at all; one piece and more pieces than rows
-@pytest.mark.parametrize("d,h,w,world,chunks", [(8, 12, 10, 2, 1), (16, 30, 24, 2, 4), (6, 27, 10, 2, 3), (7, 10, 12, 3, 2), (4, 5, 8, 3, 8), (9, 2, 8, 3, 1)])
+# world 4 and 8 (the node sizes the SCALE record uses) with h % G != 0 and d % G != 0: 16 x 27 x 8 on 4 and on 8 ranks, 10 frames on 8 ranks
+@pytest.mark.parametrize("d,h,w,world,chunks", [(8, 12, 10, 2, 1), (16, 30, 24, 2, 4), (6, 27, 10, 2, 3), (7, 10, 12, 3, 2), (4, 5, 8, 3, 8), (9, 2, 8, 3, 1),
+                                                (16, 27, 8, 4, 2), (16, 27, 8, 8, 3), (10, 12, 16, 8, 1)])
 def test_slab_dct3d_gloo(d, h, w, world, chunks):
     import subprocess
     subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "emul")])
@@ -129,17 +131,19 @@ def _scan_worker(rank, world, port, h, w, step, q):
         dist.destroy_process_group()
 
 
-def test_channel_sharded_scan_world2():
+@pytest.mark.parametrize("world", [2, 4])
+def test_channel_sharded_scan(world):
+    """BASELINE config 4 names 4 GPUs for 3 colour planes: with world 4 the fourth rank owns no plane (75 % ceiling, stated in DESIGN 6)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_scan_worker, args=(r, 2, port, 12, 20, 37, q)) for r in range(2)]
+    procs = [ctx.Process(target=_scan_worker, args=(r, world, port, 12, 20, 37, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert sorted(n for _, n, _ in res) == [1, 2]          # 3 planes over 2 ranks
+    assert sorted(n for _, n, _ in res) == ([1, 2] if world == 2 else [0, 1, 1, 1])          # 3 planes over the ranks
     for rank, _, errs in res:
         assert max(errs) < 1e-5, (rank, errs)

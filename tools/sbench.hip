@@ -59,7 +59,24 @@ typedef RowSpec<3840, 3, 768, 12, 10, 16> RS;
 #else
 typedef RowSpec<3840, 3, 512, 12, 10, 16> RS;
 #endif
+// column-tile variants measured in round 3: -DCS_K4: 2160 x 4-float tiles, 34.7 KB, four 256-thread workgroups per CU;
+// -DCS_2STAGE: two stages 48 x 45 (one LDS round trip fewer; 96 butterflies per stage -> 128 threads); -DCS_4STAGE: 6 x 6 x 6 x 10
+// (more, shorter butterflies: 720 / 432 work items per stage for 512 threads)
+#if defined(CS_K4)
+typedef ColSpec<2160, 4, 256, 12, 12, 15> CS;
+#elif defined(CS_2STAGE)
+typedef ColSpec<2160, 8, 128, 48, 45> CS;
+#elif defined(CS_2STAGE_K16)
+typedef ColSpec<2160, 16, 256, 48, 45> CS;
+#elif defined(CS_4STAGE)
+typedef ColSpec<2160, 8, 512, 6, 6, 6, 10> CS;
+#elif defined(CS_4STAGE_768)
+typedef ColSpec<2160, 8, 768, 6, 6, 6, 10> CS;
+#elif defined(CS_4STAGE_B)
+typedef ColSpec<2160, 8, 512, 8, 6, 5, 9> CS;
+#else
 typedef ColSpec<2160, 8, 512, 12, 12, 15> CS;
+#endif
 
 struct Tables { cf *T, *Wt; };
 static Tables make_tables(int N, int L)
