@@ -24,7 +24,8 @@ SYMBOLS = [
     "dspfft_scan_index_to_frame_ids", "dspfft_scan_magnitude_work_bytes", "dspfft_scan_magnitude_index",
     "dspfft_u8_to_f32", "dspfft_f32_to_u8",
     "dspfft_zoom_ncomponents", "dspfft_zoom_basis", "dspfft_zoom_work_floats", "dspfft_zoom_product", "dspfft_gemm_nt_f32",
-    "dspfft_zoom_last_error", "dspfft_applybasis_work_floats", "dspfft_applybasis_partsums",
+    "dspfft_zoom_last_error", "dspfft_zoomfft_create", "dspfft_zoomfft_work_floats", "dspfft_zoomfft_execute", "dspfft_zoomfft_destroy", "dspfft_zoomfft_last_error",
+    "dspfft_applybasis_work_floats", "dspfft_applybasis_partsums",
     "dspfft_applybasis_work_floats_ex", "dspfft_applybasis_partsums_ex", "dspfft_applybasis_render",
     "dspfft_motion_load_u8", "dspfft_motion_store_u8", "dspfft_motion_topn_work_bytes", "dspfft_motion_topn", "dspfft_motion_last_error",
     "dspfft_spec_encode", "dspfft_ispec_decode", "dspfft_ispec_signmap", "dspfft_motion_filter", "dspfft_scan_pruned_accumulate", "dspfft_scan_pruned_work_floats", "dspfft_scan_pruned_accumulate_ws", "dspfft_pointwise_last_error",
@@ -120,6 +121,12 @@ def bind(lib):
         lib.dspfft_gemm_nt_f32.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_longlong, C.c_longlong, C.c_int,
                                            C.c_int, C.c_longlong, C.c_longlong, C.c_longlong, C.c_float, vp]
         lib.dspfft_zoom_last_error.restype = C.c_char_p
+        lib.dspfft_zoomfft_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
+        lib.dspfft_zoomfft_work_floats.restype = C.c_size_t
+        lib.dspfft_zoomfft_work_floats.argtypes = [vp]
+        lib.dspfft_zoomfft_execute.argtypes = [vp, vp, C.c_double, C.c_double, vp, vp, vp]
+        lib.dspfft_zoomfft_destroy.argtypes = [vp]
+        lib.dspfft_zoomfft_last_error.restype = C.c_char_p
         lib.dspfft_spec_encode.argtypes = [vp, C.c_size_t, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, vp]
         lib.dspfft_ispec_decode.argtypes = [vp, C.c_size_t, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, vp]
         lib.dspfft_motion_filter.argtypes = [vp, ip, ip, ip, ip, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, vp, vp]

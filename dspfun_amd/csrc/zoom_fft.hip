@@ -1,0 +1,187 @@
+// zoom_fft.hip -- zoom's basis x coefficient product (zoom/zoom.c:36-68,361-375) by fast transforms, for the scales at which the
+// output samples of an axis lie on a DCT-III grid ("an O(N log N) alternative for integer scales").
+//
+// For the `interpolated` and `native` bases an output sample b of an axis of length `len` at scale s = num/den is
+//     out[b] = sum'_n C[n] cos(pi n (alpha b + beta))        (sum' halves n = 0; n < ncomponents, zoom.c:41,364,369)
+// with alpha = 1 / (len s) for both (zoom.c:49-57).  Whenever M = len s is an integer this is
+//     cos(pi n (b + 1/2) / M + theta n),   theta = pi (off + (s - 1) / 2) / M  (interpolated),  pi off / M  (native)
+//   = cos(theta n) cos(pi n (b + 1/2) / M) - sin(theta n) sin(pi n (b + 1/2) / M)
+// and, with n' = M - n, sin(pi (b + 1/2)(M - n') / M) = (-1)^b cos(pi (b + 1/2) n' / M).  So per axis
+//     out[b] = 1/2 REDFT01_M(A)[b] - (-1)^b 1/2 REDFT01_M(E)[b],   A[n] = C[n] cos(theta n),  E[n'] = C[M - n'] sin(theta (M - n'))
+// (zero where n >= ncomponents): two length-M REDFT01s per axis on the engine's own row / column kernels instead of a dense
+// (len s) x len product -- BASELINE config 3 (1920x1080 -> 7680x4320): 310 GFLOP of MFMA work become about 4.4 GB of streaming.
+// The offset only enters theta, so an animation's pan (zoom.c:323-340) re-plans nothing.  Other scales, the `centered` basis and
+// viewports wider than M keep the dense product (dspfft_zoom_product, zoom_gemm.hip).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/dspfft.h"
+
+namespace {
+
+thread_local char g_err[256] = "";
+
+// cs[2 n] = cos(theta n), cs[2 n + 1] = sin(theta n), evaluated in double
+__global__ void zf_table_kernel(float *cs, double theta, int n)
+{
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		double s, c;
+		sincos(theta * (double)i, &s, &c);
+		cs[2 * i] = (float)c; cs[2 * i + 1] = (float)s;
+	}
+}
+
+// x stage inputs from the coefficients: A[v][u] = C[v][u] cos(theta u), E[v][u] = C[v][M - u] sin(theta (M - u)); rows v < ch, pitch M pixels
+__global__ void zf_prep_x_kernel(float *A, float *E, const float *C, const float *cs, int w, int ch, int cw, int M)
+{
+	const size_t total = (size_t)ch * M;
+	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+		const int v = (int)(i / M), u = (int)(i - (size_t)v * M);
+		float a0 = 0, a1 = 0, a2 = 0, e0 = 0, e1 = 0, e2 = 0;
+		if (u < cw) { const float *p = C + ((size_t)v * w + u) * 3; const float c = cs[2 * u]; a0 = p[0] * c; a1 = p[1] * c; a2 = p[2] * c; }
+		const int n = M - u;
+		if (u >= 1 && n >= 1 && n < cw) { const float *p = C + ((size_t)v * w + n) * 3; const float s = cs[2 * n + 1]; e0 = p[0] * s; e1 = p[1] * s; e2 = p[2] * s; }
+		float *pa = A + i * 3, *pe = E + i * 3;
+		pa[0] = a0; pa[1] = a1; pa[2] = a2; pe[0] = e0; pe[1] = e1; pe[2] = e2;
+	}
+}
+
+// between the stages: T[v][b] = YA[v][b] - (-1)^b YE[v][b] (the 1/2 is the row plan's scale), then the y stage's inputs
+// A2[v'][b] = T[v'][b] cos(theta_y v'), E2[v'][b] = T[My - v'][b] sin(theta_y (My - v')), rows v' < My, pitch vw pixels (float4 lanes: vw*3 % 4 == 0)
+template <int VEC>
+__global__ void zf_mid_kernel(float *A2, float *E2, const float *YA, const float *YE, const float *cs, int ch, int Mx, int vw, int My)
+{
+	const size_t rowf = (size_t)vw * 3, rowv = rowf / VEC, total = (size_t)My * rowv;
+	typedef float vec __attribute__((ext_vector_type(VEC)));
+	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+		const int v = (int)(i / rowv);
+		const size_t f = (i - (size_t)v * rowv) * VEC;           // first float of this lane within the row
+		vec a, e;
+		for (int k = 0; k < VEC; k++) { a[k] = 0.f; e[k] = 0.f; }
+		const int n = My - v;
+		if (v < ch) {
+			const vec ya = *reinterpret_cast<const vec *>(YA + (size_t)v * Mx * 3 + f), ye = *reinterpret_cast<const vec *>(YE + (size_t)v * Mx * 3 + f);
+			const float c = cs[2 * v];
+			for (int k = 0; k < VEC; k++) { const int b = (int)((f + k) / 3); a[k] = (ya[k] - ((b & 1) ? -ye[k] : ye[k])) * c; }
+		}
+		if (v >= 1 && n >= 1 && n < ch) {
+			const vec ya = *reinterpret_cast<const vec *>(YA + (size_t)n * Mx * 3 + f), ye = *reinterpret_cast<const vec *>(YE + (size_t)n * Mx * 3 + f);
+			const float s = cs[2 * n + 1];
+			for (int k = 0; k < VEC; k++) { const int b = (int)((f + k) / 3); e[k] = (ya[k] - ((b & 1) ? -ye[k] : ye[k])) * s; }
+		}
+		*reinterpret_cast<vec *>(A2 + (size_t)v * rowf + f) = a;
+		*reinterpret_cast<vec *>(E2 + (size_t)v * rowf + f) = e;
+	}
+}
+
+// out[j][b] = ZA[j][b] - (-1)^j ZE[j][b]   (1 / (2 w h) is the column plan's scale)
+template <int VEC>
+__global__ void zf_final_kernel(float *out, const float *ZA, const float *ZE, int vw, int vh)
+{
+	const size_t rowv = (size_t)vw * 3 / VEC, total = (size_t)vh * rowv;
+	typedef float vec __attribute__((ext_vector_type(VEC)));
+	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+		const int j = (int)(i / rowv);
+		const vec a = reinterpret_cast<const vec *>(ZA)[i], e = reinterpret_cast<const vec *>(ZE)[i];
+		reinterpret_cast<vec *>(out)[i] = (j & 1) ? a + e : a - e;
+	}
+}
+
+// len * num / den as an integer M >= 1, or 0
+long long grid_length(int len, double num, double den)
+{
+	if (!(num > 0) || !(den > 0)) return 0;
+	if (len * num / den < 1) return 0;                    // zoom.c:37-40 clamps such scales to one sample: the dense path handles them
+	const double m = len * num / den, r = round(m);
+	return fabs(m - r) <= 1e-9 * m && r >= 1 && r < (double)(1 << 30) ? (long long)r : 0;
+}
+
+}  // namespace
+
+struct dspfft_zoomfft_s {
+	int w, h, type, vw, vh;
+	long long Mx, My;
+	size_t cw, ch;
+	double sx, sy;                 // scales
+	dspfft_plan rows, cols;
+};
+
+extern "C" const char *dspfft_zoomfft_last_error(void) { return g_err; }
+
+extern "C" int dspfft_zoomfft_create(dspfft_zoomfft *out, int w, int h, int type, double xnum, double xden, double ynum, double yden, int vw, int vh)
+{
+	if (!out || w < 1 || h < 1 || vw < 1 || vh < 1) { snprintf(g_err, sizeof g_err, "bad arguments"); return -1; }
+	*out = nullptr;
+	if (type != 0 && type != 2) { snprintf(g_err, sizeof g_err, "the centered basis does not sample a DCT-III grid: use dspfft_zoom_product"); return -2; }
+	const long long Mx = grid_length(w, xnum, xden), My = grid_length(h, ynum, yden);
+	if (!Mx || !My) { snprintf(g_err, sizeof g_err, "length x scale is not an integer: use dspfft_zoom_product"); return -2; }
+	if (vw > Mx || vh > My) { snprintf(g_err, sizeof g_err, "viewport larger than the scaled image: use dspfft_zoom_product"); return -2; }
+	dspfft_zoomfft z = new dspfft_zoomfft_s();
+	z->w = w; z->h = h; z->type = type; z->vw = vw; z->vh = vh; z->Mx = Mx; z->My = My;
+	z->cw = dspfft_zoom_ncomponents(xnum, xden, (size_t)w); z->ch = dspfft_zoom_ncomponents(ynum, yden, (size_t)h);
+	z->sx = xnum / xden; z->sy = ynum / yden;
+	z->rows = z->cols = nullptr;
+	const int k01[1] = {DSPFFT_REDFT01};
+	// x stage: A and E one after the other = 2 ch lines of Mx RGB pixels, transformed along x
+	const dspfft_iodim rd[1] = {{(int)Mx, 3, 3}}, rb[2] = {{3, 1, 1}, {(int)(2 * z->ch), (int)(Mx * 3), (int)(Mx * 3)}};
+	// y stage: two arrays of My rows x vw RGB pixels, transformed along y
+	const long long arr = My * (long long)vw * 3;
+	if (arr >= (1ll << 31) || Mx * 3 * 2 * (long long)z->ch >= (1ll << 31)) { delete z; snprintf(g_err, sizeof g_err, "frame too large for 31-bit strides"); return -2; }
+	const dspfft_iodim cd[1] = {{(int)My, vw * 3, vw * 3}}, cb[2] = {{vw * 3, 1, 1}, {2, (int)arr, (int)arr}};
+	if (dspfft_plan_guru_r2r(&z->rows, 1, rd, 2, rb, k01, 0) || dspfft_plan_guru_r2r(&z->cols, 1, cd, 2, cb, k01, 0)) {
+		snprintf(g_err, sizeof g_err, "plan: %s", dspfft_last_error());
+		if (z->rows) dspfft_destroy_plan(z->rows);
+		delete z;
+		return -3;
+	}
+	dspfft_plan_set_scale(z->rows, 0.5f);
+	dspfft_plan_set_scale_f64(z->cols, 0.5 / ((double)w * (double)h));
+	*out = z;
+	return 0;
+}
+
+extern "C" void dspfft_zoomfft_destroy(dspfft_zoomfft z)
+{
+	if (!z) return;
+	dspfft_destroy_plan(z->rows); dspfft_destroy_plan(z->cols);
+	delete z;
+}
+
+// layout of d_work: tables (2 cw + 2 ch floats, rounded up to 4) | AX, EX (2 ch Mx 3) | AY, EY (2 My vw 3)
+extern "C" size_t dspfft_zoomfft_work_floats(dspfft_zoomfft z)
+{
+	if (!z) return 0;
+	const size_t tab = (2 * z->cw + 2 * z->ch + 3) & ~(size_t)3;
+	return tab + (size_t)2 * z->ch * z->Mx * 3 + (size_t)2 * z->My * z->vw * 3;
+}
+
+extern "C" int dspfft_zoomfft_execute(dspfft_zoomfft z, const float *d_coeffs, double vx, double vy, float *d_out, float *d_work, void *stream)
+{
+	if (!z || !d_coeffs || !d_out || !d_work) { snprintf(g_err, sizeof g_err, "bad arguments"); return -1; }
+	if (15u & ((uintptr_t)d_work | (uintptr_t)d_out)) { snprintf(g_err, sizeof g_err, "d_out and d_work must be 16-byte aligned"); return -1; }
+	hipStream_t s = (hipStream_t)stream;
+	const double pi = 3.14159265358979323846;
+	// zoom.c:49-57: interpolated k = (b + off) / s on length len; native k = b + off on length len s
+	const double thx = z->type == 0 ? pi * (vx + (z->sx - 1) / 2) / (double)z->Mx : pi * vx / (double)z->Mx;
+	const double thy = z->type == 0 ? pi * (vy + (z->sy - 1) / 2) / (double)z->My : pi * vy / (double)z->My;
+	float *csx = d_work, *csy = csx + 2 * z->cw;
+	const size_t tab = (2 * z->cw + 2 * z->ch + 3) & ~(size_t)3;
+	float *AX = d_work + tab, *EX = AX + (size_t)z->ch * z->Mx * 3;
+	float *AY = EX + (size_t)z->ch * z->Mx * 3, *EY = AY + (size_t)z->My * z->vw * 3;
+	hipLaunchKernelGGL(zf_table_kernel, dim3(32), dim3(256), 0, s, csx, thx, (int)z->cw);
+	hipLaunchKernelGGL(zf_table_kernel, dim3(32), dim3(256), 0, s, csy, thy, (int)z->ch);
+	hipLaunchKernelGGL(zf_prep_x_kernel, dim3(4096), dim3(256), 0, s, AX, EX, d_coeffs, csx, z->w, (int)z->ch, (int)z->cw, (int)z->Mx);
+	if (dspfft_execute(z->rows, AX, AX, stream)) { snprintf(g_err, sizeof g_err, "x stage: %s", dspfft_last_error()); return -4; }
+	if ((z->vw * 3) % 4 == 0 && (z->Mx * 3) % 4 == 0)
+		hipLaunchKernelGGL(zf_mid_kernel<4>, dim3(8192), dim3(256), 0, s, AY, EY, AX, EX, csy, (int)z->ch, (int)z->Mx, z->vw, (int)z->My);
+	else
+		hipLaunchKernelGGL(zf_mid_kernel<1>, dim3(8192), dim3(256), 0, s, AY, EY, AX, EX, csy, (int)z->ch, (int)z->Mx, z->vw, (int)z->My);
+	if (dspfft_execute(z->cols, AY, AY, stream)) { snprintf(g_err, sizeof g_err, "y stage: %s", dspfft_last_error()); return -4; }
+	if ((z->vw * 3) % 4 == 0)
+		hipLaunchKernelGGL(zf_final_kernel<4>, dim3(8192), dim3(256), 0, s, d_out, AY, EY, z->vw, z->vh);
+	else
+		hipLaunchKernelGGL(zf_final_kernel<1>, dim3(8192), dim3(256), 0, s, d_out, AY, EY, z->vw, z->vh);
+	if (hipGetLastError() != hipSuccess) { snprintf(g_err, sizeof g_err, "launch failed"); return -4; }
+	return 0;
+}

@@ -19,6 +19,37 @@ class Zoom:
         self.coeffs = image_hwc.contiguous().clone()
         Plan.image(self.h, self.w, 3, REDFT10).execute(self.coeffs.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
 
+    def _frame_fft(self, vw, vh, xscale, yscale, vx, vy, basis_type):
+        key = (vw, vh, tuple(xscale), tuple(yscale), basis_type)
+        if not hasattr(self, "_fft"):
+            self._fft = {}
+        if key not in self._fft:
+            z = C.c_void_p()
+            rc = self.lib.dspfft_zoomfft_create(C.byref(z), self.w, self.h, basis_type, xscale[0], xscale[1], yscale[0], yscale[1], vw, vh)
+            if rc == -2:
+                self._fft[key] = None              # this scale / basis / viewport keeps the dense product
+            elif rc:
+                raise DspfftError(self.lib.dspfft_zoomfft_last_error().decode())
+            else:
+                work = self.torch.empty(self.lib.dspfft_zoomfft_work_floats(z), dtype=self.torch.float32, device=self.coeffs.device)
+                self._fft[key] = (z, work)
+        if self._fft[key] is None:
+            return None
+        z, work = self._fft[key]
+        out = self.torch.empty((vh, vw, 3), dtype=self.torch.float32, device=self.coeffs.device)
+        if self.lib.dspfft_zoomfft_execute(z, self.coeffs.data_ptr(), float(vx), float(vy), out.data_ptr(), work.data_ptr(),
+                                           self.torch.cuda.current_stream().cuda_stream):
+            raise DspfftError(self.lib.dspfft_zoomfft_last_error().decode())
+        return out
+
+    def __del__(self):
+        try:
+            for v in getattr(self, "_fft", {}).values():
+                if v is not None:
+                    self.lib.dspfft_zoomfft_destroy(v[0])
+        except Exception:
+            pass
+
     def _basis(self, basis_type, num, den, offset, nvectors, length):
         nc = self.lib.dspfft_zoom_ncomponents(num, den, length)
         b = self.torch.empty(nvectors * nc, dtype=self.torch.float32, device=self.coeffs.device)
@@ -26,9 +57,17 @@ class Zoom:
             raise DspfftError(self.lib.dspfft_zoom_last_error().decode())
         return b, nc
 
-    def frame(self, vw, vh, xscale=(1.0, 1.0), yscale=(1.0, 1.0), vx=0.0, vy=0.0, basis_type=INTERPOLATED):
-        """one output frame: (vh, vw, 3) f32"""
+    def frame(self, vw, vh, xscale=(1.0, 1.0), yscale=(1.0, 1.0), vx=0.0, vy=0.0, basis_type=INTERPOLATED, method="auto"):
+        """one output frame: (vh, vw, 3) f32.  method "auto": fast transforms (dspfft_zoomfft_*) when the scaled lengths are integers
+        and the basis is interpolated or native, the dense MFMA product otherwise; "fft" / "gemm" force one (fft raises if it does
+        not apply)."""
         torch = self.torch
+        if method in ("auto", "fft"):
+            out = self._frame_fft(vw, vh, xscale, yscale, vx, vy, basis_type)
+            if out is not None:
+                return out
+            if method == "fft":
+                raise DspfftError(self.lib.dspfft_zoomfft_last_error().decode())
         xb, cw = self._basis(basis_type, xscale[0], xscale[1], vx, vw, self.w)
         yb, ch = self._basis(basis_type, yscale[0], yscale[1], vy, vh, self.h)
         out = torch.empty((vh, vw, 3), dtype=torch.float32, device=self.coeffs.device)

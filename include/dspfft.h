@@ -309,6 +309,21 @@ int dspfft_gemm_nt_f32(const float *A, const float *B, float *C, int M, int N, i
                        int batch, long long sa, long long sb, long long sc, float alpha, void *hip_stream);
 const char *dspfft_zoom_last_error(void);
 
+/* The same frame by fast transforms, for the scales at which an axis's output samples lie on a DCT-III grid: `interpolated` (0) or
+ * `native` (2) basis with len * num / den an integer M on both axes and a viewport of at most Mx x My samples (any offset: a pan
+ * re-plans nothing).  Per axis  out[b] = 1/2 REDFT01_M(C[n] cos(theta n))[b] - (-1)^b 1/2 REDFT01_M(C[M - n'] sin(theta (M - n')))[b],
+ * theta = pi (offset + (s - 1) / 2) / M (interpolated), pi offset / M (native)  (zoom/zoom.c:49-57): two
+ * length-M REDFT01 executions per axis on the row / column kernels instead of the dense product -- BASELINE config 3 (4x of
+ * 1920x1080): 310 GFLOP become about 4.4 GB of streaming.  dspfft_zoomfft_create returns -2 when the scale, basis or viewport does
+ * not qualify (use dspfft_zoom_product then); d_out (vh x vw x 3) and d_work (dspfft_zoomfft_work_floats floats) 16-byte aligned. */
+typedef struct dspfft_zoomfft_s *dspfft_zoomfft;
+int dspfft_zoomfft_create(dspfft_zoomfft *z, int w, int h, int type, double xscale_num, double xscale_den, double yscale_num, double yscale_den,
+                          int vw, int vh);
+size_t dspfft_zoomfft_work_floats(dspfft_zoomfft z);
+int dspfft_zoomfft_execute(dspfft_zoomfft z, const float *d_coeffs, double vx, double vy, float *d_out, float *d_work, void *hip_stream);
+void dspfft_zoomfft_destroy(dspfft_zoomfft z);
+const char *dspfft_zoomfft_last_error(void);
+
 /* ---- applybasis' basis x pixel partial sums on the matrix cores ----
  * applybasis/applybasis.c:410-431, forward direction:
  *   out[k_h][k_w][n_h][n_w][j] = sum_{s_h < Ph, s_w < Pw} f(k_h + offh, n_h Ph + s_h, h) f(k_w + offw, n_w Pw + s_w, w) pix[..][j]

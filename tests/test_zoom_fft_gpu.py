@@ -1,0 +1,124 @@
+"""GPU (-m gpu): zoom's frame by fast transforms (dspfft_zoomfft_*: two REDFT01 executions per axis, zoom_fft.hip) against the
+reference's own loop (tests/golden/ref_direct.npz: zoom.c:36-68,361-375 compiled as they lie), against the oracle restatement and
+against the dense MFMA product, incl. BASELINE config 3 at full size."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
+    from dspfun_amd import _lib
+    _lib.load()
+    return torch
+
+
+def zoomfft(gpu, coeffs, typ, xn, xd, yn, yd, vx, vy, vw, vh):
+    """-> (rc of create, output or None)"""
+    from dspfun_amd import _lib
+    L = _lib.load()
+    h, w, _ = coeffs.shape
+    z = C.c_void_p()
+    rc = L.dspfft_zoomfft_create(C.byref(z), w, h, typ, xn, xd, yn, yd, vw, vh)
+    if rc:
+        return rc, None
+    try:
+        c = gpu.from_numpy(np.ascontiguousarray(coeffs, dtype=np.float32)).to("cuda:0")
+        out = gpu.empty((vh, vw, 3), dtype=gpu.float32, device="cuda:0")
+        work = gpu.empty(L.dspfft_zoomfft_work_floats(z), dtype=gpu.float32, device="cuda:0")
+        assert L.dspfft_zoomfft_execute(z, c.data_ptr(), vx, vy, out.data_ptr(), work.data_ptr(), None) == 0, L.dspfft_zoomfft_last_error()
+        gpu.cuda.synchronize()
+        return 0, out.cpu().numpy()
+    finally:
+        L.dspfft_zoomfft_destroy(z)
+
+
+def test_against_the_references_compiled_loop(gpu):
+    fx = np.load(os.path.join(HERE, "golden", "ref_direct.npz"))
+    ran = 0
+    for i, case in enumerate(fx["zoom_cases"]):
+        h, w, typ = int(case[0]), int(case[1]), int(case[2])
+        xn, xd, yn, yd, vx, vy = (float(v) for v in case[3:])
+        want = fx[f"zoom{i}_out"]
+        vh, vw, _ = want.shape
+        rc, got = zoomfft(gpu, fx[f"zoom{i}_coeffs"], typ, xn, xd, yn, yd, vx, vy, vw, vh)
+        integer = abs(w * xn / xd - round(w * xn / xd)) < 1e-9 and abs(h * yn / yd - round(h * yn / yd)) < 1e-9
+        if typ == 1 or not integer:
+            assert rc == -2, case                       # centered basis / non-integer scaled length: the dense product's job
+            continue
+        assert rc == 0, case
+        assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max(), case
+        ran += 1
+    assert ran >= 7
+
+
+@pytest.mark.parametrize("w,h,xs,ys,vx,vy,typ,vw,vh", [
+    (64, 48, (3, 1), (3, 1), 0.0, 0.0, 0, None, None), (64, 48, (2, 1), (5, 2), 7.25, -3.5, 0, None, None), (60, 36, (3, 2), (4, 3), 0.0, 0.0, 2, None, None),
+    (60, 36, (1, 2), (1, 3), 1.5, 0.0, 0, None, None), (96, 64, (4, 1), (4, 1), 10.0, 20.0, 0, 100, 60), (33, 17, (2, 1), (2, 1), 0.5, 0.25, 2, None, None)])
+def test_fft_equals_dense_product_and_oracle(gpu, w, h, xs, ys, vx, vy, typ, vw, vh):
+    from dspfun_amd.zoom import Zoom
+    x = ol.synth_f32(w * h + 5, w * h * 3).reshape(h, w, 3)
+    vw = vw or int(w * xs[0] / xs[1]); vh = vh or int(h * ys[0] / ys[1])
+    z = Zoom(gpu, gpu.from_numpy(x).to("cuda:0"))
+    fast = z.frame(vw, vh, xs, ys, vx, vy, typ, method="fft").cpu().numpy()
+    dense = z.frame(vw, vh, xs, ys, vx, vy, typ, method="gemm").cpu().numpy()
+    assert np.abs(fast - dense).max() <= 2e-5 * max(1.0, np.abs(dense).max())
+    # f64 restatement of zoom.c:36-68,361-375
+    L = ol.lib()
+    cf = np.ascontiguousarray(ol.dct2d_interleaved(x.astype(np.float64), ol.REDFT10))
+    cw = L.oracle_zoom_basis_f64(None, typ, xs[0], xs[1], vx, vw, w); ch = L.oracle_zoom_basis_f64(None, typ, ys[0], ys[1], vy, vh, h)
+    xb = np.zeros(max(1, vw * (cw - 1))); yb = np.zeros(max(1, vh * (ch - 1)))
+    L.oracle_zoom_basis_f64(xb.ctypes.data, typ, xs[0], xs[1], vx, vw, w); L.oracle_zoom_basis_f64(yb.ctypes.data, typ, ys[0], ys[1], vy, vh, h)
+    ref = np.zeros((vh, vw, 3))
+    L.oracle_zoom_product_f64(cf.ctypes.data, w, h, xb.ctypes.data, cw, yb.ctypes.data, ch, ref.ctypes.data, vw, vh)
+    assert np.abs(fast - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_what_does_not_qualify_is_refused(gpu):
+    c = np.zeros((12, 16, 3))
+    assert zoomfft(gpu, c, 1, 2, 1, 2, 1, 0, 0, 32, 24)[0] == -2          # centered
+    assert zoomfft(gpu, c, 0, 5, 3, 2, 1, 0, 0, 26, 24)[0] == -2          # 16 * 5 / 3 is not an integer
+    assert zoomfft(gpu, c, 0, 2, 1, 2, 1, 0, 0, 40, 24)[0] == -2          # viewport wider than the scaled image
+
+
+def test_c3_zoom_4x_1080p_fft(gpu):
+    """BASELINE config 3 on the fast path: 1920x1080 RGB -> 7680x4320, scale 4/1, offset 0, interpolated basis.  out[::4, ::4] == input
+    (SURVEY 8d), one full output row against the f64 restatement, and agreement with the dense MFMA product."""
+    from dspfun_amd.zoom import Zoom
+    w, h = 1920, 1080
+    x = ol.synth_f32(0xD5F0003, w * h * 3).reshape(h, w, 3)
+    z = Zoom(gpu, gpu.from_numpy(x).to("cuda:0"))
+    out = z.frame(4 * w, 4 * h, (4.0, 1.0), (4.0, 1.0), method="fft")
+    gpu.cuda.synchronize()
+    assert np.abs(out[::4, ::4].cpu().numpy() - x).max() <= 2e-5
+    dense = z.frame(4 * w, 4 * h, (4.0, 1.0), (4.0, 1.0), method="gemm")
+    assert float((out - dense).abs().max()) <= 3e-5
+    L = ol.lib()
+    cf = ol.dct2d_interleaved(x.astype(np.float64), ol.REDFT10, impl="port", threads=8)
+    cw = L.oracle_zoom_basis_f64(None, 0, 4.0, 1.0, 0.0, 4 * w, w)
+    xb = np.zeros(4 * w * (cw - 1)); L.oracle_zoom_basis_f64(xb.ctypes.data, 0, 4.0, 1.0, 0.0, 4 * w, w)
+    for j in (1234, 4319, 1):
+        ybj = np.cos(np.pi * ((j / 4.0) + 0.5) * np.arange(1, h) / h)
+        trow = cf[0] / 2 + np.tensordot(ybj, cf[1:], axes=(0, 0))
+        XB = np.concatenate([np.full((4 * w, 1), 0.5), xb.reshape(4 * w, cw - 1)], axis=1)
+        ref_row = (XB @ trow) / (w * h)
+        assert np.abs(out[j].cpu().numpy() - ref_row).max() <= 2e-5
+    # timing (informative): events around 5 frames of each path
+    for name in ("fft", "gemm"):
+        a, b = gpu.cuda.Event(enable_timing=True), gpu.cuda.Event(enable_timing=True)
+        z.frame(4 * w, 4 * h, (4.0, 1.0), (4.0, 1.0), method=name)
+        a.record()
+        for _ in range(5):
+            z.frame(4 * w, 4 * h, (4.0, 1.0), (4.0, 1.0), method=name)
+        b.record(); gpu.cuda.synchronize()
+        print(f"C3 zoom frame, {name}: {a.elapsed_time(b) / 5:.3f} ms")
