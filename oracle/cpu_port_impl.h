@@ -230,19 +230,60 @@ int FN(cpu_port_r2r_many)(int rank, const int *n, int howmany,
 		const REAL *src = first ? in : out;
 		const ptrdiff_t *ss = first ? is : os;
 		const ptrdiff_t sdist = first ? idist : odist;
-		const long lines = (long)howmany * dims[o1] * dims[o2];
+		const long per = (long)dims[o1] * dims[o2], lines = (long)howmany * per;
+		/* Lines whose first samples lie next to each other in memory are transformed a BLOCK at a time through a transposed scratch
+		 * tile, so a strided pass (image columns: 46 KB between samples of one line at 4K) moves whole cache lines instead of one float
+		 * per line fetched:
+		 *   interleaved images (dist 1, stride = howmany: spec.c:63), any axis: the `run` = howmany (x axis: the channels of one row)
+		 *     or dims[2] * howmany (y axis: every column and channel of the image) consecutive lines;
+		 *   planar arrays (x stride 1: motion.c:535), axes other than x: run = dims[2] consecutive lines per (batch, other index). */
+		long run = 1;               /* lines per memory-consecutive run */
+		int mode = 0;               /* 0 line by line, 1 interleaved x axis, 2 interleaved other axis, 3 planar non-x axis */
+		if (sdist == 1 && odist == 1 && ss[2] == howmany && os[2] == howmany && howmany > 1) { mode = ax == 2 ? 1 : 2; run = ax == 2 ? howmany : (long)dims[2] * howmany; }
+		else if (ax != 2 && ss[2] == 1 && os[2] == 1 && dims[2] > 1) { mode = 3; run = dims[2]; }
+		if (mode == 2 && ((ax == 1 && dims[0] != 1) || ax == 0)) { mode = 0; run = 1; }      /* rank-3 interleaved: keep the plain path */
+		enum { BL = 16 };
+		const long nruns = mode ? lines / run : 0, bpr = mode ? (run + BL - 1) / BL : 0;   /* blocks per run */
 		#pragma omp parallel num_threads(threads)
 		{
 			DCTPLAN P; FN(dct_plan_init)(&P, N);
-			REAL *tmp = malloc(sizeof(REAL) * (size_t)N);
-			#pragma omp for schedule(static)
-			for (long l = 0; l < lines; l++) {
-				long t = l / ((long)dims[o1] * dims[o2]), r = l % ((long)dims[o1] * dims[o2]);
-				long p = r / dims[o2], q = r % dims[o2];
-				const REAL *x = src + t * sdist + p * ss[o1] + q * ss[o2];
-				REAL *y = out + t * odist + p * os[o1] + q * os[o2];
-				if (kd[ax] == 5) FN(dct2_1d)(&P, x, ss[ax], tmp, 1); else FN(dct3_1d)(&P, x, ss[ax], tmp, 1);
-				for (int k = 0; k < N; k++) y[(ptrdiff_t)k * os[ax]] = tmp[k];
+			REAL *tmp = malloc(sizeof(REAL) * (size_t)N * (mode ? 2 * BL : 1));
+			if (!mode) {
+				#pragma omp for schedule(static)
+				for (long l = 0; l < lines; l++) {
+					long t = l / per, r = l % per;
+					long p = r / dims[o2], q = r % dims[o2];
+					const REAL *x = src + t * sdist + p * ss[o1] + q * ss[o2];
+					REAL *y = out + t * odist + p * os[o1] + q * os[o2];
+					if (kd[ax] == 5) FN(dct2_1d)(&P, x, ss[ax], tmp, 1); else FN(dct3_1d)(&P, x, ss[ax], tmp, 1);
+					for (int k = 0; k < N; k++) y[(ptrdiff_t)k * os[ax]] = tmp[k];
+				}
+			} else {
+				REAL *tin = tmp, *tout = tmp + (size_t)BL * N;
+				#pragma omp for schedule(dynamic, 4)
+				for (long blk = 0; blk < nruns * bpr; blk++) {
+					const long rn = blk / bpr, j0 = (blk % bpr) * BL;
+					const int nb = (int)(run - j0 < BL ? run - j0 : BL);
+					/* base of the run (its line j sits at base + j) */
+					ptrdiff_t bi, bo;
+					if (mode == 1) {                               /* run = one row: rn = (y) for rank 2, (z, y) flattened otherwise */
+						long p = rn / dims[1], q = rn % dims[1];       /* o1 = 0, o2 = 1 */
+						bi = p * ss[0] + q * ss[1]; bo = p * os[0] + q * os[1];
+					} else if (mode == 2) { bi = 0; bo = 0; }      /* rank 2: the whole image row direction */
+					else {                                         /* planar: rn = (batch t, index of the remaining axis) */
+						const int oth = ax == 0 ? 1 : 0;
+						long t = rn / dims[oth], p = rn % dims[oth];
+						bi = t * sdist + p * ss[oth]; bo = t * odist + p * os[oth];
+					}
+					const REAL *x = src + bi + j0;
+					REAL *y = out + bo + j0;
+					for (int k = 0; k < N; k++) { const REAL *xr = x + (ptrdiff_t)k * ss[ax]; for (int b = 0; b < nb; b++) tin[(size_t)b * N + k] = xr[b]; }
+					for (int b = 0; b < nb; b++) {
+						if (kd[ax] == 5) FN(dct2_1d)(&P, tin + (size_t)b * N, 1, tout + (size_t)b * N, 1);
+						else FN(dct3_1d)(&P, tin + (size_t)b * N, 1, tout + (size_t)b * N, 1);
+					}
+					for (int k = 0; k < N; k++) { REAL *yr = y + (ptrdiff_t)k * os[ax]; for (int b = 0; b < nb; b++) yr[b] = tout[(size_t)b * N + k]; }
+				}
 			}
 			free(tmp); FN(dct_plan_free)(&P);
 		}
