@@ -13,6 +13,8 @@ direct-sum statement of the same transforms, and this script compiles that code 
   applybasis/applybasis.c:146-147,370-380,410-425  coords/offsets, the forward / --inverse index aliasing, the
                              partial-sum loops (with the --offset handling of :419-421)
   scan/scan_methods.c:210-228  init_random: the `random` scan order as this image's libc rand() draws it
+  scan/scan_methods.c:5-7,11-14,16-184,203-331 + scan/scan_precomputed.c   every scan method that needs no libavutil (all but evalxy /
+                             evali): limits, intervals, coordinate generators, radial / iradial / magnitude  ->  tests/golden/ref_scan.npz
 
 The text of those line ranges is read from /root/reference at generation time into a temporary translation unit
 that includes the reference's include/precision.h (COEFF_PRECISION=L, INTERMEDIATE_PRECISION=L: the tightest build
@@ -128,6 +130,132 @@ def build_random(tmp):
     return compile_tu(tmp, "random", tu)
 
 
+def build_scan_methods(tmp):
+    """scan/scan_methods.c without its libavutil parts: :5-7 (its own headers), :11-14, :16-184 (limits, intervals, the scan functions
+    through scan_mirror), :203-331 (scan_precomputed, init_random, init_magnitude, round_function, init_radial, init_iradial) -- i.e.
+    everything except <libavutil/eval.h> (:9), scan_evali (:186-201), init_evalxy / init_evali (:333-391) and the tables that name them.
+    Linked with the reference's scan_precomputed.c as it lies; COEFF_PRECISION=F, INTERMEDIATE_PRECISION=D as scan/Makefile:1-2 builds."""
+    tu = lines("scan/scan_methods.c", 5, 7) + lines("scan/scan_methods.c", 11, 14) + lines("scan/scan_methods.c", 16, 184) + lines("scan/scan_methods.c", 203, 331)
+    tu += """
+/* ---- this script's own dispatch over the reference's static functions ---- */
+typedef void (*scan_fn)(void*, size_t, size_t, size_t, size_t (*)[2]);
+static scan_fn fn_of(int m) { scan_fn t[] = {scan_horiz, scan_vert, scan_zigzag, scan_row, scan_col, scan_diag, scan_mirror, scan_box, scan_ibox}; return t[m]; }
+size_t ref_limit(int m, size_t w, size_t h)
+{
+	switch (m) { case 3: return limit_height(0, w, h); case 4: return limit_width(0, w, h); case 5: return limit_sum(0, w, h); case 6: case 7: return limit_max(0, w, h);
+	             case 8: return limit_min(0, w, h); default: return w * h; }          /* scan_context.c:30: limit ? limit() : width * height */
+}
+size_t ref_max_interval(int m, size_t w, size_t h)
+{
+	switch (m) { case 3: return limit_width(0, w, h); case 4: return limit_height(0, w, h); case 5: return limit_min(0, w, h); case 6: return limit_mirror(0, w, h);
+	             case 7: case 8: return limit_sum(0, w, h); default: return 1; }      /* the .max_interval entries of :453-567; scan_context.c:31 */
+}
+size_t ref_interval(int m, size_t w, size_t h, size_t i)
+{
+	switch (m) { case 3: return w; case 4: return h; case 5: return interval_diag(0, w, h, i); case 6: return interval_mirror(0, w, h, i);
+	             case 7: return interval_box(0, w, h, i); case 8: return interval_ibox(0, w, h, i); default: return 1; }
+}
+void ref_scan(int m, size_t w, size_t h, size_t i, size_t (*coords)[2]) { fn_of(m)(0, w, h, i, coords); }
+/* precomputed methods: 0 radial, 1 iradial, 2 magnitude (coeffs: w*h*channels floats; args as on the command line or NULL) */
+struct scan_precomputed *ref_precomputed(int which, size_t w, size_t h, size_t channels, float *coeffs, const char *args)
+{
+	return which == 0 ? init_radial(w, h, channels, coeffs, args) : which == 1 ? init_iradial(w, h, channels, coeffs, args) : init_magnitude(w, h, channels, coeffs, args);
+}
+"""
+    src = os.path.join(tmp, "scanmethods.c")
+    so = os.path.join(tmp, "scanmethods.so")
+    with open(src, "w") as f:
+        f.write(tu)
+    subprocess.check_call(["gcc", "-std=c11", "-D_GNU_SOURCE", "-DCOEFF_PRECISION=F", "-DINTERMEDIATE_PRECISION=D", "-O2", "-fPIC", "-shared", "-w",
+                           "-I" + os.path.join(REF, "include"), "-I" + os.path.join(REF, "scan"), src, os.path.join(REF, "scan", "scan_precomputed.c"), "-o", so, "-lm"])
+    return C.CDLL(so)
+
+
+SCAN_METHODS = ["horizontal", "vertical", "zigzag", "row", "column", "diagonal", "mirror", "box", "ibox"]
+
+
+def fnv_words(words):
+    """order-sensitive 64-bit checksum that numpy can evaluate: sum_k word_k * (2k + 1) mod 2^64"""
+    wv = np.asarray(words, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        return int((wv * (np.arange(len(wv), dtype=np.uint64) * np.uint64(2) + np.uint64(1))).sum(dtype=np.uint64))
+
+
+def scan_fixtures(tmp):
+    """every scan method but random / file / evalxy / evali: coordinate lists at small sizes, hashes at real ones"""
+    sm = build_scan_methods(tmp)
+    st = C.c_size_t
+    sm.ref_limit.restype = sm.ref_max_interval.restype = sm.ref_interval.restype = st
+    sm.ref_limit.argtypes = sm.ref_max_interval.argtypes = [C.c_int, st, st]
+    sm.ref_interval.argtypes = [C.c_int, st, st, st]
+    sm.ref_scan.argtypes = [C.c_int, st, st, st, C.c_void_p]
+
+    class Pre(C.Structure):
+        _fields_ = [("limit", st), ("intervals", C.POINTER(st)), ("scans", C.POINTER(C.POINTER(st * 2)))]
+    sm.ref_precomputed.restype = C.POINTER(Pre)
+    sm.ref_precomputed.argtypes = [C.c_int, st, st, st, C.c_void_p, C.c_char_p]
+    out = {}
+    small = [(8, 8), (16, 9), (9, 16), (33, 20), (1, 7), (7, 1)]
+    big = [(1920, 1080), (1080, 1920), (640, 480)]
+    out["small_sizes"] = np.array(small); out["big_sizes"] = np.array(big)
+    for m, name in enumerate(SCAN_METHODS):
+        for (w, h) in small + big:
+            lim, mi = sm.ref_limit(m, w, h), sm.ref_max_interval(m, w, h)
+            buf = np.zeros((mi + 2, 2), dtype=np.uint64)
+            flat, counts = [], []
+            for i in range(lim):
+                n = sm.ref_interval(m, w, h, i)
+                sm.ref_scan(m, w, h, i, buf.ctypes.data)
+                counts.append(n)
+                flat.append(buf[:n].copy())
+            flat = np.concatenate(flat) if flat else np.zeros((0, 2), dtype=np.uint64)
+            key = f"{name}_{w}x{h}"
+            out[key + "_meta"] = np.array([lim, mi, len(flat)], dtype=np.uint64)
+            if (w, h) in small:
+                out[key + "_counts"] = np.array(counts, dtype=np.uint32)
+                out[key + "_yx"] = flat.astype(np.uint32)
+            else:       # hash of (count, y, x ...) per index in order
+                out[key + "_fnv"] = np.array([fnv_words(counts), fnv_words((flat[:, 0] << np.uint64(32)) | flat[:, 1])], dtype=np.uint64)
+        print("scan", name)
+    # precomputed methods: owner index per pixel and the per-index coordinate order
+    for which, name, args in ((0, "radial", None), (1, "iradial", None), (0, "radial_floor", b"floor"), (1, "iradial_ceil", b"upward")):
+        for (w, h) in small + [(640, 480), (1920, 1080)]:
+            p = sm.ref_precomputed(which, w, h, 3, None, args).contents
+            idx = np.zeros(w * h, dtype=np.uint32)
+            order = []
+            for i in range(p.limit):
+                for k in range(p.intervals[i]):
+                    y, x = p.scans[i][k][0], p.scans[i][k][1]
+                    idx[y * w + x] = i
+                    order.append(y * w + x)
+            key = f"{name}_{w}x{h}"
+            out[key + "_limit"] = np.array([p.limit], dtype=np.uint64)
+            if w * h <= 33 * 20:
+                out[key + "_index"] = idx
+                out[key + "_order"] = np.array(order, dtype=np.uint32)
+            else:
+                out[key + "_fnv"] = np.array([fnv_words(idx), fnv_words(order)], dtype=np.uint64)
+        print("scan", name)
+    # magnitude: distinct float keys (no ties: the order is then independent of qsort's tie-breaking), and a quantised variant whose
+    # GROUPS are compared as sets (scan_methods.c:263: ties keep whatever order qsort left them in)
+    for ci, (w, h, q) in enumerate([(16, 9, None), (33, 20, None), (16, 9, b"64"), (33, 20, b"40")]):
+        coeffs = (synth_f32(0xD5F1800 + ci, w * h * 3) * 2 - 1).astype(np.float32) / np.float32(4 * w * h)
+        coeffs[:3] = 0.5
+        p = sm.ref_precomputed(2, w, h, 3, coeffs.ctypes.data, q).contents
+        groups, flat = [], []
+        for i in range(p.limit):
+            g = [int(p.scans[i][k][0]) * w + int(p.scans[i][k][1]) for k in range(p.intervals[i])]
+            groups.append(len(g)); flat += g
+        out[f"magnitude{ci}_shape"] = np.array([w, h, int(q) if q else 0])
+        out[f"magnitude{ci}_coeffs"] = coeffs
+        out[f"magnitude{ci}_group_sizes"] = np.array(groups, dtype=np.uint32)
+        out[f"magnitude{ci}_order"] = np.array(flat, dtype=np.uint32)
+    print("scan magnitude")
+    path = os.path.join(HERE, "ref_scan.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path))
+
+
 def compile_tu(tmp, name, text):
     src = os.path.join(tmp, name + ".c")
     so = os.path.join(tmp, name + ".so")
@@ -147,6 +275,10 @@ def main():
     assert os.path.isdir(REF), REF
     out = {}
     with tempfile.TemporaryDirectory() as tmp:
+        if len(sys.argv) < 2 or sys.argv[1] == "scan":
+            scan_fixtures(tmp)
+        if len(sys.argv) > 1 and sys.argv[1] == "scan":
+            return
         sz = build_scan_zoom(tmp)
         ab = build_applybasis(tmp)
         vp = C.c_void_p

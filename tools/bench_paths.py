@@ -27,11 +27,27 @@ def timeit(fn, reps=10, warm=2):
 # ---- zoom, config 3: 1920x1080 -> 7680x4320 ----
 w, h = 1920, 1080
 z = Zoom(torch, torch.rand(h, w, 3, device=dev))
-ms = timeit(lambda: z.frame(4 * w, 4 * h, (4.0, 1.0), (4.0, 1.0)), reps=5, warm=1)
+ms = timeit(lambda: z.frame(4 * w, 4 * h, (4.0, 1.0), (4.0, 1.0), method="gemm"), reps=5, warm=1)
 flop = 2.0 * 3 * (h * (4 * w) * w + (4 * h) * (4 * w) * h)
 res["zoom_c3"] = {"ms_per_frame": round(ms, 3), "TFLOPs": round(flop / ms / 1e9, 2), "GFLOP": round(flop / 1e9, 1),
-                  "mfma_f32_peak_TFLOPs": 157.3, "frac": round(flop / ms / 1e9 / 157.3, 4), "note": "includes basis generation + deinterleave"}
+                  "mfma_f32_peak_TFLOPs": 157.3, "frac": round(flop / ms / 1e9 / 157.3, 4), "note": "dense MFMA product (method gemm); includes basis generation + deinterleave"}
+ms = timeit(lambda: z.frame(4 * w, 4 * h, (4.0, 1.0), (4.0, 1.0), method="fft"), reps=10, warm=2)
+# compulsory bytes of the frame: the coefficients in, the 7680x4320x3 frame out
+res["zoom_c3_fft"] = {"ms_per_frame": round(ms, 3), "speedup_over_gemm": round(res["zoom_c3"]["ms_per_frame"] / ms, 2),
+                      "algorithmic_GBps": round((w * h * 3 + 16 * w * h * 3) * 4 / ms / 1e6, 1), "frac_of_8TBps": round((w * h * 3 + 16 * w * h * 3) * 4 / ms / 1e6 / 8000, 4),
+                      "note": "dspfft_zoomfft_*: two REDFT01 executions per axis (zoom_fft.hip); moves about 4.4 GB per frame"}
+del z
 
+# ---- 8K frame roundtrip (the transform of configs 3 and 4's frame size) ----
+w, h, c = 7680, 4320, 3
+x8 = torch.rand(h, w, c, device=dev)
+f8 = Plan.image(h, w, c, REDFT10)
+i8 = Plan.image(h, w, c, REDFT01).set_scale(1.0 / (4.0 * w * h))
+def rt8():
+    f8.execute(x8.data_ptr()); i8.execute(x8.data_ptr())
+ms = timeit(rt8, reps=10, warm=2)
+res["f32_8k_frame_roundtrip"] = {"ms": round(ms, 3), "Mpixels_per_s": round(h * w / ms / 1e3, 1), "frac_of_8TBps": round(h * w * c * 16 / ms / 1e6 / 8000, 4), "plan": f8.describe()}
+del x8, f8, i8
 # ---- scan, config 4: 7680x4320x3, zigzag, step 2^20 -> 32 frames, fused step ----
 w, h, c = 7680, 4320, 3
 coeffs = torch.rand(h, w, c, device=dev)
@@ -59,6 +75,7 @@ samples = w * h * c
 res["scan_c4_frame_step"] = {"fused_ms": round(msf, 3), "unfused_ms": round(msu, 3), "algorithmic_GBps_fused": round(samples * 12 / msf / 1e6, 1),
                              "frac_of_8TBps": round(samples * 12 / msf / 1e6 / 8000, 4), "frames": nframes, "note": "12 B/sample algorithmic (SURVEY 8d); 1 GPU, all 3 channels"}
 
+del coeffs, acc, work, recon, image, ids, order
 # ---- motion, config 5 luma plane: 1920x1080x256 3-D roundtrip ----
 d_, h, w = 256, 1080, 1920
 vol = torch.rand(d_, h, w, device=dev)
@@ -134,6 +151,14 @@ res["motion_c5_luma_per_frame_u8_to_u8"] = {"separate_steps_ms": round(ms_u2, 2)
                                             "Msamples_per_s": round(n / ms_f2 / 1e3, 1), "fps_1080p_luma": round(d_ / ms_f2 * 1e3, 0),
                                             "note": "256 frames; separate: 7 launches, 50 B/sample; fused: 3 launches, 18 B/sample"}
 del vol, v8, o8
+# ---- the same luma volume through SlabDCT3D on this one GPU (the multi-GPU path's local work: y, x passes into the exchange buffers, z pass) ----
+from dspfun_amd.dist import SlabDCT3D
+eng = SlabDCT3D(d_, h, w, chunks=4)
+v3 = (torch.rand(d_, h, w, device=dev) * 255).floor()
+ms = timeit(lambda: eng.inverse(eng.forward(v3)), reps=3, warm=1)
+res["motion_c5_luma_slab3d_1gpu"] = {"ms": round(ms, 2), "algorithmic_GBps": round(n * 16 / ms / 1e6, 1), "frac_of_8TBps": round(n * 16 / ms / 1e6 / 8000, 4), "row_pieces": eng.P}
+del eng, v3
+torch.cuda.empty_cache()
 # ---- double precision (fftw_ API, spec's default build): 4K frame roundtrip on the runtime-geometry kernels ----
 h, w, c = 2160, 3840, 3
 x64 = torch.rand(h, w, c, device=dev, dtype=torch.float64)

@@ -1,0 +1,62 @@
+"""Summarises rocprofv3 output directories into the small files kept under profiles/.
+   python tools/summarise_prof.py stats <dir> <out.csv>          kernel-trace --stats: per kernel calls, average / total duration
+   python tools/summarise_prof.py pmc <fetch_dir> <write_dir> <out.json>   FETCH_SIZE / WRITE_SIZE passes: bytes per dispatch per kernel
+gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports half of the bytes of wide streaming reads (x2), WRITE_SIZE is exact;
+both are in KB."""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+
+def short(name):
+    """kernel name without the argument list and with the spec template kept (what tells the kernels apart)"""
+    name = re.sub(r"\(.*$", "", name)
+    name = name.replace("dspfft::", "").replace("(anonymous namespace)::", "")
+    return name[:220]
+
+
+def stats(d, out):
+    files = glob.glob(f"{d}/**/*kernel_stats.csv", recursive=True)
+    rows = []
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            rows.append(r)
+    rows.sort(key=lambda r: -float(r.get("TotalDurationNs", r.get("Total Duration (ns)", 0)) or 0))
+    with open(out, "w", newline="") as fo:
+        w = csv.writer(fo)
+        w.writerow(["kernel", "calls", "avg_us", "total_ms", "percent"])
+        for r in rows:
+            tot = float(r.get("TotalDurationNs", 0) or 0)
+            w.writerow([short(r["Name"]), r["Calls"], round(float(r["AverageNs"]) / 1e3, 2), round(tot / 1e6, 3), r.get("Percentage", "")])
+    print("wrote", out, len(rows), "kernels")
+
+
+def pmc(fd, wd, out):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d, c in ((fd, "FETCH_SIZE"), (wd, "WRITE_SIZE")):
+        for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] == c:
+                    acc[short(r["Kernel_Name"])][c].append(float(r["Counter_Value"]))
+    res = {}
+    for k, v in acc.items():
+        fe = v.get("FETCH_SIZE", []); wr = v.get("WRITE_SIZE", [])
+        if not fe or not wr:
+            continue
+        f_kb, w_kb = sum(fe) / len(fe), sum(wr) / len(wr)
+        res[k] = {"dispatches": len(fe), "FETCH_SIZE_KB": round(f_kb, 1), "WRITE_SIZE_KB": round(w_kb, 1),
+                  "hbm_MB_per_dispatch": round((2 * f_kb + w_kb) * 1024 / 1e6, 2)}
+    res = dict(sorted(res.items(), key=lambda kv: -kv[1]["hbm_MB_per_dispatch"] * kv[1]["dispatches"]))
+    json.dump({"correction": "FETCH_SIZE x 2 (gfx950 reports half of wide streaming reads) + WRITE_SIZE, KB -> bytes x 1024; averages per dispatch",
+               "kernels": res}, open(out, "w"), indent=1)
+    print("wrote", out, len(res), "kernels")
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3])
+    else:
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
