@@ -146,6 +146,22 @@ __global__ void __launch_bounds__(256) dense_kernel(const DenseArgsT<R> a)
 	dense_compute(a, x, bout, threadIdx.x, blockDim.x);
 }
 
+// lines longer than LDS holds (DenseArgsT::stage): copy every line into the plan's staging array, then sum from there
+template <class R>
+__global__ void __launch_bounds__(256) dense_stage_kernel(const DenseArgsT<R> a)
+{
+	long long bin, bout;
+	dense_base(a, blockIdx.x, bin, bout);
+	dense_load(a, a.stage + (size_t)blockIdx.x * a.N, bin, threadIdx.x, blockDim.x);
+}
+template <class R>
+__global__ void __launch_bounds__(256) dense_staged_kernel(const DenseArgsT<R> a)
+{
+	long long bin, bout;
+	dense_base(a, blockIdx.x, bin, bout);
+	dense_compute(a, a.stage + (size_t)blockIdx.x * a.N, bout, threadIdx.x, blockDim.x);
+}
+
 // ---------------------------------------------------------------------------------------------
 __global__ void zigzag_kernel(uint32_t *lin, uint32_t w, uint32_t h, uint64_t first, uint64_t count)
 {
@@ -257,6 +273,12 @@ static int launch_col(const PassArgsT<R> &a, const LaunchGeom &g, void *stream)
 template <class R>
 static int launch_dense(const DenseArgsT<R> &a, const LaunchGeom &g, void *stream)
 {
+	if (a.stage) {
+		hipLaunchKernelGGL((dense_stage_kernel<R>), dim3(g.nwg), dim3(g.nthr), 0, (hipStream_t)stream, a);
+		hipLaunchKernelGGL((dense_staged_kernel<R>), dim3(g.nwg), dim3(g.nthr), 0, (hipStream_t)stream, a);
+		HIPCHK(hipGetLastError());
+		return 0;
+	}
 	if (int rc = allow_lds(dense_kernel<R>, g.lds_bytes)) return rc;
 	hipLaunchKernelGGL((dense_kernel<R>), dim3(g.nwg), dim3(g.nthr), g.lds_bytes, (hipStream_t)stream, a);
 	HIPCHK(hipGetLastError());

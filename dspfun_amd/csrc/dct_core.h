@@ -744,6 +744,8 @@ struct DenseArgsT : DenseGeom {
 	R *out;
 	const R *cosTab;
 	R scale, out_scale0, in_scale0;
+	R *stage;          // lines too long for LDS: the (masked, scaled) samples of every line are copied here first -- [line][N], owned by
+	                   // the plan -- and the sums read them from memory (a second launch, so in-place transforms stay correct)
 };
 typedef DenseArgsT<float> DenseArgs;
 typedef DenseArgsT<double> DenseArgsD;

@@ -86,10 +86,11 @@ struct Tables {
 	void *T = nullptr, *W = nullptr, *pos = nullptr, *cosTab = nullptr;
 	void *WM = nullptr, *chirp = nullptr, *Bhat = nullptr;     // Bluestein (BLUE passes)
 	void *H = nullptr;                                         // half-tile column passes: exp(-2 pi i n / N), n < N/2
+	void *stage = nullptr;                                     // DENSE passes on lines longer than LDS holds: [line][N] staging copy
 	void release()
 	{
-		be_free(T); be_free(W); be_free(pos); be_free(cosTab); be_free(WM); be_free(chirp); be_free(Bhat); be_free(H);
-		T = W = pos = cosTab = WM = chirp = Bhat = H = nullptr;
+		be_free(T); be_free(W); be_free(pos); be_free(cosTab); be_free(WM); be_free(chirp); be_free(Bhat); be_free(H); be_free(stage);
+		T = W = pos = cosTab = WM = chirp = Bhat = H = stage = nullptr;
 	}
 };
 
@@ -627,7 +628,9 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 	}
 	// ---------------- DENSE ----------------
 	{
-		if ((size_t)N * es > maxlds) return fail(-2, "axis %d: length %d has a prime factor > 13 (or no usable layout) and exceeds the dense path's LDS limit", a, N);
+		// a line longer than LDS holds (beyond Bluestein's range too: a prime factor > 13 in a length of tens of thousands) is staged in a
+		// device array of the plan instead: the reference never checks for a NULL plan (spec/spec.c:63-64), so every length gets one
+		const bool staged = (size_t)N * es > maxlds || env_int("DSPFFT_DENSE_STAGED") == 1;
 		merge_dims(others);
 		DenseGeom &da = P.da;
 		da.N = N; da.kind = kind; da.es_in = ax.is; da.es_out = ax.os;
@@ -652,8 +655,13 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 		P.type = Pass::DENSE;
 		long long lines = (long long)da.nb0 * da.nb1 * da.nb2;
 		if (lines > 0x7fffffff) return fail(-2, "too many lines for the dense path");
-		P.g.nwg = (int)lines; P.g.nthr = 256; P.g.lds_bytes = (size_t)N * es;
-		snprintf(buf, sizeof buf, "axis %d: DENSE%s N=%d lines=%lld lds=%zu", a, tag, N, lines, P.g.lds_bytes);
+		P.g.nwg = (int)lines; P.g.nthr = 256; P.g.lds_bytes = staged ? 0 : (size_t)N * es;
+		if (staged) {
+			for (const Dim &d : P.hostloop) (void)d;      // one staging array serves every host-loop iteration (they run one after the other)
+			P.tab.stage = be_alloc((size_t)lines * N * es);
+			if (!P.tab.stage) return fail(-3, "axis %d: no memory for the staging copy of %lld lines of %d samples", a, lines, N);
+		}
+		snprintf(buf, sizeof buf, "axis %d: DENSE%s N=%d lines=%lld lds=%zu%s", a, tag, N, lines, P.g.lds_bytes, staged ? " (lines staged in device memory)" : "");
 		P.desc = buf;
 		return 0;
 	}
@@ -711,7 +719,7 @@ int run_pass(const dspfft_plan_s *pl, const Pass &P, const R *in, R *out, bool l
 		} else if (P.type == Pass::DENSE) {
 			DenseArgsT<R> a;
 			static_cast<DenseGeom &>(a) = P.da;
-			a.in = in + oin; a.out = out + oout; a.cosTab = (const R *)P.tab.cosTab;
+			a.in = in + oin; a.out = out + oout; a.cosTab = (const R *)P.tab.cosTab; a.stage = (R *)P.tab.stage;
 			a.scale = (R)scale; a.in_scale0 = (R)pl->in0[P.axis]; a.out_scale0 = (R)pl->out0[P.axis];
 			a.mask = fz.mask; a.mask_id = fz.id; a.mask_div = make_div((uint32_t)fz.div); a.accumulate = fz.accumulate;
 			rc = be_launch_dense(a, P.g, stream);

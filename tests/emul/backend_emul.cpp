@@ -76,6 +76,12 @@ static int emul_col(const PassArgsT<R> &a, const LaunchGeom &g)
 template <class R>
 static int emul_dense(const DenseArgsT<R> &a, const LaunchGeom &g)
 {
+	if (a.stage) {      // lines too long for LDS: stage every line, then sum from the staging array (two launches on the device)
+		const int nthr = g.nthr;
+		for (int wg = 0; wg < g.nwg; wg++) { long long bin, bout; dense_base(a, wg, bin, bout); for (int tid = 0; tid < nthr; tid++) dense_load(a, a.stage + (size_t)wg * a.N, bin, tid, nthr); }
+		for (int wg = 0; wg < g.nwg; wg++) { long long bin, bout; dense_base(a, wg, bin, bout); for (int tid = 0; tid < nthr; tid++) dense_compute(a, a.stage + (size_t)wg * a.N, bout, tid, nthr); }
+		return 0;
+	}
 	std::vector<R> x(a.N);
 	const int nthr = g.nthr;
 	for (int wg = 0; wg < g.nwg; wg++) {

@@ -1022,3 +1022,29 @@ def test_plan_time_kernels_run_motions_fused_pipeline(gpu, monkeypatch, tmp_path
     assert np.abs(a[0].astype(np.int32) - b[0].astype(np.int32)).max() <= 1 and (a[0] != b[0]).mean() < 1e-3
     assert abs(a[1] - b[1]) <= max(4, b[1] // 10000) and b[1] > 0
     assert np.abs(a[0].astype(np.int32) - u8).max() <= 6          # quantiser 4: a coarse but close copy
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_huge_prime_length_gets_a_working_plan(gpu, dtype):
+    """the reference never checks for a NULL plan (spec.c:63-64).  N = 50021 is prime and beyond the LDS range of both the
+    Bluestein and the dense pass: the line is staged in device memory (engine.cpp DENSE).  Selected coefficients against the definition
+    in f64, and the 2N roundtrip identity."""
+    from dspfun_amd import Plan, REDFT10, REDFT01
+    N = 50021
+    npd = np.float32 if dtype == "f32" else np.float64
+    x = (ol.synth_f32(N, N).astype(np.float64) - 0.5).astype(npd)
+    fwd = Plan.many_r2r([N], [REDFT10], dtype=dtype)
+    assert "staged in device memory" in fwd.describe(), fwd.describe()
+    d = dev(gpu, x)
+    fwd.execute(d.data_ptr())
+    gpu.cuda.synchronize()
+    got = d.cpu().numpy().astype(np.float64)
+    j = np.arange(N)
+    scale = np.abs(got).max()
+    tol = 2e-5 if dtype == "f32" else 1e-11
+    for k in (0, 1, 2, 777, 25010, 50020):
+        want = 2.0 * np.sum(x.astype(np.float64) * np.cos(np.pi * (j + 0.5) * k / N))
+        assert abs(got[k] - want) <= tol * scale, (k, got[k], want)
+    Plan.many_r2r([N], [REDFT01], dtype=dtype).set_scale(1.0 / (2.0 * N)).execute(d.data_ptr())
+    gpu.cuda.synchronize()
+    assert np.abs(d.cpu().numpy().astype(np.float64) - x).max() <= (5e-5 if dtype == "f32" else 1e-11)

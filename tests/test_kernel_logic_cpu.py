@@ -935,3 +935,22 @@ def test_fused_block_roundtrip_volume_layout(block):
     u = raw[1:] if raw.ctypes.data % 16 == 0 else raw[:-1]
     with pytest.raises(DspfftError):
         fv.roundtrip(iv, u.ctypes.data, filter=flt)
+
+
+def test_dense_lines_staged_in_memory(monkeypatch):
+    """a line too long for LDS is staged in a device array of the plan (engine.cpp DENSE: the reference never checks for a NULL plan,
+    spec.c:63-64); forced here on small prime lengths, in place, with a batch and with the fused scales"""
+    monkeypatch.setenv("DSPFFT_DENSE_STAGED", "1")
+    monkeypatch.setenv("DSPFFT_NO_BLUESTEIN", "1")
+    for (h, w, c) in ((37, 5, 3), (3, 41, 2)):
+        x = ol.synth_f32(h * 100 + w, h * w * c).reshape(h, w, c)
+        for kind in (REDFT10, REDFT01):
+            p = Plan.image(h, w, c, kind, lib=emul())
+            assert "staged in device memory" in p.describe(), p.describe()
+            ref = ol.dct2d_interleaved(x.astype(np.float64), kind, impl="port")
+            assert relerr(run(p, x.copy()), ref) < TOL
+    p = Plan.many_r2r([43], [REDFT10], lib=emul()).set_scale(0.25).set_axis_scale0(0, 3.0, 0.5)
+    x = ol.synth_f32(9, 43)
+    want = ol.r2r_many(x.astype(np.float64) * np.where(np.arange(43) == 0, 3.0, 1.0), [43], [ol.REDFT10]) * 0.25
+    want[0] *= 0.5
+    assert relerr(run(p, x.copy()), want) < TOL
