@@ -59,11 +59,20 @@ def cpu_baseline(max_seconds=30.0):
     x = ol.synth_f32(SEED, H * W * C)
     n, kinds2, kinds3 = [H, W], [ol.REDFT10] * 2, [ol.REDFT01] * 2
 
+    # straight into the C entry point on preallocated arrays: ol.r2r_many copies its 100 MB input and output on one host thread, which at
+    # 128 threads cost more than the transforms themselves (round 2's 24.5 Mpix/s was mostly those copies)
+    import ctypes as C_
+    L = ol.lib()
+    ia = lambda v: (C_.c_int * len(v))(*v)
+    f = np.empty_like(x); b = np.empty_like(x)
+    fn = L.cpu_port_r2r_many_f32
+
     def run(nthr, budget):
         reps, t0 = 0, time.perf_counter()
         while True:
-            f = ol.r2r_many(x, n, kinds2, howmany=C, istride=C, idist=1, ostride=C, odist=1, impl="port", threads=nthr)
-            b = ol.r2r_many(f, n, kinds3, howmany=C, istride=C, idist=1, ostride=C, odist=1, impl="port", threads=nthr)
+            rc = fn(2, ia(n), C, x.ctypes.data, None, C, 1, f.ctypes.data, None, C, 1, ia(kinds2), nthr)
+            rc |= fn(2, ia(n), C, f.ctypes.data, None, C, 1, b.ctypes.data, None, C, 1, ia(kinds3), nthr)
+            assert rc == 0
             reps += 1
             el = time.perf_counter() - t0
             if el * (reps + 1) / reps > budget or reps >= 64:

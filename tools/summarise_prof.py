@@ -13,8 +13,8 @@ import sys
 
 def short(name):
     """kernel name without the argument list and with the spec template kept (what tells the kernels apart)"""
-    name = re.sub(r"\(.*$", "", name)
     name = name.replace("dspfft::", "").replace("(anonymous namespace)::", "")
+    name = re.sub(r"\(.*$", "", name)
     return name[:220]
 
 
