@@ -3,6 +3,7 @@
 // specs per translation unit, so the groups compile in parallel.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "backend.h"
 #include "dct_spec.h"
 #include "spec_list.h"
@@ -55,6 +56,52 @@ __global__ void __launch_bounds__(S::T, S::WPE) row_spec_kernel(const typename S
 			if constexpr (ph + 1 < S::NPH) __syncthreads();
 		}
 	});
+}
+
+// ---- lines that fill a CU's LDS on their own (7680 x 3 floats, 3840 x 3 doubles: 92 KB -> ONE workgroup per CU) ----
+// With a single resident workgroup nothing overlaps its load, butterfly and store phases.  This variant is persistent (one workgroup
+// per CU walks the lines) and software-pipelined at no register cost: the line's samples wait in State::pre only until phase 0 has put
+// them into LDS, so the NEXT line is fetched into the same registers right after phase 0 and lands during the butterfly stages.
+// vmcnt is in-order, so any vector-memory load between that prefetch and its use would wait for it: the stage twiddles W (the only
+// loads of phases 1 .. NS + 1) are therefore kept in LDS (30 KB beside the 92 KB line; one workgroup per CU either way).
+template <class S> constexpr size_t persist_lds() { return S::LDS + sizeof(typename S::CX) * (size_t)S::L; }
+template <class S> constexpr bool persist_ok() { return S::C > 1 && S::LDS > 80 * 1024 && persist_lds<S>() <= 160 * 1024; }
+template <class S, int KIND>
+__global__ void __launch_bounds__(S::T, S::WPE) row_persist_kernel(const typename S::PA a_, int nwork)
+{
+	typedef typename S::CX CX;
+	extern __shared__ __attribute__((aligned(32))) unsigned char lds[];
+	CX *planes = reinterpret_cast<CX *>(lds);
+	CX *wtab = reinterpret_cast<CX *>(lds + S::LDS);
+	const int tid = threadIdx.x;
+	for (int i = tid; i < S::L; i += S::T) wtab[i] = a_.W[i];
+	typename S::PA a = plain_args(a_);
+	a.W = wtab;
+	typename S::template State<KIND> st;
+	int work = blockIdx.x;
+	long long bin, bout;
+	row_base(a, work, bin, bout);
+	S::template prefetch<KIND>(a, bin, tid, st, nullptr, nullptr);
+	__syncthreads();                                         // the twiddle table is in place
+	while (work < nwork) {
+		// the thread index is re-made opaque every iteration: everything the phases derive from it (LDS addresses, twiddle indices)
+		// is loop-invariant, and hoisted out of the loop it would be carried in registers across all of it (128 VGPRs + scratch)
+		int t = tid; asm volatile("" : "+v"(t));
+		S::template phase<KIND, 0>(a, planes, bout, t, st);
+		__syncthreads();
+		const int next = work + (int)gridDim.x;
+		const long long bout_cur = bout;
+		if (next < nwork) {                                  // uniform: the next line's loads go out now and land behind the stages
+			row_base(a, next, bin, bout);
+			S::template prefetch<KIND>(a, bin, t, st, nullptr, nullptr);
+		}
+		static_for<1, S::NPH>([&](auto ph) {
+			int u = t; asm volatile("" : "+v"(u));
+			S::template phase<KIND, ph>(a, planes, bout_cur, u, st);
+			__syncthreads();
+		});
+		work = next;
+	}
 }
 
 // the same with 8-bit input (REDFT10) or quantised 8-bit output (REDFT01): planar rows only
@@ -203,6 +250,18 @@ int launch_row_spec(const typename S::PA &a, int nwork, void *stream)
 {
 	static int lds_ok = allow_lds(row_spec_kernel<S, KIND, false>, S::LDS) | allow_lds(row_spec_kernel<S, KIND, true>, S::LDS);
 	if (lds_ok) return lds_ok;
+	if constexpr (persist_ok<S>()) {
+		// DSPFFT_ROW_PERSIST=0 keeps one workgroup per line (A/B runs)
+		static const int on = []() { const char *e = getenv("DSPFFT_ROW_PERSIST"); return e ? atoi(e) : 1; }();
+		static const int cus = []() { int d = 0, n = 0; if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n < 1) n = 256; return n; }();
+		if (on && is_plain(a) && nwork > cus) {
+			static int p_ok = allow_lds(row_persist_kernel<S, KIND>, persist_lds<S>());
+			if (p_ok) return p_ok;
+			hipLaunchKernelGGL((row_persist_kernel<S, KIND>), dim3(cus), dim3(S::T), persist_lds<S>(), (hipStream_t)stream, a, nwork);
+			HIPCHK(hipGetLastError());
+			return 0;
+		}
+	}
 	if (is_plain(a)) hipLaunchKernelGGL((row_spec_kernel<S, KIND, true>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a);
 	else hipLaunchKernelGGL((row_spec_kernel<S, KIND, false>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a);
 	HIPCHK(hipGetLastError());

@@ -90,13 +90,13 @@
 // Same structures over double samples: X(N, C | K, THREADS, radices ...).  A slot is 16 bytes, so a 3840 x 3 line needs 92 KB of
 // LDS (one workgroup per CU) and column tiles are K = 4 doubles wide = the same 32-B row segments / 69 KB as the float K = 8 tile.
 #define DSPFFT_ROW_SPECS_F64(X)      \
-	X(3840, 3, 1024, 12, 10, 16)     \
+	X(3840, 3, 512, 12, 10, 16)      \
 	X(1920, 3, 512, 4, 15, 16)       \
 	X(960, 3, 256, 2, 16, 15)        \
 	X(3840, 1, 256, 12, 10, 16)      \
 	X(1920, 1, 128, 4, 16, 15)       \
 	X(512, 3, 128, 16, 16)           \
-	X(4096, 3, 1024, 8, 16, 16)      \
+	X(4096, 3, 512, 8, 16, 16)       \
 	X(2560, 3, 512, 8, 10, 16)       \
 	X(2048, 3, 512, 4, 16, 16)       \
 	X(1280, 3, 256, 4, 10, 16)       \
