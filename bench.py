@@ -164,7 +164,7 @@ def main():
     ap.add_argument("--streams", type=int, default=int(os.environ.get("BENCH_STREAMS", "2")), help="HIP streams the independent frames are spread over")
     ap.add_argument("--realign", type=int, default=8, help="with --schedule realign: re-join the streams every N steps")
     ap.add_argument("--schedule", choices=["free", "aligned", "realign"], default="realign", help="how two streams interleave their frames (see step())")
-    ap.add_argument("--event-every", type=int, default=4, help="bracket the passes of one frame with events every N-th step (events between "
+    ap.add_argument("--event-every", type=int, default=8, help="bracket the passes of one frame with events every N-th step (events between "
                     "dependent launches cost throughput: every step -3 %%, every launch -7 %%)")
     ap.add_argument("--inverse-order", choices=["columns-first", "rows-first"], default="columns-first", help="axis order of the REDFT01 plan")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -335,7 +335,10 @@ def main():
         torch.cuda.empty_cache()
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         from bench_motion import motion_c5
-        motion = motion_c5(torch, dist, dev, rank, world)
+        try:
+            motion = motion_c5(torch, dist, dev, rank, world)
+        except Exception as e:          # the headline line must still be printed
+            motion = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         pixels = args.steps * args.frames * world * H * W

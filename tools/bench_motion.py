@@ -123,7 +123,10 @@ def motion_c5(torch, dist, dev, rank, world, reps_frames=50, reps_volume=8):
     torch.cuda.empty_cache()
     out["per_frame_weak"] = frames_bench(torch, dist, dev, rank, world, True, max(4, reps_frames // 4)) if world > 1 else "n_gpus = 1: same as per_frame_strong"
     torch.cuda.empty_cache()
-    out["volume_3d"] = volume_bench(torch, dist, dev, rank, world, reps_volume)
+    try:
+        out["volume_3d"] = volume_bench(torch, dist, dev, rank, world, reps_volume)
+    except Exception as e:              # the collective path must not take the frame-sharded numbers down with it
+        out["volume_3d"] = {"error": f"{type(e).__name__}: {e}"}
     torch.cuda.empty_cache()
     return out
 
