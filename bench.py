@@ -169,6 +169,7 @@ def main():
     ap.add_argument("--inverse-order", choices=["columns-first", "rows-first"], default="columns-first", help="axis order of the REDFT01 plan")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-motion", action="store_true", help="skip the motion_c5 object (BASELINE configs[4]: per-frame blocks and the RCCL slab volume)")
+    ap.add_argument("--no-scan", action="store_true", help="skip the scan_c4 object (BASELINE configs[3]: channel-sharded progressive reconstruct of an 8K frame)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -330,8 +331,8 @@ def main():
     # weak) and its one-3-D-block mode through SlabDCT3D -- the one path that exercises RCCL all-to-all -- so that a SCALE record at
     # N = 2, 4, 8 carries the curve north_star asks for.  Every rank takes part; its own barriers and max-over-ranks timing.
     motion = None
+    del frames, ref0
     if not args.no_motion:
-        del frames, ref0
         torch.cuda.empty_cache()
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         from bench_motion import motion_c5
@@ -339,6 +340,16 @@ def main():
             motion = motion_c5(torch, dist, dev, rank, world)
         except Exception as e:          # the headline line must still be printed
             motion = {"error": f"{type(e).__name__}: {e}"}
+
+    scan = None
+    if not args.no_scan:
+        torch.cuda.empty_cache()
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from bench_scan_c4 import scan_c4
+        try:
+            scan = scan_c4(torch, dist, dev, rank, world)
+        except Exception as e:
+            scan = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         pixels = args.steps * args.frames * world * H * W
@@ -357,6 +368,8 @@ def main():
         }
         if motion is not None:
             line["motion_c5"] = motion
+        if scan is not None:
+            line["scan_c4"] = scan
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
             fw_ = fftw_cpu_baseline()

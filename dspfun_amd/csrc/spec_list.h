@@ -32,7 +32,8 @@
 	X(2560, 1, 256, 8, 10, 16)         \
 	X(4096, 1, 256, 8, 16, 16)         \
 	X(2048, 1, 128, 4, 16, 16)         \
-	X(1024, 1, 64, 4, 8, 16)
+	X(1024, 1, 64, 4, 8, 16)           \
+	X(7680, 1, 256, 16, 15, 16)        /* planar 8K rows: scan's colour planes on separate GPUs (BASELINE config 4, dist.ChannelShardedScan) */
 
 // (An outer radix-2 column split -- half of the tile parked in registers so 2160-row tiles could be K = 16 wide in
 // the same 69 KB -- was built and measured SLOWER at every size tried: 2160 (K=16): 57/68 us vs 49/53 us; 4320 (K=8):
@@ -81,6 +82,7 @@
 
 // row specs (N, C) that also get the paired kernel
 #define DSPFFT_ROW_PAIR_SPECS(X) \
+	X(7680, 1, 256, 16, 15, 16) \
 	X(3840, 3, 512, 12, 10, 16) \
 	X(7680, 3, 1024, 16, 15, 16) \
 	X(1920, 3, 256, 12, 5, 16) \

@@ -231,6 +231,8 @@ class ChannelShardedScan:
         self.ids = torch.zeros(self.w * self.h, dtype=torch.int32, device=dev)
         st = SlabDCT3D._stream(image_hwc) or None     # every helper on torch's current stream, like the transforms
         self._check(self.lib.dspfft_scan_zigzag_frame_ids(self.ids.data_ptr(), self.w, self.h, self.step, st))
+        # the owner ids stay the same over the frames: let the fused step skip the column tiles a frame does not touch without reading their ids
+        self.inv.scan_prepare(self.ids.data_ptr(), 1, stream=st or 0)
         self.work = torch.empty((self.h, self.w), dtype=torch.float32, device=dev)
         self.sums = []
         for cz in self.coeffs:

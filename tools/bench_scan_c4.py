@@ -1,0 +1,73 @@
+"""BASELINE config 4 (scan zigzag progressive reconstruct of 7680x4320 RGB, channel-sharded), as a function bench.py calls for its
+`scan_c4` object and as a script (`python tools/bench_scan_c4.py`, or under torch.distributed.run with N ranks).
+
+scan/scan.c:292-298 forward + normalisation once, then per output frame (scan.c:421-459) the fused masked-accumulate step, zigzag order,
+step 2^20 -> 32 frames.  dspfun_amd.dist.ChannelShardedScan puts colour plane z on rank z mod N: no collective inside the frame loop, one
+all_gather at the end.  Three planes do not divide over four ranks: at N = 4 one rank idles (75 % ceiling), at N = 8 five do -- stated in
+the object.  The timed region is the frame loop (barrier + synchronize on both sides, max over ranks); the final sum is checked against
+the input on every rank."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+W, H, C, STEP = 7680, 4320, 3, 1 << 20
+
+
+def scan_c4(torch, dist, dev, rank, world):
+    from dspfun_amd.dist import ChannelShardedScan
+    g = torch.Generator(device=dev); g.manual_seed(0xD5F0004)
+    img = torch.rand((H, W, C), device=dev, generator=g)
+    eng = ChannelShardedScan(img, STEP)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    while eng.next_frame():
+        pass
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    err = float((eng.gather() - img).abs().max())
+    busy = min(C, world)
+    samples = W * H * C
+    ms = dt / eng.nframes * 1e3
+    return {"workload": "scan zigzag progressive reconstruct of 7680x4320 RGB, step 2^20 (BASELINE configs[3]), colour planes over the ranks",
+            "frames": eng.nframes, "ms_per_frame": round(ms, 4), "frames_per_s": round(eng.nframes / dt, 1),
+            "algorithmic_GBps_total": round(samples * 12 / ms / 1e6, 1), "frac_of_8TBps_per_busy_gpu": round(samples * 12 / ms / 1e6 / 8000 / busy, 4),
+            "planes_per_rank": [len([z for z in range(C) if z % world == r]) for r in range(world)], "ranks_with_a_plane": busy,
+            # the busiest rank owns ceil(3 / N) planes: speed-up over one GPU is at most 3 / ceil(3 / N), i.e. efficiency 3 / (N ceil(3 / N))
+            "scaling_efficiency_ceiling": round(C / (world * -(-C // world)), 3),
+            "max_abs_final_sum_minus_input": err, "parallelism": f"channel-sharded x{world}: plane z on rank z mod {world}, no collective in the frame loop, one all_gather"}
+
+
+def main():
+    import torch
+    rank, local, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    dev = torch.device("cuda", local if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    res = scan_c4(torch, dist, dev, rank, world)
+    if rank == 0:
+        res["n_gpus"] = world
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
