@@ -98,7 +98,9 @@ struct PassGeom {
 	uint8_t *zflags;      // null: off.  COL side writes (when mask is set), ROW side reads
 	int zshift;           // ROW side: log2 of the column pass's tile width in samples
 	int zhalf;            // ROW side: the flags of odd lines start at zflags + zhalf (split column passes: half 1), else 0
-	const void *zpage;    // ROW side: 64 zero bytes to load from in place of a skipped tile
+	const void *zpage;    // ROW side: 64 zero bytes to load from in place of a skipped tile (also what rows outside win_* load)
+	int win_lo, win_hi;   // specialised COL REDFT01 first pass: input rows outside [win_lo, win_hi) are zero BY CONTRACT and are not read
+	                      // (dspfft_plan_set_input_window: zoom's y stage transforms a spectrum zero-padded to 4x its length); 0, 0: off
 	const uint32_t *zranges;   // COL side, optional: (min, max) owner id of every tile (dspfft_plan_scan_prepare): a tile whose range
 	                           // excludes mask_id is skipped without reading its owner ids
 	FftDesc fft;

@@ -558,14 +558,23 @@ struct ColSpecT {
 				}
 			});
 		} else {
+			const bool win = !MASKED && a.win_hi > 0;      // uniform; folds away in the plain instantiation
 			static_for<0, K_ROUNDS>([&](auto i) {
 				const int it = tid + i * T;
 				if ((i + 1) * T <= (N / 2 + 1) * NP || it < (N / 2 + 1) * NP) {
 					const int k = it / NP, jp = it - k * NP;
 					const int km = k ? N - k : 0;
 					const long long p = bin + VW * jp;
-					st.pre[2 * i] = g_get(loadv_m<MASKED, Re>(a, p + (long long)k * a.es_in, hit));
-					st.pre[2 * i + 1] = g_get(loadv_m<MASKED, Re>(a, p + (long long)km * a.es_in, hit));
+					if (win) {
+						// rows outside the window are zero by contract: load the zero page instead (no branch around the loads, see load_pix_m)
+						const V *pk = (k >= a.win_lo && k < a.win_hi) ? reinterpret_cast<const V *>(a.in + p + (long long)k * a.es_in) : reinterpret_cast<const V *>(a.zpage);
+						const V *pm = (km >= a.win_lo && km < a.win_hi) ? reinterpret_cast<const V *>(a.in + p + (long long)km * a.es_in) : reinterpret_cast<const V *>(a.zpage);
+						st.pre[2 * i] = g_get(*pk);
+						st.pre[2 * i + 1] = g_get(*pm);
+					} else {
+						st.pre[2 * i] = g_get(loadv_m<MASKED, Re>(a, p + (long long)k * a.es_in, hit));
+						st.pre[2 * i + 1] = g_get(loadv_m<MASKED, Re>(a, p + (long long)km * a.es_in, hit));
+					}
 				}
 			});
 		}

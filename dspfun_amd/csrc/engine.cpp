@@ -184,6 +184,8 @@ struct dspfft_plan_s {
 	const void *zr_ids = nullptr;
 	int zr_div = 0;
 	bool zr_split = false;
+	// dspfft_plan_set_input_window: rows of `win_axis` outside [win_lo, win_hi) are zero by contract (first pass, specialised COL REDFT01)
+	int win_axis = -1, win_lo = 0, win_hi = 0;
 };
 
 namespace {
@@ -678,6 +680,8 @@ void fill_args(PassArgsT<R> &a, const PassGeom &g, const dspfft_plan_s *pl, cons
 	a.scale = (R)scale; a.in_scale0 = (R)pl->in0[P.axis]; a.out_scale0 = (R)pl->out0[P.axis];
 	a.mask = fz.mask; a.mask_id = fz.id; a.mask_div = make_div((uint32_t)fz.div); a.accumulate = fz.accumulate;
 	a.zflags = fz.zflags; a.zshift = fz.zshift; a.zhalf = fz.zhalf; a.zpage = fz.zpage; a.zranges = fz.zranges;
+	a.win_lo = a.win_hi = 0;
+	if (pl->win_axis == P.axis && P.first && !fz.mask && pl->zpage) { a.win_lo = pl->win_lo; a.win_hi = pl->win_hi; a.zpage = pl->zpage; }
 }
 
 // one candidate of the planning-effort-2 search: mean of three launches on the scratch buffer, in milliseconds (<= 0: failed)
@@ -1033,6 +1037,22 @@ extern "C" int dspfft_plan_set_axis_scale0(dspfft_plan pl, int axis, float in_sc
 {
 	if (!pl || axis < 0 || axis >= pl->rank) return fail(-1, "bad plan/axis");
 	pl->in0[axis] = in_scale0; pl->out0[axis] = out_scale0; return 0;
+}
+// Input rows of `axis` outside [lo, hi) are zero by contract and need not be read.  Honoured (return 1) only where it is implemented:
+// f32 plans whose FIRST pass is a listed specialised column REDFT01 pass along `axis` (zoom's y stage); returns 0 -- nothing changes, the
+// caller must really store those zeros -- everywhere else.  lo = hi = 0 turns it off.
+extern "C" int dspfft_plan_set_input_window(dspfft_plan pl, int axis, int lo, int hi)
+{
+	if (!pl || axis < 0 || axis >= pl->rank || lo < 0 || hi < lo || hi > pl->n[axis]) return fail(-1, "bad plan / axis / window");
+	pl->win_axis = -1; pl->win_lo = pl->win_hi = 0;
+	if (hi == 0) return 0;
+	if (pl->f64 || pl->passes.empty() || !pl->split.empty() || pl->has_block) return 0;
+	const Pass &P = pl->passes[0];
+	if (P.axis != axis || P.type != Pass::COL || !P.has_spec || P.jit || pl->kinds[axis] != DSPFFT_REDFT01 || !P.hostloop.empty()) return 0;
+	if (!pl->zpage) { pl->zpage = be_alloc(64); if (pl->zpage) { const char z[64] = {0}; if (be_upload(pl->zpage, z, 64)) { be_free(pl->zpage); pl->zpage = nullptr; } } }
+	if (!pl->zpage) return 0;
+	pl->win_axis = axis; pl->win_lo = lo; pl->win_hi = hi;
+	return 1;
 }
 extern "C" int dspfft_plan_set_scale_f64(dspfft_plan pl, double scale)
 {

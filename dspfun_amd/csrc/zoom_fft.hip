@@ -48,30 +48,26 @@ __global__ void zf_prep_x_kernel(float *A, float *E, const float *C, const float
 }
 
 // between the stages: T[v][b] = YA[v][b] - (-1)^b YE[v][b] (the 1/2 is the row plan's scale), then the y stage's inputs
-// A2[v'][b] = T[v'][b] cos(theta_y v'), E2[v'][b] = T[My - v'][b] sin(theta_y (My - v')), rows v' < My, pitch vw pixels (float4 lanes: vw*3 % 4 == 0)
+// A2[v][b] = T[v][b] cos(theta_y v) and E2[My - v][b] = T[v][b] sin(theta_y v) (v >= 1), rows v < ch, pitch vw pixels (float4 lanes when
+// vw * 3 % 4 == 0).  The other rows of A2 / E2 are zero: never read when the column plans honour the input window, cleared otherwise.
 template <int VEC>
 __global__ void zf_mid_kernel(float *A2, float *E2, const float *YA, const float *YE, const float *cs, int ch, int Mx, int vw, int My)
 {
-	const size_t rowf = (size_t)vw * 3, rowv = rowf / VEC, total = (size_t)My * rowv;
+	const size_t rowf = (size_t)vw * 3, rowv = rowf / VEC, total = (size_t)ch * rowv;
 	typedef float vec __attribute__((ext_vector_type(VEC)));
 	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
 		const int v = (int)(i / rowv);
 		const size_t f = (i - (size_t)v * rowv) * VEC;           // first float of this lane within the row
+		const vec ya = *reinterpret_cast<const vec *>(YA + (size_t)v * Mx * 3 + f), ye = *reinterpret_cast<const vec *>(YE + (size_t)v * Mx * 3 + f);
+		const float c = cs[2 * v], sn = cs[2 * v + 1];
 		vec a, e;
-		for (int k = 0; k < VEC; k++) { a[k] = 0.f; e[k] = 0.f; }
-		const int n = My - v;
-		if (v < ch) {
-			const vec ya = *reinterpret_cast<const vec *>(YA + (size_t)v * Mx * 3 + f), ye = *reinterpret_cast<const vec *>(YE + (size_t)v * Mx * 3 + f);
-			const float c = cs[2 * v];
-			for (int k = 0; k < VEC; k++) { const int b = (int)((f + k) / 3); a[k] = (ya[k] - ((b & 1) ? -ye[k] : ye[k])) * c; }
-		}
-		if (v >= 1 && n >= 1 && n < ch) {
-			const vec ya = *reinterpret_cast<const vec *>(YA + (size_t)n * Mx * 3 + f), ye = *reinterpret_cast<const vec *>(YE + (size_t)n * Mx * 3 + f);
-			const float s = cs[2 * n + 1];
-			for (int k = 0; k < VEC; k++) { const int b = (int)((f + k) / 3); e[k] = (ya[k] - ((b & 1) ? -ye[k] : ye[k])) * s; }
+		for (int k = 0; k < VEC; k++) {
+			const int b = (int)((f + k) / 3);
+			const float t = ya[k] - ((b & 1) ? -ye[k] : ye[k]);
+			a[k] = t * c; e[k] = t * sn;
 		}
 		*reinterpret_cast<vec *>(A2 + (size_t)v * rowf + f) = a;
-		*reinterpret_cast<vec *>(E2 + (size_t)v * rowf + f) = e;
+		if (v >= 1) *reinterpret_cast<vec *>(E2 + (size_t)(My - v) * rowf + f) = e;
 	}
 }
 
@@ -104,7 +100,8 @@ struct dspfft_zoomfft_s {
 	long long Mx, My;
 	size_t cw, ch;
 	double sx, sy;                 // scales
-	dspfft_plan rows, cols;
+	dspfft_plan rows, colsA, colsE;
+	bool windowed;                 // the column plans skip the zero rows of their inputs (dspfft_plan_set_input_window)
 };
 
 extern "C" const char *dspfft_zoomfft_last_error(void) { return g_err; }
@@ -121,22 +118,30 @@ extern "C" int dspfft_zoomfft_create(dspfft_zoomfft *out, int w, int h, int type
 	z->w = w; z->h = h; z->type = type; z->vw = vw; z->vh = vh; z->Mx = Mx; z->My = My;
 	z->cw = dspfft_zoom_ncomponents(xnum, xden, (size_t)w); z->ch = dspfft_zoom_ncomponents(ynum, yden, (size_t)h);
 	z->sx = xnum / xden; z->sy = ynum / yden;
-	z->rows = z->cols = nullptr;
+	z->rows = z->colsA = z->colsE = nullptr;
 	const int k01[1] = {DSPFFT_REDFT01};
 	// x stage: A and E one after the other = 2 ch lines of Mx RGB pixels, transformed along x
 	const dspfft_iodim rd[1] = {{(int)Mx, 3, 3}}, rb[2] = {{3, 1, 1}, {(int)(2 * z->ch), (int)(Mx * 3), (int)(Mx * 3)}};
-	// y stage: two arrays of My rows x vw RGB pixels, transformed along y
+	// y stage: two arrays of My rows x vw RGB pixels, each transformed along y by its own plan: the cosine part's input is non-zero in
+	// rows [0, ch), the sine part's in rows (My - ch, My) -- the plans are told (input window), and then the zero rows are neither
+	// written by the re-pack kernel nor read by the column pass
 	const long long arr = My * (long long)vw * 3;
 	if (arr >= (1ll << 31) || Mx * 3 * 2 * (long long)z->ch >= (1ll << 31)) { delete z; snprintf(g_err, sizeof g_err, "frame too large for 31-bit strides"); return -2; }
-	const dspfft_iodim cd[1] = {{(int)My, vw * 3, vw * 3}}, cb[2] = {{vw * 3, 1, 1}, {2, (int)arr, (int)arr}};
-	if (dspfft_plan_guru_r2r(&z->rows, 1, rd, 2, rb, k01, 0) || dspfft_plan_guru_r2r(&z->cols, 1, cd, 2, cb, k01, 0)) {
+	const dspfft_iodim cd[1] = {{(int)My, vw * 3, vw * 3}}, cb[1] = {{vw * 3, 1, 1}};
+	if (dspfft_plan_guru_r2r(&z->rows, 1, rd, 2, rb, k01, 0) || dspfft_plan_guru_r2r(&z->colsA, 1, cd, 1, cb, k01, 0) || dspfft_plan_guru_r2r(&z->colsE, 1, cd, 1, cb, k01, 0)) {
 		snprintf(g_err, sizeof g_err, "plan: %s", dspfft_last_error());
 		if (z->rows) dspfft_destroy_plan(z->rows);
+		if (z->colsA) dspfft_destroy_plan(z->colsA);
 		delete z;
 		return -3;
 	}
 	dspfft_plan_set_scale(z->rows, 0.5f);
-	dspfft_plan_set_scale_f64(z->cols, 0.5 / ((double)w * (double)h));
+	dspfft_plan_set_scale_f64(z->colsA, 0.5 / ((double)w * (double)h));
+	dspfft_plan_set_scale_f64(z->colsE, 0.5 / ((double)w * (double)h));
+	const int wa = dspfft_plan_set_input_window(z->colsA, 0, 0, (int)z->ch);
+	const int we = z->ch > 1 ? dspfft_plan_set_input_window(z->colsE, 0, (int)(My - (long long)z->ch + 1), (int)My) : 0;
+	z->windowed = wa == 1 && (we == 1 || z->ch == 1) && z->ch < (size_t)My;
+	if (!z->windowed) { dspfft_plan_set_input_window(z->colsA, 0, 0, 0); dspfft_plan_set_input_window(z->colsE, 0, 0, 0); }
 	*out = z;
 	return 0;
 }
@@ -144,7 +149,7 @@ extern "C" int dspfft_zoomfft_create(dspfft_zoomfft *out, int w, int h, int type
 extern "C" void dspfft_zoomfft_destroy(dspfft_zoomfft z)
 {
 	if (!z) return;
-	dspfft_destroy_plan(z->rows); dspfft_destroy_plan(z->cols);
+	dspfft_destroy_plan(z->rows); dspfft_destroy_plan(z->colsA); dspfft_destroy_plan(z->colsE);
 	delete z;
 }
 
@@ -173,11 +178,16 @@ extern "C" int dspfft_zoomfft_execute(dspfft_zoomfft z, const float *d_coeffs, d
 	hipLaunchKernelGGL(zf_table_kernel, dim3(32), dim3(256), 0, s, csy, thy, (int)z->ch);
 	hipLaunchKernelGGL(zf_prep_x_kernel, dim3(4096), dim3(256), 0, s, AX, EX, d_coeffs, csx, z->w, (int)z->ch, (int)z->cw, (int)z->Mx);
 	if (dspfft_execute(z->rows, AX, AX, stream)) { snprintf(g_err, sizeof g_err, "x stage: %s", dspfft_last_error()); return -4; }
+	// rows the re-pack kernel does not write must read as zero: either the column plans skip them (input window) or they are cleared here
+	// (ch == 1: the sine part has no non-zero row at all and no window)
+	const size_t arrf = (size_t)z->My * z->vw * 3;
+	if (!z->windowed && hipMemsetAsync(AY, 0, 2 * arrf * sizeof(float), s) != hipSuccess) { snprintf(g_err, sizeof g_err, "memset failed"); return -4; }
+	if (z->windowed && z->ch == 1 && hipMemsetAsync(EY, 0, arrf * sizeof(float), s) != hipSuccess) { snprintf(g_err, sizeof g_err, "memset failed"); return -4; }
 	if ((z->vw * 3) % 4 == 0 && (z->Mx * 3) % 4 == 0)
 		hipLaunchKernelGGL(zf_mid_kernel<4>, dim3(8192), dim3(256), 0, s, AY, EY, AX, EX, csy, (int)z->ch, (int)z->Mx, z->vw, (int)z->My);
 	else
 		hipLaunchKernelGGL(zf_mid_kernel<1>, dim3(8192), dim3(256), 0, s, AY, EY, AX, EX, csy, (int)z->ch, (int)z->Mx, z->vw, (int)z->My);
-	if (dspfft_execute(z->cols, AY, AY, stream)) { snprintf(g_err, sizeof g_err, "y stage: %s", dspfft_last_error()); return -4; }
+	if (dspfft_execute(z->colsA, AY, AY, stream) || dspfft_execute(z->colsE, EY, EY, stream)) { snprintf(g_err, sizeof g_err, "y stage: %s", dspfft_last_error()); return -4; }
 	if ((z->vw * 3) % 4 == 0)
 		hipLaunchKernelGGL(zf_final_kernel<4>, dim3(8192), dim3(256), 0, s, d_out, AY, EY, z->vw, z->vh);
 	else

@@ -106,6 +106,13 @@ class Plan:
             self._check(self._lib.dspfft_plan_set_axis_scale0(self._h, axis, in_scale0, out_scale0))
         return self
 
+    def set_input_window(self, axis, lo, hi):
+        """promise that input samples of `axis` outside [lo, hi) are zero; True when the plan then skips reading (and needing) them"""
+        rc = self._lib.dspfft_plan_set_input_window(self._h, axis, lo, hi)
+        if rc < 0:
+            raise DspfftError(self._lib.dspfft_last_error().decode())
+        return bool(rc)
+
     def execute(self, d_in, d_out=None, stream=0):
         d_out = d_in if d_out is None else d_out
         run = self._lib.dspfft_execute_f64 if self.f64 else self._lib.dspfft_execute

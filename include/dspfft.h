@@ -98,6 +98,11 @@ int dspfft_plan_many_r2r_f64(dspfft_plan *plan, int rank, const int *n, int howm
 int dspfft_plan_set_scale_f64(dspfft_plan plan, double scale);
 int dspfft_plan_set_axis_scale0_f64(dspfft_plan plan, int axis, double in_scale0, double out_scale0);
 int dspfft_execute_f64(dspfft_plan plan, const double *d_in, double *d_out, void *hip_stream);
+/* Optional: the caller promises that input samples of `axis` outside [lo, hi) are ZERO (a spectrum zero-padded to a longer transform:
+ * zoom's y stage, motion's scaled > block) so that they need not be read.  Returns 1 when the plan honours it -- then those rows need
+ * not even be stored -- and 0 when it does not (nothing changes: the zeros must really be there).  Today: f32 plans whose first pass
+ * is a listed specialised column REDFT01 pass along `axis`.  lo = hi = 0 turns it off.  Negative: bad arguments. */
+int dspfft_plan_set_input_window(dspfft_plan plan, int axis, int lo, int hi);
 /* Optional, for owner ids that stay the same over the frames of a scan (every method but box, whose ids are stamped per frame):
  * records the (min, max) owner id of every column tile of `plan`, so that a later dspfft_execute_masked_accumulate with the SAME
  * d_ids pointer and elems_per_id leaves a tile alone -- without reading its owner ids -- when `id` lies outside its range.  Call it

@@ -954,3 +954,14 @@ def test_dense_lines_staged_in_memory(monkeypatch):
     want = ol.r2r_many(x.astype(np.float64) * np.where(np.arange(43) == 0, 3.0, 1.0), [43], [ol.REDFT10]) * 0.25
     want[0] *= 0.5
     assert relerr(run(p, x.copy()), want) < TOL
+
+
+def test_input_window_is_declined_where_it_is_not_implemented():
+    """dspfft_plan_set_input_window on the emulation backend (no listed specialised kernels in play for this shape): 0 = not honoured,
+    the zeros must really be stored; bad arguments are errors"""
+    p = Plan.many_r2r([37], [REDFT01], howmany=6, istride=6, idist=1, ostride=6, odist=1, lib=emul())
+    assert p.set_input_window(0, 0, 10) is False
+    with pytest.raises(DspfftError):
+        p.set_input_window(1, 0, 10)
+    with pytest.raises(DspfftError):
+        p.set_input_window(0, 10, 5)

@@ -122,3 +122,31 @@ def test_c3_zoom_4x_1080p_fft(gpu):
             z.frame(4 * w, 4 * h, (4.0, 1.0), (4.0, 1.0), method=name)
         b.record(); gpu.cuda.synchronize()
         print(f"C3 zoom frame, {name}: {a.elapsed_time(b) / 5:.3f} ms")
+
+
+def test_input_window_skips_rows_that_are_zero_by_contract(gpu):
+    """dspfft_plan_set_input_window: a listed column REDFT01 pass does not read rows outside the window (they may hold garbage); plans
+    that cannot honour it say so (return 0) and read everything."""
+    from dspfun_amd import Plan, REDFT10, REDFT01
+    N, inner = 1080, 64
+    x = ol.synth_f32(77, N * inner).reshape(N, inner) - 0.5
+    for (lo, hi) in ((0, 270), (811, 1080), (100, 101)):
+        pad = np.zeros_like(x); pad[lo:hi] = x[lo:hi]
+        want = ol.r2r_many(pad.astype(np.float64), [N], [ol.REDFT01], howmany=inner, istride=inner, idist=1, ostride=inner, odist=1, impl="port").reshape(N, inner)
+        p = Plan.guru([(N, inner, inner)], [(inner, 1, 1)], [REDFT01])
+        assert "COL*" in p.describe(), p.describe()
+        assert p.set_input_window(0, lo, hi) is True
+        dirty = x.copy(); dirty[:lo] = np.nan; dirty[hi:] = np.inf          # garbage where the contract says zero
+        d = gpu.from_numpy(np.ascontiguousarray(dirty, dtype=np.float32)).to("cuda:0")
+        p.execute(d.data_ptr())
+        gpu.cuda.synchronize()
+        got = d.cpu().numpy()
+        assert np.isfinite(got).all() and np.abs(got - want).max() <= 1e-5 * np.abs(want).max(), (lo, hi)
+        assert p.set_input_window(0, 0, 0) is False                           # off again: everything is read
+    # not honoured: forward kind, a row pass first, double precision -- the call says so and changes nothing
+    assert Plan.guru([(N, inner, inner)], [(inner, 1, 1)], [REDFT10]).set_input_window(0, 0, 270) is False
+    assert Plan.image(1080, 1920, 3, REDFT01).set_input_window(0, 0, 270) is False
+    assert Plan.guru([(N, inner, inner)], [(inner, 1, 1)], [REDFT01], dtype="f64").set_input_window(0, 0, 270) is False
+    from dspfun_amd.engine import DspfftError
+    with pytest.raises(DspfftError):
+        Plan.guru([(N, inner, inner)], [(inner, 1, 1)], [REDFT01]).set_input_window(0, 5, 2000)
