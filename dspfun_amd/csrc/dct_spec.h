@@ -755,7 +755,8 @@ struct ColSpecT {
 					const int n = it / NP, jp = it - n * NP;
 					const LC F = l_get(buf[n * NP + jp]);
 					const int y = makhoul_src(n, N);
-					const Re sc = (y == 0) ? a.scale * a.out_scale0 : a.scale;
+					Re sc = (y == 0) ? a.scale * a.out_scale0 : a.scale;
+					if (a.alt_out && (y & 1)) sc = -sc;          // folds away in the plain instantiation
 					storev_a<Re>(a, bout + (long long)y * a.es_out + VW * jp, g_put(cmk<LR>(F.x * sc, -F.y * sc)));
 				});
 			}

@@ -186,6 +186,7 @@ struct dspfft_plan_s {
 	bool zr_split = false;
 	// dspfft_plan_set_input_window: rows of `win_axis` outside [win_lo, win_hi) are zero by contract (first pass, specialised COL REDFT01)
 	int win_axis = -1, win_lo = 0, win_hi = 0;
+	int alt_axis = -1;         // dspfft_plan_set_output_alternate
 };
 
 namespace {
@@ -680,6 +681,7 @@ void fill_args(PassArgsT<R> &a, const PassGeom &g, const dspfft_plan_s *pl, cons
 	a.scale = (R)scale; a.in_scale0 = (R)pl->in0[P.axis]; a.out_scale0 = (R)pl->out0[P.axis];
 	a.mask = fz.mask; a.mask_id = fz.id; a.mask_div = make_div((uint32_t)fz.div); a.accumulate = fz.accumulate;
 	a.zflags = fz.zflags; a.zshift = fz.zshift; a.zhalf = fz.zhalf; a.zpage = fz.zpage; a.zranges = fz.zranges;
+	a.alt_out = (pl->alt_axis == P.axis && pl->alt_axis >= 0) ? 1 : 0;
 	a.win_lo = a.win_hi = 0;
 	if (pl->win_axis == P.axis && P.first && !fz.mask && pl->zpage) { a.win_lo = pl->win_lo; a.win_hi = pl->win_hi; a.zpage = pl->zpage; }
 }
@@ -1052,6 +1054,19 @@ extern "C" int dspfft_plan_set_input_window(dspfft_plan pl, int axis, int lo, in
 	if (!pl->zpage) { pl->zpage = be_alloc(64); if (pl->zpage) { const char z[64] = {0}; if (be_upload(pl->zpage, z, 64)) { be_free(pl->zpage); pl->zpage = nullptr; } } }
 	if (!pl->zpage) return 0;
 	pl->win_axis = axis; pl->win_lo = lo; pl->win_hi = hi;
+	return 1;
+}
+// Output sample j of `axis` times (-1)^j, fused into the pass of that axis.  Honoured (return 1) only where it is implemented: f32 plans
+// whose pass along `axis` is a listed specialised column REDFT01 pass and the plan's LAST one; 0 otherwise (nothing changes).
+extern "C" int dspfft_plan_set_output_alternate(dspfft_plan pl, int axis, int on)
+{
+	if (!pl || axis < 0 || axis >= pl->rank) return fail(-1, "bad plan / axis");
+	pl->alt_axis = -1;
+	if (!on) return 0;
+	if (pl->f64 || pl->passes.empty() || !pl->split.empty() || pl->has_block) return 0;
+	const Pass &P = pl->passes.back();
+	if (P.axis != axis || P.type != Pass::COL || !P.has_spec || P.jit || pl->kinds[axis] != DSPFFT_REDFT01 || !P.hostloop.empty()) return 0;
+	pl->alt_axis = axis;
 	return 1;
 }
 extern "C" int dspfft_plan_set_scale_f64(dspfft_plan pl, double scale)

@@ -102,6 +102,8 @@ struct dspfft_zoomfft_s {
 	double sx, sy;                 // scales
 	dspfft_plan rows, colsA, colsE;
 	bool windowed;                 // the column plans skip the zero rows of their inputs (dspfft_plan_set_input_window)
+	bool fused;                    // the sine part's column plan alternates its output signs and ADDS into the cosine part's result
+	                               // (dspfft_plan_set_output_alternate + accumulating execution): no combine kernel
 };
 
 extern "C" const char *dspfft_zoomfft_last_error(void) { return g_err; }
@@ -142,6 +144,9 @@ extern "C" int dspfft_zoomfft_create(dspfft_zoomfft *out, int w, int h, int type
 	const int we = z->ch > 1 ? dspfft_plan_set_input_window(z->colsE, 0, (int)(My - (long long)z->ch + 1), (int)My) : 0;
 	z->windowed = wa == 1 && (we == 1 || z->ch == 1) && z->ch < (size_t)My;
 	if (!z->windowed) { dspfft_plan_set_input_window(z->colsA, 0, 0, 0); dspfft_plan_set_input_window(z->colsE, 0, 0, 0); }
+	// out = ZA - (-1)^j ZE: the sine part's plan takes the sign and the minus (negative scale) and accumulates into ZA
+	z->fused = dspfft_plan_set_output_alternate(z->colsE, 0, 1) == 1;
+	if (z->fused) dspfft_plan_set_scale_f64(z->colsE, -0.5 / ((double)w * (double)h));
 	*out = z;
 	return 0;
 }
@@ -187,6 +192,16 @@ extern "C" int dspfft_zoomfft_execute(dspfft_zoomfft z, const float *d_coeffs, d
 		hipLaunchKernelGGL(zf_mid_kernel<4>, dim3(8192), dim3(256), 0, s, AY, EY, AX, EX, csy, (int)z->ch, (int)z->Mx, z->vw, (int)z->My);
 	else
 		hipLaunchKernelGGL(zf_mid_kernel<1>, dim3(8192), dim3(256), 0, s, AY, EY, AX, EX, csy, (int)z->ch, (int)z->Mx, z->vw, (int)z->My);
+	if (z->fused) {
+		// cosine part straight into the caller's frame when the viewport is the whole scaled height (else in place, rows [0, vh) copied out);
+		// the sine part adds -(-1)^j ZE[j] into it in its own store phase
+		float *dst = z->vh == z->My ? d_out : AY;
+		if (dspfft_execute(z->colsA, AY, dst, stream) || dspfft_execute_masked_accumulate(z->colsE, EY, EY, dst, nullptr, 0, 1, stream)) {
+			snprintf(g_err, sizeof g_err, "y stage: %s", dspfft_last_error()); return -4;
+		}
+		if (dst != d_out && hipMemcpyAsync(d_out, AY, (size_t)z->vh * z->vw * 3 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) { snprintf(g_err, sizeof g_err, "copy failed"); return -4; }
+		return hipGetLastError() == hipSuccess ? 0 : -4;
+	}
 	if (dspfft_execute(z->colsA, AY, AY, stream) || dspfft_execute(z->colsE, EY, EY, stream)) { snprintf(g_err, sizeof g_err, "y stage: %s", dspfft_last_error()); return -4; }
 	if ((z->vw * 3) % 4 == 0)
 		hipLaunchKernelGGL(zf_final_kernel<4>, dim3(8192), dim3(256), 0, s, d_out, AY, EY, z->vw, z->vh);

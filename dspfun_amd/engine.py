@@ -113,6 +113,13 @@ class Plan:
             raise DspfftError(self._lib.dspfft_last_error().decode())
         return bool(rc)
 
+    def set_output_alternate(self, axis, on=True):
+        """output sample j of `axis` times (-1)^j, fused into that axis's pass; True when the plan honours it"""
+        rc = self._lib.dspfft_plan_set_output_alternate(self._h, axis, int(on))
+        if rc < 0:
+            raise DspfftError(self._lib.dspfft_last_error().decode())
+        return bool(rc)
+
     def execute(self, d_in, d_out=None, stream=0):
         d_out = d_in if d_out is None else d_out
         run = self._lib.dspfft_execute_f64 if self.f64 else self._lib.dspfft_execute

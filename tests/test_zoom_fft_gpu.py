@@ -150,3 +150,28 @@ def test_input_window_skips_rows_that_are_zero_by_contract(gpu):
     from dspfun_amd.engine import DspfftError
     with pytest.raises(DspfftError):
         Plan.guru([(N, inner, inner)], [(inner, 1, 1)], [REDFT01]).set_input_window(0, 5, 2000)
+
+
+def test_output_alternate_fused_into_the_column_pass(gpu):
+    """dspfft_plan_set_output_alternate: output row j times (-1)^j in the pass's store, alone and together with an accumulating execution
+    (acc += plan(in)): what zoom's sine part uses instead of a combine kernel"""
+    from dspfun_amd import Plan, REDFT01
+    N, inner = 1080, 64
+    x = ol.synth_f32(78, N * inner).reshape(N, inner) - 0.5
+    want = ol.r2r_many(x.astype(np.float64), [N], [ol.REDFT01], howmany=inner, istride=inner, idist=1, ostride=inner, odist=1, impl="port").reshape(N, inner)
+    sign = np.where(np.arange(N) % 2 == 1, -1.0, 1.0)[:, None]
+    p = Plan.guru([(N, inner, inner)], [(inner, 1, 1)], [REDFT01]).set_scale(-0.25)
+    assert p.set_output_alternate(0) is True
+    d = gpu.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to("cuda:0")
+    out = gpu.empty_like(d)
+    p.execute(d.data_ptr(), out.data_ptr())
+    gpu.cuda.synchronize()
+    assert np.abs(out.cpu().numpy() - (-0.25) * sign * want).max() <= 1e-5 * np.abs(want).max()
+    acc0 = ol.synth_f32(79, N * inner).reshape(N, inner)
+    acc = gpu.from_numpy(acc0.copy()).to("cuda:0")
+    work = gpu.empty_like(d)
+    p.execute_masked_accumulate(d.data_ptr(), work.data_ptr(), acc.data_ptr())
+    gpu.cuda.synchronize()
+    assert np.abs(acc.cpu().numpy() - (acc0 + (-0.25) * sign * want)).max() <= 1e-5 * np.abs(want).max()
+    assert p.set_output_alternate(0, False) is False
+    assert Plan.image(1080, 1920, 3, REDFT01).set_output_alternate(1) is False         # the x axis runs as a row pass (and first): not honoured
