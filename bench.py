@@ -252,14 +252,24 @@ def main():
         rejoin = max(1, args.realign)
         schedule = f"free, streams re-joined every {rejoin} steps"
 
+    bar = {"ms": [0.0, 0.0, 0.0]}
+
     def barrier():
+        a0 = time.perf_counter()
         torch.cuda.synchronize()
+        a1 = time.perf_counter()
         if dist is not None:
             dist.barrier()
+        a2 = time.perf_counter()
         torch.cuda.synchronize()
+        bar["ms"] = [round((a1 - a0) * 1e3, 3), round((a2 - a1) * 1e3, 3), round((time.perf_counter() - a2) * 1e3, 3)]
 
     # clocks and caches settle over a few tens of milliseconds: whatever --warmup says, run at least that much untimed work
     # first (a short --steps run is otherwise timed on a GPU that is still ramping up)
+    # The FIRST dist.barrier() of a process costs the work behind it about 1.7 ms, once (tools/dist_gap_probe.py: 20 steps take 13.2 ms
+    # behind the first barrier, 11.6 ms behind any later one -- RCCL still setting itself up in the background): take it here, before
+    # the warm-up, so that the barrier which opens the timed region is not the first.
+    barrier()
     if args.warmup < 60:
         batch.run_repeat(60 - args.warmup, rejoin)
     batch.run_repeat(args.warmup, rejoin)
@@ -269,6 +279,7 @@ def main():
     enqueue_s = time.perf_counter() - t0          # host time to enqueue all steps (must stay well below the GPU's time)
     barrier()
     elapsed = time.perf_counter() - t0
+    closing = list(bar["ms"])                     # [synchronize, dist.barrier, synchronize] of the closing bracket, ms (inside the timed region)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -364,6 +375,7 @@ def main():
                        "parallelism": f"frame-sharded x{world}, no collective"},
             "roundtrip_frac_of_hbm_roofline": round(value * 1e6 * ALG_BYTES_PER_PIXEL / (HBM_PEAK * world), 4),      # per GPU
             "max_abs_drift_after_all_roundtrips": drift, "host_enqueue_ms_per_step": round(enqueue_s / args.steps * 1e3, 5),
+            "closing_bracket_ms": {"synchronize": closing[0], "barrier": closing[1], "synchronize_after": closing[2]},
             "roofline": roof,
         }
         if motion is not None:
