@@ -751,14 +751,40 @@ struct ColSpecT {
 					if (k > 0 && km != k) storev_a<Re>(a, o + (long long)km * a.es_out, g_put(r1));
 				});
 			} else {
-				tloop<N * NP, T>(tid, [&](int it) {
+				auto value = [&](int it, long long &off) {
 					const int n = it / NP, jp = it - n * NP;
 					const LC F = l_get(buf[n * NP + jp]);
 					const int y = makhoul_src(n, N);
 					Re sc = (y == 0) ? a.scale * a.out_scale0 : a.scale;
 					if (a.alt_out && (y & 1)) sc = -sc;          // folds away in the plain instantiation
-					storev_a<Re>(a, bout + (long long)y * a.es_out + VW * jp, g_put(cmk<LR>(F.x * sc, -F.y * sc)));
-				});
+					off = bout + (long long)y * a.es_out + VW * jp;
+					return g_put(cmk<LR>(F.x * sc, -F.y * sc));
+				};
+				if (a.accumulate) {
+					// read-modify-write: all the old values first (the loads go out back to back), then add and store -- a load issued
+					// right before its store would wait for its own data every time (the compiler cannot move it above the previous
+					// store: same array)
+					constexpr int ROUNDS = (N * NP + T - 1) / T;
+					V old[ROUNDS];
+					static_for<0, ROUNDS>([&](auto i) {
+						const int it = tid + i * T;
+						if ((i + 1) * T <= N * NP || it < N * NP) {
+							const int n = it / NP, jp = it - n * NP;
+							old[i] = *reinterpret_cast<const V *>(a.out + bout + (long long)makhoul_src(n, N) * a.es_out + VW * jp);
+						}
+					});
+					static_for<0, ROUNDS>([&](auto i) {
+						const int it = tid + i * T;
+						if ((i + 1) * T <= N * NP || it < N * NP) {
+							long long off;
+							V r = value(it, off);
+							static_for<0, NCS>([&](auto q) { r.s[q].x += old[i].s[q].x; r.s[q].y += old[i].s[q].y; });
+							*reinterpret_cast<V *>(a.out + off) = r;
+						}
+					});
+				} else {
+					tloop<N * NP, T>(tid, [&](int it) { long long off; const V r = value(it, off); *reinterpret_cast<V *>(a.out + off) = r; });
+				}
 			}
 		}
 	}
