@@ -488,17 +488,19 @@ struct ColSpecT {
 	};
 
 	// ---- lane vector <-> lane complex ----
-	// Global memory order is column order: (c0, c1 | c2, c3), signal i = c(2i) + j c(2i+1).  g_get gives x = the first column of each
-	// signal, y = the second.  In LDS a float lane keeps (re_a, re_b, im_a, im_b) so that l_get / l_put are register-pair moves and
-	// the swap happens once, where the tile meets global memory.
+	// Global memory order is column order (c0, c1, c2, c3).  g_get gives x = the first column of each of the lane's signals, y = the
+	// second.  In LDS a float lane keeps (re_a, re_b, im_a, im_b) so that l_get / l_put are register-pair moves.
+	// (round 3) float lanes pair columns (c0, c2) and (c1, c3) -- any two real columns may share a complex signal -- so that the first
+	// columns of both signals, c0 and c1, already sit in one aligned register pair as loaded (likewise c2, c3): g_get / g_put cost no
+	// register moves (the (c0, c1) | (c2, c3) pairing needed two v_mov per 16-byte access: 40 of the column kernel's 109)
 	static DSP_HD LC g_get(V v)
 	{
-		if constexpr (NCS == 2) return cmk<LR>(pk2(v.s[0].x, v.s[1].x), pk2(v.s[0].y, v.s[1].y)); else return cmk<LR>(v.s[0].x, v.s[0].y);
+		if constexpr (NCS == 2) return cmk<LR>(pk2(v.s[0].x, v.s[0].y), pk2(v.s[1].x, v.s[1].y)); else return cmk<LR>(v.s[0].x, v.s[0].y);
 	}
 	static DSP_HD V g_put(LC c)
 	{
 		V v;
-		if constexpr (NCS == 2) { v.s[0].x = c.x.x; v.s[0].y = c.y.x; v.s[1].x = c.x.y; v.s[1].y = c.y.y; } else { v.s[0].x = c.x; v.s[0].y = c.y; }
+		if constexpr (NCS == 2) { v.s[0].x = c.x.x; v.s[0].y = c.x.y; v.s[1].x = c.y.x; v.s[1].y = c.y.y; } else { v.s[0].x = c.x; v.s[0].y = c.y; }
 		return v;
 	}
 	static DSP_HD LC l_get(V v)
