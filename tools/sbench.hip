@@ -40,6 +40,46 @@ __global__ void __launch_bounds__(S::T, S::WPE) pass_k(const PassArgs a)
 	});
 }
 
+#ifdef CS_DMA
+// -DCS_DMA: the REAL column REDFT10 kernel with its tile loaded by LDS-DMA (global_load_lds_dwordx4) instead of
+// through registers.  Since round 3 a lane's 16 loaded bytes are already the LDS slot format (columns (c0, c2) / (c1, c3) paired), so the
+// DMA needs no conversion: lane q of a wave instruction fetches padded slot q's source row -- makhoul_src of the slot's row, the even/odd
+// reorder applied on the SOURCE address -- and the 64 lanes land in 64 consecutive slots (1 KiB).  Pad slots fetch row 0 (junk nobody
+// reads).  State::pre and phase 0's ds_write_b128 pass disappear.  (in_scale0 is 1 in this bench.)
+template <class S, int KIND>
+__global__ void __launch_bounds__(S::T, S::WPE) pass_k_dma(const PassArgs a)
+{
+	static_assert(KIND == KIND_REDFT10, "DMA variant: forward column pass");
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+	typedef SigVec<float, 2> V;
+	V *buf = reinterpret_cast<V *>(lds);
+	const int tid = threadIdx.x;
+	typename S::template State<KIND> st;
+	long long bin, bout;
+	S::base(a, blockIdx.x, bin, bout);
+	constexpr int SLOTS = S::ROWS * S::NP, ROUNDS = (SLOTS + S::T - 1) / S::T, BLK = S::SB + S::PADC;
+#pragma unroll
+	for (int r = 0; r < ROUNDS; r++) {
+		const int q = tid + r * S::T;
+		if (q - (tid & 63) < SLOTS) {                        // wave-uniform: the wave's first slot exists
+			const int qq = q < SLOTS ? q : SLOTS - 1;
+			const int rowp = qq / S::NP, jp = qq - rowp * S::NP;
+			const int blk = rowp / BLK, rr = rowp - blk * BLK;
+			const int n = rr < S::SB ? blk * S::SB + rr : 0;     // pad row: any valid source
+			const int y = makhoul_src(n, S::N);
+			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.in + bin + (long long)y * a.es_in + S::VW * jp),
+			                                 (__attribute__((address_space(3))) void *)(buf + (q & ~63)), 16, 0, 0);
+		}
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	static_for<1, S::NPH>([&](auto ph) {
+		S::template phase<KIND, ph>(a, buf, bout, tid, st);
+		if constexpr (ph + 1 < S::NPH) __syncthreads();
+	});
+}
+#endif
+
 #ifdef SPLIT
 #include <hip/hip_runtime.h>
 #include "backend.h"
@@ -141,7 +181,11 @@ static void launch_pass(int p, int f0, int nfr, hipStream_t s)
 		a.N = H; a.K = CS::K; a.B = CS::B; a.ninner = W * C; a.ntiles = W * C / CS::K; a.es_in = a.es_out = (long long)W * C;
 		a.nb0 = nfr; a.nb1 = 1; a.sb0_in = a.sb0_out = (long long)NF;
 		a.T = g_tcol.T; a.W = g_tcol.Wt;
+#ifdef CS_DMA
+		if (p == 1) hipLaunchKernelGGL((pass_k_dma<CS, KIND_REDFT10>), dim3(a.ntiles * nfr), dim3(CS::T), CS::LDS + 1024, s, a);
+#else
 		if (p == 1) hipLaunchKernelGGL((pass_k<CS, KIND_REDFT10, false>), dim3(a.ntiles * nfr), dim3(CS::T), CS::LDS, s, a);
+#endif
 		else hipLaunchKernelGGL((pass_k<CS, KIND_REDFT01, false>), dim3(a.ntiles * nfr), dim3(CS::T), CS::LDS, s, a);
 	}
 }
@@ -267,6 +311,24 @@ int main(int argc, char **argv)
 	CHK(hipFuncSetAttribute((const void *)pass_k<RS, KIND_REDFT01, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RS::LDS));
 	CHK(hipFuncSetAttribute((const void *)pass_k<CS, KIND_REDFT10, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CS::LDS));
 	CHK(hipFuncSetAttribute((const void *)pass_k<CS, KIND_REDFT01, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CS::LDS));
+#ifdef CS_DMA
+	CHK(hipFuncSetAttribute((const void *)pass_k_dma<CS, KIND_REDFT10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CS::LDS + 1024));
+	{	// correctness of the DMA-loaded pass against the register-staged one on frame 0 (then frame 0 is restored)
+		std::vector<float> ref(NF), got(NF), keep(NF);
+		CHK(hipMemcpy(keep.data(), g_buf, NF * 4, hipMemcpyDeviceToHost));
+		PassArgs a; memset((void *)&a, 0, sizeof a);
+		a.in = a.out = g_buf; a.in_scale0 = a.out_scale0 = 1.f; a.kind = KIND_REDFT10; a.scale = 1.f;
+		a.N = H; a.K = CS::K; a.B = CS::B; a.ninner = W * C; a.ntiles = W * C / CS::K; a.es_in = a.es_out = (long long)W * C; a.nb0 = 1; a.nb1 = 1; a.sb0_in = a.sb0_out = (long long)NF;
+		a.T = g_tcol.T; a.W = g_tcol.Wt;
+		hipLaunchKernelGGL((pass_k<CS, KIND_REDFT10, false>), dim3(a.ntiles), dim3(CS::T), CS::LDS, 0, a);
+		CHK(hipMemcpy(ref.data(), g_buf, NF * 4, hipMemcpyDeviceToHost)); CHK(hipMemcpy(g_buf, keep.data(), NF * 4, hipMemcpyHostToDevice));
+		hipLaunchKernelGGL((pass_k_dma<CS, KIND_REDFT10>), dim3(a.ntiles), dim3(CS::T), CS::LDS + 1024, 0, a);
+		CHK(hipMemcpy(got.data(), g_buf, NF * 4, hipMemcpyDeviceToHost)); CHK(hipMemcpy(g_buf, keep.data(), NF * 4, hipMemcpyHostToDevice));
+		double e = 0, m = 0;
+		for (size_t i = 0; i < NF; i++) { e = std::max(e, (double)fabsf(ref[i] - got[i])); m = std::max(m, (double)fabsf(ref[i])); }
+		printf("CS_DMA: LDS-DMA column REDFT10 vs register-staged: max abs diff %.3g (max |value| %.3g)\n", e, m);
+	}
+#endif
 	printf("ROW LDS %zu B (%.2f granules of 1280), COL LDS %zu B (%.2f granules); %d steps of %d frames\n", (size_t)RS::LDS, RS::LDS / 1280.0, (size_t)CS::LDS, CS::LDS / 1280.0, steps, NFR);
 	{	// each pass alone, one frame (cache-resident)
 		for (int p = 0; p < 4; p++) {
