@@ -1048,3 +1048,28 @@ def test_huge_prime_length_gets_a_working_plan(gpu, dtype):
     Plan.many_r2r([N], [REDFT01], dtype=dtype).set_scale(1.0 / (2.0 * N)).execute(d.data_ptr())
     gpu.cuda.synchronize()
     assert np.abs(d.cpu().numpy().astype(np.float64) - x).max() <= (5e-5 if dtype == "f32" else 1e-11)
+
+
+def test_execute_many_repeat_on_two_library_streams(gpu):
+    """bench.py's step loop (dspfft_execute_many_repeat) on real streams: four frames on two library-owned streams, seven repeats with a
+    re-join every two, per-pass event windows rotating through the frames; afterwards every frame is the input again and the events
+    carry positive times"""
+    from dspfun_amd import Plan, REDFT10, REDFT01
+    from dspfun_amd.engine import Batch, Events, Stream
+    h, w, c = 540, 960, 3
+    fwd = Plan.image(h, w, c, REDFT10)
+    inv = Plan.many_r2r([h, w], [REDFT01] * 2, howmany=c, istride=c, idist=1, ostride=c, odist=1, first_axis_first=True).set_scale(1.0 / (4.0 * w * h))
+    x = ol.synth_f32(0xD5F0A01, 4 * h * w * c).reshape(4, h, w, c)
+    d = dev(gpu, x)
+    streams = [Stream(), Stream()]
+    batch = Batch([(pl, d[f].data_ptr(), None, streams[f % 2].handle) for f in range(4) for pl in (fwd, inv)])
+    npass = fwd.num_passes + inv.num_passes
+    reps, every, window = 7, 3, 4                                   # windows on repeats 0, 3, 6
+    ev = Events(2 * npass * 2 * 3)
+    gpu.cuda.synchronize()
+    batch.run_repeat(reps, 2, every, window, ev)
+    for s_ in streams:
+        s_.synchronize()
+    assert np.abs(d.cpu().numpy() - x).max() <= 3e-5               # seven in-place roundtrips
+    times = [ev.elapsed_ms(2 * j, 2 * j + 1) for j in range(npass * 2 * 3)]
+    assert all(0.0 < t < 50.0 for t in times), times
