@@ -3,7 +3,7 @@
  *   gcc -O2 -std=c11 -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include tools/cbench.c -o tools/cbench \
  *       -Ldspfun_amd/csrc -Wl,-rpath,$PWD/dspfun_amd/csrc -ldspfft_hip -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib -lamdhip64
  *   tools/cbench [steps] [frames] [rejoin_every] [data: 0 splitmix64 uniform (bench.py's), 1 the 1000-level ramp tools/sbench.hip uses, 2 zeros]
- *                [inverse plan order: 0 last axis first (ROW, COL), 1 first axis first (COL, ROW)] */
+ *                [inverse plan order: 0 last axis first (ROW, COL), 1 first axis first (COL, ROW)] [width height: default 3840 2160] */
 #define _GNU_SOURCE
 #include <stdio.h>
 #include <stdlib.h>
@@ -17,7 +17,8 @@ static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
 int main(int argc, char **argv)
 {
 	const int steps = argc > 1 ? atoi(argv[1]) : 300, nfr = argc > 2 ? atoi(argv[2]) : 4, rejoin = argc > 3 ? atoi(argv[3]) : 8, data = argc > 4 ? atoi(argv[4]) : 0, order = argc > 5 ? atoi(argv[5]) : 0;
-	const int H = 2160, W = 3840, C = 3;
+	const int Wc = argc > 6 ? atoi(argv[6]) : 3840, Hc = argc > 7 ? atoi(argv[7]) : 2160;
+	const int H = Hc, W = Wc, C = 3;
 	const size_t NF = (size_t)H * W * C;
 	float *buf, *h = malloc(NF * 4);
 	unsigned long long s = 0xD5F0002ull;
