@@ -3,6 +3,7 @@
 // functions for CPU-only unit tests of the planner and kernel logic; that build is never shipped.
 #pragma once
 #include <stddef.h>
+#include <stdlib.h>
 #include "dct_core.h"
 #include "motion_filter.h"
 #include "dct_spec.h"
@@ -53,7 +54,9 @@ int be_launch_block(const BlockArgs &a, int nwg, size_t lds, void *stream);
 int be_launch_block_roundtrip(const BlockRtArgs &a, int nwg, size_t lds, void *stream);
 
 // compile-time-specialised kernels (dct_spec.h / spec_list.h)
-struct SpecInfo { int id, nthr, P; size_t lds; };   // P = C (ROW) or K (COL)
+struct SpecInfo { int id, nthr, P; size_t lds; int chan = 0; };   // P = C (ROW) or K (COL); chan = G when the interleaved line runs as G channel lines (nthr, lds are theirs)
+// DSPFFT_ROW_CHAN=0 keeps such lines in one workgroup (A/B runs)
+inline bool chan_lines_enabled() { const char *e = getenv("DSPFFT_ROW_CHAN"); return !e || atoi(e) != 0; }
 bool be_find_spec(int is_col, int N, int P, SpecInfo *info);
 int be_launch_spec(int is_col, int id, const PassArgs &a, int nwg, void *stream);
 // the same for double samples (spec_list.h DSPFFT_*_SPECS_F64): plain passes only

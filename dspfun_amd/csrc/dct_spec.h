@@ -16,6 +16,7 @@
 #pragma once
 #include "dct_core.h"
 #include "elementwise_core.h"
+#include "spec_list.h"
 
 // LDS pad (elements / rows per first-stage sub-block); overridable for experiments (tools/sbench.hip)
 #ifndef DSP_ROW_PADC
@@ -186,12 +187,17 @@ template <class Re> DSP_HD void storev_a(const PassArgsT<Re> &a, long long off, 
 struct U8IO { const uint8_t *in; uint8_t *out; double mul; };
 
 // =================================================================================================
-template <class Re_, int N_, int C_, int T_, int... Rs>
-struct RowSpecT {
+// GS_ = distance in samples between consecutive pixels of the line in global memory.  GS_ == C_: the line's C_ interleaved channels all
+// pass through this workgroup's LDS.  C_ == 1 with GS_ > 1 ("channel lines", RowChanSpecT below): the workgroup transforms ONE channel of
+// an interleaved line, a 1/GS_ of the LDS -- 7680 x 3 floats / 3840 x 3 doubles are 92 KB per line, one workgroup per CU, whose load,
+// butterfly and store phases then overlap with nothing; a channel line is 31 KB and five workgroups share the CU.
+template <class Re_, int N_, int C_, int GS_, int T_, int... Rs>
+struct RowSpecG {
 	typedef Re_ Re;                                    // sample type
 	typedef cx<Re_> CX;
 	typedef PassArgsT<Re_> PA;
-	static constexpr int N = N_, C = C_, T = T_, L = N_ / 2, NS = (int)sizeof...(Rs), NPH = NS + 3;
+	static constexpr int N = N_, C = C_, GS = GS_, T = T_, L = N_ / 2, NS = (int)sizeof...(Rs), NPH = NS + 3;
+	static_assert(GS_ == C_ || C_ == 1, "channel lines hold one channel");
 	// min waves per SIMD asked of the register allocator.  double: as many workgroups as the line's LDS allows, capped at 4 (128 VGPRs);
 	// left alone the allocator spends 140+ on the double kernels and a second workgroup no longer fits a CU
 	static constexpr int WPE_D = (int)((160 * 1024) / ((size_t)C_ * (N_ / 2 + 16) * sizeof(CX))) * T_ / 256;
@@ -211,7 +217,7 @@ struct RowSpecT {
 	static constexpr int K_ROUNDS = (L / 2 + 1 + T - 1) / T;     // REDFT01: (k, L-k) pairs per thread
 	// 8-bit ends (U8IO, planar rows): a thread moves FOUR consecutive pixels as one dword, x = 4 (tid + i T) + q
 	static constexpr int U8_ROUNDS = (N / 4 + T - 1) / T;
-	static constexpr bool U8_OK = (C == 1) && (N % 4 == 0) && std::is_same<Re, float>::value;
+	static constexpr bool U8_OK = (C == 1) && (GS == 1) && (N % 4 == 0) && std::is_same<Re, float>::value;
 	// per-thread registers that live across barriers: the last stage's butterflies and the
 	// line's global data, loaded before the first LDS phase
 	template <int KIND> struct State {
@@ -221,18 +227,19 @@ struct RowSpecT {
 
 	// issue the global loads of one line into registers (no LDS access, no waiting)
 	template <int KIND, class ST>
-	static DSP_HD void prefetch(const PA &a, long long bin, int tid, ST &st, const U8IO *io = nullptr, const uint8_t *zf = nullptr)
+	// ch: channel lines only -- which channel of the interleaved line `bin` already points at (the tile flags go by the offset in the line)
+	static DSP_HD void prefetch(const PA &a, long long bin, int tid, ST &st, const U8IO *io = nullptr, const uint8_t *zf = nullptr, int ch = 0)
 	{
-		if (a.mask) prefetch_m<KIND, true, false>(a, bin, tid, st, io, nullptr);
-		else if (zf) prefetch_m<KIND, false, true>(a, bin, tid, st, io, zf);       // zf: this line's tile flags (PassGeom::zflags)
-		else prefetch_m<KIND, false, false>(a, bin, tid, st, io, nullptr);
+		if (a.mask) prefetch_m<KIND, true, false>(a, bin, tid, st, io, nullptr, ch);
+		else if (zf) prefetch_m<KIND, false, true>(a, bin, tid, st, io, zf, ch);       // zf: this line's tile flags (PassGeom::zflags)
+		else prefetch_m<KIND, false, false>(a, bin, tid, st, io, nullptr, ch);
 	}
 	template <int KIND, bool MASKED, bool FLAGGED, class ST>
-	static DSP_HD void prefetch_m(const PA &a, long long bin, int tid, ST &st, const U8IO *io, const uint8_t *zf)
+	static DSP_HD void prefetch_m(const PA &a, long long bin, int tid, ST &st, const U8IO *io, const uint8_t *zf, int ch = 0)
 	{
 		auto ld = [&](int x) {
-			if constexpr (FLAGGED) return load_pix_z<C, Re>(a, zf, x * C, bin + (long long)x * C);
-			else return load_pix_m<C, MASKED, Re>(a, bin + (long long)x * C);
+			if constexpr (FLAGGED) return load_pix_z<C, Re>(a, zf, x * GS + ch, bin + (long long)x * GS);
+			else return load_pix_m<C, MASKED, Re>(a, bin + (long long)x * GS);
 		};
 		if constexpr (KIND == KIND_REDFT10 && U8_OK) {
 			if (io && io->in) {
@@ -402,10 +409,10 @@ struct RowSpecT {
 						o2.v[c] = wm.x * sc;
 						o3.v[c] = -wm.y * sc;
 					});
-					store_pix_a<C, Re>(a, bout + (long long)k * C, o0);
-					if (k > 0) store_pix_a<C, Re>(a, bout + (long long)(N - k) * C, o1);
-					if (L - k != k) store_pix_a<C, Re>(a, bout + (long long)(L - k) * C, o2);
-					if (k > 0 && L + k != N - k) store_pix_a<C, Re>(a, bout + (long long)(L + k) * C, o3);
+					store_pix_a<C, Re>(a, bout + (long long)k * GS, o0);
+					if (k > 0) store_pix_a<C, Re>(a, bout + (long long)(N - k) * GS, o1);
+					if (L - k != k) store_pix_a<C, Re>(a, bout + (long long)(L - k) * GS, o2);
+					if (k > 0 && L + k != N - k) store_pix_a<C, Re>(a, bout + (long long)(L + k) * GS, o3);
 				});
 			} else {
 				if constexpr (U8_OK) {
@@ -431,13 +438,15 @@ struct RowSpecT {
 						const Re f = pf[c * (2 * PL) + n];
 						o.v[c] = ((n & 1) ? -f : f) * sc;
 					});
-					store_pix_a<C, Re>(a, bout + (long long)x * C, o);
+					store_pix_a<C, Re>(a, bout + (long long)x * GS, o);
 				});
 			}
 		}
 	}
 };
 
+template <class Re_, int N_, int C_, int T_, int... Rs> using RowSpecT = RowSpecG<Re_, N_, C_, C_, T_, Rs...>;
+template <class Re_, int N_, int G_, int T_, int... Rs> using RowChanSpecT = RowSpecG<Re_, N_, 1, G_, T_, Rs...>;     // one channel of a G_-channel line
 template <int N_, int C_, int T_, int... Rs> using RowSpec = RowSpecT<float, N_, C_, T_, Rs...>;
 
 // =================================================================================================
@@ -971,5 +980,22 @@ struct ColHalfSpecT {
 };
 
 template <int N_, int K_, int T_, int... Rs> using ColHalfSpec = ColHalfSpecT<float, N_, K_, T_, Rs...>;
+
+// ---- channel lines (RowChanSpecT) ----
+// work item b of a pass over `lines` interleaved lines of G channels -> (line, channel).  The G channel lines of a line read and write
+// the SAME cache lines, a third each: they go to the same XCD (workgroups b, b + 8, ... share one: see xcd_remap), back to back, so that
+// their partial stores meet in one L2 before the line is written back.  Measured on MI355X (tools/rowchan.hip, 3840 x 2160 x 3 doubles,
+// out of place): 208-217 us with the channels of a line on different XCDs, 103 us on the same one (the interleaved kernel: 125-134 us).
+template <int G> DSP_HD void chan_work(int b, int lines, int &line, int &ch)
+{
+	const int full = (lines >> 3) << 3;
+	if (b < full * G) { const int x = b & 7, j = b >> 3, q = j / G; line = q * 8 + x; ch = j - q * G; }
+	else { const int r = b - full * G; line = full + r / G; ch = r - (r / G) * G; }
+}
+// which interleaved row specs (sample type, N, channels) run as channel lines, and on which spec: spec_list.h
+template <class Re, int N, int C> struct chan_lines_of { typedef void type; };
+#define DSP_CHAN_TRAIT_D(N, G, T, ...) template <> struct chan_lines_of<double, N, G> { typedef RowChanSpecT<double, N, G, T, __VA_ARGS__> type; };
+DSPFFT_ROW_CHAN_SPECS_F64(DSP_CHAN_TRAIT_D)
+#undef DSP_CHAN_TRAIT_D
 
 }  // namespace dspfft

@@ -547,7 +547,8 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 				for (const Dim &d : lines) aligned = aligned && (d.is % al == 0) && (d.os % al == 0);
 				if (aligned && (pl->f64 ? be_find_spec_f64(0, N, C, &P.spec) : be_find_spec(0, N, C, &P.spec))) {
 					P.has_spec = true; P.spa = pa; P.spec_nwg = (int)nlines;
-					snprintf(buf, sizeof buf, "axis %d: ROW*%s N=%d C=%d spec#%d threads=%d lines=%lld lds=%zu", a, tag, N, C, P.spec.id, P.spec.nthr, nlines, P.spec.lds);
+					if (P.spec.chan) snprintf(buf, sizeof buf, "axis %d: ROW*%s N=%d C=%d spec#%d as %d channel lines, threads=%d lines=%lld lds=%zu", a, tag, N, C, P.spec.id, P.spec.chan, P.spec.nthr, nlines, P.spec.lds);
+					else snprintf(buf, sizeof buf, "axis %d: ROW*%s N=%d C=%d spec#%d threads=%d lines=%lld lds=%zu", a, tag, N, C, P.spec.id, P.spec.nthr, nlines, P.spec.lds);
 					P.desc = buf;
 				} else if (aligned && jit_enabled() && lines.size() <= 2) {
 					jit_row(pl, P, N, C, nlines, F, kind);
@@ -1426,8 +1427,24 @@ extern "C" int dspfft_execute_pass(dspfft_plan pl, int index, const float *d_in,
 	return run_pass<float>(pl, P, P.first ? d_in : d_out, d_out, index + 1 == (int)passes.size(), stream);
 }
 
-// one pass over the items; items [timed_item, timed_item + timed_count) bracket each of their passes with pass_events (2 per pass)
-static int execute_many_once(int count, const dspfft_plan *plans, const float *const *d_in, float *const *d_out, void *const *streams,
+// one pass over the items; items [timed_item, timed_item + timed_count) bracket each of their passes with pass_events (2 per pass).
+// Buffers are float or double according to each item's plan.
+template <class R>
+static int execute_item(dspfft_plan pl, const void *in, void *out, void *st, bool timed, void *const *pass_events, int &ev)
+{
+	const R *d_in = (const R *)in;
+	R *d_out = (R *)out;
+	if (!timed) return execute_t<R>(pl, d_in, d_out, st);
+	const std::vector<Pass> &passes = pick_passes(pl, d_in, d_out);
+	for (size_t p = 0; p < passes.size(); p++) {
+		const Pass &P = passes[p];
+		if (be_event_record(pass_events[ev++], st)) return fail(-4, "event record failed");
+		if (int rc = run_pass<R>(pl, P, P.first ? d_in : d_out, d_out, p + 1 == passes.size(), st)) return rc;
+		if (be_event_record(pass_events[ev++], st)) return fail(-4, "event record failed");
+	}
+	return 0;
+}
+static int execute_many_once(int count, const dspfft_plan *plans, const void *const *d_in, void *const *d_out, void *const *streams,
                              int timed_item, int timed_count, void *const *pass_events)
 {
 	int ev = 0;
@@ -1435,23 +1452,17 @@ static int execute_many_once(int count, const dspfft_plan *plans, const float *c
 		dspfft_plan pl = plans[i];
 		void *st = streams ? streams[i] : nullptr;
 		const bool timed = pass_events && i >= timed_item && i < timed_item + timed_count;
-		if (!timed) { if (int rc = execute_t<float>(pl, d_in[i], d_out[i], st)) return rc; continue; }
-		const std::vector<Pass> &passes = pick_passes(pl, d_in[i], d_out[i]);
-		for (size_t p = 0; p < passes.size(); p++) {
-			const Pass &P = passes[p];
-			if (be_event_record(pass_events[ev++], st)) return fail(-4, "event record failed");
-			if (int rc = run_pass<float>(pl, P, P.first ? d_in[i] : d_out[i], d_out[i], p + 1 == passes.size(), st)) return rc;
-			if (be_event_record(pass_events[ev++], st)) return fail(-4, "event record failed");
-		}
+		const int rc = pl->f64 ? execute_item<double>(pl, d_in[i], d_out[i], st, timed, pass_events, ev) : execute_item<float>(pl, d_in[i], d_out[i], st, timed, pass_events, ev);
+		if (rc) return rc;
 	}
 	return 0;
 }
-static int check_many(int count, const dspfft_plan *plans, const float *const *d_in, float *const *d_out, int timed_item, int timed_count, bool events)
+static int check_many(int count, const dspfft_plan *plans, const void *const *d_in, void *const *d_out, int timed_item, int timed_count, bool events, bool f64_ok)
 {
 	if (count < 0 || (count && (!plans || !d_in || !d_out))) return fail(-1, "bad arguments");
 	for (int i = 0; i < count; i++) {
 		if (!plans[i] || !d_in[i] || !d_out[i]) return fail(-1, "item %d: null plan or buffer", i);
-		if (plans[i]->f64) return fail(-1, "dspfft_execute_many takes f32 plans");
+		if (plans[i]->f64 && !f64_ok) return fail(-1, "dspfft_execute_many takes f32 plans");
 	}
 	if (events) {
 		if (timed_item < 0 || timed_count < 0 || timed_item + timed_count > count) return fail(-1, "timed items [%d, %d) lie outside the batch of %d", timed_item, timed_item + timed_count, count);
@@ -1465,19 +1476,19 @@ static int check_many(int count, const dspfft_plan *plans, const float *const *d
 extern "C" int dspfft_execute_many(int count, const dspfft_plan *plans, const float *const *d_in, float *const *d_out, void *const *streams,
                                    int timed_item, int timed_count, void *const *pass_events)
 {
-	if (int rc = check_many(count, plans, d_in, d_out, timed_item, timed_count, pass_events != nullptr)) return rc;
-	return execute_many_once(count, plans, d_in, d_out, streams, timed_item, timed_count, pass_events);
+	if (int rc = check_many(count, plans, (const void *const *)d_in, (void *const *)d_out, timed_item, timed_count, pass_events != nullptr, false)) return rc;
+	return execute_many_once(count, plans, (const void *const *)d_in, (void *const *)d_out, streams, timed_item, timed_count, pass_events);
 }
 
 // The frame loop of a clip inside the library: the batch `repeats` times (motion/motion.c:613-753 runs its per-frame plans once per
 // frame of the clip, scan/scan.c:421-447 its inverse plan once per output frame).  See include/dspfft.h.
-extern "C" int dspfft_execute_many_repeat(int count, const dspfft_plan *plans, const float *const *d_in, float *const *d_out, void *const *streams,
+extern "C" int dspfft_execute_many_repeat(int count, const dspfft_plan *plans, const void *const *d_in, void *const *d_out, void *const *streams,
                                           int repeats, int rejoin_every, int timed_every, int timed_count, void *const *pass_events)
 {
 	if (repeats < 0 || rejoin_every < 0 || timed_every < 0) return fail(-1, "bad arguments");
 	const bool ev = pass_events && timed_every > 0 && timed_count > 0;
 	if (ev && count % timed_count) return fail(-1, "the timed window (%d items) must divide the batch (%d items)", timed_count, count);
-	if (int rc = check_many(count, plans, d_in, d_out, 0, ev ? count : 0, ev)) return rc;
+	if (int rc = check_many(count, plans, d_in, d_out, 0, ev ? count : 0, ev, true)) return rc;
 	// distinct streams of the batch, in order of first use
 	std::vector<void *> uniq;
 	for (int i = 0; i < count; i++) { void *st = streams ? streams[i] : nullptr; if (std::find(uniq.begin(), uniq.end(), st) == uniq.end()) uniq.push_back(st); }
@@ -1498,7 +1509,7 @@ extern "C" int dspfft_execute_many_repeat(int count, const dspfft_plan *plans, c
 		if (ev && k % timed_every == 0) {
 			const int first = (int)(((long long)windows * timed_count) % count);
 			rc = execute_many_once(count, plans, d_in, d_out, streams, first, timed_count, pass_events + ev_off);
-			for (int i = first; i < first + timed_count; i++) ev_off += 2 * pick_passes(plans[i], d_in[i], d_out[i]).size();
+			for (int i = first; i < first + timed_count; i++) ev_off += 2 * pick_passes(plans[i], d_in[i], d_out[i]).size();    // (alignment of the pointers only)
 			windows++;
 		} else rc = execute_many_once(count, plans, d_in, d_out, streams, 0, 0, nullptr);
 	}

@@ -58,6 +58,32 @@ __global__ void __launch_bounds__(S::T, S::WPE) row_spec_kernel(const typename S
 	});
 }
 
+// ---- channel lines (dct_spec.h RowChanSpecT, chan_work): one workgroup per (line, channel) of an interleaved line ----
+template <class S, int KIND, bool PLAIN>
+__global__ void __launch_bounds__(S::T, S::WPE) row_chan_kernel(const typename S::PA a_, int lines)
+{
+	const typename S::PA a = PLAIN ? plain_args(a_) : a_;
+	extern __shared__ __attribute__((aligned(32))) unsigned char lds[];
+	typename S::CX *planes = reinterpret_cast<typename S::CX *>(lds);
+	const int tid = threadIdx.x;
+	typename S::template State<KIND> st;
+	int line, ch;
+	chan_work<S::GS>(blockIdx.x, lines, line, ch);
+	long long bin, bout;
+	row_base(a, line, bin, bout);
+	bin += ch; bout += ch;
+	const uint8_t *zf = a.zflags ? a.zflags + (line & 1) * a.zhalf : nullptr;     // see row_spec_kernel
+	S::template prefetch<KIND>(a, bin, tid, st, nullptr, zf, ch);
+	S::template phase<KIND, 0>(a, planes, bout, tid, st);
+	__syncthreads();
+	static_for<1, S::NPH>([&](auto ph) {
+		{
+			S::template phase<KIND, ph>(a, planes, bout, tid, st);
+			if constexpr (ph + 1 < S::NPH) __syncthreads();
+		}
+	});
+}
+
 // ---- lines that fill a CU's LDS on their own (7680 x 3 floats, 3840 x 3 doubles: 92 KB -> ONE workgroup per CU) ----
 // With a single resident workgroup nothing overlaps its load, butterfly and store phases.  This variant is persistent (one workgroup
 // per CU walks the lines) and software-pipelined at no register cost: the line's samples wait in State::pre only until phase 0 has put
@@ -250,6 +276,18 @@ int launch_row_spec(const typename S::PA &a, int nwork, void *stream)
 {
 	static int lds_ok = allow_lds(row_spec_kernel<S, KIND, false>, S::LDS) | allow_lds(row_spec_kernel<S, KIND, true>, S::LDS);
 	if (lds_ok) return lds_ok;
+	typedef typename chan_lines_of<typename S::Re, S::N, S::C>::type CH;
+	if constexpr (!std::is_void<CH>::value) {
+		// DSPFFT_ROW_CHAN=0 keeps the interleaved line in one workgroup (A/B runs)
+		if (chan_lines_enabled()) {
+			static int c_ok = allow_lds(row_chan_kernel<CH, KIND, false>, CH::LDS) | allow_lds(row_chan_kernel<CH, KIND, true>, CH::LDS);
+			if (c_ok) return c_ok;
+			if (is_plain(a)) hipLaunchKernelGGL((row_chan_kernel<CH, KIND, true>), dim3(nwork * CH::GS), dim3(CH::T), CH::LDS, (hipStream_t)stream, a, nwork);
+			else hipLaunchKernelGGL((row_chan_kernel<CH, KIND, false>), dim3(nwork * CH::GS), dim3(CH::T), CH::LDS, (hipStream_t)stream, a, nwork);
+			HIPCHK(hipGetLastError());
+			return 0;
+		}
+	}
 	if constexpr (persist_ok<S>()) {
 		// DSPFFT_ROW_PERSIST=0 keeps one workgroup per line (A/B runs)
 		static const int on = []() { const char *e = getenv("DSPFFT_ROW_PERSIST"); return e ? atoi(e) : 1; }();

@@ -105,6 +105,17 @@
 	X(1024, 3, 256, 4, 8, 16)        \
 	X(1280, 1, 128, 4, 10, 16)
 
+// interleaved double lines that fill a CU's LDS on their own (92 KB: ONE workgroup per CU) run as CHANNEL LINES instead: one workgroup
+// per (line, channel) on a third of the LDS (dct_spec.h RowChanSpecT, chan_work): X(N, channels, THREADS, radices of N/2 ...).
+// Measured (round 3, tools/rowchan.hip and tools/cbench): 3840 x 2160 x 3 row pass in place 107-112 -> 84 us with the frame in the Infinity
+// Cache, 122-127 -> 101 us over frames in HBM; roundtrip of one frame 341 -> 318 us.  What it costs: the three channel lines of a line
+// write a third of every cache line each and rely on meeting in one L2 -- with a SECOND stream's column pass sharing the L2s the
+// roundtrip of two frames on two streams is 8 % slower (0.76 -> 0.82 ms), so such clips should run on one stream (or DSPFFT_ROW_CHAN=0).
+// Not listed, measured slower: 4096 x 3 doubles (402 MB frame, 0.971 -> 1.005 ms per roundtrip), 7680 x 3 floats (row pass 205 -> 215-219 us
+// in place over HBM-resident frames), 3840 x 3 floats (46 KB lines, three workgroups per CU already: 46-48 -> 57-61 us).
+#define DSPFFT_ROW_CHAN_SPECS_F64(X) \
+	X(3840, 3, 256, 12, 10, 16)
+
 #define DSPFFT_COL_SPECS_F64(X)      \
 	X(2160, 4, 512, 12, 12, 15)      \
 	X(1080, 8, 512, 12, 10, 9)       \

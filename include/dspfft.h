@@ -71,8 +71,9 @@ int dspfft_execute_many(int count, const dspfft_plan *plans, const float *const 
  * gave them, and that phase decides how well their kernels share the CUs).
  * Profiling aid: with pass_events non-NULL and timed_every > 0, repeats 0, timed_every, 2 timed_every ... bracket every pass of a window
  * of timed_count consecutive items (timed_count must divide count); the window advances by timed_count items (mod count) each time, and
- * the events of the j-th bracketed pass overall are pass_events[2j], pass_events[2j+1].  One-pass block plans cannot be bracketed. */
-int dspfft_execute_many_repeat(int count, const dspfft_plan *plans, const float *const *d_in, float *const *d_out, void *const *hip_streams,
+ * the events of the j-th bracketed pass overall are pass_events[2j], pass_events[2j+1].  One-pass block plans cannot be bracketed.
+ * Items may be f32 or f64 plans: each item's buffers are float or double as its plan says (hence the void pointers). */
+int dspfft_execute_many_repeat(int count, const dspfft_plan *plans, const void *const *d_in, void *const *d_out, void *const *hip_streams,
                                int repeats, int rejoin_every, int timed_every, int timed_count, void *const *pass_events);
 /* Streams of the library's own for the calls above: plain non-blocking HIP streams (hipStreamCreateWithFlags(hipStreamNonBlocking)),
  * for hosts without a HIP binding of their own (cgo, ctypes ...) and for hosts whose framework hands out streams from a pool:

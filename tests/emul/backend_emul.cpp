@@ -168,6 +168,26 @@ int be_launch_dense(const DenseArgsD &a, const LaunchGeom &g, void *) { return e
 template <class S, int KIND>
 int launch_row_spec(const typename S::PA &a, int nwork, void *)
 {
+	// channel lines (spec_kernels.h row_chan_kernel): one "workgroup" per (line, channel), in the order chan_work hands them out
+	typedef typename chan_lines_of<typename S::Re, S::N, S::C>::type CH;
+	if constexpr (!std::is_void<CH>::value) {
+		if (chan_lines_enabled()) {
+			std::vector<unsigned char> clds(CH::LDS + 32);
+			typename CH::CX *planes = (typename CH::CX *)(((uintptr_t)clds.data() + 31) & ~(uintptr_t)31);
+			for (int wg = 0; wg < nwork * CH::GS; wg++) {
+				std::vector<typename CH::template State<KIND>> st(CH::T);
+				int line, ch;
+				chan_work<CH::GS>(wg, nwork, line, ch);
+				long long bin, bout;
+				row_base(a, line, bin, bout);
+				bin += ch; bout += ch;
+				const uint8_t *zf = a.zflags ? a.zflags + (line & 1) * a.zhalf : nullptr;
+				for (int tid = 0; tid < CH::T; tid++) CH::template prefetch<KIND>(a, bin, tid, st[tid], nullptr, zf, ch);
+				static_for<0, CH::NPH>([&](auto ph) { for (int tid = 0; tid < CH::T; tid++) CH::template phase<KIND, ph>(a, planes, bout, tid, st[tid]); });
+			}
+			return 0;
+		}
+	}
 	std::vector<unsigned char> lds(S::LDS + 32);
 	typename S::CX *planes = (typename S::CX *)(((uintptr_t)lds.data() + 31) & ~(uintptr_t)31);
 	for (int wg = 0; wg < nwork; wg++) {

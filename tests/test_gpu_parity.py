@@ -353,6 +353,48 @@ def test_f64_specialised_kernels_vs_port(gpu, h, w, c, kind):
     check(o.cpu().numpy(), ref, tol=TOL64)
 
 
+@pytest.mark.parametrize("h", [2160, 27, 5])
+def test_f64_channel_lines_equal_the_interleaved_kernel(gpu, h, monkeypatch):
+    """3840-pixel RGB double lines run one workgroup per (line, channel) (dct_spec.h RowChanSpecT; the three channel lines of a line
+    store a third of every cache line each): bit-identical to the interleaved kernel (DSPFFT_ROW_CHAN=0: same butterflies in the same
+    order), in place, out of place and through the fused scan step; line counts with and without a tail of chan_work's groups of 8"""
+    from dspfun_amd import Plan, _lib
+    w, c = 3840, 3
+    x = ol.synth_f32(h + 11, h * w * c).astype(np.float64).reshape(h, w, c) * (1 + 2.0 ** -31)
+    for kind in (5, 4):
+        monkeypatch.setenv("DSPFFT_ROW_CHAN", "1")
+        p = Plan.image(h, w, c, kind, dtype="f64").set_scale(0.37).set_axis_scale0(1, 0.5, 0.7)
+        assert "as 3 channel lines" in p.describe(), p.describe()
+        res = {}
+        for on in ("1", "0"):
+            monkeypatch.setenv("DSPFFT_ROW_CHAN", on)
+            d = gpu.from_numpy(x.copy()).to("cuda:0")
+            o = gpu.zeros_like(d)
+            p.execute(d.data_ptr(), o.data_ptr())
+            p.execute(d.data_ptr())
+            gpu.cuda.synchronize()
+            res[on] = (d.cpu().numpy(), o.cpu().numpy())
+        assert np.array_equal(res["1"][0], res["0"][0]) and np.array_equal(res["1"][1], res["0"][1]) and np.array_equal(res["1"][0], res["1"][1])
+        assert np.abs(res["1"][0]).max() > 0
+    L = _lib.load()
+    coeffs = gpu.from_numpy(x.copy()).to("cuda:0")
+    Plan.image(h, w, c, 5, dtype="f64").set_scale(1.0 / (4 * w * h)).execute(coeffs.data_ptr())
+    ids = gpu.zeros(h * w, dtype=gpu.int32, device="cuda:0")
+    assert L.dspfft_scan_zigzag_frame_ids(ids.data_ptr(), w, h, (h * w + 2) // 3, None) == 0
+    inv = Plan.image(h, w, c, 4, dtype="f64")
+    res = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("DSPFFT_ROW_CHAN", on)
+        acc = coeffs[0, 0].expand(h, w, c).contiguous()
+        work = gpu.zeros_like(acc)
+        for f in range(3):
+            inv.execute_masked_accumulate(coeffs.data_ptr(), work.data_ptr(), acc.data_ptr(), ids.data_ptr(), f, c)
+        gpu.cuda.synchronize()
+        res[on] = acc.cpu().numpy()
+    assert np.array_equal(res["1"], res["0"])
+    assert np.abs(res["1"] - x).max() < 1e-13
+
+
 def test_f64_c2_frame_roundtrip_with_spec_normalisation(gpu):
     """3840x2160x3 in double: spec.c:63-78 then ispec.c:153-167, normalisation fused, against the f64 port and
     by the round trip"""

@@ -965,3 +965,42 @@ def test_input_window_is_declined_where_it_is_not_implemented():
         p.set_input_window(1, 0, 10)
     with pytest.raises(DspfftError):
         p.set_input_window(0, 10, 5)
+
+
+# ---- channel lines (dct_spec.h RowChanSpecT): interleaved double lines of 3840 pixels run one workgroup per (line, channel) ----
+@pytest.mark.parametrize("w", [3840])
+@pytest.mark.parametrize("h", [10, 3])          # 10: one full group of eight lines + the tail of chan_work; 3: tail only
+def test_f64_channel_lines_match_the_interleaved_kernel_and_the_port(w, h, monkeypatch):
+    c = 3
+    L = emul()
+    x = ol.synth_f32(w + h, h * w * c).astype(np.float64).reshape(h, w, c) + 1e-9 * np.arange(h * w * c).reshape(h, w, c)
+    for kind in (REDFT10, REDFT01):
+        p = Plan.image(h, w, c, kind, lib=L, dtype="f64").set_scale(0.37).set_axis_scale0(1, 0.5, 0.7)
+        assert f"ROW* f64 N={w} C=3" in p.describe() and "as 3 channel lines" in p.describe(), p.describe()
+        ref = ol.dct2d_interleaved(x, kind, impl="port")
+        monkeypatch.setenv("DSPFFT_ROW_CHAN", "1")
+        got = run64(p, x.copy())
+        out = np.zeros_like(x)
+        run64(p, x.copy(), out)                               # out of place
+        monkeypatch.setenv("DSPFFT_ROW_CHAN", "0")
+        base = run64(p, x.copy())
+        assert np.array_equal(got, base) and np.array_equal(out, base)      # same butterflies, same order: bit-identical
+        q = Plan.image(h, w, c, kind, lib=L, dtype="f64").set_scale(0.37)        # no per-index scales: the port's transform times 0.37
+        monkeypatch.setenv("DSPFFT_ROW_CHAN", "1")
+        assert relerr(run64(q, x.copy()), 0.37 * ref) < TOL64
+    # the fused scan step (owner-id mask on the first pass, accumulation in the row pass's stores) through channel lines
+    coeffs = x.copy()
+    Plan.image(h, w, c, REDFT10, lib=L, dtype="f64").set_scale(1.0 / (4 * w * h)).execute(coeffs.ctypes.data)
+    ids = np.zeros(h * w, dtype=np.uint32)
+    assert L.dspfft_scan_zigzag_frame_ids(ids.ctypes.data, w, h, (h * w + 2) // 3, None) == 0
+    inv = Plan.image(h, w, c, REDFT01, lib=L, dtype="f64")
+    res = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("DSPFFT_ROW_CHAN", on)
+        acc = np.ascontiguousarray(np.broadcast_to(coeffs[0, 0], (h, w, c)).copy())
+        work = np.zeros_like(acc)
+        for f in range(3):
+            inv.execute_masked_accumulate(coeffs.ctypes.data, work.ctypes.data, acc.ctypes.data, ids.ctypes.data, f, c)
+        res[on] = acc
+    assert np.array_equal(res["1"], res["0"])
+    assert np.abs(res["1"] - x).max() < 1e-13

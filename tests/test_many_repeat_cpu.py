@@ -63,3 +63,23 @@ def test_block_plans_cannot_be_bracketed_per_pass():
     b.run()                                             # untimed: fine
     with pytest.raises(DspfftError, match="block plans"):
         b.run(timed_item=0, timed_count=1, events=Events(16, lib=L))
+
+
+def test_double_and_float_plans_share_a_repeated_batch():
+    """dspfft_execute_many_repeat takes each item's buffers as float or double according to its plan (dspfft_execute_many stays f32 only)"""
+    L = emul()
+    h, w, c = 20, 28, 3
+    f32 = ol.synth_f32(5, h * w * c).reshape(h, w, c).copy()
+    f64 = ol.synth_f32(6, h * w * c).reshape(h, w, c).astype(np.float64)
+    ref32, ref64 = f32.copy(), f64.copy()
+    pl32 = Plan.image(h, w, c, REDFT10, lib=L)
+    pl64f = Plan.image(h, w, c, REDFT10, dtype="f64", lib=L)
+    pl64i = Plan.image(h, w, c, REDFT01, dtype="f64", lib=L).set_scale(1.0 / (4 * w * h))
+    b = Batch([(pl64f, f64.ctypes.data, None, 1), (pl32, f32.ctypes.data, None, 2), (pl64i, f64.ctypes.data, None, 1)], lib=L)
+    ev = Events(2 * (pl64f.num_passes + pl32.num_passes + pl64i.num_passes), lib=L)
+    b.run_repeat(1, 0, 1, 3, ev)                      # one repeat, every pass bracketed
+    assert np.abs(f64 - ref64).max() <= 1e-13        # double roundtrip
+    want = ol.dct2d_interleaved(ref32.astype(np.float64), REDFT10, impl="port")
+    assert np.abs(f32 - want).max() <= 2e-6 * np.abs(want).max()
+    with pytest.raises(DspfftError, match="f32 plans"):
+        b.run()
