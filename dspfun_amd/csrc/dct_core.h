@@ -99,9 +99,9 @@ struct PassGeom {
 	int zshift;           // ROW side: log2 of the column pass's tile width in samples
 	int zhalf;            // ROW side: the flags of odd lines start at zflags + zhalf (split column passes: half 1), else 0
 	const void *zpage;    // ROW side: 64 zero bytes to load from in place of a skipped tile (also what rows outside win_* load)
-	int alt_out;          // specialised COL REDFT01 last pass: output row y is multiplied by (-1)^y (dspfft_plan_set_output_alternate: the sine
+	int alt_out;          // specialised COL / ROW REDFT01 last pass: output sample y of the axis is multiplied by (-1)^y (dspfft_plan_set_output_alternate: the sine
 	                      // part of zoom's shifted cosine series is (-1)^b REDFT01 of the reversed input); 0: off
-	int win_lo, win_hi;   // specialised COL REDFT01 first pass: input rows outside [win_lo, win_hi) are zero BY CONTRACT and are not read
+	int win_lo, win_hi;   // specialised COL / ROW REDFT01 first pass: input samples of the axis outside [win_lo, win_hi) are zero BY CONTRACT and are not read
 	                      // (dspfft_plan_set_input_window: zoom's y stage transforms a spectrum zero-padded to 4x its length); 0, 0: off
 	const uint32_t *zranges;   // COL side, optional: (min, max) owner id of every tile (dspfft_plan_scan_prepare): a tile whose range
 	                           // excludes mask_id is skipped without reading its owner ids

@@ -239,7 +239,14 @@ struct RowSpecG {
 	{
 		auto ld = [&](int x) {
 			if constexpr (FLAGGED) return load_pix_z<C, Re>(a, zf, x * GS + ch, bin + (long long)x * GS);
-			else return load_pix_m<C, MASKED, Re>(a, bin + (long long)x * GS);
+			else if constexpr (MASKED) return load_pix_m<C, true, Re>(a, bin + (long long)x * GS);
+			else {
+				// dspfft_plan_set_input_window: pixels outside [win_lo, win_hi) are zero by contract and are not read (no branch around the
+				// load, see load_pix_m: they load from a page of zeros).  Folds away in the plain instantiation.
+				const Re *p = a.in + bin + (long long)x * GS;
+				if (a.win_hi > 0 && (x < a.win_lo || x >= a.win_hi)) p = reinterpret_cast<const Re *>(a.zpage);
+				return load_pix<C, Re>(p);
+			}
 		};
 		if constexpr (KIND == KIND_REDFT10 && U8_OK) {
 			if (io && io->in) {
@@ -433,7 +440,8 @@ struct RowSpecG {
 				tloop<N, T>(tid, [&](int x) {
 					const int n = makhoul_dst(x, N);
 					Pix<C, Re> o;
-					const Re sc = (x == 0) ? a.scale * a.out_scale0 : a.scale;
+					Re sc = (x == 0) ? a.scale * a.out_scale0 : a.scale;
+					if (a.alt_out && (x & 1)) sc = -sc;          // dspfft_plan_set_output_alternate; folds away in the plain instantiation
 					static_for<0, C>([&](auto c) {
 						const Re f = pf[c * (2 * PL) + n];
 						o.v[c] = ((n & 1) ? -f : f) * sc;

@@ -1051,14 +1051,14 @@ extern "C" int dspfft_plan_set_input_window(dspfft_plan pl, int axis, int lo, in
 	if (hi == 0) return 0;
 	if (pl->f64 || pl->passes.empty() || !pl->split.empty() || pl->has_block) return 0;
 	const Pass &P = pl->passes[0];
-	if (P.axis != axis || P.type != Pass::COL || !P.has_spec || P.jit || pl->kinds[axis] != DSPFFT_REDFT01 || !P.hostloop.empty()) return 0;
+	if (P.axis != axis || (P.type != Pass::COL && P.type != Pass::ROW) || !P.has_spec || P.jit || pl->kinds[axis] != DSPFFT_REDFT01 || !P.hostloop.empty()) return 0;
 	if (!pl->zpage) { pl->zpage = be_alloc(64); if (pl->zpage) { const char z[64] = {0}; if (be_upload(pl->zpage, z, 64)) { be_free(pl->zpage); pl->zpage = nullptr; } } }
 	if (!pl->zpage) return 0;
 	pl->win_axis = axis; pl->win_lo = lo; pl->win_hi = hi;
 	return 1;
 }
 // Output sample j of `axis` times (-1)^j, fused into the pass of that axis.  Honoured (return 1) only where it is implemented: f32 plans
-// whose pass along `axis` is a listed specialised column REDFT01 pass and the plan's LAST one; 0 otherwise (nothing changes).
+// whose pass along `axis` is a listed specialised column or row REDFT01 pass and the plan's LAST one; 0 otherwise (nothing changes).
 extern "C" int dspfft_plan_set_output_alternate(dspfft_plan pl, int axis, int on)
 {
 	if (!pl || axis < 0 || axis >= pl->rank) return fail(-1, "bad plan / axis");
@@ -1066,7 +1066,7 @@ extern "C" int dspfft_plan_set_output_alternate(dspfft_plan pl, int axis, int on
 	if (!on) return 0;
 	if (pl->f64 || pl->passes.empty() || !pl->split.empty() || pl->has_block) return 0;
 	const Pass &P = pl->passes.back();
-	if (P.axis != axis || P.type != Pass::COL || !P.has_spec || P.jit || pl->kinds[axis] != DSPFFT_REDFT01 || !P.hostloop.empty()) return 0;
+	if (P.axis != axis || (P.type != Pass::COL && P.type != Pass::ROW) || !P.has_spec || P.jit || pl->kinds[axis] != DSPFFT_REDFT01 || !P.hostloop.empty()) return 0;
 	pl->alt_axis = axis;
 	return 1;
 }

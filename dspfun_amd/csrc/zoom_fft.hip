@@ -16,6 +16,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "../../include/dspfft.h"
 
 namespace {
@@ -84,6 +85,39 @@ __global__ void zf_final_kernel(float *out, const float *ZA, const float *ZE, in
 	}
 }
 
+// ---- x stage last (rows): y stage inputs straight from the coefficients, then the x stage's compact inputs ----
+// A[v][u] = C[v][u] cos(theta_y v) in rows [0, ch), E[My - v][u] = C[v][u] sin(theta_y v) (v >= 1) in rows (My - ch, My); pitch cw pixels.
+// The other rows are zero: never read when the column plans honour the input window, cleared otherwise.
+__global__ void zf_prep_y_kernel(float *A, float *E, const float *C, const float *cs, int w, int ch, int cw, int My)
+{
+	const size_t rowf = (size_t)cw * 3, total = (size_t)ch * rowf;
+	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+		const int v = (int)(i / rowf);
+		const size_t f = i - (size_t)v * rowf;
+		const float c = C[(size_t)v * w * 3 + f];
+		A[(size_t)v * rowf + f] = c * cs[2 * v];
+		if (v >= 1) E[(size_t)(My - v) * rowf + f] = c * cs[2 * v + 1];
+	}
+}
+// T[j][u] = YA[j][u] - (-1)^j YE[j][u] (the 1/2 is the column plans' scale), j < vh, u < cw; then the x stage's inputs WITHOUT their zeros:
+// AX[j][u] = T[j][u] cos(theta_x u), pitch cw pixels (the row plan's window [0, cw)), and EX[j][q] = T[j][u] sin(theta_x u) at
+// q = cw - 1 - u for u >= 1, pitch cw - 1 pixels (sample Mx - u of the window (Mx - cw, Mx))
+__global__ void zf_mid_x_kernel(float *AX, float *EX, const float *YA, const float *YE, const float *cs, int vh, int cw)
+{
+	const size_t rowf = (size_t)cw * 3, total = (size_t)vh * rowf;
+	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+		const int j = (int)(i / rowf);
+		const size_t f = i - (size_t)j * rowf;
+		const int u = (int)(f / 3), c = (int)(f - (size_t)u * 3);
+		const float ya = YA[i], ye = YE[i];
+		const float t = (j & 1) ? ya + ye : ya - ye;
+		AX[i] = t * cs[2 * u];
+		if (u >= 1) EX[((size_t)j * (cw - 1) + (cw - 1 - u)) * 3 + c] = t * cs[2 * u + 1];
+	}
+}
+
+size_t r4(size_t floats) { return (floats + 3) & ~(size_t)3; }
+
 // len * num / den as an integer M >= 1, or 0
 long long grid_length(int len, double num, double den)
 {
@@ -104,6 +138,13 @@ struct dspfft_zoomfft_s {
 	bool windowed;                 // the column plans skip the zero rows of their inputs (dspfft_plan_set_input_window)
 	bool fused;                    // the sine part's column plan alternates its output signs and ADDS into the cosine part's result
 	                               // (dspfft_plan_set_output_alternate + accumulating execution): no combine kernel
+	// x stage LAST (preferred when the row plans can do it): the y stage runs first, on the cw columns the coefficients have (a quarter of
+	// the output width at BASELINE config 3), and the pass that writes the full frame is a ROW pass -- whose lines are loaded and stored
+	// whole -- instead of a column pass over 32-byte row segments.  Needs row plans that honour the input window (their compact inputs
+	// hold only the non-zero samples) and, for the sine part, the alternating accumulating store.
+	bool xlast;
+	dspfft_plan ycolsA, ycolsE, rowsA, rowsE;
+	bool ywindowed;
 };
 
 extern "C" const char *dspfft_zoomfft_last_error(void) { return g_err; }
@@ -120,8 +161,37 @@ extern "C" int dspfft_zoomfft_create(dspfft_zoomfft *out, int w, int h, int type
 	z->w = w; z->h = h; z->type = type; z->vw = vw; z->vh = vh; z->Mx = Mx; z->My = My;
 	z->cw = dspfft_zoom_ncomponents(xnum, xden, (size_t)w); z->ch = dspfft_zoom_ncomponents(ynum, yden, (size_t)h);
 	z->sx = xnum / xden; z->sy = ynum / yden;
-	z->rows = z->colsA = z->colsE = nullptr;
+	z->rows = z->colsA = z->colsE = z->ycolsA = z->ycolsE = z->rowsA = z->rowsE = nullptr;
+	z->xlast = false; z->ywindowed = false;
 	const int k01[1] = {DSPFFT_REDFT01};
+	{
+		// x stage last: rows of Mx RGB pixels read from compact lines (cw resp. cw - 1 pixels: only the window is ever read), written
+		// Mx pixels apart; the y stage before it: My rows x cw RGB pixels, in place
+		const char *e = getenv("DSPFFT_ZOOM_ORDER");       // "y": keep the column pass last (A/B runs)
+		const long long cw = (long long)z->cw, lo = Mx - cw + 1;
+		if (!(e && *e == 'y') && cw >= 1 && cw < Mx && Mx * 3 * (long long)vh < (1ll << 31) && My * cw * 3 < (1ll << 31)) {
+			const dspfft_iodim xd[1] = {{(int)Mx, 3, 3}};
+			const dspfft_iodim xa[2] = {{3, 1, 1}, {vh, (int)(cw * 3), (int)(Mx * 3)}}, xe[2] = {{3, 1, 1}, {vh, (int)((cw - 1) * 3), (int)(Mx * 3)}};
+			const dspfft_iodim yd[1] = {{(int)My, (int)(cw * 3), (int)(cw * 3)}}, yb[1] = {{(int)(cw * 3), 1, 1}};
+			bool ok = !dspfft_plan_guru_r2r(&z->rowsA, 1, xd, 2, xa, k01, 0) && !dspfft_plan_guru_r2r(&z->ycolsA, 1, yd, 1, yb, k01, 0) && !dspfft_plan_guru_r2r(&z->ycolsE, 1, yd, 1, yb, k01, 0);
+			if (ok && cw > 1) ok = !dspfft_plan_guru_r2r(&z->rowsE, 1, xd, 2, xe, k01, 0);
+			ok = ok && dspfft_plan_set_input_window(z->rowsA, 0, 0, (int)cw) == 1;
+			if (ok && cw > 1) ok = dspfft_plan_set_input_window(z->rowsE, 0, (int)lo, (int)Mx) == 1 && dspfft_plan_set_output_alternate(z->rowsE, 0, 1) == 1;
+			if (ok) {
+				dspfft_plan_set_scale(z->ycolsA, 0.5f); dspfft_plan_set_scale(z->ycolsE, 0.5f);
+				dspfft_plan_set_scale_f64(z->rowsA, 0.5 / ((double)w * (double)h));
+				if (z->rowsE) dspfft_plan_set_scale_f64(z->rowsE, -0.5 / ((double)w * (double)h));
+				const int wa = dspfft_plan_set_input_window(z->ycolsA, 0, 0, (int)z->ch);
+				const int we = z->ch > 1 ? dspfft_plan_set_input_window(z->ycolsE, 0, (int)(My - (long long)z->ch + 1), (int)My) : 0;
+				z->ywindowed = wa == 1 && (we == 1 || z->ch == 1) && z->ch < (size_t)My;
+				if (!z->ywindowed) { dspfft_plan_set_input_window(z->ycolsA, 0, 0, 0); dspfft_plan_set_input_window(z->ycolsE, 0, 0, 0); }
+				z->xlast = true;
+				*out = z;
+				return 0;
+			}
+			for (dspfft_plan *p : {&z->rowsA, &z->rowsE, &z->ycolsA, &z->ycolsE}) { if (*p) dspfft_destroy_plan(*p); *p = nullptr; }
+		}
+	}
 	// x stage: A and E one after the other = 2 ch lines of Mx RGB pixels, transformed along x
 	const dspfft_iodim rd[1] = {{(int)Mx, 3, 3}}, rb[2] = {{3, 1, 1}, {(int)(2 * z->ch), (int)(Mx * 3), (int)(Mx * 3)}};
 	// y stage: two arrays of My rows x vw RGB pixels, each transformed along y by its own plan: the cosine part's input is non-zero in
@@ -154,7 +224,7 @@ extern "C" int dspfft_zoomfft_create(dspfft_zoomfft *out, int w, int h, int type
 extern "C" void dspfft_zoomfft_destroy(dspfft_zoomfft z)
 {
 	if (!z) return;
-	dspfft_destroy_plan(z->rows); dspfft_destroy_plan(z->colsA); dspfft_destroy_plan(z->colsE);
+	for (dspfft_plan p : {z->rows, z->colsA, z->colsE, z->ycolsA, z->ycolsE, z->rowsA, z->rowsE}) if (p) dspfft_destroy_plan(p);
 	delete z;
 }
 
@@ -163,6 +233,8 @@ extern "C" size_t dspfft_zoomfft_work_floats(dspfft_zoomfft z)
 {
 	if (!z) return 0;
 	const size_t tab = (2 * z->cw + 2 * z->ch + 3) & ~(size_t)3;
+	if (z->xlast)    // tables | AY, EY (My x cw x 3 each) | AX (vh x cw x 3) | EX (vh x (cw - 1) x 3) | full lines when the viewport is narrower than Mx; each rounded up to 16 bytes
+		return tab + 2 * r4((size_t)z->My * z->cw * 3) + r4((size_t)z->vh * z->cw * 3) + r4((size_t)z->vh * (z->cw - 1) * 3) + (z->vw < z->Mx ? (size_t)z->vh * z->Mx * 3 : 0);
 	return tab + (size_t)2 * z->ch * z->Mx * 3 + (size_t)2 * z->My * z->vw * 3;
 }
 
@@ -181,6 +253,28 @@ extern "C" int dspfft_zoomfft_execute(dspfft_zoomfft z, const float *d_coeffs, d
 	float *AY = EX + (size_t)z->ch * z->Mx * 3, *EY = AY + (size_t)z->My * z->vw * 3;
 	hipLaunchKernelGGL(zf_table_kernel, dim3(32), dim3(256), 0, s, csx, thx, (int)z->cw);
 	hipLaunchKernelGGL(zf_table_kernel, dim3(32), dim3(256), 0, s, csy, thy, (int)z->ch);
+	if (z->xlast) {
+		const size_t cw = z->cw, yarr = (size_t)z->My * cw * 3;
+		float *AYx = d_work + tab, *EYx = AYx + r4(yarr);
+		float *AXc = EYx + r4(yarr), *EXc = AXc + r4((size_t)z->vh * cw * 3);
+		float *full = EXc + r4((size_t)z->vh * (cw - 1) * 3);
+		if (!z->ywindowed && hipMemsetAsync(AYx, 0, (r4(yarr) + yarr) * sizeof(float), s) != hipSuccess) { snprintf(g_err, sizeof g_err, "memset failed"); return -4; }
+		if (z->ywindowed && z->ch == 1 && hipMemsetAsync(EYx, 0, yarr * sizeof(float), s) != hipSuccess) { snprintf(g_err, sizeof g_err, "memset failed"); return -4; }
+		hipLaunchKernelGGL(zf_prep_y_kernel, dim3(4096), dim3(256), 0, s, AYx, EYx, d_coeffs, csy, z->w, (int)z->ch, (int)cw, (int)z->My);
+		if (dspfft_execute(z->ycolsA, AYx, AYx, stream) || dspfft_execute(z->ycolsE, EYx, EYx, stream)) { snprintf(g_err, sizeof g_err, "y stage: %s", dspfft_last_error()); return -4; }
+		hipLaunchKernelGGL(zf_mid_x_kernel, dim3(8192), dim3(256), 0, s, AXc, EXc, AYx, EYx, csx, z->vh, (int)cw);
+		float *dst = z->vw == z->Mx ? d_out : full;
+		// the sine part's window starts at sample Mx - cw + 1: its compact lines are addressed from that many pixels before their start
+		// (samples outside the window are not read)
+		if (dspfft_execute(z->rowsA, AXc, dst, stream)) { snprintf(g_err, sizeof g_err, "x stage: %s", dspfft_last_error()); return -4; }
+		if (z->rowsE && dspfft_execute_masked_accumulate(z->rowsE, EXc - (size_t)(z->Mx - (long long)cw + 1) * 3, dst, dst, nullptr, 0, 1, stream)) {
+			snprintf(g_err, sizeof g_err, "x stage: %s", dspfft_last_error()); return -4;
+		}
+		if (dst != d_out && hipMemcpy2DAsync(d_out, (size_t)z->vw * 3 * sizeof(float), full, (size_t)z->Mx * 3 * sizeof(float), (size_t)z->vw * 3 * sizeof(float), (size_t)z->vh,
+		                                     hipMemcpyDeviceToDevice, s) != hipSuccess) { snprintf(g_err, sizeof g_err, "copy failed"); return -4; }
+		if (hipGetLastError() != hipSuccess) { snprintf(g_err, sizeof g_err, "launch failed"); return -4; }
+		return 0;
+	}
 	hipLaunchKernelGGL(zf_prep_x_kernel, dim3(4096), dim3(256), 0, s, AX, EX, d_coeffs, csx, z->w, (int)z->ch, (int)z->cw, (int)z->Mx);
 	if (dspfft_execute(z->rows, AX, AX, stream)) { snprintf(g_err, sizeof g_err, "x stage: %s", dspfft_last_error()); return -4; }
 	// rows the re-pack kernel does not write must read as zero: either the column plans skip them (input window) or they are cleared here

@@ -102,11 +102,11 @@ int dspfft_execute_f64(dspfft_plan plan, const double *d_in, double *d_out, void
 /* Optional: the caller promises that input samples of `axis` outside [lo, hi) are ZERO (a spectrum zero-padded to a longer transform:
  * zoom's y stage, motion's scaled > block) so that they need not be read.  Returns 1 when the plan honours it -- then those rows need
  * not even be stored -- and 0 when it does not (nothing changes: the zeros must really be there).  Today: f32 plans whose first pass
- * is a listed specialised column REDFT01 pass along `axis`.  lo = hi = 0 turns it off.  Negative: bad arguments. */
+ * is a listed specialised column or row REDFT01 pass along `axis`.  lo = hi = 0 turns it off.  Negative: bad arguments. */
 int dspfft_plan_set_input_window(dspfft_plan plan, int axis, int lo, int hi);
 /* Optional: output sample j of `axis` is multiplied by (-1)^j, fused into that axis's pass (with REDFT01 on index-reversed input this is
  * the sine counterpart of the transform: sum_u D[u] sin(pi (j + 1/2) u / M) = (-1)^j 1/2 REDFT01(E)[j], E[u'] = D[M - u'] -- the second
- * half of zoom's shifted cosine series).  Returns 1 when honoured (f32 plans whose pass along `axis` is a listed specialised column REDFT01
+ * half of zoom's shifted cosine series).  Returns 1 when honoured (f32 plans whose pass along `axis` is a listed specialised column or row REDFT01
  * pass and the last of the plan), 0 when not (nothing changes).  Combined with dspfft_execute_masked_accumulate(plan, in, work, acc, NULL,
  * ...) the signed result is added into `acc` by the same pass. */
 int dspfft_plan_set_output_alternate(dspfft_plan plan, int axis, int on);

@@ -1004,3 +1004,38 @@ def test_f64_channel_lines_match_the_interleaved_kernel_and_the_port(w, h, monke
         res[on] = acc
     assert np.array_equal(res["1"], res["0"])
     assert np.abs(res["1"] - x).max() < 1e-13
+
+
+# ---- input window / alternating output on a listed ROW REDFT01 pass (zoom's x stage when it runs last: zoom_fft.hip) ----
+def test_row_pass_honours_window_and_alternate_with_compact_input_lines():
+    """samples outside the window are not read, so a line needs to hold only its window: the cosine part's lines are cw pixels long, the sine
+    part's cw - 1 pixels and addressed from `lo` pixels before their start; the sine part's store alternates its sign and accumulates"""
+    L = emul()
+    N, c, lines, cw = 640, 3, 5, 160
+    full = np.zeros((lines, N, c))
+    full[:, :cw] = ol.synth_f32(3, lines * cw * c).reshape(lines, cw, c) - 0.5
+    want = np.stack([ol.r2r_many(full[j], [N], [ol.REDFT01], howmany=c, istride=c, idist=1, ostride=c, odist=1, impl="port").reshape(N, c) for j in range(lines)])
+    pa = Plan.guru([(N, c, c)], [(c, 1, 1), (lines, cw * c, N * c)], [REDFT01], lib=L).set_scale(0.5)
+    assert "ROW*" in pa.describe(), pa.describe()
+    assert pa.set_input_window(0, 0, cw) is True
+    compact = np.ascontiguousarray(full[:, :cw], dtype=np.float32)
+    out = np.full((lines, N, c), np.nan, dtype=np.float32)
+    pa.execute(compact.ctypes.data, out.ctypes.data)
+    assert np.abs(out - 0.5 * want).max() <= 2e-6 * np.abs(want).max()
+    # the sine part: window [lo, N), lo = N - cw + 1; compact lines of cw - 1 pixels addressed from lo pixels before their start
+    lo = N - cw + 1
+    fe = np.zeros((lines, N, c))
+    fe[:, lo:] = ol.synth_f32(4, lines * (cw - 1) * c).reshape(lines, cw - 1, c) - 0.5
+    we = np.stack([ol.r2r_many(fe[j], [N], [ol.REDFT01], howmany=c, istride=c, idist=1, ostride=c, odist=1, impl="port").reshape(N, c) for j in range(lines)])
+    pe = Plan.guru([(N, c, c)], [(c, 1, 1), (lines, (cw - 1) * c, N * c)], [REDFT01], lib=L).set_scale(-0.25)
+    assert pe.set_input_window(0, lo, N) is True and pe.set_output_alternate(0) is True
+    ce = np.ascontiguousarray(fe[:, lo:], dtype=np.float32)
+    guard = np.concatenate([np.full(8, np.nan, dtype=np.float32), ce.ravel(), np.full(8, np.nan, dtype=np.float32)])     # NaNs either side: nothing else is read
+    acc = out.copy()
+    pe.execute_masked_accumulate(guard[8:].ctypes.data - lo * c * 4, acc.ctypes.data, acc.ctypes.data)
+    sign = np.where(np.arange(N) % 2 == 1, -1.0, 1.0)[None, :, None]
+    assert np.abs(acc - (0.5 * want - 0.25 * sign * we)).max() <= 2e-6 * (np.abs(want).max() + np.abs(we).max())
+    # turned off again / a forward plan / a double plan: not honoured
+    assert pa.set_input_window(0, 0, 0) is False
+    assert Plan.guru([(N, c, c)], [(c, 1, 1), (lines, N * c, N * c)], [REDFT10], lib=L).set_input_window(0, 0, cw) is False
+    assert Plan.guru([(N, c, c)], [(c, 1, 1), (lines, N * c, N * c)], [REDFT01], lib=L, dtype="f64").set_output_alternate(0) is False

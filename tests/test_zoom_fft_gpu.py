@@ -64,7 +64,10 @@ def test_against_the_references_compiled_loop(gpu):
 
 @pytest.mark.parametrize("w,h,xs,ys,vx,vy,typ,vw,vh", [
     (64, 48, (3, 1), (3, 1), 0.0, 0.0, 0, None, None), (64, 48, (2, 1), (5, 2), 7.25, -3.5, 0, None, None), (60, 36, (3, 2), (4, 3), 0.0, 0.0, 2, None, None),
-    (60, 36, (1, 2), (1, 3), 1.5, 0.0, 0, None, None), (96, 64, (4, 1), (4, 1), 10.0, 20.0, 0, 100, 60), (33, 17, (2, 1), (2, 1), 0.5, 0.25, 2, None, None)])
+    (60, 36, (1, 2), (1, 3), 1.5, 0.0, 0, None, None), (96, 64, (4, 1), (4, 1), 10.0, 20.0, 0, 100, 60), (33, 17, (2, 1), (2, 1), 0.5, 0.25, 2, None, None),
+    # scaled widths with a listed row kernel (256, 640, 1280 RGB pixels): the x stage runs LAST, as row passes over compact windowed lines
+    (128, 40, (2, 1), (3, 1), 0.0, 0.0, 0, None, None), (160, 30, (4, 1), (2, 1), 3.25, -1.5, 0, 500, 50), (320, 24, (4, 1), (1, 1), 0.0, 0.0, 2, None, None),
+    (320, 18, (2, 1), (5, 2), -2.0, 4.0, 2, 640, 20), (1, 7, (256, 1), (3, 1), 0.0, 0.0, 0, None, None)])
 def test_fft_equals_dense_product_and_oracle(gpu, w, h, xs, ys, vx, vy, typ, vw, vh):
     from dspfun_amd.zoom import Zoom
     x = ol.synth_f32(w * h + 5, w * h * 3).reshape(h, w, 3)
