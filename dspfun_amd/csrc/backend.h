@@ -65,6 +65,8 @@ int be_launch_spec(int is_col, int id, const PassArgsD &a, int nwg, void *stream
 // planar row pass reading u8 (REDFT10) or writing quantised u8 (REDFT01); only specs with C == 1 have it
 bool be_spec_has_u8(int row_spec_id);
 int be_launch_spec_u8(int row_spec_id, const PassArgs &a, const U8IO &io, int nwg, void *stream);
+// out = A(in_a) + B(in_b): two REDFT01 row transforms (same row spec, same output lines) in one launch
+int be_launch_row_sum2(int row_spec_id, const PassArgs &a, const PassArgs &b, int nwg, void *stream);
 // fused column roundtrip: REDFT10 along the tile axis (af), pointwise filter, REDFT01 (ai); both passes share spec `id`
 int be_launch_roundtrip(int id, const PassArgs &af, const PassArgs &ai, const MotionFilter &filt, unsigned long long *coded, int nwg, void *stream);
 

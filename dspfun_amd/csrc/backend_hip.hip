@@ -18,6 +18,7 @@ namespace dspfft {
 #define DSP_EXTERN_ROW(N, C, T, ...) \
 	extern template int launch_row_spec<RowSpec<N, C, T, __VA_ARGS__>, 0>(const PassArgs &, int, void *); \
 	extern template int launch_row_spec<RowSpec<N, C, T, __VA_ARGS__>, 1>(const PassArgs &, int, void *); \
+	extern template int launch_row_sum2<RowSpec<N, C, T, __VA_ARGS__>>(const PassArgs &, const PassArgs &, int, void *); \
 	extern template int launch_row_spec_u8<RowSpec<N, C, T, __VA_ARGS__>, 0>(const PassArgs &, const U8IO &, int, void *); \
 	extern template int launch_row_spec_u8<RowSpec<N, C, T, __VA_ARGS__>, 1>(const PassArgs &, const U8IO &, int, void *);
 #define DSP_EXTERN_COL(N, K, T, ...) \

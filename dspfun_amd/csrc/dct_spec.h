@@ -451,6 +451,28 @@ struct RowSpecG {
 			}
 		}
 	}
+
+	// ---- two REDFT01 transforms summed into one output line (row_sum2_kernel: out = A(in_a) + B(in_b)) ----
+	// the first transform's output line waits in registers (N C / T values per thread) while the second runs through the same LDS
+	struct Hold { Pix<C, Re> v[PIX_ROUNDS]; };
+	// the closing phase of REDFT01 (phase<KIND_REDFT01, NS + 2>) with MODE 1: the line kept in `h`, MODE 2: h + this line stored
+	template <int MODE>
+	static DSP_HD void final01_hold(const PA &a, CX *planes, long long bout, int tid, Hold &h)
+	{
+		const Re *pf = reinterpret_cast<const Re *>(planes);
+		static_for<0, PIX_ROUNDS>([&](auto i) {
+			const int x = tid + i * T;
+			if ((i + 1) * T <= N || x < N) {
+				const int n = makhoul_dst(x, N);
+				Re sc = (x == 0) ? a.scale * a.out_scale0 : a.scale;
+				if (a.alt_out && (x & 1)) sc = -sc;
+				Pix<C, Re> o;
+				static_for<0, C>([&](auto c) { const Re f = pf[c * (2 * PL) + n]; o.v[c] = ((n & 1) ? -f : f) * sc; });
+				if constexpr (MODE == 1) h.v[i] = o;
+				else { static_for<0, C>([&](auto c) { o.v[c] += h.v[i].v[c]; }); store_pix_a<C, Re>(a, bout + (long long)x * GS, o); }
+			}
+		});
+	}
 };
 
 template <class Re_, int N_, int C_, int T_, int... Rs> using RowSpecT = RowSpecG<Re_, N_, C_, C_, T_, Rs...>;

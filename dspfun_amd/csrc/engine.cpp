@@ -1221,6 +1221,32 @@ int execute_masked_accumulate_t(dspfft_plan pl, const R *d_in, R *d_work, R *d_a
 }
 }  // namespace
 
+// out = a(in_a) + b(in_b).  One launch when both are f32 single-pass plans on the same listed row REDFT01 kernel writing the same lines
+// (zoom's x stage: the cosine and the sine part of a shifted cosine series); otherwise a's execution followed by b's accumulating one.
+extern "C" int dspfft_execute_sum2(dspfft_plan pa, dspfft_plan pb, const float *d_in_a, const float *d_in_b, float *d_out, void *stream)
+{
+	if (!pa || !pb || !d_in_a || !d_in_b || !d_out) return fail(-1, "null plan or buffer");
+	if (pa->f64 || pb->f64) return fail(-1, "dspfft_execute_sum2 takes f32 plans");
+	auto one_row = [](const dspfft_plan_s *pl) {
+		if (pl->passes.size() != 1 || !pl->split.empty() || pl->has_block) return false;
+		const Pass &P = pl->passes[0];
+		return P.type == Pass::ROW && P.has_spec && !P.jit && P.hostloop.empty() && pl->kinds[P.axis] == DSPFFT_REDFT01;
+	};
+	if (one_row(pa) && one_row(pb)) {
+		const Pass &A = pa->passes[0], &B = pb->passes[0];
+		const PassGeom &ga = A.spa, &gb = B.spa;
+		if (A.spec.id == B.spec.id && A.spec_nwg == B.spec_nwg && ga.nb0 == gb.nb0 && ga.nb1 == gb.nb1 && ga.sb0_out == gb.sb0_out && ga.sb1_out == gb.sb1_out) {
+			PassArgs a, b;
+			fill_args(a, ga, pa, A, d_in_a, d_out, pa->scale, Fuse());
+			fill_args(b, gb, pb, B, d_in_b, d_out, pb->scale, Fuse());
+			if (int rc = be_launch_row_sum2(A.spec.id, a, b, A.spec_nwg, stream)) return fail(-4, "kernel launch failed (%s, sum of two): backend code %d", A.desc.c_str(), rc);
+			return 0;
+		}
+	}
+	if (int rc = dspfft_execute(pa, d_in_a, d_out, stream)) return rc;
+	return dspfft_execute_masked_accumulate(pb, d_in_b, d_out, d_out, nullptr, 0, 1, stream);
+}
+
 namespace {
 // a planar row pass that can take / produce 8-bit samples itself
 bool pass_has_u8(const Pass &P)

@@ -9,6 +9,7 @@ template <class S, int KIND> struct U8Inst<S, KIND, false> { static constexpr vo
 #define DSP_INST_ROW(N, C, T, ...) \
 	template int launch_row_spec<RowSpec<N, C, T, __VA_ARGS__>, 0>(const PassArgs &, int, void *); \
 	template int launch_row_spec<RowSpec<N, C, T, __VA_ARGS__>, 1>(const PassArgs &, int, void *); \
+	template int launch_row_sum2<RowSpec<N, C, T, __VA_ARGS__>>(const PassArgs &, const PassArgs &, int, void *); \
 	template struct U8Inst<RowSpec<N, C, T, __VA_ARGS__>, 0>; \
 	template struct U8Inst<RowSpec<N, C, T, __VA_ARGS__>, 1>;
 DSPFFT_ROW_SPECS(DSP_INST_ROW)

@@ -130,6 +130,37 @@ __global__ void __launch_bounds__(S::T, S::WPE) row_persist_kernel(const typenam
 	}
 }
 
+// ---- out = A(in_a) + B(in_b): two REDFT01 row transforms of the same output line in ONE workgroup (dspfft_execute_sum2) ----
+// zoom's x stage by fast transforms is the sum of a cosine and a sine part (zoom_fft.hip), each a REDFT01 of its own zero-padded input:
+// as two launches the second reads the frame back to add into it; here the first part's line waits in registers (RowSpecG::Hold) while
+// the second runs through the same LDS, and the frame is written once.  Each part keeps its own scale, input window and output sign.
+template <class S>
+__global__ void __launch_bounds__(S::T, 1) row_sum2_kernel(const typename S::PA a, const typename S::PA b)
+{
+	extern __shared__ __attribute__((aligned(32))) unsigned char lds[];
+	typename S::CX *planes = reinterpret_cast<typename S::CX *>(lds);
+	const int tid = threadIdx.x;
+	typename S::template State<KIND_REDFT01> st, st2;
+	long long bin, bout, bin2, bout2;
+	row_base(a, blockIdx.x, bin, bout);
+	row_base(b, blockIdx.x, bin2, bout2);
+	S::template prefetch<KIND_REDFT01>(a, bin, tid, st);
+	S::template prefetch<KIND_REDFT01>(b, bin2, tid, st2);
+	typename S::Hold hold;
+	static_for<0, S::NPH - 1>([&](auto ph) {
+		S::template phase<KIND_REDFT01, ph>(a, planes, bout, tid, st);
+		__syncthreads();
+	});
+	S::template final01_hold<1>(a, planes, bout, tid, hold);
+	__syncthreads();
+	int t = tid; asm volatile("" : "+v"(t));             // keeps the second transform's index arithmetic from being hoisted above the first
+	static_for<0, S::NPH - 1>([&](auto ph) {
+		S::template phase<KIND_REDFT01, ph>(b, planes, bout2, t, st2);
+		__syncthreads();
+	});
+	S::template final01_hold<2>(b, planes, bout2, t, hold);
+}
+
 // the same with 8-bit input (REDFT10) or quantised 8-bit output (REDFT01): planar rows only
 template <class S, int KIND>
 __global__ void __launch_bounds__(S::T, S::WPE) row_spec_u8_kernel(const typename S::PA a, const U8IO io)
@@ -321,6 +352,15 @@ int launch_row_pair(const typename S::PA &a, int npairs, void *stream)
 	static int lds_ok = allow_lds(row_pair_kernel<S, KIND>, S::LDS);
 	if (lds_ok) return lds_ok;
 	hipLaunchKernelGGL((row_pair_kernel<S, KIND>), dim3(npairs), dim3(S::T), S::LDS, (hipStream_t)stream, a);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+template <class S>
+int launch_row_sum2(const typename S::PA &a, const typename S::PA &b, int nwork, void *stream)
+{
+	static int lds_ok = allow_lds(row_sum2_kernel<S>, S::LDS);
+	if (lds_ok) return lds_ok;
+	hipLaunchKernelGGL((row_sum2_kernel<S>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a, b);
 	HIPCHK(hipGetLastError());
 	return 0;
 }

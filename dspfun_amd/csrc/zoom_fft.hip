@@ -266,8 +266,8 @@ extern "C" int dspfft_zoomfft_execute(dspfft_zoomfft z, const float *d_coeffs, d
 		float *dst = z->vw == z->Mx ? d_out : full;
 		// the sine part's window starts at sample Mx - cw + 1: its compact lines are addressed from that many pixels before their start
 		// (samples outside the window are not read)
-		if (dspfft_execute(z->rowsA, AXc, dst, stream)) { snprintf(g_err, sizeof g_err, "x stage: %s", dspfft_last_error()); return -4; }
-		if (z->rowsE && dspfft_execute_masked_accumulate(z->rowsE, EXc - (size_t)(z->Mx - (long long)cw + 1) * 3, dst, dst, nullptr, 0, 1, stream)) {
+		// (one launch that writes the frame once: dspfft_execute_sum2)
+		if (z->rowsE ? dspfft_execute_sum2(z->rowsA, z->rowsE, AXc, EXc - (size_t)(z->Mx - (long long)cw + 1) * 3, dst, stream) : dspfft_execute(z->rowsA, AXc, dst, stream)) {
 			snprintf(g_err, sizeof g_err, "x stage: %s", dspfft_last_error()); return -4;
 		}
 		if (dst != d_out && hipMemcpy2DAsync(d_out, (size_t)z->vw * 3 * sizeof(float), full, (size_t)z->Mx * 3 * sizeof(float), (size_t)z->vw * 3 * sizeof(float), (size_t)z->vh,

@@ -139,6 +139,10 @@ class Plan:
         self._check(run(
             self._h, C.c_void_p(d_in), C.c_void_p(d_work), C.c_void_p(d_acc), C.c_void_p(d_ids or None), frame_id, elems_per_id, C.c_void_p(stream)))
 
+    def execute_sum2(self, other, d_in, d_in_other, d_out, stream=0):
+        """d_out = self(d_in) + other(d_in_other) (dspfft_execute_sum2: one launch for two one-axis row REDFT01 plans on the same kernel)"""
+        self._check(self._lib.dspfft_execute_sum2(self._h, other._h, d_in, d_in_other, d_out, stream or None))
+
     def scan_prepare(self, d_ids=0, elems_per_id=1, stream=0):
         """owner ids that stay the same over a scan's frames: record each column tile's id range so that the fused step skips a tile
         outside the frame without reading its ids (dspfft_plan_scan_prepare); d_ids = 0 forgets"""

@@ -218,6 +218,25 @@ int launch_col_spec(const typename S::PA &a, int nwork, void *)
 	}
 	return 0;
 }
+template <class S>
+int launch_row_sum2(const typename S::PA &a, const typename S::PA &b, int nwork, void *)
+{
+	std::vector<unsigned char> lds(S::LDS + 32);
+	typename S::CX *planes = (typename S::CX *)(((uintptr_t)lds.data() + 31) & ~(uintptr_t)31);
+	for (int wg = 0; wg < nwork; wg++) {
+		std::vector<typename S::template State<KIND_REDFT01>> st(S::T), st2(S::T);
+		std::vector<typename S::Hold> hold(S::T);
+		long long bin, bout, bin2, bout2;
+		row_base(a, wg, bin, bout);
+		row_base(b, wg, bin2, bout2);
+		for (int tid = 0; tid < S::T; tid++) { S::template prefetch<KIND_REDFT01>(a, bin, tid, st[tid]); S::template prefetch<KIND_REDFT01>(b, bin2, tid, st2[tid]); }
+		static_for<0, S::NPH - 1>([&](auto ph) { for (int tid = 0; tid < S::T; tid++) S::template phase<KIND_REDFT01, ph>(a, planes, bout, tid, st[tid]); });
+		for (int tid = 0; tid < S::T; tid++) S::template final01_hold<1>(a, planes, bout, tid, hold[tid]);
+		static_for<0, S::NPH - 1>([&](auto ph) { for (int tid = 0; tid < S::T; tid++) S::template phase<KIND_REDFT01, ph>(b, planes, bout2, tid, st2[tid]); });
+		for (int tid = 0; tid < S::T; tid++) S::template final01_hold<2>(b, planes, bout2, tid, hold[tid]);
+	}
+	return 0;
+}
 template <class S, int KIND>
 int launch_row_spec_u8(const PassArgs &a, const U8IO &io, int nwork, void *)
 {

@@ -1035,6 +1035,16 @@ def test_row_pass_honours_window_and_alternate_with_compact_input_lines():
     pe.execute_masked_accumulate(guard[8:].ctypes.data - lo * c * 4, acc.ctypes.data, acc.ctypes.data)
     sign = np.where(np.arange(N) % 2 == 1, -1.0, 1.0)[None, :, None]
     assert np.abs(acc - (0.5 * want - 0.25 * sign * we)).max() <= 2e-6 * (np.abs(want).max() + np.abs(we).max())
+    # the two parts in ONE launch (dspfft_execute_sum2: the cosine part's line waits in registers, the frame is written once)
+    both = np.full((lines, N, c), np.nan, dtype=np.float32)
+    pa.execute_sum2(pe, compact.ctypes.data, guard[8:].ctypes.data - lo * c * 4, both.ctypes.data)
+    assert np.abs(both - acc).max() <= 1e-6 * (np.abs(want).max() + np.abs(we).max())
+    # ... and where the two plans do not share a row kernel: one execution after the other, same result
+    pc = Plan.guru([(N, c * lines, c * lines)], [(c * lines, 1, 1)], [REDFT01], lib=L).set_scale(0.5)        # a column plan over the transposed data
+    xt = np.ascontiguousarray(full.transpose(1, 0, 2), dtype=np.float32)
+    fb = np.full((N, lines, c), np.nan, dtype=np.float32)
+    pc.execute_sum2(pc, xt.ctypes.data, xt.ctypes.data, fb.ctypes.data)
+    assert np.abs(fb.transpose(1, 0, 2) - want).max() <= 2e-6 * np.abs(want).max()
     # turned off again / a forward plan / a double plan: not honoured
     assert pa.set_input_window(0, 0, 0) is False
     assert Plan.guru([(N, c, c)], [(c, 1, 1), (lines, N * c, N * c)], [REDFT10], lib=L).set_input_window(0, 0, cw) is False
