@@ -243,9 +243,16 @@ struct RowSpecG {
 			else {
 				// dspfft_plan_set_input_window: pixels outside [win_lo, win_hi) are zero by contract and are not read (no branch around the
 				// load, see load_pix_m: they load from a page of zeros).  Folds away in the plain instantiation.
-				const Re *p = a.in + bin + (long long)x * GS;
-				if (a.win_hi > 0 && (x < a.win_lo || x >= a.win_hi)) p = reinterpret_cast<const Re *>(a.zpage);
-				return load_pix<C, Re>(p);
+				// dspfft_plan_set_input_modulation: the sample sits at position px of the line and is multiplied by in_mul[px] on the way in
+				const int px = a.in_rev > 0 ? a.in_rev - x : x;
+				const bool outside = a.win_hi > 0 && (x < a.win_lo || x >= a.win_hi);
+				const Re *p = outside ? reinterpret_cast<const Re *>(a.zpage) : a.in + bin + (long long)px * GS;
+				Pix<C, Re> v = load_pix<C, Re>(p);
+				if (a.in_mul) {
+					const Re m = *(outside ? reinterpret_cast<const Re *>(a.zpage) : reinterpret_cast<const Re *>(a.in_mul) + px);
+					static_for<0, C>([&](auto c) { v.v[c] *= m; });
+				}
+				return v;
 			}
 		};
 		if constexpr (KIND == KIND_REDFT10 && U8_OK) {

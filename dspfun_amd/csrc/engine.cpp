@@ -187,6 +187,8 @@ struct dspfft_plan_s {
 	// dspfft_plan_set_input_window: rows of `win_axis` outside [win_lo, win_hi) are zero by contract (first pass, specialised COL REDFT01)
 	int win_axis = -1, win_lo = 0, win_hi = 0;
 	int alt_axis = -1;         // dspfft_plan_set_output_alternate
+	int mod_axis = -1, mod_rev = 0;          // dspfft_plan_set_input_modulation
+	const void *mod_table = nullptr;
 };
 
 namespace {
@@ -685,6 +687,8 @@ void fill_args(PassArgsT<R> &a, const PassGeom &g, const dspfft_plan_s *pl, cons
 	a.alt_out = (pl->alt_axis == P.axis && pl->alt_axis >= 0) ? 1 : 0;
 	a.win_lo = a.win_hi = 0;
 	if (pl->win_axis == P.axis && P.first && !fz.mask && pl->zpage) { a.win_lo = pl->win_lo; a.win_hi = pl->win_hi; a.zpage = pl->zpage; }
+	a.in_mul = nullptr; a.in_rev = 0;
+	if (pl->mod_axis == P.axis && P.first && !fz.mask && a.win_hi > 0) { a.in_mul = pl->mod_table; a.in_rev = pl->mod_rev; }
 }
 
 // one candidate of the planning-effort-2 search: mean of three launches on the scratch buffer, in milliseconds (<= 0: failed)
@@ -1048,6 +1052,7 @@ extern "C" int dspfft_plan_set_input_window(dspfft_plan pl, int axis, int lo, in
 {
 	if (!pl || axis < 0 || axis >= pl->rank || lo < 0 || hi < lo || hi > pl->n[axis]) return fail(-1, "bad plan / axis / window");
 	pl->win_axis = -1; pl->win_lo = pl->win_hi = 0;
+	pl->mod_axis = -1; pl->mod_table = nullptr; pl->mod_rev = 0;      // a modulation lives on its window
 	if (hi == 0) return 0;
 	if (pl->f64 || pl->passes.empty() || !pl->split.empty() || pl->has_block) return 0;
 	const Pass &P = pl->passes[0];
@@ -1055,6 +1060,21 @@ extern "C" int dspfft_plan_set_input_window(dspfft_plan pl, int axis, int lo, in
 	if (!pl->zpage) { pl->zpage = be_alloc(64); if (pl->zpage) { const char z[64] = {0}; if (be_upload(pl->zpage, z, 64)) { be_free(pl->zpage); pl->zpage = nullptr; } } }
 	if (!pl->zpage) return 0;
 	pl->win_axis = axis; pl->win_lo = lo; pl->win_hi = hi;
+	return 1;
+}
+// Input sample x of `axis` is read from position p = reversed_from > 0 ? reversed_from - x : x of its line and multiplied by d_mul[p]
+// (floats, device memory, kept by the caller) as it is loaded.  Only together with an input window (set it first): samples outside the
+// window stay zero, and with reversed_from every sample inside it must map to a position >= 0.  Honoured (return 1) for f32 plans whose
+// FIRST pass is a listed specialised ROW REDFT01 pass along `axis`; d_mul = NULL turns it off.
+extern "C" int dspfft_plan_set_input_modulation(dspfft_plan pl, int axis, const float *d_mul, int reversed_from)
+{
+	if (!pl || axis < 0 || axis >= pl->rank || reversed_from < 0) return fail(-1, "bad plan / axis / reversal");
+	pl->mod_axis = -1; pl->mod_table = nullptr; pl->mod_rev = 0;
+	if (!d_mul) return 0;
+	if (pl->win_axis != axis || pl->win_hi <= 0) return 0;
+	if (reversed_from > 0 && pl->win_hi - 1 > reversed_from) return fail(-1, "input window [%d, %d) reaches beyond the reversal point %d", pl->win_lo, pl->win_hi, reversed_from);
+	if (pl->passes.empty() || pl->passes[0].type != Pass::ROW) return 0;
+	pl->mod_axis = axis; pl->mod_table = d_mul; pl->mod_rev = reversed_from;
 	return 1;
 }
 // Output sample j of `axis` times (-1)^j, fused into the pass of that axis.  Honoured (return 1) only where it is implemented: f32 plans

@@ -30,10 +30,10 @@ static int allow_lds(K kernel, size_t bytes)
 template <class PA> __device__ inline PA plain_args(const PA &a_)
 {
 	PA a = a_;
-	a.mask = nullptr; a.zflags = nullptr; a.zranges = nullptr; a.accumulate = 0; a.win_lo = a.win_hi = 0; a.alt_out = 0;
+	a.mask = nullptr; a.zflags = nullptr; a.zranges = nullptr; a.accumulate = 0; a.win_lo = a.win_hi = 0; a.alt_out = 0; a.in_mul = nullptr; a.in_rev = 0;
 	return a;
 }
-template <class PA> static inline bool is_plain(const PA &a) { return !a.mask && !a.zflags && !a.accumulate && a.win_hi <= 0 && !a.alt_out; }
+template <class PA> static inline bool is_plain(const PA &a) { return !a.mask && !a.zflags && !a.accumulate && a.win_hi <= 0 && !a.alt_out && !a.in_mul && !a.in_rev; }
 
 template <class S, int KIND, bool PLAIN>
 __global__ void __launch_bounds__(S::T, S::WPE) row_spec_kernel(const typename S::PA a_)

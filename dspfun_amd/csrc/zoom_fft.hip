@@ -10,6 +10,13 @@
 //     out[b] = 1/2 REDFT01_M(A)[b] - (-1)^b 1/2 REDFT01_M(E)[b],   A[n] = C[n] cos(theta n),  E[n'] = C[M - n'] sin(theta (M - n'))
 // (zero where n >= ncomponents): two length-M REDFT01s per axis on the engine's own row / column kernels instead of a dense
 // (len s) x len product -- BASELINE config 3 (1920x1080 -> 7680x4320): 310 GFLOP of MFMA work become about 4.4 GB of streaming.
+// Order of the stages (round 3): y first, on the cw columns the coefficients have, as windowed column passes (the zero-padded rows are
+// neither stored nor read); the sine part's column pass alternates its output sign and accumulates, leaving T = YA - (-1)^j YE.  Then x
+// as ROW passes -- whole lines loaded and stored, instead of column tiles of 32-byte row segments, in the pass that writes the full
+// frame -- and both parts in ONE launch (dspfft_execute_sum2): each reads T through its own window and multiplier table
+// (dspfft_plan_set_input_modulation: T[u] cos(theta u) in place, T[Mx - x] sin(theta (Mx - x)) mirrored), the cosine part's output
+// line waits in registers while the sine part runs through the same LDS, and the frame is written once.  Four launches and one table
+// kernel per frame.  Scaled widths without a listed row kernel keep the first cut (x first, column passes last, below).
 // The offset only enters theta, so an animation's pan (zoom.c:323-340) re-plans nothing.  Other scales, the `centered` basis and
 // viewports wider than M keep the dense product (dspfft_zoom_product, zoom_gemm.hip).
 #include <hip/hip_runtime.h>
@@ -23,13 +30,15 @@ namespace {
 
 thread_local char g_err[256] = "";
 
-// cs[2 n] = cos(theta n), cs[2 n + 1] = sin(theta n), evaluated in double
-__global__ void zf_table_kernel(float *cs, double theta, int n)
+// tables: cos(theta n), sin(theta n), evaluated in double.  both tables of a frame in one launch: y interleaved (cos, sin), x planar (xmod) or interleaved
+__global__ void zf_tables_kernel(float *csy, double thy, int ny, float *csx, double thx, int nx, int x_planar)
 {
-	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ny + nx; i += gridDim.x * blockDim.x) {
 		double s, c;
-		sincos(theta * (double)i, &s, &c);
-		cs[2 * i] = (float)c; cs[2 * i + 1] = (float)s;
+		if (i < ny) { sincos(thy * (double)i, &s, &c); csy[2 * i] = (float)c; csy[2 * i + 1] = (float)s; continue; }
+		const int u = i - ny;
+		sincos(thx * (double)u, &s, &c);
+		if (x_planar) { csx[u] = (float)c; csx[nx + u] = (float)s; } else { csx[2 * u] = (float)c; csx[2 * u + 1] = (float)s; }
 	}
 }
 
@@ -145,6 +154,10 @@ struct dspfft_zoomfft_s {
 	bool xlast;
 	dspfft_plan ycolsA, ycolsE, rowsA, rowsE;
 	bool ywindowed;
+	// ... and without a kernel between the stages: the y stage's sine part adds -(-1)^j YE[j] into the cosine part's result (T, My x cw
+	// pixels), and BOTH row plans read T -- the cosine part T[u] cos(theta u) in place, the sine part T[Mx - x] sin(theta (Mx - x)) mirrored
+	// (dspfft_plan_set_input_modulation), the multiplier tables being the only thing a pan changes
+	bool xmod;
 };
 
 extern "C" const char *dspfft_zoomfft_last_error(void) { return g_err; }
@@ -174,17 +187,23 @@ extern "C" int dspfft_zoomfft_create(dspfft_zoomfft *out, int w, int h, int type
 			const dspfft_iodim xa[2] = {{3, 1, 1}, {vh, (int)(cw * 3), (int)(Mx * 3)}}, xe[2] = {{3, 1, 1}, {vh, (int)((cw - 1) * 3), (int)(Mx * 3)}};
 			const dspfft_iodim yd[1] = {{(int)My, (int)(cw * 3), (int)(cw * 3)}}, yb[1] = {{(int)(cw * 3), 1, 1}};
 			bool ok = !dspfft_plan_guru_r2r(&z->rowsA, 1, xd, 2, xa, k01, 0) && !dspfft_plan_guru_r2r(&z->ycolsA, 1, yd, 1, yb, k01, 0) && !dspfft_plan_guru_r2r(&z->ycolsE, 1, yd, 1, yb, k01, 0);
-			if (ok && cw > 1) ok = !dspfft_plan_guru_r2r(&z->rowsE, 1, xd, 2, xe, k01, 0);
 			ok = ok && dspfft_plan_set_input_window(z->rowsA, 0, 0, (int)cw) == 1;
+			// both row plans on the y stage's result itself?  (the table pointers are set per frame: they live in the caller's work buffer)
+			const float probe = 0.f;
+			const char *em = getenv("DSPFFT_ZOOM_MID");     // "1": keep the kernel between the stages (A/B runs)
+			z->xmod = ok && cw > 1 && !(em && *em == '1') && dspfft_plan_set_output_alternate(z->ycolsE, 0, 1) == 1 && dspfft_plan_set_input_modulation(z->rowsA, 0, &probe, 0) == 1;
+			if (ok && cw > 1) ok = !dspfft_plan_guru_r2r(&z->rowsE, 1, xd, 2, z->xmod ? xa : xe, k01, 0);
 			if (ok && cw > 1) ok = dspfft_plan_set_input_window(z->rowsE, 0, (int)lo, (int)Mx) == 1 && dspfft_plan_set_output_alternate(z->rowsE, 0, 1) == 1;
+			if (ok && z->xmod && dspfft_plan_set_input_modulation(z->rowsE, 0, &probe, (int)Mx) != 1) ok = false;
 			if (ok) {
-				dspfft_plan_set_scale(z->ycolsA, 0.5f); dspfft_plan_set_scale(z->ycolsE, 0.5f);
+				dspfft_plan_set_scale(z->ycolsA, 0.5f); dspfft_plan_set_scale(z->ycolsE, z->xmod ? -0.5f : 0.5f);
 				dspfft_plan_set_scale_f64(z->rowsA, 0.5 / ((double)w * (double)h));
 				if (z->rowsE) dspfft_plan_set_scale_f64(z->rowsE, -0.5 / ((double)w * (double)h));
 				const int wa = dspfft_plan_set_input_window(z->ycolsA, 0, 0, (int)z->ch);
 				const int we = z->ch > 1 ? dspfft_plan_set_input_window(z->ycolsE, 0, (int)(My - (long long)z->ch + 1), (int)My) : 0;
 				z->ywindowed = wa == 1 && (we == 1 || z->ch == 1) && z->ch < (size_t)My;
 				if (!z->ywindowed) { dspfft_plan_set_input_window(z->ycolsA, 0, 0, 0); dspfft_plan_set_input_window(z->ycolsE, 0, 0, 0); }
+				if (!z->xmod) dspfft_plan_set_output_alternate(z->ycolsE, 0, 0);
 				z->xlast = true;
 				*out = z;
 				return 0;
@@ -251,8 +270,7 @@ extern "C" int dspfft_zoomfft_execute(dspfft_zoomfft z, const float *d_coeffs, d
 	const size_t tab = (2 * z->cw + 2 * z->ch + 3) & ~(size_t)3;
 	float *AX = d_work + tab, *EX = AX + (size_t)z->ch * z->Mx * 3;
 	float *AY = EX + (size_t)z->ch * z->Mx * 3, *EY = AY + (size_t)z->My * z->vw * 3;
-	hipLaunchKernelGGL(zf_table_kernel, dim3(32), dim3(256), 0, s, csx, thx, (int)z->cw);
-	hipLaunchKernelGGL(zf_table_kernel, dim3(32), dim3(256), 0, s, csy, thy, (int)z->ch);
+	hipLaunchKernelGGL(zf_tables_kernel, dim3(32), dim3(256), 0, s, csy, thy, (int)z->ch, csx, thx, (int)z->cw, z->xlast && z->xmod ? 1 : 0);
 	if (z->xlast) {
 		const size_t cw = z->cw, yarr = (size_t)z->My * cw * 3;
 		float *AYx = d_work + tab, *EYx = AYx + r4(yarr);
@@ -261,14 +279,24 @@ extern "C" int dspfft_zoomfft_execute(dspfft_zoomfft z, const float *d_coeffs, d
 		if (!z->ywindowed && hipMemsetAsync(AYx, 0, (r4(yarr) + yarr) * sizeof(float), s) != hipSuccess) { snprintf(g_err, sizeof g_err, "memset failed"); return -4; }
 		if (z->ywindowed && z->ch == 1 && hipMemsetAsync(EYx, 0, yarr * sizeof(float), s) != hipSuccess) { snprintf(g_err, sizeof g_err, "memset failed"); return -4; }
 		hipLaunchKernelGGL(zf_prep_y_kernel, dim3(4096), dim3(256), 0, s, AYx, EYx, d_coeffs, csy, z->w, (int)z->ch, (int)cw, (int)z->My);
+		float *dst = z->vw == z->Mx ? d_out : full;
+		if (z->xmod) {
+			// T = YA - (-1)^j YE in AYx (the sine part's column pass alternates, carries the minus in its scale and accumulates); the row plans
+			// read T through their multiplier tables cos(theta_x u) and sin(theta_x u), the sine part mirrored about Mx
+			if (dspfft_execute(z->ycolsA, AYx, AYx, stream) || dspfft_execute_masked_accumulate(z->ycolsE, EYx, EYx, AYx, nullptr, 0, 1, stream)) {
+				snprintf(g_err, sizeof g_err, "y stage: %s", dspfft_last_error()); return -4;
+			}
+			if (dspfft_plan_set_input_modulation(z->rowsA, 0, csx, 0) != 1 || dspfft_plan_set_input_modulation(z->rowsE, 0, csx + cw, (int)z->Mx) != 1 ||
+			    dspfft_execute_sum2(z->rowsA, z->rowsE, AYx, AYx, dst, stream)) { snprintf(g_err, sizeof g_err, "x stage: %s", dspfft_last_error()); return -4; }
+		} else {
 		if (dspfft_execute(z->ycolsA, AYx, AYx, stream) || dspfft_execute(z->ycolsE, EYx, EYx, stream)) { snprintf(g_err, sizeof g_err, "y stage: %s", dspfft_last_error()); return -4; }
 		hipLaunchKernelGGL(zf_mid_x_kernel, dim3(8192), dim3(256), 0, s, AXc, EXc, AYx, EYx, csx, z->vh, (int)cw);
-		float *dst = z->vw == z->Mx ? d_out : full;
 		// the sine part's window starts at sample Mx - cw + 1: its compact lines are addressed from that many pixels before their start
 		// (samples outside the window are not read)
 		// (one launch that writes the frame once: dspfft_execute_sum2)
 		if (z->rowsE ? dspfft_execute_sum2(z->rowsA, z->rowsE, AXc, EXc - (size_t)(z->Mx - (long long)cw + 1) * 3, dst, stream) : dspfft_execute(z->rowsA, AXc, dst, stream)) {
 			snprintf(g_err, sizeof g_err, "x stage: %s", dspfft_last_error()); return -4;
+		}
 		}
 		if (dst != d_out && hipMemcpy2DAsync(d_out, (size_t)z->vw * 3 * sizeof(float), full, (size_t)z->Mx * 3 * sizeof(float), (size_t)z->vw * 3 * sizeof(float), (size_t)z->vh,
 		                                     hipMemcpyDeviceToDevice, s) != hipSuccess) { snprintf(g_err, sizeof g_err, "copy failed"); return -4; }

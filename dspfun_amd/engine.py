@@ -113,6 +113,13 @@ class Plan:
             raise DspfftError(self._lib.dspfft_last_error().decode())
         return bool(rc)
 
+    def set_input_modulation(self, axis, d_mul, reversed_from=0):
+        """dspfft_plan_set_input_modulation (on top of an input window): True when honoured"""
+        rc = self._lib.dspfft_plan_set_input_modulation(self._h, axis, d_mul or None, int(reversed_from))
+        if rc < 0:
+            raise DspfftError(self._lib.dspfft_last_error().decode())
+        return rc == 1
+
     def set_output_alternate(self, axis, on=True):
         """output sample j of `axis` times (-1)^j, fused into that axis's pass; True when the plan honours it"""
         rc = self._lib.dspfft_plan_set_output_alternate(self._h, axis, int(on))

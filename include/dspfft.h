@@ -104,6 +104,12 @@ int dspfft_execute_f64(dspfft_plan plan, const double *d_in, double *d_out, void
  * not even be stored -- and 0 when it does not (nothing changes: the zeros must really be there).  Today: f32 plans whose first pass
  * is a listed specialised column or row REDFT01 pass along `axis`.  lo = hi = 0 turns it off.  Negative: bad arguments. */
 int dspfft_plan_set_input_window(dspfft_plan plan, int axis, int lo, int hi);
+/* On top of an input window (set it first; setting a window again drops this): input sample x of `axis` is taken from position
+ * p = reversed_from > 0 ? reversed_from - x : x of its line and multiplied by d_mul[p] while it is loaded (d_mul: floats in device memory,
+ * kept by the caller, indexed by position).  zoom's x stage reads ONE array twice this way -- T[u] cos(theta u) in its place and
+ * T[M - x] sin(theta (M - x)) mirrored -- instead of having a kernel write both products out.  Returns 1 when honoured (f32 plans whose
+ * first pass is a listed specialised ROW REDFT01 pass along `axis` with a window), 0 when not (nothing changes); d_mul = NULL: off. */
+int dspfft_plan_set_input_modulation(dspfft_plan plan, int axis, const float *d_mul, int reversed_from);
 /* Optional: output sample j of `axis` is multiplied by (-1)^j, fused into that axis's pass (with REDFT01 on index-reversed input this is
  * the sine counterpart of the transform: sum_u D[u] sin(pi (j + 1/2) u / M) = (-1)^j 1/2 REDFT01(E)[j], E[u'] = D[M - u'] -- the second
  * half of zoom's shifted cosine series).  Returns 1 when honoured (f32 plans whose pass along `axis` is a listed specialised column or row REDFT01

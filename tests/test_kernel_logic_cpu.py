@@ -1045,6 +1045,29 @@ def test_row_pass_honours_window_and_alternate_with_compact_input_lines():
     fb = np.full((N, lines, c), np.nan, dtype=np.float32)
     pc.execute_sum2(pc, xt.ctypes.data, xt.ctypes.data, fb.ctypes.data)
     assert np.abs(fb.transpose(1, 0, 2) - want).max() <= 2e-6 * np.abs(want).max()
+    # input modulation: both parts read ONE array T through multiplier tables, the second mirrored about N (zoom's x stage)
+    T = np.ascontiguousarray(ol.synth_f32(6, lines * cw * c).reshape(lines, cw, c) - 0.5, dtype=np.float32)
+    ma, mb = ol.synth_f32(7, cw).astype(np.float32), ol.synth_f32(8, cw).astype(np.float32)
+    fa = np.zeros((lines, N, c)); fa[:, :cw] = T * ma[None, :, None]
+    fb = np.zeros((lines, N, c)); fb[:, lo:] = (T * mb[None, :, None])[:, N - np.arange(lo, N)]          # sample x <- position N - x
+    wa = np.stack([ol.r2r_many(fa[j], [N], [ol.REDFT01], howmany=c, istride=c, idist=1, ostride=c, odist=1, impl="port").reshape(N, c) for j in range(lines)])
+    wb = np.stack([ol.r2r_many(fb[j], [N], [ol.REDFT01], howmany=c, istride=c, idist=1, ostride=c, odist=1, impl="port").reshape(N, c) for j in range(lines)])
+    qa = Plan.guru([(N, c, c)], [(c, 1, 1), (lines, cw * c, N * c)], [REDFT01], lib=L).set_scale(0.5)
+    qb = Plan.guru([(N, c, c)], [(c, 1, 1), (lines, cw * c, N * c)], [REDFT01], lib=L).set_scale(-0.25)
+    assert qa.set_input_modulation(0, ma.ctypes.data) is False                      # no window yet: declined
+    assert qa.set_input_window(0, 0, cw) is True and qa.set_input_modulation(0, ma.ctypes.data) is True
+    assert qb.set_input_window(0, lo, N) is True and qb.set_output_alternate(0) is True and qb.set_input_modulation(0, mb.ctypes.data, N) is True
+    both = np.full((lines, N, c), np.nan, dtype=np.float32)
+    qa.execute_sum2(qb, T.ctypes.data, T.ctypes.data, both.ctypes.data)
+    assert np.abs(both - (0.5 * wa - 0.25 * sign * wb)).max() <= 2e-6 * (np.abs(wa).max() + np.abs(wb).max())
+    with pytest.raises(DspfftError):
+        qa.set_input_modulation(0, ma.ctypes.data, cw - 5)                             # the window reaches beyond the reversal point
+    assert qa.set_input_window(0, 0, cw) is True                                      # setting a window again drops the modulation
+    alone = np.full((lines, N, c), np.nan, dtype=np.float32)
+    qa.execute(T.ctypes.data, alone.ctypes.data)
+    fz = np.zeros((lines, N, c)); fz[:, :cw] = T
+    wz = np.stack([ol.r2r_many(fz[j], [N], [ol.REDFT01], howmany=c, istride=c, idist=1, ostride=c, odist=1, impl="port").reshape(N, c) for j in range(lines)])
+    assert np.abs(alone - 0.5 * wz).max() <= 2e-6 * np.abs(wz).max()
     # turned off again / a forward plan / a double plan: not honoured
     assert pa.set_input_window(0, 0, 0) is False
     assert Plan.guru([(N, c, c)], [(c, 1, 1), (lines, N * c, N * c)], [REDFT10], lib=L).set_input_window(0, 0, cw) is False
