@@ -178,3 +178,34 @@ def test_output_alternate_fused_into_the_column_pass(gpu):
     assert np.abs(acc.cpu().numpy() - (acc0 + (-0.25) * sign * want)).max() <= 1e-5 * np.abs(want).max()
     assert p.set_output_alternate(0, False) is False
     assert Plan.image(1080, 1920, 3, REDFT01).set_output_alternate(1) is False         # the x axis runs as a row pass (and first): not honoured
+
+
+@pytest.mark.parametrize("N,lines,cw", [(640, 7, 160), (7680, 5, 1920), (256, 3, 255)])
+def test_row_window_modulation_and_sum_of_two(gpu, N, lines, cw):
+    """the pieces zoom's x stage is made of, on listed ROW REDFT01 kernels: input window with compact lines, the mirrored modulated read
+    (dspfft_plan_set_input_modulation), the alternating store, and both parts in one launch (dspfft_execute_sum2) against one after the other"""
+    from dspfun_amd import Plan, REDFT01
+    c = 3
+    lo = N - cw + 1
+    T = np.ascontiguousarray(ol.synth_f32(N + cw, lines * cw * c).reshape(lines, cw, c) - 0.5, dtype=np.float32)
+    ma, mb = ol.synth_f32(7, cw).astype(np.float32), ol.synth_f32(8, cw).astype(np.float32)
+    fa = np.zeros((lines, N, c)); fa[:, :cw] = T * ma[None, :, None]
+    fb = np.zeros((lines, N, c)); fb[:, lo:] = (T * mb[None, :, None])[:, N - np.arange(lo, N)]
+    tr = lambda f: np.stack([ol.r2r_many(f[j], [N], [ol.REDFT01], howmany=c, istride=c, idist=1, ostride=c, odist=1, impl="port").reshape(N, c) for j in range(lines)])
+    wa, wb = tr(fa), tr(fb)
+    sign = np.where(np.arange(N) % 2 == 1, -1.0, 1.0)[None, :, None]
+    want = 0.5 * wa - 0.25 * sign * wb
+    qa = Plan.guru([(N, c, c)], [(c, 1, 1), (lines, cw * c, N * c)], [REDFT01]).set_scale(0.5)
+    qb = Plan.guru([(N, c, c)], [(c, 1, 1), (lines, cw * c, N * c)], [REDFT01]).set_scale(-0.25)
+    assert "ROW*" in qa.describe(), qa.describe()
+    dT, dma, dmb = (gpu.from_numpy(a).to("cuda:0") for a in (T, ma, mb))
+    assert qa.set_input_window(0, 0, cw) and qa.set_input_modulation(0, dma.data_ptr())
+    assert qb.set_input_window(0, lo, N) and qb.set_output_alternate(0) and qb.set_input_modulation(0, dmb.data_ptr(), N)
+    both = gpu.full((lines, N, c), float("nan"), dtype=gpu.float32, device="cuda:0")
+    qa.execute_sum2(qb, dT.data_ptr(), dT.data_ptr(), both.data_ptr())
+    seq = gpu.full((lines, N, c), float("nan"), dtype=gpu.float32, device="cuda:0")
+    qa.execute(dT.data_ptr(), seq.data_ptr())
+    qb.execute_masked_accumulate(dT.data_ptr(), seq.data_ptr(), seq.data_ptr())
+    gpu.cuda.synchronize()
+    tol = 1e-5 * (np.abs(wa).max() + np.abs(wb).max())
+    assert np.abs(both.cpu().numpy() - want).max() <= tol and np.abs(seq.cpu().numpy() - want).max() <= tol
