@@ -1263,6 +1263,8 @@ extern "C" int dspfft_execute_sum2(dspfft_plan pa, dspfft_plan pb, const float *
 			return 0;
 		}
 	}
+	// one after the other: b's accumulating execution has no work buffer of its own here, so b must be a one-pass plan
+	if (pb->passes.size() != 1 || pb->has_block) return fail(-2, "dspfft_execute_sum2: the second plan must be a one-pass plan (its result is added in that pass's store)");
 	if (int rc = dspfft_execute(pa, d_in_a, d_out, stream)) return rc;
 	return dspfft_execute_masked_accumulate(pb, d_in_b, d_out, d_out, nullptr, 0, 1, stream);
 }

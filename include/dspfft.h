@@ -118,8 +118,8 @@ int dspfft_plan_set_input_modulation(dspfft_plan plan, int axis, const float *d_
 int dspfft_plan_set_output_alternate(dspfft_plan plan, int axis, int on);
 /* d_out = a(d_in_a) + b(d_in_b): the sum of two plans' results, each with its own scale, input window and output sign.  ONE launch
  * that writes d_out once when both are f32 one-axis plans on the same listed row REDFT01 kernel over the same output lines (zoom's
- * x stage by fast transforms: cosine part + sine part); otherwise dspfft_execute(a) followed by an accumulating execution of b (for
- * which b must not be a multi-pass plan whose work buffer would be d_out).  d_out must not overlap the inputs. */
+ * x stage by fast transforms: cosine part + sine part); otherwise dspfft_execute(a) followed by an accumulating execution of b, for
+ * which b must be a one-pass plan (-2 otherwise).  d_out must not overlap the inputs. */
 int dspfft_execute_sum2(dspfft_plan a, dspfft_plan b, const float *d_in_a, const float *d_in_b, float *d_out, void *hip_stream);
 /* Optional, for owner ids that stay the same over the frames of a scan (every method but box, whose ids are stamped per frame):
  * records the (min, max) owner id of every column tile of `plan`, so that a later dspfft_execute_masked_accumulate with the SAME

@@ -1068,6 +1068,10 @@ def test_row_pass_honours_window_and_alternate_with_compact_input_lines():
     fz = np.zeros((lines, N, c)); fz[:, :cw] = T
     wz = np.stack([ol.r2r_many(fz[j], [N], [ol.REDFT01], howmany=c, istride=c, idist=1, ostride=c, odist=1, impl="port").reshape(N, c) for j in range(lines)])
     assert np.abs(alone - 0.5 * wz).max() <= 2e-6 * np.abs(wz).max()
+    two = Plan.image(8, 16, 3, REDFT01, lib=L)                # two passes: cannot be the accumulating second plan
+    z = np.zeros((8, 16, 3), dtype=np.float32)
+    with pytest.raises(DspfftError, match="one-pass"):
+        two.execute_sum2(two, z.ctypes.data, z.ctypes.data, np.zeros_like(z).ctypes.data)
     # turned off again / a forward plan / a double plan: not honoured
     assert pa.set_input_window(0, 0, 0) is False
     assert Plan.guru([(N, c, c)], [(c, 1, 1), (lines, N * c, N * c)], [REDFT10], lib=L).set_input_window(0, 0, cw) is False
