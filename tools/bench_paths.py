@@ -35,7 +35,7 @@ ms = timeit(lambda: z.frame(4 * w, 4 * h, (4.0, 1.0), (4.0, 1.0), method="fft"),
 # compulsory bytes of the frame: the coefficients in, the 7680x4320x3 frame out
 res["zoom_c3_fft"] = {"ms_per_frame": round(ms, 3), "speedup_over_gemm": round(res["zoom_c3"]["ms_per_frame"] / ms, 2),
                       "algorithmic_GBps": round((w * h * 3 + 16 * w * h * 3) * 4 / ms / 1e6, 1), "frac_of_8TBps": round((w * h * 3 + 16 * w * h * 3) * 4 / ms / 1e6 / 8000, 4),
-                      "note": "dspfft_zoomfft_*: two REDFT01 executions per axis (zoom_fft.hip); moves about 4.4 GB per frame"}
+                      "note": "dspfft_zoomfft_*: two REDFT01 transforms per axis (zoom_fft.hip): y first on the coefficients' columns, x last as one summed row pass; four launches, about 1.1 GB moved per frame"}
 del z
 
 # ---- 8K frame roundtrip (the transform of configs 3 and 4's frame size) ----
