@@ -105,6 +105,7 @@ int be_stream_wait_event(void *stream, void *e);
 // a multiple of the tile width, and the paired row kernel of row spec (N, C); be_find_row_pair returns an id or -1
 bool be_find_half_spec(int N, int inner, SpecInfo *info);
 int be_find_row_pair(int N, int C);
+int be_row_pair_threads(int id);      // the paired kernel may run on another workgroup size than the row spec of the same (N, C)
 int be_launch_col_half(int id, const PassArgs &a, int nwg, void *stream);
 int be_launch_row_pair(int id, const PassArgs &a, int npairs, void *stream);
 

@@ -819,7 +819,7 @@ void build_split(dspfft_plan_s *pl)
 	    PC.type != Pass::COL || !PC.has_spec || !PC.hostloop.empty()) { drop(); return; }
 	char buf[256];
 	PR.pair = true; PR.pair_id = pid;
-	snprintf(buf, sizeof buf, "axis %d: ROW*2 N=%d C=%d row pairs of axis %d, spec#%d threads=%d pairs=%d lds=%zu", ra, PR.pa.N, PR.pa.C, ca, PR.spec.id, PR.spec.nthr, PR.spec_nwg / 2, PR.spec.lds);
+	snprintf(buf, sizeof buf, "axis %d: ROW*2 N=%d C=%d row pairs of axis %d, spec#%d threads=%d pairs=%d lds=%zu", ra, PR.pa.N, PR.pa.C, ca, PR.spec.id, be_row_pair_threads(pid), PR.spec_nwg / 2, PR.spec.lds);
 	PR.desc = buf;
 	// column pass: FFT of length N/2; T stays the table of the full length, W becomes the half length's, H = exp(-2 pi i n / N)
 	const int M = N / 2;

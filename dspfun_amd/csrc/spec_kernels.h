@@ -225,10 +225,16 @@ __global__ void __launch_bounds__(S::T, S::WPE) col_spec_kernel(const typename S
 #ifndef DSP_PAIR_WPE_MAX
 #define DSP_PAIR_WPE_MAX 6
 #endif
+#ifndef DSP_PAIR_WPE_LONG
+#define DSP_PAIR_WPE_LONG 4
+#endif
 template <class S> constexpr int pair_waves_per_simd()
 {
 	const int wgs = (int)((160 * 1024) / S::LDS), w = wgs * S::T / 256;
-	return w < 1 ? 1 : w > DSP_PAIR_WPE_MAX ? DSP_PAIR_WPE_MAX : w;
+	// long planar lines (7680 x 1: two lines of 15-30 samples per thread waiting beside the butterfly registers) need 108-141 registers: at
+	// 5-6 waves per SIMD (80-96) the kernel spilled 104-260 bytes per lane; 4 waves (128) hold the 512-thread kernel's 108-111
+	const int cap = (S::C == 1 && S::N >= 7680) ? DSP_PAIR_WPE_LONG : DSP_PAIR_WPE_MAX;
+	return w < 1 ? 1 : w > cap ? cap : w;
 }
 template <class S, int KIND>
 __global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_kernel(const typename S::PA a)

@@ -82,7 +82,7 @@
 
 // row specs (N, C) that also get the paired kernel
 #define DSPFFT_ROW_PAIR_SPECS(X) \
-	X(7680, 1, 256, 16, 15, 16) \
+	X(7680, 1, 512, 16, 15, 16) /* 512 threads although the plain planar row runs on 256: two waiting lines of 30 samples per thread spilled (260 B per lane at 96 VGPRs, 187 us per 8K plane; 4 waves per SIMD here: 108 VGPRs, plane inverse 200 -> 143 us, fused scan step 301 -> 213) */ \
 	X(3840, 3, 512, 12, 10, 16) \
 	X(7680, 3, 1024, 16, 15, 16) \
 	X(1920, 3, 256, 12, 5, 16) \

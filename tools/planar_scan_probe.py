@@ -1,5 +1,5 @@
 import os, sys, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dspfun_amd import Plan, REDFT10, REDFT01, _lib
 L = _lib.load()
 h, w = 4320, 7680
