@@ -92,6 +92,73 @@ __global__ void __launch_bounds__(S1::T, WAVES) row_seq10_kernel(const typename 
 	});
 }
 
+// the same with the channels in GROUPS: channels 0 and 1 together through two planes (SA: the C = 2 spec: 480-512 butterflies per stage for
+// 512 threads), then channel 2 alone (SB: C = 1) -- 12 barrier phases per line instead of 18, 62 KB of LDS, still two workgroups per CU
+template <class S, int C0, int G, class IN, class OUT>
+__device__ inline void seq_group(const typename S::PA &a, typename S::CX *planes, long long bout, int tid, const IN (&in)[S::PIX_ROUNDS], OUT (&o)[4 * S::K_ROUNDS])
+{
+	typedef typename S::Re Re;
+	typedef typename S::CX CX;
+	constexpr int L = S::L, T = S::T, PL = S::PL, CG = S::C;
+	int t = tid; asm volatile("" : "+v"(t));
+	typename S::template State<KIND_REDFT10> st;
+	static_for<0, S::PIX_ROUNDS>([&](auto i) { static_for<0, CG>([&](auto c) { st.pre[i * CG + c] = in[i].v[C0 + c]; }); });
+	static_for<0, S::NPH - 1>([&](auto ph) {
+		S::template phase<KIND_REDFT10, ph>(a, planes, bout, t, st);
+		__syncthreads();
+	});
+	static_for<0, S::K_ROUNDS>([&](auto ri) {
+		const int k = t + ri * T;
+		if (!((ri + 1) * T <= L / 2 + 1 || k <= L / 2)) return;
+		const int km = k ? L - k : 0;
+		const CX tk = a.T[k];
+		const CX tlk = cmul(cconj(tk), cmk<Re>((Re)0.70710678118654752440, (Re)-0.70710678118654752440));
+		const CX t1 = csqr(csqr(tk));
+		static_for<0, CG>([&](auto c) {
+			const CX zk = planes[c * PL + k];
+			const CX zm = cconj(planes[c * PL + km]);
+			const CX E = cadd(zk, zm);
+			const CX D = cmul_mi(csub(zk, zm));
+			const CX P = cmul(t1, D);
+			const CX wk = cmul(tk, cadd(E, P));
+			const CX wm = cmul(tlk, cconj(csub(E, P)));
+			const Re sc = a.scale;
+			o[ri * 4 + 0].v[C0 + c] = wk.x * (k == 0 ? sc * a.out_scale0 : sc);
+			o[ri * 4 + 1].v[C0 + c] = -wk.y * sc;
+			o[ri * 4 + 2].v[C0 + c] = wm.x * sc;
+			o[ri * 4 + 3].v[C0 + c] = -wm.y * sc;
+		});
+	});
+	__syncthreads();
+}
+template <class SA, class SB, int WAVES>
+__global__ void __launch_bounds__(SA::T, WAVES) row_seq21_kernel(const typename SA::PA a)
+{
+	typedef typename SA::Re Re;
+	constexpr int N = SA::N, L = SA::L, T = SA::T, G = 3;
+	extern __shared__ __attribute__((aligned(32))) unsigned char lds[];
+	typename SA::CX *planes = reinterpret_cast<typename SA::CX *>(lds);
+	const int tid = threadIdx.x;
+	long long bin, bout;
+	row_base(a, blockIdx.x, bin, bout);
+	Pix<G, Re> in[SA::PIX_ROUNDS];
+	static_for<0, SA::PIX_ROUNDS>([&](auto i) {
+		const int x = tid + i * T;
+		if ((i + 1) * T <= N || x < N) in[i] = load_pix<G, Re>(a.in + bin + (long long)x * G);
+	});
+	Pix<G, Re> o[4 * SA::K_ROUNDS];
+	seq_group<SA, 0, G>(a, planes, bout, tid, in, o);
+	seq_group<SB, 2, G>(a, planes, bout, tid, in, o);
+	static_for<0, SA::K_ROUNDS>([&](auto ri) {
+		const int k = tid + ri * T;
+		if (!((ri + 1) * T <= L / 2 + 1 || k <= L / 2)) return;
+		store_pix<G, Re>(a.out + bout + (long long)k * G, o[ri * 4 + 0]);
+		if (k > 0) store_pix<G, Re>(a.out + bout + (long long)(N - k) * G, o[ri * 4 + 1]);
+		if (L - k != k) store_pix<G, Re>(a.out + bout + (long long)(L - k) * G, o[ri * 4 + 2]);
+		if (k > 0 && L + k != N - k) store_pix<G, Re>(a.out + bout + (long long)(L + k) * G, o[ri * 4 + 3]);
+	});
+}
+
 template <class Re> struct Tab { cx<Re> *T, *W; };
 template <class Re> static Tab<Re> make_tables(int N, int L)
 {
@@ -147,6 +214,17 @@ static void bench(const char *name, int H, int nbuf)
 	const float t_il = run(row_k<IL, 0>, IL::T, IL::LDS, c, H, 24, nbuf, NF);
 	const float t_s4 = run(row_seq10_kernel<S1, 3, 4>, S1::T, S1::LDS, c, H, 24, nbuf, NF);
 	const float t_s4p = run(row_seq10_kernel<S1, 3, 4>, S1::T, S1::LDS + 70000, c, H, 24, nbuf, NF);     // one workgroup per CU (extra LDS: two no longer fit 160 KB): what the second one is worth
+	if constexpr (std::is_same<Re, float>::value) {
+		typedef RowSpecT<Re, IL::N, 2, S1::T, 16, 15, 16> S2;
+		typename IL::PA b2 = a; b2.out = o2;
+		CHK(hipMemset(o2, 0, NF * sizeof(Re)));
+		run(row_seq21_kernel<S2, S1, 4>, S2::T, S2::LDS, b2, H, 1, 1, 0);
+		CHK(hipMemcpy(r2.data(), o2, NF * sizeof(Re), hipMemcpyDeviceToHost));
+		double md2 = 0;
+		for (size_t i = 0; i < NF; i++) md2 = fmax(md2, fabs((double)r1[i] - (double)r2[i]));
+		const float t21 = run(row_seq21_kernel<S2, S1, 4>, S2::T, S2::LDS, c, H, 24, nbuf, NF);
+		printf("%s: channels (0, 1) together then 2 (12 phases, %zu B of LDS): %.1f us, max |diff| %.3g\n", name, (size_t)S2::LDS, t21, md2);
+	}
 	const double gb = 2.0 * NF * sizeof(Re) / 1e9;
 	printf("%s REDFT10 in place over %d frames: interleaved (three planes, %d threads) %.1f us = %.2f TB/s | channels in sequence (%d threads, one plane): two per CU %.1f us = %.2f TB/s, one per CU %.1f us | max |diff| %.3g of %.3g\n",
 	       name, nbuf, IL::T, t_il, gb / t_il * 1e3, S1::T, t_s4, gb / t_s4 * 1e3, t_s4p, md, mx);
