@@ -17,6 +17,7 @@ host cores of the same box on a bounded sample; it is a reported baseline, not t
 """
 import argparse
 import json
+import threading
 import os
 import sys
 import time
@@ -169,6 +170,7 @@ def main():
     ap.add_argument("--inverse-order", choices=["columns-first", "rows-first"], default="columns-first", help="axis order of the REDFT01 plan")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-motion", action="store_true", help="skip the motion_c5 object (BASELINE configs[4]: per-frame blocks and the RCCL slab volume)")
+    ap.add_argument("--extras-timeout", type=float, default=300.0, help="N > 1 only: seconds the motion_c5 / scan_c4 objects may take after the headline before the line is printed without them")
     ap.add_argument("--no-scan", action="store_true", help="skip the scan_c4 object (BASELINE configs[3]: channel-sharded progressive reconstruct of an 8K frame)")
     args = ap.parse_args()
 
@@ -343,26 +345,13 @@ def main():
     # N = 2, 4, 8 carries the curve north_star asks for.  Every rank takes part; its own barriers and max-over-ranks timing.
     motion = None
     del frames, ref0
-    if not args.no_motion:
-        torch.cuda.empty_cache()
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        from bench_motion import motion_c5
-        try:
-            motion = motion_c5(torch, dist, dev, rank, world)
-        except Exception as e:          # the headline line must still be printed
-            motion = {"error": f"{type(e).__name__}: {e}"}
+    # On N > 1 ranks the extras below run collectives (RCCL all-to-all, all_gather) that no box of this round could exercise: if one of them
+    # hangs, the headline measured above must still be printed.  A watchdog per rank: past --extras-timeout seconds rank 0 prints the line
+    # with what has finished (the unfinished object says so) and every rank leaves without waiting for the others.
+    extras = {"motion": None, "scan": None, "done": False}
+    finished = threading.Event()
 
-    scan = None
-    if not args.no_scan:
-        torch.cuda.empty_cache()
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        from bench_scan_c4 import scan_c4
-        try:
-            scan = scan_c4(torch, dist, dev, rank, world)
-        except Exception as e:
-            scan = {"error": f"{type(e).__name__}: {e}"}
-
-    if rank == 0:
+    def make_line(motion, scan):
         pixels = args.steps * args.frames * world * H * W
         value = pixels / 1e6 / elapsed
         line = {
@@ -382,16 +371,53 @@ def main():
             line["motion_c5"] = motion
         if scan is not None:
             line["scan_c4"] = scan
+        # a run whose frames no longer equal the input after all the roundtrips did not time the transform: no headline number
+        if not (drift <= DRIFT_BOUND):
+            line["value"] = None
+            line["error"] = f"max_abs_drift_after_all_roundtrips {drift} exceeds {DRIFT_BOUND}"
+        return line
+
+    def watchdog():
+        if finished.wait(args.extras_timeout):
+            return
+        late = {"error": f"not finished {args.extras_timeout} s after the headline (a collective that hangs?); the headline above stands"}
+        if rank == 0:
+            print(json.dumps(make_line(extras["motion"] if extras["motion"] is not None or args.no_motion else late,
+                                       extras["scan"] if extras["scan"] is not None or args.no_scan else late)), flush=True)
+        os._exit(0 if drift <= DRIFT_BOUND else 1)
+
+    if dist is not None and not (args.no_motion and args.no_scan):
+        threading.Thread(target=watchdog, daemon=True).start()
+    if not args.no_motion:
+        torch.cuda.empty_cache()
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from bench_motion import motion_c5
+        try:
+            motion = motion_c5(torch, dist, dev, rank, world)
+        except Exception as e:          # the headline line must still be printed
+            motion = {"error": f"{type(e).__name__}: {e}"}
+        extras["motion"] = motion
+
+    scan = None
+    if not args.no_scan:
+        torch.cuda.empty_cache()
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from bench_scan_c4 import scan_c4
+        try:
+            scan = scan_c4(torch, dist, dev, rank, world)
+        except Exception as e:
+            scan = {"error": f"{type(e).__name__}: {e}"}
+        extras["scan"] = scan
+    finished.set()
+
+    if rank == 0:
+        line = make_line(motion, scan)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
             fw_ = fftw_cpu_baseline()
             # the oracle's port stays THE cpu_baseline object (kind "port"); a real FFTW, when the box has one, is reported beside it
             line["cpu_baseline_fftw"] = fw_ if fw_ is not None else "libfftw3f.so.3 not present on this box"
-        # a run whose frames no longer equal the input after all the roundtrips did not time the transform: no headline number
         bad = not (drift <= DRIFT_BOUND)
-        if bad:
-            line["value"] = None
-            line["error"] = f"max_abs_drift_after_all_roundtrips {drift} exceeds {DRIFT_BOUND}"
         print(json.dumps(line), flush=True)
         status = 1 if bad else 0
     else:
