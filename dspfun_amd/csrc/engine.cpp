@@ -1492,9 +1492,24 @@ static int execute_item(dspfft_plan pl, const void *in, void *out, void *st, boo
 	}
 	return 0;
 }
+// double frames on more than one stream: the 3840 x 3 row pass goes back to one workgroup per line for the batch (backend.h)
+struct ChanLinesGuard {
+	bool on = false;
+	ChanLinesGuard(int count, const dspfft_plan *plans, void *const *streams)
+	{
+		void *first = nullptr; bool have = false;
+		for (int i = 0; streams && i < count && !on; i++) {
+			if (!plans[i] || !plans[i]->f64) continue;
+			if (!have) { first = streams[i]; have = true; } else if (streams[i] != first) on = true;
+		}
+		if (on) g_chan_lines_suspended++;
+	}
+	~ChanLinesGuard() { if (on) g_chan_lines_suspended--; }
+};
 static int execute_many_once(int count, const dspfft_plan *plans, const void *const *d_in, void *const *d_out, void *const *streams,
                              int timed_item, int timed_count, void *const *pass_events)
 {
+	ChanLinesGuard guard(count, plans, streams);
 	int ev = 0;
 	for (int i = 0; i < count; i++) {
 		dspfft_plan pl = plans[i];
