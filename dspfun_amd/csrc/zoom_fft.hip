@@ -252,8 +252,8 @@ extern "C" size_t dspfft_zoomfft_work_floats(dspfft_zoomfft z)
 {
 	if (!z) return 0;
 	const size_t tab = (2 * z->cw + 2 * z->ch + 3) & ~(size_t)3;
-	if (z->xlast)    // tables | AY, EY (My x cw x 3 each) | AX (vh x cw x 3) | EX (vh x (cw - 1) x 3) | full lines when the viewport is narrower than Mx; each rounded up to 16 bytes
-		return tab + 2 * r4((size_t)z->My * z->cw * 3) + r4((size_t)z->vh * z->cw * 3) + r4((size_t)z->vh * (z->cw - 1) * 3) + (z->vw < z->Mx ? (size_t)z->vh * z->Mx * 3 : 0);
+	if (z->xlast)    // tables | AY, EY (My x cw x 3 each) | without input modulation: AX (vh x cw x 3), EX (vh x (cw - 1) x 3) | full lines when the viewport is narrower than Mx; each rounded up to 16 bytes
+		return tab + 2 * r4((size_t)z->My * z->cw * 3) + (z->xmod ? 0 : r4((size_t)z->vh * z->cw * 3) + r4((size_t)z->vh * (z->cw - 1) * 3)) + (z->vw < z->Mx ? (size_t)z->vh * z->Mx * 3 : 0);
 	return tab + (size_t)2 * z->ch * z->Mx * 3 + (size_t)2 * z->My * z->vw * 3;
 }
 
@@ -275,7 +275,7 @@ extern "C" int dspfft_zoomfft_execute(dspfft_zoomfft z, const float *d_coeffs, d
 		const size_t cw = z->cw, yarr = (size_t)z->My * cw * 3;
 		float *AYx = d_work + tab, *EYx = AYx + r4(yarr);
 		float *AXc = EYx + r4(yarr), *EXc = AXc + r4((size_t)z->vh * cw * 3);
-		float *full = EXc + r4((size_t)z->vh * (cw - 1) * 3);
+		float *full = z->xmod ? AXc : EXc + r4((size_t)z->vh * (cw - 1) * 3);
 		if (!z->ywindowed && hipMemsetAsync(AYx, 0, (r4(yarr) + yarr) * sizeof(float), s) != hipSuccess) { snprintf(g_err, sizeof g_err, "memset failed"); return -4; }
 		if (z->ywindowed && z->ch == 1 && hipMemsetAsync(EYx, 0, yarr * sizeof(float), s) != hipSuccess) { snprintf(g_err, sizeof g_err, "memset failed"); return -4; }
 		hipLaunchKernelGGL(zf_prep_y_kernel, dim3(4096), dim3(256), 0, s, AYx, EYx, d_coeffs, csy, z->w, (int)z->ch, (int)cw, (int)z->My);
