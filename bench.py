@@ -88,6 +88,31 @@ def cpu_baseline(max_seconds=30.0):
                       f"(columns transformed in transposed blocks of 16; roundtrip max abs err {max(err1, erra):.1e})"}
 
 
+def scipy_cpu_baseline(max_seconds=10.0):
+    """scipy's pocketfft on the same frame, all host threads -- an INDEPENDENT CPU number beside the port's (never called
+    FFTW, never the oracle).  None when scipy does not import on this box."""
+    try:
+        import numpy as np
+        import scipy
+        import scipy.fft as sf
+    except Exception:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol                      # only for the synthetic frame of SURVEY 8d
+    x = ol.synth_f32(SEED, H * W * C).reshape(H, W, C)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        f = sf.dctn(x, type=2, axes=(0, 1), workers=-1)
+        b = sf.dctn(f, type=3, axes=(0, 1), workers=-1)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el * (reps + 1) / reps > max_seconds or reps >= 32:
+            break
+    err = float(np.abs(b / np.float32(4.0 * W * H) - x).max())
+    return {"value": round(reps * H * W / 1e6 / el, 3), "unit": "Mpixels/s", "cores": os.cpu_count(), "kind": "scipy.fft.dctn (pocketfft), not FFTW",
+            "sample": f"{reps} roundtrip(s) of one 3840x2160x3 f32 frame, scipy {scipy.__version__}, workers=-1 (roundtrip max abs err {err:.1e})"}
+
+
 def fftw_cpu_baseline(max_seconds=20.0):
     """The real FFTW (north_star "next to the FFTW CPU path") when the box has it: dlopen libfftw3f.so.3
     (never our own alias, which has no .3 soname and is not on the loader path), fftwf_plan_many_r2r(FFTW_ESTIMATE) of the 4K
@@ -417,6 +442,8 @@ def main():
             fw_ = fftw_cpu_baseline()
             # the oracle's port stays THE cpu_baseline object (kind "port"); a real FFTW, when the box has one, is reported beside it
             line["cpu_baseline_fftw"] = fw_ if fw_ is not None else "libfftw3f.so.3 not present on this box"
+            sp_ = scipy_cpu_baseline()
+            line["cpu_baseline_scipy"] = sp_ if sp_ is not None else "scipy does not import on this box"
         bad = not (drift <= DRIFT_BOUND)
         print(json.dumps(line), flush=True)
         status = 1 if bad else 0
