@@ -1076,3 +1076,35 @@ def test_row_pass_honours_window_and_alternate_with_compact_input_lines():
     assert pa.set_input_window(0, 0, 0) is False
     assert Plan.guru([(N, c, c)], [(c, 1, 1), (lines, N * c, N * c)], [REDFT10], lib=L).set_input_window(0, 0, cw) is False
     assert Plan.guru([(N, c, c)], [(c, 1, 1), (lines, N * c, N * c)], [REDFT01], lib=L, dtype="f64").set_output_alternate(0) is False
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_row_window_modulation_sum2_random_geometry(seed):
+    """random listed row lengths, windows, line counts and pitches: the sum of a windowed modulated part and a mirrored, alternating one in
+    one launch equals the zero-padded transforms of the port (edge cases: one-sample windows, windows touching either end, one line)"""
+    rng = np.random.default_rng(1000 + seed)
+    L = emul()
+    N = int(rng.choice([256, 512, 640, 720, 800, 960]))
+    c, lines = 3, int(rng.integers(1, 5))
+    cw = int(rng.choice([1, 2, N // 4, N // 2, N - 1]))
+    hi_a = cw
+    lo_b = N - cw + 1 if cw > 1 else N - 1           # the mirrored part's window (lo_b, N) maps to positions [1, N - lo_b]
+    pitch = max(cw, 2) * c + int(rng.integers(0, 3)) * c      # input lines may be further apart than their window (the mirrored part reads position 1 at least)
+    T = np.ascontiguousarray(rng.standard_normal((lines, pitch // c, c)).astype(np.float32))
+    ma, mb = rng.standard_normal(pitch // c).astype(np.float32), rng.standard_normal(pitch // c).astype(np.float32)
+    fa = np.zeros((lines, N, c)); fa[:, :hi_a] = (T * ma[None, :, None])[:, :hi_a]
+    fb = np.zeros((lines, N, c))
+    xs = np.arange(lo_b, N)
+    fb[:, xs] = (T * mb[None, :, None])[:, N - xs]
+    tr = lambda f: np.stack([ol.r2r_many(f[j], [N], [ol.REDFT01], howmany=c, istride=c, idist=1, ostride=c, odist=1, impl="port").reshape(N, c) for j in range(lines)])
+    wa, wb = tr(fa), tr(fb)
+    sign = np.where(np.arange(N) % 2 == 1, -1.0, 1.0)[None, :, None]
+    qa = Plan.guru([(N, c, c)], [(c, 1, 1), (lines, pitch, N * c)], [REDFT01], lib=L).set_scale(0.5)
+    qb = Plan.guru([(N, c, c)], [(c, 1, 1), (lines, pitch, N * c)], [REDFT01], lib=L).set_scale(-0.25)
+    assert "ROW*" in qa.describe(), qa.describe()
+    assert qa.set_input_window(0, 0, hi_a) and qa.set_input_modulation(0, ma.ctypes.data)
+    assert qb.set_input_window(0, lo_b, N) and qb.set_output_alternate(0) and qb.set_input_modulation(0, mb.ctypes.data, N)
+    both = np.full((lines, N, c), np.nan, dtype=np.float32)
+    qa.execute_sum2(qb, T.ctypes.data, T.ctypes.data, both.ctypes.data)
+    want = 0.5 * wa - 0.25 * sign * wb
+    assert np.abs(both - want).max() <= 3e-6 * max(1e-3, np.abs(wa).max() + np.abs(wb).max()), (N, cw, lines, pitch)
