@@ -69,6 +69,42 @@ static void FN(fft_rec)(const FFTPLAN *P, const CPX *in, CPX *out, int n, int s,
 			out[k + 2 * m].re = s0r - s2r; out[k + 2 * m].im = s0i - s2i;
 			out[k + 3 * m].re = s1r - s3i; out[k + 3 * m].im = s1i + s3r;
 		}
+	} else if (p == 3) {
+		/* w_3 = -1/2 - i sqrt(3)/2 */
+		const REAL hs = (REAL)0.86602540378443864676372317075293618L;
+		for (int k = 0; k < m; k++) {
+			CPX a = out[k], b = out[k + m], c = out[k + 2 * m];
+			CPX w1 = tw[(size_t)k * tws], w2 = tw[(size_t)2 * k * tws];
+			REAL br = b.re * w1.re - b.im * w1.im, bi = b.re * w1.im + b.im * w1.re;
+			REAL cr = c.re * w2.re - c.im * w2.im, ci = c.re * w2.im + c.im * w2.re;
+			REAL sr = br + cr, si = bi + ci, dr = (br - cr) * hs, di = (bi - ci) * hs;
+			REAL mr = a.re - (REAL)0.5 * sr, mi = a.im - (REAL)0.5 * si;
+			out[k].re = a.re + sr;         out[k].im = a.im + si;
+			out[k + m].re = mr + di;       out[k + m].im = mi - dr;       /* a + w b' + w^2 c' */
+			out[k + 2 * m].re = mr - di;   out[k + 2 * m].im = mi + dr;
+		}
+	} else if (p == 5) {
+		/* c1 = cos(2 pi/5), c2 = cos(4 pi/5), s1 = sin(2 pi/5), s2 = sin(4 pi/5) */
+		const REAL c1 = (REAL)0.30901699437494742410229341718281906L, c2 = (REAL)-0.80901699437494742410229341718281906L;
+		const REAL s1 = (REAL)0.95105651629515357211643933337938214L, s2 = (REAL)0.58778525229247312916870595463907277L;
+		for (int k = 0; k < m; k++) {
+			CPX a = out[k], v[4];
+			for (int q = 1; q < 5; q++) {
+				CPX b = out[k + (size_t)q * m], w = tw[((size_t)q * k * tws)];
+				v[q - 1].re = b.re * w.re - b.im * w.im; v[q - 1].im = b.re * w.im + b.im * w.re;
+			}
+			REAL p1r = v[0].re + v[3].re, p1i = v[0].im + v[3].im, m1r = v[0].re - v[3].re, m1i = v[0].im - v[3].im;
+			REAL p2r = v[1].re + v[2].re, p2i = v[1].im + v[2].im, m2r = v[1].re - v[2].re, m2i = v[1].im - v[2].im;
+			out[k].re = a.re + p1r + p2r; out[k].im = a.im + p1i + p2i;
+			REAL ar = a.re + c1 * p1r + c2 * p2r, ai = a.im + c1 * p1i + c2 * p2i;      /* outputs 1 and 4 */
+			REAL br = s1 * m1r + s2 * m2r, bi = s1 * m1i + s2 * m2i;
+			out[k + m].re = ar + bi;             out[k + m].im = ai - br;                  /* e^{-2 pi i/5}: -i sin terms */
+			out[k + (size_t)4 * m].re = ar - bi; out[k + (size_t)4 * m].im = ai + br;
+			REAL cr = a.re + c2 * p1r + c1 * p2r, ci = a.im + c2 * p1i + c1 * p2i;      /* outputs 2 and 3 */
+			REAL dr = s2 * m1r - s1 * m2r, di = s2 * m1i - s1 * m2i;
+			out[k + (size_t)2 * m].re = cr + di; out[k + (size_t)2 * m].im = ci - dr;
+			out[k + (size_t)3 * m].re = cr - di; out[k + (size_t)3 * m].im = ci + dr;
+		}
 	} else {
 		/* generic odd radix: p-point DFT of the twiddled sub-results, O(p^2) */
 		CPX t[64];
