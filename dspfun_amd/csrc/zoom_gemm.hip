@@ -28,18 +28,20 @@ constexpr int BM = 128, BN = 128;
 // scalar writes) and every lane takes its MFMA operands for four k-steps with ONE ds_read_b128.  The two k-slots of
 // an MFMA need not be adjacent in memory, only the same for A and B: lane half lk owns k = 4 lk .. 4 lk + 3 of each
 // group of eight.  Row pitch BK + 4 floats keeps the b128 accesses of a wave spread over the banks.
-template <int BK>
+// TW = 2: the 128 x 128 tile above.  TW = 1: 64 x 64 (2 x 2 waves of 32 x 32, one MFMA tile each) for products too small to give every CU a
+// 128 x 128 tile (applybasis' partial sums of a 512 x 512 image: 48 workgroups for 256 CUs); half of the threads stage A, the other half B.
+template <int BK, int TW = 2>
 __global__ void __launch_bounds__(256) gemm_nt_f32_mfma(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
                                                         int M, int N, int K, long long lda, long long ldb, long long ldc, int cs,
                                                         long long sa, long long sb, long long sc, float alpha,
                                                         int nb1 = 0, long long sa2 = 0, long long sb2 = 0, long long sc2 = 0)
 {
-	constexpr int PITCH = BK + 4;
+	constexpr int PITCH = BK + 4, BM = 64 * TW, BN = 64 * TW, WT = 32 * TW;      // WT: a wave's square of the tile
 	__shared__ __attribute__((aligned(16))) float As[2][BM][PITCH];
 	__shared__ __attribute__((aligned(16))) float Bs[2][BN][PITCH];
 	constexpr int NV = BK / 8;                               // float4 per thread per operand per K-tile
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const int wm = wave >> 1, wn = wave & 1;                 // 2 x 2 waves, each 64 x 64
+	const int wm = wave >> 1, wn = wave & 1;                 // 2 x 2 waves, each WT x WT
 	const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
 	{	// blockIdx.z = b1 + nb1 * b2: two batch levels (e.g. partial-sum block and colour channel), nb1 = 0: one level
 		const int b2 = nb1 ? (int)blockIdx.z / nb1 : 0, b1 = (int)blockIdx.z - b2 * nb1;
@@ -47,8 +49,9 @@ __global__ void __launch_bounds__(256) gemm_nt_f32_mfma(const float *__restrict_
 	}
 
 	// staging: thread -> (row = tid / 2, k4 = (tid % 2) * 4 + 8 v): float4 along K
-	const int srow = tid >> 1, sk = (tid & 1) * 4;
-	const bool a_ok = bm + srow < M, b_ok = bn + srow < N;
+	const int srow = (tid >> 1) & (BM - 1), sk = (tid & 1) * 4;
+	const bool does_a = TW == 2 || tid < 128, does_b = TW == 2 || tid >= 128;
+	const bool a_ok = does_a && bm + srow < M, b_ok = does_b && bn + srow < N;
 	const float *ap = A + (long long)(bm + srow) * lda + sk;
 	const float *bp = B + (long long)(bn + srow) * ldb + sk;
 	const bool vec = ((lda | ldb | sa | sb | sa2 | sb2) & 3) == 0 && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0;
@@ -71,13 +74,13 @@ __global__ void __launch_bounds__(256) gemm_nt_f32_mfma(const float *__restrict_
 	auto stash = [&](int buf) {
 #pragma unroll
 		for (int v = 0; v < NV; v++) {
-			*reinterpret_cast<float4 *>(&As[buf][srow][sk + 8 * v]) = ra[v];
-			*reinterpret_cast<float4 *>(&Bs[buf][srow][sk + 8 * v]) = rb[v];
+			if (does_a) *reinterpret_cast<float4 *>(&As[buf][srow][sk + 8 * v]) = ra[v];
+			if (does_b) *reinterpret_cast<float4 *>(&Bs[buf][srow][sk + 8 * v]) = rb[v];
 		}
 	};
 
-	f32x16 acc[2][2];
-	for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+	f32x16 acc[TW][TW];
+	for (int i = 0; i < TW; i++) for (int j = 0; j < TW; j++) for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
 	fetch_tile(0);
 	stash(0);
@@ -89,30 +92,31 @@ __global__ void __launch_bounds__(256) gemm_nt_f32_mfma(const float *__restrict_
 		if (kt + 1 < nk) fetch_tile((kt + 1) * BK);
 #pragma unroll
 		for (int g = 0; g < BK / 8; g++) {
-			const float4 a0 = *reinterpret_cast<const float4 *>(&As[cur][wm * 64 + li][8 * g + 4 * lk]);
-			const float4 a1 = *reinterpret_cast<const float4 *>(&As[cur][wm * 64 + 32 + li][8 * g + 4 * lk]);
-			const float4 b0 = *reinterpret_cast<const float4 *>(&Bs[cur][wn * 64 + li][8 * g + 4 * lk]);
-			const float4 b1 = *reinterpret_cast<const float4 *>(&Bs[cur][wn * 64 + 32 + li][8 * g + 4 * lk]);
-			const float a0v[4] = {a0.x, a0.y, a0.z, a0.w}, a1v[4] = {a1.x, a1.y, a1.z, a1.w};
-			const float b0v[4] = {b0.x, b0.y, b0.z, b0.w}, b1v[4] = {b1.x, b1.y, b1.z, b1.w};
+			float av[TW][4], bv[TW][4];
 #pragma unroll
-			for (int s = 0; s < 4; s++) {
-				acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[s], b0v[s], acc[0][0], 0, 0, 0);
-				acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[s], b1v[s], acc[0][1], 0, 0, 0);
-				acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[s], b0v[s], acc[1][0], 0, 0, 0);
-				acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[s], b1v[s], acc[1][1], 0, 0, 0);
+			for (int i = 0; i < TW; i++) {
+				const float4 a = *reinterpret_cast<const float4 *>(&As[cur][wm * WT + 32 * i + li][8 * g + 4 * lk]);
+				const float4 b = *reinterpret_cast<const float4 *>(&Bs[cur][wn * WT + 32 * i + li][8 * g + 4 * lk]);
+				av[i][0] = a.x; av[i][1] = a.y; av[i][2] = a.z; av[i][3] = a.w;
+				bv[i][0] = b.x; bv[i][1] = b.y; bv[i][2] = b.z; bv[i][3] = b.w;
 			}
+#pragma unroll
+			for (int s = 0; s < 4; s++)
+#pragma unroll
+				for (int i = 0; i < TW; i++)
+#pragma unroll
+					for (int j = 0; j < TW; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][s], bv[j][s], acc[i][j], 0, 0, 0);
 		}
 		if (kt + 1 < nk) stash(cur ^ 1);
 		__syncthreads();
 	}
 	// C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-	for (int i = 0; i < 2; i++)
-		for (int j = 0; j < 2; j++) {
-			const int n = bn + wn * 64 + j * 32 + li;
+	for (int i = 0; i < TW; i++)
+		for (int j = 0; j < TW; j++) {
+			const int n = bn + wn * WT + j * 32 + li;
 			if (n >= N) continue;
 			for (int r = 0; r < 16; r++) {
-				const int m = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+				const int m = bm + wm * WT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
 				if (m < M) C[(long long)m * ldc + (long long)n * cs] = alpha * acc[i][j][r];
 			}
 		}
@@ -201,12 +205,27 @@ extern "C" int dspfft_zoom_basis(float *d_basis, int type, double scale_num, dou
 	return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
+// fewer 128 x 128 tiles than the chip has CUs (DSPFFT_GEMM_TILE=128 / 64 forces either)
+static bool small_product(const dim3 &grid128)
+{
+	static const int force = getenv("DSPFFT_GEMM_TILE") ? atoi(getenv("DSPFFT_GEMM_TILE")) : 0;
+	if (force == 128) return false;
+	if (force == 64) return true;
+	return (long long)grid128.x * grid128.y * grid128.z < 256;
+}
+
 extern "C" int dspfft_gemm_nt_f32(const float *A, const float *B, float *C, int M, int N, int K,
                                   long long lda, long long ldb, long long ldc, int cs,
                                   int batch, long long sa, long long sb, long long sc, float alpha, void *stream)
 {
 	if (!A || !B || !C || M < 1 || N < 1 || K < 1 || batch < 1 || cs < 1) { snprintf(g_zerr, sizeof g_zerr, "bad arguments"); return -1; }
 	dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
+	if (small_product(grid)) {
+		dim3 g64((N + 63) / 64, (M + 63) / 64, batch);
+		if (K >= 16) hipLaunchKernelGGL((gemm_nt_f32_mfma<16, 1>), g64, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, cs, sa, sb, sc, alpha, 0, 0ll, 0ll, 0ll);
+		else hipLaunchKernelGGL((gemm_nt_f32_mfma<8, 1>), g64, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, cs, sa, sb, sc, alpha, 0, 0ll, 0ll, 0ll);
+		return hipGetLastError() == hipSuccess ? 0 : -4;
+	}
 	static const int bk = getenv("DSPFFT_GEMM_BK") ? atoi(getenv("DSPFFT_GEMM_BK")) : 8;
 	if (K >= 32 && bk == 32) hipLaunchKernelGGL(gemm_nt_f32_mfma<32>, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, cs, sa, sb, sc, alpha);
 	else if (K >= 16 && bk >= 16) hipLaunchKernelGGL(gemm_nt_f32_mfma<16>, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, cs, sa, sb, sc, alpha);
@@ -219,6 +238,12 @@ static int gemm_nt_f32_batch2(const float *A, const float *B, float *C, int M, i
                               int nb1, long long sa1, long long sb1, long long sc1, int nb2, long long sa2, long long sb2, long long sc2, void *stream)
 {
 	dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, nb1 * nb2);
+	if (small_product(grid)) {
+		dim3 g64((N + 63) / 64, (M + 63) / 64, nb1 * nb2);
+		if (K >= 16) hipLaunchKernelGGL((gemm_nt_f32_mfma<16, 1>), g64, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, 1, sa1, sb1, sc1, 1.f, nb1, sa2, sb2, sc2);
+		else hipLaunchKernelGGL((gemm_nt_f32_mfma<8, 1>), g64, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, 1, sa1, sb1, sc1, 1.f, nb1, sa2, sb2, sc2);
+		return hipGetLastError() == hipSuccess ? 0 : -4;
+	}
 	if (K >= 16) hipLaunchKernelGGL(gemm_nt_f32_mfma<16>, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, 1, sa1, sb1, sc1, 1.f, nb1, sa2, sb2, sc2);
 	else hipLaunchKernelGGL(gemm_nt_f32_mfma<8>, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, 1, sa1, sb1, sc1, 1.f, nb1, sa2, sb2, sc2);
 	return hipGetLastError() == hipSuccess ? 0 : -4;
