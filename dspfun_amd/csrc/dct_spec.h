@@ -444,7 +444,7 @@ struct RowSpecG {
 						return;
 					}
 				}
-				tloop<N, T>(tid, [&](int x) {
+				auto value = [&](int x) {
 					const int n = makhoul_dst(x, N);
 					Pix<C, Re> o;
 					Re sc = (x == 0) ? a.scale * a.out_scale0 : a.scale;
@@ -453,8 +453,27 @@ struct RowSpecG {
 						const Re f = pf[c * (2 * PL) + n];
 						o.v[c] = ((n & 1) ? -f : f) * sc;
 					});
-					store_pix_a<C, Re>(a, bout + (long long)x * GS, o);
-				});
+					return o;
+				};
+				if (a.accumulate) {
+					// sum += image (scan.c:451-459): ALL the old values first, then add and store -- a load issued right before its store
+					// waits for its own data every time (the compiler may not move it above the previous store into the same array)
+					Pix<C, Re> old[PIX_ROUNDS];
+					static_for<0, PIX_ROUNDS>([&](auto i) {
+						const int x = tid + i * T;
+						if ((i + 1) * T <= N || x < N) old[i] = load_pix<C, Re>(a.out + bout + (long long)x * GS);
+					});
+					static_for<0, PIX_ROUNDS>([&](auto i) {
+						const int x = tid + i * T;
+						if ((i + 1) * T <= N || x < N) {
+							Pix<C, Re> o = value(x);
+							static_for<0, C>([&](auto c) { o.v[c] += old[i].v[c]; });
+							store_pix<C, Re>(a.out + bout + (long long)x * GS, o);
+						}
+					});
+				} else {
+					tloop<N, T>(tid, [&](int x) { store_pix<C, Re>(a.out + bout + (long long)x * GS, value(x)); });
+				}
 			}
 		}
 	}
