@@ -223,6 +223,8 @@ struct RowSpecG {
 	template <int KIND> struct State {
 		CX x[LAST_ROUNDS * RL];
 		Re pre[(KIND == KIND_REDFT10 ? (U8_OK && 4 * U8_ROUNDS > PIX_ROUNDS ? 4 * U8_ROUNDS : PIX_ROUNDS) : 4 * K_ROUNDS) * C];
+		CX tw[K_ROUNDS];     // T[k] of this thread's (k, L - k) pairs, fetched with the line: a load at its point of use (REDFT01's phase 0,
+		                     // REDFT10's closing phase) is a full cache round trip in front of every line's arithmetic
 	};
 
 	// issue the global loads of one line into registers (no LDS access, no waiting)
@@ -237,6 +239,10 @@ struct RowSpecG {
 	template <int KIND, bool MASKED, bool FLAGGED, class ST>
 	static DSP_HD void prefetch_m(const PA &a, long long bin, int tid, ST &st, const U8IO *io, const uint8_t *zf, int ch = 0)
 	{
+		static_for<0, K_ROUNDS>([&](auto i) {
+			const int k = tid + i * T;
+			if ((i + 1) * T <= L / 2 + 1 || k <= L / 2) st.tw[i] = a.T[k];
+		});
 		auto ld = [&](int x) {
 			if constexpr (FLAGGED) return load_pix_z<C, Re>(a, zf, x * GS + ch, bin + (long long)x * GS);
 			else if constexpr (MASKED) return load_pix_m<C, true, Re>(a, bin + (long long)x * GS);
@@ -376,7 +382,7 @@ struct RowSpecG {
 				static_for<0, K_ROUNDS>([&](auto i) {
 					const int k = tid + i * T;
 					if ((i + 1) * T <= L / 2 + 1 || k <= L / 2) {
-						const CX tk = a.T[k];
+						const CX tk = st.tw[i];
 						const CX tlk = cmul(cconj(tk), cmk<Re>((Re)0.70710678118654752440, (Re)-0.70710678118654752440));   // T[L-k]
 						const CX t1 = csqr(csqr(tk));                                                      // T[4k]
 						static_for<0, C>([&](auto c) {
@@ -405,7 +411,7 @@ struct RowSpecG {
 					const int k = tid + ri * T;
 					if (!((ri + 1) * T <= L / 2 + 1 || k <= L / 2)) return;
 					const int km = k ? L - k : 0;
-					const CX tk = a.T[k];
+					const CX tk = st.tw[ri];
 					const CX tlk = cmul(cconj(tk), cmk<Re>((Re)0.70710678118654752440, (Re)-0.70710678118654752440));
 					const CX t1 = csqr(csqr(tk));
 					Pix<C, Re> o0, o1, o2, o3;

@@ -263,6 +263,8 @@ __global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_kerne
 		int t = tid; asm volatile("" : "+v"(t));
 		typename S::template State<KIND> w;
 		static_for<0, NPRE>([&](auto i) { w.pre[i] = cur[i]; });
+		// (the twiddles are fetched again per line instead of being carried around the loop: 8 more live registers made the planar kernel spill)
+		static_for<0, S::K_ROUNDS>([&](auto i) { const int k = t + i * S::T; if ((i + 1) * S::T <= S::L / 2 + 1 || k <= S::L / 2) w.tw[i] = a.T[k]; });
 		static_for<0, S::NPH>([&](auto ph) {
 			S::template phase<KIND, ph, decltype(w), true>(a, planes, bout, t, w);
 			__syncthreads();
