@@ -97,15 +97,17 @@ __global__ void zf_final_kernel(float *out, const float *ZA, const float *ZE, in
 // ---- x stage last (rows): y stage inputs straight from the coefficients, then the x stage's compact inputs ----
 // A[v][u] = C[v][u] cos(theta_y v) in rows [0, ch), E[My - v][u] = C[v][u] sin(theta_y v) (v >= 1) in rows (My - ch, My); pitch cw pixels.
 // The other rows are zero: never read when the column plans honour the input window, cleared otherwise.
+template <int VEC>
 __global__ void zf_prep_y_kernel(float *A, float *E, const float *C, const float *cs, int w, int ch, int cw, int My)
 {
-	const size_t rowf = (size_t)cw * 3, total = (size_t)ch * rowf;
+	typedef float vec __attribute__((ext_vector_type(VEC)));
+	const size_t rowf = (size_t)cw * 3, rowv = rowf / VEC, total = (size_t)ch * rowv;
 	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-		const int v = (int)(i / rowf);
-		const size_t f = i - (size_t)v * rowf;
-		const float c = C[(size_t)v * w * 3 + f];
-		A[(size_t)v * rowf + f] = c * cs[2 * v];
-		if (v >= 1) E[(size_t)(My - v) * rowf + f] = c * cs[2 * v + 1];
+		const int v = (int)(i / rowv);
+		const size_t f = (i - (size_t)v * rowv) * VEC;
+		const vec c = *reinterpret_cast<const vec *>(C + (size_t)v * w * 3 + f);
+		*reinterpret_cast<vec *>(A + (size_t)v * rowf + f) = c * cs[2 * v];
+		if (v >= 1) *reinterpret_cast<vec *>(E + (size_t)(My - v) * rowf + f) = c * cs[2 * v + 1];
 	}
 }
 // T[j][u] = YA[j][u] - (-1)^j YE[j][u] (the 1/2 is the column plans' scale), j < vh, u < cw; then the x stage's inputs WITHOUT their zeros:
@@ -278,7 +280,11 @@ extern "C" int dspfft_zoomfft_execute(dspfft_zoomfft z, const float *d_coeffs, d
 		float *full = z->xmod ? AXc : EXc + r4((size_t)z->vh * (cw - 1) * 3);
 		if (!z->ywindowed && hipMemsetAsync(AYx, 0, (r4(yarr) + yarr) * sizeof(float), s) != hipSuccess) { snprintf(g_err, sizeof g_err, "memset failed"); return -4; }
 		if (z->ywindowed && z->ch == 1 && hipMemsetAsync(EYx, 0, yarr * sizeof(float), s) != hipSuccess) { snprintf(g_err, sizeof g_err, "memset failed"); return -4; }
-		hipLaunchKernelGGL(zf_prep_y_kernel, dim3(4096), dim3(256), 0, s, AYx, EYx, d_coeffs, csy, z->w, (int)z->ch, (int)cw, (int)z->My);
+		// float4 lanes when every row of the three arrays starts on 16 bytes
+		if ((cw * 3) % 4 == 0 && ((size_t)z->w * 3) % 4 == 0 && !(15u & (uintptr_t)d_coeffs))
+			hipLaunchKernelGGL(zf_prep_y_kernel<4>, dim3(4096), dim3(256), 0, s, AYx, EYx, d_coeffs, csy, z->w, (int)z->ch, (int)cw, (int)z->My);
+		else
+			hipLaunchKernelGGL(zf_prep_y_kernel<1>, dim3(4096), dim3(256), 0, s, AYx, EYx, d_coeffs, csy, z->w, (int)z->ch, (int)cw, (int)z->My);
 		float *dst = z->vw == z->Mx ? d_out : full;
 		if (z->xmod) {
 			// T = YA - (-1)^j YE in AYx (the sine part's column pass alternates, carries the minus in its scale and accumulates); the row plans
