@@ -640,10 +640,19 @@ struct ColSpecT {
 					const long long p = bin + VW * jp;
 					if (win) {
 						// rows outside the window are zero by contract: load the zero page instead (no branch around the loads, see load_pix_m)
-						const V *pk = (k >= a.win_lo && k < a.win_hi) ? reinterpret_cast<const V *>(a.in + p + (long long)k * a.es_in) : reinterpret_cast<const V *>(a.zpage);
-						const V *pm = (km >= a.win_lo && km < a.win_hi) ? reinterpret_cast<const V *>(a.in + p + (long long)km * a.es_in) : reinterpret_cast<const V *>(a.zpage);
-						st.pre[2 * i] = g_get(*pk);
-						st.pre[2 * i + 1] = g_get(*pm);
+						// dspfft_plan_set_input_modulation: row k sits at row pk = in_rev - k (or k) of the array and is multiplied by in_mul[pk]
+						const bool ik = k >= a.win_lo && k < a.win_hi, im = km >= a.win_lo && km < a.win_hi;
+						const int qk = a.in_rev > 0 ? a.in_rev - k : k, qm = a.in_rev > 0 ? a.in_rev - km : km;
+						const V *pk = ik ? reinterpret_cast<const V *>(a.in + p + (long long)qk * a.es_in) : reinterpret_cast<const V *>(a.zpage);
+						const V *pm = im ? reinterpret_cast<const V *>(a.in + p + (long long)qm * a.es_in) : reinterpret_cast<const V *>(a.zpage);
+						LC vk = g_get(*pk), vm = g_get(*pm);
+						if (a.in_mul) {
+							const Re mk = *(ik ? reinterpret_cast<const Re *>(a.in_mul) + qk : reinterpret_cast<const Re *>(a.zpage));
+							const Re mm = *(im ? reinterpret_cast<const Re *>(a.in_mul) + qm : reinterpret_cast<const Re *>(a.zpage));
+							vk = lscale(vk, mk); vm = lscale(vm, mm);
+						}
+						st.pre[2 * i] = vk;
+						st.pre[2 * i + 1] = vm;
 					} else {
 						st.pre[2 * i] = g_get(loadv_m<MASKED, Re>(a, p + (long long)k * a.es_in, hit));
 						st.pre[2 * i + 1] = g_get(loadv_m<MASKED, Re>(a, p + (long long)km * a.es_in, hit));

@@ -1065,7 +1065,7 @@ extern "C" int dspfft_plan_set_input_window(dspfft_plan pl, int axis, int lo, in
 // Input sample x of `axis` is read from position p = reversed_from > 0 ? reversed_from - x : x of its line and multiplied by d_mul[p]
 // (floats, device memory, kept by the caller) as it is loaded.  Only together with an input window (set it first): samples outside the
 // window stay zero, and with reversed_from every sample inside it must map to a position >= 0.  Honoured (return 1) for f32 plans whose
-// FIRST pass is a listed specialised ROW REDFT01 pass along `axis`; d_mul = NULL turns it off.
+// FIRST pass is a listed specialised ROW or COL REDFT01 pass along `axis`; d_mul = NULL turns it off.
 extern "C" int dspfft_plan_set_input_modulation(dspfft_plan pl, int axis, const float *d_mul, int reversed_from)
 {
 	if (!pl || axis < 0 || axis >= pl->rank || reversed_from < 0) return fail(-1, "bad plan / axis / reversal");
@@ -1073,7 +1073,7 @@ extern "C" int dspfft_plan_set_input_modulation(dspfft_plan pl, int axis, const 
 	if (!d_mul) return 0;
 	if (pl->win_axis != axis || pl->win_hi <= 0) return 0;
 	if (reversed_from > 0 && pl->win_hi - 1 > reversed_from) return fail(-1, "input window [%d, %d) reaches beyond the reversal point %d", pl->win_lo, pl->win_hi, reversed_from);
-	if (pl->passes.empty() || pl->passes[0].type != Pass::ROW) return 0;
+	if (pl->passes.empty() || (pl->passes[0].type != Pass::ROW && pl->passes[0].type != Pass::COL)) return 0;
 	pl->mod_axis = axis; pl->mod_table = d_mul; pl->mod_rev = reversed_from;
 	return 1;
 }

@@ -15,7 +15,8 @@
 // as ROW passes -- whole lines loaded and stored, instead of column tiles of 32-byte row segments, in the pass that writes the full
 // frame -- and both parts in ONE launch (dspfft_execute_sum2): each reads T through its own window and multiplier table
 // (dspfft_plan_set_input_modulation: T[u] cos(theta u) in place, T[Mx - x] sin(theta (Mx - x)) mirrored), the cosine part's output
-// line waits in registers while the sine part runs through the same LDS, and the frame is written once.  Four launches and one table
+// line waits in registers while the sine part runs through the same LDS, and the frame is written once.  The y stage's column plans
+// read the coefficients themselves the same way (window + per-row multiplier + mirror): three transform launches and one table
 // kernel per frame.  Scaled widths without a listed row kernel keep the first cut (x first, column passes last, below).
 // The offset only enters theta, so an animation's pan (zoom.c:323-340) re-plans nothing.  Other scales, the `centered` basis and
 // viewports wider than M keep the dense product (dspfft_zoom_product, zoom_gemm.hip).
@@ -31,11 +32,15 @@ namespace {
 thread_local char g_err[256] = "";
 
 // tables: cos(theta n), sin(theta n), evaluated in double.  both tables of a frame in one launch: y interleaved (cos, sin), x planar (xmod) or interleaved
-__global__ void zf_tables_kernel(float *csy, double thy, int ny, float *csx, double thx, int nx, int x_planar)
+__global__ void zf_tables_kernel(float *csy, double thy, int ny, float *csx, double thx, int nx, int x_planar, int y_planar)
 {
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ny + nx; i += gridDim.x * blockDim.x) {
 		double s, c;
-		if (i < ny) { sincos(thy * (double)i, &s, &c); csy[2 * i] = (float)c; csy[2 * i + 1] = (float)s; continue; }
+		if (i < ny) {
+			sincos(thy * (double)i, &s, &c);
+			if (y_planar) { csy[i] = (float)c; csy[ny + i] = (float)s; } else { csy[2 * i] = (float)c; csy[2 * i + 1] = (float)s; }
+			continue;
+		}
 		const int u = i - ny;
 		sincos(thx * (double)u, &s, &c);
 		if (x_planar) { csx[u] = (float)c; csx[nx + u] = (float)s; } else { csx[2 * u] = (float)c; csx[2 * u + 1] = (float)s; }
@@ -160,6 +165,7 @@ struct dspfft_zoomfft_s {
 	// pixels), and BOTH row plans read T -- the cosine part T[u] cos(theta u) in place, the sine part T[Mx - x] sin(theta (Mx - x)) mirrored
 	// (dspfft_plan_set_input_modulation), the multiplier tables being the only thing a pan changes
 	bool xmod;
+	bool ymod;                     // the y stage's column plans read the coefficients directly (window + modulation + mirror): no input kernel
 };
 
 extern "C" const char *dspfft_zoomfft_last_error(void) { return g_err; }
@@ -177,7 +183,7 @@ extern "C" int dspfft_zoomfft_create(dspfft_zoomfft *out, int w, int h, int type
 	z->cw = dspfft_zoom_ncomponents(xnum, xden, (size_t)w); z->ch = dspfft_zoom_ncomponents(ynum, yden, (size_t)h);
 	z->sx = xnum / xden; z->sy = ynum / yden;
 	z->rows = z->colsA = z->colsE = z->ycolsA = z->ycolsE = z->rowsA = z->rowsE = nullptr;
-	z->xlast = false; z->ywindowed = false;
+	z->xlast = false; z->ywindowed = false; z->xmod = false; z->ymod = false;
 	const int k01[1] = {DSPFFT_REDFT01};
 	{
 		// x stage last: rows of Mx RGB pixels read from compact lines (cw resp. cw - 1 pixels: only the window is ever read), written
@@ -206,6 +212,27 @@ extern "C" int dspfft_zoomfft_create(dspfft_zoomfft *out, int w, int h, int type
 				z->ywindowed = wa == 1 && (we == 1 || z->ch == 1) && z->ch < (size_t)My;
 				if (!z->ywindowed) { dspfft_plan_set_input_window(z->ycolsA, 0, 0, 0); dspfft_plan_set_input_window(z->ycolsE, 0, 0, 0); }
 				if (!z->xmod) dspfft_plan_set_output_alternate(z->ycolsE, 0, 0);
+				// ... and no kernel in front of the y stage either: its two column plans read the coefficients themselves (rows w pixels
+				// apart), the cosine part C[v] cos(theta_y v) in place, the sine part C[My - y] sin(theta_y (My - y)) mirrored
+				z->ymod = false;
+				const char *ep = getenv("DSPFFT_ZOOM_PREP");       // "1": keep the kernel that writes the y stage's inputs (A/B runs)
+				if (z->xmod && z->ywindowed && z->ch > 1 && !(ep && *ep == '1') && My * (long long)w * 3 < (1ll << 31)) {
+					const dspfft_iodim ydd[1] = {{(int)My, w * 3, (int)(cw * 3)}};
+					dspfft_plan da = nullptr, de = nullptr;
+					bool yok = !dspfft_plan_guru_r2r(&da, 1, ydd, 1, yb, k01, 0) && !dspfft_plan_guru_r2r(&de, 1, ydd, 1, yb, k01, 0);
+					yok = yok && dspfft_plan_set_input_window(da, 0, 0, (int)z->ch) == 1 && dspfft_plan_set_input_modulation(da, 0, &probe, 0) == 1;
+					yok = yok && dspfft_plan_set_input_window(de, 0, (int)(My - (long long)z->ch + 1), (int)My) == 1 && dspfft_plan_set_input_modulation(de, 0, &probe, (int)My) == 1 &&
+					      dspfft_plan_set_output_alternate(de, 0, 1) == 1;
+					if (yok) {
+						dspfft_destroy_plan(z->ycolsA); dspfft_destroy_plan(z->ycolsE);
+						z->ycolsA = da; z->ycolsE = de;
+						dspfft_plan_set_scale(z->ycolsA, 0.5f); dspfft_plan_set_scale(z->ycolsE, -0.5f);
+						z->ymod = true;
+					} else {
+						if (da) dspfft_destroy_plan(da);
+						if (de) dspfft_destroy_plan(de);
+					}
+				}
 				z->xlast = true;
 				*out = z;
 				return 0;
@@ -263,6 +290,7 @@ extern "C" int dspfft_zoomfft_execute(dspfft_zoomfft z, const float *d_coeffs, d
 {
 	if (!z || !d_coeffs || !d_out || !d_work) { snprintf(g_err, sizeof g_err, "bad arguments"); return -1; }
 	if (15u & ((uintptr_t)d_work | (uintptr_t)d_out)) { snprintf(g_err, sizeof g_err, "d_out and d_work must be 16-byte aligned"); return -1; }
+	if (z->xlast && z->ymod && (15u & (uintptr_t)d_coeffs)) { snprintf(g_err, sizeof g_err, "d_coeffs must be 16-byte aligned (the y stage's column passes read it directly)"); return -1; }
 	hipStream_t s = (hipStream_t)stream;
 	const double pi = 3.14159265358979323846;
 	// zoom.c:49-57: interpolated k = (b + off) / s on length len; native k = b + off on length len s
@@ -272,7 +300,7 @@ extern "C" int dspfft_zoomfft_execute(dspfft_zoomfft z, const float *d_coeffs, d
 	const size_t tab = (2 * z->cw + 2 * z->ch + 3) & ~(size_t)3;
 	float *AX = d_work + tab, *EX = AX + (size_t)z->ch * z->Mx * 3;
 	float *AY = EX + (size_t)z->ch * z->Mx * 3, *EY = AY + (size_t)z->My * z->vw * 3;
-	hipLaunchKernelGGL(zf_tables_kernel, dim3(32), dim3(256), 0, s, csy, thy, (int)z->ch, csx, thx, (int)z->cw, z->xlast && z->xmod ? 1 : 0);
+	hipLaunchKernelGGL(zf_tables_kernel, dim3(32), dim3(256), 0, s, csy, thy, (int)z->ch, csx, thx, (int)z->cw, z->xlast && z->xmod ? 1 : 0, z->xlast && z->ymod ? 1 : 0);
 	if (z->xlast) {
 		const size_t cw = z->cw, yarr = (size_t)z->My * cw * 3;
 		float *AYx = d_work + tab, *EYx = AYx + r4(yarr);
@@ -280,6 +308,13 @@ extern "C" int dspfft_zoomfft_execute(dspfft_zoomfft z, const float *d_coeffs, d
 		float *full = z->xmod ? AXc : EXc + r4((size_t)z->vh * (cw - 1) * 3);
 		if (!z->ywindowed && hipMemsetAsync(AYx, 0, (r4(yarr) + yarr) * sizeof(float), s) != hipSuccess) { snprintf(g_err, sizeof g_err, "memset failed"); return -4; }
 		if (z->ywindowed && z->ch == 1 && hipMemsetAsync(EYx, 0, yarr * sizeof(float), s) != hipSuccess) { snprintf(g_err, sizeof g_err, "memset failed"); return -4; }
+		if (z->ymod) {
+			// T = 1/2 REDFT01(C cos) - (-1)^j 1/2 REDFT01(mirrored C sin), both column plans reading d_coeffs, into AYx
+			if (dspfft_plan_set_input_modulation(z->ycolsA, 0, csy, 0) != 1 || dspfft_plan_set_input_modulation(z->ycolsE, 0, csy + z->ch, (int)z->My) != 1 ||
+			    dspfft_execute(z->ycolsA, d_coeffs, AYx, stream) || dspfft_execute_masked_accumulate(z->ycolsE, d_coeffs, EYx, AYx, nullptr, 0, 1, stream)) {
+				snprintf(g_err, sizeof g_err, "y stage: %s", dspfft_last_error()); return -4;
+			}
+		} else
 		// float4 lanes when every row of the three arrays starts on 16 bytes
 		if ((cw * 3) % 4 == 0 && ((size_t)z->w * 3) % 4 == 0 && !(15u & (uintptr_t)d_coeffs))
 			hipLaunchKernelGGL(zf_prep_y_kernel<4>, dim3(4096), dim3(256), 0, s, AYx, EYx, d_coeffs, csy, z->w, (int)z->ch, (int)cw, (int)z->My);
@@ -289,7 +324,7 @@ extern "C" int dspfft_zoomfft_execute(dspfft_zoomfft z, const float *d_coeffs, d
 		if (z->xmod) {
 			// T = YA - (-1)^j YE in AYx (the sine part's column pass alternates, carries the minus in its scale and accumulates); the row plans
 			// read T through their multiplier tables cos(theta_x u) and sin(theta_x u), the sine part mirrored about Mx
-			if (dspfft_execute(z->ycolsA, AYx, AYx, stream) || dspfft_execute_masked_accumulate(z->ycolsE, EYx, EYx, AYx, nullptr, 0, 1, stream)) {
+			if (!z->ymod && (dspfft_execute(z->ycolsA, AYx, AYx, stream) || dspfft_execute_masked_accumulate(z->ycolsE, EYx, EYx, AYx, nullptr, 0, 1, stream))) {
 				snprintf(g_err, sizeof g_err, "y stage: %s", dspfft_last_error()); return -4;
 			}
 			if (dspfft_plan_set_input_modulation(z->rowsA, 0, csx, 0) != 1 || dspfft_plan_set_input_modulation(z->rowsE, 0, csx + cw, (int)z->Mx) != 1 ||

@@ -108,7 +108,7 @@ int dspfft_plan_set_input_window(dspfft_plan plan, int axis, int lo, int hi);
  * p = reversed_from > 0 ? reversed_from - x : x of its line and multiplied by d_mul[p] while it is loaded (d_mul: floats in device memory,
  * kept by the caller, indexed by position).  zoom's x stage reads ONE array twice this way -- T[u] cos(theta u) in its place and
  * T[M - x] sin(theta (M - x)) mirrored -- instead of having a kernel write both products out.  Returns 1 when honoured (f32 plans whose
- * first pass is a listed specialised ROW REDFT01 pass along `axis` with a window), 0 when not (nothing changes); d_mul = NULL: off. */
+ * first pass is a listed specialised row or column REDFT01 pass along `axis` with a window), 0 when not (nothing changes); d_mul = NULL: off. */
 int dspfft_plan_set_input_modulation(dspfft_plan plan, int axis, const float *d_mul, int reversed_from);
 /* Optional: output sample j of `axis` is multiplied by (-1)^j, fused into that axis's pass (with REDFT01 on index-reversed input this is
  * the sine counterpart of the transform: sum_u D[u] sin(pi (j + 1/2) u / M) = (-1)^j 1/2 REDFT01(E)[j], E[u'] = D[M - u'] -- the second
@@ -337,8 +337,9 @@ const char *dspfft_zoom_last_error(void);
  * re-plans nothing).  Per axis  out[b] = 1/2 REDFT01_M(C[n] cos(theta n))[b] - (-1)^b 1/2 REDFT01_M(C[M - n'] sin(theta (M - n')))[b],
  * theta = pi (offset + (s - 1) / 2) / M (interpolated), pi offset / M (native)  (zoom/zoom.c:49-57): two
  * length-M REDFT01 executions per axis on the row / column kernels instead of the dense product -- BASELINE config 3 (4x of
- * 1920x1080): 310 GFLOP become about 4.4 GB of streaming.  dspfft_zoomfft_create returns -2 when the scale, basis or viewport does
- * not qualify (use dspfft_zoom_product then); d_out (vh x vw x 3) and d_work (dspfft_zoomfft_work_floats floats) 16-byte aligned. */
+ * 1920x1080): 310 GFLOP become about 1 GB of streaming in three transform launches.  dspfft_zoomfft_create returns -2 when the scale,
+ * basis or viewport does not qualify (use dspfft_zoom_product then); d_coeffs, d_out (vh x vw x 3) and d_work
+ * (dspfft_zoomfft_work_floats floats) 16-byte aligned.  One object serves one stream at a time. */
 typedef struct dspfft_zoomfft_s *dspfft_zoomfft;
 int dspfft_zoomfft_create(dspfft_zoomfft *z, int w, int h, int type, double xscale_num, double xscale_den, double yscale_num, double yscale_den,
                           int vw, int vh);

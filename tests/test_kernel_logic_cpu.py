@@ -1108,3 +1108,30 @@ def test_row_window_modulation_sum2_random_geometry(seed):
     qa.execute_sum2(qb, T.ctypes.data, T.ctypes.data, both.ctypes.data)
     want = 0.5 * wa - 0.25 * sign * wb
     assert np.abs(both - want).max() <= 3e-6 * max(1e-3, np.abs(wa).max() + np.abs(wb).max()), (N, cw, lines, pitch)
+
+
+def test_column_pass_honours_modulation_and_mirror():
+    """dspfft_plan_set_input_modulation on a listed COL REDFT01 pass: rows of the window are read from (mirrored) rows of a SHORTER array
+    with another row pitch and multiplied by a per-row table on the way in (zoom's y stage reads the coefficients themselves this way)"""
+    L = emul()
+    N, inner, ch, pitch = 1080, 64, 270, 96
+    C0 = np.ascontiguousarray(ol.synth_f32(21, ch * pitch).reshape(ch, pitch) - 0.5, dtype=np.float32)
+    ma, mb = ol.synth_f32(22, ch).astype(np.float32), ol.synth_f32(23, ch).astype(np.float32)
+    fa = np.zeros((N, inner)); fa[:ch] = C0[:, :inner] * ma[:, None]
+    lo = N - ch + 1
+    fb = np.zeros((N, inner)); ys = np.arange(lo, N); fb[ys] = (C0[:, :inner] * mb[:, None])[N - ys]
+    tr = lambda f: ol.r2r_many(f, [N], [ol.REDFT01], howmany=inner, istride=inner, idist=1, ostride=inner, odist=1, impl="port").reshape(N, inner)
+    wa, wb = tr(fa), tr(fb)
+    pa = Plan.guru([(N, pitch, inner)], [(inner, 1, 1)], [REDFT01], lib=L).set_scale(0.5)
+    pb = Plan.guru([(N, pitch, inner)], [(inner, 1, 1)], [REDFT01], lib=L).set_scale(-0.5)
+    if "COL*" not in pa.describe():
+        pytest.skip("no listed column kernel for this shape in this build")
+    assert pa.set_input_window(0, 0, ch) and pa.set_input_modulation(0, ma.ctypes.data)
+    assert pb.set_input_window(0, lo, N) and pb.set_input_modulation(0, mb.ctypes.data, N) and pb.set_output_alternate(0)
+    out = np.full((N, inner), np.nan, dtype=np.float32)
+    pa.execute(C0.ctypes.data, out.ctypes.data)
+    work = np.zeros((N, inner), dtype=np.float32)
+    pb.execute_masked_accumulate(C0.ctypes.data, work.ctypes.data, out.ctypes.data)
+    sign = np.where(np.arange(N) % 2 == 1, -1.0, 1.0)[:, None]
+    want = 0.5 * wa - 0.5 * sign * wb
+    assert np.abs(out - want).max() <= 3e-6 * (np.abs(wa).max() + np.abs(wb).max())

@@ -209,3 +209,31 @@ def test_row_window_modulation_and_sum_of_two(gpu, N, lines, cw):
     gpu.cuda.synchronize()
     tol = 1e-5 * (np.abs(wa).max() + np.abs(wb).max())
     assert np.abs(both.cpu().numpy() - want).max() <= tol and np.abs(seq.cpu().numpy() - want).max() <= tol
+
+
+@pytest.mark.parametrize("N,inner,ch,pitch", [(1080, 64, 270, 96), (4320, 96, 1079, 5760), (2160, 32, 2, 32)])
+def test_column_window_modulation_and_mirror(gpu, N, inner, ch, pitch):
+    """a listed COL REDFT01 pass reads the rows of its window from (mirrored) rows of a shorter array with another row pitch, times a
+    per-row table (dspfft_plan_set_input_modulation): zoom's y stage on the coefficients themselves"""
+    from dspfun_amd import Plan, REDFT01
+    C0 = np.ascontiguousarray(ol.synth_f32(N + ch, ch * pitch).reshape(ch, pitch) - 0.5, dtype=np.float32)
+    ma, mb = ol.synth_f32(22, ch).astype(np.float32), ol.synth_f32(23, ch).astype(np.float32)
+    fa = np.zeros((N, inner)); fa[:ch] = C0[:, :inner] * ma[:, None]
+    lo = N - ch + 1
+    fb = np.zeros((N, inner)); ys = np.arange(lo, N); fb[ys] = (C0[:, :inner] * mb[:, None])[N - ys]
+    tr = lambda f: ol.r2r_many(f, [N], [ol.REDFT01], howmany=inner, istride=inner, idist=1, ostride=inner, odist=1, impl="port").reshape(N, inner)
+    wa, wb = tr(fa), tr(fb)
+    pa = Plan.guru([(N, pitch, inner)], [(inner, 1, 1)], [REDFT01]).set_scale(0.5)
+    pb = Plan.guru([(N, pitch, inner)], [(inner, 1, 1)], [REDFT01]).set_scale(-0.5)
+    assert "COL*" in pa.describe(), pa.describe()
+    dC, dma, dmb = (gpu.from_numpy(a).to("cuda:0") for a in (C0, ma, mb))
+    assert pa.set_input_window(0, 0, ch) and pa.set_input_modulation(0, dma.data_ptr())
+    assert pb.set_input_window(0, lo, N) and pb.set_input_modulation(0, dmb.data_ptr(), N) and pb.set_output_alternate(0)
+    out = gpu.full((N, inner), float("nan"), dtype=gpu.float32, device="cuda:0")
+    work = gpu.zeros((N, inner), dtype=gpu.float32, device="cuda:0")
+    pa.execute(dC.data_ptr(), out.data_ptr())
+    pb.execute_masked_accumulate(dC.data_ptr(), work.data_ptr(), out.data_ptr())
+    gpu.cuda.synchronize()
+    sign = np.where(np.arange(N) % 2 == 1, -1.0, 1.0)[:, None]
+    want = 0.5 * wa - 0.5 * sign * wb
+    assert np.abs(out.cpu().numpy() - want).max() <= 1e-5 * (np.abs(wa).max() + np.abs(wb).max())
