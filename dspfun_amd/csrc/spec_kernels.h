@@ -163,8 +163,12 @@ __global__ void __launch_bounds__(S::T, 1) row_sum2_kernel(const typename S::PA 
 
 // the same with 8-bit input (REDFT10) or quantised 8-bit output (REDFT01): planar rows only
 template <class S, int KIND>
-__global__ void __launch_bounds__(S::T, S::WPE) row_spec_u8_kernel(const typename S::PA a, const U8IO io)
+__global__ void __launch_bounds__(S::T, S::WPE) row_spec_u8_kernel(const typename S::PA a, const U8IO io_)
 {
+	// this instantiation's 8-bit end is known: the phases' float alternatives (and what merging the two paths cost: a dynamically indexed
+	// copy of the line's samples in scratch behind a full wait for the loads) fold away
+	U8IO io = io_;
+	if constexpr (KIND == KIND_REDFT10) { __builtin_assume(io.in != nullptr); io.out = nullptr; } else { __builtin_assume(io.out != nullptr); io.in = nullptr; }
 	extern __shared__ __attribute__((aligned(32))) unsigned char lds[];
 	typename S::CX *planes = reinterpret_cast<typename S::CX *>(lds);
 	const int tid = threadIdx.x;
