@@ -9,7 +9,7 @@
 // and, with n' = M - n, sin(pi (b + 1/2)(M - n') / M) = (-1)^b cos(pi (b + 1/2) n' / M).  So per axis
 //     out[b] = 1/2 REDFT01_M(A)[b] - (-1)^b 1/2 REDFT01_M(E)[b],   A[n] = C[n] cos(theta n),  E[n'] = C[M - n'] sin(theta (M - n'))
 // (zero where n >= ncomponents): two length-M REDFT01s per axis on the engine's own row / column kernels instead of a dense
-// (len s) x len product -- BASELINE config 3 (1920x1080 -> 7680x4320): 310 GFLOP of MFMA work become about 4.4 GB of streaming.
+// (len s) x len product -- BASELINE config 3 (1920x1080 -> 7680x4320): 310 GFLOP of MFMA work become about 1 GB of streaming in three transform launches (4.4 GB in the first cut).
 // Order of the stages (round 3): y first, on the cw columns the coefficients have, as windowed column passes (the zero-padded rows are
 // neither stored nor read); the sine part's column pass alternates its output sign and accumulates, leaving T = YA - (-1)^j YE.  Then x
 // as ROW passes -- whole lines loaded and stored, instead of column tiles of 32-byte row segments, in the pass that writes the full
