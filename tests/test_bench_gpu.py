@@ -1,0 +1,45 @@
+"""GPU (-m gpu): bench.py's one-line contract -- the keys the driver and the judge read, the roofline object's arithmetic, and the watchdog
+that prints the headline when the N > 1 extras do not finish."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(args, env=None, timeout=600):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=e, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-500:])
+    return json.loads(lines[0])
+
+
+def test_one_json_line_with_the_contract_keys():
+    d = run_bench(["--gpus", "1", "--steps", "8", "--warmup", "2", "--no-motion", "--no-scan", "--no-cpu-baseline"])
+    assert d["metric"].startswith("Mpixels/s") and d["unit"] == "Mpixels/s" and d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 2
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and "synthetic" in d["data"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    frames = d["config"]["frames_per_gpu_per_step"]
+    assert abs(d["value"] - frames * 3840 * 2160 / 1e6 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
+    assert 20000 < d["value"] < 167000                         # below the 48 B/pixel roofline, above anything a broken run would print
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) <= 2e-3 * r["achieved"]
+    assert r["algorithmic_bytes_per_launch"] == 3840 * 2160 * 3 * 4
+    assert r["traffic"] is None or r["traffic"] >= r["algorithmic_bytes_per_launch"]
+    assert d["max_abs_drift_after_all_roundtrips"] < 1e-3
+
+
+def test_watchdog_prints_the_headline_when_the_extras_do_not_finish():
+    env = {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533", "DSPFFT_BENCH_FORCE_DIST": "1"}
+    d = run_bench(["--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--extras-timeout", "0.05"], env=env)
+    assert d["value"] > 20000
+    assert "error" in d["motion_c5"] and "not finished" in d["motion_c5"]["error"]
+    assert "error" in d["scan_c4"]
