@@ -111,10 +111,13 @@
 // Cache, 122-127 -> 101 us over frames in HBM; roundtrip of one frame 341 -> 318 us.  What it costs: the three channel lines of a line
 // write a third of every cache line each and rely on meeting in one L2 -- with a SECOND stream's column pass sharing the L2s the
 // roundtrip of two frames on two streams is 8 % slower (0.76 -> 0.82 ms), so such clips should run on one stream (or DSPFFT_ROW_CHAN=0).
-// Not listed, measured slower: 4096 x 3 doubles (402 MB frame, 0.971 -> 1.005 ms per roundtrip), 7680 x 3 floats (row pass 205 -> 215-219 us
+// 4096 x 3 doubles: a DCI 4K frame (4096 x 2160, 212 MB) 21.7K -> 25.2K Mpix/s per roundtrip (+16 %); a 4096 x 4096 frame (402 MB, HBM)
+// neither gains nor loses (15.5K / 15.7K; an earlier build read -3 %).
+// Not listed, measured slower: 7680 x 3 floats (row pass 205 -> 215-219 us
 // in place over HBM-resident frames), 3840 x 3 floats (46 KB lines, three workgroups per CU already: 46-48 -> 57-61 us).
 #define DSPFFT_ROW_CHAN_SPECS_F64(X) \
-	X(3840, 3, 256, 12, 10, 16)
+	X(3840, 3, 256, 12, 10, 16)      \
+	X(4096, 3, 256, 8, 16, 16)
 
 #define DSPFFT_COL_SPECS_F64(X)      \
 	X(2160, 4, 512, 12, 12, 15)      \

@@ -967,8 +967,8 @@ def test_input_window_is_declined_where_it_is_not_implemented():
         p.set_input_window(0, 10, 5)
 
 
-# ---- channel lines (dct_spec.h RowChanSpecT): interleaved double lines of 3840 pixels run one workgroup per (line, channel) ----
-@pytest.mark.parametrize("w", [3840])
+# ---- channel lines (dct_spec.h RowChanSpecT): interleaved double lines of 3840 / 4096 pixels run one workgroup per (line, channel) ----
+@pytest.mark.parametrize("w", [3840, 4096])
 @pytest.mark.parametrize("h", [10, 3])          # 10: one full group of eight lines + the tail of chan_work; 3: tail only
 def test_f64_channel_lines_match_the_interleaved_kernel_and_the_port(w, h, monkeypatch):
     c = 3
