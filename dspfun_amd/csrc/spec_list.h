@@ -113,6 +113,7 @@
 // roundtrip of two frames on two streams is 8 % slower (0.76 -> 0.82 ms), so such clips should run on one stream (or DSPFFT_ROW_CHAN=0).
 // 4096 x 3 doubles: a DCI 4K frame (4096 x 2160, 212 MB) 21.7K -> 25.2K Mpix/s per roundtrip (+16 %); a 4096 x 4096 frame (402 MB, HBM)
 // neither gains nor loses (15.5K / 15.7K; an earlier build read -3 %).
+// Not listed, measured within 1 %: 2560 x 3 and 1920 x 3 doubles (61 / 46 KB lines: two or three workgroups per CU already).
 // Not listed, measured slower: 7680 x 3 floats (row pass 205 -> 215-219 us
 // in place over HBM-resident frames), 3840 x 3 floats (46 KB lines, three workgroups per CU already: 46-48 -> 57-61 us).
 #define DSPFFT_ROW_CHAN_SPECS_F64(X) \
