@@ -297,7 +297,9 @@ def main():
     # behind the first barrier, 11.6 ms behind any later one -- RCCL still setting itself up in the background): take it here, before
     # the warm-up, so that the barrier which opens the timed region is not the first.
     barrier()
-    preroll = int(os.environ.get("DSPFFT_BENCH_PREROLL", "60"))
+    # (700 steps = 0.4 s: on a box that has just been handed out the first process measured 55.1-56.1K Mpix/s behind 60 untimed steps and
+    # 57.4-57.8K behind 700, `--steps 20 --warmup 5` both times; a second process on the same box 56.4-56.6K against 57.6-57.9K)
+    preroll = int(os.environ.get("DSPFFT_BENCH_PREROLL", "700"))
     if args.warmup < preroll:
         batch.run_repeat(preroll - args.warmup, rejoin)
     batch.run_repeat(args.warmup, rejoin)
