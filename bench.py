@@ -29,7 +29,8 @@ H, W, C = 2160, 3840, 3
 ALG_BYTES_PER_PIXEL = 48.0        # 16 B/sample roundtrip = 48 B/pixel
 HBM_PEAK = 8.0e12                 # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy ceiling)
 SEED = 0xD5F0002
-DRIFT_BOUND = 1e-3                # |frame - input| after every roundtrip of the run (one roundtrip: <= 5e-6, tests/test_gpu_parity.py)
+DRIFT_PER_ROUNDTRIP = 5e-6        # |frame - input| after ONE roundtrip (tests/test_gpu_parity.py pins it); a run's frames have been through
+DRIFT_BOUND = 1e-3                # n in-place roundtrips (untimed + timed): the sanity bound is max(DRIFT_BOUND, n * DRIFT_PER_ROUNDTRIP) -- set in main()
 
 
 def synth_frames(torch, nframes, device):
@@ -320,6 +321,8 @@ def main():
     # sanity of what was timed: after (warmup+steps) consecutive in-place roundtrips the frame is still the input
     # (single-roundtrip accuracy is what tests/test_gpu_parity.py pins: <= 5e-6)
     drift = float((frames[0] - ref0).abs().max())
+    global DRIFT_BOUND
+    DRIFT_BOUND = max(DRIFT_BOUND, (max(preroll, args.warmup) + args.steps) * DRIFT_PER_ROUNDTRIP)     # measured: 8.4e-7 per roundtrip
 
     # roofline object (rank 0): dominant kernel = longest average in-region launch
     roof = None

@@ -34,7 +34,7 @@ def test_one_json_line_with_the_contract_keys():
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) <= 2e-3 * r["achieved"]
     assert r["algorithmic_bytes_per_launch"] == 3840 * 2160 * 3 * 4
     assert r["traffic"] is None or r["traffic"] >= r["algorithmic_bytes_per_launch"]
-    assert d["max_abs_drift_after_all_roundtrips"] < 1e-3
+    assert d["max_abs_drift_after_all_roundtrips"] < 800 * 5e-6          # about 710 in-place roundtrips (untimed + timed), 5e-6 each at most
 
 
 def test_watchdog_prints_the_headline_when_the_extras_do_not_finish():
