@@ -27,9 +27,11 @@
 // pins a float4 in registers HERE: without it the compiler sinks the computation of values that are
 // consumed several barriers later and keeps their (twice as many) inputs alive instead
 #define DSP_PIN4(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
+#define DSP_PIN1(v) asm volatile("" : "+v"(v))
 #else
 #define DSP_SCHED_FENCE() ((void)0)
 #define DSP_PIN4(v) ((void)0)
+#define DSP_PIN1(v) ((void)0)
 #endif
 
 namespace dspfft {

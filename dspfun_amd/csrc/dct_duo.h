@@ -1,0 +1,303 @@
+// dct_duo.h -- ROW passes that carry TWO real signals of a line through ONE set of butterfly phases.
+//
+// The row kernels of dct_spec.h are bound by vector-ALU issue on long lines (7680 x 3: ~1350 VALU instructions per wave and
+// transform, two thirds of them the butterflies' float arithmetic; the LDS and memory phases of the single resident workgroup
+// run beside it, not instead of it).  Where a line needs two transforms of the same length -- zoom's x stage by fast transforms
+// (cosine and sine part, zoom_fft.hip), the two lines of a row pair (outer radix-2 split) -- the two signals ride through the FFT as
+// the halves of a Pk2 (packed FP32: every butterfly instruction is a v_pk_*_f32), i.e. ONE pass at half the instruction count instead
+// of two passes through the same LDS.  A slot is then 16 bytes (re_a, re_b, im_a, im_b), so a 7680-sample signal pair needs 61 KB:
+// the channels of an interleaved line go through the plane one after another and the line's outputs wait in registers, two
+// workgroups per CU.
+//
+// The N/2-point complex FFT of the plane is the column kernels' (ColSpecT with one lane vector per row: NP = 1): stages,
+// digit-reversed last stage, padding, all shared.
+#pragma once
+#include "dct_spec.h"
+
+namespace dspfft {
+
+template <int N_, int T_, int... Rs>
+struct RowDuoT {
+	typedef ColSpecT<float, N_ / 2, 4, T_, Rs...> B;
+	typedef typename B::V V;         // LDS slot: (re_a, re_b, im_a, im_b)
+	typedef typename B::LC LC;       // the slot as one complex number over Pk2
+	static constexpr int N = N_, L = N_ / 2, T = T_, NS = B::NS;
+	static constexpr size_t LDS = B::LDS;
+	static constexpr int K_ROUNDS = (L / 2 + 1 + T - 1) / T;    // (k, L - k) slot pairs per thread
+	static constexpr int X_ROUNDS = (N + T - 1) / T;            // samples of a signal per thread
+	static constexpr int KT = L / 2 + 1;                        // entries of a per-k table
+	static_assert(N_ % 4 == 0, "duo rows need N divisible by 4");
+	struct Regs { LC x[B::LAST_ROUNDS * B::RL]; };
+	static DSP_HD int padded(int p) { return B::padded(p); }
+	// phases 1 .. NS + 1: the L-point forward FFT of the plane, in place (a barrier after each); w.W = exp(-2 pi i t / L)
+	template <int PH> static DSP_HD void fft_phase(const PassArgs &w, V *buf, int tid, Regs &r)
+	{
+		if constexpr (PH < NS) B::template stage<PH - 1>(w, buf, tid);
+		else if constexpr (PH == NS) B::last_read(buf, r, tid);
+		else B::last_write(buf, r, tid);
+	}
+	// after the last phase the plane is in natural order: element n of the two length-N real sequences z[m] = v[2m] + i v[2m+1]
+	static DSP_HD Pk2 sample(const V *buf, int n) { return reinterpret_cast<const Pk2 *>(buf)[n]; }
+};
+
+// =================================================================================================
+// zoom's x stage (zoom/zoom.c:361-368 with the basis of :36-68 on a DCT-III grid, see zoom_fft.hip):
+//     out[j][b][c] = sum_{u < cw} g_u in[j][u][c] cos(u (pi (b + 1/2) / M + theta)),   b < vw <= M,  g_0 = scale / 2, g_u = scale
+// = yc[b] - ys[b] with yc / ys the cosine / sine series of in[u] cos(theta u) / in[u] sin(theta u).  In Makhoul's order
+// (v[j] = y[2j], v[M-1-j] = y[2j+1]) both are real inverse DFTs of length M -- of the Hermitian resp. anti-Hermitian extension of
+// V[u] = in[u] e^{i theta' u}-weighted spectra -- and each of those is an M/2-point complex FFT.  Every FFT input slot is a fixed
+// complex multiple of at most four input pixels:
+//     slot[k], slot[L - k]  <-  in[k], in[L - k], in[L + k], in[M - k]        (L = M / 2, k <= L / 2)
+// with multipliers that depend on (k, theta, scale) only: a table the caller fills per frame (zoomx_table_entry, evaluated in double).
+// cw <= L / 2 (scales >= 4: BASELINE config 3) needs the first source only, cw <= L the first two.
+struct ZoomXArgs {
+	const float *in;       // lines of cw pixels
+	float *out;            // lines of vw pixels
+	const float *tab;      // [NSRC][2][KT] slots of four floats: multiplier of source s for slot k (0) and slot L - k (1), as (re_a, re_b, im_a, im_b)
+	const cf *W;           // exp(-2 pi i t / L), t < L
+	long long in_pitch, out_pitch;    // floats between lines
+	int cw, vw, lines;
+};
+
+// (lo, hi) = what a unit sample at pixel n contributes to slots k and L - k of the (cosine, sine) pair; everything in double.
+// ca = g_n cos(theta n), sb = g_n sin(theta n) (0 for n >= cw).  Written for clarity, not speed: it runs once per frame and table entry.
+struct ZoomXEntry { double lo[4], hi[4]; };    // (re_a, re_b, im_a, im_b)
+// bin q of the length-M spectrum X enters Z[q mod L] as X (1 + i w^k) for q < L and X (1 - i w^k) for q >= L, w = e^{2 pi i / M}
+// (v[2m] + i v[2m+1] = IDFT_L(Z)[m]); the plane holds conj(Z): the forward FFT of the conjugate is the conjugate of the inverse FFT
+DSP_HD void zoomx_accumulate(double *slot, int M, int k, int bin, double xr_a, double xi_a, double xr_b, double xi_b)
+{
+	const int L = M / 2;
+	const double pi = 3.14159265358979323846264338327950288;
+	const double wr = cos(2 * pi * k / M), wi = sin(2 * pi * k / M);
+	const double s = bin < L ? 1.0 : -1.0;
+	const double fr = 1.0 - s * wi, fi = s * wr;          // 1 +- i w^k
+	slot[0] += xr_a * fr - xi_a * fi; slot[2] -= xr_a * fi + xi_a * fr;
+	slot[1] += xr_b * fr - xi_b * fi; slot[3] -= xr_b * fi + xi_b * fr;
+}
+DSP_HD ZoomXEntry zoomx_table_entry(int M, int cw, int k, int src, double theta, double scale)
+{
+	ZoomXEntry e;
+	for (int i = 0; i < 4; i++) e.lo[i] = e.hi[i] = 0.0;
+	const int L = M / 2;
+	const double pi = 3.14159265358979323846264338327950288;
+	const int n = src == 0 ? k : src == 1 ? L - k : src == 2 ? L + k : M - k;
+	// the four sources coincide in pairs at k = 0 (L - k = L + k; M - k is out of range) and at k = L / 2: each pixel counts once
+	if ((src == 2 && k == 0) || (src == 3 && (k == 0 || 2 * k == L)) || (src == 1 && 2 * k == L)) return e;
+	if (n >= cw || n >= M) return e;
+	const double g = (n == 0 ? 0.5 : 1.0) * scale, ca = g * cos(theta * n), sb = g * sin(theta * n);
+	const double er = cos(pi * n / (2.0 * M)), ei = sin(pi * n / (2.0 * M));     // V = (ca | sb) e^{i pi n / 2M}
+	// cosine series: vc = Re IDFT(Vc): X[n] += V / 2, X[M - n] += conj(V) / 2 (X[0] = V).  Sine series: vs = Im IDFT(Vs):
+	// X[n] += V / (2i), X[M - n] -= conj(V) / (2i).  (On the odd outputs v[M-1-j] the sine series comes out negated: the closing phase adds
+	// there instead of subtracting.)
+	for (int which = 0; which < 2; which++) {
+		const int slot_k = which == 0 ? k : L - k;
+		if (which == 1 && (k == 0 || 2 * k == L)) continue;       // slot L does not exist; slot L / 2 is `lo`
+		for (int term = 0; term < 2; term++) {
+			if (n == 0 && term == 1) continue;
+			const int q = term ? M - n : n;
+			if (q % L != slot_k % L) continue;
+			double xr_a, xi_a, xr_b, xi_b;
+			if (n == 0) { xr_a = ca; xi_a = 0; xr_b = 0; xi_b = 0; }
+			else if (term == 0) { xr_a = ca * er / 2; xi_a = ca * ei / 2; xr_b = sb * ei / 2; xi_b = -sb * er / 2; }
+			else { xr_a = ca * er / 2; xi_a = -ca * ei / 2; xr_b = sb * ei / 2; xi_b = sb * er / 2; }
+			zoomx_accumulate(which == 0 ? e.lo : e.hi, M, slot_k, q, xr_a, xi_a, xr_b, xi_b);
+		}
+	}
+	return e;
+}
+
+template <class S, int C, int NSRC>
+struct ZoomXRowsT {
+	typedef typename S::V V;
+	typedef typename S::LC LC;
+	static constexpr int N = S::N, L = S::L, T = S::T, KT = S::KT;
+	static constexpr int NPH = S::NS + 3;                       // per channel: phase 0, the FFT's NS + 1, the closing phase
+	struct State {
+		float px[S::K_ROUNDS * NSRC];                           // the input samples of the channel whose phase 0 comes next (fetched while the previous channel's stages run)
+		float hold[(C > 1 ? C - 1 : 1) * S::X_ROUNDS];          // the line's output samples, all channels but the last (whose closing phase stores the pixels)
+	};
+	static DSP_HD int src_pixel(int s, int k) { return s == 0 ? k : s == 1 ? L - k : s == 2 ? L + k : N - k; }
+	static DSP_HD void load(const ZoomXArgs &a, long long bin, int ch, int tid, State &st)
+	{
+		static_for<0, S::K_ROUNDS>([&](auto i) {
+			const int k = tid + i * T;
+			if ((i + 1) * T <= L / 2 + 1 || k <= L / 2)
+				static_for<0, NSRC>([&](auto s) {
+					// a source beyond the window has a zero multiplier: any valid pixel will do (no branch around the load)
+					int n = src_pixel(s, k);
+					n = n < a.cw ? n : a.cw - 1;
+					st.px[i * NSRC + s] = a.in[bin + (long long)n * C + ch];
+				});
+		});
+	}
+	static DSP_HD void phase0(const ZoomXArgs &a, V *buf, int tid, const State &st)
+	{
+		const V *tab = reinterpret_cast<const V *>(a.tab);
+		static_for<0, S::K_ROUNDS>([&](auto i) {
+			const int k = tid + i * T;
+			if ((i + 1) * T <= L / 2 + 1 || k <= L / 2) {
+				LC lo = S::B::lzero(), hi = S::B::lzero();
+				static_for<0, NSRC>([&](auto s) {
+					const float v = st.px[i * NSRC + s];
+					const LC p = S::B::l_get(tab[(2 * s) * KT + k]), q = S::B::l_get(tab[(2 * s + 1) * KT + k]);
+					lo = cmk<Pk2>(lo.x + p.x * v, lo.y + p.y * v);
+					hi = cmk<Pk2>(hi.x + q.x * v, hi.y + q.y * v);
+				});
+				buf[S::padded(k)] = S::B::l_put(lo);
+				if (k > 0 && 2 * k != L) buf[S::padded(L - k)] = S::B::l_put(hi);
+			}
+		});
+	}
+	// closing phase of channel ch (a run-time value: the kernel walks the channels in a real loop, so that the compiler cannot interleave
+	// them and carry one channel's addresses and twiddles through the next -- 80 -> 176 -> 220 VGPRs for 1 -> 2 -> 3 unrolled channels):
+	// y[x] from the plane, kept in registers (selected into its slot: a register array cannot be indexed by ch); the last channel
+	// stores whole pixels
+	static DSP_HD void finish(const ZoomXArgs &a, const V *buf, long long bout, int ch, int tid, State &st)
+	{
+		static_for<0, S::X_ROUNDS>([&](auto i) {
+			const int x = tid + i * T;
+			if ((i + 1) * T <= N || x < N) {
+				const int n = makhoul_dst(x, N);
+				const Pk2 g = S::sample(buf, n);
+				// plane element n = v[n] for even n, -v[n] for odd n; out = v_cos - v_sin on even samples x, v_cos + v_sin on odd ones
+				const float t = (x & 1) ? g.x + g.y : g.x - g.y;
+				const float y = (n & 1) ? -t : t;
+				if (ch + 1 < C) {
+					static_for<0, C - 1>([&](auto c) { float &h = st.hold[c * S::X_ROUNDS + i]; h = (ch == c) ? y : h; });
+				} else if (x < a.vw) {
+					Pix<C, float> o;
+					// (handed over one by one: read as a Pix straight from the array, the compiler uses a vector load that keeps the array in scratch)
+					static_for<0, C - 1>([&](auto c) { float v = st.hold[c * S::X_ROUNDS + i]; DSP_PIN1(v); o.v[c] = v; });
+					o.v[C - 1] = y;
+					store_pix<C, float>(a.out + bout + (long long)x * C, o);
+				}
+			}
+		});
+	}
+};
+
+// =================================================================================================
+// The same x stage with THREE barrier-separated phases per channel instead of NS + 3 (round 4).  Measured on MI355X, the kernel above is
+// not bound by its arithmetic but by the latency at the head of every phase with two 4-wave workgroups per CU (phase 0 and the closing
+// phase alone -- no butterflies -- take 145 of its 341 us at BASELINE config 3): so fewer, fatter phases.
+//   A  the first DIF stage reads its R0 slots straight from global memory (slot = table x pixel, as phase 0 computed it) -- no phase 0,
+//      no LDS round trip in front of the first butterfly;
+//   B  the middle stages, in place (ColSpecT::stage);
+//   C  the last stage keeps its outputs in registers: thread kb holds FFT outputs j = kb + NBL r.  Output j carries samples x = 4j, 4j + 2
+//      (j < L/2) resp. 4j' + 3, 4j' + 1 (j' = L - 1 - j); the partner slot L - 1 - j = (NBL - 1 - kb) + NBL (RL - 1 - r) belongs to thread
+//      NBL - 1 - kb, which the lane map puts on the mirror lane (63 - lane) of the same wave: ONE cross-lane exchange per slot
+//      (ds_bpermute, no LDS round trip, no barrier) leaves every thread with pixel PAIRS (4j, 4j + 1) | (4j + 2, 4j + 3), and the wave's
+//      store of slot index i is one contiguous run of 32 x 48 bytes.
+// Needs T = NBL = L / RL threads (one last-stage butterfly each), T a multiple of 64.
+// CLIP: the viewport is narrower than the scaled line (vw < N): every pixel store is tested (the usual frame stores the whole line)
+template <class S, int C, int NSRC, bool CLIP = true>
+struct ZoomXLeanT {
+	typedef typename S::B B;
+	typedef typename S::V V;
+	typedef typename S::LC LC;
+	static constexpr int N = S::N, L = S::L, T = S::T, NS = S::NS;
+	static constexpr int R0 = B::R0, RL = B::RL, SB = B::SB, NBL = B::NBL;
+	static_assert(NS >= 2 && NBL == T && T % 64 == 0, "one last-stage butterfly per thread");
+	static_assert(RL % 2 == 1, "odd last radix (conflict-free gather; the middle slot index pairs with itself)");
+	static constexpr int A_ROUNDS = (SB + T - 1) / T;
+	struct State { float hold[(C > 1 ? C - 1 : 1) * 2 * RL]; };      // pixel pairs of the channels before the last
+	struct Ex { float p[RL], s[RL]; };                                 // per store index i: the sample this thread keeps, the one its partner needs
+
+	// source pixel q of slot s: k = min(s, L - s); q = 0: k, 1: L - k, 2: L + k, 3: N - k
+	static DSP_HD int src_pixel(int q, int s) { const int k = s < L - s ? s : L - s; return q == 0 ? k : q == 1 ? L - k : q == 2 ? L + k : N - k; }
+
+	// phase A: slots s = m + r SB from global memory, first DIF butterfly + twiddles, into the padded plane
+	static DSP_HD void phase_a(const ZoomXArgs &a, const PassArgs &w, V *buf, long long bin, int ch, int tid)
+	{
+		const V *tab = reinterpret_cast<const V *>(a.tab);
+		const float *line = a.in + bin + ch;
+		static_for<0, A_ROUNDS>([&](auto i) {
+			const int m = tid + i * T;
+			if ((i + 1) * T <= SB || m < SB) {
+				LC x[R0];
+				static_for<0, R0>([&](auto r) {
+					const int s = m + r * SB;
+					LC v = B::lzero();
+					static_for<0, NSRC>([&](auto q) {
+						int n = src_pixel(q, s);
+						n = n < a.cw ? n : a.cw - 1;                       // beyond the window the multiplier is zero: any valid pixel will do
+						const float f = line[(unsigned)(n * C)];               // (32-bit offset from a uniform base: no 64-bit address arithmetic per load)
+						const LC t = B::l_get(tab[(unsigned)(q * L + s)]);
+						v = cmk<Pk2>(v.x + t.x * f, v.y + t.y * f);
+					});
+					x[r] = v;
+				});
+				Dft<R0>::run(x);
+				cf tw[R0];
+				tw[1] = w.W[m];
+				static_for<2, R0>([&](auto r) { if constexpr (r % 2 == 0) tw[r] = csqr(tw[r / 2]); else tw[r] = cmul(tw[r / 2], tw[r - r / 2]); });
+				static_for<1, R0>([&](auto r) { x[r] = B::lmul(x[r], tw[r]); });
+				static_for<0, R0>([&](auto r) { buf[m + r * (SB + B::PADC)] = B::l_put(x[r]); });
+			}
+		});
+	}
+	// phases B: stage I = 1 .. NS - 2
+	template <int I> static DSP_HD void phase_b(const PassArgs &w, V *buf, int tid) { B::template stage<I>(w, buf, tid); }
+
+	// thread -> last-stage butterfly: partners kb, NBL - 1 - kb on mirror lanes of one wave
+	static DSP_HD int kb_of(int tid) { const int wv = tid >> 6, l = tid & 63; return l < 32 ? 32 * wv + l : NBL - 1 - (32 * wv + 63 - l); }
+	// phase C, first half: last butterfly from the plane, the two series combined; per store index i the kept sample p and the sample s
+	// the partner thread needs.  Lanes >= 32 run through their slots backwards (r = RL - 1 - i) so that partners meet at the same i.
+	static DSP_HD void phase_c(const V *buf, int tid, Ex &e)
+	{
+		const int kb = kb_of(tid);
+		const bool up = (tid & 63) >= 32;
+		const V *p = buf + B::padded(B::last_blk(kb) * RL);
+		LC x[RL];
+		static_for<0, RL>([&](auto r) { x[r] = B::l_get(p[r]); });
+		Dft<RL>::run(x);
+		float ore[RL], oim[RL];
+		static_for<0, RL>([&](auto r) {
+			// output j = kb + NBL r holds plane elements n = 2j (re), 2j + 1 (im): v[n] for even n, -v[n] for odd n; samples x = 4j, 4j + 2 (even:
+			// cosine minus sine series) for j < L/2, odd samples (cosine plus sine) above
+			const int j = kb + NBL * r;
+			const float sg = 2 * j < L ? -1.f : 1.f;
+			ore[r] = x[r].x.x + sg * x[r].x.y;
+			oim[r] = -(x[r].y.x + sg * x[r].y.y);
+		});
+		static_for<0, RL>([&](auto i) {
+			e.p[i] = up ? ore[RL - 1 - i] : ore[i];
+			e.s[i] = up ? oim[RL - 1 - i] : oim[i];
+		});
+	}
+	// phase C, second half: recv[i] = the partner's s[i].  Channels before the last keep their pixel pairs; the last stores whole pixels
+	static DSP_HD void phase_c_emit(const ZoomXArgs &a, long long bout, int ch, int tid, const Ex &e, const float (&recv)[RL], State &st)
+	{
+		const int kb = kb_of(tid);
+		const bool up = (tid & 63) >= 32;
+		// slot of store index i: r = i (lanes < 32) or RL - 1 - i; low slot: pixels 4j (kept), 4j + 1 (received); high slot: 4j' + 2 (received),
+		// 4j' + 3 (kept), j' = L - 1 - j
+		if (ch + 1 < C) {
+			static_for<0, RL>([&](auto i) {
+				const int j = kb + NBL * (up ? RL - 1 - i : i);
+				const bool low = 2 * j < L;
+				const float y0 = low ? e.p[i] : recv[i], y1 = low ? recv[i] : e.p[i];
+				static_for<0, C - 1>([&](auto c) {
+					float &h0 = st.hold[(c * RL + i) * 2], &h1 = st.hold[(c * RL + i) * 2 + 1];
+					h0 = (ch == c) ? y0 : h0; h1 = (ch == c) ? y1 : h1;
+				});
+			});
+			return;
+		}
+		float *line = a.out + bout;
+		static_for<0, RL>([&](auto i) {
+			const int j = kb + NBL * (up ? RL - 1 - i : i);
+			const bool low = 2 * j < L;
+			const float y0 = low ? e.p[i] : recv[i], y1 = low ? recv[i] : e.p[i];
+			const int x0 = low ? 4 * j : 4 * (L - 1 - j) + 2;
+			Pix<C, float> o0, o1;
+			// (handed over one by one: read as a Pix straight from the array, the compiler uses a vector load that keeps the array in scratch)
+			static_for<0, C - 1>([&](auto c) { float v0 = st.hold[(c * RL + i) * 2], v1 = st.hold[(c * RL + i) * 2 + 1]; DSP_PIN1(v0); DSP_PIN1(v1); o0.v[c] = v0; o1.v[c] = v1; });
+			o0.v[C - 1] = y0; o1.v[C - 1] = y1;
+			if (!CLIP || x0 < a.vw) store_pix<C, float>(line + (unsigned)(x0 * C), o0);
+			if (!CLIP || x0 + 1 < a.vw) store_pix<C, float>(line + (unsigned)((x0 + 1) * C), o1);
+		});
+	}
+};
+
+}  // namespace dspfft

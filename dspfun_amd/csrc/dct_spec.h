@@ -701,6 +701,8 @@ struct ColSpecT {
 		});
 	}
 
+	// first slot block of last-stage butterfly kb (digit reversal over the earlier stages)
+	static DSP_HD int last_blk(int kb) { if constexpr (NS >= 2) return PosCalcFirst<NBL, NS - 1, Rs..., 1>::run(kb); else return 0; }
 	template <class ST>
 	static DSP_HD void last_read(const V *buf, ST &st, int tid)
 	{

@@ -663,7 +663,8 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 		if (lines > 0x7fffffff) return fail(-2, "too many lines for the dense path");
 		P.g.nwg = (int)lines; P.g.nthr = 256; P.g.lds_bytes = staged ? 0 : (size_t)N * es;
 		if (staged) {
-			for (const Dim &d : P.hostloop) (void)d;      // one staging array serves every host-loop iteration (they run one after the other)
+			// one staging array serves every host-loop iteration (they run one after the other); executions of this plan on two streams
+			// at once would share it: dspfft_execute_many[_repeat] refuses that (staged_plan_on_two_streams)
 			P.tab.stage = be_alloc((size_t)lines * N * es);
 			if (!P.tab.stage) return fail(-3, "axis %d: no memory for the staging copy of %lld lines of %d samples", a, lines, N);
 		}
@@ -750,6 +751,15 @@ int run_pass(const dspfft_plan_s *pl, const Pass &P, const R *in, R *out, bool l
 				const uintptr_t al = sizeof(R) * (P.type == Pass::ROW ? (P.pa.C == 2 || P.pa.C == 4 ? P.pa.C : 1) : 4);
 				const bool ptr_ok = ((al - 1) & ((uintptr_t)(in + oin) | (uintptr_t)(out + oout))) == 0;
 				use_spec = (P.has_spec || P.jit) && ptr_ok;
+				// the plan options that let a caller leave zeros unstored (input window), or that change values (modulation, alternating output
+				// sign), live in the listed kernels only: a run that cannot take them must fail, not fall through to a kernel that ignores them
+				const bool windowed = pl->win_axis == P.axis && P.first && pl->win_hi > 0;
+				const bool alternating = pl->alt_axis >= 0 && pl->alt_axis == P.axis;
+				if ((windowed || alternating) && !(P.has_spec && !P.jit && ptr_ok))
+					return fail(-1, "%s: the plan's input window / modulation / alternating output need 16-byte aligned buffers (in %p, out %p): the listed kernel cannot run and no other honours them",
+					            P.desc.c_str(), (const void *)(in + oin), (const void *)(out + oout));
+				if (windowed && fz.mask)
+					return fail(-1, "%s: an owner-id mask cannot be combined with an input window (the masked loads would read the rows the window leaves unstored)", P.desc.c_str());
 				if (use_spec) {
 					PassArgsT<R> a;
 					fill_args(a, P.spa, pl, P, in + oin, out + oout, scale, fz);
@@ -1256,6 +1266,9 @@ extern "C" int dspfft_execute_sum2(dspfft_plan pa, dspfft_plan pb, const float *
 		const Pass &A = pa->passes[0], &B = pb->passes[0];
 		const PassGeom &ga = A.spa, &gb = B.spa;
 		if (A.spec.id == B.spec.id && A.spec_nwg == B.spec_nwg && ga.nb0 == gb.nb0 && ga.nb1 == gb.nb1 && ga.sb0_out == gb.sb0_out && ga.sb1_out == gb.sb1_out) {
+			// same pointer rule as run_pass (whole pixels per access); the two-launch path below applies it by itself
+			const uintptr_t al = sizeof(float) * (ga.C == 2 || ga.C == 4 ? ga.C : 1);
+			if ((al - 1) & ((uintptr_t)d_in_a | (uintptr_t)d_in_b | (uintptr_t)d_out)) return fail(-1, "dspfft_execute_sum2: buffers must be aligned to a pixel of %d floats", ga.C);
 			PassArgs a, b;
 			fill_args(a, ga, pa, A, d_in_a, d_out, pa->scale, Fuse());
 			fill_args(b, gb, pb, B, d_in_b, d_out, pb->scale, Fuse());
@@ -1520,12 +1533,22 @@ static int execute_many_once(int count, const dspfft_plan *plans, const void *co
 	}
 	return 0;
 }
-static int check_many(int count, const dspfft_plan *plans, const void *const *d_in, void *const *d_out, int timed_item, int timed_count, bool events, bool f64_ok)
+static bool plan_is_staged(const dspfft_plan_s *pl)
+{
+	for (const Pass &P : pl->passes) if (P.tab.stage) return true;
+	return false;
+}
+static int check_many(int count, const dspfft_plan *plans, const void *const *d_in, void *const *d_out, void *const *streams, int timed_item, int timed_count, bool events, bool f64_ok)
 {
 	if (count < 0 || (count && (!plans || !d_in || !d_out))) return fail(-1, "bad arguments");
 	for (int i = 0; i < count; i++) {
 		if (!plans[i] || !d_in[i] || !d_out[i]) return fail(-1, "item %d: null plan or buffer", i);
 		if (plans[i]->f64 && !f64_ok) return fail(-1, "dspfft_execute_many takes f32 plans");
+		// a staged DENSE pass (lines beyond what LDS holds) copies through ONE array owned by the plan: the same plan on two streams at once
+		// would race on it
+		if (streams && plan_is_staged(plans[i]))
+			for (int j = 0; j < i; j++)
+				if (plans[j] == plans[i] && streams[j] != streams[i]) return fail(-1, "items %d and %d: a plan with a staged pass (its lines pass through a device array of the plan) cannot run on two streams at once", j, i);
 	}
 	if (events) {
 		if (timed_item < 0 || timed_count < 0 || timed_item + timed_count > count) return fail(-1, "timed items [%d, %d) lie outside the batch of %d", timed_item, timed_item + timed_count, count);
@@ -1539,7 +1562,7 @@ static int check_many(int count, const dspfft_plan *plans, const void *const *d_
 extern "C" int dspfft_execute_many(int count, const dspfft_plan *plans, const float *const *d_in, float *const *d_out, void *const *streams,
                                    int timed_item, int timed_count, void *const *pass_events)
 {
-	if (int rc = check_many(count, plans, (const void *const *)d_in, (void *const *)d_out, timed_item, timed_count, pass_events != nullptr, false)) return rc;
+	if (int rc = check_many(count, plans, (const void *const *)d_in, (void *const *)d_out, streams, timed_item, timed_count, pass_events != nullptr, false)) return rc;
 	return execute_many_once(count, plans, (const void *const *)d_in, (void *const *)d_out, streams, timed_item, timed_count, pass_events);
 }
 
@@ -1551,7 +1574,7 @@ extern "C" int dspfft_execute_many_repeat(int count, const dspfft_plan *plans, c
 	if (repeats < 0 || rejoin_every < 0 || timed_every < 0) return fail(-1, "bad arguments");
 	const bool ev = pass_events && timed_every > 0 && timed_count > 0;
 	if (ev && count % timed_count) return fail(-1, "the timed window (%d items) must divide the batch (%d items)", timed_count, count);
-	if (int rc = check_many(count, plans, d_in, d_out, 0, ev ? count : 0, ev, true)) return rc;
+	if (int rc = check_many(count, plans, d_in, d_out, streams, 0, ev ? count : 0, ev, true)) return rc;
 	// distinct streams of the batch, in order of first use
 	std::vector<void *> uniq;
 	for (int i = 0; i < count; i++) { void *st = streams ? streams[i] : nullptr; if (std::find(uniq.begin(), uniq.end(), st) == uniq.end()) uniq.push_back(st); }

@@ -8,6 +8,7 @@
 #include "dct_spec.h"
 #include "spec_list.h"
 #include "spec_fused.h"
+#include "dct_duo.h"
 
 namespace dspfft {
 
@@ -18,6 +19,26 @@ static int allow_lds(K kernel, size_t bytes)
 {
 	if (bytes > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
 	return 0;
+}
+// The attribute is per device: a process that drives several GPUs must set it on each (one flag per device ordinal and launcher;
+// a race between two host threads sets it twice, which is harmless).
+struct DevOnce { enum { MAXDEV = 32 }; unsigned char done[MAXDEV] = {}; int rc[MAXDEV] = {}; int cus[MAXDEV] = {}; };
+static inline int current_device() { int d = 0; return hipGetDevice(&d) == hipSuccess && d >= 0 ? d : 0; }
+template <class... K>
+static int allow_lds_dev(DevOnce &o, size_t bytes, K... kernels)
+{
+	const int d = current_device();
+	if (d >= DevOnce::MAXDEV) { int rc = 0; ((rc = rc ? rc : allow_lds(kernels, bytes)), ...); return rc; }
+	if (!o.done[d]) { int rc = 0; ((rc = rc ? rc : allow_lds(kernels, bytes)), ...); o.rc[d] = rc; o.done[d] = 1; }
+	return o.rc[d];
+}
+static inline int device_cus()
+{
+	static DevOnce o;
+	const int d = current_device();
+	if (d >= DevOnce::MAXDEV) return 256;
+	if (!o.cus[d]) { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n < 1) n = 256; o.cus[d] = n; }
+	return o.cus[d];
 }
 
 // ---- compile-time-specialised kernels (dct_spec.h) ----
@@ -159,6 +180,69 @@ __global__ void __launch_bounds__(S::T, 1) row_sum2_kernel(const typename S::PA 
 		__syncthreads();
 	});
 	S::template final01_hold<2>(b, planes, bout2, t, hold);
+}
+
+// ---- zoom's x stage with the cosine and the sine part as the two halves of a Pk2 (dct_duo.h): one pass per channel through a 16-byte-slot
+// plane instead of two passes of the whole line through 8-byte slots; the line's outputs wait in registers and leave as whole pixels ----
+template <class S, int C, int NSRC, int WPE>
+__global__ void __launch_bounds__(S::T, WPE) zoomx_rows_kernel(const ZoomXArgs a)
+{
+	typedef ZoomXRowsT<S, C, NSRC> Z;
+	extern __shared__ __attribute__((aligned(32))) unsigned char lds[];
+	typename S::V *buf = reinterpret_cast<typename S::V *>(lds);
+	const int tid = threadIdx.x;
+	const long long bin = (long long)blockIdx.x * a.in_pitch, bout = (long long)blockIdx.x * a.out_pitch;
+	PassArgs w;
+	w.W = a.W;                                               // the stages read nothing else
+	typename Z::State st;
+	Z::load(a, bin, 0, tid, st);
+	// a real loop over the channels (see ZoomXRowsT::finish)
+#pragma nounroll
+	for (int c = 0; c < C; c++) {
+		int t = tid; asm volatile("" : "+v"(t));
+		typename S::Regs r;                                  // (declared per channel: written under a condition, it would otherwise be carried around the loop)
+		Z::phase0(a, buf, t, st);
+		__syncthreads();
+		if (c + 1 < C) Z::load(a, bin, c + 1, t, st);        // lands behind the stages
+		static_for<1, S::NS + 2>([&](auto ph) {
+			S::template fft_phase<ph>(w, buf, t, r);
+			__syncthreads();
+		});
+		Z::finish(a, buf, bout, c, t, st);
+		__syncthreads();                                     // the plane is the next channel's
+	}
+}
+
+// ---- the same x stage in three phases per channel (dct_duo.h ZoomXLeanT): first stage fed from global memory, middle stages in the
+// plane, last stage to registers + one mirror-lane exchange per slot; pixel pairs wait in registers until the last channel stores ----
+template <class S, int C, int NSRC, int WPE, bool CLIP>
+__global__ void __launch_bounds__(S::T, WPE) zoomx_lean_kernel(const ZoomXArgs a)
+{
+	typedef ZoomXLeanT<S, C, NSRC, CLIP> Z;
+	extern __shared__ __attribute__((aligned(32))) unsigned char lds[];
+	typename S::V *buf = reinterpret_cast<typename S::V *>(lds);
+	const int tid = threadIdx.x;
+	const long long bin = (long long)blockIdx.x * a.in_pitch, bout = (long long)blockIdx.x * a.out_pitch;
+	PassArgs w;
+	w.W = a.W;                                               // the stages read nothing else
+	typename Z::State st;
+	// a real loop over the channels (see ZoomXRowsT::finish)
+#pragma nounroll
+	for (int c = 0; c < C; c++) {
+		int t = tid; asm volatile("" : "+v"(t));
+		Z::phase_a(a, w, buf, bin, c, t);
+		__syncthreads();
+		static_for<1, S::NS - 1>([&](auto I) {
+			Z::template phase_b<I>(w, buf, t);
+			__syncthreads();
+		});
+		typename Z::Ex e;
+		Z::phase_c(buf, t, e);
+		float recv[Z::RL];
+		static_for<0, Z::RL>([&](auto i) { recv[i] = __shfl_xor(e.s[i], 63); });      // the partner slot's thread sits on the mirror lane
+		Z::phase_c_emit(a, bout, c, t, e, recv, st);
+		if (c + 1 < C) __syncthreads();                      // the plane is the next channel's
+	}
 }
 
 // the same with 8-bit input (REDFT10) or quantised 8-bit output (REDFT01): planar rows only
@@ -317,14 +401,14 @@ __global__ void __launch_bounds__(S::T, rt_waves_per_simd<S>()) col_roundtrip_ke
 template <class S, int KIND>
 int launch_row_spec(const typename S::PA &a, int nwork, void *stream)
 {
-	static int lds_ok = allow_lds(row_spec_kernel<S, KIND, false>, S::LDS) | allow_lds(row_spec_kernel<S, KIND, true>, S::LDS);
-	if (lds_ok) return lds_ok;
+	static DevOnce once;
+	if (int lds_rc = allow_lds_dev(once, S::LDS, row_spec_kernel<S, KIND, false>, row_spec_kernel<S, KIND, true>)) return lds_rc;
 	typedef typename chan_lines_of<typename S::Re, S::N, S::C>::type CH;
 	if constexpr (!std::is_void<CH>::value) {
 		// DSPFFT_ROW_CHAN=0 keeps the interleaved line in one workgroup (A/B runs)
 		if (chan_lines_enabled()) {
-			static int c_ok = allow_lds(row_chan_kernel<CH, KIND, false>, CH::LDS) | allow_lds(row_chan_kernel<CH, KIND, true>, CH::LDS);
-			if (c_ok) return c_ok;
+			static DevOnce conce;
+			if (int c_rc = allow_lds_dev(conce, CH::LDS, row_chan_kernel<CH, KIND, false>, row_chan_kernel<CH, KIND, true>)) return c_rc;
 			if (is_plain(a)) hipLaunchKernelGGL((row_chan_kernel<CH, KIND, true>), dim3(nwork * CH::GS), dim3(CH::T), CH::LDS, (hipStream_t)stream, a, nwork);
 			else hipLaunchKernelGGL((row_chan_kernel<CH, KIND, false>), dim3(nwork * CH::GS), dim3(CH::T), CH::LDS, (hipStream_t)stream, a, nwork);
 			HIPCHK(hipGetLastError());
@@ -334,10 +418,10 @@ int launch_row_spec(const typename S::PA &a, int nwork, void *stream)
 	if constexpr (persist_ok<S>()) {
 		// DSPFFT_ROW_PERSIST=0 keeps one workgroup per line (A/B runs)
 		static const int on = []() { const char *e = getenv("DSPFFT_ROW_PERSIST"); return e ? atoi(e) : 1; }();
-		static const int cus = []() { int d = 0, n = 0; if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n < 1) n = 256; return n; }();
+		const int cus = device_cus();
 		if (on && is_plain(a) && nwork > cus) {
-			static int p_ok = allow_lds(row_persist_kernel<S, KIND>, persist_lds<S>());
-			if (p_ok) return p_ok;
+			static DevOnce ponce;
+			if (int p_rc = allow_lds_dev(ponce, persist_lds<S>(), row_persist_kernel<S, KIND>)) return p_rc;
 			hipLaunchKernelGGL((row_persist_kernel<S, KIND>), dim3(cus), dim3(S::T), persist_lds<S>(), (hipStream_t)stream, a, nwork);
 			HIPCHK(hipGetLastError());
 			return 0;
@@ -351,8 +435,8 @@ int launch_row_spec(const typename S::PA &a, int nwork, void *stream)
 template <class S, int KIND>
 int launch_col_spec(const typename S::PA &a, int nwork, void *stream)
 {
-	static int lds_ok = allow_lds(col_spec_kernel<S, KIND, false>, S::LDS) | allow_lds(col_spec_kernel<S, KIND, true>, S::LDS);
-	if (lds_ok) return lds_ok;
+	static DevOnce once;
+	if (int lds_rc = allow_lds_dev(once, S::LDS, col_spec_kernel<S, KIND, false>, col_spec_kernel<S, KIND, true>)) return lds_rc;
 	if (is_plain(a)) hipLaunchKernelGGL((col_spec_kernel<S, KIND, true>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a);
 	else hipLaunchKernelGGL((col_spec_kernel<S, KIND, false>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a);
 	HIPCHK(hipGetLastError());
@@ -361,8 +445,8 @@ int launch_col_spec(const typename S::PA &a, int nwork, void *stream)
 template <class S, int KIND>
 int launch_row_pair(const typename S::PA &a, int npairs, void *stream)
 {
-	static int lds_ok = allow_lds(row_pair_kernel<S, KIND>, S::LDS);
-	if (lds_ok) return lds_ok;
+	static DevOnce once;
+	if (int lds_rc = allow_lds_dev(once, S::LDS, row_pair_kernel<S, KIND>)) return lds_rc;
 	hipLaunchKernelGGL((row_pair_kernel<S, KIND>), dim3(npairs), dim3(S::T), S::LDS, (hipStream_t)stream, a);
 	HIPCHK(hipGetLastError());
 	return 0;
@@ -370,8 +454,8 @@ int launch_row_pair(const typename S::PA &a, int npairs, void *stream)
 template <class S>
 int launch_row_sum2(const typename S::PA &a, const typename S::PA &b, int nwork, void *stream)
 {
-	static int lds_ok = allow_lds(row_sum2_kernel<S>, S::LDS);
-	if (lds_ok) return lds_ok;
+	static DevOnce once;
+	if (int lds_rc = allow_lds_dev(once, S::LDS, row_sum2_kernel<S>)) return lds_rc;
 	hipLaunchKernelGGL((row_sum2_kernel<S>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a, b);
 	HIPCHK(hipGetLastError());
 	return 0;
@@ -379,8 +463,8 @@ int launch_row_sum2(const typename S::PA &a, const typename S::PA &b, int nwork,
 template <class S, int KIND>
 int launch_col_half(const typename S::PA &a, int nwork, void *stream)
 {
-	static int lds_ok = allow_lds(col_half_kernel<S, KIND>, S::LDS);
-	if (lds_ok) return lds_ok;
+	static DevOnce once;
+	if (int lds_rc = allow_lds_dev(once, S::LDS, col_half_kernel<S, KIND>)) return lds_rc;
 	hipLaunchKernelGGL((col_half_kernel<S, KIND>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a);
 	HIPCHK(hipGetLastError());
 	return 0;
@@ -388,8 +472,8 @@ int launch_col_half(const typename S::PA &a, int nwork, void *stream)
 template <class S, int KIND>
 int launch_row_spec_u8(const typename S::PA &a, const U8IO &io, int nwork, void *stream)
 {
-	static int lds_ok = allow_lds(row_spec_u8_kernel<S, KIND>, S::LDS);
-	if (lds_ok) return lds_ok;
+	static DevOnce once;
+	if (int lds_rc = allow_lds_dev(once, S::LDS, row_spec_u8_kernel<S, KIND>)) return lds_rc;
 	hipLaunchKernelGGL((row_spec_u8_kernel<S, KIND>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a, io);
 	HIPCHK(hipGetLastError());
 	return 0;
@@ -397,8 +481,8 @@ int launch_row_spec_u8(const typename S::PA &a, const U8IO &io, int nwork, void 
 template <class S>
 int launch_col_roundtrip(const typename S::PA &af, const typename S::PA &ai, const MotionFilter &filt, unsigned long long *coded, int nwork, void *stream)
 {
-	static int lds_ok = allow_lds(col_roundtrip_kernel<S>, S::LDS);
-	if (lds_ok) return lds_ok;
+	static DevOnce once;
+	if (int lds_rc = allow_lds_dev(once, S::LDS, col_roundtrip_kernel<S>)) return lds_rc;
 	FilterOp f; f.p = filt;
 	hipLaunchKernelGGL((col_roundtrip_kernel<S>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, af, ai, f, coded);
 	HIPCHK(hipGetLastError());

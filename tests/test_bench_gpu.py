@@ -34,7 +34,19 @@ def test_one_json_line_with_the_contract_keys():
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) <= 2e-3 * r["achieved"]
     assert r["algorithmic_bytes_per_launch"] == 3840 * 2160 * 3 * 4
     assert r["traffic"] is None or r["traffic"] >= r["algorithmic_bytes_per_launch"]
-    assert d["max_abs_drift_after_all_roundtrips"] < 800 * 5e-6          # about 710 in-place roundtrips (untimed + timed), 5e-6 each at most
+    assert d["max_abs_drift_after_all_roundtrips"] < d["roundtrips_of_frame0"] * 2e-6 + 1e-3
+    # round 4: the line says what it did
+    c = d["config"]
+    assert c["preroll_steps"] == 700 - 2 and c["untimed_steps_total"] == 700 and "independent frames" in c["batch"] and "stream" in c["batch"]
+    assert 15000 < d["single_stream_value"] < 167000
+    assert d["forward_check"]["dc_rel_err"] < 1e-4 and d["forward_check"]["energy_rel_err"] < 1e-4
+    if r["traffic"] is not None:
+        assert "PROFILE LOOKUP" in r["traffic_source"]
+        assert abs(r["physical_frac"] - r["traffic"] / (r["kernel_ms"] * 1e-3) / 8e12) < 1e-3 and r["physical_frac"] >= r["frac"]
+    else:
+        assert r["physical_frac"] is None
+    e = d["fftw_abi_end_to_end"]
+    assert e["ms"] >= e["pcie_floor_ms"] * 0.8 and e["bytes_each_way"] == 3840 * 2160 * 3 * 4 and e["host_GBps_each_way"] > 1
 
 
 def test_watchdog_prints_the_headline_when_the_extras_do_not_finish():

@@ -125,6 +125,81 @@ def test_double_precision_entry_points(fftw):
     fftw.fftw_free(p)
 
 
+def _bind_r2r_2d(lib):
+    for name in ("fftwf_plan_r2r_2d", "fftw_plan_r2r_2d"):
+        f = getattr(lib, name)
+        f.restype = C.c_void_p
+        f.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint]
+
+
+def test_plan_r2r_2d_in_place_float(fftw):
+    # applybasis/draw.c:66-76 exactly: alloc_real, zeroed canvas, a few coefficients, plan_r2r_2d(h, w, c, c, REDFT01, REDFT01, ESTIMATE), execute
+    _bind_r2r_2d(fftw)
+    h, w = 96, 160
+    p = fftw.fftwf_alloc_real(h * w)
+    f = _host_array(p, h * w, np.float32)
+    f[:] = 0
+    for (x, y, v) in ((3, 2, 0.5), (10, 7, 0.25), (0, 5, 0.125), (159, 95, -0.3)):
+        f[y * w + x] = v / 4
+    f[0] += 0.5
+    src = f.copy()
+    plan = fftw.fftwf_plan_r2r_2d(h, w, p, p, ol.REDFT01, ol.REDFT01, 1 << 6)
+    assert plan
+    assert np.array_equal(f, src)                       # plan time: untouched
+    fftw.fftwf_execute(plan)
+    ref = ol.r2r_many(src.astype(np.float64), [h, w], [ol.REDFT01, ol.REDFT01])
+    assert np.abs(f - ref).max() <= 1e-5 * np.abs(ref).max()
+    fftw.fftwf_destroy_plan(plan)
+    fftw.fftwf_free(p)
+
+
+@pytest.mark.parametrize("kinds", [(ol.REDFT10, ol.REDFT10), (ol.REDFT01, ol.REDFT10), (ol.REDFT10, ol.REDFT01)])
+def test_plan_r2r_2d_out_of_place_double_mixed_kinds(fftw, kinds):
+    # the basic interface takes one kind per axis (FFTW manual 4.3.5); out of place leaves the input alone
+    _bind_r2r_2d(fftw)
+    h, w = 48, 80
+    x = ol.synth_f32(17, h * w).astype(np.float64) - 0.5
+    p, q = fftw.fftw_alloc_real(h * w), fftw.fftw_alloc_real(h * w)
+    f, g = _host_array(p, h * w, np.float64), _host_array(q, h * w, np.float64)
+    f[:] = x
+    g[:] = np.nan
+    plan = fftw.fftw_plan_r2r_2d(h, w, p, q, kinds[0], kinds[1], 1 << 6)
+    assert plan
+    fftw.fftw_execute(plan)
+    assert np.array_equal(f, x)
+    ref = ol.r2r_many(x, [h, w], list(kinds))
+    assert np.abs(g - ref).max() <= 1e-13 * np.abs(ref).max()
+    fftw.fftw_destroy_plan(plan)
+    fftw.fftw_free(q)
+    fftw.fftw_free(p)
+
+
+def _read_p1f(path, dtype):
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"P1F"
+        w, h = [int(v) for v in f.readline().split()]
+        return np.frombuffer(f.read(), dtype=dtype).reshape(h, w)
+
+
+@pytest.mark.parametrize("exe,dtype,tol", [("draw_gpu", np.float32, 1e-5), ("draw_gpu_d", np.float64, 1e-13)])
+def test_draw_harness(tmp_path, exe, dtype, tol):
+    """applybasis/draw.c:43-76 through the C harness: -f components (one without a strength: it takes what the others leave of 1)
+    on a zeroed canvas, + 0.5 at DC, REDFT01 x REDFT01 through fftw(plan_r2r_2d)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    w, h = 200, 120
+    out = str(tmp_path / "canvas.raw")
+    comps = ["3x2:0.5", "10x7", "0x5:0.125", "199x119:-0.25"]
+    subprocess.check_call([os.path.join(ROOT, "host", exe), "%dx%d" % (w, h), out] + comps)
+    img = _read_p1f(out, dtype)
+    c = np.zeros((h, w), dtype=dtype)
+    energy = dtype(0.5) + dtype(0.125) + dtype(-0.25)
+    for spec, v in (((3, 2), 0.5), ((10, 7), None), ((0, 5), 0.125), ((199, 119), -0.25)):
+        c[spec[1], spec[0]] = (dtype(v) if v is not None else (dtype(1) - energy) / dtype(1)) / dtype(4)
+    c[0, 0] += dtype(0.5)
+    ref = ol.r2r_many(c.astype(np.float64), [h, w], [ol.REDFT01, ol.REDFT01]).reshape(h, w)
+    assert np.abs(img - ref).max() <= tol * np.abs(ref).max()
+
+
 def _write_ppm(path, img_u8):
     h, w, _ = img_u8.shape
     with open(path, "wb") as f:
