@@ -17,7 +17,7 @@ SYMBOLS = [
     "dspfft_plan_many_r2r_f64", "dspfft_plan_set_scale_f64", "dspfft_plan_set_axis_scale0_f64", "dspfft_execute_f64", "dspfft_execute_masked_accumulate_f64", "dspfft_plan_scan_prepare", "dspfft_plan_set_input_window", "dspfft_plan_set_output_alternate", "dspfft_set_plan_effort", "dspfft_get_plan_effort",
     "dspfft_plan_many_r2r_ordered", "dspfft_plan_guru_r2r", "dspfft_execute_roundtrip", "dspfft_execute_roundtrip_u8",
     "dspfft_execute", "dspfft_plan_num_passes", "dspfft_execute_pass", "dspfft_destroy_plan", "dspfft_plan_describe", "dspfft_plan_algorithmic_bytes",
-    "dspfft_execute_many", "dspfft_execute_many_repeat", "dspfft_execute_sum2", "dspfft_plan_set_input_modulation", "dspfft_stream_create", "dspfft_stream_destroy", "dspfft_stream_synchronize", "dspfft_event_create", "dspfft_event_destroy", "dspfft_event_synchronize", "dspfft_event_elapsed_ms",
+    "dspfft_execute_many", "dspfft_execute_many_repeat", "dspfft_execute_sum2", "dspfft_cosrows_create", "dspfft_cosrows_execute", "dspfft_cosrows_destroy", "dspfft_plan_set_input_modulation", "dspfft_stream_create", "dspfft_stream_destroy", "dspfft_stream_synchronize", "dspfft_event_create", "dspfft_event_destroy", "dspfft_event_synchronize", "dspfft_event_elapsed_ms",
     "dspfft_last_error", "dspfft_version",
     "dspfft_scan_zigzag", "dspfft_scan_zigzag_frame_ids", "dspfft_execute_masked_accumulate", "dspfft_scan_scatter", "dspfft_accumulate", "dspfft_broadcast_dc",
     "dspfft_scan_limit", "dspfft_scan_max_interval", "dspfft_scan_coord_slots", "dspfft_scan_owner_index", "dspfft_scan_frame_ids", "dspfft_scan_coords", "dspfft_scan_stamp",
@@ -56,6 +56,10 @@ def bind(lib):
     lib.dspfft_plan_set_axis_scale0.argtypes = [vp, C.c_int, C.c_float, C.c_float]
     lib.dspfft_execute.argtypes = [vp, vp, vp, vp]
     lib.dspfft_execute_sum2.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.dspfft_cosrows_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.dspfft_cosrows_execute.argtypes = [vp, vp, C.c_longlong, vp, C.c_longlong, C.c_double, C.c_double, vp]
+    lib.dspfft_cosrows_destroy.argtypes = [vp]
+    lib.dspfft_cosrows_destroy.restype = None
     lib.dspfft_plan_set_input_modulation.argtypes = [vp, C.c_int, vp, C.c_int]
     lib.dspfft_plan_set_input_window.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     lib.dspfft_plan_set_output_alternate.argtypes = [vp, C.c_int, C.c_int]

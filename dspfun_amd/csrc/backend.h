@@ -7,6 +7,7 @@
 #include "dct_core.h"
 #include "motion_filter.h"
 #include "dct_spec.h"
+#include "dct_duo.h"
 #include "scan_core.h"
 #include "block_core.h"
 
@@ -75,6 +76,13 @@ bool be_spec_has_u8(int row_spec_id);
 int be_launch_spec_u8(int row_spec_id, const PassArgs &a, const U8IO &io, int nwg, void *stream);
 // out = A(in_a) + B(in_b): two REDFT01 row transforms (same row spec, same output lines) in one launch
 int be_launch_row_sum2(int row_spec_id, const PassArgs &a, const PassArgs &b, int nwg, void *stream);
+// zoom's x stage on the duo row kernel (dct_duo.h, spec_list.h DSPFFT_ZOOMX_SPECS): lines of M RGB samples from cw coefficients each.
+// be_find_zoomx: id or -1.  nsrc = source pixels per slot pair (1: cw <= M/4, 2: cw <= M/2, 4); clip: a.vw < M.
+// be_zoomx_tables fills tab ([nsrc][M/2] slots of four floats) for (cw, theta, scale) on the stream -- double-precision arithmetic, one
+// entry per thread (zoomx_table_entry)
+int be_find_zoomx(int M);
+int be_launch_zoomx(int id, const ZoomXArgs &a, int nsrc, bool clip, void *stream);
+int be_zoomx_tables(float *tab, int M, int cw, int nsrc, double theta, double scale, void *stream);
 // fused column roundtrip: REDFT10 along the tile axis (af), pointwise filter, REDFT01 (ai); both passes share spec `id`
 int be_launch_roundtrip(int id, const PassArgs &af, const PassArgs &ai, const MotionFilter &filt, unsigned long long *coded, int nwg, void *stream);
 

@@ -37,6 +37,8 @@ namespace dspfft {
 #define DSP_EXTERN_COL_D(N, K, T, ...) \
 	extern template int launch_col_spec<ColSpecT<double, N, K, T, __VA_ARGS__>, 0>(const PassArgsD &, int, void *); \
 	extern template int launch_col_spec<ColSpecT<double, N, K, T, __VA_ARGS__>, 1>(const PassArgsD &, int, void *);
+#define DSP_EXTERN_ZOOMX(M, T, ...) extern template int launch_zoomx<RowDuoT<M, T, __VA_ARGS__>, 3>(const ZoomXArgs &, int, bool, void *);
+DSPFFT_ZOOMX_SPECS(DSP_EXTERN_ZOOMX)
 DSPFFT_ROW_SPECS_F64(DSP_EXTERN_ROW_D)
 DSPFFT_COL_SPECS_F64(DSP_EXTERN_COL_D)
 DSPFFT_ROW_SPECS(DSP_EXTERN_ROW)
@@ -353,6 +355,18 @@ int be_motion_filter(float *buf, const MotionFilter &filt, uint64_t span, unsign
 	if (!span) return 0;
 	uint64_t b = (span + 255) / 256;
 	hipLaunchKernelGGL(motion_filter_span_kernel, dim3((unsigned)(b > 8192 ? 8192 : b)), dim3(256), 0, (hipStream_t)stream, buf, filt, span, coded);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+__global__ void zoomx_table_kernel(float *tab, int M, int cw, int nsrc, double theta, double scale)
+{
+	zoomx_table_item(tab, M, cw, nsrc, theta, scale, (int)(blockIdx.x * blockDim.x + threadIdx.x));
+}
+int be_zoomx_tables(float *tab, int M, int cw, int nsrc, double theta, double scale, void *stream)
+{
+	const int items = nsrc * (M / 4 + 1);
+	hipLaunchKernelGGL(zoomx_table_kernel, dim3((items + 127) / 128), dim3(128), 0, (hipStream_t)stream, tab, M, cw, nsrc, theta, scale);
 	HIPCHK(hipGetLastError());
 	return 0;
 }

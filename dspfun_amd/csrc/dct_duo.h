@@ -106,80 +106,11 @@ DSP_HD ZoomXEntry zoomx_table_entry(int M, int cw, int k, int src, double theta,
 	return e;
 }
 
-template <class S, int C, int NSRC>
-struct ZoomXRowsT {
-	typedef typename S::V V;
-	typedef typename S::LC LC;
-	static constexpr int N = S::N, L = S::L, T = S::T, KT = S::KT;
-	static constexpr int NPH = S::NS + 3;                       // per channel: phase 0, the FFT's NS + 1, the closing phase
-	struct State {
-		float px[S::K_ROUNDS * NSRC];                           // the input samples of the channel whose phase 0 comes next (fetched while the previous channel's stages run)
-		float hold[(C > 1 ? C - 1 : 1) * S::X_ROUNDS];          // the line's output samples, all channels but the last (whose closing phase stores the pixels)
-	};
-	static DSP_HD int src_pixel(int s, int k) { return s == 0 ? k : s == 1 ? L - k : s == 2 ? L + k : N - k; }
-	static DSP_HD void load(const ZoomXArgs &a, long long bin, int ch, int tid, State &st)
-	{
-		static_for<0, S::K_ROUNDS>([&](auto i) {
-			const int k = tid + i * T;
-			if ((i + 1) * T <= L / 2 + 1 || k <= L / 2)
-				static_for<0, NSRC>([&](auto s) {
-					// a source beyond the window has a zero multiplier: any valid pixel will do (no branch around the load)
-					int n = src_pixel(s, k);
-					n = n < a.cw ? n : a.cw - 1;
-					st.px[i * NSRC + s] = a.in[bin + (long long)n * C + ch];
-				});
-		});
-	}
-	static DSP_HD void phase0(const ZoomXArgs &a, V *buf, int tid, const State &st)
-	{
-		const V *tab = reinterpret_cast<const V *>(a.tab);
-		static_for<0, S::K_ROUNDS>([&](auto i) {
-			const int k = tid + i * T;
-			if ((i + 1) * T <= L / 2 + 1 || k <= L / 2) {
-				LC lo = S::B::lzero(), hi = S::B::lzero();
-				static_for<0, NSRC>([&](auto s) {
-					const float v = st.px[i * NSRC + s];
-					const LC p = S::B::l_get(tab[(2 * s) * KT + k]), q = S::B::l_get(tab[(2 * s + 1) * KT + k]);
-					lo = cmk<Pk2>(lo.x + p.x * v, lo.y + p.y * v);
-					hi = cmk<Pk2>(hi.x + q.x * v, hi.y + q.y * v);
-				});
-				buf[S::padded(k)] = S::B::l_put(lo);
-				if (k > 0 && 2 * k != L) buf[S::padded(L - k)] = S::B::l_put(hi);
-			}
-		});
-	}
-	// closing phase of channel ch (a run-time value: the kernel walks the channels in a real loop, so that the compiler cannot interleave
-	// them and carry one channel's addresses and twiddles through the next -- 80 -> 176 -> 220 VGPRs for 1 -> 2 -> 3 unrolled channels):
-	// y[x] from the plane, kept in registers (selected into its slot: a register array cannot be indexed by ch); the last channel
-	// stores whole pixels
-	static DSP_HD void finish(const ZoomXArgs &a, const V *buf, long long bout, int ch, int tid, State &st)
-	{
-		static_for<0, S::X_ROUNDS>([&](auto i) {
-			const int x = tid + i * T;
-			if ((i + 1) * T <= N || x < N) {
-				const int n = makhoul_dst(x, N);
-				const Pk2 g = S::sample(buf, n);
-				// plane element n = v[n] for even n, -v[n] for odd n; out = v_cos - v_sin on even samples x, v_cos + v_sin on odd ones
-				const float t = (x & 1) ? g.x + g.y : g.x - g.y;
-				const float y = (n & 1) ? -t : t;
-				if (ch + 1 < C) {
-					static_for<0, C - 1>([&](auto c) { float &h = st.hold[c * S::X_ROUNDS + i]; h = (ch == c) ? y : h; });
-				} else if (x < a.vw) {
-					Pix<C, float> o;
-					// (handed over one by one: read as a Pix straight from the array, the compiler uses a vector load that keeps the array in scratch)
-					static_for<0, C - 1>([&](auto c) { float v = st.hold[c * S::X_ROUNDS + i]; DSP_PIN1(v); o.v[c] = v; });
-					o.v[C - 1] = y;
-					store_pix<C, float>(a.out + bout + (long long)x * C, o);
-				}
-			}
-		});
-	}
-};
-
 // =================================================================================================
-// The same x stage with THREE barrier-separated phases per channel instead of NS + 3 (round 4).  Measured on MI355X, the kernel above is
-// not bound by its arithmetic but by the latency at the head of every phase with two 4-wave workgroups per CU (phase 0 and the closing
-// phase alone -- no butterflies -- take 145 of its 341 us at BASELINE config 3): so fewer, fatter phases.
+// THREE barrier-separated phases per channel.  (The first cut kept the row kernels' NS + 3 -- phase 0 writing the slots, the stages, the
+// natural-order write, a closing phase reading the samples back: 334-346 us at BASELINE config 3, no better than the two-pass kernel it
+// was to replace; with two 4-wave workgroups per CU what costs is the head of every phase -- phase 0 and the closing phase alone, no
+// butterflies, took 145 of the 341 us.  profiles/r04_zoomx_variants.txt)
 //   A  the first DIF stage reads its R0 slots straight from global memory (slot = table x pixel, as phase 0 computed it) -- no phase 0,
 //      no LDS round trip in front of the first butterfly;
 //   B  the middle stages, in place (ColSpecT::stage);
@@ -189,6 +120,20 @@ struct ZoomXRowsT {
 //      (ds_bpermute, no LDS round trip, no barrier) leaves every thread with pixel PAIRS (4j, 4j + 1) | (4j + 2, 4j + 3), and the wave's
 //      store of slot index i is one contiguous run of 32 x 48 bytes.
 // Needs T = NBL = L / RL threads (one last-stage butterfly each), T a multiple of 64.
+// item i < nsrc (M/4 + 1) of the per-slot table tab[q][s] (q < nsrc sources, s < M/2 slots, four floats each): the entries of slot pair
+// (k, L - k) for source q.  Every slot is written (slot L/2 by k = L/2, slot 0 by k = 0), so the table needs no clearing between frames.
+DSP_HD void zoomx_table_item(float *tab, int M, int cw, int nsrc, double theta, double scale, int i)
+{
+	const int L = M / 2, KT = M / 4 + 1;
+	if (i >= nsrc * KT) return;
+	const int q = i / KT, k = i - q * KT;
+	const ZoomXEntry e = zoomx_table_entry(M, cw, k, q, theta, scale);
+	for (int j = 0; j < 4; j++) {
+		tab[((size_t)q * L + k) * 4 + j] = (float)e.lo[j];
+		if (k > 0 && 2 * k != L) tab[((size_t)q * L + (L - k)) * 4 + j] = (float)e.hi[j];
+	}
+}
+
 // CLIP: the viewport is narrower than the scaled line (vw < N): every pixel store is tested (the usual frame stores the whole line)
 template <class S, int C, int NSRC, bool CLIP = true>
 struct ZoomXLeanT {

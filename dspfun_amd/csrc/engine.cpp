@@ -1282,6 +1282,57 @@ extern "C" int dspfft_execute_sum2(dspfft_plan pa, dspfft_plan pb, const float *
 	return dspfft_execute_masked_accumulate(pb, d_in_b, d_out, d_out, nullptr, 0, 1, stream);
 }
 
+// ---- rows of a phase-shifted cosine series (include/dspfft.h dspfft_cosrows_*; dct_duo.h) ----
+struct dspfft_cosrows_s {
+	int M, cw, vw, lines, id, nsrc;
+	void *W;        // exp(-2 pi i t / (M/2)), t < M/2
+	float *tab;     // [nsrc][M/2] slots of four floats, rebuilt per execution
+};
+extern "C" int dspfft_cosrows_create(dspfft_cosrows *out, int M, int cw, int vw, int lines)
+{
+	if (!out) return fail(-1, "null plan pointer");
+	*out = nullptr;
+	if (M < 4 || cw < 1 || cw > M || vw < 1 || vw > M || lines < 1) return fail(-1, "bad arguments (M %d, cw %d, vw %d, lines %d)", M, cw, vw, lines);
+	const int id = be_find_zoomx(M);
+	if (id < 0) return fail(-2, "no cosine-series row kernel for lines of %d samples", M);
+	dspfft_cosrows p = new dspfft_cosrows_s();
+	p->M = M; p->cw = cw; p->vw = vw; p->lines = lines; p->id = id;
+	p->nsrc = 4 * cw <= M ? 1 : 2 * cw <= M ? 2 : 4;
+	const int L = M / 2;
+	std::vector<cf> w((size_t)L);
+	const long double pi = 3.14159265358979323846264338327950288L;
+	for (int t = 0; t < L; t++) w[t] = cmk<float>((float)cosl(2 * pi * t / L), (float)-sinl(2 * pi * t / L));
+	p->W = be_alloc((size_t)L * sizeof(cf));
+	p->tab = (float *)be_alloc((size_t)p->nsrc * L * 4 * sizeof(float));
+	if (!p->W || !p->tab || be_upload(p->W, w.data(), w.size() * sizeof(cf))) {
+		if (p->W) be_free(p->W);
+		if (p->tab) be_free(p->tab);
+		delete p;
+		return fail(-3, "no device memory for the tables");
+	}
+	*out = p;
+	return 0;
+}
+extern "C" int dspfft_cosrows_execute(dspfft_cosrows p, const float *d_in, long long in_pitch, float *d_out, long long out_pitch, double theta, double scale, void *stream)
+{
+	if (!p || !d_in || !d_out) return fail(-1, "null plan or buffer");
+	if (in_pitch < 0 || out_pitch < 0 || (p->lines > 1 && (in_pitch < (long long)p->cw * 3 || out_pitch < (long long)p->vw * 3))) return fail(-1, "line pitch shorter than a line");
+	if (3u & ((uintptr_t)d_in | (uintptr_t)d_out)) return fail(-1, "buffers must be 4-byte aligned");
+	// 32-bit offsets inside a line
+	if ((long long)p->M * 3 >= (1ll << 30)) return fail(-2, "line too long");
+	if (int rc = be_zoomx_tables(p->tab, p->M, p->cw, p->nsrc, theta, scale, stream)) return fail(-4, "table kernel launch failed: backend code %d", rc);
+	ZoomXArgs a;
+	a.in = d_in; a.out = d_out; a.tab = p->tab; a.W = (const cf *)p->W; a.in_pitch = in_pitch; a.out_pitch = out_pitch; a.cw = p->cw; a.vw = p->vw; a.lines = p->lines;
+	if (int rc = be_launch_zoomx(p->id, a, p->nsrc, p->vw < p->M, stream)) return fail(-4, "kernel launch failed (cosine-series rows, M = %d): backend code %d", p->M, rc);
+	return 0;
+}
+extern "C" void dspfft_cosrows_destroy(dspfft_cosrows p)
+{
+	if (!p) return;
+	be_free(p->W); be_free(p->tab);
+	delete p;
+}
+
 namespace {
 // a planar row pass that can take / produce 8-bit samples itself
 bool pass_has_u8(const Pass &P)

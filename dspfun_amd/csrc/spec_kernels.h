@@ -182,38 +182,8 @@ __global__ void __launch_bounds__(S::T, 1) row_sum2_kernel(const typename S::PA 
 	S::template final01_hold<2>(b, planes, bout2, t, hold);
 }
 
-// ---- zoom's x stage with the cosine and the sine part as the two halves of a Pk2 (dct_duo.h): one pass per channel through a 16-byte-slot
-// plane instead of two passes of the whole line through 8-byte slots; the line's outputs wait in registers and leave as whole pixels ----
-template <class S, int C, int NSRC, int WPE>
-__global__ void __launch_bounds__(S::T, WPE) zoomx_rows_kernel(const ZoomXArgs a)
-{
-	typedef ZoomXRowsT<S, C, NSRC> Z;
-	extern __shared__ __attribute__((aligned(32))) unsigned char lds[];
-	typename S::V *buf = reinterpret_cast<typename S::V *>(lds);
-	const int tid = threadIdx.x;
-	const long long bin = (long long)blockIdx.x * a.in_pitch, bout = (long long)blockIdx.x * a.out_pitch;
-	PassArgs w;
-	w.W = a.W;                                               // the stages read nothing else
-	typename Z::State st;
-	Z::load(a, bin, 0, tid, st);
-	// a real loop over the channels (see ZoomXRowsT::finish)
-#pragma nounroll
-	for (int c = 0; c < C; c++) {
-		int t = tid; asm volatile("" : "+v"(t));
-		typename S::Regs r;                                  // (declared per channel: written under a condition, it would otherwise be carried around the loop)
-		Z::phase0(a, buf, t, st);
-		__syncthreads();
-		if (c + 1 < C) Z::load(a, bin, c + 1, t, st);        // lands behind the stages
-		static_for<1, S::NS + 2>([&](auto ph) {
-			S::template fft_phase<ph>(w, buf, t, r);
-			__syncthreads();
-		});
-		Z::finish(a, buf, bout, c, t, st);
-		__syncthreads();                                     // the plane is the next channel's
-	}
-}
-
-// ---- the same x stage in three phases per channel (dct_duo.h ZoomXLeanT): first stage fed from global memory, middle stages in the
+// ---- zoom's x stage with the cosine and the sine part of a line as the two halves of a Pk2 (dct_duo.h ZoomXLeanT): the channels of a
+// line one after another through a 16-byte-slot plane, three phases each -- first stage fed from global memory, middle stages in the
 // plane, last stage to registers + one mirror-lane exchange per slot; pixel pairs wait in registers until the last channel stores ----
 template <class S, int C, int NSRC, int WPE, bool CLIP>
 __global__ void __launch_bounds__(S::T, WPE) zoomx_lean_kernel(const ZoomXArgs a)
@@ -226,7 +196,8 @@ __global__ void __launch_bounds__(S::T, WPE) zoomx_lean_kernel(const ZoomXArgs a
 	PassArgs w;
 	w.W = a.W;                                               // the stages read nothing else
 	typename Z::State st;
-	// a real loop over the channels (see ZoomXRowsT::finish)
+	// a real loop over the channels: unrolled, the compiler interleaves them and carries one channel's addresses and twiddles through the
+	// next (80 -> 176 -> 220 VGPRs for 1 -> 2 -> 3 unrolled channels of the first cut)
 #pragma nounroll
 	for (int c = 0; c < C; c++) {
 		int t = tid; asm volatile("" : "+v"(t));
@@ -466,6 +437,30 @@ int launch_col_half(const typename S::PA &a, int nwork, void *stream)
 	static DevOnce once;
 	if (int lds_rc = allow_lds_dev(once, S::LDS, col_half_kernel<S, KIND>)) return lds_rc;
 	hipLaunchKernelGGL((col_half_kernel<S, KIND>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+// nsrc = 1 (cw <= M/4), 2 (cw <= M/2) or 4 source pixels per slot pair; clip: vw < M
+template <class S, int C>
+int launch_zoomx(const ZoomXArgs &a, int nsrc, bool clip, void *stream)
+{
+	// waves per SIMD to ask of the register allocator: what the plane's LDS lets onto a CU, at most two (256 VGPRs: the held pixel pairs + a
+	// radix-16 butterfly over Pk2 need 214-244)
+	constexpr int WPE = (int)((160 * 1024) / S::LDS) * S::T / 256 >= 2 ? 2 : 1;
+	static DevOnce once;
+	if (int rc = allow_lds_dev(once, S::LDS, zoomx_lean_kernel<S, C, 1, WPE, false>, zoomx_lean_kernel<S, C, 1, WPE, true>, zoomx_lean_kernel<S, C, 2, WPE, false>,
+	                           zoomx_lean_kernel<S, C, 2, WPE, true>, zoomx_lean_kernel<S, C, 4, WPE, false>, zoomx_lean_kernel<S, C, 4, WPE, true>)) return rc;
+	const dim3 g(a.lines), b(S::T);
+	hipStream_t st = (hipStream_t)stream;
+	switch (nsrc * 2 + (clip ? 1 : 0)) {
+	case 2: hipLaunchKernelGGL((zoomx_lean_kernel<S, C, 1, WPE, false>), g, b, S::LDS, st, a); break;
+	case 3: hipLaunchKernelGGL((zoomx_lean_kernel<S, C, 1, WPE, true>), g, b, S::LDS, st, a); break;
+	case 4: hipLaunchKernelGGL((zoomx_lean_kernel<S, C, 2, WPE, false>), g, b, S::LDS, st, a); break;
+	case 5: hipLaunchKernelGGL((zoomx_lean_kernel<S, C, 2, WPE, true>), g, b, S::LDS, st, a); break;
+	case 8: hipLaunchKernelGGL((zoomx_lean_kernel<S, C, 4, WPE, false>), g, b, S::LDS, st, a); break;
+	case 9: hipLaunchKernelGGL((zoomx_lean_kernel<S, C, 4, WPE, true>), g, b, S::LDS, st, a); break;
+	default: return -1;
+	}
 	HIPCHK(hipGetLastError());
 	return 0;
 }

@@ -130,3 +130,14 @@
 	X(1440, 4, 512, 8, 12, 15)       \
 	X(1024, 8, 512, 4, 16, 16)       \
 	X(720, 8, 256, 6, 8, 15)
+
+// ---- zoom's x stage on the duo row kernel (dct_duo.h ZoomXLeanT, RGB lines): X(M, THREADS, radices of M/2 ...) ----
+// M = scaled line length; the last radix RL is odd and THREADS = (M/2) / RL (one last-stage butterfly per thread), a multiple of 64.
+// Scaled lengths without an entry keep the two-transform row pass (dspfft_execute_sum2) or the column-last order (zoom_fft.hip).
+#define DSPFFT_ZOOMX_SPECS(X)        \
+	X(7680, 256, 16, 16, 15)         /* BASELINE config 3: 1920 x 4 */ \
+	X(5760, 192, 12, 16, 15)         /* 1920 x 3, 1440 x 4 */ \
+	X(3840, 128, 8, 16, 15)          /* 1920 x 2, 960 x 4, 1280 x 3 */ \
+	X(2560, 256, 16, 16, 5)          /* 1280 x 2, 640 x 4 */ \
+	X(1920, 64, 8, 8, 15)            /* 960 x 2, 640 x 3, 480 x 4 */ \
+	X(1280, 128, 8, 16, 5)           /* 640 x 2, 320 x 4 */

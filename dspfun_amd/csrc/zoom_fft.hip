@@ -166,6 +166,9 @@ struct dspfft_zoomfft_s {
 	// (dspfft_plan_set_input_modulation), the multiplier tables being the only thing a pan changes
 	bool xmod;
 	bool ymod;                     // the y stage's column plans read the coefficients directly (window + modulation + mirror): no input kernel
+	// round 4: the x stage as ONE transform per line and channel -- cosine and sine part as the halves of a packed-FP32 pair, three phases
+	// per channel (dspfft_cosrows_*, dct_duo.h) -- where the scaled width has a listed kernel; reads T like the two row plans it replaces
+	dspfft_cosrows xrows;
 };
 
 extern "C" const char *dspfft_zoomfft_last_error(void) { return g_err; }
@@ -183,7 +186,7 @@ extern "C" int dspfft_zoomfft_create(dspfft_zoomfft *out, int w, int h, int type
 	z->cw = dspfft_zoom_ncomponents(xnum, xden, (size_t)w); z->ch = dspfft_zoom_ncomponents(ynum, yden, (size_t)h);
 	z->sx = xnum / xden; z->sy = ynum / yden;
 	z->rows = z->colsA = z->colsE = z->ycolsA = z->ycolsE = z->rowsA = z->rowsE = nullptr;
-	z->xlast = false; z->ywindowed = false; z->xmod = false; z->ymod = false;
+	z->xlast = false; z->ywindowed = false; z->xmod = false; z->ymod = false; z->xrows = nullptr;
 	const int k01[1] = {DSPFFT_REDFT01};
 	{
 		// x stage last: rows of Mx RGB pixels read from compact lines (cw resp. cw - 1 pixels: only the window is ever read), written
@@ -233,6 +236,10 @@ extern "C" int dspfft_zoomfft_create(dspfft_zoomfft *out, int w, int h, int type
 						if (de) dspfft_destroy_plan(de);
 					}
 				}
+				// the probes above left the address of a local in the plans' modulation slots: clear them (every execution sets the real tables)
+				for (dspfft_plan pm : {z->rowsA, z->rowsE, z->ycolsA, z->ycolsE}) if (pm) dspfft_plan_set_input_modulation(pm, 0, nullptr, 0);
+				const char *ex = getenv("DSPFFT_ZOOM_XROWS");      // "0": keep the two-transform row pass (A/B runs)
+				if (z->xmod && !(ex && *ex == '0') && dspfft_cosrows_create(&z->xrows, (int)Mx, (int)cw, vw, vh)) z->xrows = nullptr;
 				z->xlast = true;
 				*out = z;
 				return 0;
@@ -273,6 +280,7 @@ extern "C" void dspfft_zoomfft_destroy(dspfft_zoomfft z)
 {
 	if (!z) return;
 	for (dspfft_plan p : {z->rows, z->colsA, z->colsE, z->ycolsA, z->ycolsE, z->rowsA, z->rowsE}) if (p) dspfft_destroy_plan(p);
+	if (z->xrows) dspfft_cosrows_destroy(z->xrows);
 	delete z;
 }
 
@@ -327,6 +335,14 @@ extern "C" int dspfft_zoomfft_execute(dspfft_zoomfft z, const float *d_coeffs, d
 			if (!z->ymod && (dspfft_execute(z->ycolsA, AYx, AYx, stream) || dspfft_execute_masked_accumulate(z->ycolsE, EYx, EYx, AYx, nullptr, 0, 1, stream))) {
 				snprintf(g_err, sizeof g_err, "y stage: %s", dspfft_last_error()); return -4;
 			}
+			if (z->xrows) {
+				// out[j][b] = 1 / (w h) sum'_u T[j][u] cos(u (pi (b + 1/2) / Mx + theta_x)), straight into the caller's frame (a narrower viewport
+				// clips in the store)
+				if (dspfft_cosrows_execute(z->xrows, AYx, (long long)cw * 3, d_out, (long long)z->vw * 3, thx, 1.0 / ((double)z->w * (double)z->h), stream)) {
+					snprintf(g_err, sizeof g_err, "x stage: %s", dspfft_last_error()); return -4;
+				}
+				dst = d_out;
+			} else
 			if (dspfft_plan_set_input_modulation(z->rowsA, 0, csx, 0) != 1 || dspfft_plan_set_input_modulation(z->rowsE, 0, csx + cw, (int)z->Mx) != 1 ||
 			    dspfft_execute_sum2(z->rowsA, z->rowsE, AYx, AYx, dst, stream)) { snprintf(g_err, sizeof g_err, "x stage: %s", dspfft_last_error()); return -4; }
 		} else {

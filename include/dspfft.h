@@ -121,6 +121,22 @@ int dspfft_plan_set_output_alternate(dspfft_plan plan, int axis, int on);
  * x stage by fast transforms: cosine part + sine part); otherwise dspfft_execute(a) followed by an accumulating execution of b, for
  * which b must be a one-pass plan (-2 otherwise).  d_out must not overlap the inputs. */
 int dspfft_execute_sum2(dspfft_plan a, dspfft_plan b, const float *d_in_a, const float *d_in_b, float *d_out, void *hip_stream);
+
+/* ---- rows of a phase-shifted cosine series (zoom's x stage: zoom/zoom.c:361-368 with the basis of :36-68 on a DCT-III grid) ----
+ *     out[j][b][c] = scale * sum'_{u < cw} in[j][u][c] cos(u (pi (b + 1/2) / M + theta)),    b < vw <= M, c < 3, j < lines
+ * (sum' halves u = 0: zoom.c:364 `coeffs[..]/2`).  With theta = 0 this is 1/2 REDFT01_M of the zero-padded line; a non-zero theta is a
+ * pan by theta M / pi samples (zoom.c:49-57 `offset`), which two transforms would need (cosine and sine part: dspfft_execute_sum2).
+ * Here both parts ride through ONE half-length FFT per channel as the halves of a packed-FP32 pair: a kernel of its own
+ * (dspfun_amd/csrc/dct_duo.h), three barrier-separated phases per channel, whole pixels stored once.
+ * Scaled lengths M with a listed kernel only (spec_list.h DSPFFT_ZOOMX_SPECS: 7680, 5760, 3840, 2560, 1920, 1280): create returns -2 for the
+ * others and the caller keeps dspfft_execute_sum2.  Lines: `in` cw pixels of 3 floats, in_pitch floats apart; `out` vw pixels, out_pitch
+ * floats apart; 4-byte alignment suffices.  theta and scale are arguments of the execution (a pan re-plans nothing): the multiplier table
+ * they determine (M/2 .. 2M slots of 16 bytes, evaluated in double on the device) is rebuilt per call, on the stream, in the plan's
+ * own buffer -- one execution of a plan at a time. */
+typedef struct dspfft_cosrows_s *dspfft_cosrows;
+int dspfft_cosrows_create(dspfft_cosrows *plan, int M, int cw, int vw, int lines);
+int dspfft_cosrows_execute(dspfft_cosrows plan, const float *d_in, long long in_pitch, float *d_out, long long out_pitch, double theta, double scale, void *hip_stream);
+void dspfft_cosrows_destroy(dspfft_cosrows plan);
 /* Optional, for owner ids that stay the same over the frames of a scan (every method but box, whose ids are stamped per frame):
  * records the (min, max) owner id of every column tile of `plan`, so that a later dspfft_execute_masked_accumulate with the SAME
  * d_ids pointer and elems_per_id leaves a tile alone -- without reading its owner ids -- when `id` lies outside its range.  Call it

@@ -237,6 +237,51 @@ int launch_row_sum2(const typename S::PA &a, const typename S::PA &b, int nwork,
 	}
 	return 0;
 }
+// zoom's x stage on the duo row kernel (spec_kernels.h zoomx_lean_kernel): the cross-lane exchange (mirror lane of the same wave) is a
+// read of the partner thread's values between the two halves of phase C
+template <class S, int C, int NSRC, bool CLIP>
+int emul_zoomx(const ZoomXArgs &a)
+{
+	typedef ZoomXLeanT<S, C, NSRC, CLIP> Z;
+	std::vector<unsigned char> lds(S::LDS + 64);
+	typename S::V *buf = (typename S::V *)(((uintptr_t)lds.data() + 31) & ~(uintptr_t)31);
+	PassArgs w = {};
+	w.W = a.W;
+	for (int line = 0; line < a.lines; line++) {
+		const long long bin = (long long)line * a.in_pitch, bout = (long long)line * a.out_pitch;
+		std::vector<typename Z::State> st(S::T);
+		std::vector<typename Z::Ex> ex(S::T);
+		for (int c = 0; c < C; c++) {
+			for (int tid = 0; tid < S::T; tid++) Z::phase_a(a, w, buf, bin, c, tid);
+			static_for<1, S::NS - 1>([&](auto I) { for (int tid = 0; tid < S::T; tid++) Z::template phase_b<I>(w, buf, tid); });
+			for (int tid = 0; tid < S::T; tid++) Z::phase_c(buf, tid, ex[tid]);
+			for (int tid = 0; tid < S::T; tid++) {
+				float recv[Z::RL];
+				for (int i = 0; i < Z::RL; i++) recv[i] = ex[tid ^ 63].s[i];
+				Z::phase_c_emit(a, bout, c, tid, ex[tid], recv, st[tid]);
+			}
+		}
+	}
+	return 0;
+}
+template <class S, int C>
+int launch_zoomx(const ZoomXArgs &a, int nsrc, bool clip, void *)
+{
+	switch (nsrc * 2 + (clip ? 1 : 0)) {
+	case 2: return emul_zoomx<S, C, 1, false>(a);
+	case 3: return emul_zoomx<S, C, 1, true>(a);
+	case 4: return emul_zoomx<S, C, 2, false>(a);
+	case 5: return emul_zoomx<S, C, 2, true>(a);
+	case 8: return emul_zoomx<S, C, 4, false>(a);
+	case 9: return emul_zoomx<S, C, 4, true>(a);
+	}
+	return -1;
+}
+int be_zoomx_tables(float *tab, int M, int cw, int nsrc, double theta, double scale, void *)
+{
+	for (int i = 0; i < nsrc * (M / 4 + 1); i++) zoomx_table_item(tab, M, cw, nsrc, theta, scale, i);
+	return 0;
+}
 template <class S, int KIND>
 int launch_row_spec_u8(const PassArgs &a, const U8IO &io, int nwork, void *)
 {
