@@ -107,6 +107,7 @@ struct PassGeom {
 	                      // (dspfft_plan_set_input_window: zoom's y stage transforms a spectrum zero-padded to 4x its length); 0, 0: off
 	const void *in_mul;   // specialised ROW / COL REDFT01 first pass (dspfft_plan_set_input_modulation): input sample x of the axis is read from position
 	int in_rev;           // p = in_rev > 0 ? in_rev - x : x of its line and multiplied by in_mul[p] (a table of the plan's sample type); null / 0: off
+	int lean_off;         // specialised COL REDFT01 passes: 1 keeps the natural-order write + closing phase (DSPFFT_LEAN01=0, A/B runs); 0: the last stage stores
 	const uint32_t *zranges;   // COL side, optional: (min, max) owner id of every tile (dspfft_plan_scan_prepare): a tile whose range
 	                           // excludes mask_id is skipped without reading its owner ids
 	FftDesc fft;

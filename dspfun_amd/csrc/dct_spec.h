@@ -731,6 +731,34 @@ struct ColSpecT {
 		});
 	}
 
+	// REDFT01 without accumulation closes in the LAST STAGE (round 4): the butterfly's outputs are FFT outputs n = kb + NBL r in natural order,
+	// i.e. output rows makhoul_src(n) up to a sign and the scale -- a permutation, so they are stored from registers instead of going
+	// through the natural-order write and a closing phase that reads them back (two LDS round trips and two barriers fewer per tile).
+	// (The mirror image for REDFT10 -- the first butterflies fed from the registers the global loads fill, in butterfly order -- was built
+	// and measured slower: three quarters of the threads then issue all the loads, 12 each; profiles/r04_lean_col.txt.)
+	static DSP_HD bool lean01(const PA &a) { return !a.accumulate && !a.lean_off; }
+	template <int KIND> static DSP_HD bool skip_phase(const PA &a, int ph) { return KIND == KIND_REDFT01 && ph > NS && lean01(a); }
+	template <int KIND> static DSP_HD bool barrier_after(const PA &a, int ph) { return (KIND == KIND_REDFT01 && lean01(a)) ? ph < NS : ph + 1 < NPH; }
+	static DSP_HD void last_store01(const PA &a, const V *buf, long long bout, int tid)
+	{
+		static_for<0, LAST_ROUNDS>([&](auto i) {
+			const int it = tid + i * T;
+			if (it < NBL * NP) {
+				const int kb = it / NP, jp = it - kb * NP;
+				const V *p = buf + (NS >= 2 ? padded(last_blk(kb) * RL) : 0) * NP + jp;
+				LC x[RL];
+				static_for<0, RL>([&](auto r) { x[r] = l_get(p[r * NP]); });
+				Dft<RL>::run(x);
+				static_for<0, RL>([&](auto r) {
+					const int y = makhoul_src(kb + NBL * r, N);
+					Re sc = (y == 0) ? a.scale * a.out_scale0 : a.scale;
+					if (a.alt_out && (y & 1)) sc = -sc;          // folds away in the plain instantiation
+					*reinterpret_cast<V *>(a.out + bout + (long long)y * a.es_out + VW * jp) = g_put(cmk<LR>(x[r].x * sc, -x[r].y * sc));
+				});
+			}
+		});
+	}
+
 	// ---- fused forward -> pointwise filter -> inverse along this axis (dspfft_execute_roundtrip) ----
 	// The tile never leaves LDS between the two transforms.  mid_read turns the forward FFT output into the
 	// coefficient rows k and N-k (exactly REDFT10's last phase), filters them, and applies REDFT01's first phase;
@@ -816,10 +844,12 @@ struct ColSpecT {
 		} else if constexpr (PH < NS) {
 			stage<PH - 1>(a, buf, tid);
 		} else if constexpr (PH == NS) {
-			last_read(buf, st, tid);
+			if (KIND == KIND_REDFT01 && lean01(a)) last_store01(a, buf, bout, tid); else last_read(buf, st, tid);
 		} else if constexpr (PH == NS + 1) {
+			if (KIND == KIND_REDFT01 && lean01(a)) return;
 			last_write(buf, st, tid);
 		} else {
+			if (KIND == KIND_REDFT01 && lean01(a)) return;
 			if constexpr (KIND == KIND_REDFT10) {
 				static_for<0, K_ROUNDS>([&](auto ri) {
 					const int it = tid + ri * T;
@@ -987,6 +1017,34 @@ struct ColHalfSpecT {
 		}
 	}
 
+	// REDFT01 without accumulation closes in the last stage (see ColSpecT::last_store01): FFT output n of half h is image row row_of(n, h),
+	// times conj(w)^n for the odd half
+	static DSP_HD bool lean01(const PA &a) { return B::lean01(a); }
+	template <int KIND> static DSP_HD bool skip_phase(const PA &a, int ph) { return KIND == KIND_REDFT01 && ph > NS && lean01(a); }
+	template <int KIND> static DSP_HD bool barrier_after(const PA &a, int ph) { return (KIND == KIND_REDFT01 && lean01(a)) ? ph < NS : ph + 1 < NPH; }
+	static DSP_HD void last_store01(const PA &a, const V *buf, long long bout, int h, int tid)
+	{
+		static_for<0, B::LAST_ROUNDS>([&](auto i) {
+			const int it = tid + i * T;
+			if (it < B::NBL * NP) {
+				const int kb = it / NP, jp = it - kb * NP;
+				const V *p = buf + (NS >= 2 ? B::padded(B::last_blk(kb) * B::RL) : 0) * NP + jp;
+				LC x[B::RL];
+				CX hw[B::RL];
+				if (h) static_for<0, B::RL>([&](auto r) { hw[r] = a.H[kb + B::NBL * r]; });      // fetched beside the LDS reads
+				static_for<0, B::RL>([&](auto r) { x[r] = B::l_get(p[r * NP]); });
+				Dft<B::RL>::run(x);
+				const Re sc = a.scale;
+				static_for<0, B::RL>([&](auto r) {
+					const int n = kb + B::NBL * r;
+					LC F = x[r];
+					if (h) F = B::lmul(F, hw[r]);
+					*reinterpret_cast<V *>(a.out + bout + (long long)row_of(n, h) * a.es_out + VW * jp) = B::g_put(cmk<LR>(F.x * sc, -F.y * sc));
+				});
+			}
+		});
+	}
+
 	template <int KIND, int PH, class ST>
 	static DSP_HD void phase(const PA &a, V *buf, long long bout, int h, int tid, ST &st)
 	{
@@ -1020,10 +1078,12 @@ struct ColHalfSpecT {
 		} else if constexpr (PH < NS) {
 			B::template stage<PH - 1>(a, buf, tid);
 		} else if constexpr (PH == NS) {
-			B::last_read(buf, st, tid);
+			if (KIND == KIND_REDFT01 && lean01(a)) last_store01(a, buf, bout, h, tid); else B::last_read(buf, st, tid);
 		} else if constexpr (PH == NS + 1) {
+			if (KIND == KIND_REDFT01 && lean01(a)) return;
 			B::last_write(buf, st, tid);
 		} else {
+			if (KIND == KIND_REDFT01 && lean01(a)) return;
 			if constexpr (KIND == KIND_REDFT10) {
 				static_for<0, Q_ROUNDS>([&](auto ri) {
 					const int it = tid + ri * T;

@@ -686,6 +686,8 @@ void fill_args(PassArgsT<R> &a, const PassGeom &g, const dspfft_plan_s *pl, cons
 	a.mask = fz.mask; a.mask_id = fz.id; a.mask_div = make_div((uint32_t)fz.div); a.accumulate = fz.accumulate;
 	a.zflags = fz.zflags; a.zshift = fz.zshift; a.zhalf = fz.zhalf; a.zpage = fz.zpage; a.zranges = fz.zranges;
 	a.alt_out = (pl->alt_axis == P.axis && pl->alt_axis >= 0) ? 1 : 0;
+	static const int lean_off = []() { const char *e = getenv("DSPFFT_LEAN01"); return e && *e == '0' ? 1 : 0; }();
+	a.lean_off = lean_off;
 	a.win_lo = a.win_hi = 0;
 	if (pl->win_axis == P.axis && P.first && !fz.mask && pl->zpage) { a.win_lo = pl->win_lo; a.win_hi = pl->win_hi; a.zpage = pl->zpage; }
 	a.in_mul = nullptr; a.in_rev = 0;

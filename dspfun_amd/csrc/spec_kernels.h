@@ -52,6 +52,7 @@ template <class PA> __device__ inline PA plain_args(const PA &a_)
 {
 	PA a = a_;
 	a.mask = nullptr; a.zflags = nullptr; a.zranges = nullptr; a.accumulate = 0; a.win_lo = a.win_hi = 0; a.alt_out = 0; a.in_mul = nullptr; a.in_rev = 0;
+	// (lean_off stays a run-time value: DSPFFT_LEAN01=0 must reach the plain kernels too)
 	return a;
 }
 template <class PA> static inline bool is_plain(const PA &a) { return !a.mask && !a.zflags && !a.accumulate && a.win_hi <= 0 && !a.alt_out && !a.in_mul && !a.in_rev; }
@@ -267,10 +268,11 @@ __global__ void __launch_bounds__(S::T, S::WPE) col_spec_kernel(const typename S
 	}
 	S::template phase<KIND, 0>(a, buf, bout, tid, st);
 	__syncthreads();
+	// (a REDFT01 pass that closes in its last stage has two empty phases: no barrier around those)
 	static_for<1, S::NPH>([&](auto ph) {
-		{
+		if (!S::template skip_phase<KIND>(a, ph)) {
 			S::template phase<KIND, ph>(a, buf, bout, tid, st);
-			if constexpr (ph + 1 < S::NPH) __syncthreads();
+			if (S::template barrier_after<KIND>(a, ph)) __syncthreads();
 		}
 	});
 }
@@ -355,8 +357,10 @@ __global__ void __launch_bounds__(S::T, S::WPE) col_half_kernel(const typename S
 		if (!nz) return;
 	}
 	static_for<0, S::NPH>([&](auto ph) {
-		S::template phase<KIND, ph>(a, buf, bout, h, tid, st);
-		if constexpr (ph + 1 < S::NPH) __syncthreads();
+		if (!S::template skip_phase<KIND>(a, ph)) {           // see col_spec_kernel
+			S::template phase<KIND, ph>(a, buf, bout, h, tid, st);
+			if (S::template barrier_after<KIND>(a, ph)) __syncthreads();
+		}
 	});
 }
 

@@ -3,8 +3,8 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dspfun_amd import Plan, REDFT10, REDFT01, _lib
 L = _lib.load()
-def t(fn, reps=20):
-    for _ in range(3): fn()
+def t(fn, reps=100):
+    for _ in range(60): fn()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
