@@ -280,6 +280,12 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+    # how many ranks RCCL itself joined (an all-reduce of ones): what the collectives below really span, whatever WORLD_SIZE says
+    ranks_seen = None
+    if dist is not None:
+        one = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
 
     from dspfun_amd import Plan, REDFT10, REDFT01
     fwd = Plan.image(H, W, C, REDFT10)
@@ -463,7 +469,7 @@ def main():
         value = pixels / 1e6 / elapsed
         line = {
             "metric": "Mpixels/s DCT-II+III roundtrip 3840x2160x3", "value": round(value, 2), "unit": "Mpixels/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "ranks_seen_by_rccl": ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (splitmix64 uniform [0,1), SURVEY.md 8d seed 0xD5F0002)",
             "config": {"workload": "spec + ispec roundtrip on 3840x2160 RGB float32 (BASELINE configs[1])",

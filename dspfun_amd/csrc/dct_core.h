@@ -78,6 +78,7 @@ struct PassGeom {
 	// ROW
 	int C;            // interleaved signals per line
 	int LPW;          // lines per workgroup (generic ROW kernel; the specialised kernels take one)
+	long long nlines; // ROW: lines of the launch (nb0 * nb1 * the third level's extent)
 	FastDiv divC, divNC, divKC;   // ROW: divide by C, by N*C (samples per line), by (N/4+1)*C (output pairs per line)
 	// COL
 	int K;            // tile width in samples (even)
@@ -88,6 +89,8 @@ struct PassGeom {
 	// batch dimensions (two levels) -- line/tile base = i0*sb0 + i1*sb1
 	int nb0, nb1;
 	long long sb0_in, sb1_in, sb0_out, sb1_out;
+	long long sb2_in, sb2_out;   // ROW passes: a third batch level (lines beyond nb0 * nb1 step by these; 0, 0 = none).  Round 4: the slab transform's
+	                             // x pass writes the blocks of ALL destination ranks in one launch (dist.py SlabDCT3D)
 	const uint32_t *pos;  // pos[k] = LDS slot holding FFT output k after the DIF stages
 	// fused scan step (scan/scan.c:429-459): the FIRST pass zeroes every input element whose owner
 	// id differs (mask[offset / mask_div] != mask_id); the LAST pass adds into `out` instead of storing
@@ -255,14 +258,20 @@ DSP_HD int makhoul_dst(int y, int N) { return (y & 1) ? N - 1 - (y >> 1) : (y >>
 
 DSP_HD void row_base(const PassGeom &a, int line, long long &bin, long long &bout)
 {
-	const int i1 = line / a.nb0, i0 = line - i1 * a.nb0;
-	bin = i0 * a.sb0_in + i1 * a.sb1_in;
-	bout = i0 * a.sb0_out + i1 * a.sb1_out;
+	int i1 = line / a.nb0;
+	const int i0 = line - i1 * a.nb0;
+	bin = i0 * a.sb0_in; bout = i0 * a.sb0_out;
+	if (a.sb2_in | a.sb2_out) {                   // (uniform: only plans with a third level pay the second division)
+		const int i2 = i1 / a.nb1;
+		i1 -= i2 * a.nb1;
+		bin += i2 * a.sb2_in; bout += i2 * a.sb2_out;
+	}
+	bin += i1 * a.sb1_in; bout += i1 * a.sb1_out;
 }
 // lines of workgroup `wg`: returns how many (the last workgroup may hold fewer than LPW) and fills bases[]
 DSP_HD int row_bases(const PassGeom &a, int wg, long long *bases, int tid)
 {
-	const long long nlines = (long long)a.nb0 * a.nb1;
+	const long long nlines = a.nlines;
 	long long cnt = nlines - (long long)wg * a.LPW;
 	if (cnt > a.LPW) cnt = a.LPW;
 	if (tid < (int)cnt) row_base(a, wg * a.LPW + tid, bases[2 * tid], bases[2 * tid + 1]);

@@ -526,9 +526,12 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 				pa.N = N; pa.kind = kind; pa.C = C; pa.fft = F;
 				pa.nb0 = lines.size() > 0 ? lines[0].n : 1; pa.sb0_in = lines.size() > 0 ? lines[0].is : 0; pa.sb0_out = lines.size() > 0 ? lines[0].os : 0;
 				pa.nb1 = lines.size() > 1 ? lines[1].n : 1; pa.sb1_in = lines.size() > 1 ? lines[1].is : 0; pa.sb1_out = lines.size() > 1 ? lines[1].os : 0;
-				for (size_t i = 2; i < lines.size(); i++) P.hostloop.push_back(lines[i]);
+				const long long nb2 = lines.size() > 2 ? lines[2].n : 1;
+				pa.sb2_in = lines.size() > 2 ? lines[2].is : 0; pa.sb2_out = lines.size() > 2 ? lines[2].os : 0;
+				for (size_t i = 3; i < lines.size(); i++) P.hostloop.push_back(lines[i]);
 				P.type = Pass::ROW;
-				const long long nlines = (long long)pa.nb0 * pa.nb1;
+				const long long nlines = (long long)pa.nb0 * pa.nb1 * nb2;
+				pa.nlines = nlines;
 				if (nlines > 0x7fffffffLL) return fail(-2, "too many lines for one launch");
 				// short lines: several per workgroup (about 2048 samples), as long as the launch keeps well over a workgroup per CU
 				int LPW = 1;
@@ -801,7 +804,7 @@ void build_split(dspfft_plan_s *pl)
 	if (pl->f64 || pl->rank != 2 || pl->passes.size() != 2 || env_int("DSPFFT_NO_SPLIT") == 1) return;
 	const Pass *R = nullptr, *Cc = nullptr;
 	for (const Pass &P : pl->passes) {
-		if (!P.has_spec || !P.hostloop.empty()) return;
+		if (!P.has_spec || !P.hostloop.empty() || P.pa.sb2_in || P.pa.sb2_out) return;
 		if (P.type == Pass::ROW) R = &P; else if (P.type == Pass::COL) Cc = &P;
 	}
 	if (!R || !Cc) return;
@@ -1170,7 +1173,7 @@ bool sparse_order(const dspfft_plan_s *pl, const std::vector<Pass> &passes, bool
 	const Pass &PC = passes[order[0]], &PR = passes[order[1]];
 	const bool col_ok = PC.type == Pass::COL && (split ? PC.half : PC.has_spec), row_ok = PR.type == Pass::ROW && (split ? PR.pair : PR.has_spec);
 	const PassGeom &gc = split ? PC.hpa : PC.spa, &gr = PR.spa;
-	const bool ok = col_ok && row_ok && PC.hostloop.empty() && PR.hostloop.empty() && gc.nb0 == 1 && gc.nb1 == 1 && gr.nb1 == 1 && gr.nb0 == gc.N &&
+	const bool ok = col_ok && row_ok && PC.hostloop.empty() && PR.hostloop.empty() && !gr.sb2_in && !gr.sb2_out && gc.nb0 == 1 && gc.nb1 == 1 && gr.nb1 == 1 && gr.nb0 == gc.N &&
 	                gr.N * gr.C == gc.ninner && gr.sb0_in == gc.ninner && gc.es_in == gc.ninner && gc.es_out == gc.ninner && gc.ninner % gc.K == 0 && (gc.K & (gc.K - 1)) == 0;
 	if (!ok) { order[0] = 0; order[1] = 1; }
 	return ok;
@@ -1214,7 +1217,7 @@ int execute_masked_accumulate_t(dspfft_plan pl, const R *d_in, R *d_work, R *d_a
 	const std::vector<Pass> &passes = split_ok ? pl->split : pl->passes;
 	const size_t np = passes.size();
 	for (const Pass &P : passes)
-		if (!P.hostloop.empty()) return fail(-2, "masked/accumulating execution is not available for plans that need a host-side batch loop");
+		if (!P.hostloop.empty() || P.pa.sb2_in || P.pa.sb2_out) return fail(-2, "masked/accumulating execution is not available for plans with more than two batch levels");
 	// Sparse frames: one image, a specialised column pass first and a specialised row pass over the same dense rows second.  The
 	// column pass flags the tiles none of whose coefficients belongs to this frame and leaves them alone; the row pass reads zeros
 	// there.  At BASELINE config 4 (zigzag, 32 frames) a frame touches about half of the columns.
@@ -1262,7 +1265,7 @@ extern "C" int dspfft_execute_sum2(dspfft_plan pa, dspfft_plan pb, const float *
 	auto one_row = [](const dspfft_plan_s *pl) {
 		if (pl->passes.size() != 1 || !pl->split.empty() || pl->has_block) return false;
 		const Pass &P = pl->passes[0];
-		return P.type == Pass::ROW && P.has_spec && !P.jit && P.hostloop.empty() && pl->kinds[P.axis] == DSPFFT_REDFT01;
+		return P.type == Pass::ROW && P.has_spec && !P.jit && P.hostloop.empty() && !P.pa.sb2_in && !P.pa.sb2_out && pl->kinds[P.axis] == DSPFFT_REDFT01;
 	};
 	if (one_row(pa) && one_row(pb)) {
 		const Pass &A = pa->passes[0], &B = pb->passes[0];

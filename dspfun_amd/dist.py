@@ -88,18 +88,38 @@ class SlabDCT3D:
             self.inv_y = u(Plan.guru([(h, w, w)], [(w, 1, 1), (dl, h * w, h * w)], [REDFT01], lib=lib), False).set_scale(1.0 / (8.0 * d * h * w))
 
     # ---- plans that depend on a piece's row count (cached: at most three distinct counts occur) ----
-    def _plan_x(self, nrows, fwd):
-        """x pass over `nrows` rows of every one of my frames, between the frame layout [dl, h, w] and a block [dlp, ch, w] of
-        an exchange buffer"""
-        key = ("x", nrows, fwd)
+    def _plan_x(self, nrows, fwd, nblocks=1):
+        """x pass over `nrows` rows of every one of my frames, for `nblocks` consecutive destination (source) ranks in ONE launch: between
+        the frame layout [dl, h, w] (the blocks' rows hp rows apart) and the blocks [dlp, ch, w] of an exchange buffer (dlp*ch*w apart).
+        Round 3 launched one execution per rank: at 8 ranks x 4 pieces 32 launches of ~34 rows x 32 frames per plane and direction,
+        launch-bound before xGMI is; the third batch level of the row passes (PassGeom::sb2_*) makes it one per piece."""
+        key = ("x", nrows, fwd, nblocks)
         if key not in self._plans:
             w, h, ch = self.w, self.h, self.ch
+            img, blk = (nblocks, self.hp * w), (nblocks, self.dlp * ch * w)
             if fwd:
-                p = Plan.guru([(w, 1, 1)], [(nrows, w, w), (self.dl, h * w, ch * w)], [REDFT10], lib=self.lib)
+                dims = [(nrows, w, w), (self.dl, h * w, ch * w)] + ([(img[0], img[1], blk[1])] if nblocks > 1 else [])
+                p = Plan.guru([(w, 1, 1)], dims, [REDFT10], lib=self.lib)
             else:
-                p = Plan.guru([(w, 1, 1)], [(nrows, w, w), (self.dl, ch * w, h * w)], [REDFT01], lib=self.lib)
+                dims = [(nrows, w, w), (self.dl, ch * w, h * w)] + ([(img[0], blk[1], img[1])] if nblocks > 1 else [])
+                p = Plan.guru([(w, 1, 1)], dims, [REDFT01], lib=self.lib)
             self._plans[key] = self._u(p, fwd)
         return self._plans[key]
+
+    def _groups(self, p):
+        """runs of consecutive blocks whose piece p has the same number of rows: [(first block, blocks, rows)] -- all full blocks form
+        one run, a short last block its own, empty blocks none: at most two x-pass launches per piece whatever G is"""
+        out = []
+        for r in range(self.G):
+            y0, y1 = self._rows_of(r, p)
+            n = y1 - y0
+            if n <= 0:
+                continue
+            if out and out[-1][2] == n and out[-1][0] + out[-1][1] == r:
+                out[-1] = (out[-1][0], out[-1][1] + 1, n)
+            else:
+                out.append((r, 1, n))
+        return out
 
     def _plan_z(self, nrows, fwd):
         """z pass over the columns of `nrows` of my rows, between a received piece [G*dlp, ch, w] and coeffs [d, hl, w]"""
@@ -164,10 +184,9 @@ class SlabDCT3D:
                 self._plan_z(y1 - y0, True).execute(recv[p].data_ptr(), coeffs.data_ptr() + (y0 - self.y_lo) * self.w * es, stream=st)
 
         for p in range(self.P):
-            for r in range(self.G):
-                y0, y1 = self._rows_of(r, p)
-                if y1 > y0 and self.dl:
-                    self._plan_x(y1 - y0, True).execute(frames.data_ptr() + y0 * self.w * es, send[p, r].data_ptr(), stream=st)
+            for r0, nb, n in (self._groups(p) if self.dl else []):
+                y0 = self._rows_of(r0, p)[0]
+                self._plan_x(n, True, nb).execute(frames.data_ptr() + y0 * self.w * es, send[p, r0].data_ptr(), stream=st)
             work[p] = self._exchange(send[p], recv[p])
             if p > 0:
                 zpass(p - 1)
@@ -187,10 +206,9 @@ class SlabDCT3D:
         def xpass(p):
             if work[p] is not None:
                 work[p].wait()
-            for s in range(self.G):
-                y0, y1 = self._rows_of(s, p)
-                if y1 > y0 and self.dl:
-                    self._plan_x(y1 - y0, False).execute(recv[p, s].data_ptr(), frames.data_ptr() + y0 * self.w * es, stream=st)
+            for s0, nb, n in (self._groups(p) if self.dl else []):
+                y0 = self._rows_of(s0, p)[0]
+                self._plan_x(n, False, nb).execute(recv[p, s0].data_ptr(), frames.data_ptr() + y0 * self.w * es, stream=st)
 
         for p in range(self.P):
             y0, y1 = self._rows_of(self.rank, p)

@@ -53,5 +53,6 @@ def test_watchdog_prints_the_headline_when_the_extras_do_not_finish():
     env = {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533", "DSPFFT_BENCH_FORCE_DIST": "1"}
     d = run_bench(["--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--extras-timeout", "0.05"], env=env)
     assert d["value"] > 20000
+    assert d["ranks_seen_by_rccl"] == 1                     # the RCCL path ran (one rank): an all-reduce of ones
     assert "error" in d["motion_c5"] and "not finished" in d["motion_c5"]["error"]
     assert "error" in d["scan_c4"]

@@ -59,7 +59,10 @@ def _worker(rank, world, port, d, h, w, chunks, q):
 # a rank with no rows at all; one piece and more pieces than rows
 # world 4 and 8 (the node sizes the SCALE record uses) with h % G != 0 and d % G != 0: 16 x 27 x 8 on 4 and on 8 ranks, 10 frames on 8 ranks
 @pytest.mark.parametrize("d,h,w,world,chunks", [(8, 12, 10, 2, 1), (16, 30, 24, 2, 4), (6, 27, 10, 2, 3), (7, 10, 12, 3, 2), (4, 5, 8, 3, 8), (9, 2, 8, 3, 1),
-                                                (16, 27, 8, 4, 2), (16, 27, 8, 8, 3), (10, 12, 16, 8, 1)])
+                                                (16, 27, 8, 4, 2), (16, 27, 8, 8, 3), (10, 12, 16, 8, 1),
+                                                # BASELINE config 5's real chroma row count on 8 ranks: 540 rows = 7 blocks of 68 + one of 64, four pieces of 17
+                                                # rows (the short block's last piece has 13) -- width and depth reduced so that the emulation finishes in seconds
+                                                (8, 540, 8, 8, 4)])
 def test_slab_dct3d_gloo(d, h, w, world, chunks):
     import subprocess
     subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "emul")])
@@ -147,3 +150,50 @@ def test_channel_sharded_scan(world):
     assert sorted(n for _, n, _ in res) == ([1, 2] if world == 2 else [0, 1, 1, 1])          # 3 planes over the ranks
     for rank, _, errs in res:
         assert max(errs) < 1e-5, (rank, errs)
+
+
+def test_x_pass_launches_per_piece():
+    """one x-pass launch per piece for all full blocks (a third batch level of the row pass) + at most one for a short last block,
+    whatever the number of ranks (round 3: one per rank)"""
+    from dspfun_amd.dist import SlabDCT3D
+    for d, h, G, chunks in ((256, 540, 8, 4), (256, 1080, 8, 4), (16, 27, 8, 3), (10, 12, 16, 1), (7, 10, 3, 2)):
+        eng = SlabDCT3D.__new__(SlabDCT3D)
+        eng.G, eng.h, eng.hp = G, h, -(-h // G)
+        eng.ch = -(-eng.hp // max(1, min(chunks, eng.hp)))
+        eng.P = -(-eng.hp // eng.ch)
+        rows = 0
+        for p in range(eng.P):
+            g = eng._groups(p)
+            assert len(g) <= 2
+            covered = []
+            for r0, nb, n in g:
+                for r in range(r0, r0 + nb):
+                    y0, y1 = eng._rows_of(r, p)
+                    assert y1 - y0 == n and y0 == eng._rows_of(r0, p)[0] + (r - r0) * eng.hp
+                    covered.append(r)
+                    rows += n
+            assert covered == [r for r in range(G) if eng._rows_of(r, p)[1] > eng._rows_of(r, p)[0]]
+        assert rows == h
+
+
+def test_row_pass_with_three_batch_levels_matches_the_oracle():
+    """guru plan: transform along x, batch (rows, frames, blocks) with independent in / out strides -- ONE launch (no host loop)"""
+    sys.path.insert(0, HERE)
+    import ctypes as C
+    import oracle_lib as ol
+    from emul_lib import emul
+    from dspfun_amd.engine import Plan, REDFT10
+    L = emul()
+    w, nrows, dl, nb, h, hp, ch, dlp = 16, 3, 2, 3, 12, 4, 3, 2
+    x = ol.synth_f32(3, dl * h * w).reshape(dl, h, w)
+    out = np.full((nb, dlp, ch, w), np.float32(-7))
+    p = Plan.guru([(w, 1, 1)], [(nrows, w, w), (dl, h * w, ch * w), (nb, hp * w, dlp * ch * w)], [REDFT10], lib=L)
+    assert "hostloop" not in p.describe()
+    src = np.ascontiguousarray(x)
+    p.execute(src.ctypes.data, out.ctypes.data)
+    for b in range(nb):
+        for f in range(dl):
+            for y in range(nrows):
+                ref = ol.r2r_many(x[f, b * hp + y].astype(np.float64), [w], [ol.REDFT10])
+                assert np.abs(out[b, f, y] - ref).max() <= 1e-5 * np.abs(ref).max()
+    assert np.all(out[:, :, nrows:, :] == -7) if ch > nrows else True
