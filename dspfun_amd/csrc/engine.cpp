@@ -517,7 +517,12 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 		if (ok) ok = build_fft(N / 2, F, pos);
 		if (ok) {
 			const int L = N / 2;
-			if ((size_t)L * C * 2 * es > maxlds) ok = false;       // the line's C signals sit in LDS together; longer lines go to the column pass
+			// the line's C signals sit in LDS together; longer lines go to the column pass -- unless the line has listed channel-line kernels
+			// (one channel per workgroup: 7680 x 3 doubles, spec_list.h)
+			if ((size_t)L * C * 2 * es > maxlds) {
+				SpecInfo si;
+				ok = pl->f64 && C > 1 && be_find_spec_f64(0, N, C, &si) && si.chan;
+			}
 			if (ok) {
 				std::vector<Dim> lines;
 				for (size_t i = 0; i < others.size(); i++) if ((int)i != cdim) lines.push_back(others[i]);

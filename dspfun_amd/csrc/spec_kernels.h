@@ -376,12 +376,11 @@ __global__ void __launch_bounds__(S::T, rt_waves_per_simd<S>()) col_roundtrip_ke
 template <class S, int KIND>
 int launch_row_spec(const typename S::PA &a, int nwork, void *stream)
 {
-	static DevOnce once;
-	if (int lds_rc = allow_lds_dev(once, S::LDS, row_spec_kernel<S, KIND, false>, row_spec_kernel<S, KIND, true>)) return lds_rc;
 	typedef typename chan_lines_of<typename S::Re, S::N, S::C>::type CH;
+	constexpr bool whole_fits = S::LDS <= 160 * 1024;       // a 7680 x 3 double line does not: it exists as channel lines only
 	if constexpr (!std::is_void<CH>::value) {
 		// DSPFFT_ROW_CHAN=0 keeps the interleaved line in one workgroup (A/B runs)
-		if (chan_lines_enabled()) {
+		if (chan_lines_enabled() || !whole_fits) {
 			static DevOnce conce;
 			if (int c_rc = allow_lds_dev(conce, CH::LDS, row_chan_kernel<CH, KIND, false>, row_chan_kernel<CH, KIND, true>)) return c_rc;
 			if (is_plain(a)) hipLaunchKernelGGL((row_chan_kernel<CH, KIND, true>), dim3(nwork * CH::GS), dim3(CH::T), CH::LDS, (hipStream_t)stream, a, nwork);
@@ -390,22 +389,28 @@ int launch_row_spec(const typename S::PA &a, int nwork, void *stream)
 			return 0;
 		}
 	}
-	if constexpr (persist_ok<S>()) {
-		// DSPFFT_ROW_PERSIST=0 keeps one workgroup per line (A/B runs)
-		static const int on = []() { const char *e = getenv("DSPFFT_ROW_PERSIST"); return e ? atoi(e) : 1; }();
-		const int cus = device_cus();
-		if (on && is_plain(a) && nwork > cus) {
-			static DevOnce ponce;
-			if (int p_rc = allow_lds_dev(ponce, persist_lds<S>(), row_persist_kernel<S, KIND>)) return p_rc;
-			hipLaunchKernelGGL((row_persist_kernel<S, KIND>), dim3(cus), dim3(S::T), persist_lds<S>(), (hipStream_t)stream, a, nwork);
-			HIPCHK(hipGetLastError());
-			return 0;
+	if constexpr (!whole_fits) {
+		return -1;          // (the interleaved kernels of such a line are never instantiated)
+	} else {
+		static DevOnce once;
+		if (int lds_rc = allow_lds_dev(once, S::LDS, row_spec_kernel<S, KIND, false>, row_spec_kernel<S, KIND, true>)) return lds_rc;
+		if constexpr (persist_ok<S>()) {
+			// DSPFFT_ROW_PERSIST=0 keeps one workgroup per line (A/B runs)
+			static const int on = []() { const char *e = getenv("DSPFFT_ROW_PERSIST"); return e ? atoi(e) : 1; }();
+			const int cus = device_cus();
+			if (on && is_plain(a) && nwork > cus) {
+				static DevOnce ponce;
+				if (int p_rc = allow_lds_dev(ponce, persist_lds<S>(), row_persist_kernel<S, KIND>)) return p_rc;
+				hipLaunchKernelGGL((row_persist_kernel<S, KIND>), dim3(cus), dim3(S::T), persist_lds<S>(), (hipStream_t)stream, a, nwork);
+				HIPCHK(hipGetLastError());
+				return 0;
+			}
 		}
+		if (is_plain(a)) hipLaunchKernelGGL((row_spec_kernel<S, KIND, true>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a);
+		else hipLaunchKernelGGL((row_spec_kernel<S, KIND, false>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a);
+		HIPCHK(hipGetLastError());
+		return 0;
 	}
-	if (is_plain(a)) hipLaunchKernelGGL((row_spec_kernel<S, KIND, true>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a);
-	else hipLaunchKernelGGL((row_spec_kernel<S, KIND, false>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a);
-	HIPCHK(hipGetLastError());
-	return 0;
 }
 template <class S, int KIND>
 int launch_col_spec(const typename S::PA &a, int nwork, void *stream)

@@ -103,7 +103,8 @@
 	X(2048, 3, 512, 4, 16, 16)       \
 	X(1280, 3, 256, 4, 10, 16)       \
 	X(1024, 3, 256, 4, 8, 16)        \
-	X(1280, 1, 128, 4, 10, 16)
+	X(1280, 1, 128, 4, 10, 16)       \
+	X(7680, 3, 1024, 16, 15, 16)     /* 184 KB a line: never launched as one -- runs as channel lines only (below); 8K frames of spec / zoom's default double build */
 
 // interleaved double lines that fill a CU's LDS on their own (92 KB: ONE workgroup per CU) run as CHANNEL LINES instead: one workgroup
 // per (line, channel) on a third of the LDS (dct_spec.h RowChanSpecT, chan_work): X(N, channels, THREADS, radices of N/2 ...).
@@ -118,7 +119,9 @@
 // in place over HBM-resident frames), 3840 x 3 floats (46 KB lines, three workgroups per CU already: 46-48 -> 57-61 us).
 #define DSPFFT_ROW_CHAN_SPECS_F64(X) \
 	X(3840, 3, 256, 12, 10, 16)      \
-	X(4096, 3, 256, 8, 16, 16)
+	X(4096, 3, 256, 8, 16, 16)       \
+	X(7680, 3, 256, 16, 15, 16)      /* round 4: the only row pass an 8K double line has (61 KB a channel line, two workgroups per CU): without it the axis ran as a
+	                                    runtime-geometry column pass, 4.05 ms per roundtrip = 10 % */
 
 #define DSPFFT_COL_SPECS_F64(X)      \
 	X(2160, 4, 512, 12, 12, 15)      \
@@ -129,7 +132,8 @@
 	X(2048, 4, 512, 8, 16, 16)       \
 	X(1440, 4, 512, 8, 12, 15)       \
 	X(1024, 8, 512, 4, 16, 16)       \
-	X(720, 8, 256, 6, 8, 15)
+	X(720, 8, 256, 6, 8, 15)         \
+	X(4320, 4, 1024, 2, 12, 12, 15)  /* round 4: 8K double frames (138 KB tiles of 4 doubles, one workgroup per CU) */
 
 // ---- zoom's x stage on the duo row kernel (dct_duo.h ZoomXLeanT, RGB lines): X(M, THREADS, radices of M/2 ...) ----
 // M = scaled line length; the last radix RL is odd and THREADS = (M/2) / RL (one last-stage butterfly per thread), a multiple of 64.

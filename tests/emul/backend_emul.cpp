@@ -171,7 +171,7 @@ int launch_row_spec(const typename S::PA &a, int nwork, void *)
 	// channel lines (spec_kernels.h row_chan_kernel): one "workgroup" per (line, channel), in the order chan_work hands them out
 	typedef typename chan_lines_of<typename S::Re, S::N, S::C>::type CH;
 	if constexpr (!std::is_void<CH>::value) {
-		if (chan_lines_enabled()) {
+		if (chan_lines_enabled() || S::LDS > 160 * 1024) {
 			std::vector<unsigned char> clds(CH::LDS + 32);
 			typename CH::CX *planes = (typename CH::CX *)(((uintptr_t)clds.data() + 31) & ~(uintptr_t)31);
 			for (int wg = 0; wg < nwork * CH::GS; wg++) {

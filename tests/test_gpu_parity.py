@@ -353,6 +353,41 @@ def test_f64_specialised_kernels_vs_port(gpu, h, w, c, kind):
     check(o.cpu().numpy(), ref, tol=TOL64)
 
 
+def test_f64_8k_frame_listed_kernels(gpu):
+    """7680 x 4320 x 3 doubles (an 8K frame of spec / zoom's default double build, 796 MB): rows as channel lines (the only row pass such a
+    line has), columns on the listed 4320 x 4 tile.  Forward coefficients against the definition at sampled positions (a matrix-vector
+    product per coefficient column, float64 on the host), roundtrip identity, and one timing line (informative)."""
+    from dspfun_amd import Plan
+    h, w, c = 4320, 7680, 3
+    x = ol.synth_f32(0xD5F0004, h * w * c).astype(np.float64).reshape(h, w, c) - 0.5
+    fwd = Plan.image(h, w, c, 5, dtype="f64")
+    inv = Plan.image(h, w, c, 4, dtype="f64").set_scale(1.0 / (4.0 * w * h))
+    assert "ROW* f64 N=7680 C=3" in fwd.describe() and "channel lines" in fwd.describe() and "COL* f64 N=4320" in fwd.describe(), fwd.describe()
+    d = gpu.from_numpy(x).to("cuda:0")
+    fwd.execute(d.data_ptr())
+    gpu.cuda.synchronize()
+    yy = np.arange(h) + 0.5
+    xx = np.arange(w) + 0.5
+    for ky, kx in ((0, 0), (1, 0), (0, 1), (7, 11), (4319, 7679), (2160, 3840), (4000, 13), (5, 7000)):
+        col = np.cos(np.pi * xx * kx / w)
+        row = np.cos(np.pi * yy * ky / h)
+        ref = 4.0 * np.einsum("y,yc->c", row, np.einsum("yxc,x->yc", x, col))
+        got = d[ky, kx].cpu().numpy()
+        assert np.abs(got - ref).max() <= 1e-11 * (4.0 * h * w) ** 0.5, (ky, kx, got, ref)
+    inv.execute(d.data_ptr())
+    gpu.cuda.synchronize()
+    assert float((d.cpu() - gpu.from_numpy(x)).abs().max()) <= 1e-13
+    a, b = gpu.cuda.Event(enable_timing=True), gpu.cuda.Event(enable_timing=True)
+    for _ in range(5):
+        fwd.execute(d.data_ptr()); inv.execute(d.data_ptr())
+    a.record()
+    for _ in range(20):
+        fwd.execute(d.data_ptr()); inv.execute(d.data_ptr())
+    b.record(); gpu.cuda.synchronize()
+    ms = a.elapsed_time(b) / 20
+    print(f"8K f64 roundtrip: {ms:.3f} ms = {96.0 * w * h / ms / 1e6 / 8000 * 100:.1f} % of 8 TB/s at 96 B/pixel")
+
+
 @pytest.mark.parametrize("h", [2160, 27, 5])
 def test_f64_channel_lines_equal_the_interleaved_kernel(gpu, h, monkeypatch):
     """3840-pixel RGB double lines run one workgroup per (line, channel) (dct_spec.h RowChanSpecT; the three channel lines of a line

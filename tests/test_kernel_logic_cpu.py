@@ -277,6 +277,20 @@ def test_f64_image_plan(h, w, c, kind):
         assert relerr(got32, ref) > 100 * TOL64
 
 
+@pytest.mark.parametrize("kind", [REDFT10, REDFT01])
+def test_f64_8k_lines_run_as_channel_lines_only(kind, monkeypatch):
+    """a 7680 x 3 double line is 184 KB -- more than a CU's LDS: it has no interleaved kernel, only channel lines (round 4), and those
+    run even where DSPFFT_ROW_CHAN=0 would switch channel lines off"""
+    monkeypatch.setenv("DSPFFT_ROW_CHAN", "0")
+    h, w, c = 5, 7680, 3
+    x = ol.synth_f32(77, h * w * c).astype(np.float64).reshape(h, w, c) * (1 + 2.0 ** -31)
+    p = Plan.image(h, w, c, kind, lib=emul(), dtype="f64")
+    assert "ROW* f64 N=7680 C=3" in p.describe() and "3 channel lines" in p.describe(), p.describe()
+    got = run64(p, x.copy())
+    ref = ol.dct2d_interleaved(x, kind, impl="port")
+    assert relerr(got, ref) < TOL64
+
+
 @pytest.mark.parametrize("N", [2, 6, 16, 30, 64, 270, 1080, 3840, 1, 3, 17, 45, 97, 135])
 def test_f64_1d_lengths(N):
     x = ol.synth_f32(N, N).astype(np.float64) * (1 + 2.0 ** -30)
