@@ -122,6 +122,105 @@ __global__ void __launch_bounds__(256) gemm_nt_f32_mfma(const float *__restrict_
 		}
 }
 
+// ---- round 4: the same product with its operands staged by LDS-DMA (global_load_lds_dwordx4) in K-tiles of 32 ----
+// 128 x 128 x 32 block tile, 256 threads = 2 x 2 waves of 64 x 64 (2 x 2 MFMA 32x32x2 tiles each), two LDS buffers of 32 KB.
+// The kernel above stages through registers one 8-deep K-tile ahead: 16 MFMAs (1024 cycles per wave) between barriers, less than a
+// global load's latency, so every K-tile ends waiting for the next one's operands (MfmaUtil 0.58-0.71).  Here a K-tile is 64 MFMAs per
+// wave (4096 cycles): the DMA of tile t + 1 is issued before the MFMAs of tile t and has landed when they end; no staging registers, no
+// ds_write pass.
+// LDS image of an operand tile (lane-linear per DMA instruction: its destination is base + lane x 16 bytes): [32-row block][k-group of 8]
+// [k-half lk][row li] x 16 bytes, i.e. DMA lane lk * 32 + li fetches the four floats k0 + 8 g + 4 lk .. + 3 of row 32 blk + li -- exactly the
+// float4 that lane (li, lk) of the MFMA reads for k-group g (consecutive lanes, consecutive 16 bytes: conflict-free ds_read_b128).
+// Rows beyond M / N fetch a valid row (their products are never stored); k beyond K fetches a page of zeros.
+// NB = 3 (zoom's second product: three colour channels that share the A operand, stored interleaved, cs = 3): ONE workgroup computes the
+// tile for all three channels -- three accumulator sets, the A fragments read once for the three -- and stores whole pixels (12 bytes per
+// lane, 384 contiguous bytes per row and half-wave) instead of three workgroups writing a third of every cache line each.  Built and
+// measured SLOWER (396 registers: one workgroup per CU, nothing beside a wave's own LDS waits): off unless DSPFFT_GEMM_NB3=1.
+template <int NB>
+__global__ void __launch_bounds__(256, NB == 1 ? 2 : 1) gemm_nt_f32_mfma_dma(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
+                                                                             int M, int N, int K, long long lda, long long ldb, long long ldc, int cs,
+                                                                             long long sa, long long sb, long long sc, float alpha, const float *zero_page, int ntn)
+{
+	constexpr int BKD = 32, G = BKD / 8, OPB = 128 * BKD;            // floats per operand tile
+	extern __shared__ __attribute__((aligned(16))) float smem[];     // [2 buffers][A tile | NB B tiles]
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int wm = wave >> 1, wn = wave & 1;
+	const int tile = blockIdx.x, batch = NB == 1 ? (int)blockIdx.z : 0;
+	const int tm = tile / ntn, tn = tile - tm * ntn;
+	const int bm = tm * 128, bn = tn * 128;
+	A += (long long)batch * sa; B += (long long)batch * sb; C += (long long)batch * sc;
+
+	// DMA: wave w stages 32-row block w of A and of (each) B: G instructions each per K-tile
+	const int li = lane & 31, lk = lane >> 5;
+	const int arow = bm + 32 * wave + li, brow = bn + 32 * wave + li;
+	const float *ap = A + (long long)(arow < M ? arow : M - 1) * lda + 4 * lk;
+	const float *bp = B + (long long)(brow < N ? brow : N - 1) * ldb + 4 * lk;
+	auto stage = [&](int buf, int k0) {
+		float *as = smem + buf * (1 + NB) * OPB + wave * (32 * BKD);
+#pragma unroll
+		for (int g = 0; g < G; g++) {
+			const int k = k0 + 8 * g + 4 * lk;
+			const float *pa = k < K ? ap + k0 + 8 * g : zero_page;
+			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)pa, (__attribute__((address_space(3))) void *)(as + g * 256), 16, 0, 0);
+#pragma unroll
+			for (int z = 0; z < NB; z++) {
+				const float *pb = k < K ? bp + z * sb + k0 + 8 * g : zero_page;
+				__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)pb, (__attribute__((address_space(3))) void *)(as + (1 + z) * OPB + g * 256), 16, 0, 0);
+			}
+		}
+	};
+
+	f32x16 acc[NB][2][2];
+	for (int z = 0; z < NB; z++) for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int r = 0; r < 16; r++) acc[z][i][j][r] = 0.f;
+	const int nk = (K + BKD - 1) / BKD;
+	stage(0, 0);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	for (int kt = 0; kt < nk; kt++) {
+		const int cur = kt & 1;
+		if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BKD);
+		const float *as = smem + cur * (1 + NB) * OPB;
+#pragma unroll
+		for (int g = 0; g < G; g++) {
+			float4 a[2];
+#pragma unroll
+			for (int i = 0; i < 2; i++) a[i] = *reinterpret_cast<const float4 *>(as + (2 * wm + i) * (32 * BKD) + g * 256 + lane * 4);
+#pragma unroll
+			for (int z = 0; z < NB; z++) {
+				float4 b[2];
+#pragma unroll
+				for (int i = 0; i < 2; i++) b[i] = *reinterpret_cast<const float4 *>(as + (1 + z) * OPB + (2 * wn + i) * (32 * BKD) + g * 256 + lane * 4);
+#pragma unroll
+				for (int s = 0; s < 4; s++) {
+					const float av[2] = {s == 0 ? a[0].x : s == 1 ? a[0].y : s == 2 ? a[0].z : a[0].w, s == 0 ? a[1].x : s == 1 ? a[1].y : s == 2 ? a[1].z : a[1].w};
+					const float bv[2] = {s == 0 ? b[0].x : s == 1 ? b[0].y : s == 2 ? b[0].z : b[0].w, s == 0 ? b[1].x : s == 1 ? b[1].y : s == 2 ? b[1].z : b[1].w};
+#pragma unroll
+					for (int i = 0; i < 2; i++)
+#pragma unroll
+						for (int j = 0; j < 2; j++) acc[z][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[z][i][j], 0, 0, 0);
+				}
+			}
+		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile has landed (issued a K-tile of MFMAs ago)
+		__syncthreads();
+	}
+	// C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+	for (int i = 0; i < 2; i++)
+		for (int j = 0; j < 2; j++) {
+			const int n = bn + wn * 64 + j * 32 + li;
+			if (n >= N) continue;
+			for (int r = 0; r < 16; r++) {
+				const int m = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+				if (m >= M) continue;
+				if constexpr (NB == 3) {
+					typedef float f3 __attribute__((ext_vector_type(3)));
+					f3 v; v.x = alpha * acc[0][i][j][r]; v.y = alpha * acc[1][i][j][r]; v.z = alpha * acc[2][i][j][r];
+					__builtin_memcpy(C + (long long)m * ldc + (long long)n * 3, &v, 12);       // sc = 1, cs = 3: the three channels of a pixel
+				} else C[(long long)m * ldc + (long long)n * cs] = alpha * acc[0][i][j][r];
+			}
+		}
+}
+
 // zoom/zoom.c:36-68 with column 0 = 1/2 (the halved DC term) and columns 1.. = the reference's basis
 __global__ void zoom_basis_kernel(float *basis, int type, double scale_num, double scale_den, double offset, size_t nvectors, size_t len, size_t nc)
 {
@@ -224,6 +323,30 @@ extern "C" int dspfft_gemm_nt_f32(const float *A, const float *B, float *C, int 
 		dim3 g64((N + 63) / 64, (M + 63) / 64, batch);
 		if (K >= 16) hipLaunchKernelGGL((gemm_nt_f32_mfma<16, 1>), g64, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, cs, sa, sb, sc, alpha, 0, 0ll, 0ll, 0ll);
 		else hipLaunchKernelGGL((gemm_nt_f32_mfma<8, 1>), g64, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, cs, sa, sb, sc, alpha, 0, 0ll, 0ll, 0ll);
+		return hipGetLastError() == hipSuccess ? 0 : -4;
+	}
+	// operands by LDS-DMA in K-tiles of 32 (round 4) where every 16-byte piece is aligned; DSPFFT_GEMM_DMA=0: the register-staged kernel (A/B runs)
+	static const int dma = getenv("DSPFFT_GEMM_DMA") ? atoi(getenv("DSPFFT_GEMM_DMA")) : 1;
+	if (dma && K >= 32 && ((lda | ldb | sa | sb) & 3) == 0 && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0) {
+		static thread_local float *zero_page[32] = {};
+		int dev = 0;
+		if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
+		if (!zero_page[dev]) {
+			if (hipMalloc((void **)&zero_page[dev], 256) != hipSuccess || hipMemset(zero_page[dev], 0, 256) != hipSuccess) { snprintf(g_zerr, sizeof g_zerr, "no memory for the zero page"); return -3; }
+		}
+		const int ntn = (int)grid.x, ntiles = (int)(grid.x * grid.y);
+		// three batches that share A and interleave their outputs element by element (zoom's second product): one workgroup per tile for all three
+		static const int nb3 = getenv("DSPFFT_GEMM_NB3") ? atoi(getenv("DSPFFT_GEMM_NB3")) : 0;      // 1: one workgroup per tile for all three channels (measured slower: 2.26 against 2.11 ms for zoom's second product -- one workgroup per CU; profiles/r04_gemm.txt)
+		const bool b3 = nb3 && batch == 3 && cs == 3 && sa == 0 && sc == 1;
+		const size_t lds = 2 * (size_t)(b3 ? 4 : 2) * 128 * 32 * sizeof(float);
+		static thread_local bool attr[2] = {false, false};
+		if (!attr[b3]) {
+			const void *k = b3 ? reinterpret_cast<const void *>(gemm_nt_f32_mfma_dma<3>) : reinterpret_cast<const void *>(gemm_nt_f32_mfma_dma<1>);
+			if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { snprintf(g_zerr, sizeof g_zerr, "cannot raise the LDS limit"); return -4; }
+			attr[b3] = true;
+		}
+		if (b3) hipLaunchKernelGGL(gemm_nt_f32_mfma_dma<3>, dim3(ntiles, 1, 1), dim3(256), lds, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, cs, sa, sb, sc, alpha, zero_page[dev], ntn);
+		else hipLaunchKernelGGL(gemm_nt_f32_mfma_dma<1>, dim3(ntiles, 1, batch), dim3(256), lds, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, cs, sa, sb, sc, alpha, zero_page[dev], ntn);
 		return hipGetLastError() == hipSuccess ? 0 : -4;
 	}
 	static const int bk = getenv("DSPFFT_GEMM_BK") ? atoi(getenv("DSPFFT_GEMM_BK")) : 8;

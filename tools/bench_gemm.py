@@ -4,8 +4,9 @@ import torch
 from dspfun_amd import _lib
 from dspfun_amd.zoom import Zoom
 L = _lib.load()
-def t(fn, reps=5):
-    fn(); torch.cuda.synchronize()
+def t(fn, reps=40):
+    for _ in range(20): fn()
+    torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(reps): fn()
@@ -32,3 +33,13 @@ print("gemm2 4320x7680x1080 cs=1 ms", ms, "TF", 2 * 4320 * 7680 * 1080 / ms / 1e
 A3 = torch.rand(8192, 4096, device="cuda:0"); B3 = torch.rand(8192, 4096, device="cuda:0"); C3 = torch.empty(8192, 8192, device="cuda:0")
 ms = t(lambda: L.dspfft_gemm_nt_f32(A3.data_ptr(), B3.data_ptr(), C3.data_ptr(), 8192, 8192, 4096, 4096, 4096, 8192, 1, 1, 0, 0, 0, 1.0, None))
 print("gemm 8192x8192x4096 ms", ms, "TF", 2 * 8192 * 8192 * 4096 / ms / 1e9)
+
+# the two products of a config-3 frame as dspfft_zoom_product launches them: three channels per launch
+planes = torch.rand(3, h, w, device="cuda:0"); Tt = torch.empty(3, vw, ch, device="cuda:0")
+ms = t(lambda: L.dspfft_gemm_nt_f32(xb.data_ptr(), planes.data_ptr(), Tt.data_ptr(), vw, ch, cw, cw, w, ch, 1, 3, 0, w * h, vw * ch, 1.0, None))
+print("product 1 (7680x1080x1920 x 3 channels) ms", ms, "TF", 3 * 2 * vw * ch * cw / ms / 1e9)
+ms = t(lambda: L.dspfft_gemm_nt_f32(yb.data_ptr(), Tt.data_ptr(), out.data_ptr(), vh, vw, ch, ch, ch, vw * 3, 3, 3, 0, vw * ch, 1, 1.0, None))
+print("product 2 (4320x7680x1080 x 3 channels, interleaved store) ms", ms, "TF", 3 * 2 * vh * vw * ch / ms / 1e9)
+A4 = torch.rand(4096, 4096, device="cuda:0"); B4 = torch.rand(4096, 4096, device="cuda:0"); C4 = torch.empty(4096, 4096, device="cuda:0")
+ms = t(lambda: L.dspfft_gemm_nt_f32(A4.data_ptr(), B4.data_ptr(), C4.data_ptr(), 4096, 4096, 4096, 4096, 4096, 4096, 1, 1, 0, 0, 0, 1.0, None))
+print("gemm 4096^3 ms", ms, "TF", 2 * 4096 ** 3 / ms / 1e9)
