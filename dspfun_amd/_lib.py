@@ -17,14 +17,14 @@ SYMBOLS = [
     "dspfft_plan_many_r2r_f64", "dspfft_plan_set_scale_f64", "dspfft_plan_set_axis_scale0_f64", "dspfft_execute_f64", "dspfft_execute_masked_accumulate_f64", "dspfft_plan_scan_prepare", "dspfft_plan_set_input_window", "dspfft_plan_set_output_alternate", "dspfft_set_plan_effort", "dspfft_get_plan_effort",
     "dspfft_plan_many_r2r_ordered", "dspfft_plan_guru_r2r", "dspfft_execute_roundtrip", "dspfft_execute_roundtrip_u8",
     "dspfft_execute", "dspfft_plan_num_passes", "dspfft_execute_pass", "dspfft_destroy_plan", "dspfft_plan_describe", "dspfft_plan_algorithmic_bytes",
-    "dspfft_execute_many", "dspfft_execute_many_repeat", "dspfft_execute_sum2", "dspfft_cosrows_create", "dspfft_cosrows_execute", "dspfft_cosrows_destroy", "dspfft_plan_set_input_modulation", "dspfft_stream_create", "dspfft_stream_destroy", "dspfft_stream_synchronize", "dspfft_event_create", "dspfft_event_destroy", "dspfft_event_synchronize", "dspfft_event_elapsed_ms",
+    "dspfft_execute_many", "dspfft_execute_many_repeat", "dspfft_execute_sum2", "dspfft_cosrows_create", "dspfft_cosrows_execute", "dspfft_cosrows_destroy", "dspfft_cztrows_create", "dspfft_cztrows_execute", "dspfft_cztrows_length", "dspfft_cztrows_destroy", "dspfft_transpose_f32", "dspfft_plan_set_input_modulation", "dspfft_stream_create", "dspfft_stream_destroy", "dspfft_stream_synchronize", "dspfft_event_create", "dspfft_event_destroy", "dspfft_event_synchronize", "dspfft_event_elapsed_ms",
     "dspfft_last_error", "dspfft_version",
     "dspfft_scan_zigzag", "dspfft_scan_zigzag_frame_ids", "dspfft_execute_masked_accumulate", "dspfft_scan_scatter", "dspfft_accumulate", "dspfft_broadcast_dc",
     "dspfft_scan_limit", "dspfft_scan_max_interval", "dspfft_scan_coord_slots", "dspfft_scan_owner_index", "dspfft_scan_frame_ids", "dspfft_scan_coords", "dspfft_scan_stamp",
     "dspfft_scan_index_to_frame_ids", "dspfft_scan_magnitude_work_bytes", "dspfft_scan_magnitude_index",
     "dspfft_u8_to_f32", "dspfft_f32_to_u8",
     "dspfft_zoom_ncomponents", "dspfft_zoom_basis", "dspfft_zoom_work_floats", "dspfft_zoom_product", "dspfft_gemm_nt_f32",
-    "dspfft_zoom_last_error", "dspfft_zoomfft_create", "dspfft_zoomfft_work_floats", "dspfft_zoomfft_execute", "dspfft_zoomfft_destroy", "dspfft_zoomfft_last_error",
+    "dspfft_zoom_last_error", "dspfft_zoomfft_create", "dspfft_zoomfft_work_floats", "dspfft_zoomfft_execute", "dspfft_zoomfft_destroy", "dspfft_zoomfft_last_error", "dspfft_zoomczt_create", "dspfft_zoomczt_work_floats", "dspfft_zoomczt_execute", "dspfft_zoomczt_destroy",
     "dspfft_applybasis_work_floats", "dspfft_applybasis_partsums",
     "dspfft_applybasis_work_floats_ex", "dspfft_applybasis_partsums_ex", "dspfft_applybasis_render",
     "dspfft_motion_load_u8", "dspfft_motion_store_u8", "dspfft_motion_topn_work_bytes", "dspfft_motion_topn", "dspfft_motion_last_error",
@@ -60,6 +60,12 @@ def bind(lib):
     lib.dspfft_cosrows_execute.argtypes = [vp, vp, C.c_longlong, vp, C.c_longlong, C.c_double, C.c_double, vp]
     lib.dspfft_cosrows_destroy.argtypes = [vp]
     lib.dspfft_cosrows_destroy.restype = None
+    lib.dspfft_cztrows_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.dspfft_cztrows_execute.argtypes = [vp, vp, C.c_longlong, C.c_longlong, C.c_int, vp, C.c_longlong, C.c_longlong, C.c_int, C.c_double, C.c_double, C.c_double, vp]
+    lib.dspfft_cztrows_length.argtypes = [vp]
+    lib.dspfft_cztrows_destroy.argtypes = [vp]
+    lib.dspfft_cztrows_destroy.restype = None
+    lib.dspfft_transpose_f32.argtypes = [vp, C.c_longlong, vp, C.c_longlong, C.c_int, C.c_int, vp]
     lib.dspfft_plan_set_input_modulation.argtypes = [vp, C.c_int, vp, C.c_int]
     lib.dspfft_plan_set_input_window.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     lib.dspfft_plan_set_output_alternate.argtypes = [vp, C.c_int, C.c_int]
@@ -135,6 +141,11 @@ def bind(lib):
         lib.dspfft_zoomfft_execute.argtypes = [vp, vp, C.c_double, C.c_double, vp, vp, vp]
         lib.dspfft_zoomfft_destroy.argtypes = [vp]
         lib.dspfft_zoomfft_last_error.restype = C.c_char_p
+        lib.dspfft_zoomczt_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
+        lib.dspfft_zoomczt_work_floats.restype = C.c_size_t
+        lib.dspfft_zoomczt_work_floats.argtypes = [vp]
+        lib.dspfft_zoomczt_execute.argtypes = [vp, vp, C.c_double, C.c_double, vp, vp, vp]
+        lib.dspfft_zoomczt_destroy.argtypes = [vp]
         lib.dspfft_spec_encode.argtypes = [vp, C.c_size_t, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, vp]
         lib.dspfft_ispec_decode.argtypes = [vp, C.c_size_t, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, vp]
         lib.dspfft_motion_filter.argtypes = [vp, ip, ip, ip, ip, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, vp, vp]

@@ -8,6 +8,7 @@
 #include "motion_filter.h"
 #include "dct_spec.h"
 #include "dct_duo.h"
+#include "dct_czt.h"
 #include "scan_core.h"
 #include "block_core.h"
 
@@ -83,6 +84,14 @@ int be_launch_row_sum2(int row_spec_id, const PassArgs &a, const PassArgs &b, in
 int be_find_zoomx(int M);
 int be_launch_zoomx(int id, const ZoomXArgs &a, int nsrc, bool clip, void *stream);
 int be_zoomx_tables(float *tab, int M, int cw, int nsrc, double theta, double scale, void *stream);
+// chirp-z rows (dct_czt.h, spec_list.h DSPFFT_CZT_SPECS): be_find_czt returns the id of the smallest listed convolution length P >= need (or -1);
+// be_czt_tables fills whichever of the a- (nc), e- (nout) and h- (P entries) tables is non-null; be_launch_czt_spectrum turns the h-table
+// (a.atab, a.nc = P, a.in = null) into the slot-ordered spectrum the row kernel multiplies by; be_transpose: out[c][r] = in[r][c]
+int be_find_czt(int need, int *P);
+int be_launch_czt_rows(int id, const CztArgs &a, void *stream);
+int be_launch_czt_spectrum(int id, const CztArgs &a, cf *hspec, void *stream);
+int be_czt_tables(cf *atab, cf *etab, cf *htab, int nc, int nout, int P, double omega, double phi, double scale, void *stream);
+int be_transpose(float *out, long long out_pitch, const float *in, long long in_pitch, int rows, int cols, void *stream);
 // fused column roundtrip: REDFT10 along the tile axis (af), pointwise filter, REDFT01 (ai); both passes share spec `id`
 int be_launch_roundtrip(int id, const PassArgs &af, const PassArgs &ai, const MotionFilter &filt, unsigned long long *coded, int nwg, void *stream);
 

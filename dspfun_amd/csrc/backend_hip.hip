@@ -39,6 +39,10 @@ namespace dspfft {
 	extern template int launch_col_spec<ColSpecT<double, N, K, T, __VA_ARGS__>, 1>(const PassArgsD &, int, void *);
 #define DSP_EXTERN_ZOOMX(M, T, ...) extern template int launch_zoomx<RowDuoT<M, T, __VA_ARGS__>, 3>(const ZoomXArgs &, int, bool, void *);
 DSPFFT_ZOOMX_SPECS(DSP_EXTERN_ZOOMX)
+#define DSP_EXTERN_CZT(P, T, ...) \
+	extern template int launch_czt_rows<CztSpecT<P, T, __VA_ARGS__>>(const CztArgs &, void *); \
+	extern template int launch_czt_spectrum<CztSpecT<P, T, __VA_ARGS__>>(const CztArgs &, cf *, void *);
+DSPFFT_CZT_SPECS(DSP_EXTERN_CZT)
 DSPFFT_ROW_SPECS_F64(DSP_EXTERN_ROW_D)
 DSPFFT_COL_SPECS_F64(DSP_EXTERN_COL_D)
 DSPFFT_ROW_SPECS(DSP_EXTERN_ROW)
@@ -367,6 +371,36 @@ int be_zoomx_tables(float *tab, int M, int cw, int nsrc, double theta, double sc
 {
 	const int items = nsrc * (M / 4 + 1);
 	hipLaunchKernelGGL(zoomx_table_kernel, dim3((items + 127) / 128), dim3(128), 0, (hipStream_t)stream, tab, M, cw, nsrc, theta, scale);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+__global__ void czt_tables_kernel(cf *atab, cf *etab, cf *htab, int nc, int nout, int P, double omega, double phi, double scale)
+{
+	const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	if (atab && i < nc) atab[i] = czt_a_entry(i, omega, phi);
+	if (etab && i < nout) etab[i] = czt_e_entry(i, omega, scale);
+	if (htab && i < P) htab[i] = czt_h_entry(i, P, nc, nout, omega);
+}
+int be_czt_tables(cf *atab, cf *etab, cf *htab, int nc, int nout, int P, double omega, double phi, double scale, void *stream)
+{
+	const int n = P > nout ? (P > nc ? P : nc) : (nout > nc ? nout : nc);
+	hipLaunchKernelGGL(czt_tables_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, atab, etab, htab, nc, nout, P, omega, phi, scale);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+// out[c][r] = in[r][c] for r < rows, c < cols (pitches in floats): 32 x 32 tiles through LDS
+__global__ void transpose_kernel(float *out, long long out_pitch, const float *in, long long in_pitch, int rows, int cols)
+{
+	__shared__ float tile[32][33];
+	const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+	for (int i = ty; i < 32; i += 8) if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = in[(long long)(r0 + i) * in_pitch + c0 + tx];
+	__syncthreads();
+	for (int i = ty; i < 32; i += 8) if (c0 + i < cols && r0 + tx < rows) out[(long long)(c0 + i) * out_pitch + r0 + tx] = tile[tx][i];
+}
+int be_transpose(float *out, long long out_pitch, const float *in, long long in_pitch, int rows, int cols, void *stream)
+{
+	hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, (hipStream_t)stream, out, out_pitch, in, in_pitch, rows, cols);
 	HIPCHK(hipGetLastError());
 	return 0;
 }

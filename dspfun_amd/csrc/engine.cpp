@@ -1343,6 +1343,73 @@ extern "C" void dspfft_cosrows_destroy(dspfft_cosrows p)
 	delete p;
 }
 
+// ---- chirp-z rows (include/dspfft.h dspfft_cztrows_*; dct_czt.h) ----
+struct dspfft_cztrows_s {
+	int nc, nout, lines, group, id, P;
+	void *W;                    // exp(-2 pi i t / P)
+	cf *atab, *etab, *htab, *hspec;
+	double omega_of_spectrum;   // the omega hspec was made for (NaN: none yet)
+};
+extern "C" int dspfft_cztrows_create(dspfft_cztrows *out, int nc, int nout, int lines, int group)
+{
+	if (!out) return fail(-1, "null plan pointer");
+	*out = nullptr;
+	if (nc < 1 || nout < 1 || lines < 1 || group < 1 || lines % group) return fail(-1, "bad arguments (nc %d, nout %d, lines %d, group %d)", nc, nout, lines, group);
+	int P = 0;
+	const int id = be_find_czt(nc + nout - 1, &P);
+	if (id < 0) return fail(-2, "no chirp-z row kernel for a convolution of %d points", nc + nout - 1);
+	dspfft_cztrows p = new dspfft_cztrows_s();
+	p->nc = nc; p->nout = nout; p->lines = lines; p->group = group; p->id = id; p->P = P;
+	p->omega_of_spectrum = std::nan("");
+	std::vector<cf> w((size_t)P);
+	const long double pi = 3.14159265358979323846264338327950288L;
+	for (int t = 0; t < P; t++) w[t] = cmk<float>((float)cosl(2 * pi * t / P), (float)-sinl(2 * pi * t / P));
+	p->W = be_alloc((size_t)P * sizeof(cf));
+	p->atab = (cf *)be_alloc(((size_t)nc + nout + 2 * (size_t)P) * sizeof(cf));
+	if (!p->W || !p->atab || be_upload(p->W, w.data(), w.size() * sizeof(cf))) {
+		if (p->W) be_free(p->W);
+		if (p->atab) be_free(p->atab);
+		delete p;
+		return fail(-3, "no device memory for the tables");
+	}
+	p->etab = p->atab + nc; p->htab = p->etab + nout; p->hspec = p->htab + P;
+	*out = p;
+	return 0;
+}
+extern "C" int dspfft_cztrows_length(dspfft_cztrows p) { return p ? p->P : 0; }
+extern "C" int dspfft_cztrows_execute(dspfft_cztrows p, const float *d_in, long long in_group, long long in_pitch, int es_in,
+                                      float *d_out, long long out_group, long long out_pitch, int es_out, double omega, double phi, double scale, void *stream)
+{
+	if (!p || !d_in || !d_out || es_in < 1 || es_out < 1) return fail(-1, "null plan or buffer, or a stride below 1");
+	if (3u & ((uintptr_t)d_in | (uintptr_t)d_out)) return fail(-1, "buffers must be 4-byte aligned");
+	const bool fresh = !(omega == p->omega_of_spectrum);
+	if (int rc = be_czt_tables(p->atab, p->etab, fresh ? p->htab : nullptr, p->nc, p->nout, p->P, omega, phi, scale, stream)) return fail(-4, "table kernel launch failed: backend code %d", rc);
+	CztArgs a;
+	a.in = nullptr; a.out = nullptr; a.atab = p->htab; a.hspec = nullptr; a.etab = nullptr; a.W = (const cf *)p->W;
+	a.in_pitch = a.out_pitch = a.in_group = a.out_group = 0; a.es_in = a.es_out = 1; a.nc = p->P; a.nout = 0; a.lines = 1; a.group = 1;
+	if (fresh) {
+		if (int rc = be_launch_czt_spectrum(p->id, a, p->hspec, stream)) return fail(-4, "kernel launch failed (chirp spectrum, P = %d): backend code %d", p->P, rc);
+		p->omega_of_spectrum = omega;
+	}
+	a.in = d_in; a.out = d_out; a.atab = p->atab; a.hspec = p->hspec; a.etab = p->etab;
+	a.in_pitch = in_pitch; a.out_pitch = out_pitch; a.in_group = in_group; a.out_group = out_group; a.es_in = es_in; a.es_out = es_out;
+	a.nc = p->nc; a.nout = p->nout; a.lines = p->lines; a.group = p->group;
+	if (int rc = be_launch_czt_rows(p->id, a, stream)) return fail(-4, "kernel launch failed (chirp-z rows, P = %d): backend code %d", p->P, rc);
+	return 0;
+}
+extern "C" void dspfft_cztrows_destroy(dspfft_cztrows p)
+{
+	if (!p) return;
+	be_free(p->W); be_free(p->atab);
+	delete p;
+}
+extern "C" int dspfft_transpose_f32(float *d_out, long long out_pitch, const float *d_in, long long in_pitch, int rows, int cols, void *stream)
+{
+	if (!d_out || !d_in || rows < 1 || cols < 1 || out_pitch < rows || in_pitch < cols) return fail(-1, "bad arguments");
+	if (int rc = be_transpose(d_out, out_pitch, d_in, in_pitch, rows, cols, stream)) return fail(-4, "kernel launch failed (transpose): backend code %d", rc);
+	return 0;
+}
+
 namespace {
 // a planar row pass that can take / produce 8-bit samples itself
 bool pass_has_u8(const Pass &P)

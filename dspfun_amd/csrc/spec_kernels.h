@@ -9,6 +9,7 @@
 #include "spec_list.h"
 #include "spec_fused.h"
 #include "dct_duo.h"
+#include "dct_czt.h"
 
 namespace dspfft {
 
@@ -215,6 +216,58 @@ __global__ void __launch_bounds__(S::T, WPE) zoomx_lean_kernel(const ZoomXArgs a
 		Z::phase_c_emit(a, bout, c, t, e, recv, st);
 		if (c + 1 < C) __syncthreads();                      // the plane is the next channel's
 	}
+}
+
+// ---- chirp-z rows (dct_czt.h): one workgroup per line, the line's circular convolution in one LDS plane ----
+template <class S> constexpr int czt_waves_per_simd() { const int w = (int)((160 * 1024) / S::LDS) * S::T / 256; return w < 1 ? 1 : w > 4 ? 4 : w; }
+template <class S>
+__global__ void __launch_bounds__(S::T, czt_waves_per_simd<S>()) czt_rows_kernel(const CztArgs a)
+{
+	extern __shared__ __attribute__((aligned(32))) unsigned char lds[];
+	cf *plane = reinterpret_cast<cf *>(lds);
+	const int tid = threadIdx.x;
+	long long bin, bout;
+	S::base(a, blockIdx.x, bin, bout);
+	PassArgs w;
+	w.W = a.W;                                               // the stages read nothing else
+	static_for<0, S::NPH>([&](auto ph) {
+		S::template phase<ph>(a, w, plane, bin, bout, tid);
+		if constexpr (ph + 1 < S::NPH) __syncthreads();
+	});
+}
+// FFT_P of the table in a.atab (P entries), in the slot order the forward stages leave: what czt_rows_kernel multiplies by in its MID phase
+template <class S>
+__global__ void __launch_bounds__(S::T, 1) czt_spectrum_kernel(const CztArgs a, cf *hspec)
+{
+	extern __shared__ __attribute__((aligned(32))) unsigned char lds[];
+	cf *plane = reinterpret_cast<cf *>(lds);
+	const int tid = threadIdx.x;
+	PassArgs w;
+	w.W = a.W;
+	S::f0(a, plane, 0, tid);
+	__syncthreads();
+	static_for<1, S::NS - 1>([&](auto I) { S::template fwd<I>(w, plane, tid); __syncthreads(); });
+	S::flast(plane, tid);
+	__syncthreads();
+	for (int i = tid; i < S::P; i += S::T) hspec[i] = plane[S::F::padded(i)];
+}
+template <class S>
+int launch_czt_rows(const CztArgs &a, void *stream)
+{
+	static DevOnce once;
+	if (int rc = allow_lds_dev(once, S::LDS, czt_rows_kernel<S>, czt_spectrum_kernel<S>)) return rc;
+	hipLaunchKernelGGL((czt_rows_kernel<S>), dim3(a.lines), dim3(S::T), S::LDS, (hipStream_t)stream, a);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+template <class S>
+int launch_czt_spectrum(const CztArgs &a, cf *hspec, void *stream)
+{
+	static DevOnce once;
+	if (int rc = allow_lds_dev(once, S::LDS, czt_rows_kernel<S>, czt_spectrum_kernel<S>)) return rc;
+	hipLaunchKernelGGL((czt_spectrum_kernel<S>), dim3(1), dim3(S::T), S::LDS, (hipStream_t)stream, a, hspec);
+	HIPCHK(hipGetLastError());
+	return 0;
 }
 
 // the same with 8-bit input (REDFT10) or quantised 8-bit output (REDFT01): planar rows only

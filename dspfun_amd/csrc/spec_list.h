@@ -145,3 +145,18 @@
 	X(2560, 256, 16, 16, 5)          /* 1280 x 2, 640 x 4 */ \
 	X(1920, 64, 8, 8, 15)            /* 960 x 2, 640 x 3, 480 x 4 */ \
 	X(1280, 128, 8, 16, 5)           /* 640 x 2, 320 x 4 */
+
+// ---- chirp-z rows (dct_czt.h): circular convolutions of P points, X(P, THREADS, radices of P ...) ----
+// A line of nc coefficients and nout samples runs on the smallest P >= nc + nout - 1 listed here (8 bytes a point in LDS: two workgroups per
+// CU up to P = 9600).  Longer lines than the last entry keep the dense product.
+#define DSPFFT_CZT_SPECS(X)          \
+	X(1200, 128, 8, 10, 15)          \
+	X(2400, 256, 16, 10, 15)         \
+	X(3600, 256, 16, 15, 15)         \
+	X(4800, 256, 8, 8, 15, 5)        \
+	X(5400, 256, 8, 9, 15, 5)        /* config 3's y axis: 1080 + 4320 - 1 */ \
+	X(7200, 512, 16, 10, 9, 5)       \
+	X(9600, 512, 16, 15, 8, 5)       /* config 3's x axis: 1920 + 7680 - 1 */ \
+	X(12000, 512, 16, 10, 15, 5)     \
+	X(14400, 512, 16, 15, 12, 5)     \
+	X(19200, 1024, 16, 16, 15, 5)

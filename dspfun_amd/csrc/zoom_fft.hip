@@ -389,3 +389,84 @@ extern "C" int dspfft_zoomfft_execute(dspfft_zoomfft z, const float *d_coeffs, d
 	if (hipGetLastError() != hipSuccess) { snprintf(g_err, sizeof g_err, "launch failed"); return -4; }
 	return 0;
 }
+
+// ---- any scale, offset and basis: chirp-z transforms along both axes (round 4; dspfft_cztrows_*, dct_czt.h) ----
+// zoom.c:49-61: sample b of an axis sits at k = alpha (b + offset) on a basis of N points: interpolated alpha = den / num, N = len;
+// native alpha = 1, N = len num / den; centered alpha = (len - 1) den / (len num - den), N = len.  Per axis
+//     out[b] = sum'_n C[n] cos(n (omega b + phi)),   omega = pi alpha / N,  phi = pi (alpha offset + 1/2) / N.
+// y first, on the cw columns the coefficients have: the coefficient block is transposed so that a column is a planar line, transformed
+// (ch -> vh samples), transposed back to rows of cw RGB pixels, and the x axis runs on those rows (one line per channel, the three
+// lines of a row on one XCD so that their interleaved stores meet in its L2).
+struct dspfft_zoomczt_s {
+	int w, h, type, vw, vh;
+	size_t cw, ch;
+	double xnum, xden, ynum, yden;
+	dspfft_cztrows rows_y, rows_x;
+};
+namespace {
+void czt_axis(int type, double num, double den, double len, double off, double &omega, double &phi)
+{
+	const double pi = 3.14159265358979323846;
+	if (len * num / den < 1) { num = 1; den = len; }          // zoom.c:37-40
+	double alpha, N;
+	if (type == 2) { alpha = 1.0; N = len * num / den; }
+	else if (type == 0) { alpha = den / num; N = len; }
+	else { alpha = (len - 1) * den / (len * num - den); N = len; }
+	omega = pi * alpha / N;
+	phi = pi * (alpha * off + 0.5) / N;
+}
+}  // namespace
+
+extern "C" int dspfft_zoomczt_create(dspfft_zoomczt *out, int w, int h, int type, double xnum, double xden, double ynum, double yden, int vw, int vh)
+{
+	if (!out || w < 1 || h < 1 || vw < 1 || vh < 1 || type < 0 || type > 2 || !(xnum > 0) || !(xden > 0) || !(ynum > 0) || !(yden > 0)) { snprintf(g_err, sizeof g_err, "bad arguments"); return -1; }
+	*out = nullptr;
+	if (type == 1 && (!(w * xnum - xden > 0) || !(h * ynum - yden > 0))) { snprintf(g_err, sizeof g_err, "centered basis: len * scale must exceed 1"); return -2; }
+	dspfft_zoomczt z = new dspfft_zoomczt_s();
+	z->w = w; z->h = h; z->type = type; z->vw = vw; z->vh = vh; z->xnum = xnum; z->xden = xden; z->ynum = ynum; z->yden = yden;
+	z->cw = dspfft_zoom_ncomponents(xnum, xden, (size_t)w); z->ch = dspfft_zoom_ncomponents(ynum, yden, (size_t)h);
+	z->rows_y = z->rows_x = nullptr;
+	if ((long long)z->cw * 3 * (long long)(vh > (int)z->ch ? vh : (int)z->ch) >= (1ll << 31)) { delete z; snprintf(g_err, sizeof g_err, "frame too large for 31-bit strides"); return -2; }
+	const int ry = dspfft_cztrows_create(&z->rows_y, (int)z->ch, vh, (int)z->cw * 3, 1);
+	const int rx = ry ? ry : dspfft_cztrows_create(&z->rows_x, (int)z->cw, vw, vh * 3, 3);
+	if (ry || rx) {
+		snprintf(g_err, sizeof g_err, "%s", dspfft_last_error());
+		if (z->rows_y) dspfft_cztrows_destroy(z->rows_y);
+		delete z;
+		return (ry ? ry : rx) == -2 ? -2 : -3;
+	}
+	*out = z;
+	return 0;
+}
+extern "C" void dspfft_zoomczt_destroy(dspfft_zoomczt z)
+{
+	if (!z) return;
+	dspfft_cztrows_destroy(z->rows_y); dspfft_cztrows_destroy(z->rows_x);
+	delete z;
+}
+// Ct (cw 3 x ch) | Yt (cw 3 x vh) | T (vh x cw 3)
+extern "C" size_t dspfft_zoomczt_work_floats(dspfft_zoomczt z)
+{
+	if (!z) return 0;
+	return r4(z->cw * 3 * z->ch) + r4(z->cw * 3 * (size_t)z->vh) + r4((size_t)z->vh * z->cw * 3);
+}
+extern "C" int dspfft_zoomczt_execute(dspfft_zoomczt z, const float *d_coeffs, double vx, double vy, float *d_out, float *d_work, void *stream)
+{
+	if (!z || !d_coeffs || !d_out || !d_work) { snprintf(g_err, sizeof g_err, "bad arguments"); return -1; }
+	const long long cols = (long long)z->cw * 3, ch = (long long)z->ch;
+	float *Ct = d_work, *Yt = Ct + r4((size_t)(cols * ch)), *T = Yt + r4((size_t)(cols * z->vh));
+	double wx, px, wy, py;
+	czt_axis(z->type, z->xnum, z->xden, (double)z->w, vx, wx, px);
+	czt_axis(z->type, z->ynum, z->yden, (double)z->h, vy, wy, py);
+	// columns of the coefficient block as planar lines: Ct[(u, c)][v]
+	if (dspfft_transpose_f32(Ct, ch, d_coeffs, (long long)z->w * 3, (int)ch, (int)cols, stream) ||
+	    // y axis: ch coefficients -> vh samples per column
+	    dspfft_cztrows_execute(z->rows_y, Ct, ch, 0, 1, Yt, z->vh, 0, 1, wy, py, 1.0, stream) ||
+	    // back to rows of cw RGB pixels: T[j][u][c]
+	    dspfft_transpose_f32(T, cols, Yt, z->vh, (int)cols, z->vh, stream) ||
+	    // x axis: channel c of row j is a line of cw coefficients (3 floats apart) -> vw samples of the caller's interleaved frame
+	    dspfft_cztrows_execute(z->rows_x, T, cols, 1, 3, d_out, (long long)z->vw * 3, 1, 3, wx, px, 1.0 / ((double)z->w * (double)z->h), stream)) {
+		snprintf(g_err, sizeof g_err, "%s", dspfft_last_error()); return -4;
+	}
+	return 0;
+}

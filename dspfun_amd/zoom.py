@@ -42,11 +42,39 @@ class Zoom:
             raise DspfftError(self.lib.dspfft_zoomfft_last_error().decode())
         return out
 
+    def _frame_czt(self, vw, vh, xscale, yscale, vx, vy, basis_type):
+        """chirp-z transforms along both axes (dspfft_zoomczt_*): any scale, offset and basis; None when an axis is too long for the
+        listed convolution lengths"""
+        key = (vw, vh, tuple(xscale), tuple(yscale), basis_type)
+        if not hasattr(self, "_czt"):
+            self._czt = {}
+        if key not in self._czt:
+            z = C.c_void_p()
+            rc = self.lib.dspfft_zoomczt_create(C.byref(z), self.w, self.h, basis_type, xscale[0], xscale[1], yscale[0], yscale[1], vw, vh)
+            if rc == -2:
+                self._czt[key] = None
+            elif rc:
+                raise DspfftError(self.lib.dspfft_zoomfft_last_error().decode())
+            else:
+                work = self.torch.empty(self.lib.dspfft_zoomczt_work_floats(z), dtype=self.torch.float32, device=self.coeffs.device)
+                self._czt[key] = (z, work)
+        if self._czt[key] is None:
+            return None
+        z, work = self._czt[key]
+        out = self.torch.empty((vh, vw, 3), dtype=self.torch.float32, device=self.coeffs.device)
+        if self.lib.dspfft_zoomczt_execute(z, self.coeffs.data_ptr(), float(vx), float(vy), out.data_ptr(), work.data_ptr(),
+                                           self.torch.cuda.current_stream().cuda_stream):
+            raise DspfftError(self.lib.dspfft_zoomfft_last_error().decode())
+        return out
+
     def __del__(self):
         try:
             for v in getattr(self, "_fft", {}).values():
                 if v is not None:
                     self.lib.dspfft_zoomfft_destroy(v[0])
+            for v in getattr(self, "_czt", {}).values():
+                if v is not None:
+                    self.lib.dspfft_zoomczt_destroy(v[0])
         except Exception:
             pass
 
@@ -58,15 +86,22 @@ class Zoom:
         return b, nc
 
     def frame(self, vw, vh, xscale=(1.0, 1.0), yscale=(1.0, 1.0), vx=0.0, vy=0.0, basis_type=INTERPOLATED, method="auto"):
-        """one output frame: (vh, vw, 3) f32.  method "auto": fast transforms (dspfft_zoomfft_*) when the scaled lengths are integers
-        and the basis is interpolated or native, the dense MFMA product otherwise; "fft" / "gemm" force one (fft raises if it does
-        not apply)."""
+        """one output frame: (vh, vw, 3) f32.  method "auto": fast transforms on the DCT-III grid (dspfft_zoomfft_*) when the scaled lengths
+        are integers and the basis is interpolated or native; chirp-z transforms (dspfft_zoomczt_*) for every other scale and the centered
+        basis; the dense MFMA product only for axes beyond the listed convolution lengths.  "fft" / "czt" / "gemm" force one (fft and czt
+        raise if they do not apply)."""
         torch = self.torch
         if method in ("auto", "fft"):
             out = self._frame_fft(vw, vh, xscale, yscale, vx, vy, basis_type)
             if out is not None:
                 return out
             if method == "fft":
+                raise DspfftError(self.lib.dspfft_zoomfft_last_error().decode())
+        if method in ("auto", "czt"):
+            out = self._frame_czt(vw, vh, xscale, yscale, vx, vy, basis_type)
+            if out is not None:
+                return out
+            if method == "czt":
                 raise DspfftError(self.lib.dspfft_zoomfft_last_error().decode())
         xb, cw = self._basis(basis_type, xscale[0], xscale[1], vx, vw, self.w)
         yb, ch = self._basis(basis_type, yscale[0], yscale[1], vy, vh, self.h)

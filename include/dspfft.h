@@ -137,6 +137,24 @@ typedef struct dspfft_cosrows_s *dspfft_cosrows;
 int dspfft_cosrows_create(dspfft_cosrows *plan, int M, int cw, int vw, int lines);
 int dspfft_cosrows_execute(dspfft_cosrows plan, const float *d_in, long long in_pitch, float *d_out, long long out_pitch, double theta, double scale, void *hip_stream);
 void dspfft_cosrows_destroy(dspfft_cosrows plan);
+
+/* ---- rows of a cosine series at ANY sample spacing, by the chirp-z transform (zoom's product at scales off the DCT-III grid and for
+ * the `centered` basis: zoom/zoom.c:36-68,361-375; dspfun_amd/csrc/dct_czt.h) ----
+ *     out[b] = scale * sum'_{n < nc} in[n] cos(n (omega b + phi)),    b < nout           (sum' halves n = 0)
+ * per line: a circular convolution of a listed smooth length P >= nc + nout - 1 (1200 ... 19200: spec_list.h DSPFFT_CZT_SPECS) in LDS,
+ * forward FFT, times the chirp's spectrum, inverse FFT.  create returns -2 when nc + nout - 1 exceeds the longest listed P.
+ * Lines come in `groups` of `group` members (1, or 3 = the channels of an image row, which share their output cache lines and are then run
+ * on one XCD back to back): line (g, m) reads in[g * in_group + m * in_pitch + n * es_in] and writes out[g * out_group + m * out_pitch + b * es_out].
+ * omega, phi and scale are arguments of the execution; the tables they determine live in the plan (one execution of a plan at a time);
+ * the chirp's spectrum is rebuilt only when omega changes. */
+typedef struct dspfft_cztrows_s *dspfft_cztrows;
+int dspfft_cztrows_create(dspfft_cztrows *plan, int nc, int nout, int lines, int group);
+int dspfft_cztrows_execute(dspfft_cztrows plan, const float *d_in, long long in_group, long long in_pitch, int es_in,
+                           float *d_out, long long out_group, long long out_pitch, int es_out, double omega, double phi, double scale, void *hip_stream);
+int dspfft_cztrows_length(dspfft_cztrows plan);      /* the convolution length P the plan runs on */
+void dspfft_cztrows_destroy(dspfft_cztrows plan);
+/* out[c * out_pitch + r] = in[r * in_pitch + c], r < rows, c < cols (the re-layout between the two axes of a chirp-z zoom frame) */
+int dspfft_transpose_f32(float *d_out, long long out_pitch, const float *d_in, long long in_pitch, int rows, int cols, void *hip_stream);
 /* Optional, for owner ids that stay the same over the frames of a scan (every method but box, whose ids are stamped per frame):
  * records the (min, max) owner id of every column tile of `plan`, so that a later dspfft_execute_masked_accumulate with the SAME
  * d_ids pointer and elems_per_id leaves a tile alone -- without reading its owner ids -- when `id` lies outside its range.  Call it
@@ -363,6 +381,14 @@ size_t dspfft_zoomfft_work_floats(dspfft_zoomfft z);
 int dspfft_zoomfft_execute(dspfft_zoomfft z, const float *d_coeffs, double vx, double vy, float *d_out, float *d_work, void *hip_stream);
 void dspfft_zoomfft_destroy(dspfft_zoomfft z);
 const char *dspfft_zoomfft_last_error(void);
+/* zoom's frame at ANY scale, offset and basis (interpolated, centered, native) by chirp-z transforms along both axes: same arguments as
+ * dspfft_zoomfft_*, no restriction on the scaled lengths (dspfft_zoomfft_* needs them integer and refuses `centered`).  -2 when an axis is
+ * longer than the longest listed convolution (coefficients + samples - 1 > 19200): the dense product (dspfft_zoom_product) remains. */
+typedef struct dspfft_zoomczt_s *dspfft_zoomczt;
+int dspfft_zoomczt_create(dspfft_zoomczt *z, int w, int h, int type, double xnum, double xden, double ynum, double yden, int vw, int vh);
+size_t dspfft_zoomczt_work_floats(dspfft_zoomczt z);
+int dspfft_zoomczt_execute(dspfft_zoomczt z, const float *d_coeffs, double vx, double vy, float *d_out, float *d_work, void *hip_stream);
+void dspfft_zoomczt_destroy(dspfft_zoomczt z);
 
 /* ---- applybasis' basis x pixel partial sums on the matrix cores ----
  * applybasis/applybasis.c:410-431, forward direction:

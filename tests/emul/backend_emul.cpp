@@ -282,6 +282,46 @@ int be_zoomx_tables(float *tab, int M, int cw, int nsrc, double theta, double sc
 	for (int i = 0; i < nsrc * (M / 4 + 1); i++) zoomx_table_item(tab, M, cw, nsrc, theta, scale, i);
 	return 0;
 }
+// chirp-z rows (spec_kernels.h czt_rows_kernel / czt_spectrum_kernel)
+template <class S>
+int launch_czt_rows(const CztArgs &a, void *)
+{
+	std::vector<unsigned char> lds(S::LDS + 64);
+	cf *plane = (cf *)(((uintptr_t)lds.data() + 31) & ~(uintptr_t)31);
+	PassArgs w = {};
+	w.W = a.W;
+	for (int wg = 0; wg < a.lines; wg++) {
+		long long bin, bout;
+		S::base(a, wg, bin, bout);
+		static_for<0, S::NPH>([&](auto ph) { for (int tid = 0; tid < S::T; tid++) S::template phase<ph>(a, w, plane, bin, bout, tid); });
+	}
+	return 0;
+}
+template <class S>
+int launch_czt_spectrum(const CztArgs &a, cf *hspec, void *)
+{
+	std::vector<unsigned char> lds(S::LDS + 64);
+	cf *plane = (cf *)(((uintptr_t)lds.data() + 31) & ~(uintptr_t)31);
+	PassArgs w = {};
+	w.W = a.W;
+	for (int tid = 0; tid < S::T; tid++) S::f0(a, plane, 0, tid);
+	static_for<1, S::NS - 1>([&](auto I) { for (int tid = 0; tid < S::T; tid++) S::template fwd<I>(w, plane, tid); });
+	for (int tid = 0; tid < S::T; tid++) S::flast(plane, tid);
+	for (int i = 0; i < S::P; i++) hspec[i] = plane[S::F::padded(i)];
+	return 0;
+}
+int be_czt_tables(cf *atab, cf *etab, cf *htab, int nc, int nout, int P, double omega, double phi, double scale, void *)
+{
+	if (atab) for (int i = 0; i < nc; i++) atab[i] = czt_a_entry(i, omega, phi);
+	if (etab) for (int i = 0; i < nout; i++) etab[i] = czt_e_entry(i, omega, scale);
+	if (htab) for (int i = 0; i < P; i++) htab[i] = czt_h_entry(i, P, nc, nout, omega);
+	return 0;
+}
+int be_transpose(float *out, long long out_pitch, const float *in, long long in_pitch, int rows, int cols, void *)
+{
+	for (int r = 0; r < rows; r++) for (int c = 0; c < cols; c++) out[(long long)c * out_pitch + r] = in[(long long)r * in_pitch + c];
+	return 0;
+}
 template <class S, int KIND>
 int launch_row_spec_u8(const PassArgs &a, const U8IO &io, int nwork, void *)
 {
