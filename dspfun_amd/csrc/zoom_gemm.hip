@@ -139,7 +139,8 @@ __global__ void __launch_bounds__(256) gemm_nt_f32_mfma(const float *__restrict_
 template <int NB>
 __global__ void __launch_bounds__(256, NB == 1 ? 2 : 1) gemm_nt_f32_mfma_dma(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
                                                                              int M, int N, int K, long long lda, long long ldb, long long ldc, int cs,
-                                                                             long long sa, long long sb, long long sc, float alpha, const float *zero_page, int ntn)
+                                                                             long long sa, long long sb, long long sc, float alpha, const float *zero_page, int ntn,
+                                                                             int nb1 = 0, long long sa2 = 0, long long sb2 = 0, long long sc2 = 0)
 {
 	constexpr int BKD = 32, G = BKD / 8, OPB = 128 * BKD;            // floats per operand tile
 	extern __shared__ __attribute__((aligned(16))) float smem[];     // [2 buffers][A tile | NB B tiles]
@@ -148,7 +149,10 @@ __global__ void __launch_bounds__(256, NB == 1 ? 2 : 1) gemm_nt_f32_mfma_dma(con
 	const int tile = blockIdx.x, batch = NB == 1 ? (int)blockIdx.z : 0;
 	const int tm = tile / ntn, tn = tile - tm * ntn;
 	const int bm = tm * 128, bn = tn * 128;
-	A += (long long)batch * sa; B += (long long)batch * sb; C += (long long)batch * sc;
+	{	// blockIdx.z = b1 + nb1 * b2: two batch levels (see gemm_nt_f32_mfma), nb1 = 0: one level
+		const int b2 = nb1 ? batch / nb1 : 0, b1 = batch - b2 * nb1;
+		A += (long long)b1 * sa + (long long)b2 * sa2; B += (long long)b1 * sb + (long long)b2 * sb2; C += (long long)b1 * sc + (long long)b2 * sc2;
+	}
 
 	// DMA: wave w stages 32-row block w of A and of (each) B: G instructions each per K-tile
 	const int li = lane & 31, lk = lane >> 5;
@@ -313,6 +317,35 @@ static bool small_product(const dim3 &grid128)
 	return (long long)grid128.x * grid128.y * grid128.z < 256;
 }
 
+// operands by LDS-DMA in K-tiles of 32 (round 4) where every 16-byte piece is aligned; DSPFFT_GEMM_DMA=0: the register-staged kernel (A/B runs).
+// Returns 1 when the product does not qualify (the caller launches the register-staged kernel), else 0 / an error.
+static int launch_dma(const float *A, const float *B, float *C, int M, int N, int K, long long lda, long long ldb, long long ldc, int cs,
+                      int batch, long long sa, long long sb, long long sc, float alpha, int nb1, long long sa2, long long sb2, long long sc2, const dim3 &grid, void *stream)
+{
+	static const int dma = getenv("DSPFFT_GEMM_DMA") ? atoi(getenv("DSPFFT_GEMM_DMA")) : 1;
+	if (!(dma && K >= 32 && ((lda | ldb | sa | sb | sa2 | sb2) & 3) == 0 && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0)) return 1;
+	static thread_local float *zero_page[32] = {};
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
+	if (!zero_page[dev]) {
+		if (hipMalloc((void **)&zero_page[dev], 256) != hipSuccess || hipMemset(zero_page[dev], 0, 256) != hipSuccess) { snprintf(g_zerr, sizeof g_zerr, "no memory for the zero page"); return -3; }
+	}
+	const int ntn = (int)grid.x, ntiles = (int)(grid.x * grid.y);
+	// three batches that share A and interleave their outputs element by element (zoom's second product): one workgroup per tile for all three
+	static const int nb3 = getenv("DSPFFT_GEMM_NB3") ? atoi(getenv("DSPFFT_GEMM_NB3")) : 0;      // 1: one workgroup per tile for all three channels (measured slower: 2.26 against 2.11 ms for zoom's second product -- one workgroup per CU; profiles/r04_gemm.txt)
+	const bool b3 = nb3 && !nb1 && batch == 3 && cs == 3 && sa == 0 && sc == 1;
+	const size_t lds = 2 * (size_t)(b3 ? 4 : 2) * 128 * 32 * sizeof(float);
+	static thread_local bool attr[2] = {false, false};
+	if (!attr[b3]) {
+		const void *k = b3 ? reinterpret_cast<const void *>(gemm_nt_f32_mfma_dma<3>) : reinterpret_cast<const void *>(gemm_nt_f32_mfma_dma<1>);
+		if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { snprintf(g_zerr, sizeof g_zerr, "cannot raise the LDS limit"); return -4; }
+		attr[b3] = true;
+	}
+	if (b3) hipLaunchKernelGGL(gemm_nt_f32_mfma_dma<3>, dim3(ntiles, 1, 1), dim3(256), lds, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, cs, sa, sb, sc, alpha, zero_page[dev], ntn, 0, 0ll, 0ll, 0ll);
+	else hipLaunchKernelGGL(gemm_nt_f32_mfma_dma<1>, dim3(ntiles, 1, batch), dim3(256), lds, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, cs, sa, sb, sc, alpha, zero_page[dev], ntn, nb1, sa2, sb2, sc2);
+	return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
 extern "C" int dspfft_gemm_nt_f32(const float *A, const float *B, float *C, int M, int N, int K,
                                   long long lda, long long ldb, long long ldc, int cs,
                                   int batch, long long sa, long long sb, long long sc, float alpha, void *stream)
@@ -325,30 +358,7 @@ extern "C" int dspfft_gemm_nt_f32(const float *A, const float *B, float *C, int 
 		else hipLaunchKernelGGL((gemm_nt_f32_mfma<8, 1>), g64, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, cs, sa, sb, sc, alpha, 0, 0ll, 0ll, 0ll);
 		return hipGetLastError() == hipSuccess ? 0 : -4;
 	}
-	// operands by LDS-DMA in K-tiles of 32 (round 4) where every 16-byte piece is aligned; DSPFFT_GEMM_DMA=0: the register-staged kernel (A/B runs)
-	static const int dma = getenv("DSPFFT_GEMM_DMA") ? atoi(getenv("DSPFFT_GEMM_DMA")) : 1;
-	if (dma && K >= 32 && ((lda | ldb | sa | sb) & 3) == 0 && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0) {
-		static thread_local float *zero_page[32] = {};
-		int dev = 0;
-		if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
-		if (!zero_page[dev]) {
-			if (hipMalloc((void **)&zero_page[dev], 256) != hipSuccess || hipMemset(zero_page[dev], 0, 256) != hipSuccess) { snprintf(g_zerr, sizeof g_zerr, "no memory for the zero page"); return -3; }
-		}
-		const int ntn = (int)grid.x, ntiles = (int)(grid.x * grid.y);
-		// three batches that share A and interleave their outputs element by element (zoom's second product): one workgroup per tile for all three
-		static const int nb3 = getenv("DSPFFT_GEMM_NB3") ? atoi(getenv("DSPFFT_GEMM_NB3")) : 0;      // 1: one workgroup per tile for all three channels (measured slower: 2.26 against 2.11 ms for zoom's second product -- one workgroup per CU; profiles/r04_gemm.txt)
-		const bool b3 = nb3 && batch == 3 && cs == 3 && sa == 0 && sc == 1;
-		const size_t lds = 2 * (size_t)(b3 ? 4 : 2) * 128 * 32 * sizeof(float);
-		static thread_local bool attr[2] = {false, false};
-		if (!attr[b3]) {
-			const void *k = b3 ? reinterpret_cast<const void *>(gemm_nt_f32_mfma_dma<3>) : reinterpret_cast<const void *>(gemm_nt_f32_mfma_dma<1>);
-			if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { snprintf(g_zerr, sizeof g_zerr, "cannot raise the LDS limit"); return -4; }
-			attr[b3] = true;
-		}
-		if (b3) hipLaunchKernelGGL(gemm_nt_f32_mfma_dma<3>, dim3(ntiles, 1, 1), dim3(256), lds, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, cs, sa, sb, sc, alpha, zero_page[dev], ntn);
-		else hipLaunchKernelGGL(gemm_nt_f32_mfma_dma<1>, dim3(ntiles, 1, batch), dim3(256), lds, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, cs, sa, sb, sc, alpha, zero_page[dev], ntn);
-		return hipGetLastError() == hipSuccess ? 0 : -4;
-	}
+	if (int rc = launch_dma(A, B, C, M, N, K, lda, ldb, ldc, cs, batch, sa, sb, sc, alpha, 0, 0, 0, 0, grid, stream); rc != 1) return rc;
 	static const int bk = getenv("DSPFFT_GEMM_BK") ? atoi(getenv("DSPFFT_GEMM_BK")) : 8;
 	if (K >= 32 && bk == 32) hipLaunchKernelGGL(gemm_nt_f32_mfma<32>, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, cs, sa, sb, sc, alpha);
 	else if (K >= 16 && bk >= 16) hipLaunchKernelGGL(gemm_nt_f32_mfma<16>, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, cs, sa, sb, sc, alpha);
@@ -367,6 +377,10 @@ static int gemm_nt_f32_batch2(const float *A, const float *B, float *C, int M, i
 		else hipLaunchKernelGGL((gemm_nt_f32_mfma<8, 1>), g64, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, 1, sa1, sb1, sc1, 1.f, nb1, sa2, sb2, sc2);
 		return hipGetLastError() == hipSuccess ? 0 : -4;
 	}
+	// (the LDS-DMA kernel holds two workgroups per CU against three here: applybasis' 2048^2 spectrum -- 768 tiles, one and a half rounds -- ran
+	// at MfmaUtil 0.56 on it against 0.60 on this one; it takes over from 2048 tiles up)
+	if ((long long)grid.x * grid.y * grid.z >= 2048)
+		if (int rc = launch_dma(A, B, C, M, N, K, lda, ldb, ldc, 1, nb1 * nb2, sa1, sb1, sc1, 1.f, nb1, sa2, sb2, sc2, grid, stream); rc != 1) return rc;
 	if (K >= 16) hipLaunchKernelGGL(gemm_nt_f32_mfma<16>, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, 1, sa1, sb1, sc1, 1.f, nb1, sa2, sb2, sc2);
 	else hipLaunchKernelGGL(gemm_nt_f32_mfma<8>, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, 1, sa1, sb1, sc1, 1.f, nb1, sa2, sb2, sc2);
 	return hipGetLastError() == hipSuccess ? 0 : -4;
