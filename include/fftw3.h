@@ -63,8 +63,9 @@ int fftwf_export_wisdom_to_filename(const char *filename);     /* motion.c:557 *
 /* ---------------- double precision: COEFF_PRECISION=D (spec/Makefile, zoom/Makefile default) ----------------
  * Same engine with double buffers, double arithmetic and double tables on the device
  * (dspfft_plan_many_r2r_f64 / dspfft_execute_f64): results agree with a double FFTW to ~1e-14 of max|coeff|.
- * The common frame sizes (spec_list.h DSPFFT_*_SPECS_F64: 4K, 1080p, 720p, powers of two) run compile-time-specialised double
- * kernels (3840x2160 RGB roundtrip 383 us = 26 % of the 96 B/pixel roofline); other sizes run the runtime-geometry kernels. */
+ * The common frame sizes (spec_list.h DSPFFT_*_SPECS_F64: 8K, 4K, 1080p, 720p, powers of two) run compile-time-specialised double
+ * kernels (3840x2160 RGB roundtrip 0.33 ms = 30 % of the 96 B/pixel roofline, 7680x4320 1.94 ms = 20.5 %, round 4); other sizes run
+ * the runtime-geometry kernels. */
 typedef struct fftw_plan_s *fftw_plan;
 double *fftw_alloc_real(size_t n);
 void fftw_free(void *p);

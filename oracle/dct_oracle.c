@@ -18,9 +18,12 @@
  *     motion/motion.c:535-538,549-552                                     (rank 3, embedded in minbuf, howmany=1)
  *     applybasis/draw.c:74                                                (plan_r2r_2d)
  *
- * PARITY UNPINNED for the float arithmetic: the reference holds no golden vectors or tests
- * for this path and FFTW cannot be built here; the restatement is cross-checked against an
- * independent implementation (scipy/pocketfft, tests/golden/make_golden.py) instead.
+ * Pinning.  FFTW itself was never run (absent here and on every GPU box).  Since round 3 this restatement is pinned to code the
+ * REFERENCE holds: its own direct-sum statements of the same transforms -- scan/scan.c:20-41 (generate_basis_matrix + pruned_idct: the
+ * 2-D REDFT01), zoom/zoom.c:36-68,361-375 and applybasis/applybasis.c:77-140 (dct2 = REDFT10's kernel, dct3 = REDFT01's) -- compiled as
+ * they lie by tests/golden/make_ref_fixtures.py into tests/golden/ref_direct.npz and compared <= 1e-12 in tests/test_ref_direct.py
+ * (REDFT01 directly, REDFT10 through the dct2 tables and the 4wh roundtrip identity).  The scipy / pocketfft cross-check of round 1
+ * (tests/golden/make_golden.py) stays as a second, independent witness.
  *
  * Everything is computed by direct O(N^2) summation per axis with a long-double cosine
  * table indexed by the exactly reduced integer phase, so the result is the definition to

@@ -46,8 +46,25 @@ ms = timeit(lambda: z.frame(4 * w, 4 * h, (4.0, 1.0), (4.0, 1.0), method="fft"),
 # compulsory bytes of the frame: the coefficients in, the 7680x4320x3 frame out
 res["zoom_c3_fft"] = {"ms_per_frame": round(ms, 3), "speedup_over_gemm": round(res["zoom_c3"]["ms_per_frame"] / ms, 2),
                       "algorithmic_GBps": round((w * h * 3 + 16 * w * h * 3) * 4 / ms / 1e6, 1), "frac_of_8TBps": round((w * h * 3 + 16 * w * h * 3) * 4 / ms / 1e6 / 8000, 4),
-                      "note": "dspfft_zoomfft_*: two REDFT01 transforms per axis (zoom_fft.hip): y first on the coefficients' columns, x last as one summed row pass; four launches, about 1.1 GB moved per frame"}
+                      "note": "dspfft_zoomfft_*: y first on the coefficients' columns (two windowed column passes), x last on the duo row kernel (dspfft_cosrows_*): cosine and sine part as a packed pair through one half-length FFT per channel"}
+# the same source at 3.7x with the centered basis (off the DCT-III grid): chirp-z transforms against the dense product (round 4)
+vw37, vh37 = int(w * 3.7), int(h * 3.7)
+msg = timeit(lambda: z.frame(vw37, vh37, (3.7, 1.0), (3.7, 1.0), 12.5, -4.25, 1, method="gemm"), reps=5, warm=1)
+msc = timeit(lambda: z.frame(vw37, vh37, (3.7, 1.0), (3.7, 1.0), 12.5, -4.25, 1, method="czt"), reps=10, warm=2)
+res["zoom_1080p_3p7x_centered"] = {"czt_ms_per_frame": round(msc, 3), "gemm_ms_per_frame": round(msg, 3), "speedup": round(msg / msc, 2),
+                                   "note": "dspfft_zoomczt_*: Bluestein convolutions of 5400 (y) and 9600 (x) points in LDS, two transposes between"}
 del z
+
+# ---- 8K double frame roundtrip (spec / zoom's default COEFF_PRECISION=D build at configs 3 / 4's frame size) ----
+w, h, c = 7680, 4320, 3
+x8d = torch.rand(h, w, c, device=dev, dtype=torch.float64)
+f8d = Plan.image(h, w, c, REDFT10, dtype="f64")
+i8d = Plan.image(h, w, c, REDFT01, dtype="f64").set_scale(1.0 / (4.0 * w * h))
+def rt8d():
+    f8d.execute(x8d.data_ptr()); i8d.execute(x8d.data_ptr())
+ms = timeit(rt8d, reps=5, warm=2)
+res["f64_8k_frame_roundtrip"] = {"ms": round(ms, 3), "Mpixels_per_s": round(h * w / ms / 1e3, 1), "frac_of_8TBps": round(h * w * c * 32 / ms / 1e6 / 8000, 4), "plan": f8d.describe()}
+del x8d, f8d, i8d
 
 # ---- 8K frame roundtrip (the transform of configs 3 and 4's frame size) ----
 w, h, c = 7680, 4320, 3
