@@ -384,7 +384,10 @@ def test_random_geometries_on_host_pointers(fftw, seed):
 
 
 @pytest.mark.parametrize("method", ["horizontal", "vertical", "zigzag", "row", "column", "diagonal", "mirror", "box", "ibox", "radial", "iradial",
-                                    "magnitude", "magnitude:200", "file:coordinate", "file:index", "file:box"])
+                                    "magnitude", "magnitude:200", "file:coordinate", "file:index", "file:box",
+                                    # round 4: the expression methods (scan_methods.c:186-201,333-391; host/expr_eval.h).  Both visit every pixel once here:
+                                    # evalxy's index = x + y * 80 is the horizontal order, evali's is the vertical one of an 80 x 48 frame
+                                    "evalxy:x+y*80", "evalxy:bitand(x,y)*0 + hypot(x,y)", "evali:floor(i/height); mod(i,height)"])
 def test_scan_device_resident_harness_every_method(tmp_path, method):
     """host/scan_dev.c: scan's loop with every buffer and every scan order on the GPU.  The final sum equals
     the input for every method that visits each pixel once; box (shared pixels are added once per frame they appear in) is checked

@@ -27,8 +27,8 @@ pmc() {     # name, command...
 if [ $WHAT = headline ] || [ $WHAT = all ]; then
   python3 $R/bench.py > $O/bench.json 2> $O/bench.err || true
   python3 $R/bench.py --streams 1 --no-motion > $O/bench_streams1.json 2> $O/bench_streams1.err || true
-  trace headline python3 $R/bench.py --no-cpu-baseline --no-motion
-  trace headline_streams1 python3 $R/bench.py --no-cpu-baseline --no-motion --streams 1
+  trace headline python3 $R/bench.py --no-cpu-baseline --no-motion --no-scan --no-single-stream --no-fftw-abi
+  trace headline_streams1 python3 $R/bench.py --no-cpu-baseline --no-motion --no-scan --no-fftw-abi --streams 1
   REPS=6 pmc headline_passes python3 $R/tools/prof_passes.py
 fi
 if [ $WHAT = paths ] || [ $WHAT = all ]; then
