@@ -3,8 +3,8 @@
 // vector-FP32 rate, 157 TFLOP/s peak).  This is the one place on the hot path that is a true dense
 // GEMM: at BASELINE config 3 it is 310.6 GFLOP against ~0.45 GB of operands.
 //
-//   per channel z:   Tt = XB (vw x cw) . C_z^T (cw x ch)          -> Tt  (vw x ch)
-//                    out_z = YB (vh x ch) . Tt^T (ch x vw) / (w h) -> out (vh x vw), interleaved store
+//   per channel z:   Tt[3 x + z] = XB (vw x cw) . C_z^T (cw x ch)      -> Tt (3 vw x ch), the channels interleaved by row
+//   once:            out = YB (vh x ch) . Tt^T (ch x 3 vw) / (w h)     -> out (vh x 3 vw) = the interleaved frame, contiguous stores
 // where XB/YB are the reference's bases with the halved DC term folded in as column 0 = 1/2
 // (zoom.c:364 `tmp = C[row][0]/2`, :369 `s = tmp[0]/2`).  Both products are "NT" GEMMs (both
 // operands have the summed index contiguous), so one kernel serves both.
@@ -123,104 +123,142 @@ __global__ void __launch_bounds__(256) gemm_nt_f32_mfma(const float *__restrict_
 }
 
 // ---- round 4: the same product with its operands staged by LDS-DMA (global_load_lds_dwordx4) in K-tiles of 32 ----
-// 128 x 128 x 32 block tile, 256 threads = 2 x 2 waves of 64 x 64 (2 x 2 MFMA 32x32x2 tiles each), two LDS buffers of 32 KB.
-// The kernel above stages through registers one 8-deep K-tile ahead: 16 MFMAs (1024 cycles per wave) between barriers, less than a
-// global load's latency, so every K-tile ends waiting for the next one's operands (MfmaUtil 0.58-0.71).  Here a K-tile is 64 MFMAs per
-// wave (4096 cycles): the DMA of tile t + 1 is issued before the MFMAs of tile t and has landed when they end; no staging registers, no
-// ds_write pass.
+// 256 threads = 2 x 2 waves, two LDS buffers.  The kernel above stages through registers one 8-deep K-tile ahead: 16 MFMAs (1024 cycles per
+// wave) between barriers, less than a global load's latency, so every K-tile ends waiting for the next one's operands (MfmaUtil 0.58-0.71).
+// Here a K-tile is 64 MFMAs per wave (4096 cycles): the DMA of tile t + 1 is issued before the MFMAs of tile t and has landed when they end;
+// no staging registers, no ds_write pass.  What it took to get from there (119 TF on 8192 x 8192 x 4096) to 133 TF = MfmaUtil 0.85
+// (profiles/r04_gemm.txt): the compiler must SEE that the DMA's LDS writes and the ds_reads never meet (`ktile`'s __restrict__ buffers:
+// without that, s_waitcnt vmcnt(0) sits between the DMA and the first ds_read and nothing is prefetched), and the DMA's addressing must
+// not cost vector instructions (`stage`): every VALU instruction a wave issues between its MFMAs is a slot the matrix pipe idles.
 // LDS image of an operand tile (lane-linear per DMA instruction: its destination is base + lane x 16 bytes): [32-row block][k-group of 8]
 // [k-half lk][row li] x 16 bytes, i.e. DMA lane lk * 32 + li fetches the four floats k0 + 8 g + 4 lk .. + 3 of row 32 blk + li -- exactly the
 // float4 that lane (li, lk) of the MFMA reads for k-group g (consecutive lanes, consecutive 16 bytes: conflict-free ds_read_b128).
 // Rows beyond M / N fetch a valid row (their products are never stored); k beyond K fetches a page of zeros.
-// NB = 3 (zoom's second product: three colour channels that share the A operand, stored interleaved, cs = 3): ONE workgroup computes the
-// tile for all three channels -- three accumulator sets, the A fragments read once for the three -- and stores whole pixels (12 bytes per
-// lane, 384 contiguous bytes per row and half-wave) instead of three workgroups writing a third of every cache line each.  Built and
-// measured SLOWER (396 registers: one workgroup per CU, nothing beside a wave's own LDS waits): off unless DSPFFT_GEMM_NB3=1.
-template <int NB>
-__global__ void __launch_bounds__(256, NB == 1 ? 2 : 1) gemm_nt_f32_mfma_dma(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
-                                                                             int M, int N, int K, long long lda, long long ldb, long long ldc, int cs,
-                                                                             long long sa, long long sb, long long sc, float alpha, const float *zero_page, int ntn,
-                                                                             int nb1 = 0, long long sa2 = 0, long long sb2 = 0, long long sc2 = 0)
+// WI x WJ: the MFMA tiles of a wave, i.e. a block tile of 64 WI x 64 WJ.  <2, 2> is the 128 x 128 tile; <2, 3> (128 x 192, 80 KB of LDS: still two
+// workgroups per CU, 24 MFMAs for five ds_read_b128) exists because a product's tile count rarely divides by the 512 workgroups the chip
+// holds: zoom's first product at config 3 is 1560 tiles of 128 x 128 (3.05 rounds -- the fourth round nearly empty) and 1020 of 128 x 192
+// (1.99 rounds).  launch_dma takes the shape with the fewest rounds x tile area.
+// (One workgroup for the three colour channels of a tile -- three accumulator sets, whole pixels stored -- was built and measured slower,
+// 396 registers and one workgroup per CU: profiles/r04_gemm.txt.  zoom's second product now has no interleaved store at all: dspfft_zoom_product.)
+template <int WI, int WJ>
+__global__ void __launch_bounds__(256, 2) gemm_nt_f32_mfma_dma(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
+                                                                int M, int N, int K, long long lda, long long ldb, long long ldc, int cs,
+                                                                long long sa, long long sb, long long sc, float alpha, const float *zero_page, int ntn,
+                                                                int nb1 = 0, long long sa2 = 0, long long sb2 = 0, long long sc2 = 0)
 {
-	constexpr int BKD = 32, G = BKD / 8, OPB = 128 * BKD;            // floats per operand tile
-	extern __shared__ __attribute__((aligned(16))) float smem[];     // [2 buffers][A tile | NB B tiles]
+	constexpr int BKD = 32, G = BKD / 8, BLK = 32 * BKD;             // floats of a 32-row block of an operand tile
+	constexpr int TM = 64 * WI, TN = 64 * WJ, ABLK = 2 * WI, BBLK = 2 * WJ;
+	extern __shared__ __attribute__((aligned(16))) float smem[];     // [2 buffers][A blocks | B blocks]
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int wm = wave >> 1, wn = wave & 1;
-	const int tile = blockIdx.x, batch = NB == 1 ? (int)blockIdx.z : 0;
+	const int tile = blockIdx.x, batch = (int)blockIdx.z;
 	const int tm = tile / ntn, tn = tile - tm * ntn;
-	const int bm = tm * 128, bn = tn * 128;
+	const int bm = tm * TM, bn = tn * TN;
 	{	// blockIdx.z = b1 + nb1 * b2: two batch levels (see gemm_nt_f32_mfma), nb1 = 0: one level
 		const int b2 = nb1 ? batch / nb1 : 0, b1 = batch - b2 * nb1;
 		A += (long long)b1 * sa + (long long)b2 * sa2; B += (long long)b1 * sb + (long long)b2 * sb2; C += (long long)b1 * sc + (long long)b2 * sc2;
 	}
 
-	// DMA: wave w stages 32-row block w of A and of (each) B: G instructions each per K-tile
+	// DMA: wave w stages the 32-row blocks w, w + 4, .. of A and of B: G instructions per block and K-tile.  An instruction's address is a
+	// wave-uniform 64-bit base (the tile's first row, advanced by k0: scalar registers) plus a 32-bit lane offset that never changes (row and
+	// k-half of the lane) plus an immediate (the k-group); its LDS destination is scalar too (the wave index is read into an SGPR) -- no vector
+	// arithmetic per instruction.  (Computing full 64-bit lane pointers, with a select against the zero page, cost 55 vector instructions
+	// per wave and K-tile next to its 64 MFMAs.)  Only the last K-tile of a K that is no multiple of 32 takes the selects (stage_tail).
 	const int li = lane & 31, lk = lane >> 5;
-	const int arow = bm + 32 * wave + li, brow = bn + 32 * wave + li;
-	const float *ap = A + (long long)(arow < M ? arow : M - 1) * lda + 4 * lk;
-	const float *bp = B + (long long)(brow < N ? brow : N - 1) * ldb + 4 * lk;
-	auto stage = [&](int buf, int k0) {
-		float *as = smem + buf * (1 + NB) * OPB + wave * (32 * BKD);
+	const int swave = __builtin_amdgcn_readfirstlane(wave);
+	constexpr int NA = (ABLK + 3) / 4, NBB = (BBLK + 3) / 4;
+	unsigned aoff[NA], boff[NBB];
+#pragma unroll
+	for (int q = 0; q < NA; q++) { const int r = bm + 32 * (swave + 4 * q) + li; aoff[q] = (unsigned)(((long long)((r < M ? r : M - 1) - bm) * lda + 4 * lk) * 4); }
+#pragma unroll
+	for (int q = 0; q < NBB; q++) { const int r = bn + 32 * (swave + 4 * q) + li; boff[q] = (unsigned)(((long long)((r < N ? r : N - 1) - bn) * ldb + 4 * lk) * 4); }
+	const char *const abase = reinterpret_cast<const char *>(A + (long long)bm * lda), *const bbase = reinterpret_cast<const char *>(B + (long long)bn * ldb);
+	auto stage = [&](float *base, int k0) __attribute__((always_inline)) {
+		const char *ak = abase + (long long)k0 * 4, *bk = bbase + (long long)k0 * 4;
 #pragma unroll
 		for (int g = 0; g < G; g++) {
-			const int k = k0 + 8 * g + 4 * lk;
-			const float *pa = k < K ? ap + k0 + 8 * g : zero_page;
-			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)pa, (__attribute__((address_space(3))) void *)(as + g * 256), 16, 0, 0);
 #pragma unroll
-			for (int z = 0; z < NB; z++) {
-				const float *pb = k < K ? bp + z * sb + k0 + 8 * g : zero_page;
-				__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)pb, (__attribute__((address_space(3))) void *)(as + (1 + z) * OPB + g * 256), 16, 0, 0);
-			}
+			for (int q = 0; q < NA; q++)
+				if (ABLK % 4 == 0 || swave + 4 * q < ABLK)
+					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ak + aoff[q] + 32 * g), (__attribute__((address_space(3))) void *)(base + (swave + 4 * q) * BLK + g * 256), 16, 0, 0);
+#pragma unroll
+			for (int q = 0; q < NBB; q++)
+				if (BBLK % 4 == 0 || swave + 4 * q < BBLK)
+					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bk + boff[q] + 32 * g), (__attribute__((address_space(3))) void *)(base + (ABLK + swave + 4 * q) * BLK + g * 256), 16, 0, 0);
 		}
 	};
-
-	f32x16 acc[NB][2][2];
-	for (int z = 0; z < NB; z++) for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int r = 0; r < 16; r++) acc[z][i][j][r] = 0.f;
-	const int nk = (K + BKD - 1) / BKD;
-	stage(0, 0);
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	__syncthreads();
-	for (int kt = 0; kt < nk; kt++) {
-		const int cur = kt & 1;
-		if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BKD);
-		const float *as = smem + cur * (1 + NB) * OPB;
+	auto stage_tail = [&](float *base, int k0) __attribute__((always_inline)) {      // k beyond K reads the page of zeros
+		const char *ak = abase + (long long)k0 * 4, *bk = bbase + (long long)k0 * 4;
 #pragma unroll
 		for (int g = 0; g < G; g++) {
-			float4 a[2];
+			const bool in = k0 + 8 * g + 4 * lk < K;
 #pragma unroll
-			for (int i = 0; i < 2; i++) a[i] = *reinterpret_cast<const float4 *>(as + (2 * wm + i) * (32 * BKD) + g * 256 + lane * 4);
-#pragma unroll
-			for (int z = 0; z < NB; z++) {
-				float4 b[2];
-#pragma unroll
-				for (int i = 0; i < 2; i++) b[i] = *reinterpret_cast<const float4 *>(as + (1 + z) * OPB + (2 * wn + i) * (32 * BKD) + g * 256 + lane * 4);
-#pragma unroll
-				for (int s = 0; s < 4; s++) {
-					const float av[2] = {s == 0 ? a[0].x : s == 1 ? a[0].y : s == 2 ? a[0].z : a[0].w, s == 0 ? a[1].x : s == 1 ? a[1].y : s == 2 ? a[1].z : a[1].w};
-					const float bv[2] = {s == 0 ? b[0].x : s == 1 ? b[0].y : s == 2 ? b[0].z : b[0].w, s == 0 ? b[1].x : s == 1 ? b[1].y : s == 2 ? b[1].z : b[1].w};
-#pragma unroll
-					for (int i = 0; i < 2; i++)
-#pragma unroll
-						for (int j = 0; j < 2; j++) acc[z][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[z][i][j], 0, 0, 0);
+			for (int q = 0; q < NA; q++)
+				if (ABLK % 4 == 0 || swave + 4 * q < ABLK) {
+					const char *pa = in ? ak + aoff[q] + 32 * g : reinterpret_cast<const char *>(zero_page);
+					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)pa, (__attribute__((address_space(3))) void *)(base + (swave + 4 * q) * BLK + g * 256), 16, 0, 0);
 				}
-			}
+#pragma unroll
+			for (int q = 0; q < NBB; q++)
+				if (BBLK % 4 == 0 || swave + 4 * q < BBLK) {
+					const char *pb = in ? bk + boff[q] + 32 * g : reinterpret_cast<const char *>(zero_page);
+					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)pb, (__attribute__((address_space(3))) void *)(base + (ABLK + swave + 4 * q) * BLK + g * 256), 16, 0, 0);
+				}
+		}
+	};
+	auto stage_any = [&](float *base, int k0) __attribute__((always_inline)) { if (k0 + BKD <= K) stage(base, k0); else stage_tail(base, k0); };
+
+	f32x16 acc[WI][WJ];
+	for (int i = 0; i < WI; i++) for (int j = 0; j < WJ; j++) for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+	const int nk = (K + BKD - 1) / BKD;
+	// one K-tile: the DMA of the next tile into `nxt`, the MFMAs of this one out of `cur`.  The two are `__restrict__` parameters of an inlined
+	// function so that the compiler knows the DMA's LDS writes and the ds_reads never meet: without that it puts s_waitcnt vmcnt(0) between
+	// the DMA and the first ds_read -- the "prefetch" then lands before the tile's first MFMA instead of behind its last.
+	auto ktile = [&](const float *__restrict__ cur, float *__restrict__ nxt, int k0, bool more) __attribute__((always_inline)) {
+		if (more) stage_any(nxt, k0 + BKD);
+		float4 a[2][WI], b[2][WJ];
+		auto frags = [&](int g, int set) __attribute__((always_inline)) {
+#pragma unroll
+			for (int i = 0; i < WI; i++) a[set][i] = *reinterpret_cast<const float4 *>(cur + (WI * wm + i) * BLK + g * 256 + lane * 4);
+#pragma unroll
+			for (int j = 0; j < WJ; j++) b[set][j] = *reinterpret_cast<const float4 *>(cur + (ABLK + WJ * wn + j) * BLK + g * 256 + lane * 4);
+		};
+		// the fragments of k-group g + 1 are read while the MFMAs of group g run (two register sets).  (s_setprio around the MFMAs: -10 %.)
+		frags(0, 0);
+#pragma unroll
+		for (int g = 0; g < G; g++) {
+			const int set = g & 1;
+			if (g + 1 < G) frags(g + 1, set ^ 1);
+#pragma unroll
+			for (int s = 0; s < 4; s++)
+#pragma unroll
+				for (int i = 0; i < WI; i++)
+#pragma unroll
+					for (int j = 0; j < WJ; j++) {
+						const float av = s == 0 ? a[set][i].x : s == 1 ? a[set][i].y : s == 2 ? a[set][i].z : a[set][i].w;
+						const float bv = s == 0 ? b[set][j].x : s == 1 ? b[set][j].y : s == 2 ? b[set][j].z : b[set][j].w;
+						acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+					}
 		}
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile has landed (issued a K-tile of MFMAs ago)
 		__syncthreads();
+	};
+	float *const buf0 = smem, *const buf1 = smem + (ABLK + BBLK) * BLK;
+	stage_any(buf0, 0);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	for (int kt = 0; kt < nk; kt += 2) {
+		ktile(buf0, buf1, kt * BKD, kt + 1 < nk);
+		if (kt + 1 < nk) ktile(buf1, buf0, (kt + 1) * BKD, kt + 2 < nk);
 	}
 	// C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-	for (int i = 0; i < 2; i++)
-		for (int j = 0; j < 2; j++) {
-			const int n = bn + wn * 64 + j * 32 + li;
+	for (int i = 0; i < WI; i++)
+		for (int j = 0; j < WJ; j++) {
+			const int n = bn + wn * (32 * WJ) + j * 32 + li;
 			if (n >= N) continue;
 			for (int r = 0; r < 16; r++) {
-				const int m = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-				if (m >= M) continue;
-				if constexpr (NB == 3) {
-					typedef float f3 __attribute__((ext_vector_type(3)));
-					f3 v; v.x = alpha * acc[0][i][j][r]; v.y = alpha * acc[1][i][j][r]; v.z = alpha * acc[2][i][j][r];
-					__builtin_memcpy(C + (long long)m * ldc + (long long)n * 3, &v, 12);       // sc = 1, cs = 3: the three channels of a pixel
-				} else C[(long long)m * ldc + (long long)n * cs] = alpha * acc[0][i][j][r];
+				const int m = bm + wm * (32 * WI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+				if (m < M) C[(long long)m * ldc + (long long)n * cs] = alpha * acc[i][j][r];
 			}
 		}
 }
@@ -308,6 +346,17 @@ extern "C" int dspfft_zoom_basis(float *d_basis, int type, double scale_num, dou
 	return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
+static int device_cu_count(int dev)
+{
+	static thread_local int cus[32] = {};
+	if (dev < 0 || dev >= 32) dev = 0;
+	if (!cus[dev]) {
+		int n = 0;
+		cus[dev] = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0 ? n : 256;
+	}
+	return cus[dev];
+}
+
 // fewer 128 x 128 tiles than the chip has CUs (DSPFFT_GEMM_TILE=128 / 64 forces either)
 static bool small_product(const dim3 &grid128)
 {
@@ -323,26 +372,32 @@ static int launch_dma(const float *A, const float *B, float *C, int M, int N, in
                       int batch, long long sa, long long sb, long long sc, float alpha, int nb1, long long sa2, long long sb2, long long sc2, const dim3 &grid, void *stream)
 {
 	static const int dma = getenv("DSPFFT_GEMM_DMA") ? atoi(getenv("DSPFFT_GEMM_DMA")) : 1;
-	if (!(dma && K >= 32 && ((lda | ldb | sa | sb | sa2 | sb2) & 3) == 0 && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0)) return 1;
+	if (!(dma && K >= 32 && ((lda | ldb | sa | sb | sa2 | sb2) & 3) == 0 && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0 && lda > 0 && ldb > 0 && lda < (1 << 22) && ldb < (1 << 22))) return 1;      // (32-bit lane offsets within a tile)
 	static thread_local float *zero_page[32] = {};
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
 	if (!zero_page[dev]) {
 		if (hipMalloc((void **)&zero_page[dev], 256) != hipSuccess || hipMemset(zero_page[dev], 0, 256) != hipSuccess) { snprintf(g_zerr, sizeof g_zerr, "no memory for the zero page"); return -3; }
 	}
-	const int ntn = (int)grid.x, ntiles = (int)(grid.x * grid.y);
-	// three batches that share A and interleave their outputs element by element (zoom's second product): one workgroup per tile for all three
-	static const int nb3 = getenv("DSPFFT_GEMM_NB3") ? atoi(getenv("DSPFFT_GEMM_NB3")) : 0;      // 1: one workgroup per tile for all three channels (measured slower: 2.26 against 2.11 ms for zoom's second product -- one workgroup per CU; profiles/r04_gemm.txt)
-	const bool b3 = nb3 && !nb1 && batch == 3 && cs == 3 && sa == 0 && sc == 1;
-	const size_t lds = 2 * (size_t)(b3 ? 4 : 2) * 128 * 32 * sizeof(float);
+	// tile shape: fewest rounds of 2 workgroups x CUs, weighted by the tile's area (DSPFFT_GEMM_SHAPE=0 / 1 forces 128 x 128 / 128 x 192)
+	static const int force = getenv("DSPFFT_GEMM_SHAPE") ? atoi(getenv("DSPFFT_GEMM_SHAPE")) : -1;
+	const long long slots = 2ll * device_cu_count(dev);
+	auto rounds_area = [&](int tm, int tn) {
+		const long long tiles = (long long)((M + tm - 1) / tm) * ((N + tn - 1) / tn) * batch;
+		return ((tiles + slots - 1) / slots) * tm * tn;
+	};
+	const bool wide = force >= 0 ? force == 1 : rounds_area(128, 192) < rounds_area(128, 128);
+	const int TN = wide ? 192 : 128;
+	const int ntn = (N + TN - 1) / TN, ntiles = ntn * (int)grid.y;
+	const size_t lds = 2 * (size_t)(128 + TN) * 32 * sizeof(float);
+	typedef void (*kern_t)(const float *, const float *, float *, int, int, int, long long, long long, long long, int, long long, long long, long long, float, const float *, int, int, long long, long long, long long);
+	const kern_t kern = wide ? static_cast<kern_t>(gemm_nt_f32_mfma_dma<2, 3>) : static_cast<kern_t>(gemm_nt_f32_mfma_dma<2, 2>);
 	static thread_local bool attr[2] = {false, false};
-	if (!attr[b3]) {
-		const void *k = b3 ? reinterpret_cast<const void *>(gemm_nt_f32_mfma_dma<3>) : reinterpret_cast<const void *>(gemm_nt_f32_mfma_dma<1>);
-		if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { snprintf(g_zerr, sizeof g_zerr, "cannot raise the LDS limit"); return -4; }
-		attr[b3] = true;
+	if (!attr[wide]) {
+		if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { snprintf(g_zerr, sizeof g_zerr, "cannot raise the LDS limit"); return -4; }
+		attr[wide] = true;
 	}
-	if (b3) hipLaunchKernelGGL(gemm_nt_f32_mfma_dma<3>, dim3(ntiles, 1, 1), dim3(256), lds, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, cs, sa, sb, sc, alpha, zero_page[dev], ntn, 0, 0ll, 0ll, 0ll);
-	else hipLaunchKernelGGL(gemm_nt_f32_mfma_dma<1>, dim3(ntiles, 1, batch), dim3(256), lds, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, cs, sa, sb, sc, alpha, zero_page[dev], ntn, nb1, sa2, sb2, sc2);
+	hipLaunchKernelGGL(kern, dim3(ntiles, 1, batch), dim3(256), lds, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, cs, sa, sb, sc, alpha, zero_page[dev], ntn, nb1, sa2, sb2, sc2);
 	return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
@@ -377,9 +432,9 @@ static int gemm_nt_f32_batch2(const float *A, const float *B, float *C, int M, i
 		else hipLaunchKernelGGL((gemm_nt_f32_mfma<8, 1>), g64, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, 1, sa1, sb1, sc1, 1.f, nb1, sa2, sb2, sc2);
 		return hipGetLastError() == hipSuccess ? 0 : -4;
 	}
-	// (the LDS-DMA kernel holds two workgroups per CU against three here: applybasis' 2048^2 spectrum -- 768 tiles, one and a half rounds -- ran
-	// at MfmaUtil 0.56 on it against 0.60 on this one; it takes over from 2048 tiles up)
-	if ((long long)grid.x * grid.y * grid.z >= 2048)
+	// the LDS-DMA kernel from one full round of the chip up (applybasis' 2048^2 spectrum, 768 tiles: 1.01 ms on it against 1.25 ms on this one)
+	static const long long dma_min = getenv("DSPFFT_GEMM_DMA_MIN_TILES") ? atoll(getenv("DSPFFT_GEMM_DMA_MIN_TILES")) : 512;
+	if ((long long)grid.x * grid.y * grid.z >= dma_min)
 		if (int rc = launch_dma(A, B, C, M, N, K, lda, ldb, ldc, 1, nb1 * nb2, sa1, sb1, sc1, 1.f, nb1, sa2, sb2, sc2, grid, stream); rc != 1) return rc;
 	if (K >= 16) hipLaunchKernelGGL(gemm_nt_f32_mfma<16>, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, 1, sa1, sb1, sc1, 1.f, nb1, sa2, sb2, sc2);
 	else hipLaunchKernelGGL(gemm_nt_f32_mfma<8>, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, 1, sa1, sb1, sc1, 1.f, nb1, sa2, sb2, sc2);
@@ -398,11 +453,14 @@ extern "C" int dspfft_zoom_product(const float *d_coeffs, int w, int h, const fl
 	const size_t npix = (size_t)w * h;
 	float *planes = d_work, *Tt = d_work + 3 * npix;
 	hipLaunchKernelGGL(deinterleave3_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, planes, d_coeffs, npix);
-	// Tt_z (vw x ch) = XB (vw x cw) . plane_z[:ch, :cw]^T
-	int rc = dspfft_gemm_nt_f32(d_xb, planes, Tt, vw, (int)ch, (int)cw, (long long)cw, w, (long long)ch, 1, 3, 0, (long long)npix, (long long)vw * ch, 1.f, stream);
+	// Tt (vw x 3 x ch: row 3 x + z) = XB (vw x cw) . plane_z[:ch, :cw]^T: the channels interleave by ROW, so every store is a contiguous run of ch floats
+	// (all rows kept, ch == h: the three planes are one matrix of 3 h rows and the product is one launch -- 1020 tiles of 128 x 192 for config 3
+	// instead of 3 x 540 of 128 x 128, two full rounds of the chip instead of three and a sixth)
+	int rc = ch == (size_t)h ? dspfft_gemm_nt_f32(d_xb, planes, Tt, vw, 3 * h, (int)cw, (long long)cw, w, (long long)ch * 3, 1, 1, 0, 0, 0, 1.f, stream)
+	                         : dspfft_gemm_nt_f32(d_xb, planes, Tt, vw, (int)ch, (int)cw, (long long)cw, w, (long long)ch * 3, 1, 3, 0, (long long)npix, (long long)ch, 1.f, stream);
 	if (rc) return rc;
-	// out_z (vh x vw, interleaved) = YB (vh x ch) . Tt_z^T / (w h)
-	return dspfft_gemm_nt_f32(d_yb, Tt, d_out, vh, vw, (int)ch, (long long)ch, (long long)ch, (long long)vw * 3, 3, 3, 0, (long long)vw * ch, 1, 1.f / ((float)w * (float)h), stream);
+	// out (vh x 3 vw: the interleaved frame as it is) = YB (vh x ch) . Tt^T / (w h): ONE product for the three channels, plain contiguous stores
+	return dspfft_gemm_nt_f32(d_yb, Tt, d_out, vh, vw * 3, (int)ch, (long long)ch, (long long)ch, (long long)vw * 3, 1, 1, 0, 0, 0, 1.f / ((float)w * (float)h), stream);
 }
 
 // ---- applybasis' partial sums (applybasis/applybasis.c:410-431) as TWO batched NT GEMM launches ----

@@ -34,12 +34,24 @@ A3 = torch.rand(8192, 4096, device="cuda:0"); B3 = torch.rand(8192, 4096, device
 ms = t(lambda: L.dspfft_gemm_nt_f32(A3.data_ptr(), B3.data_ptr(), C3.data_ptr(), 8192, 8192, 4096, 4096, 4096, 8192, 1, 1, 0, 0, 0, 1.0, None))
 print("gemm 8192x8192x4096 ms", ms, "TF", 2 * 8192 * 8192 * 4096 / ms / 1e9)
 
-# the two products of a config-3 frame as dspfft_zoom_product launches them: three channels per launch
+# the two products of a config-3 frame the way round 3 launched them: three channels per launch, the second storing with cs = 3
 planes = torch.rand(3, h, w, device="cuda:0"); Tt = torch.empty(3, vw, ch, device="cuda:0")
 ms = t(lambda: L.dspfft_gemm_nt_f32(xb.data_ptr(), planes.data_ptr(), Tt.data_ptr(), vw, ch, cw, cw, w, ch, 1, 3, 0, w * h, vw * ch, 1.0, None))
-print("product 1 (7680x1080x1920 x 3 channels) ms", ms, "TF", 3 * 2 * vw * ch * cw / ms / 1e9)
+print("product 1, one launch of 3 channels (7680x1080x1920 x 3) ms", ms, "TF", 3 * 2 * vw * ch * cw / ms / 1e9)
 ms = t(lambda: L.dspfft_gemm_nt_f32(yb.data_ptr(), Tt.data_ptr(), out.data_ptr(), vh, vw, ch, ch, ch, vw * 3, 3, 3, 0, vw * ch, 1, 1.0, None))
-print("product 2 (4320x7680x1080 x 3 channels, interleaved store) ms", ms, "TF", 3 * 2 * vh * vw * ch / ms / 1e9)
+print("product 2, 3 channels with the interleaved store (4320x7680x1080 x 3, cs=3) ms", ms, "TF", 3 * 2 * vh * vw * ch / ms / 1e9)
+# ... and as dspfft_zoom_product launches them now: Tt's rows are (x, channel), so both are ONE plain product with contiguous stores
+ms = t(lambda: L.dspfft_gemm_nt_f32(xb.data_ptr(), planes.data_ptr(), Tt.data_ptr(), vw, 3 * ch, cw, cw, w, 3 * ch, 1, 1, 0, 0, 0, 1.0, None))
+print("product 1 as one matrix (7680x3240x1920) ms", ms, "TF", 3 * 2 * vw * ch * cw / ms / 1e9)
+ms = t(lambda: L.dspfft_gemm_nt_f32(yb.data_ptr(), Tt.data_ptr(), out.data_ptr(), vh, 3 * vw, ch, ch, ch, vw * 3, 1, 1, 0, 0, 0, 1.0, None))
+print("product 2 as one matrix (4320x23040x1080) ms", ms, "TF", 3 * 2 * vh * vw * ch / ms / 1e9)
 A4 = torch.rand(4096, 4096, device="cuda:0"); B4 = torch.rand(4096, 4096, device="cuda:0"); C4 = torch.empty(4096, 4096, device="cuda:0")
 ms = t(lambda: L.dspfft_gemm_nt_f32(A4.data_ptr(), B4.data_ptr(), C4.data_ptr(), 4096, 4096, 4096, 4096, 4096, 4096, 1, 1, 0, 0, 0, 1.0, None))
 print("gemm 4096^3 ms", ms, "TF", 2 * 4096 ** 3 / ms / 1e9)
+
+# applybasis: the full dct2 spectrum of an n x n image (two batched products of n^3 per channel)
+from dspfun_amd.applybasis import partsums
+for n in (1024, 2048):
+    img = torch.rand(n, n, 3, device="cuda:0") * 2 - 1
+    ms = t(lambda: partsums(torch, img, "dct2", True, None, (n, n)), reps=10)
+    print("applybasis dct2 spectrum of %d^2 ms" % n, ms, "TF", 3 * 2 * 2 * n ** 3 / ms / 1e9)
