@@ -230,9 +230,11 @@ class ChannelShardedScan:
     one all_gather to rebuild the interleaved sum on every rank (e.g. to encode the output frame).
 
     Each rank holds its planes planar ([h][w] f32): forward REDFT10^2 with the 1/(4wh) normalisation fused, zigzag
-    frame ids, then per output frame one fused masked-accumulate execution (or the pruned path for tiny steps)."""
+    frame ids, then per output frame one fused masked-accumulate execution (or the pruned path for tiny steps).
+    A rank that owns EVERY plane (one GPU) keeps the image interleaved as the tool has it (scan.c:292-293) and runs one
+    execution per frame for the three channels instead of three; `layout="planar"` forces the planar form there too."""
 
-    def __init__(self, image_hwc, step, group=None, lib=None):
+    def __init__(self, image_hwc, step, group=None, lib=None, layout="auto"):
         from . import _lib
         self.lib = lib or _lib.load()
         self.group = group
@@ -242,21 +244,30 @@ class ChannelShardedScan:
         self.step = int(step)
         self.nframes = (self.w * self.h + self.step - 1) // self.step          # scan.c:347-348 with limit = w*h
         self.mine = [z for z in range(self.c) if z % self.G == self.rank]
+        if layout not in ("auto", "planar"):
+            raise ValueError("layout is 'auto' or 'planar'")
+        self.interleaved = layout == "auto" and len(self.mine) == self.c
+        self.nch = self.c if self.interleaved else 1             # channels of one execution
         dev = image_hwc.device
-        self.coeffs = [image_hwc[:, :, z].contiguous().clone() for z in self.mine]
-        self.fwd = Plan.many_r2r([self.h, self.w], [REDFT10] * 2, lib=lib).set_scale(1.0 / (4.0 * self.w * self.h))
-        self.inv = Plan.many_r2r([self.h, self.w], [REDFT01] * 2, lib=lib)
+        if self.interleaved:
+            self.coeffs = [image_hwc.contiguous().clone()]
+            self.fwd = Plan.image(self.h, self.w, self.c, REDFT10, lib=lib).set_scale(1.0 / (4.0 * self.w * self.h))
+            self.inv = Plan.image(self.h, self.w, self.c, REDFT01, lib=lib)
+        else:
+            self.coeffs = [image_hwc[:, :, z].contiguous().clone() for z in self.mine]
+            self.fwd = Plan.many_r2r([self.h, self.w], [REDFT10] * 2, lib=lib).set_scale(1.0 / (4.0 * self.w * self.h))
+            self.inv = Plan.many_r2r([self.h, self.w], [REDFT01] * 2, lib=lib)
         self.ids = torch.zeros(self.w * self.h, dtype=torch.int32, device=dev)
         st = SlabDCT3D._stream(image_hwc) or None     # every helper on torch's current stream, like the transforms
         self._check(self.lib.dspfft_scan_zigzag_frame_ids(self.ids.data_ptr(), self.w, self.h, self.step, st))
         # the owner ids stay the same over the frames: let the fused step skip the column tiles a frame does not touch without reading their ids
-        self.inv.scan_prepare(self.ids.data_ptr(), 1, stream=st or 0)
-        self.work = torch.empty((self.h, self.w), dtype=torch.float32, device=dev)
+        self.inv.scan_prepare(self.ids.data_ptr(), self.nch, stream=st or 0)
+        self.work = torch.empty_like(self.coeffs[0]) if self.coeffs else None
         self.sums = []
         for cz in self.coeffs:
             self.fwd.execute(cz.data_ptr(), stream=SlabDCT3D._stream(cz))
             s = torch.empty_like(cz)
-            self._check(self.lib.dspfft_broadcast_dc(s.data_ptr(), cz.data_ptr(), self.w * self.h, 1, st))   # scan.c:377-383
+            self._check(self.lib.dspfft_broadcast_dc(s.data_ptr(), cz.data_ptr(), self.w * self.h, self.nch, st))   # scan.c:377-383
             self.sums.append(s)
         self.frame = 0
 
@@ -264,12 +275,19 @@ class ChannelShardedScan:
         if rc:
             raise RuntimeError(self.lib.dspfft_last_error().decode())
 
+    def warm(self):
+        """one step with a frame id that no coefficient carries: every column tile is skipped and zeros are added to the running sums, which
+        stay as they are -- loads the step's kernels before a timed loop"""
+        for cz, s in zip(self.coeffs, self.sums):
+            self.inv.execute_masked_accumulate(cz.data_ptr(), self.work.data_ptr(), s.data_ptr(), self.ids.data_ptr(), self.nframes, self.nch,
+                                               stream=SlabDCT3D._stream(cz))
+
     def next_frame(self):
         """adds the coefficients of output frame `self.frame` into this rank's running sums"""
         if self.frame >= self.nframes:
             return False
         for cz, s in zip(self.coeffs, self.sums):
-            self.inv.execute_masked_accumulate(cz.data_ptr(), self.work.data_ptr(), s.data_ptr(), self.ids.data_ptr(), self.frame, 1,
+            self.inv.execute_masked_accumulate(cz.data_ptr(), self.work.data_ptr(), s.data_ptr(), self.ids.data_ptr(), self.frame, self.nch,
                                                stream=SlabDCT3D._stream(cz))
         self.frame += 1
         return True
@@ -277,6 +295,8 @@ class ChannelShardedScan:
     def gather(self):
         """interleaved (h, w, c) running sum on every rank"""
         dev = self.ids.device
+        if self.interleaved:
+            return self.sums[0].clone()
         out = torch.empty((self.h, self.w, self.c), dtype=torch.float32, device=dev)
         if self.G == 1:
             for z, s in zip(self.mine, self.sums):

@@ -134,6 +134,33 @@ def _scan_worker(rank, world, port, h, w, step, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("layout", ["auto", "planar"])
+def test_channel_sharded_scan_one_rank_layouts(layout):
+    """no process group: the only rank owns the three planes and keeps the image interleaved (one execution per frame); "planar" forces the
+    per-plane form the larger worlds use -- both against the f64 restatement of scan.c:421-459"""
+    import oracle_lib as ol
+    from emul_lib import emul
+    from dspfun_amd.dist import ChannelShardedScan
+    h, w, step = 12, 20, 37
+    x = ol.synth_f32(0xD5F0004, h * w * 3).reshape(h, w, 3)
+    eng = ChannelShardedScan(torch.from_numpy(x.copy()), step, lib=emul(), layout=layout)
+    assert eng.interleaved == (layout == "auto") and eng.mine == [0, 1, 2]
+    before = eng.gather().numpy().copy()
+    eng.warm()                                              # a frame id nobody owns: the sums stay bit for bit
+    assert np.array_equal(before, eng.gather().numpy())
+    c64 = np.ascontiguousarray(ol.dct2d_interleaved(x.astype(np.float64), ol.REDFT10))
+    ol.lib().oracle_scan_normalise_f64(c64.ctypes.data, w, h, 3)
+    ref = np.ascontiguousarray(np.broadcast_to(c64[0, 0], (h, w, 3)).copy())
+    zz = ol.zigzag_order(w, h)
+    k = 0
+    while eng.next_frame():
+        lin = np.ascontiguousarray(zz[k * step:(k + 1) * step])
+        ol.lib().oracle_scan_frame_f64(w, h, 3, c64.ctypes.data, lin.ctypes.data, lin.size, ref.ctypes.data)
+        k += 1
+        assert float(np.abs(eng.gather().numpy() - ref).max()) < 5e-6, k
+    assert k == eng.nframes and float(np.abs(eng.gather().numpy() - x).max()) < 5e-6
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_channel_sharded_scan(world):
     """BASELINE config 4 names 4 GPUs for 3 colour planes: with world 4 the fourth rank owns no plane (75 % ceiling, stated in DESIGN 6)"""

@@ -590,15 +590,17 @@ def test_slab_dct3d_single_rank_matches_rank3_plan(gpu):
     assert float((eng5.inverse(c5) - x).abs().max()) < 1e-3
 
 
-def test_channel_sharded_scan_single_rank(gpu):
-    """config 4's channel-sharded layout (planar planes, dspfun_amd.dist.ChannelShardedScan) reconstructs the
-    same running sums as the interleaved path; world size 1 here, world 2 in tests/test_dist_cpu.py"""
+@pytest.mark.parametrize("layout", ["auto", "planar"])
+def test_channel_sharded_scan_single_rank(gpu, layout):
+    """config 4's channel-sharded layout (dspfun_amd.dist.ChannelShardedScan) reconstructs the running sums of scan.c:421-459; world size 1
+    here (a rank that owns every plane keeps the image interleaved; "planar" forces the form the other world sizes use), world 2 and 4 in
+    tests/test_dist_cpu.py"""
     from dspfun_amd.dist import ChannelShardedScan
     w, h, c = 960, 540, 3
     x = ol.synth_f32(0xD5F0004, w * h * c).reshape(h, w, c)
     step = (w * h + 4) // 5
-    eng = ChannelShardedScan(dev(gpu, x), step)
-    assert eng.nframes == 5 and eng.mine == [0, 1, 2]
+    eng = ChannelShardedScan(dev(gpu, x), step, layout=layout)
+    assert eng.nframes == 5 and eng.mine == [0, 1, 2] and eng.interleaved == (layout == "auto")
     cf64 = np.ascontiguousarray(ol.dct2d_interleaved(x.astype(np.float64), 5, impl="port"))
     ol.lib().oracle_scan_normalise_f64(cf64.ctypes.data, w, h, c)
     ref = np.ascontiguousarray(np.broadcast_to(cf64[0, 0], (h, w, c)).copy())
