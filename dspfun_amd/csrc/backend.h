@@ -109,6 +109,8 @@ int be_scan_stamp(uint32_t *ids, const uint32_t *lin, uint64_t n, uint32_t frame
 int be_scan_index_to_frame_ids(uint32_t *ids, uint64_t n, uint64_t step, void *stream);
 // ranges[2 * (half * ntiles + tile)] = min, [.. + 1] = max owner id of the tile (scan_core.h tile_range_item); halves = 1 or 2
 int be_scan_tile_ranges(uint32_t *ranges, const uint32_t *ids, TileRangeGeom g, int halves, void *stream);
+int be_scan_tile_eids(void *eids, const uint32_t *ids, TileEidGeom g, void *stream);     // scan_core.h tile_eid_item over every element
+int be_download(void *dst, const void *src, size_t bytes, void *stream);                // device -> host, after the stream's work (synchronous)
 size_t be_scan_magnitude_work_bytes(uint32_t w, uint32_t h);
 int be_scan_magnitude_index(uint32_t *idx, const float *coeffs, uint32_t w, uint32_t h, int ch, double q, void *work, size_t work_bytes, uint32_t *limit, void *stream);
 

@@ -240,6 +240,7 @@ __global__ void region_f32_to_u8_kernel(uint8_t *d, const float *s, double mul, 
 void *be_alloc(size_t bytes) { void *p = nullptr; if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return nullptr; return p; }
 void be_free(void *p) { if (p) (void)hipFree(p); }
 int be_upload(void *dst, const void *src, size_t bytes) { HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return 0; }
+int be_download(void *dst, const void *src, size_t bytes, void *stream) { HIPCHK(hipStreamSynchronize((hipStream_t)stream)); HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return 0; }
 void *be_event_create() { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return nullptr; return (void *)e; }
 void be_event_destroy(void *e) { if (e) (void)hipEventDestroy((hipEvent_t)e); }
 int be_event_record(void *e, void *stream) { HIPCHK(hipEventRecord((hipEvent_t)e, (hipStream_t)stream)); return 0; }

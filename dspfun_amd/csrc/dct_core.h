@@ -97,6 +97,8 @@ struct PassGeom {
 	const uint32_t *mask;
 	uint32_t mask_id;
 	FastDiv mask_div;     // elements per owner id (32-bit offsets: masked runs are limited to 2^32 / d elements)
+	int mask_mode;        // column tiles (dct_spec.h, masked_two_step): 0 = owner ids from `mask`, item by item; 1 / 2 = from `eids`, one / two bytes per id
+	const void *eids;     // dspfft_plan_scan_prepare: the owner id of every element, in column-tile order (eid_index); needs zpage
 	int accumulate;
 	// sparse scan frames (specialised kernels, dct_spec.h): a masked COL first pass records per tile whether any coefficient was
 	// selected (zflags[tile] = 0 / 1) and skips the tiles with none; the ROW pass that follows reads zeros for those tiles, not `in`

@@ -173,6 +173,52 @@ template <bool MASKED, class Re> DSP_HD typename sig_of<Re>::type loadv_m(const 
 	}
 	return *reinterpret_cast<const V *>(a.in + off);
 }
+// The same from a table the plan prepared (dspfft_plan_scan_prepare, PassGeom::eids): the owner id of every ELEMENT of the image, one or two
+// bytes each, in the order the column tiles read them -- [tile][row][K] (rows of a split pass: even rows, then odd rows).  A lane's ids
+// are then one 4- or 8-byte load next to its neighbours' (a wave: 256 or 512 contiguous bytes), where the owner-id array itself costs one
+// 128-byte line per tile ROW for 22 bytes of it: 6.8 M L2 requests per 8K frame, every one a miss in the vector L1 -- the 8K column pass
+// spent 155 of its 200 us on them, whatever the order of the loads and whichever XCD the neighbours ran on (profiles/r04_scan_mask.txt).
+// Two steps: all ids of a thread's items, then all coefficients, an item nobody selected from the page of zeros (no branch between loads).
+// EB = bytes per id; ids that do not fit (and the DC pixel's "no frame") are stored as all ones and match no frame the table is used for.
+template <int EB, class Re> struct MaskIds { uint32_t v[EB == 1 ? 1 : 2 * sig_of<Re>::NCS * EB / 4]; };
+template <int EB, class Re> DSP_HD void mask_fetch_ids(const PassArgsT<Re> &a, long long eoff, MaskIds<EB, Re> &m)
+{
+	constexpr int NW = sizeof(m.v) / 4;
+	const uint32_t *p = reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(a.eids) + eoff * EB);
+	static_for<0, NW>([&](auto w) { m.v[w] = p[w]; });
+}
+template <int EB, class Re> DSP_HD typename sig_of<Re>::type mask_select_load(const PassArgsT<Re> &a, long long off, const MaskIds<EB, Re> &m, bool &hit)
+{
+	typedef typename sig_of<Re>::type V;
+	constexpr int NCS = sig_of<Re>::NCS, NE = 2 * NCS;
+	const uint32_t want = a.mask_id, ones = EB == 1 ? 0xffu : 0xffffu;
+	bool sel[NE];
+	bool any = false;
+	static_for<0, NE>([&](auto c) {
+		constexpr int bit = c * 8 * EB;
+		sel[c] = ((m.v[bit / 32] >> (bit % 32)) & ones) == want;
+		any = any || sel[c];
+	});
+	hit = hit || any;
+	V v = *(any ? reinterpret_cast<const V *>(a.in + off) : reinterpret_cast<const V *>(a.zpage));
+	static_for<0, NCS>([&](auto i) { if (!sel[2 * i]) v.s[i].x = (Re)0; if (!sel[2 * i + 1]) v.s[i].y = (Re)0; });
+	return v;
+}
+// NITEM items: off_of(i, off, eoff) -> whether item i exists for this thread, its element offset in the image and in the id table; sink(i, v)
+template <int EB, int NITEM, class Re, class OFF, class SINK>
+DSP_HD void masked_two_step(const PassArgsT<Re> &a, bool &hit, OFF off_of, SINK sink)
+{
+	MaskIds<EB, Re> ids[NITEM];
+	static_for<0, NITEM>([&](auto i) { long long off, eoff; if (off_of(i, off, eoff)) mask_fetch_ids<EB, Re>(a, eoff, ids[i]); });
+	static_for<0, NITEM>([&](auto i) { long long off, eoff; if (off_of(i, off, eoff)) sink(i, mask_select_load<EB, Re>(a, off, ids[i], hit)); });
+}
+// element (row y, tile t, k) of the id table; rows of a split pass (halves == 2) are stored by parity
+DSP_HD long long eid_index(int N, int K, int halves, int t, int y, int k)
+{
+	const int r = halves == 2 ? (y & 1) * (N / 2) + (y >> 1) : y;
+	return ((long long)t * N + r) * K + k;
+}
+
 template <class Re> DSP_HD void storev_a(const PassArgsT<Re> &a, long long off, typename sig_of<Re>::type r)
 {
 	typedef typename sig_of<Re>::type V;
@@ -612,7 +658,40 @@ struct ColSpecT {
 	template <int KIND, class ST>
 	static DSP_HD void prefetch(const PA &a, long long bin, int tid, ST &st, bool &hit)
 	{
-		if (a.mask) prefetch_m<KIND, true>(a, bin, tid, st, hit); else prefetch_m<KIND, false>(a, bin, tid, st, hit);
+		if (a.mask && a.mask_mode == 1) prefetch_2step<KIND, 1>(a, bin, tid, st, hit);
+		else if (a.mask && a.mask_mode == 2) prefetch_2step<KIND, 2>(a, bin, tid, st, hit);
+		else if (a.mask) prefetch_m<KIND, true>(a, bin, tid, st, hit); else prefetch_m<KIND, false>(a, bin, tid, st, hit);
+	}
+	// masked loads with the ids from the plan's table (masked_two_step; one image: bin = tile * K): the items and their order are prefetch_m's
+	template <int KIND, int EB, class ST>
+	static DSP_HD void prefetch_2step(const PA &a, long long bin, int tid, ST &st, bool &hit)
+	{
+		const int t = (int)(bin / K);
+		if constexpr (KIND == KIND_REDFT10) {
+			masked_two_step<EB, Y_ROUNDS, Re>(a, hit, [&](auto i, long long &off, long long &eoff) {
+				const int it = tid + i * T;
+				if (!((i + 1) * T <= N * NP || it < N * NP)) return false;
+				const int y = it / NP, jp = it - y * NP;
+				off = bin + (long long)y * a.es_in + VW * jp;
+				eoff = eid_index(N, K, 1, t, y, VW * jp);
+				return true;
+			}, [&](auto i, V v) { st.pre[i] = g_get(v); });
+		} else {
+			static_for<0, K_ROUNDS>([&](auto i) {
+				const int it = tid + i * T;
+				if ((i + 1) * T <= (N / 2 + 1) * NP || it < (N / 2 + 1) * NP) st.tw[i] = a.T[it / NP];
+			});
+			masked_two_step<EB, 2 * K_ROUNDS, Re>(a, hit, [&](auto j, long long &off, long long &eoff) {
+				constexpr int i = j / 2;
+				const int it = tid + i * T;
+				if (!((i + 1) * T <= (N / 2 + 1) * NP || it < (N / 2 + 1) * NP)) return false;
+				const int k = it / NP, jp = it - k * NP;
+				const int y = j % 2 ? (k ? N - k : 0) : k;
+				off = bin + VW * jp + (long long)y * a.es_in;
+				eoff = eid_index(N, K, 1, t, y, VW * jp);
+				return true;
+			}, [&](auto j, V v) { st.pre[j] = g_get(v); });
+		}
 	}
 	template <int KIND, bool MASKED, class ST>
 	static DSP_HD void prefetch_m(const PA &a, long long bin, int tid, ST &st, bool &hit)
@@ -983,7 +1062,42 @@ struct ColHalfSpecT {
 	template <int KIND, class ST>
 	static DSP_HD void prefetch(const PA &a, long long bin, int h, int tid, ST &st, bool &hit)
 	{
-		if (a.mask) prefetch_m<KIND, true>(a, bin, h, tid, st, hit); else prefetch_m<KIND, false>(a, bin, h, tid, st, hit);
+		if (a.mask && a.mask_mode == 1) prefetch_2step<KIND, 1>(a, bin, h, tid, st, hit);
+		else if (a.mask && a.mask_mode == 2) prefetch_2step<KIND, 2>(a, bin, h, tid, st, hit);
+		else if (a.mask) prefetch_m<KIND, true>(a, bin, h, tid, st, hit); else prefetch_m<KIND, false>(a, bin, h, tid, st, hit);
+	}
+	// masked loads with the ids from the plan's table (masked_two_step; one image: bin = tile * K): the items and their order are prefetch_m's
+	template <int KIND, int EB, class ST>
+	static DSP_HD void prefetch_2step(const PA &a, long long bin, int h, int tid, ST &st, bool &hit)
+	{
+		const int t = (int)(bin / K);
+		if constexpr (KIND == KIND_REDFT10) {
+			masked_two_step<EB, Y_ROUNDS, Re>(a, hit, [&](auto i, long long &off, long long &eoff) {
+				const int it = tid + i * T;
+				if (!((i + 1) * T <= M * NP || it < M * NP)) return false;
+				const int n = it / NP, jp = it - n * NP, y = row_of(n, h);
+				off = bin + (long long)y * a.es_in + VW * jp;
+				eoff = eid_index(N, K, 2, t, y, VW * jp);
+				return true;
+			}, [&](auto i, V v) { st.pre[i] = B::g_get(v); });
+			prefetch_tw<KIND>(a, h, tid, st);
+		} else {
+			auto item = [&](int i, int &q, int &jp) {
+				const int it = tid + i * T;
+				if (!((i + 1) * T <= NQ || it < NQ)) return false;
+				q = it / NP; jp = it - q * NP;
+				return !(h && q >= M / 2);
+			};
+			static_for<0, Q_ROUNDS>([&](auto i) { int q, jp; if (item(i, q, jp)) st.tw[i] = a.T[2 * q + h]; });
+			masked_two_step<EB, 2 * Q_ROUNDS, Re>(a, hit, [&](auto j, long long &off, long long &eoff) {
+				int q, jp;
+				if (!item(j / 2, q, jp)) return false;
+				const int k = 2 * q + h, y = j % 2 ? (k ? N - k : 0) : k;
+				off = bin + VW * jp + (long long)y * a.es_in;
+				eoff = eid_index(N, K, 2, t, y, VW * jp);
+				return true;
+			}, [&](auto j, V v) { st.pre[j] = B::g_get(v); });
+		}
 	}
 	// WITH_TW = false leaves the twiddles of the tile (hw / tw) to prefetch_tw: the persistent kernel fetches them late, so that only
 	// the rows of the next tile occupy registers during the butterfly stages

@@ -184,6 +184,10 @@ struct dspfft_plan_s {
 	const void *zr_ids = nullptr;
 	int zr_div = 0;
 	bool zr_split = false;
+	// ... and, for single-precision plans, the owner id of every element in the column tiles' reading order (PassGeom::eids), eid_bytes each
+	void *eids = nullptr;
+	size_t eids_bytes = 0;
+	int eid_bytes = 0;         // 0: not built (the column pass reads zr_ids itself)
 	// dspfft_plan_set_input_window: rows of `win_axis` outside [win_lo, win_hi) are zero by contract (first pass, specialised COL REDFT01)
 	int win_axis = -1, win_lo = 0, win_hi = 0;
 	int alt_axis = -1;         // dspfft_plan_set_output_alternate
@@ -682,7 +686,7 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 	}
 }
 
-struct Fuse { const uint32_t *mask = nullptr; uint32_t id = 0; int div = 1; bool accumulate = false; uint8_t *zflags = nullptr; int zshift = 0, zhalf = 0; const void *zpage = nullptr; const uint32_t *zranges = nullptr; };
+struct Fuse { const void *eids = nullptr; int eid_bytes = 0; const uint32_t *mask = nullptr; uint32_t id = 0; int div = 1; bool accumulate = false; uint8_t *zflags = nullptr; int zshift = 0, zhalf = 0; const void *zpage = nullptr; const uint32_t *zranges = nullptr; };
 FastDiv make_div(uint32_t d);
 
 template <class R>
@@ -693,6 +697,9 @@ void fill_args(PassArgsT<R> &a, const PassGeom &g, const dspfft_plan_s *pl, cons
 	a.scale = (R)scale; a.in_scale0 = (R)pl->in0[P.axis]; a.out_scale0 = (R)pl->out0[P.axis];
 	a.mask = fz.mask; a.mask_id = fz.id; a.mask_div = make_div((uint32_t)fz.div); a.accumulate = fz.accumulate;
 	a.zflags = fz.zflags; a.zshift = fz.zshift; a.zhalf = fz.zhalf; a.zpage = fz.zpage; a.zranges = fz.zranges;
+	// masked column tiles take their owner ids from the plan's element-order table where one was prepared for this id array and the frame id fits it
+	a.mask_mode = 0; a.eids = nullptr;
+	if (fz.mask && fz.zpage && fz.eids && fz.eid_bytes && fz.id < (fz.eid_bytes == 1 ? 0xffu : 0xffffu)) { a.mask_mode = fz.eid_bytes; a.eids = fz.eids; }
 	a.alt_out = (pl->alt_axis == P.axis && pl->alt_axis >= 0) ? 1 : 0;
 	static const int lean_off = []() { const char *e = getenv("DSPFFT_LEAN01"); return e && *e == '0' ? 1 : 0; }();
 	a.lean_off = lean_off;
@@ -1204,6 +1211,28 @@ extern "C" int dspfft_plan_scan_prepare(dspfft_plan pl, const uint32_t *d_ids, i
 	g.K = gc.K; g.ntiles = gc.ntiles; g.nrows = gc.N / halves; g.row_start = 0; g.row_step = 1; g.es = gc.es_in; g.div = make_div((uint32_t)elems_per_id);
 	if (be_scan_tile_ranges((uint32_t *)pl->zranges, d_ids, g, halves, stream)) return fail(-4, "launch failed");
 	pl->zr_ids = d_ids; pl->zr_div = elems_per_id; pl->zr_split = split;
+	// the element-order id table (dct_spec.h, masked_two_step): one byte per id while every frame id is below 255, else two.
+	// DSPFFT_SCAN_EIDS=0: not built (A/B runs)
+	pl->eid_bytes = 0;
+	const char *env_eids = getenv("DSPFFT_SCAN_EIDS");
+	const bool no_eids = env_eids && *env_eids == '0';
+	if (!pl->f64 && !no_eids && gc.K % 4 == 0 && gc.es_in % elems_per_id == 0 && (long long)gc.ntiles * gc.K == gc.ninner) {
+		std::vector<uint32_t> rg((size_t)2 * halves * gc.ntiles);
+		if (be_download(rg.data(), pl->zranges, rg.size() * sizeof(uint32_t), stream)) return fail(-4, "download failed");
+		uint32_t top = 0;
+		for (size_t i = 0; i < rg.size(); i += 2) if (rg[i] <= rg[i + 1] && rg[i + 1] > top) top = rg[i + 1];      // (an empty tile holds lo > hi)
+		const int eb = top < 0xffu ? 1 : top < 0xffffu ? 2 : 0;
+		const size_t bytes = (size_t)gc.ntiles * gc.N * gc.K * eb;
+		if (eb) {
+			if (pl->eids_bytes < bytes) { be_free(pl->eids); pl->eids = be_alloc(bytes); pl->eids_bytes = pl->eids ? bytes : 0; }
+			if (pl->eids) {
+				TileEidGeom e;
+				e.K = gc.K; e.ntiles = gc.ntiles; e.N = gc.N; e.halves = halves; e.bytes = eb; e.es = gc.es_in; e.div = make_div((uint32_t)elems_per_id);
+				if (be_scan_tile_eids(pl->eids, d_ids, e, stream)) return fail(-4, "launch failed");
+				pl->eid_bytes = eb;
+			}
+		}
+	}
 	return 0;
 }
 
@@ -1229,6 +1258,8 @@ int execute_masked_accumulate_t(dspfft_plan pl, const R *d_in, R *d_work, R *d_a
 	uint8_t *zflags = nullptr;
 	int zshift = 0, zhalf = 0;
 	const uint32_t *zranges = nullptr;
+	const void *eids = nullptr;
+	int eid_bytes = 0;
 	size_t order[2] = {0, 1};
 	if (d_ids && np == 2 && sparse_order(pl, passes, split_ok, order)) {
 		const PassGeom &gc = split_ok ? passes[order[0]].hpa : passes[order[0]].spa;
@@ -1240,7 +1271,10 @@ int execute_masked_accumulate_t(dspfft_plan pl, const R *d_in, R *d_work, R *d_a
 			if (pl->zflags && pl->zpage) {
 				zflags = (uint8_t *)pl->zflags; zhalf = split_ok ? gc.ntiles : 0;
 				while ((1 << zshift) < gc.K) zshift++;
-				if (pl->zranges && pl->zr_ids == (const void *)d_ids && pl->zr_div == elems_per_id && pl->zr_split == split_ok) zranges = (const uint32_t *)pl->zranges;
+				if (pl->zranges && pl->zr_ids == (const void *)d_ids && pl->zr_div == elems_per_id && pl->zr_split == split_ok) {
+					zranges = (const uint32_t *)pl->zranges;
+					if (pl->eid_bytes) { eids = pl->eids; eid_bytes = pl->eid_bytes; }
+				}
 			}
 		}
 	}
@@ -1252,6 +1286,7 @@ int execute_masked_accumulate_t(dspfft_plan pl, const R *d_in, R *d_work, R *d_a
 		if (firstp && d_ids) { fz.mask = d_ids; fz.id = id; fz.div = elems_per_id; }
 		fz.accumulate = lastp;
 		fz.zflags = zflags; fz.zshift = zshift; fz.zhalf = zhalf; fz.zpage = pl->zpage; fz.zranges = zranges;
+		if (firstp && std::is_same<R, float>::value) { fz.eids = eids; fz.eid_bytes = eid_bytes; }
 		const R *src = firstp ? d_in : d_work;
 		R *dst = lastp ? d_acc : d_work;
 		int rc = run_pass<R>(pl, P, src, dst, lastp, stream, fz);
@@ -1747,7 +1782,7 @@ extern "C" void dspfft_destroy_plan(dspfft_plan pl)
 	if (!pl) return;
 	for (Pass &P : pl->passes) P.tab.release();
 	for (Pass &P : pl->split) P.tab.release();
-	be_free(pl->zflags); be_free(pl->zpage); be_free(pl->zranges);
+	be_free(pl->zflags); be_free(pl->zpage); be_free(pl->zranges); be_free(pl->eids);
 	delete pl;
 }
 

@@ -123,4 +123,19 @@ DSP_HD void tile_range_item(const TileRangeGeom &g, const uint32_t *ids, int til
 	if (id != 0xFFFFFFFFu) { lo = id < lo ? id : lo; hi = id > hi ? id : hi; }
 }
 
+// The owner id of every element of the image in the order the column tiles of a fused scan step read them (dct_spec.h, eid_index:
+// [tile][row][K], the rows of a split pass by parity), `bytes` (1 or 2) per id; ids that do not fit, and 0xFFFFFFFF, become all ones.
+struct TileEidGeom { int K, ntiles, N, halves, bytes; long long es; FastDiv div; };
+DSP_HD void tile_eid_item(const TileEidGeom &g, const uint32_t *ids, void *eids, long long item)
+{
+	const long long per_tile = (long long)g.N * g.K;
+	const int t = (int)(item / per_tile);
+	const long long rem = item - (long long)t * per_tile;
+	const int r = (int)(rem / g.K), k = (int)(rem - (long long)r * g.K);
+	const int y = g.halves == 2 ? (r < g.N / 2 ? 2 * r : 2 * (r - g.N / 2) + 1) : r;       // the inverse of eid_index's row order
+	const uint32_t id = ids[g.div.div((uint32_t)((long long)y * g.es + (long long)t * g.K + k))];
+	if (g.bytes == 1) reinterpret_cast<uint8_t *>(eids)[item] = id < 0xffu ? (uint8_t)id : (uint8_t)0xffu;
+	else reinterpret_cast<uint16_t *>(eids)[item] = id < 0xffffu ? (uint16_t)id : (uint16_t)0xffffu;
+}
+
 }  // namespace dspfft

@@ -116,6 +116,17 @@ int be_scan_tile_ranges(uint32_t *ranges, const uint32_t *ids, TileRangeGeom g, 
 	HIPCHK(hipGetLastError());
 	return 0;
 }
+__global__ void __launch_bounds__(256) tile_eids_kernel(void *eids, const uint32_t *ids, const TileEidGeom g, long long items)
+{
+	for (long long it = blockIdx.x * 256ll + threadIdx.x; it < items; it += (long long)gridDim.x * 256) tile_eid_item(g, ids, eids, it);
+}
+int be_scan_tile_eids(void *eids, const uint32_t *ids, TileEidGeom g, void *stream)
+{
+	const long long items = (long long)g.ntiles * g.N * g.K;
+	hipLaunchKernelGGL(tile_eids_kernel, dim3(8192), dim3(256), 0, (hipStream_t)stream, eids, ids, g, items);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
 int be_scan_index_to_frame_ids(uint32_t *ids, uint64_t n, uint64_t step, void *stream)
 {
 	hipLaunchKernelGGL(index_to_frame_kernel, dim3(sgrid(n)), dim3(256), 0, (hipStream_t)stream, ids, n, step);

@@ -535,6 +535,12 @@ int be_scan_tile_ranges(uint32_t *ranges, const uint32_t *ids, TileRangeGeom g0,
 	}
 	return 0;
 }
+int be_scan_tile_eids(void *eids, const uint32_t *ids, TileEidGeom g, void *)
+{
+	for (long long it = 0; it < (long long)g.ntiles * g.N * g.K; it++) tile_eid_item(g, ids, eids, it);
+	return 0;
+}
+int be_download(void *dst, const void *src, size_t bytes, void *) { memcpy(dst, src, bytes); return 0; }
 int be_scan_index_to_frame_ids(uint32_t *ids, uint64_t n, uint64_t step, void *)
 {
 	for (uint64_t p = 0; p < n; p++) ids[p] = p ? (uint32_t)(ids[p] / step) : SCAN_NONE;

@@ -174,3 +174,41 @@ def test_masked_accumulate_skips_empty_tiles(force_split, dtype, monkeypatch):
             # the plain plan runs its column pass first when it skips (the passes commute): equal to rounding
             assert np.abs(sa - sb).max() < (2e-6 if dtype == "f32" else 1e-14)
     assert np.abs(a[-1] - x).max() < (2e-5 if dtype == "f32" else 1e-12)
+
+
+@pytest.mark.parametrize("force_split", [False, True])
+@pytest.mark.parametrize("nframes", [7, 300])
+def test_masked_accumulate_prepared_id_table(force_split, nframes, monkeypatch):
+    """dspfft_plan_scan_prepare also lays the owner ids out in the column tiles' reading order (one byte per id below 255 frames, two
+    above: dct_spec.h masked_two_step); a frame step with the table is bit for bit the step that reads the id array itself, and a frame
+    id beyond the table's width falls back to the array"""
+    h, w, c = 512, 512, 3
+    if force_split:
+        monkeypatch.setenv("DSPFFT_FORCE_SPLIT", "1")
+    else:
+        monkeypatch.setenv("DSPFFT_ZSKIP", "1")
+    L = emul()
+    x = ol.synth_f32(777, h * w * c).reshape(h, w, c)
+    coeffs = x.copy()
+    Plan.image(h, w, c, REDFT10, lib=L).set_scale(1.0 / (4 * w * h)).execute(coeffs.ctypes.data)
+    ids = np.zeros(h * w, dtype=np.uint32)
+    assert L.dspfft_scan_zigzag_frame_ids(ids.ctypes.data, w, h, (h * w + nframes - 1) // nframes, None) == 0
+    assert int(ids[ids != 0xFFFFFFFF].max()) == nframes - 1
+    frames = [0, nframes // 2, nframes - 1, nframes + 5]          # the last one is nobody's: adds zeros
+
+    def run(prepare, eids):
+        monkeypatch.setenv("DSPFFT_SCAN_EIDS", "1" if eids else "0")
+        inv = Plan.image(h, w, c, REDFT01, lib=emul())
+        if prepare:
+            inv.scan_prepare(ids.ctypes.data, c)
+        acc = np.zeros((h, w, c), dtype=np.float32)
+        work = np.empty((h, w, c), dtype=np.float32)
+        out = []
+        for f in frames:
+            inv.execute_masked_accumulate(coeffs.ctypes.data, work.ctypes.data, acc.ctypes.data, ids.ctypes.data, f, c)
+            out.append(acc.copy())
+        return out
+    with_table, without, unprepared = run(True, True), run(True, False), run(False, False)
+    for a, b, u in zip(with_table, without, unprepared):
+        assert np.array_equal(a, b) and np.array_equal(a, u)
+    assert np.array_equal(with_table[-1], with_table[-2])      # the frame nobody owns changed nothing
