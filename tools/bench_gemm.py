@@ -3,6 +3,9 @@ sys.path.insert(0, os.getcwd())
 import torch
 from dspfun_amd import _lib
 from dspfun_amd.zoom import Zoom
+if os.environ.get("BENCH_LIB"):          # same-box A/B against another build of the library (tools/ab_oldlib.sh)
+    import ctypes
+    _lib._lib = _lib.bind(ctypes.CDLL(os.environ["BENCH_LIB"]))
 L = _lib.load()
 def t(fn, reps=40):
     for _ in range(20): fn()
