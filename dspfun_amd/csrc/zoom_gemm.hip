@@ -369,7 +369,7 @@ static bool small_product(const dim3 &grid128)
 // operands by LDS-DMA in K-tiles of 32 (round 4) where every 16-byte piece is aligned; DSPFFT_GEMM_DMA=0: the register-staged kernel (A/B runs).
 // Returns 1 when the product does not qualify (the caller launches the register-staged kernel), else 0 / an error.
 static int launch_dma(const float *A, const float *B, float *C, int M, int N, int K, long long lda, long long ldb, long long ldc, int cs,
-                      int batch, long long sa, long long sb, long long sc, float alpha, int nb1, long long sa2, long long sb2, long long sc2, const dim3 &grid, void *stream)
+                      int batch, long long sa, long long sb, long long sc, float alpha, int nb1, long long sa2, long long sb2, long long sc2, const dim3 &grid, void *stream, bool small = false)
 {
 	static const int dma = getenv("DSPFFT_GEMM_DMA") ? atoi(getenv("DSPFFT_GEMM_DMA")) : 1;
 	if (!(dma && K >= 32 && ((lda | ldb | sa | sb | sa2 | sb2) & 3) == 0 && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0 && lda > 0 && ldb > 0 && lda < (1 << 22) && ldb < (1 << 22))) return 1;      // (32-bit lane offsets within a tile)
@@ -386,16 +386,17 @@ static int launch_dma(const float *A, const float *B, float *C, int M, int N, in
 		const long long tiles = (long long)((M + tm - 1) / tm) * ((N + tn - 1) / tn) * batch;
 		return ((tiles + slots - 1) / slots) * tm * tn;
 	};
-	const bool wide = force >= 0 ? force == 1 : rounds_area(128, 192) < rounds_area(128, 128);
-	const int TN = wide ? 192 : 128;
-	const int ntn = (N + TN - 1) / TN, ntiles = ntn * (int)grid.y;
-	const size_t lds = 2 * (size_t)(128 + TN) * 32 * sizeof(float);
+	// shape 0 / 1 / 2: 128 x 128, 128 x 192, 64 x 64 (products that cannot give every CU a 128 x 128 tile: `small`)
+	const int shape = small ? 2 : (force >= 0 ? force == 1 : rounds_area(128, 192) < rounds_area(128, 128)) ? 1 : 0;
+	const int TM = shape == 2 ? 64 : 128, TN = shape == 2 ? 64 : shape == 1 ? 192 : 128;
+	const int ntn = (N + TN - 1) / TN, ntiles = ntn * ((M + TM - 1) / TM);
+	const size_t lds = 2 * (size_t)(TM + TN) * 32 * sizeof(float);
 	typedef void (*kern_t)(const float *, const float *, float *, int, int, int, long long, long long, long long, int, long long, long long, long long, float, const float *, int, int, long long, long long, long long);
-	const kern_t kern = wide ? static_cast<kern_t>(gemm_nt_f32_mfma_dma<2, 3>) : static_cast<kern_t>(gemm_nt_f32_mfma_dma<2, 2>);
-	static thread_local bool attr[2] = {false, false};
-	if (!attr[wide]) {
+	const kern_t kern = shape == 2 ? static_cast<kern_t>(gemm_nt_f32_mfma_dma<1, 1>) : shape == 1 ? static_cast<kern_t>(gemm_nt_f32_mfma_dma<2, 3>) : static_cast<kern_t>(gemm_nt_f32_mfma_dma<2, 2>);
+	static thread_local bool attr[3] = {false, false, false};
+	if (!attr[shape]) {
 		if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { snprintf(g_zerr, sizeof g_zerr, "cannot raise the LDS limit"); return -4; }
-		attr[wide] = true;
+		attr[shape] = true;
 	}
 	hipLaunchKernelGGL(kern, dim3(ntiles, 1, batch), dim3(256), lds, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, cs, sa, sb, sc, alpha, zero_page[dev], ntn, nb1, sa2, sb2, sc2);
 	return hipGetLastError() == hipSuccess ? 0 : -4;
@@ -407,7 +408,9 @@ extern "C" int dspfft_gemm_nt_f32(const float *A, const float *B, float *C, int 
 {
 	if (!A || !B || !C || M < 1 || N < 1 || K < 1 || batch < 1 || cs < 1) { snprintf(g_zerr, sizeof g_zerr, "bad arguments"); return -1; }
 	dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
+	static const int small_dma = getenv("DSPFFT_GEMM_SMALL_DMA") ? atoi(getenv("DSPFFT_GEMM_SMALL_DMA")) : 1;
 	if (small_product(grid)) {
+		if (small_dma) if (int rc = launch_dma(A, B, C, M, N, K, lda, ldb, ldc, cs, batch, sa, sb, sc, alpha, 0, 0, 0, 0, grid, stream, true); rc != 1) return rc;
 		dim3 g64((N + 63) / 64, (M + 63) / 64, batch);
 		if (K >= 16) hipLaunchKernelGGL((gemm_nt_f32_mfma<16, 1>), g64, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, cs, sa, sb, sc, alpha, 0, 0ll, 0ll, 0ll);
 		else hipLaunchKernelGGL((gemm_nt_f32_mfma<8, 1>), g64, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, cs, sa, sb, sc, alpha, 0, 0ll, 0ll, 0ll);
@@ -426,7 +429,9 @@ static int gemm_nt_f32_batch2(const float *A, const float *B, float *C, int M, i
                               int nb1, long long sa1, long long sb1, long long sc1, int nb2, long long sa2, long long sb2, long long sc2, void *stream)
 {
 	dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, nb1 * nb2);
+	static const int small_dma = getenv("DSPFFT_GEMM_SMALL_DMA") ? atoi(getenv("DSPFFT_GEMM_SMALL_DMA")) : 1;
 	if (small_product(grid)) {
+		if (small_dma) if (int rc = launch_dma(A, B, C, M, N, K, lda, ldb, ldc, 1, nb1 * nb2, sa1, sb1, sc1, 1.f, nb1, sa2, sb2, sc2, grid, stream, true); rc != 1) return rc;
 		dim3 g64((N + 63) / 64, (M + 63) / 64, nb1 * nb2);
 		if (K >= 16) hipLaunchKernelGGL((gemm_nt_f32_mfma<16, 1>), g64, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, 1, sa1, sb1, sc1, 1.f, nb1, sa2, sb2, sc2);
 		else hipLaunchKernelGGL((gemm_nt_f32_mfma<8, 1>), g64, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, 1, sa1, sb1, sc1, 1.f, nb1, sa2, sb2, sc2);

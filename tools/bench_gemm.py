@@ -54,7 +54,7 @@ print("gemm 4096^3 ms", ms, "TF", 2 * 4096 ** 3 / ms / 1e9)
 
 # applybasis: the full dct2 spectrum of an n x n image (two batched products of n^3 per channel)
 from dspfun_amd.applybasis import partsums
-for n in (1024, 2048):
+for n in (512, 1024, 2048):
     img = torch.rand(n, n, 3, device="cuda:0") * 2 - 1
     ms = t(lambda: partsums(torch, img, "dct2", True, None, (n, n)), reps=10)
     print("applybasis dct2 spectrum of %d^2 ms" % n, ms, "TF", 3 * 2 * 2 * n ** 3 / ms / 1e9)
