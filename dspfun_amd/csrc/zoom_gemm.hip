@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(256) gemm_nt_f32_mfma(const float *__restrict_
 template <int WI, int WJ>
 __global__ void __launch_bounds__(256, 2) gemm_nt_f32_mfma_dma(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
                                                                 int M, int N, int K, long long lda, long long ldb, long long ldc, int cs,
-                                                                long long sa, long long sb, long long sc, float alpha, const float *zero_page, int ntn,
+                                                                long long sa, long long sb, long long sc, float alpha, const float *zero_page, int ntn, int ntiles,
                                                                 int nb1 = 0, long long sa2 = 0, long long sb2 = 0, long long sc2 = 0)
 {
 	constexpr int BKD = 32, G = BKD / 8, BLK = 32 * BKD;             // floats of a 32-row block of an operand tile
@@ -151,116 +151,139 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_f32_mfma_dma(const float *__re
 	extern __shared__ __attribute__((aligned(16))) float smem[];     // [2 buffers][A blocks | B blocks]
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int wm = wave >> 1, wn = wave & 1;
-	const int tile = blockIdx.x, batch = (int)blockIdx.z;
-	const int tm = tile / ntn, tn = tile - tm * ntn;
-	const int bm = tm * TM, bn = tn * TN;
+	const int batch = (int)blockIdx.z;
 	{	// blockIdx.z = b1 + nb1 * b2: two batch levels (see gemm_nt_f32_mfma), nb1 = 0: one level
 		const int b2 = nb1 ? batch / nb1 : 0, b1 = batch - b2 * nb1;
 		A += (long long)b1 * sa + (long long)b2 * sa2; B += (long long)b1 * sb + (long long)b2 * sb2; C += (long long)b1 * sc + (long long)b2 * sc2;
 	}
+	const int li = lane & 31, lk = lane >> 5;
+	const int swave = __builtin_amdgcn_readfirstlane(wave);
+	constexpr int NA = (ABLK + 3) / 4, NBB = (BBLK + 3) / 4;
+	float *const buf0 = smem, *const buf1 = smem + (ABLK + BBLK) * BLK;
+	const int nk = (K + BKD - 1) / BKD;
 
 	// DMA: wave w stages the 32-row blocks w, w + 4, .. of A and of B: G instructions per block and K-tile.  An instruction's address is a
 	// wave-uniform 64-bit base (the tile's first row, advanced by k0: scalar registers) plus a 32-bit lane offset that never changes (row and
 	// k-half of the lane) plus an immediate (the k-group); its LDS destination is scalar too (the wave index is read into an SGPR) -- no vector
 	// arithmetic per instruction.  (Computing full 64-bit lane pointers, with a select against the zero page, cost 55 vector instructions
-	// per wave and K-tile next to its 64 MFMAs.)  Only the last K-tile of a K that is no multiple of 32 takes the selects (stage_tail).
-	const int li = lane & 31, lk = lane >> 5;
-	const int swave = __builtin_amdgcn_readfirstlane(wave);
-	constexpr int NA = (ABLK + 3) / 4, NBB = (BBLK + 3) / 4;
-	unsigned aoff[NA], boff[NBB];
+	// per wave and K-tile next to its 64 MFMAs.)  Only the last K-tile of a K that is no multiple of 32 takes the selects.
+	struct Aim { unsigned aoff[NA], boff[NBB]; const char *abase, *bbase; int bm, bn; };
+	auto aim = [&](int tile) __attribute__((always_inline)) {
+		Aim t;
+		const int tm = tile / ntn, tn = tile - tm * ntn;
+		t.bm = tm * TM; t.bn = tn * TN;
 #pragma unroll
-	for (int q = 0; q < NA; q++) { const int r = bm + 32 * (swave + 4 * q) + li; aoff[q] = (unsigned)(((long long)((r < M ? r : M - 1) - bm) * lda + 4 * lk) * 4); }
+		for (int q = 0; q < NA; q++) { const int r = t.bm + 32 * (swave + 4 * q) + li; t.aoff[q] = (unsigned)(((long long)((r < M ? r : M - 1) - t.bm) * lda + 4 * lk) * 4); }
 #pragma unroll
-	for (int q = 0; q < NBB; q++) { const int r = bn + 32 * (swave + 4 * q) + li; boff[q] = (unsigned)(((long long)((r < N ? r : N - 1) - bn) * ldb + 4 * lk) * 4); }
-	const char *const abase = reinterpret_cast<const char *>(A + (long long)bm * lda), *const bbase = reinterpret_cast<const char *>(B + (long long)bn * ldb);
-	auto stage = [&](float *base, int k0) __attribute__((always_inline)) {
-		const char *ak = abase + (long long)k0 * 4, *bk = bbase + (long long)k0 * 4;
-#pragma unroll
-		for (int g = 0; g < G; g++) {
-#pragma unroll
-			for (int q = 0; q < NA; q++)
-				if (ABLK % 4 == 0 || swave + 4 * q < ABLK)
-					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ak + aoff[q] + 32 * g), (__attribute__((address_space(3))) void *)(base + (swave + 4 * q) * BLK + g * 256), 16, 0, 0);
-#pragma unroll
-			for (int q = 0; q < NBB; q++)
-				if (BBLK % 4 == 0 || swave + 4 * q < BBLK)
-					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bk + boff[q] + 32 * g), (__attribute__((address_space(3))) void *)(base + (ABLK + swave + 4 * q) * BLK + g * 256), 16, 0, 0);
-		}
+		for (int q = 0; q < NBB; q++) { const int r = t.bn + 32 * (swave + 4 * q) + li; t.boff[q] = (unsigned)(((long long)((r < N ? r : N - 1) - t.bn) * ldb + 4 * lk) * 4); }
+		t.abase = reinterpret_cast<const char *>(A + (long long)t.bm * lda); t.bbase = reinterpret_cast<const char *>(B + (long long)t.bn * ldb);
+		return t;
 	};
-	auto stage_tail = [&](float *base, int k0) __attribute__((always_inline)) {      // k beyond K reads the page of zeros
-		const char *ak = abase + (long long)k0 * 4, *bk = bbase + (long long)k0 * 4;
+	auto stage_any = [&](const Aim &t, float *base, int k0) __attribute__((always_inline)) {
+		const char *ak = t.abase + (long long)k0 * 4, *bk = t.bbase + (long long)k0 * 4;
+		if (k0 + BKD <= K) {
 #pragma unroll
-		for (int g = 0; g < G; g++) {
-			const bool in = k0 + 8 * g + 4 * lk < K;
+			for (int g = 0; g < G; g++) {
 #pragma unroll
-			for (int q = 0; q < NA; q++)
-				if (ABLK % 4 == 0 || swave + 4 * q < ABLK) {
-					const char *pa = in ? ak + aoff[q] + 32 * g : reinterpret_cast<const char *>(zero_page);
-					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)pa, (__attribute__((address_space(3))) void *)(base + (swave + 4 * q) * BLK + g * 256), 16, 0, 0);
-				}
+				for (int q = 0; q < NA; q++)
+					if (ABLK % 4 == 0 || swave + 4 * q < ABLK)
+						__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ak + t.aoff[q] + 32 * g), (__attribute__((address_space(3))) void *)(base + (swave + 4 * q) * BLK + g * 256), 16, 0, 0);
 #pragma unroll
-			for (int q = 0; q < NBB; q++)
-				if (BBLK % 4 == 0 || swave + 4 * q < BBLK) {
-					const char *pb = in ? bk + boff[q] + 32 * g : reinterpret_cast<const char *>(zero_page);
-					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)pb, (__attribute__((address_space(3))) void *)(base + (ABLK + swave + 4 * q) * BLK + g * 256), 16, 0, 0);
-				}
-		}
-	};
-	auto stage_any = [&](float *base, int k0) __attribute__((always_inline)) { if (k0 + BKD <= K) stage(base, k0); else stage_tail(base, k0); };
-
-	f32x16 acc[WI][WJ];
-	for (int i = 0; i < WI; i++) for (int j = 0; j < WJ; j++) for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-	const int nk = (K + BKD - 1) / BKD;
-	// one K-tile: the DMA of the next tile into `nxt`, the MFMAs of this one out of `cur`.  The two are `__restrict__` parameters of an inlined
-	// function so that the compiler knows the DMA's LDS writes and the ds_reads never meet: without that it puts s_waitcnt vmcnt(0) between
-	// the DMA and the first ds_read -- the "prefetch" then lands before the tile's first MFMA instead of behind its last.
-	auto ktile = [&](const float *__restrict__ cur, float *__restrict__ nxt, int k0, bool more) __attribute__((always_inline)) {
-		if (more) stage_any(nxt, k0 + BKD);
-		float4 a[2][WI], b[2][WJ];
-		auto frags = [&](int g, int set) __attribute__((always_inline)) {
+				for (int q = 0; q < NBB; q++)
+					if (BBLK % 4 == 0 || swave + 4 * q < BBLK)
+						__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bk + t.boff[q] + 32 * g), (__attribute__((address_space(3))) void *)(base + (ABLK + swave + 4 * q) * BLK + g * 256), 16, 0, 0);
+			}
+		} else {                                      // k beyond K reads the page of zeros
 #pragma unroll
-			for (int i = 0; i < WI; i++) a[set][i] = *reinterpret_cast<const float4 *>(cur + (WI * wm + i) * BLK + g * 256 + lane * 4);
+			for (int g = 0; g < G; g++) {
+				const bool in = k0 + 8 * g + 4 * lk < K;
 #pragma unroll
-			for (int j = 0; j < WJ; j++) b[set][j] = *reinterpret_cast<const float4 *>(cur + (ABLK + WJ * wn + j) * BLK + g * 256 + lane * 4);
-		};
-		// the fragments of k-group g + 1 are read while the MFMAs of group g run (two register sets).  (s_setprio around the MFMAs: -10 %.)
-		frags(0, 0);
-#pragma unroll
-		for (int g = 0; g < G; g++) {
-			const int set = g & 1;
-			if (g + 1 < G) frags(g + 1, set ^ 1);
-#pragma unroll
-			for (int s = 0; s < 4; s++)
-#pragma unroll
-				for (int i = 0; i < WI; i++)
-#pragma unroll
-					for (int j = 0; j < WJ; j++) {
-						const float av = s == 0 ? a[set][i].x : s == 1 ? a[set][i].y : s == 2 ? a[set][i].z : a[set][i].w;
-						const float bv = s == 0 ? b[set][j].x : s == 1 ? b[set][j].y : s == 2 ? b[set][j].z : b[set][j].w;
-						acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+				for (int q = 0; q < NA; q++)
+					if (ABLK % 4 == 0 || swave + 4 * q < ABLK) {
+						const char *pa = in ? ak + t.aoff[q] + 32 * g : reinterpret_cast<const char *>(zero_page);
+						__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)pa, (__attribute__((address_space(3))) void *)(base + (swave + 4 * q) * BLK + g * 256), 16, 0, 0);
 					}
-		}
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile has landed (issued a K-tile of MFMAs ago)
-		__syncthreads();
-	};
-	float *const buf0 = smem, *const buf1 = smem + (ABLK + BBLK) * BLK;
-	stage_any(buf0, 0);
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	__syncthreads();
-	for (int kt = 0; kt < nk; kt += 2) {
-		ktile(buf0, buf1, kt * BKD, kt + 1 < nk);
-		if (kt + 1 < nk) ktile(buf1, buf0, (kt + 1) * BKD, kt + 2 < nk);
-	}
-	// C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-	for (int i = 0; i < WI; i++)
-		for (int j = 0; j < WJ; j++) {
-			const int n = bn + wn * (32 * WJ) + j * 32 + li;
-			if (n >= N) continue;
-			for (int r = 0; r < 16; r++) {
-				const int m = bm + wm * (32 * WI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-				if (m < M) C[(long long)m * ldc + (long long)n * cs] = alpha * acc[i][j][r];
+#pragma unroll
+				for (int q = 0; q < NBB; q++)
+					if (BBLK % 4 == 0 || swave + 4 * q < BBLK) {
+						const char *pb = in ? bk + t.boff[q] + 32 * g : reinterpret_cast<const char *>(zero_page);
+						__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)pb, (__attribute__((address_space(3))) void *)(base + (ABLK + swave + 4 * q) * BLK + g * 256), 16, 0, 0);
+					}
 			}
 		}
+	};
+
+	// A workgroup takes tiles blockIdx.x, + gridDim.x, .. -- normally just the one (launch_dma).  With more, a tile's LAST K-tile sends out the
+	// first operands of the workgroup's next tile, which then starts on data that is there while its predecessor's stores drain under its
+	// MFMAs.  Everything a tile's K-loop uses is a constant of that loop iteration (`cur`); the next tile's addresses are worked out inside
+	// the one K-tile that needs them (a first version kept them in variables the K-loop also read: 44 more registers and -5 %).
+	int tile = blockIdx.x;
+	{
+		const Aim first = aim(tile);
+		stage_any(first, buf0, 0);
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	bool flip = false;
+	for (;;) {
+		const Aim cur = aim(tile);
+		const int next = tile + (int)gridDim.x, then = next < ntiles ? next : -1;
+		f32x16 acc[WI][WJ];
+		for (int i = 0; i < WI; i++) for (int j = 0; j < WJ; j++) for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+		// one K-tile: the DMA of the next one into `nxt`, the MFMAs of this one out of `now`.  The two are `__restrict__` parameters of an inlined
+		// function so that the compiler knows the DMA's LDS writes and the ds_reads never meet: without that it puts s_waitcnt vmcnt(0)
+		// between the DMA and the first ds_read -- the "prefetch" then lands before the tile's first MFMA instead of behind its last.
+		auto ktile = [&](const float *__restrict__ now, float *__restrict__ nxt, int k0, bool more) __attribute__((always_inline)) {
+			if (more) stage_any(cur, nxt, k0 + BKD);
+			else if (then >= 0) { const Aim t = aim(then); stage_any(t, nxt, 0); }
+			float4 a[2][WI], b[2][WJ];
+			auto frags = [&](int g, int set) __attribute__((always_inline)) {
+#pragma unroll
+				for (int i = 0; i < WI; i++) a[set][i] = *reinterpret_cast<const float4 *>(now + (WI * wm + i) * BLK + g * 256 + lane * 4);
+#pragma unroll
+				for (int j = 0; j < WJ; j++) b[set][j] = *reinterpret_cast<const float4 *>(now + (ABLK + WJ * wn + j) * BLK + g * 256 + lane * 4);
+			};
+			// the fragments of k-group g + 1 are read while the MFMAs of group g run (two register sets).  (s_setprio around the MFMAs: -10 %.)
+			frags(0, 0);
+#pragma unroll
+			for (int g = 0; g < G; g++) {
+				const int set = g & 1;
+				if (g + 1 < G) frags(g + 1, set ^ 1);
+#pragma unroll
+				for (int s = 0; s < 4; s++)
+#pragma unroll
+					for (int i = 0; i < WI; i++)
+#pragma unroll
+						for (int j = 0; j < WJ; j++) {
+							const float av = s == 0 ? a[set][i].x : s == 1 ? a[set][i].y : s == 2 ? a[set][i].z : a[set][i].w;
+							const float bv = s == 0 ? b[set][j].x : s == 1 ? b[set][j].y : s == 2 ? b[set][j].z : b[set][j].w;
+							acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+						}
+			}
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next K-tile has landed (issued a K-tile of MFMAs ago)
+			__syncthreads();
+		};
+		auto whole_tile = [&](float *__restrict__ b0, float *__restrict__ b1) __attribute__((always_inline)) {
+			for (int kt = 0; kt < nk; kt += 2) {
+				ktile(b0, b1, kt * BKD, kt + 1 < nk);
+				if (kt + 1 < nk) ktile(b1, b0, (kt + 1) * BKD, kt + 2 < nk);
+			}
+		};
+		if (flip) whole_tile(buf1, buf0); else whole_tile(buf0, buf1);
+		// C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+		for (int i = 0; i < WI; i++)
+			for (int j = 0; j < WJ; j++) {
+				const int n = cur.bn + wn * (32 * WJ) + j * 32 + li;
+				if (n >= N) continue;
+				for (int r = 0; r < 16; r++) {
+					const int m = cur.bm + wm * (32 * WI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+					if (m < M) C[(long long)m * ldc + (long long)n * cs] = alpha * acc[i][j][r];
+				}
+			}
+		if (then < 0) break;
+		tile = next;
+		if (nk & 1) flip = !flip;         // an odd number of K-tiles leaves the next tile's first one in the other buffer
+	}
 }
 
 // zoom/zoom.c:36-68 with column 0 = 1/2 (the halved DC term) and columns 1.. = the reference's basis
@@ -391,14 +414,20 @@ static int launch_dma(const float *A, const float *B, float *C, int M, int N, in
 	const int TM = shape == 2 ? 64 : 128, TN = shape == 2 ? 64 : shape == 1 ? 192 : 128;
 	const int ntn = (N + TN - 1) / TN, ntiles = ntn * ((M + TM - 1) / TM);
 	const size_t lds = 2 * (size_t)(TM + TN) * 32 * sizeof(float);
-	typedef void (*kern_t)(const float *, const float *, float *, int, int, int, long long, long long, long long, int, long long, long long, long long, float, const float *, int, int, long long, long long, long long);
+	typedef void (*kern_t)(const float *, const float *, float *, int, int, int, long long, long long, long long, int, long long, long long, long long, float, const float *, int, int, int, long long, long long, long long);
 	const kern_t kern = shape == 2 ? static_cast<kern_t>(gemm_nt_f32_mfma_dma<1, 1>) : shape == 1 ? static_cast<kern_t>(gemm_nt_f32_mfma_dma<2, 3>) : static_cast<kern_t>(gemm_nt_f32_mfma_dma<2, 2>);
 	static thread_local bool attr[3] = {false, false, false};
 	if (!attr[shape]) {
 		if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { snprintf(g_zerr, sizeof g_zerr, "cannot raise the LDS limit"); return -4; }
 		attr[shape] = true;
 	}
-	hipLaunchKernelGGL(kern, dim3(ntiles, 1, batch), dim3(256), lds, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, cs, sa, sb, sc, alpha, zero_page[dev], ntn, nb1, sa2, sb2, sc2);
+	// One workgroup per tile.  DSPFFT_GEMM_WALK=1: one product of more tiles than the chip holds workgroups gets that many workgroups, each walking its
+	// tiles with the next tile's first operands in flight -- measured a little SLOWER than letting the dispatcher hand out tiles (8192 x 8192 x 4096:
+	// 131.7 against 134.0 TF, config 3's second product 1.771 against 1.765 ms, same box: profiles/r04_gemm.txt), so it is off.
+	static const int walk = getenv("DSPFFT_GEMM_WALK") ? atoi(getenv("DSPFFT_GEMM_WALK")) : 0;
+	const long long wslots = shape == 2 ? 4 * slots / 2 : slots;
+	const int gx = walk && batch == 1 && (long long)ntiles > wslots ? (int)wslots : ntiles;
+	hipLaunchKernelGGL(kern, dim3(gx, 1, batch), dim3(256), lds, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, cs, sa, sb, sc, alpha, zero_page[dev], ntn, ntiles, nb1, sa2, sb2, sc2);
 	return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
