@@ -427,3 +427,79 @@ def test_scan_device_resident_harness_every_method(tmp_path, method):
         assert np.abs(got - _read_pf(ref_out)).max() <= 5e-6
     else:
         assert np.abs(got - img.astype(np.float64) / 255.0).max() <= 5e-6
+
+
+def _zoom_oracle(x, btype, xs, ys, vx, vy, vw, vh):
+    """zoom.c:347-375 restated in f64 (oracle/): basis x coefficients x basis of the image's REDFT10^2"""
+    import ctypes as C
+    h, w, _ = x.shape
+    L = ol.lib()
+    cf = np.ascontiguousarray(ol.dct2d_interleaved(x.astype(np.float64), ol.REDFT10))
+    cw = L.oracle_zoom_basis_f64(None, btype, xs[0], xs[1], vx, vw, w)
+    ch = L.oracle_zoom_basis_f64(None, btype, ys[0], ys[1], vy, vh, h)
+    xb = np.zeros(max(1, vw * (cw - 1))); yb = np.zeros(max(1, vh * (ch - 1)))
+    L.oracle_zoom_basis_f64(xb.ctypes.data, btype, xs[0], xs[1], vx, vw, w)
+    L.oracle_zoom_basis_f64(yb.ctypes.data, btype, ys[0], ys[1], vy, vh, h)
+    ref = np.zeros((vh, vw, 3))
+    L.oracle_zoom_product_f64(cf.ctypes.data, w, h, xb.ctypes.data, cw, yb.ctypes.data, ch, ref.ctypes.data, vw, vh)
+    return ref
+
+
+def _read_pfs(path):
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"PFS"
+        vw, vh, n = [int(v) for v in f.readline().split()]
+        f.readline()
+        data = np.frombuffer(f.read(), dtype=np.float32)
+    return data.reshape(-1, vh, vw, 3), n
+
+
+@pytest.mark.parametrize("args,btype,xs,ys,pos,view,how", [
+    (["-s", "2"], 0, (2.0, 1.0), (2.0, 1.0), (0.0, 0.0), None, "fft"),                                # integer scale on the DCT-III grid
+    (["-s", "3/2x5/4", "-p", "3.5x1.25", "-v", "50x30"], 0, (3.0, 2.0), (5.0, 4.0), (3.5, 1.25), (50, 30), "fft"),   # rational scales with integer scaled lengths (72 x 45), a view, an offset
+    (["-s", "7/5x5/4", "-p", "3.5x1.25", "-v", "50x30"], 0, (7.0, 5.0), (5.0, 4.0), (3.5, 1.25), (50, 30), "czt"),   # 48 x 7/5 = 67.2 samples: off the DCT-III grid
+    (["-s", "1.7", "--basis", "centered"], 1, (1.7, 1.0), (1.7, 1.0), (0.0, 0.0), None, "czt"),
+    (["-s", "2", "--basis", "native", "-c", "-v", "40x20"], 2, (2.0, 1.0), (2.0, 1.0), None, (40, 20), None),
+    (["-s", "1.5", "--method", "gemm"], 0, (1.5, 1.0), (1.5, 1.0), (0.0, 0.0), None, "gemm"),          # the dense product, forced
+])
+def test_zoom_harness(tmp_path, args, btype, xs, ys, pos, view, how):
+    """zoom/zoom.c:263-375 through the C harness (host/zoom_gpu.c): fftw(plan_many_r2r) REDFT10^2 on the host buffer as the tool calls it, the
+    option handling of zoom.c:268-298, then a frame by whichever of the three device paths applies -- against the f64 restatement"""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    w, h = 48, 36
+    x = ol.synth_f32(4321, w * h * 3).reshape(h, w, 3)
+    src = tmp_path / "in.pf"
+    with open(src, "wb") as f:
+        f.write(b"PF\n%d %d\n-1.0\n" % (w, h)); f.write(x.astype(np.float32).tobytes())
+    out = tmp_path / "out.raw"
+    r = subprocess.run([os.path.join(ROOT, "host", "zoom_gpu")] + args + [str(src), str(out)], stderr=subprocess.PIPE, check=True)
+    frames, n = _read_pfs(out)
+    assert n == 1 and frames.shape[0] == 1
+    vw, vh = view if view else (int(w * xs[0] / xs[1]), int(h * ys[0] / ys[1]))           # zoom.c:286-289
+    if pos is None:                                                                        # -c (zoom.c:296-298)
+        pos = ((w * xs[0] / xs[1] - vw) / 2, (h * ys[0] / ys[1] - vh) / 2)
+    assert frames.shape[1:] == (vh, vw, 3)
+    if how:
+        assert (" by " + how).encode() in r.stderr, r.stderr
+    ref = _zoom_oracle(x, btype, xs, ys, pos[0], pos[1], vw, vh)
+    assert np.abs(frames[0] - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_zoom_harness_animation(tmp_path):
+    """-n frames with -S / -x expressions (zoom.c:320-345): every frame against the restatement at that frame's scale and position; the
+    expression language is host/expr_eval.c's restatement of libavutil's (variables i n x y xs ys w h vw vh)"""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    w, h = 40, 30
+    x = ol.synth_f32(99, w * h * 3).reshape(h, w, 3)
+    src = tmp_path / "in.pf"
+    with open(src, "wb") as f:
+        f.write(b"PF\n%d %d\n-1.0\n" % (w, h)); f.write(x.astype(np.float32).tobytes())
+    out = tmp_path / "anim.raw"
+    subprocess.check_call([os.path.join(ROOT, "host", "zoom_gpu"), "-v", "64x48", "-n", "4", "-S", "1+i/2", "-x", "2*i", "-y", "vh/16*i", str(src), str(out)],
+                          stderr=subprocess.DEVNULL)
+    frames, n = _read_pfs(out)
+    assert n == 4 and frames.shape == (4, 48, 64, 3)
+    for i in range(4):
+        s = 1 + i / 2
+        ref = _zoom_oracle(x, 0, (s, 1.0), (s, 1.0), 2.0 * i, 48 / 16 * i, 64, 48)
+        assert np.abs(frames[i] - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), i
