@@ -395,7 +395,8 @@ static int launch_dma(const float *A, const float *B, float *C, int M, int N, in
                       int batch, long long sa, long long sb, long long sc, float alpha, int nb1, long long sa2, long long sb2, long long sc2, const dim3 &grid, void *stream, bool small = false)
 {
 	static const int dma = getenv("DSPFFT_GEMM_DMA") ? atoi(getenv("DSPFFT_GEMM_DMA")) : 1;
-	if (!(dma && K >= 32 && ((lda | ldb | sa | sb | sa2 | sb2) & 3) == 0 && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0 && lda > 0 && ldb > 0 && lda < (1 << 22) && ldb < (1 << 22))) return 1;      // (32-bit lane offsets within a tile)
+	// (the K tail is masked per 16-byte piece, so K itself must be a multiple of 4: a K = 130 view of 132-wide rows would sum columns 130, 131 too)
+	if (!(dma && K >= 32 && (K & 3) == 0 && ((lda | ldb | sa | sb | sa2 | sb2) & 3) == 0 && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0 && lda > 0 && ldb > 0 && lda < (1 << 22) && ldb < (1 << 22))) return 1;      // (32-bit lane offsets within a tile)
 	static thread_local float *zero_page[32] = {};
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
@@ -416,10 +417,10 @@ static int launch_dma(const float *A, const float *B, float *C, int M, int N, in
 	const size_t lds = 2 * (size_t)(TM + TN) * 32 * sizeof(float);
 	typedef void (*kern_t)(const float *, const float *, float *, int, int, int, long long, long long, long long, int, long long, long long, long long, float, const float *, int, int, int, long long, long long, long long);
 	const kern_t kern = shape == 2 ? static_cast<kern_t>(gemm_nt_f32_mfma_dma<1, 1>) : shape == 1 ? static_cast<kern_t>(gemm_nt_f32_mfma_dma<2, 3>) : static_cast<kern_t>(gemm_nt_f32_mfma_dma<2, 2>);
-	static thread_local bool attr[3] = {false, false, false};
-	if (!attr[shape]) {
+	static thread_local bool attr[32][3] = {};            // the attribute is per device (see DevOnce, spec_kernels.h)
+	if (!attr[dev][shape]) {
 		if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { snprintf(g_zerr, sizeof g_zerr, "cannot raise the LDS limit"); return -4; }
-		attr[shape] = true;
+		attr[dev][shape] = true;
 	}
 	// One workgroup per tile.  DSPFFT_GEMM_WALK=1: one product of more tiles than the chip holds workgroups gets that many workgroups, each walking its
 	// tiles with the next tile's first operands in flight -- measured a little SLOWER than letting the dispatcher hand out tiles (8192 x 8192 x 4096:

@@ -76,6 +76,14 @@ def test_unaligned_operands_take_the_fallback(gpu):
     run(gpu, 400, 300, 130, lda=131, ldb=133, seed=7)
 
 
+def test_k_tail_inside_aligned_padded_rows(gpu):
+    # K no multiple of 4 while the rows are 16-byte aligned and padded with NON-ZERO values (run() fills the whole lda / ldb): the LDS-DMA
+    # kernel masks its K tail per 16-byte piece, so such a product must not reach it (columns K .. of both operands would be summed too)
+    run(gpu, 400, 300, 130, lda=132, ldb=136, seed=8)
+    run(gpu, 200, 260, 35, lda=64, ldb=64, seed=9)
+    run(gpu, 2048, 2048, 257, lda=260, ldb=260, seed=10)
+
+
 def test_bad_arguments_are_refused(gpu):
     from dspfun_amd import _lib
     L = _lib.load()
