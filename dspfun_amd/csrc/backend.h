@@ -9,7 +9,6 @@
 #include "dct_spec.h"
 #include "dct_duo.h"
 #include "dct_czt.h"
-#include "dct_fold.h"
 #include "scan_core.h"
 #include "block_core.h"
 
@@ -136,13 +135,6 @@ int be_find_row_pair(int N, int C);
 int be_row_pair_threads(int id);      // the paired kernel may run on another workgroup size than the row spec of the same (N, C)
 int be_launch_col_half(int id, const PassArgs &a, int nwg, void *stream);
 int be_launch_row_pair(int id, const PassArgs &a, int npairs, void *stream);
-
-// folded row passes (dct_fold.h RowFoldT, spec_list.h DSPFFT_ROW_FOLD_SPECS): be_find_row_fold returns an id or -1 and what the plan needs to
-// know (threads, LDS, length of the table array fold_tables fills: PassArgs::H of such a pass).  be_launch_row_fold: nwork lines, or row
-// pairs with `pair` (pair_flags: one zeroed word per pair, required when such a pass runs in place); returns 1 when the arguments are outside what the folded kernels take (the caller then launches the plain kernel)
-struct FoldInfo { int nthr; size_t lds; int tablen; };
-int be_find_row_fold(int N, int C, FoldInfo *info);
-int be_launch_row_fold(int id, const PassArgs &a, int nwork, bool pair, unsigned *pair_flags, void *stream);
 
 // motion's filter over every active element of a buffer of `span` elements (the unfused form of the roundtrip's middle step)
 int be_motion_filter(float *buf, const MotionFilter &filt, uint64_t span, unsigned long long *coded, void *stream);

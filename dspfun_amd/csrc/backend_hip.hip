@@ -49,10 +49,6 @@ DSPFFT_ROW_SPECS(DSP_EXTERN_ROW)
 DSPFFT_COL_SPECS(DSP_EXTERN_COL)
 DSPFFT_COL_HALF_SPECS(DSP_EXTERN_HALF)
 DSPFFT_ROW_PAIR_SPECS(DSP_EXTERN_PAIR)
-#define DSP_EXTERN_FOLD(N, C, T, ...) \
-	extern template int launch_row_fold<RowFoldT<N, C, T, __VA_ARGS__>, 0>(const PassArgs &, int, bool, unsigned *, void *); \
-	extern template int launch_row_fold<RowFoldT<N, C, T, __VA_ARGS__>, 1>(const PassArgs &, int, bool, unsigned *, void *);
-DSPFFT_ROW_FOLD_SPECS(DSP_EXTERN_FOLD)
 
 // ---------------------------------------------------------------------------------------------
 // MAXT: the largest workgroup the instantiation is launched with (512 leaves the register allocator 256 VGPRs, which

@@ -139,8 +139,6 @@ struct Pass {
 	SpecInfo hspec;
 	PassGeom hpa;
 	int half_nwg = 0;
-	// folded row pass (dct_fold.h): a listed RowFoldT also covers this pass's lines; its tables are tab.H (a ROW pass has no other use for it)
-	int fold_id = -1;
 	// a kernel compiled at plan time for this pass's geometry (jit_kernels.h; DSPFFT_JIT=1) where spec_list.h has no entry: spa /
 	// spec_nwg describe it like a listed one's, jit_fn is this pass's kind
 	bool jit = false;
@@ -227,31 +225,6 @@ int upload_tables_t(Pass &P, int N, int L, const std::vector<uint32_t> &pos)
 	if (be_upload(P.tab.pos, pos.data(), pos.size() * sizeof(uint32_t))) return -1;
 	P.pa.pos = (const uint32_t *)P.tab.pos;
 	return 0;
-}
-// tables of a folded row pass (dct_fold.h RowFoldT: OFF_T, OFF_W, OFF_OM, OFF_RH), H = N/2, M = N/4, one array of complex floats:
-//   Th[k] = exp(-i pi k / (2H)), k <= H | Wq[t] = exp(-2 pi i t / M) | Om[n] = exp(-i pi (4n+1) / (4H)) | Rh[k] = exp(-i pi k / H)
-int upload_fold_tables(Pass &P, int N, int tablen)
-{
-	const long double pi = 3.14159265358979323846264338327950288L;
-	const int H = N / 2, M = N / 4;
-	std::vector<cf> t;
-	t.reserve((size_t)tablen);
-	for (int k = 0; k <= H; k++) t.push_back(cmk<float>((float)cosl(pi * k / (2.0L * H)), (float)-sinl(pi * k / (2.0L * H))));
-	for (int k = 0; k < M; k++) t.push_back(cmk<float>((float)cosl(2 * pi * k / M), (float)-sinl(2 * pi * k / M)));
-	for (int n = 0; n < M; n++) t.push_back(cmk<float>((float)cosl(pi * (4 * n + 1) / (4.0L * H)), (float)-sinl(pi * (4 * n + 1) / (4.0L * H))));
-	for (int k = 0; k < M; k++) t.push_back(cmk<float>((float)cosl(pi * k / (long double)H), (float)-sinl(pi * k / (long double)H)));
-	if ((int)t.size() != tablen) return -1;
-	P.tab.H = be_alloc(t.size() * sizeof(cf));
-	if (!P.tab.H || be_upload(P.tab.H, t.data(), t.size() * sizeof(cf))) return -1;
-	return 0;
-}
-// DSPFFT_FOLD: unset -- folded row passes where the plain line leaves one workgroup per CU; 1 -- wherever listed (tests); 0 -- never (A/B runs)
-bool fold_wanted(size_t plain_lds)
-{
-	const char *e = getenv("DSPFFT_FOLD");
-	if (e && *e == '0') return false;
-	if (e && *e == '1') return true;
-	return plain_lds > 80 * 1024;
 }
 int upload_tables(Pass &P, bool f64, int N, int L, const std::vector<uint32_t> &pos)
 {
@@ -591,14 +564,6 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 					if (P.spec.chan) snprintf(buf, sizeof buf, "axis %d: ROW*%s N=%d C=%d spec#%d as %d channel lines, threads=%d lines=%lld lds=%zu", a, tag, N, C, P.spec.id, P.spec.chan, P.spec.nthr, nlines, P.spec.lds);
 					else snprintf(buf, sizeof buf, "axis %d: ROW*%s N=%d C=%d spec#%d threads=%d lines=%lld lds=%zu", a, tag, N, C, P.spec.id, P.spec.nthr, nlines, P.spec.lds);
 					P.desc = buf;
-					FoldInfo fi;
-					const int fid = pl->f64 ? -1 : be_find_row_fold(N, C, &fi);
-					if (fid >= 0 && fold_wanted(P.spec.lds)) {
-						if (upload_fold_tables(P, N, fi.tablen)) return fail(-3, "table upload failed");
-						P.fold_id = fid;
-						snprintf(buf, sizeof buf, " fold#%d threads=%d lds=%zu", fid, fi.nthr, fi.lds);
-						P.desc += buf;
-					}
 				} else if (aligned && jit_enabled() && lines.size() <= 2) {
 					jit_row(pl, P, N, C, nlines, F, kind);
 				}
@@ -793,10 +758,7 @@ int run_pass(const dspfft_plan_s *pl, const Pass &P, const R *in, R *out, bool l
 				if (P.pair || P.half) {          // only reached through pick_passes(), which has checked alignment and scales
 					PassArgs a;
 					fill_args(a, P.pair ? P.spa : P.hpa, pl, P, in + oin, out + oout, scale, fz);
-					if (P.pair) {
-						rc = P.fold_id >= 0 ? be_launch_row_fold(P.fold_id, a, P.spec_nwg / 2, true, (unsigned *)P.tab.stage, stream) : 1;      // 1: not for these arguments
-						if (rc == 1) rc = be_launch_row_pair(P.pair_id, a, P.spec_nwg / 2, stream);
-					} else rc = be_launch_col_half(P.hspec.id, a, P.half_nwg, stream);
+					rc = P.pair ? be_launch_row_pair(P.pair_id, a, P.spec_nwg / 2, stream) : be_launch_col_half(P.hspec.id, a, P.half_nwg, stream);
 					if (rc) return fail(-4, "kernel launch failed (%s): backend code %d", P.desc.c_str(), rc);
 					return 0;
 				}
@@ -818,9 +780,7 @@ int run_pass(const dspfft_plan_s *pl, const Pass &P, const R *in, R *out, bool l
 				if (use_spec) {
 					PassArgsT<R> a;
 					fill_args(a, P.spa, pl, P, in + oin, out + oout, scale, fz);
-					rc = 1;
-					if constexpr (std::is_same<R, float>::value) { if (P.fold_id >= 0 && !P.jit && P.type == Pass::ROW) rc = be_launch_row_fold(P.fold_id, a, P.spec_nwg, false, nullptr, stream); }
-					if (rc == 1) rc = P.jit ? be_jit_launch(P.jit_fn, &a, P.spec_nwg, P.jit_nthr, stream) : be_launch_spec(P.type == Pass::COL, P.spec.id, a, P.spec_nwg, stream);
+					rc = P.jit ? be_jit_launch(P.jit_fn, &a, P.spec_nwg, P.jit_nthr, stream) : be_launch_spec(P.type == Pass::COL, P.spec.id, a, P.spec_nwg, stream);
 				}
 			}
 			if (P.type == Pass::BLUE) {
@@ -888,15 +848,6 @@ void build_split(dspfft_plan_s *pl)
 	PR.pair = true; PR.pair_id = pid;
 	snprintf(buf, sizeof buf, "axis %d: ROW*2 N=%d C=%d row pairs of axis %d, spec#%d threads=%d pairs=%d lds=%zu", ra, PR.pa.N, PR.pa.C, ca, PR.spec.id, be_row_pair_threads(pid), PR.spec_nwg / 2, PR.spec.lds);
 	PR.desc = buf;
-	if (PR.fold_id >= 0) {
-		// the folded kernels take a pair as two workgroups, one output line each; in place the partners read each other's output lines and
-		// shake hands through one word per pair (spec_kernels.h fold_pair_arrive / _wait): tab.stage (a ROW pass has no other use for it), zeroed once.
-		// Executions of ONE plan must therefore not overlap one another on different streams (dspfft_execute_many checks).
-		const size_t fb = (size_t)(PR.spec_nwg / 2) * sizeof(unsigned);
-		PR.tab.stage = be_alloc(fb);
-		if (!PR.tab.stage || be_zero(PR.tab.stage, fb, nullptr) || be_stream_synchronize(nullptr)) { be_free(PR.tab.stage); PR.tab.stage = nullptr; PR.fold_id = -1; }
-		else { snprintf(buf, sizeof buf, " fold#%d: one output line per workgroup, wgs=%d", PR.fold_id, PR.spec_nwg); PR.desc += buf; }
-	}
 	// column pass: FFT of length N/2; T stays the table of the full length, W becomes the half length's, H = exp(-2 pi i n / N)
 	const int M = N / 2;
 	{

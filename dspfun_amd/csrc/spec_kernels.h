@@ -10,7 +10,6 @@
 #include "spec_fused.h"
 #include "dct_duo.h"
 #include "dct_czt.h"
-#include "dct_fold.h"
 
 namespace dspfft {
 
@@ -388,213 +387,6 @@ __global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_kerne
 	}
 }
 
-// ---- row pairs, PERSISTENT (round 5): one workgroup per CU walks the pairs; the NEXT pair's two lines are fetched into the registers the
-// waiting line frees when it moves into the plane (behind phase 0 of the second transform), so they land during that transform's butterfly
-// stages instead of in front of the next pair's first barrier.  As in row_persist_kernel the stage twiddles live in LDS (vmcnt is in order:
-// a table load behind the prefetch would wait for it); T[k] of a line is fetched ahead of the prefetch.  The two transforms of a pair are two
-// copies of the phases (not a loop): in a loop the prefetched lines would be live through the first transform as well, beside the waiting
-// line (46 + 23 registers of 128). ----
-template <class S> constexpr size_t pair_persist_lds() { return S::LDS + sizeof(typename S::CX) * (size_t)S::L; }
-template <class S> constexpr bool pair_persist_ok() { return S::LDS > 80 * 1024 && pair_persist_lds<S>() <= 160 * 1024; }
-template <class S, int KIND, bool PLAIN>
-__global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_persist_kernel(const typename S::PA a_, int npairs)
-{
-	typedef typename S::CX CX;
-	typedef typename S::Re Re;
-	extern __shared__ __attribute__((aligned(32))) unsigned char lds[];
-	CX *planes = reinterpret_cast<CX *>(lds);
-	CX *wtab = reinterpret_cast<CX *>(lds + S::LDS);
-	const int tid = threadIdx.x;
-	for (int i = tid; i < S::L; i += S::T) wtab[i] = a_.W[i];
-	typename S::PA a = PLAIN ? plain_args(a_) : a_;
-	a.W = wtab;
-	typedef typename S::template State<KIND> ST;
-	ST st, st2;
-	constexpr int NPRE = (int)(sizeof(st.pre) / sizeof(Re));
-	const int pairs = a.nb0 >> 1;
-	auto geom = [&](int work, long long &bin1, long long &bin2, long long &bout1, long long &bout2) {
-		const int i1 = work / pairs, n = work - i1 * pairs;
-		const int y1 = 2 * n, y2 = a.nb0 - 1 - 2 * n;
-		bin1 = y1 * a.sb0_in + i1 * a.sb1_in; bin2 = y2 * a.sb0_in + i1 * a.sb1_in;
-		bout1 = y1 * a.sb0_out + i1 * a.sb1_out; bout2 = y2 * a.sb0_out + i1 * a.sb1_out;
-	};
-	// DSP_PAIR_PREFETCH: 2 -- both lines of the next pair are fetched early, 1 -- only the first (the second at the top of the pair's own work)
-#ifndef DSP_PAIR_PREFETCH
-#define DSP_PAIR_PREFETCH 2
-#endif
-	auto fetch1 = [&](long long bin1, int t) { S::template prefetch<KIND>(a, bin1, t, st, nullptr, a.zflags); };
-	auto fetch2 = [&](long long bin2, int t) { S::template prefetch<KIND>(a, bin2, t, st2, nullptr, a.zflags ? a.zflags + a.zhalf : nullptr); };
-	auto fetch = [&](long long bin1, long long bin2, int t) { fetch1(bin1, t); fetch2(bin2, t); };
-	auto twiddles = [&](ST &w, int t) {
-		static_for<0, S::K_ROUNDS>([&](auto i) { const int k = t + i * S::T; if ((i + 1) * S::T <= S::L / 2 + 1 || k <= S::L / 2) w.tw[i] = a.T[k]; });
-	};
-	int work = blockIdx.x;
-	long long bin1, bin2, bout1, bout2;
-	geom(work, bin1, bin2, bout1, bout2);
-	fetch(bin1, bin2, tid);
-	__syncthreads();                                         // the twiddle table is in place
-	while (work < npairs) {
-		const long long o1 = bout1, o2 = bout2;
-		Re diff[NPRE];
-		{
-			// first transform: r1 + r2 -> line y1; r1 - r2 waits in `diff`
-			int t = tid; asm volatile("" : "+v"(t));
-			if (DSP_PAIR_PREFETCH == 1 && work != (int)blockIdx.x) fetch2(bin2, t);
-			ST w;
-			static_for<0, NPRE>([&](auto i) { const Re p = st.pre[i], q = st2.pre[i]; w.pre[i] = p + q; diff[i] = p - q; });
-			twiddles(w, t);
-			static_for<0, S::NPH>([&](auto ph) {
-				int u = t; asm volatile("" : "+v"(u));
-				S::template phase<KIND, ph, ST, true>(a, planes, o1, u, w);
-				__syncthreads();
-			});
-		}
-		const int next = work + (int)gridDim.x;
-		{
-			int t = tid; asm volatile("" : "+v"(t));
-			ST w;
-			static_for<0, NPRE>([&](auto i) { w.pre[i] = diff[i]; });
-			twiddles(w, t);
-			S::template phase<KIND, 0, ST, true>(a, planes, o2, t, w);
-			__syncthreads();
-			if (next < npairs) {                                 // uniform: the next pair's loads go out now and land behind the stages
-				geom(next, bin1, bin2, bout1, bout2);
-				if (DSP_PAIR_PREFETCH == 1) fetch1(bin1, t); else fetch(bin1, bin2, t);
-			}
-			static_for<1, S::NPH>([&](auto ph) {
-				int u = t; asm volatile("" : "+v"(u));
-				S::template phase<KIND, ph, ST, true>(a, planes, o2, u, w);
-				__syncthreads();
-			});
-		}
-		work = next;
-	}
-}
-
-// ---- folded row passes (dct_fold.h): a line as two half-length transforms through half the LDS; PAIR: the row-pair butterfly of a split
-// column pass with one output line per workgroup (partners b, b + 8 read both lines).  FUSED: the scan step's tile flags on the loads and
-// `sum += image` on the stores (REDFT01 only); the plain instantiation folds them away ----
-// (tools/foldbench.hip defines DSP_FOLD_STAMP to record the clock behind every barrier; nothing in the product)
-#ifndef DSP_FOLD_STAMP
-#define DSP_FOLD_STAMP(i) ((void)0)
-#endif
-template <class S>
-__device__ inline void fold_fft_stages(const PassArgs &w, cf *planes, int tid, int stamp0)
-{
-#ifndef DSP_FOLD_SEQTW
-#define DSP_FOLD_SEQTW false
-#endif
-	static_for<0, S::NS - 1>([&](auto I) { S::F::template stage<I, DSP_FOLD_SEQTW>(w, planes, tid); __syncthreads(); DSP_FOLD_STAMP(stamp0 + I); });
-}
-// PAIR in place: a workgroup's partner reads the line it is about to overwrite.  Each announces that its loads have landed (arrive) and
-// neither stores before both have (wait); the flag returns to zero behind the second one to leave, so a launch finds it as it was.  The
-// partner is 8 workgroups away in dispatch order and loading at the same time, so the wait -- at the very end of the workgroup's
-// work -- finds the flag set; the spin is bounded all the same (a lost partner must not hang the device).
-__device__ inline void fold_pair_arrive(unsigned *flag) { __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ inline void fold_pair_wait(unsigned *flag)
-{
-	for (int spin = 0; spin < (1 << 24) && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2u; spin++) __builtin_amdgcn_s_sleep(2);
-	if (__hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 3u) __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <class S, int KIND, bool PAIR, bool FUSED>
-__global__ void __launch_bounds__(S::T, S::WPE) row_fold_kernel(const PassArgs a_, int npairs, unsigned *pair_flags)
-{
-	PassArgs a = a_;
-	a.mask = nullptr; a.win_lo = a.win_hi = 0; a.alt_out = 0; a.in_mul = nullptr; a.in_rev = 0;
-	if constexpr (!FUSED) { a.zflags = nullptr; a.accumulate = 0; }
-	extern __shared__ __attribute__((aligned(32))) unsigned char lds[];
-	cf *planes = reinterpret_cast<cf *>(lds);
-	const cf *tab = a.H;
-	PassArgs w;
-	w.W = tab + S::OFF_W;                                    // the stages read nothing else
-	const int tid = threadIdx.x;
-	long long bin, bin2 = 0, bout;
-	float sg = 1.f;
-	const uint8_t *zf = nullptr, *zf2 = nullptr;
-	if constexpr (PAIR) {
-		int gp, h;
-		fold_pair_work(blockIdx.x, npairs, gp, h);
-		const int pairs = a.nb0 >> 1;
-		const int i1 = gp / pairs, n = gp - i1 * pairs;
-		const int y1 = 2 * n, y2 = a.nb0 - 1 - 2 * n;
-		bin = y1 * a.sb0_in + i1 * a.sb1_in; bin2 = y2 * a.sb0_in + i1 * a.sb1_in;
-		bout = (h ? y2 : y1) * a.sb0_out + i1 * a.sb1_out;
-		sg = h ? -1.f : 1.f;
-		if (a.zflags) { zf = a.zflags; zf2 = a.zflags + a.zhalf; }
-		if (pair_flags) pair_flags += gp;
-	} else {
-		row_base(a, blockIdx.x, bin, bout);
-		if (a.zflags) zf = a.zflags + (blockIdx.x & 1) * a.zhalf;       // see row_spec_kernel
-	}
-	typename S::Orb u, v;                                    // u: the half in the plane next / A's results; v: the half that waits for B
-	DSP_FOLD_STAMP(0);
-	if constexpr (KIND == KIND_REDFT10) {
-		S::template load10<PAIR>(a, bin, bin2, sg, tid, u, v);
-		S::a_scatter10(planes, tid, u);
-		__syncthreads();
-		DSP_FOLD_STAMP(1);
-		if (PAIR && pair_flags && tid == 0) fold_pair_arrive(pair_flags);     // every thread's loads went into the values just written
-		fold_fft_stages<S>(w, planes, tid, 2);
-		{ typename S::Last L; S::F::last_read(planes, L, tid); __syncthreads(); DSP_FOLD_STAMP(8); S::F::last_write(planes, L, tid); }
-		__syncthreads();
-		DSP_FOLD_STAMP(9);
-		S::a_post10(a, tab, planes, tid);
-		__syncthreads();
-		DSP_FOLD_STAMP(10);
-		S::a_gather10(planes, tid, u);
-		__syncthreads();
-		DSP_FOLD_STAMP(11);
-		S::b_pre(tab, planes, tid, v);
-		__syncthreads();
-		DSP_FOLD_STAMP(12);
-		fold_fft_stages<S>(w, planes, tid, 13);
-		{ typename S::Last L; S::F::last_read(planes, L, tid); __syncthreads(); DSP_FOLD_STAMP(19); S::F::last_write(planes, L, tid); }
-		if (PAIR && pair_flags && tid == 0) fold_pair_wait(pair_flags);
-		__syncthreads();
-		DSP_FOLD_STAMP(20);
-		S::b_store10(a, tab, planes, bout, tid, u);
-		DSP_FOLD_STAMP(21);
-	} else {
-		if (FUSED && zf) S::template load01<PAIR, true>(a, bin, bin2, sg, zf, zf2, tid, u, v);
-		else S::template load01<PAIR, false>(a, bin, bin2, sg, nullptr, nullptr, tid, u, v);
-		S::a_scatter01(planes, tid, u);
-		__syncthreads();
-		DSP_FOLD_STAMP(1);
-		if (PAIR && pair_flags && tid == 0) fold_pair_arrive(pair_flags);
-		S::a_pre01(tab, planes, tid);
-		__syncthreads();
-		DSP_FOLD_STAMP(2);
-		fold_fft_stages<S>(w, planes, tid, 3);
-		{ typename S::Last L; S::F::last_read(planes, L, tid); __syncthreads(); DSP_FOLD_STAMP(9); S::F::last_write(planes, L, tid); }
-		__syncthreads();
-		DSP_FOLD_STAMP(10);
-		S::a_gather01(planes, tid, u);
-		__syncthreads();
-		DSP_FOLD_STAMP(11);
-		S::b_pre(tab, planes, tid, v);
-		__syncthreads();
-		DSP_FOLD_STAMP(12);
-		fold_fft_stages<S>(w, planes, tid, 13);
-		typename S::Old old;
-		{
-			typename S::Last L;
-			S::F::last_read(planes, L, tid);
-			__syncthreads();
-			DSP_FOLD_STAMP(19);
-			// sum += image: the old values are asked for here, one barrier and the plane's reads ahead of their use (earlier they would sit
-			// in 8 C registers per orbit through the butterflies)
-			if (FUSED && a.accumulate) S::fetch_old(a, bout, tid, old);
-			S::F::last_write(planes, L, tid);
-		}
-		if (PAIR && pair_flags && tid == 0) fold_pair_wait(pair_flags);
-		__syncthreads();
-		DSP_FOLD_STAMP(20);
-		if (FUSED && a.accumulate) S::template b_store01<true>(a, tab, planes, bout, tid, u, old);
-		else S::template b_store01<false>(a, tab, planes, bout, tid, u, old);
-		DSP_FOLD_STAMP(21);
-	}
-}
-
 // COL side: one workgroup per half tile (N/2 rows x K floats)
 template <class S, int KIND>
 __global__ void __launch_bounds__(S::T, S::WPE) col_half_kernel(const typename S::PA a)
@@ -686,51 +478,9 @@ int launch_col_spec(const typename S::PA &a, int nwork, void *stream)
 template <class S, int KIND>
 int launch_row_pair(const typename S::PA &a, int npairs, void *stream)
 {
-	if constexpr (pair_persist_ok<S>()) {
-		// DSPFFT_PAIR_PERSIST=0 keeps one workgroup per pair (A/B runs)
-		static const int on = []() { const char *e = getenv("DSPFFT_PAIR_PERSIST"); return e ? atoi(e) : 1; }();
-		const int cus = device_cus();
-		if (on && npairs > cus) {
-			static DevOnce ponce;
-			if (int p_rc = allow_lds_dev(ponce, pair_persist_lds<S>(), row_pair_persist_kernel<S, KIND, false>, row_pair_persist_kernel<S, KIND, true>)) return p_rc;
-			if (is_plain(a)) hipLaunchKernelGGL((row_pair_persist_kernel<S, KIND, true>), dim3(cus), dim3(S::T), pair_persist_lds<S>(), (hipStream_t)stream, a, npairs);
-			else hipLaunchKernelGGL((row_pair_persist_kernel<S, KIND, false>), dim3(cus), dim3(S::T), pair_persist_lds<S>(), (hipStream_t)stream, a, npairs);
-			HIPCHK(hipGetLastError());
-			return 0;
-		}
-	}
 	static DevOnce once;
 	if (int lds_rc = allow_lds_dev(once, S::LDS, row_pair_kernel<S, KIND>)) return lds_rc;
 	hipLaunchKernelGGL((row_pair_kernel<S, KIND>), dim3(npairs), dim3(S::T), S::LDS, (hipStream_t)stream, a);
-	HIPCHK(hipGetLastError());
-	return 0;
-}
-// nwork = lines, or row PAIRS with pair.  Returns 1 when the arguments are outside what the folded kernels take (the caller launches the
-// plain row / row-pair kernel): owner-id masks, input windows / modulation, alternating output, REDFT10 with accumulation, buffers or
-// strides off the 16-byte grid of its four-pixel accesses.
-// pair_flags: one zeroed word per pair, needed when a pair pass runs in place (its partners read each other's output lines); null otherwise
-template <class S, int KIND>
-int launch_row_fold(const PassArgs &a, int nwork, bool pair, unsigned *pair_flags, void *stream)
-{
-	if (a.mask || a.win_hi > 0 || a.alt_out || a.in_mul || a.in_rev) return 1;
-	if (KIND == KIND_REDFT10 && (a.accumulate || a.zflags)) return 1;
-	if ((15 & ((uintptr_t)a.in | (uintptr_t)a.out)) || (3 & (a.sb0_in | a.sb0_out | a.sb1_in | a.sb1_out | a.sb2_in | a.sb2_out))) return 1;
-	if (pair && (a.sb2_in | a.sb2_out)) return 1;
-	const bool in_place = (const void *)a.in == (const void *)a.out;      // (other overlaps of `in` and `out` are the caller's to avoid, as for every pass)
-	if (pair && in_place && !pair_flags) return 1;
-	if (!(pair && in_place)) pair_flags = nullptr;
-	static DevOnce once;
-	if (int rc = allow_lds_dev(once, S::LDS, row_fold_kernel<S, KIND, false, false>, row_fold_kernel<S, KIND, false, true>, row_fold_kernel<S, KIND, true, false>, row_fold_kernel<S, KIND, true, true>)) return rc;
-	const bool fused = a.zflags || a.accumulate;
-	const dim3 g(pair ? 2 * nwork : nwork), b(S::T);
-	hipStream_t st = (hipStream_t)stream;
-	if (pair) {
-		if (fused) hipLaunchKernelGGL((row_fold_kernel<S, KIND, true, true>), g, b, S::LDS, st, a, nwork, pair_flags);
-		else hipLaunchKernelGGL((row_fold_kernel<S, KIND, true, false>), g, b, S::LDS, st, a, nwork, pair_flags);
-	} else {
-		if (fused) hipLaunchKernelGGL((row_fold_kernel<S, KIND, false, true>), g, b, S::LDS, st, a, nwork, pair_flags);
-		else hipLaunchKernelGGL((row_fold_kernel<S, KIND, false, false>), g, b, S::LDS, st, a, nwork, pair_flags);
-	}
 	HIPCHK(hipGetLastError());
 	return 0;
 }

@@ -88,14 +88,6 @@
 	X(1920, 3, 256, 12, 5, 16) \
 	X(512, 3, 64, 16, 16)
 
-// ---- folded row passes (dct_fold.h RowFoldT): X(N, C, THREADS, radices of N/4 ...) ----
-// A line as two half-length transforms (REDFT10/01 of the mirror sums, a DCT-IV of the mirror differences) through HALF the plain line's
-// LDS.  Taken where the plain line leaves one workgroup per CU (7680 x 3 floats: 92 KB); DSPFFT_FOLD=1 takes it wherever listed (the 1920
-// entry exists for the CPU/GPU tests of the mechanism on small frames), DSPFFT_FOLD=0 never.
-#define DSPFFT_ROW_FOLD_SPECS(X) \
-	X(7680, 3, 512, 12, 10, 16) \
-	X(1920, 3, 128, 8, 4, 15)   /* forced only */
-
 // ---- double precision (the fftw_ API: spec and zoom's default COEFF_PRECISION=D build) ----
 // Same structures over double samples: X(N, C | K, THREADS, radices ...).  A slot is 16 bytes, so a 3840 x 3 line needs 92 KB of
 // LDS (one workgroup per CU) and column tiles are K = 4 doubles wide = the same 32-B row segments / 69 KB as the float K = 8 tile.

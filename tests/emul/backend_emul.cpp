@@ -336,91 +336,6 @@ int launch_row_spec_u8(const PassArgs &a, const U8IO &io, int nwork, void *)
 	}
 	return 0;
 }
-// folded row passes (spec_kernels.h row_fold_kernel): the same phase sequence, barrier by barrier.  A pair's two workgroups both load
-// before either stores, as the device kernel's handshake guarantees when the pass runs in place.
-template <class S, int KIND>
-int launch_row_fold(const PassArgs &a_, int nwork, bool pair, unsigned *pair_flags, void *)
-{
-	if (a_.mask || a_.win_hi > 0 || a_.alt_out || a_.in_mul || a_.in_rev) return 1;
-	if (KIND == KIND_REDFT10 && (a_.accumulate || a_.zflags)) return 1;
-	if ((15 & ((uintptr_t)a_.in | (uintptr_t)a_.out)) || (3 & (a_.sb0_in | a_.sb0_out | a_.sb1_in | a_.sb1_out | a_.sb2_in | a_.sb2_out))) return 1;
-	if (pair && (a_.sb2_in | a_.sb2_out)) return 1;
-	if (pair && (const void *)a_.in == (const void *)a_.out && !pair_flags) return 1;
-	const PassArgs a = a_;
-	std::vector<unsigned char> lds(S::LDS + 64);
-	cf *planes = (cf *)(((uintptr_t)lds.data() + 31) & ~(uintptr_t)31);
-	const cf *tab = a.H;
-	PassArgs w = {};
-	w.W = tab + S::OFF_W;
-	const int T = S::T;
-	auto fft = [&]() {
-		static_for<0, S::NS - 1>([&](auto I) { for (int tid = 0; tid < T; tid++) S::F::template stage<I>(w, planes, tid); });
-		std::vector<typename S::Last> L(T);
-		for (int tid = 0; tid < T; tid++) S::F::last_read(planes, L[tid], tid);
-		for (int tid = 0; tid < T; tid++) S::F::last_write(planes, L[tid], tid);
-	};
-	struct WG { long long bin, bin2, bout; float sg; const uint8_t *zf, *zf2; std::vector<typename S::Orb> u, v; };
-	auto geometry = [&](int wg, WG &g) {
-		g.bin2 = 0; g.sg = 1.f; g.zf = g.zf2 = nullptr;
-		if (pair) {
-			int gp, h;
-			fold_pair_work(wg, nwork, gp, h);
-			const int pairs = a.nb0 >> 1;
-			const int i1 = gp / pairs, n = gp - i1 * pairs;
-			const int y1 = 2 * n, y2 = a.nb0 - 1 - 2 * n;
-			g.bin = y1 * a.sb0_in + i1 * a.sb1_in; g.bin2 = y2 * a.sb0_in + i1 * a.sb1_in;
-			g.bout = (h ? y2 : y1) * a.sb0_out + i1 * a.sb1_out;
-			g.sg = h ? -1.f : 1.f;
-			if (a.zflags) { g.zf = a.zflags; g.zf2 = a.zflags + a.zhalf; }
-		} else {
-			row_base(a, wg, g.bin, g.bout);
-			if (a.zflags) g.zf = a.zflags + (wg & 1) * a.zhalf;
-		}
-	};
-	auto load = [&](WG &g) {
-		g.u.assign(T, typename S::Orb()); g.v.assign(T, typename S::Orb());
-		for (int tid = 0; tid < T; tid++) {
-			if (KIND == KIND_REDFT10) { if (pair) S::template load10<true>(a, g.bin, g.bin2, g.sg, tid, g.u[tid], g.v[tid]); else S::template load10<false>(a, g.bin, g.bin2, g.sg, tid, g.u[tid], g.v[tid]); }
-			else if (pair) { if (g.zf) S::template load01<true, true>(a, g.bin, g.bin2, g.sg, g.zf, g.zf2, tid, g.u[tid], g.v[tid]); else S::template load01<true, false>(a, g.bin, g.bin2, g.sg, g.zf, g.zf2, tid, g.u[tid], g.v[tid]); }
-			else { if (g.zf) S::template load01<false, true>(a, g.bin, g.bin2, g.sg, g.zf, g.zf2, tid, g.u[tid], g.v[tid]); else S::template load01<false, false>(a, g.bin, g.bin2, g.sg, g.zf, g.zf2, tid, g.u[tid], g.v[tid]); }
-		}
-	};
-	auto rest = [&](WG &g) {
-		std::vector<typename S::Orb> &u = g.u, &v = g.v;
-		if (KIND == KIND_REDFT10) {
-			for (int tid = 0; tid < T; tid++) S::a_scatter10(planes, tid, u[tid]);
-			fft();
-			for (int tid = 0; tid < T; tid++) S::a_post10(a, tab, planes, tid);
-			for (int tid = 0; tid < T; tid++) S::a_gather10(planes, tid, u[tid]);
-			for (int tid = 0; tid < T; tid++) S::b_pre(tab, planes, tid, v[tid]);
-			fft();
-			for (int tid = 0; tid < T; tid++) S::b_store10(a, tab, planes, g.bout, tid, u[tid]);
-		} else {
-			std::vector<typename S::Old> old(T);
-			for (int tid = 0; tid < T; tid++) S::a_scatter01(planes, tid, u[tid]);
-			for (int tid = 0; tid < T; tid++) S::a_pre01(tab, planes, tid);
-			fft();
-			for (int tid = 0; tid < T; tid++) S::a_gather01(planes, tid, u[tid]);
-			for (int tid = 0; tid < T; tid++) S::b_pre(tab, planes, tid, v[tid]);
-			fft();
-			if (a.accumulate) for (int tid = 0; tid < T; tid++) S::fetch_old(a, g.bout, tid, old[tid]);
-			for (int tid = 0; tid < T; tid++) { if (a.accumulate) S::template b_store01<true>(a, tab, planes, g.bout, tid, u[tid], old[tid]); else S::template b_store01<false>(a, tab, planes, g.bout, tid, u[tid], old[tid]); }
-		}
-	};
-	if (!pair) { for (int wg = 0; wg < nwork; wg++) { WG g; geometry(wg, g); load(g); rest(g); } return 0; }
-	// partners are workgroups b and b + 8 (or neighbours in the tail): find each pair's two workgroups by their work mapping
-	std::vector<int> first(nwork, -1);
-	for (int wg = 0; wg < 2 * nwork; wg++) {
-		int gp, h;
-		fold_pair_work(wg, nwork, gp, h);
-		if (first[gp] < 0) { first[gp] = wg; continue; }
-		WG g0, g1;
-		geometry(first[gp], g0); geometry(wg, g1);
-		load(g0); load(g1);
-		rest(g0); rest(g1);
-	}
-	return 0;
-}
 template <class S, int KIND>
 int launch_row_pair(const PassArgs &a, int npairs, void *)
 {
