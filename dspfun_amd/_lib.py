@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdspfft_hip.so")
+# DSPFFT_LIB_PATH: another build of the same library (same-box A/B runs of a kernel change: tools/ab_oldlib.sh); nothing else is ever loaded
+LIB_PATH = os.environ.get("DSPFFT_LIB_PATH") or os.path.join(_HERE, "csrc", "libdspfft_hip.so")
 
 REDFT01, REDFT10 = 4, 5
 

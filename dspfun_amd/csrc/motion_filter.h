@@ -18,6 +18,7 @@ struct MotionFilter {
 	int bd;                                  // frames per block as laid out (the embedding depth; 1 = every frame its own block)
 	int enabled;
 	int quant_only;                          // nothing but the quantiser acts (no damp/boost/threshold/DC rule): positions are not needed
+	float rquant = 0.f;                      // 1 / quantizer rounded to float (motion_filter_set_divs), or 0: divide
 };
 
 inline FastDiv motion_filter_div(uint32_t d)
@@ -28,7 +29,30 @@ inline void motion_filter_set_divs(MotionFilter &p, int block_depth)
 {
 	p.bd = block_depth;
 	p.quant_only = p.quantizer > 0.f && p.damp == 1.f && p.boost == 1.f && !(p.thr_hi > 0.f) && (p.preserve_dc == 0 || !(p.b0d || p.b0h || p.b0w));
+	p.rquant = (p.quantizer > 1e-30f && p.quantizer < 1e30f) ? 1.0f / p.quantizer : 0.f;
 	p.div_mw = motion_filter_div((uint32_t)p.mw); p.div_mh = motion_filter_div((uint32_t)p.mh); p.div_bd = motion_filter_div((uint32_t)block_depth);
+}
+
+// motion.c:744  coeffs = mi(round)(coeffs / quantizer) * quantizer  with coeffs and quantizer of type `coeff` (float in motion's build,
+// motion/Makefile:1): the QUOTIENT is a float division, rounded to float before round() sees it; round() of a float is exact in any wider
+// type, and the product of an integer below 2^24 with a float is exact in `intermediate`, so the assignment rounds once -- exactly what a float
+// multiplication does.  All in single precision, bit for bit (tests/test_ref_motion.py against the reference's compiled lines).  Round 4 divided
+// in double, which rounds differently when the double quotient and its float rounding lie on opposite sides of a half-integer, and cost four
+// times the instructions (v_div_scale_f64 ...).
+// The float quotient itself, without the divider: with rq = RN(1 / q), t0 = RN(v rq) is within a couple of units in the last place of v / q;
+// each step t' = RN(t + (v - q t) rq) -- the residual v - q t exact in one FMA -- brings an approximation that is within one unit to the
+// correctly rounded quotient (Markstein's theorem, for a correctly rounded reciprocal), so two steps give RN(v / q): 5 full-rate instructions
+// for the hardware sequence's 10 and its quarter-rate v_rcp_f32 (checked against the division on 2^26 values per quantiser, adversarial
+// significands included: tests/test_ref_motion.py).  rq == 0 (quantisers outside [1e-30, 1e30]): divide.
+DSP_HD float motion_quantise(float v, float q, float rq)
+{
+	float t;
+	if (rq != 0.f) {
+		const float t0 = v * rq;
+		const float t1 = fmaf(fmaf(-t0, q, v), rq, t0);
+		t = fmaf(fmaf(-t1, q, v), rq, t1);
+	} else t = v / q;
+	return roundf(t) * q;
 }
 
 // one coefficient at block position (z, y, x); `coded` counts the non-zero quantised coefficients (motion.c:743)
@@ -46,7 +70,7 @@ DSP_HD float motion_filter_at(const MotionFilter &p, int z, int y, int x, float 
 			else v += p.grey_add;
 		}
 	}
-	if (p.quantizer > 0.f) { v = (float)(round((double)v / p.quantizer) * p.quantizer); coded += (v != 0.f); }   // :740-744
+	if (p.quantizer > 0.f) { v = motion_quantise(v, p.quantizer, p.rquant); coded += (v != 0.f); }   // :740-744
 	return v;
 }
 
@@ -66,7 +90,7 @@ DSP_HD float4 motion_filter4(const MotionFilter &p, uint32_t e, float4 v, unsign
 	if (p.quant_only) {
 		float r[4] = {v.x, v.y, v.z, v.w};
 		for (int q = 0; q < 4; q++) {
-			r[q] = (float)(round((double)r[q] / p.quantizer) * p.quantizer);                 // motion.c:740-744
+			r[q] = motion_quantise(r[q], p.quantizer, p.rquant);                                       // motion.c:740-744
 			coded += (r[q] != 0.f);
 			DSP_SCHED_FENCE();
 		}
@@ -82,7 +106,7 @@ DSP_HD float4 motion_filter4(const MotionFilter &p, uint32_t e, float4 v, unsign
 	for (int q = 0; q < 4; q++) {
 		r[q] = motion_filter_at(p, z, y, x, r[q], coded);
 		if (++x == p.mw) { x = 0; if (++y == p.mh) { y = 0; if (++z == p.bd) z = 0; } }
-		DSP_SCHED_FENCE();      // one double-precision quantiser at a time: interleaved, four of them cost ~60 VGPRs
+		DSP_SCHED_FENCE();
 	}
 	float4 o; o.x = r[0]; o.y = r[1]; o.z = r[2]; o.w = r[3];
 	return o;

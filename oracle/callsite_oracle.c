@@ -307,6 +307,7 @@ unsigned long long oracle_motion_filter_f32(float *coeffs, const int active[3], 
 		int dcstop = bb[0] || bb[1] || bb[2];
 		if (dcstop || boost != 1 || thr_hi > 0) { if (preserve_dc == 1) coeffs[0] = dc; else coeffs[0] += grey_add; }
 	}
+	/* (the quotient of two floats is a float division, as in motion.c:744 where both are `coeff`) */
 	if (quantizer > 0) for (int z = 0; z < ad; z++) for (int y = 0; y < ah; y++) for (int x = 0; x < aw; x++) coded += !!(AT(z, y, x) = round(AT(z, y, x) / quantizer) * quantizer);
 #undef AT
 	return coded;

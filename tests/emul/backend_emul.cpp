@@ -412,6 +412,24 @@ int launch_col_roundtrip(const PassArgs &af, const PassArgs &ai, const MotionFil
 }
 #include "spec_registry.inc"
 
+// TEST-ONLY entry: motion's filter (motion_filter.h motion_filter_at, the function the HIP kernels call per element) over one block, with the
+// arguments of dspfft_motion_filter (include/dspfft.h); returns the count of coded coefficients
+extern "C" unsigned long long emul_motion_filter(float *c, const int active[3], const int minbuf_hw[2], const int bb[3], const int be[3], float damp, float boost,
+                                                 float thr_lo, float thr_hi, int preserve_dc, float grey_add, float quantizer)
+{
+	MotionFilter p;
+	p.ad = active[0]; p.ah = active[1]; p.aw = active[2]; p.mh = minbuf_hw[0]; p.mw = minbuf_hw[1];
+	p.b0d = bb[0]; p.b0h = bb[1]; p.b0w = bb[2]; p.b1d = be[0]; p.b1h = be[1]; p.b1w = be[2];
+	p.damp = damp; p.boost = boost; p.thr_lo = thr_lo; p.thr_hi = thr_hi; p.preserve_dc = preserve_dc; p.grey_add = grey_add; p.quantizer = quantizer;
+	p.enabled = 1; motion_filter_set_divs(p, p.ad > 0 ? p.ad : 1);
+	unsigned long long coded = 0;
+	for (int z = 0; z < p.ad; z++) for (int y = 0; y < p.ah; y++) for (int x = 0; x < p.aw; x++) {
+		float &v = c[((size_t)z * p.mh + y) * p.mw + x];
+		v = motion_filter_at(p, z, y, x, v, coded);
+	}
+	return coded;
+}
+
 int be_motion_filter(float *buf, const MotionFilter &filt, uint64_t span, unsigned long long *coded, void *)
 {
 	unsigned long long mine = 0;

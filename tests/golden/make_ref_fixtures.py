@@ -16,6 +16,14 @@ direct-sum statement of the same transforms, and this script compiles that code 
   scan/scan_methods.c:5-7,11-14,16-184,203-331 + scan/scan_precomputed.c   every scan method that needs no libavutil (all but evalxy /
                              evali): limits, intervals, coordinate generators, radial / iradial / magnitude  ->  tests/golden/ref_scan.npz
 
+  motion/motion.c:18-35,58-60  the spectrogram / preserve-dc enums and struct coords
+  motion/motion.c:559-573    scalefactor, normalization, quantizer, threshold per component
+  motion/motion.c:644-647,650,683-744,748-751,756-776   motion's elementwise stages around its transforms: uniform-range scaling, the six-face
+                             damp / boost, threshold, DC preservation, the quantiser (with its count of coded coefficients), the reverse scaling,
+                             and the 8-bit store (clamp + lround)  ->  tests/golden/ref_motion.npz  (COEFF_PRECISION=F, INTERMEDIATE_PRECISION=L as
+                             motion/Makefile:1-2 builds; WITHOUT that Makefile's -ffast-math, under which the quantiser's division may become a
+                             multiplication by a reciprocal -- what the compiler does then is not the reference's text)
+
 The text of those line ranges is read from /root/reference at generation time into a temporary translation unit
 that includes the reference's include/precision.h (COEFF_PRECISION=L, INTERMEDIATE_PRECISION=L: the tightest build
 the reference offers) and is compiled with plain gcc -- no stand-in headers; no reference text is written to the
@@ -171,6 +179,101 @@ struct scan_precomputed *ref_precomputed(int which, size_t w, size_t h, size_t c
     return C.CDLL(so)
 
 
+def build_motion(tmp):
+    """motion.c's elementwise stages as they lie, around this script's own declarations of the variables they use (one component, i = 0)"""
+    tu = "#include <stdlib.h>\n#include <stdint.h>\n#include <stdbool.h>\n#include <string.h>\n#include <math.h>\n#include \"precision.h\"\n#include \"keyed_enum.h\"\n"
+    tu += lines("motion/motion.c", 18, 35) + lines("motion/motion.c", 58, 60)
+    tu += """
+/* stages: 1 = uniform-range scaling (:644-647), 2 = damp .. quantiser (:683-744), 4 = reverse scaling (:748-751), 8 = 8-bit store (:756-776) */
+unsigned long long ref_motion_stages(int stages, float *coeffs_, unsigned char *pblock_, const uint64_t *active_, const uint64_t *minbuf_, const uint64_t *scaled_,
+                                     const uint64_t *block_, const uint64_t *band_begin, const uint64_t *band_end, long double damp_, long double boost_,
+                                     long double threshold_min_, long double threshold_max_, int preserve_dc_, long double quant_)
+{
+	const int components = 1, i = 0;
+	coords active = {{active_[0], active_[1], active_[2]}}, minbuf = {{minbuf_[0], minbuf_[1], minbuf_[2]}}, scaled = {{scaled_[0], scaled_[1], scaled_[2]}};
+	coords block = {{block_[0], block_[1], block_[2]}};
+	range bandpass = {{{band_begin[0], band_begin[1], band_begin[2]}}, {{band_end[0], band_end[1], band_end[2]}}};
+	intermediate damp[1] = {damp_}, boost[1] = {boost_}, threshold_min = threshold_min_, threshold_max = threshold_max_, quant = quant_;
+	enum spectype spec = spectype_none;
+	enum ispectype ispec = ispectype_none;
+	enum preserve_dctype preserve_dc = preserve_dc_;
+	void *expr = NULL;
+	bool float_pixels = false, linear = false, dithering = false;
+	intermediate (*output_trc)(intermediate) = NULL;
+	coeff *coeffs = coeffs_;
+	void *pblock = pblock_;
+	uint64_t coeffs_coded = 0;
+"""
+    tu += lines("motion/motion.c", 559, 573)
+    tu += "\tif (stages & 1) {\n" + lines("motion/motion.c", 644, 647) + "\t}\n"
+    tu += lines("motion/motion.c", 650, 650)
+    tu += "\tif (stages & 2) {\n" + lines("motion/motion.c", 683, 744) + "\t}\n"
+    tu += "\tif (stages & 4) {\n" + lines("motion/motion.c", 748, 751) + "\t}\n"
+    tu += "\tif (stages & 8) {\n" + lines("motion/motion.c", 756, 776) + "\t\t\t\t\t\t}\n\t}\n"
+    tu += "\t(void)c; (void)ic; (void)components; (void)float_pixels; (void)linear; (void)dithering; (void)output_trc; (void)block; (void)dc;\n\treturn coeffs_coded;\n}\n"
+    src = os.path.join(tmp, "motion.c")
+    so = os.path.join(tmp, "motion.so")
+    with open(src, "w") as f:
+        f.write(tu)
+    subprocess.check_call(["gcc", "-std=c11", "-D_GNU_SOURCE", "-DCOEFF_PRECISION=F", "-DINTERMEDIATE_PRECISION=L", "-O2", "-fPIC", "-shared", "-w",
+                           "-I" + os.path.join(REF, "include"), src, "-o", so, "-lm"])
+    return C.CDLL(so)
+
+
+def motion_fixtures(tmp):
+    """inputs and outputs of motion's elementwise stages on blocks embedded in a larger buffer; every stage alone and the whole chain"""
+    mo = build_motion(tmp)
+    vp, ld = C.c_void_p, C.c_longdouble
+    mo.ref_motion_stages.restype = C.c_ulonglong
+    mo.ref_motion_stages.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, ld, ld, ld, ld, C.c_int, ld]
+    u64 = lambda *v: np.array(v, dtype=np.uint64)
+    out = {}
+    # (d, h, w) active block inside minbuf (d, h, w); band [begin, end) per (d, h, w); damp, boost, thr_min, thr_max, preserve_dc, quant
+    cases = [
+        ((1, 12, 16), (1, 12, 16), (0, 0, 0), (1, 12, 16), 1.0, 1.0, 0.0, 0.0, 0, 20.0),          # quantiser alone (motion --quant 20)
+        ((1, 45, 80), (1, 48, 84), (0, 0, 0), (1, 45, 80), 1.0, 1.0, 0.0, 0.0, 0, 3.0),           # ... in an embedding, another qfactor
+        ((4, 10, 12), (4, 12, 16), (1, 2, 3), (3, 8, 9), 0.3, 1.0, 0.0, 0.0, 0, 0.0),             # six-face damp
+        ((4, 10, 12), (4, 12, 16), (0, 0, 0), (2, 5, 6), 0.25, 1.75, 0.0, 0.0, 0, 0.0),           # damp outside + boost inside a corner box
+        ((2, 9, 16), (2, 9, 16), (0, 0, 0), (2, 9, 16), 1.0, 1.0, 0.002, 0.5, 0, 0.0),            # threshold
+        ((3, 8, 8), (3, 8, 8), (0, 1, 0), (3, 8, 8), 0.5, 1.0, 0.0, 0.0, 1, 0.0),                 # dc stop, preserve dc
+        ((3, 8, 8), (3, 8, 8), (0, 0, 0), (3, 6, 6), 0.5, 1.5, 0.0, 0.0, 2, 0.0),                 # boost, preserve grey
+        ((2, 16, 24), (2, 16, 24), (0, 0, 2), (2, 12, 20), 0.6, 1.2, 0.001, 0.8, 1, 7.0),         # everything at once
+    ]
+    out["cases"] = np.array([[*a, *m, *b0, *b1, da, bo, t0, t1, pd, q] for (a, m, b0, b1, da, bo, t0, t1, pd, q) in cases], dtype=np.float64)
+    for ci, (a, m, b0, b1, da, bo, t0, t1, pd, q) in enumerate(cases):
+        d, h, w = a
+        md, mh, mw = m
+        n = md * mh * mw
+        # coefficients of the size a forward transform of 8-bit samples leaves: the uniform-range values are O(255 sqrt(8 whd)) at DC, small elsewhere
+        x = ((synth_f32(0xD5F1900 + ci, n) * 2 - 1) * np.float32(255.0 * np.sqrt(8.0 * w * h * d)) * (synth_f32(0xD5F1A00 + ci, n) ** 6)).astype(np.float32)
+        x[0] = np.float32(127.0 * np.sqrt(8.0 * w * h * d))
+        A, MB, B0, B1 = u64(w, h, d), u64(mw, mh, md), u64(b0[2], b0[1], b0[0]), u64(b1[2], b1[1], b1[0])      # (kept alive across the calls)
+        args = lambda stages, buf, pb: mo.ref_motion_stages(stages, buf.ctypes.data, pb.ctypes.data, A.ctypes.data, MB.ctypes.data, A.ctypes.data, A.ctypes.data,
+                                                            B0.ctypes.data, B1.ctypes.data, da, bo, t0, t1, pd, q)
+        pb = np.zeros(n, dtype=np.uint8)
+        out[f"m{ci}_in"] = x
+        for stages, name in ((1, "scaled"), (2, "filtered"), (4, "unscaled"), (3, "scaled_filtered"), (7, "chain")):
+            b = x.copy()
+            coded = args(stages, b, pb)
+            out[f"m{ci}_{name}"] = b
+            if stages & 2:
+                out[f"m{ci}_{name}_coded"] = np.array([coded], dtype=np.uint64)
+        # the 8-bit store on values around the whole 0..255 range and beyond, with exact halves among them
+        v = ((synth_f32(0xD5F1B00 + ci, n) * 300 - 20) / (np.float64(1.0))).astype(np.float64)
+        v[:16] = np.arange(16) + 0.5
+        # pel = coeffs * scalefactor * normalization^2 with scalefactor = 1 (scaled == block): coefficients that land on those pels
+        norm2 = 1.0 / (8.0 * w * h * d)
+        cb = (v / norm2).astype(np.float32)
+        pb = np.zeros(n, dtype=np.uint8)
+        args(8, cb, pb)
+        out[f"m{ci}_store_in"] = cb
+        out[f"m{ci}_store_u8"] = pb.copy()
+        print("motion case", ci, a, m)
+    path = os.path.join(HERE, "ref_motion.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path))
+
+
 SCAN_METHODS = ["horizontal", "vertical", "zigzag", "row", "column", "diagonal", "mirror", "box", "ibox"]
 
 
@@ -277,7 +380,9 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         if len(sys.argv) < 2 or sys.argv[1] == "scan":
             scan_fixtures(tmp)
-        if len(sys.argv) > 1 and sys.argv[1] == "scan":
+        if len(sys.argv) < 2 or sys.argv[1] == "motion":
+            motion_fixtures(tmp)
+        if len(sys.argv) > 1 and sys.argv[1] in ("scan", "motion"):
             return
         sz = build_scan_zoom(tmp)
         ab = build_applybasis(tmp)
