@@ -164,6 +164,21 @@ size_t ref_interval(int m, size_t w, size_t h, size_t i)
 	             case 7: return interval_box(0, w, h, i); case 8: return interval_ibox(0, w, h, i); default: return 1; }
 }
 void ref_scan(int m, size_t w, size_t h, size_t i, size_t (*coords)[2]) { fn_of(m)(0, w, h, i, coords); }
+/* FNV-1a-64 over y*w+x of every coordinate in scan order (the word variant of SURVEY 8c / tests/golden/scan_golden.json), looped here in C: one
+   index per pixel is 33 M calls at 7680x4320 */
+unsigned long long ref_scan_fnv1a(int m, size_t w, size_t h)
+{
+	unsigned long long hsh = 1469598103934665603ULL;
+	size_t lim = ref_limit(m, w, h), mi = ref_max_interval(m, w, h);
+	size_t (*buf)[2] = malloc(sizeof(*buf) * (mi + 2));
+	for (size_t i = 0; i < lim; i++) {
+		size_t n = ref_interval(m, w, h, i);
+		fn_of(m)(0, w, h, i, buf);
+		for (size_t k = 0; k < n; k++) { hsh ^= (unsigned long long)(buf[k][0] * w + buf[k][1]); hsh *= 1099511628211ULL; }
+	}
+	free(buf);
+	return hsh;
+}
 /* precomputed methods: 0 radial, 1 iradial, 2 magnitude (coeffs: w*h*channels floats; args as on the command line or NULL) */
 struct scan_precomputed *ref_precomputed(int which, size_t w, size_t h, size_t channels, float *coeffs, const char *args)
 {
@@ -320,6 +335,16 @@ def scan_fixtures(tmp):
             else:       # hash of (count, y, x ...) per index in order
                 out[key + "_fnv"] = np.array([fnv_words(counts), fnv_words((flat[:, 0] << np.uint64(32)) | flat[:, 1])], dtype=np.uint64)
         print("scan", name)
+    # one-index-per-pixel methods at BASELINE's frame sizes (configs 2 and 4), hashed in C by this stub-free build: what SURVEY 8c recorded from a
+    # build with a stand-in <libavutil/eval.h> (tests/golden/scan_golden.json: 7680x4320 zigzag 5107222c372da523) is reproduced without one
+    sm.ref_scan_fnv1a.restype = C.c_ulonglong
+    sm.ref_scan_fnv1a.argtypes = [C.c_int, st, st]
+    frames = [(3840, 2160), (7680, 4320), (2160, 3840), (1920, 1080), (256, 256)]
+    out["fnv1a_sizes"] = np.array(frames)
+    for m, name in enumerate(SCAN_METHODS[:3]):
+        for (w, h) in frames:
+            out[f"{name}_{w}x{h}_fnv1a"] = np.array([sm.ref_scan_fnv1a(m, w, h)], dtype=np.uint64)
+        print("scan fnv1a", name, ["%016x" % int(out[f"{name}_{w}x{h}_fnv1a"][0]) for (w, h) in frames])
     # precomputed methods: owner index per pixel and the per-index coordinate order
     for which, name, args in ((0, "radial", None), (1, "iradial", None), (0, "radial_floor", b"floor"), (1, "iradial_ceil", b"upward")):
         for (w, h) in small + [(640, 480), (1920, 1080)]:

@@ -137,15 +137,39 @@ def test_linearity_full_size(gpu):
 
 
 def test_zigzag_bit_exact(gpu, scan_golden):
+    """scan/scan_methods.c:69-115 on the device, bit for bit: the survey's hashes, and the ones tests/golden/make_ref_fixtures.py takes from the
+    reference's scan_methods.c compiled WITHOUT a stand-in header (ref_scan.npz *_fnv1a: BASELINE's 3840x2160 and 7680x4320 among them)"""
+    import os
     from dspfun_amd import _lib
     L = _lib.load()
-    for key, want in scan_golden["zigzag_fnv"].items():
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_scan.npz"))
+    want_by_size = dict(scan_golden["zigzag_fnv"])
+    for (w, h) in fx["fnv1a_sizes"]:
+        v = "%016x" % int(fx[f"zigzag_{w}x{h}_fnv1a"][0])
+        assert want_by_size.setdefault(f"{w}x{h}", v) == v, (w, h)          # where both exist they agree
+    for key, want in want_by_size.items():
         w, h = [int(v) for v in key.split("x")]
         lin = gpu.zeros(w * h, dtype=gpu.int32, device="cuda:0")
         assert L.dspfft_scan_zigzag(lin.data_ptr(), w, h, 0, w * h, None) == 0
         gpu.cuda.synchronize()
         a = lin.cpu().numpy().view(np.uint32).astype(np.uint64)
         assert "%016x" % ol.lib().oracle_fnv1a64_u64(a.ctypes.data, a.size) == want, key
+
+
+def test_horizontal_vertical_zigzag_orders_at_8k(gpu):
+    """the one-index-per-pixel scan orders at 7680 x 4320 and 3840 x 2160 by the general device generator (dspfft_scan_coords), against the
+    hashes of the reference's scan_methods.c compiled without a stand-in header (ref_scan.npz *_fnv1a)"""
+    import os
+    from dspfun_amd import _lib
+    L = _lib.load()
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_scan.npz"))
+    for m, name in enumerate(("horizontal", "vertical", "zigzag")):
+        for (w, h) in ((7680, 4320), (3840, 2160)):
+            lin = gpu.zeros(w * h, dtype=gpu.int32, device="cuda:0")
+            assert L.dspfft_scan_coords(lin.data_ptr(), m, w, h, 0, w * h, None) == 0
+            gpu.cuda.synchronize()
+            a = lin.cpu().numpy().view(np.uint32).astype(np.uint64)
+            assert "%016x" % ol.lib().oracle_fnv1a64_u64(a.ctypes.data, a.size) == "%016x" % int(fx[f"{name}_{w}x{h}_fnv1a"][0]), (name, w, h)
 
 
 def test_scan_frames_c4_like(gpu):

@@ -119,6 +119,18 @@ def test_device_kernels_equal_the_reference_through_the_emulation(fx):
                 assert np.array_equal(_dev(L, L.dspfft_scan_owner_index, w * h, m, w, h), own), key
 
 
+@pytest.mark.parametrize("name", METHODS[:3])
+def test_one_index_per_pixel_orders_at_baseline_frame_sizes(fx, name):
+    """horizontal, vertical and zigzag at 3840 x 2160 (BASELINE config 2's frame) through the device kernels' per-element function (emulation),
+    hashed as the reference's compiled scan_methods.c hashed them (ref_scan.npz *_fnv1a); 7680 x 4320: tests/test_gpu_parity.py, on the GPU"""
+    import oracle_lib as ol
+    L = emul()
+    m = METHODS.index(name)
+    for (w, h) in [(3840, 2160), (256, 256)]:
+        lin = _dev(L, L.dspfft_scan_coords, w * h, m, w, h, 0, w * h).astype(np.uint64)
+        assert "%016x" % ol.lib().oracle_fnv1a64_u64(lin.ctypes.data, lin.size) == "%016x" % int(fx[f"{name}_{w}x{h}_fnv1a"][0]), (name, w, h)
+
+
 @pytest.mark.parametrize("ci", range(4))
 def test_magnitude_against_the_references_init_magnitude(fx, ci):
     """scan_methods.c:240-285 (qsort of the F/D-precision keys, then the grouping loop).  Distinct keys: the whole order is defined and
