@@ -71,25 +71,45 @@ def render(torch, parts, inverse=False, scale=1, padding=1, plane="real", rescal
     return frame
 
 
-# ---- the `.coeff` file (applybasis.c:383-390 header, :443 body; read back at :319-338) ----
+# ---- the `.coeff` file (applybasis.c:381-388 header, :443 body; read back at :319-338) ----
 # coords {unsigned long long w, h} followed by w*h*3 `complex intermediate` values in the loop order of :410-413 (k_h, k_w, n_h, n_w, channel).
-# `intermediate` depends on the build; this reader / writer uses double (INTERMEDIATE_PRECISION=D): 16 bytes per value.
-def write_coeff(path, parts_np):
+# `intermediate` depends on the build: applybasis/Makefile:1-2 builds INTERMEDIATE_PRECISION=L, so the files a default reference build
+# writes and reads hold `complex long double` -- 32 bytes a value on x86-64 (two 80-bit x87 numbers in 16-byte slots).  That layout is the
+# default here; "D" (16 bytes) and "F" (8) are the other builds' files.  A reader need not be told: the size of the file says which.
+COEFF_DTYPES = {"L": "clongdouble", "D": "complex128", "F": "complex64"}
+
+
+def _coeff_dtype(precision):
+    import numpy as np
+    dt = np.dtype(getattr(np, COEFF_DTYPES[precision]))
+    if precision == "L" and dt.itemsize != 32:
+        raise DspfftError("this platform's long double is not the 16-byte x87 format the reference's `.coeff` files hold")
+    return dt
+
+
+def write_coeff(path, parts_np, precision="L"):
+    """parts_np: complex [k_h][k_w][n_h][n_w][3] (the partial sums in loop order); precision: the INTERMEDIATE_PRECISION of the build that will read it"""
     import numpy as np
     kh, kw, nh, nw, c = parts_np.shape
     assert c == 3
     with open(path, "wb") as f:
         np.array([nw * kw, nh * kh], dtype=np.uint64).tofile(f)          # dumpsize = {N.w K.w, N.h K.h}
-        np.ascontiguousarray(parts_np, dtype=np.complex128).tofile(f)
+        np.ascontiguousarray(parts_np).astype(_coeff_dtype(precision)).tofile(f)
 
 
-def read_coeff(path):
-    """-> complex128 array [h][w][3] exactly as applybasis reads it back: `pixels[(y * insize.w + x) * 3 + j]`"""
+def read_coeff(path, precision=None):
+    """-> complex128 array [h][w][3] exactly as applybasis reads it back: `pixels[(y * insize.w + x) * 3 + j]`.  precision None: from the file's size"""
+    import os
     import numpy as np
     with open(path, "rb") as f:
         w, h = (int(v) for v in np.fromfile(f, dtype=np.uint64, count=2))
-        data = np.fromfile(f, dtype=np.complex128, count=w * h * 3)
-    if data.size != w * h * 3:
+        n = w * h * 3
+        if precision is None:
+            body = os.path.getsize(path) - 16
+            precision = {32 * n: "L", 16 * n: "D", 8 * n: "F"}.get(body) if n else None
+            if precision is None:
+                raise ValueError(f".coeff file of {w} x {h} values with a body of {body} bytes: no build of the reference writes that")
+        data = np.fromfile(f, dtype=_coeff_dtype(precision), count=n)
+    if data.size != n:
         raise ValueError("short .coeff file")
-    return data.reshape(h, w, 3)
-
+    return data.astype(np.complex128).reshape(h, w, 3)

@@ -111,6 +111,21 @@ void ref_basis(int f, long long k, long long n, unsigned long long N, int ortho,
 	complex_intermediate v = table[f](k, n, N, ortho);
 	*re = creall(v); *im = cimagl(v);
 }
+/* the `.coeff` file as applybasis.c:381-388 (header: coords dumpsize) and :443 (one fwrite of `complex_intermediate partsums[3]` per term) lay it out,
+   with the reference's own types at this build's INTERMEDIATE_PRECISION: vals[term][3][2] = (re, im) */
+#include <stdio.h>
+int ref_write_coeff(const char *path, unsigned long long w, unsigned long long h, const long double *vals, size_t nterms)
+{
+	coords dumpsize = {{w, h}};
+	FILE *df = fopen(path, "w");
+	if (!df || fwrite(&dumpsize, sizeof(dumpsize), 1, df) != 1) return 1;
+	for (size_t t = 0; t < nterms; t++) {
+		complex_intermediate partsums[3];
+		for (int j = 0; j < 3; j++) partsums[j] = vals[(t * 3 + j) * 2] + I * vals[(t * 3 + j) * 2 + 1];
+		if (fwrite(partsums, sizeof(partsums), 1, df) != 1) return 1;
+	}
+	return fclose(df);
+}
 /* the partial sums of applybasis.c:370-380,410-425; out[term][3] complex, terms in loop order */
 void ref_partsums(int f, int orthogonal, int inverse, coords insize, coords terms, coords partsum, offsets offset, const long double *pixels_, long double *out)
 {
@@ -532,6 +547,19 @@ def main():
             out[f"parts{i}_pix"] = pix
             out[f"parts{i}_out"] = o.astype(np.float64).reshape(K[1], K[0], N[1], N[0], 3, 2)
             print("partsums", parts[i])
+
+        # --- (4b) the `.coeff` file in the reference's default build (applybasis/Makefile:1-2: INTERMEDIATE_PRECISION=L: 32 bytes a value) ----
+        ab.ref_write_coeff.argtypes = [C.c_char_p, C.c_ulonglong, C.c_ulonglong, vp, C.c_size_t]
+        cw, chh = 4, 3
+        cv = rnd(0xD5F1700, cw * chh * 3 * 2).astype(LD) * LD(1e3) + LD(2) ** -60            # values that need more than a double's 53 bits
+        cpath = os.path.join(tmp, "ref.coeff")
+        assert ab.ref_write_coeff(cpath.encode(), cw, chh, np.ascontiguousarray(cv).ctypes.data, cw * chh) == 0
+        raw = np.fromfile(cpath, dtype=np.uint8)
+        # the six padding bytes of every x87 long double are whatever the stack held: zeroed here so that the fixture is reproducible
+        body = raw[16:].reshape(-1, 16).copy(); body[:, 10:] = 0
+        out["coeff_L_file"] = np.concatenate([raw[:16], body.ravel()])
+        out["coeff_L_values"] = cv.astype(np.float64).reshape(chh, cw, 3, 2)
+        print("coeff file", raw.size, "bytes")
 
         # --- (5) scan's `random` order: the permutation init_random draws with this libc's rand() ------------------------
         rn = build_random(tmp)

@@ -63,13 +63,16 @@ def test_forward_then_inverse_through_a_coeff_file_restores_the_image(gpu, tmp_p
     img = (ol.synth_f32(9, w * h * 3).reshape(h, w, 3) * 2 - 1).astype(np.float32)
     spec = ab.partsums_ex(gpu, gpu.from_numpy(img).cuda(), None, "dct2", True, (w, h), (1, 1), (w, h)).cpu().numpy()      # [h][w][1][1][3]
     path = tmp_path / "x.coeff"
-    ab.write_coeff(path, spec)
+    ab.write_coeff(path, spec)                                     # the default reference build's layout: complex long double (applybasis/Makefile:1-2)
     raw = open(path, "rb").read()
-    assert len(raw) == 16 + w * h * 3 * 16 and np.frombuffer(raw[:16], dtype=np.uint64).tolist() == [w, h]
+    assert len(raw) == 16 + w * h * 3 * 32 and np.frombuffer(raw[:16], dtype=np.uint64).tolist() == [w, h]
     back = ab.read_coeff(path)                                     # [h][w][3] complex128, the layout applybasis.c:326-331 reads
     assert np.array_equal(back, spec.reshape(h, w, 3).astype(np.complex128))
-    ab.write_coeff(tmp_path / "y.coeff", back.reshape(h, w, 1, 1, 3))
-    assert open(tmp_path / "y.coeff", "rb").read() == raw          # byte-exact round trip
+    ab.write_coeff(tmp_path / "y.coeff", back.reshape(h, w, 1, 1, 3), "D")          # an INTERMEDIATE_PRECISION=D build's file
+    rawd = open(tmp_path / "y.coeff", "rb").read()
+    assert len(rawd) == 16 + w * h * 3 * 16 and np.array_equal(ab.read_coeff(tmp_path / "y.coeff"), back)
+    ab.write_coeff(tmp_path / "z.coeff", ab.read_coeff(tmp_path / "y.coeff").reshape(h, w, 1, 1, 3), "D")
+    assert open(tmp_path / "z.coeff", "rb").read() == rawd         # byte-exact round trip
     pre, pim = np.ascontiguousarray(back.real, dtype=np.float32), np.ascontiguousarray(back.imag, dtype=np.float32)
     rec = ab.partsums_ex(gpu, gpu.from_numpy(pre).cuda(), gpu.from_numpy(pim).cuda(), "dct3", True, (w, h), (1, 1), (w, h)).cpu().numpy()
     # orthogonal DCT-II (sqrt2 on k != 0) followed by orthogonal DCT-III (x 2 on n = 0 ... sqrt2 otherwise): x (W H) / ... -> image x W H / 1
