@@ -7,8 +7,9 @@
  *   scan_dev in.{ppm,pf} out.pf [step] [method]
  *     method: a prefix of horizontal vertical zigzag row column diagonal mirror box ibox radial iradial (scan_methods.c:581-591),
  *             magnitude[:qfactor] (scan_methods.c:240-296), file:<path> (scan_methods.c:393-410, either serialisation), or
- *             random[:seed] (scan_methods.c:210-228: the permutation is drawn on the host with libc rand(), as the tool draws it),
- *             evalxy:<expr in x, y> or evali:<fx;fy in i, width, height> (scan_methods.c:186-201,333-391; host/expr_eval.h)
+ *             random[:seed] (scan_methods.c:210-228: the permutation is drawn on the host with libc rand(), as the tool draws it).
+ *             evalxy / evali (scan_methods.c:186-201,333-391) need libavutil's expression evaluator and are not mirrored: write the order
+ *             they would give to a file and pass file:<path>.
  * Output: the final `sum` image; on stderr the number of frames and max|sum - input| (0 up to rounding when the method visits
  * every pixel exactly once).
  */
@@ -67,12 +68,7 @@ int main(int argc, char *argv[])
 		DSP(dspfft_scan_magnitude_index(d_ids, d_coeffs, w, h, channels, q, d_mw, wb, &lim32, NULL));
 		HIP(hipFree(d_mw));
 		limit = lim32;
-	} else if (!strncmp(mname, "file:", 5) || !strncmp(mname, "random", 6) || !strncmp(mname, "evalxy:", 7) || !strncmp(mname, "evali:", 6)) {
-		if (!strncmp(mname, "evalxy:", 7)) {                                                     /* scan_methods.c:333-364: index = f(x, y) */
-			if (scan_order_evalxy(width, height, mname + 7, &fl)) { fprintf(stderr, "evalxy: bad expression, or no pixel selected: %s\n", mname + 7); return 1; }
-		} else if (!strncmp(mname, "evali:", 6)) {                                               /* :186-201,366-391: x = f(i, width, height); y = g(...) */
-			if (scan_order_evali(width, height, mname + 6, &fl)) { fprintf(stderr, "evali: bad expressions (want fx;fy): %s\n", mname + 6); return 1; }
-		} else
+	} else if (!strncmp(mname, "file:", 5) || !strncmp(mname, "random", 6)) {
 		if (mname[0] == 'r') {
 			const unsigned int seed = mname[6] == ':' ? (unsigned int)strtoul(mname + 7, NULL, 10) : (unsigned int)time(NULL);   /* scan_methods.c:216 */
 			if (scan_order_random(width, height, seed, &fl)) { fprintf(stderr, "cannot draw the random scan order\n"); return 1; }

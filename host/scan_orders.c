@@ -1,6 +1,5 @@
 /* scan_orders.c -- see scan_orders.h.  Each generator cites the reference lines it follows. */
 #include "scan_orders.h"
-#include "expr_eval.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -257,74 +256,6 @@ int scan_order_random(size_t w, size_t h, unsigned int seed, struct scan_order_l
 	out->limit = out->total = len;
 	out->max_interval = 1;
 	free(ctx);
-	return 0;
-}
-
-static int pre_to_list(struct pre *p, struct scan_order_list *out)
-{
-	out->limit = p->limit;
-	out->offset = malloc(sizeof(size_t) * (p->limit + 1));
-	if (!out->offset) return 1;
-	for (size_t i = 0; i < p->limit; i++) { out->offset[i] = out->total; out->total += p->intervals[i]; out->max_interval = umax(out->max_interval, p->intervals[i]); }
-	out->offset[p->limit] = out->total;
-	out->yx = malloc(sizeof(*out->yx) * (out->total + 1));
-	if (!out->yx) return 1;
-	for (size_t i = 0; i < p->limit; i++) if (p->intervals[i]) memcpy(out->yx + out->offset[i], p->scans[i], sizeof(*out->yx) * p->intervals[i]);
-	return 0;
-}
-
-int scan_order_evalxy(size_t w, size_t h, const char *args, struct scan_order_list *out)
-{
-	memset(out, 0, sizeof *out);
-	if (!args) return 1;                                                               /* scan_methods.c:334-335 */
-	const char *names[3] = {"x", "y", NULL};                                           /* :340 */
-	struct expr *e = expr_parse(args, names);
-	if (!e) return 1;
-	struct pre p = {0, NULL, NULL};
-	int rc = 1;
-	for (size_t y = 0; y < h; y++)                                                     /* :345-354 */
-		for (size_t x = 0; x < w; x++) {
-			const double v[2] = {(double)x, (double)y};
-			const double result = rint(expr_eval(e, v));
-			if (isnan(result) || isinf(result) || result < 0) continue;
-			if (!pre_add(&p, (size_t)result, x, y)) goto done;
-		}
-	if (!p.limit) goto done;                                                           /* :356-357 */
-	rc = pre_to_list(&p, out);
-done:
-	if (rc) scan_order_list_free(out);
-	pre_free(&p);
-	expr_free(e);
-	return rc;
-}
-
-int scan_order_evali(size_t w, size_t h, const char *args, struct scan_order_list *out)
-{
-	memset(out, 0, sizeof *out);
-	if (!args || !w || !h) return 1;
-	char *xs = strdup(args), *ys = xs ? strchr(xs, ';') : NULL;                         /* scan_methods.c:371-375: "fx;fy" */
-	if (!ys) { free(xs); return 1; }
-	*ys++ = 0;
-	const char *names[4] = {"i", "width", "height", NULL};                             /* :377 */
-	struct expr *ex = expr_parse(xs, names), *ey = ex ? expr_parse(ys, names) : NULL;
-	free(xs);
-	if (!ex || !ey) { expr_free(ex); expr_free(ey); return 1; }
-	const size_t len = w * h;
-	out->offset = malloc(sizeof(size_t) * (len + 1));
-	out->yx = malloc(sizeof(*out->yx) * (len + 1));
-	if (!out->offset || !out->yx) { expr_free(ex); expr_free(ey); scan_order_list_free(out); return 1; }
-	for (size_t i = 0; i < len; i++) {                                                 /* :186-201 */
-		const double v[3] = {(double)i, (double)w, (double)h};
-		double r = rint(expr_eval(ey, v));
-		out->yx[i][0] = (isnan(r) || isinf(r) || r < 0) ? 0 : (size_t)r % h;
-		r = rint(expr_eval(ex, v));
-		out->yx[i][1] = (isnan(r) || isinf(r) || r < 0) ? 0 : (size_t)r % w;
-		out->offset[i] = i;
-	}
-	out->offset[len] = len;
-	out->limit = out->total = len;
-	out->max_interval = 1;
-	expr_free(ex); expr_free(ey);
 	return 0;
 }
 

@@ -39,15 +39,6 @@ void scan_order_list_free(struct scan_order_list *l);
  * scan_order_read_file. */
 int scan_order_random(size_t w, size_t h, unsigned int seed, struct scan_order_list *out);
 
-/* The `evalxy` method (scan_methods.c:333-364): index = rint(f(x, y)) for every pixel, rows outermost; pixels whose value is NaN, infinite or
- * negative are left out; several pixels may share an index and indices may stay empty.  `evali` (:186-201,366-391): "fx;fy" with the
- * variables i, width, height: coordinate (rint(fy) % height, rint(fx) % width) of every index i < width * height (NaN / infinite / negative
- * values give 0) -- pixels may repeat or never appear.  The expressions are host/expr_eval.h's restatement of libavutil's published
- * language (libavutil itself is absent: see there).  Return 0 and fill *out like scan_order_read_file; 1 on a syntax error or an
- * evalxy expression that selects no pixel. */
-int scan_order_evalxy(size_t w, size_t h, const char *expr, struct scan_order_list *out);
-int scan_order_evali(size_t w, size_t h, const char *exprs, struct scan_order_list *out);
-
 /* scan_precomputed.c:122-153.  Return 0 on success. */
 int scan_order_serialize_coordinate(int method, size_t w, size_t h, FILE *f);
 int scan_order_serialize_index(int method, size_t w, size_t h, FILE *f);

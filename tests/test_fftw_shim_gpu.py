@@ -384,10 +384,7 @@ def test_random_geometries_on_host_pointers(fftw, seed):
 
 
 @pytest.mark.parametrize("method", ["horizontal", "vertical", "zigzag", "row", "column", "diagonal", "mirror", "box", "ibox", "radial", "iradial",
-                                    "magnitude", "magnitude:200", "file:coordinate", "file:index", "file:box",
-                                    # round 4: the expression methods (scan_methods.c:186-201,333-391; host/expr_eval.h).  Both visit every pixel once here:
-                                    # evalxy's index = x + y * 80 is the horizontal order, evali's is the vertical one of an 80 x 48 frame
-                                    "evalxy:x+y*80", "evalxy:bitand(x,y)*0 + hypot(x,y)", "evali:floor(i/height); mod(i,height)"])
+                                    "magnitude", "magnitude:200", "file:coordinate", "file:index", "file:box"])
 def test_scan_device_resident_harness_every_method(tmp_path, method):
     """host/scan_dev.c: scan's loop with every buffer and every scan order on the GPU.  The final sum equals
     the input for every method that visits each pixel once; box (shared pixels are added once per frame they appear in) is checked
@@ -454,17 +451,18 @@ def _read_pfs(path):
     return data.reshape(-1, vh, vw, 3), n
 
 
-@pytest.mark.parametrize("args,btype,xs,ys,pos,view,how", [
-    (["-s", "2"], 0, (2.0, 1.0), (2.0, 1.0), (0.0, 0.0), None, "fft"),                                # integer scale on the DCT-III grid
-    (["-s", "3/2x5/4", "-p", "3.5x1.25", "-v", "50x30"], 0, (3.0, 2.0), (5.0, 4.0), (3.5, 1.25), (50, 30), "fft"),   # rational scales with integer scaled lengths (72 x 45), a view, an offset
-    (["-s", "7/5x5/4", "-p", "3.5x1.25", "-v", "50x30"], 0, (7.0, 5.0), (5.0, 4.0), (3.5, 1.25), (50, 30), "czt"),   # 48 x 7/5 = 67.2 samples: off the DCT-III grid
-    (["-s", "1.7", "--basis", "centered"], 1, (1.7, 1.0), (1.7, 1.0), (0.0, 0.0), None, "czt"),
-    (["-s", "2", "--basis", "native", "-c", "-v", "40x20"], 2, (2.0, 1.0), (2.0, 1.0), None, (40, 20), None),
-    (["-s", "1.5", "--method", "gemm"], 0, (1.5, 1.0), (1.5, 1.0), (0.0, 0.0), None, "gemm"),          # the dense product, forced
+@pytest.mark.parametrize("btype,xs,ys,pos,view,method,how", [
+    (0, (2.0, 1.0), (2.0, 1.0), (0.0, 0.0), None, "auto", "fft"),                     # integer scale on the DCT-III grid
+    (0, (3.0, 2.0), (5.0, 4.0), (3.5, 1.25), (50, 30), "auto", "fft"),                # rational scales with integer scaled lengths (72 x 45), a view, an offset
+    (0, (7.0, 5.0), (5.0, 4.0), (3.5, 1.25), (50, 30), "auto", "czt"),                # 48 x 7/5 = 67.2 samples: off the DCT-III grid
+    (1, (1.7, 1.0), (1.7, 1.0), (0.0, 0.0), None, "auto", "czt"),
+    (2, (2.0, 1.0), (2.0, 1.0), (28.0, 26.0), (40, 20), "auto", None),                # a centred view: ((96 - 40) / 2, (72 - 20) / 2)
+    (0, (1.5, 1.0), (1.5, 1.0), (0.0, 0.0), None, "gemm", "gemm"),                    # the dense product, forced
 ])
-def test_zoom_harness(tmp_path, args, btype, xs, ys, pos, view, how):
-    """zoom/zoom.c:263-375 through the C harness (host/zoom_gpu.c): fftw(plan_many_r2r) REDFT10^2 on the host buffer as the tool calls it, the
-    option handling of zoom.c:268-298, then a frame by whichever of the three device paths applies -- against the f64 restatement"""
+def test_zoom_harness(tmp_path, btype, xs, ys, pos, view, method, how):
+    """zoom/zoom.c:263-265,347-375 through the C harness (host/zoom_gpu.c): fftw(plan_many_r2r) REDFT10^2 on the host buffer as the tool calls
+    it, then one frame by whichever of the three device paths applies -- against the f64 restatement.  The frame's geometry is passed as numbers
+    (the tool's option handling is not part of the path)"""
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
     w, h = 48, 36
     x = ol.synth_f32(4321, w * h * 3).reshape(h, w, 3)
@@ -472,34 +470,12 @@ def test_zoom_harness(tmp_path, args, btype, xs, ys, pos, view, how):
     with open(src, "wb") as f:
         f.write(b"PF\n%d %d\n-1.0\n" % (w, h)); f.write(x.astype(np.float32).tobytes())
     out = tmp_path / "out.raw"
-    r = subprocess.run([os.path.join(ROOT, "host", "zoom_gpu")] + args + [str(src), str(out)], stderr=subprocess.PIPE, check=True)
-    frames, n = _read_pfs(out)
-    assert n == 1 and frames.shape[0] == 1
     vw, vh = view if view else (int(w * xs[0] / xs[1]), int(h * ys[0] / ys[1]))           # zoom.c:286-289
-    if pos is None:                                                                        # -c (zoom.c:296-298)
-        pos = ((w * xs[0] / xs[1] - vw) / 2, (h * ys[0] / ys[1] - vh) / 2)
-    assert frames.shape[1:] == (vh, vw, 3)
+    args = [str(src), str(out), str(btype), repr(xs[0]), repr(xs[1]), repr(ys[0]), repr(ys[1]), repr(pos[0]), repr(pos[1]), str(vw), str(vh), method]
+    r = subprocess.run([os.path.join(ROOT, "host", "zoom_gpu")] + args, stderr=subprocess.PIPE, check=True)
+    frames, n = _read_pfs(out)
+    assert n == 1 and frames.shape == (1, vh, vw, 3)
     if how:
         assert (" by " + how).encode() in r.stderr, r.stderr
     ref = _zoom_oracle(x, btype, xs, ys, pos[0], pos[1], vw, vh)
     assert np.abs(frames[0] - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
-
-
-def test_zoom_harness_animation(tmp_path):
-    """-n frames with -S / -x expressions (zoom.c:320-345): every frame against the restatement at that frame's scale and position; the
-    expression language is host/expr_eval.c's restatement of libavutil's (variables i n x y xs ys w h vw vh)"""
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
-    w, h = 40, 30
-    x = ol.synth_f32(99, w * h * 3).reshape(h, w, 3)
-    src = tmp_path / "in.pf"
-    with open(src, "wb") as f:
-        f.write(b"PF\n%d %d\n-1.0\n" % (w, h)); f.write(x.astype(np.float32).tobytes())
-    out = tmp_path / "anim.raw"
-    subprocess.check_call([os.path.join(ROOT, "host", "zoom_gpu"), "-v", "64x48", "-n", "4", "-S", "1+i/2", "-x", "2*i", "-y", "vh/16*i", str(src), str(out)],
-                          stderr=subprocess.DEVNULL)
-    frames, n = _read_pfs(out)
-    assert n == 4 and frames.shape == (4, 48, 64, 3)
-    for i in range(4):
-        s = 1 + i / 2
-        ref = _zoom_oracle(x, 0, (s, 1.0), (s, 1.0), 2.0 * i, 48 / 16 * i, 64, 48)
-        assert np.abs(frames[i] - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), i

@@ -208,81 +208,3 @@ def test_random_order_is_the_references_permutation(so):
         assert np.array_equal(yx[:, 0] * np.uint64(w) + yx[:, 1], perm)
         assert sorted(perm.tolist()) == list(range(w * h))
         so.scan_order_list_free(C.byref(lst))
-
-
-# ---- evalxy / evali (scan_methods.c:186-201,333-391): libavutil's expression language restated (host/expr_eval.h; libavutil itself is
-# absent, so the language is checked against Python's arithmetic, scan's integer rules against scan_methods.c's text) ----
-def _bind_eval(so):
-    so.scan_order_evalxy.argtypes = [C.c_size_t, C.c_size_t, C.c_char_p, C.POINTER(_OrderList)]
-    so.scan_order_evali.argtypes = [C.c_size_t, C.c_size_t, C.c_char_p, C.POINTER(_OrderList)]
-    so.scan_order_list_free.argtypes = [C.POINTER(_OrderList)]
-
-
-def _as_lists(lst):
-    return [[(int(lst.yx[k][0]), int(lst.yx[k][1])) for k in range(lst.offset[i], lst.offset[i + 1])] for i in range(lst.limit)]
-
-
-@pytest.mark.parametrize("expr,fn", [
-    ("bitand(x,y)", lambda x, y: x & y),                                   # scan/README.md:105
-    ("x+y*16", lambda x, y: x + y * 16),
-    ("hypot(x,y)", lambda x, y: np.hypot(x, y)),
-    ("if(gt(x,y), x-y, -1)", lambda x, y: x - y if x > y else -1),          # negative values leave the pixel out
-    ("mod(x*3+y, 7) + 2^2 - -1", lambda x, y: (x * 3 + y) % 7 + 5),
-    ("max(x,y)*1k/1000 + floor(y/2)", lambda x, y: max(x, y) + y // 2),
-    ("st(0, x*y); ld(0) + 1", lambda x, y: x * y + 1),
-    ("sqrt(x*x+y*y) / 0", lambda x, y: float("inf") if (x or y) else float("nan")),      # inf / NaN: left out -> only error if nothing remains
-])
-def test_evalxy_orders(so, expr, fn):
-    _bind_eval(so)
-    w, h = 16, 9
-    lst = _OrderList()
-    rc = so.scan_order_evalxy(w, h, expr.encode(), C.byref(lst))
-    want = {}
-    for y in range(h):
-        for x in range(w):
-            v = fn(x, y)
-            r = np.rint(v)
-            if np.isnan(r) or np.isinf(r) or r < 0:
-                continue
-            want.setdefault(int(r), []).append((y, x))
-    if not want:
-        assert rc == 1                                                  # scan_methods.c:356-357: no pixel selected
-        return
-    assert rc == 0
-    got = _as_lists(lst)
-    assert lst.limit == max(want) + 1
-    for i, coords in enumerate(got):
-        assert coords == want.get(i, [])                                # rows outermost within an index (scan_methods.c:345-354)
-    so.scan_order_list_free(C.byref(lst))
-
-
-def test_evali_readme_example_is_the_vertical_order(so):
-    """scan/README.md:109 `mod(i,height); floor(i/height)`: x = i mod height ... read literally: fx = mod(i, height), fy = floor(i / height)"""
-    _bind_eval(so)
-    w, h = 12, 12
-    lst = _OrderList()
-    assert so.scan_order_evali(w, h, b"mod(i,height); floor(i/height)", C.byref(lst)) == 0
-    assert lst.limit == w * h and lst.max_interval == 1
-    got = _as_lists(lst)
-    assert got == [[((i // h) % h, (i % h) % w)] for i in range(w * h)]
-    so.scan_order_list_free(C.byref(lst))
-    # values that are negative, NaN or infinite give coordinate 0 (scan_methods.c:190-200); larger ones wrap modulo the extent
-    assert so.scan_order_evali(5, 4, b"i*7 - 3; log(i-2)", C.byref(lst)) == 0
-    got = _as_lists(lst)
-    for i in range(20):
-        x = i * 7 - 3
-        wx = 0 if x < 0 else x % 5
-        yv = np.log(i - 2) if i > 2 else float("nan") if i < 2 else float("-inf")
-        r = np.rint(yv)
-        wy = 0 if (np.isnan(r) or np.isinf(r) or r < 0) else int(r) % 4
-        assert got[i] == [(wy, wx)]
-    so.scan_order_list_free(C.byref(lst))
-
-
-def test_eval_syntax_errors_are_refused(so):
-    _bind_eval(so)
-    lst = _OrderList()
-    for bad in (b"x +", b"foo(x)", b"(x", b"x y", b"random(0)", b""):
-        assert so.scan_order_evalxy(4, 4, bad, C.byref(lst)) == 1
-    for bad in (b"i", b"i; ", b"i; j"):
-        assert so.scan_order_evali(4, 4, bad, C.byref(lst)) == 1
