@@ -79,8 +79,25 @@ FastDiv make_div(uint32_t d)
 	FastDiv f; f.d = d; f.mul = d >= 2 ? (uint32_t)((((uint64_t)1 << 32) + d - 1) / d) : 0; return f;
 }
 
-// tuning overrides for experiments (read at plan time; 0 = use the built-in choice)
-int env_int(const char *name) { const char *e = getenv(name); return e ? atoi(e) : 0; }
+// Tuning overrides for experiments and A/B runs (0 / unset = the built-in choice).  A plan reads the environment ONCE: plan_finish() takes a
+// snapshot of every planner switch (EnvScope) and the planner consults only that, so a plan is made under one consistent set of values
+// whatever other threads do meanwhile.  (The snapshot lives in the planning thread; execute-time switches are read where they act.)
+const char *const kPlanEnv[] = {"DSPFFT_JIT", "DSPFFT_JIT_TUNE", "DSPFFT_NO_TINY", "DSPFFT_ROW_LPW", "DSPFFT_ROW_THREADS", "DSPFFT_COL_K", "DSPFFT_COL_THREADS",
+                                "DSPFFT_DENSE_STAGED", "DSPFFT_NO_SPLIT", "DSPFFT_FORCE_SPLIT", "DSPFFT_NO_BLOCK", "DSPFFT_BLOCK_G", "DSPFFT_NO_BLUESTEIN"};
+constexpr int kNPlanEnv = (int)(sizeof kPlanEnv / sizeof kPlanEnv[0]);
+thread_local const int *t_plan_env = nullptr;
+struct EnvScope {
+	int v[kNPlanEnv];
+	const int *prev;
+	EnvScope() { for (int i = 0; i < kNPlanEnv; i++) { const char *e = getenv(kPlanEnv[i]); v[i] = e ? atoi(e) : 0; } prev = t_plan_env; t_plan_env = v; }
+	~EnvScope() { t_plan_env = prev; }
+};
+int env_int(const char *name)
+{
+	if (t_plan_env) for (int i = 0; i < kNPlanEnv; i++) if (!strcmp(name, kPlanEnv[i])) return t_plan_env[i];
+	const char *e = getenv(name);
+	return e ? atoi(e) : 0;
+}
 
 struct Tables {
 	void *T = nullptr, *W = nullptr, *pos = nullptr, *cosTab = nullptr;
@@ -260,8 +277,7 @@ void host_fft(std::vector<cld> &x)
 // DSPFFT_NO_BLUESTEIN=1 (plan time) disables the path (the O(N^2) DENSE kernel takes over; used by its tests).
 int blue_length(int lo, FftDesc &F, std::vector<uint32_t> &pos)
 {
-	const char *e = getenv("DSPFFT_NO_BLUESTEIN");
-	if (e && *e == '1') return 0;
+	if (env_int("DSPFFT_NO_BLUESTEIN") == 1) return 0;
 	int best = 0; long long bestcost = 0;
 	for (int M = lo; M <= lo + lo / 3 + 16; M++) {
 		int r = M;
@@ -345,7 +361,9 @@ std::string library_dir()
 }
 // DSPFFT_JIT=1 forces it on, =2 off; otherwise the planning effort the caller asked for decides (dspfft_set_plan_effort: the FFTW
 // shim passes FFTW_MEASURE / PATIENT / EXHAUSTIVE on as "this plan will be executed many times", FFTW_ESTIMATE as "plan fast")
-int g_plan_effort = 0;
+// planning effort of the plans THIS THREAD makes next (dspfft_set_plan_effort): thread-local, so that the FFTW shim's set / plan / restore around one
+// fftw(plan_many_r2r) call (fftw_shim.hip make_plan) cannot leak into a plan another thread is making
+thread_local int g_plan_effort = 0;
 bool jit_enabled()
 {
 	const int e = env_int("DSPFFT_JIT");
@@ -967,6 +985,7 @@ const std::vector<Pass> &pick_passes(const dspfft_plan_s *pl, const void *in, co
 
 static int plan_finish(dspfft_plan_s *pl, dspfft_plan *plan, bool first_axis_first)
 {
+	EnvScope env;                 // the planner's switches, read once for this plan
 	size_t samples = 1;
 	pl->howmany = 1;
 	for (const Dim &b : pl->batches) { samples *= (size_t)b.n; pl->howmany *= b.n; }

@@ -70,7 +70,8 @@ Shim *make_plan(int rank, const int *n, int howmany, void *in, const int *inembe
 	Shim *s = new Shim();
 	s->es = f64 ? sizeof(double) : sizeof(float); s->h_in = in; s->h_out = out;
 	// FFTW_ESTIMATE = plan fast; FFTW_MEASURE / PATIENT / EXHAUSTIVE (scan.c:359, motion.c:93-103) = this plan will run many times:
-	// frame sizes without a listed specialised kernel get one compiled now (dspfft_set_plan_effort)
+	// frame sizes without a listed specialised kernel get one compiled now (dspfft_set_plan_effort: the effort is the calling thread's own state,
+	// set and restored around this one plan -- concurrent planning from other threads is not affected)
 	const int effort_before = dspfft_get_plan_effort();
 	dspfft_set_plan_effort((flags & FFTW_ESTIMATE) ? 0 : (flags & (FFTW_PATIENT | FFTW_EXHAUSTIVE)) ? 2 : 1);
 	// fftw_ (double) plans compute in double on the device, as the reference's default build does on the CPU

@@ -6,6 +6,33 @@ from . import _lib
 from .engine import Plan, DspfftError, REDFT10
 
 INTERPOLATED, CENTERED, NATIVE = 0, 1, 2     # zoom/zoom.c:20-26
+CACHE_PLANS = 4       # frame plans kept per path: an animated zoom (a new scale every frame) would otherwise keep a plan and a frame-sized work
+                      # buffer (about 100 MB at 1080p -> 4K) alive per frame; the least recently used one is destroyed
+
+
+class _PlanCache:
+    """key -> (handle, work) or None ("does not apply"), at most CACHE_PLANS live handles, least recently used destroyed first"""
+
+    def __init__(self, destroy):
+        self.destroy, self.d = destroy, {}
+
+    def get(self, key, make):
+        if key in self.d:
+            self.d[key] = self.d.pop(key)                  # most recently used last
+            return self.d[key]
+        v = self.d[key] = make()
+        live = [k for k, e in self.d.items() if e is not None]
+        for k in live[:max(0, len(live) - CACHE_PLANS)]:
+            self.destroy(self.d.pop(k)[0])
+        for k in [k for k, e in self.d.items() if e is None][:-64]:      # (the "does not apply" marks hold nothing; bounded all the same)
+            del self.d[k]
+        return v
+
+    def clear(self):
+        for e in self.d.values():
+            if e is not None:
+                self.destroy(e[0])
+        self.d = {}
 
 
 class Zoom:
@@ -22,20 +49,20 @@ class Zoom:
     def _frame_fft(self, vw, vh, xscale, yscale, vx, vy, basis_type):
         key = (vw, vh, tuple(xscale), tuple(yscale), basis_type)
         if not hasattr(self, "_fft"):
-            self._fft = {}
-        if key not in self._fft:
+            self._fft = _PlanCache(self.lib.dspfft_zoomfft_destroy)
+
+        def make():
             z = C.c_void_p()
             rc = self.lib.dspfft_zoomfft_create(C.byref(z), self.w, self.h, basis_type, xscale[0], xscale[1], yscale[0], yscale[1], vw, vh)
             if rc == -2:
-                self._fft[key] = None              # this scale / basis / viewport keeps the dense product
-            elif rc:
+                return None                        # this scale / basis / viewport keeps the dense product
+            if rc:
                 raise DspfftError(self.lib.dspfft_zoomfft_last_error().decode())
-            else:
-                work = self.torch.empty(self.lib.dspfft_zoomfft_work_floats(z), dtype=self.torch.float32, device=self.coeffs.device)
-                self._fft[key] = (z, work)
-        if self._fft[key] is None:
+            return (z, self.torch.empty(self.lib.dspfft_zoomfft_work_floats(z), dtype=self.torch.float32, device=self.coeffs.device))
+        e = self._fft.get(key, make)
+        if e is None:
             return None
-        z, work = self._fft[key]
+        z, work = e
         out = self.torch.empty((vh, vw, 3), dtype=self.torch.float32, device=self.coeffs.device)
         if self.lib.dspfft_zoomfft_execute(z, self.coeffs.data_ptr(), float(vx), float(vy), out.data_ptr(), work.data_ptr(),
                                            self.torch.cuda.current_stream().cuda_stream):
@@ -47,20 +74,20 @@ class Zoom:
         listed convolution lengths"""
         key = (vw, vh, tuple(xscale), tuple(yscale), basis_type)
         if not hasattr(self, "_czt"):
-            self._czt = {}
-        if key not in self._czt:
+            self._czt = _PlanCache(self.lib.dspfft_zoomczt_destroy)
+
+        def make():
             z = C.c_void_p()
             rc = self.lib.dspfft_zoomczt_create(C.byref(z), self.w, self.h, basis_type, xscale[0], xscale[1], yscale[0], yscale[1], vw, vh)
             if rc == -2:
-                self._czt[key] = None
-            elif rc:
+                return None
+            if rc:
                 raise DspfftError(self.lib.dspfft_zoomfft_last_error().decode())
-            else:
-                work = self.torch.empty(self.lib.dspfft_zoomczt_work_floats(z), dtype=self.torch.float32, device=self.coeffs.device)
-                self._czt[key] = (z, work)
-        if self._czt[key] is None:
+            return (z, self.torch.empty(self.lib.dspfft_zoomczt_work_floats(z), dtype=self.torch.float32, device=self.coeffs.device))
+        e = self._czt.get(key, make)
+        if e is None:
             return None
-        z, work = self._czt[key]
+        z, work = e
         out = self.torch.empty((vh, vw, 3), dtype=self.torch.float32, device=self.coeffs.device)
         if self.lib.dspfft_zoomczt_execute(z, self.coeffs.data_ptr(), float(vx), float(vy), out.data_ptr(), work.data_ptr(),
                                            self.torch.cuda.current_stream().cuda_stream):
@@ -69,12 +96,9 @@ class Zoom:
 
     def __del__(self):
         try:
-            for v in getattr(self, "_fft", {}).values():
-                if v is not None:
-                    self.lib.dspfft_zoomfft_destroy(v[0])
-            for v in getattr(self, "_czt", {}).values():
-                if v is not None:
-                    self.lib.dspfft_zoomczt_destroy(v[0])
+            for c in (getattr(self, "_fft", None), getattr(self, "_czt", None)):
+                if c is not None:
+                    c.clear()
         except Exception:
             pass
 

@@ -177,7 +177,7 @@ int dspfft_execute_masked_accumulate_f64(dspfft_plan plan, const double *d_in, d
  * {D/8,8HW,8HW},{H/8,8W,8W},{W/8,8,8}.  rank 1..3, howmany_rank 0..6; f64 != 0 selects double samples.  Lengths up to
  * 32 run one line per thread in registers. */
 typedef struct { int n; int is; int os; } dspfft_iodim;
-/* Planning effort for the plans created after the call (per process, like fftw's planner state; plans already made keep theirs).
+/* Planning effort for the plans the CALLING THREAD creates after the call (thread-local; plans already made keep theirs).
  * 0 (default): a frame size without a compile-time-specialised kernel (spec_list.h) runs on the runtime-geometry kernels.
  * > 0: such sizes get RowSpecT / ColSpecT kernels COMPILED AT PLAN TIME (hiprtc: about a second per new size, then cached in
  * $DSPFFT_JIT_CACHE or ~/.cache/dspfft-jit) and run 1.3-1.8x faster from then on.

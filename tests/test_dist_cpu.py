@@ -179,6 +179,44 @@ def test_channel_sharded_scan(world):
         assert max(errs) < 1e-5, (rank, errs)
 
 
+def _scan_c4_worker(rank, world, port, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from emul_lib import emul
+        from bench_scan_c4 import scan_c4
+        q.put((rank, scan_c4(torch, dist, torch.device("cpu"), rank, world, size=(40, 24), step=97, lib=emul())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_scan_c4_bench_path_on_four_ranks():
+    """tools/bench_scan_c4.scan_c4 -- the function bench.py calls for its `scan_c4` object, barriers, all_reduce of the time and final gather
+    included -- under four gloo ranks on a small frame with the emulation library: the driver's first `bench.py --gpus 4` is then not the first
+    time this code runs with more than one rank"""
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_scan_c4_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        o = res[rank]
+        assert o["frames"] == -(-40 * 24 // 97) and o["planes_per_rank"] == [1, 1, 1, 0] and o["ranks_with_a_plane"] == 3
+        assert o["scaling_efficiency_ceiling"] == 0.75 and o["max_abs_final_sum_minus_input"] < 5e-6 and o["ms_per_frame"] > 0
+        assert "planar" in o["layout"]
+    assert len({res[r]["ms_per_frame"] for r in range(world)}) == 1          # the MAX over ranks, agreed by all_reduce
+
+
 def test_x_pass_launches_per_piece():
     """one x-pass launch per piece for all full blocks (a third batch level of the row pass) + at most one for a short last block,
     whatever the number of ranks (round 3: one per rank)"""

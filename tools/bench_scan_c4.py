@@ -15,17 +15,23 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 W, H, C, STEP = 7680, 4320, 3, 1 << 20
 
 
-def scan_c4(torch, dist, dev, rank, world):
+def scan_c4(torch, dist, dev, rank, world, size=(W, H), step=STEP, lib=None):
+    """size, step, lib: the CPU test of this very function (tests/test_dist_cpu.py: four gloo ranks, a small frame, the emulation library) --
+    bench.py and the script below use the defaults"""
     from dspfun_amd.dist import ChannelShardedScan
+    W, H = size
     g = torch.Generator(device=dev); g.manual_seed(0xD5F0004)
     img = torch.rand((H, W, C), device=dev, generator=g)
-    eng = ChannelShardedScan(img, STEP)
+    eng = ChannelShardedScan(img, step, lib=lib)
+    on_gpu = torch.device(dev).type == "cuda"
 
     def barrier():
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     eng.warm(); eng.warm()          # untimed: the step's kernels loaded (a frame id nobody owns adds zeros)
     barrier()
@@ -42,7 +48,7 @@ def scan_c4(torch, dist, dev, rank, world):
     busy = min(C, world)
     samples = W * H * C
     ms = dt / eng.nframes * 1e3
-    return {"workload": "scan zigzag progressive reconstruct of 7680x4320 RGB, step 2^20 (BASELINE configs[3]), colour planes over the ranks",
+    return {"workload": f"scan zigzag progressive reconstruct of {W}x{H} RGB, step {step} (BASELINE configs[3]: 7680x4320, 2^20), colour planes over the ranks",
             "frames": eng.nframes, "untimed_warm_steps": 2, "ms_per_frame": round(ms, 4), "frames_per_s": round(eng.nframes / dt, 1),
             "algorithmic_GBps_total": round(samples * 12 / ms / 1e6, 1), "frac_of_8TBps_per_busy_gpu": round(samples * 12 / ms / 1e6 / 8000 / busy, 4),
             "planes_per_rank": [len([z for z in range(C) if z % world == r]) for r in range(world)], "ranks_with_a_plane": busy,
