@@ -163,6 +163,18 @@ class SlabDCT3D:
             return None                             # one rank: forward() / inverse() alias recv to send
         return dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group, async_op=True)
 
+    def exchange_alone(self, like):
+        """the P all-to-alls of one forward() (equally of one inverse()) with no pass beside them and each waited for: what the bench derives the
+        exchange time and the xGMI fraction from.  `like`: any tensor on this rank's device.  Returns the bytes this rank sends to
+        OTHER ranks in them (its own piece of every all-to-all stays local)."""
+        send = self._buf("send", like)
+        recv = send if self.G == 1 else self._buf("recv", like)
+        for p in range(self.P):
+            w = self._exchange(send[p], recv[p])
+            if w is not None:
+                w.wait()
+        return send.numel() * 4 * (self.G - 1) // self.G
+
     def forward(self, frames):
         """frames: [dl, h, w] f32 (this rank's frames, block_range(d, rank, G); overwritten).  Returns [d, hl, w] coefficients of
         REDFT10^3 (uniform range if requested) for this rank's rows block_range(h, rank, G)."""

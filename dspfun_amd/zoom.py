@@ -28,6 +28,12 @@ class _PlanCache:
             del self.d[k]
         return v
 
+    def __len__(self):
+        return len(self.d)
+
+    def values(self):
+        return self.d.values()
+
     def clear(self):
         for e in self.d.values():
             if e is not None:

@@ -46,7 +46,28 @@ def test_one_json_line_with_the_contract_keys():
     else:
         assert r["physical_frac"] is None
     e = d["fftw_abi_end_to_end"]
-    assert e["ms"] >= e["pcie_floor_ms"] * 0.8 and e["bytes_each_way"] == 3840 * 2160 * 3 * 4 and e["host_GBps_each_way"] > 1
+    assert e["bytes_each_way"] == 3840 * 2160 * 3 * 4 and e["link_GBps"]["h2d"] > 5 and e["link_GBps"]["d2h"] > 5
+    assert abs(e["link_floor_ms"] - (e["bytes_each_way"] / e["link_GBps"]["h2d"] + e["bytes_each_way"] / e["link_GBps"]["d2h"]) / 1e6) < 0.05 * e["link_floor_ms"]
+    assert e["ms"] >= 0.9 * e["link_floor_ms"] and abs(e["frac_of_link_floor"] - e["link_floor_ms"] / e["ms"]) < 2e-3
+    assert abs(e["host_GBps_over_both_transfers"] - 2 * e["bytes_each_way"] / e["ms"] / 1e6) < 0.2
+    # round 5: SURVEY 8d's per-frame latency (median and minimum over >= 50 event-bracketed pairs), the stated target and the declared cap
+    f = d["frame_latency_ms"]
+    assert f["pairs_timed"] >= 50 and 0 < f["min"] <= f["median"] < 5.0
+    assert f["median"] * 1e-3 >= 3840 * 2160 * 48 / 8e12                      # not faster than the roofline
+    t = d["target"]
+    assert t["roundtrip_frac_of_hbm_roofline"] == 0.70 and t["declared_cap"] == 0.366
+    assert abs(t["frac_of_declared_cap"] - d["roundtrip_frac_of_hbm_roofline"] / 0.366) < 2e-3
+
+
+def test_motion_volume_reports_the_exchange_fields_and_they_are_null_on_one_gpu():
+    """motion_c5.volume_3d carries exchange_ms / xgmi_frac (bytes sent per rank / exchange time / 7 x 76.8 GB/s); with one rank there is
+    no exchange and they are null"""
+    d = run_bench(["--gpus", "1", "--steps", "8", "--warmup", "2", "--no-scan", "--no-cpu-baseline", "--no-fftw-abi", "--no-single-stream"])
+    v = d["motion_c5"]["volume_3d"]
+    assert "error" not in v, v
+    for k in ("exchange_ms", "xgmi_GBps_sent_per_rank", "xgmi_frac"):
+        assert k in v and v[k] is None
+    assert v["exchanges_per_clip"] == 0 and "7 links" in v["exchange_note"]
 
 
 def test_watchdog_prints_the_headline_when_the_extras_do_not_finish():

@@ -50,6 +50,9 @@ def _worker(rank, world, port, d, h, w, chunks, q):
         # a second roundtrip through the same (reused) exchange buffers
         back2 = eng.inverse(eng.forward(torch.from_numpy(vol[lo:hi].copy())))
         err_b = max(err_b, float(np.abs(back2.numpy() - vol[lo:hi]).max()) if hi > lo else 0.0)
+        # the exchanges alone (what tools/bench_motion.py times for `exchange_ms` / `xgmi_frac`): every rank sends (G - 1) / G of its buffer
+        sent = eng.exchange_alone(mine)
+        assert sent == eng.P * eng.G * eng.dlp * eng.ch * eng.w * 4 * (world - 1) // world
         q.put((rank, float(err_f), float(err_b)))
     finally:
         dist.destroy_process_group()

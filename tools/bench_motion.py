@@ -25,6 +25,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 FRAMES, QUANT = 256, 20.0                                       # motion --quant 20 (motion/README.md)
 PLANES = ((1080, 1920), (540, 960), (540, 960))                 # Y, U, V of yuv420p (motion.c:61-67)
 SAMPLES = FRAMES * sum(h * w for h, w in PLANES)
+XGMI_PEAK_PER_GPU = 7 * 76.8e9                                  # MI355X: seven xGMI links per GPU, 76.8 GB/s per direction each
 
 
 def _barrier(torch, dist):
@@ -110,9 +111,25 @@ def volume_bench(torch, dist, dev, rank, world, reps, chunks=None):
         err = float(t.item())
     # bytes one rank sends per all-to-all: its share of the volume minus what stays local
     a2a = SAMPLES * 4 / world * (world - 1) / world if world > 1 else 0
+    # the exchange against the xGMI roofline.  The exchanges of ONE direction of the three planes (half of a roundtrip's), alone on
+    # the links and each waited for: time, bytes that left this rank, and the fraction of 7 links x 76.8 GB/s per direction they ran at.  With
+    # one rank there is no exchange: null.
+    exchange_ms = xgmi_gbps = xgmi_frac = None
+    if world > 1:
+        sent = [0]
+
+        def exchanges():
+            sent[0] = sum(e.exchange_alone(v) for e, v in zip(engs, vols))
+        dtx = _timed(torch, dist, dev, exchanges, max(2, reps))
+        exchange_ms = round(dtx * 1e3, 3)
+        xgmi_gbps = round(sent[0] / dtx / 1e9, 1)
+        xgmi_frac = round(sent[0] / dtx / XGMI_PEAK_PER_GPU, 4)
     return {"scaling": "strong", "frames_per_rank": engs[0].dl, "row_pieces": engs[0].P, "clips_timed": reps, "ms_per_clip": round(dt * 1e3, 3),
             "Msamples_per_s": round(SAMPLES / dt / 1e6), "algorithmic_GBps_per_gpu": round(SAMPLES * 16 / dt / 1e9 / world, 1),
             "alltoall_MB_sent_per_rank_per_exchange": round(a2a / 1e6, 1), "exchanges_per_clip": 2 * len(PLANES) if world > 1 else 0,
+            "exchange_ms": exchange_ms, "xgmi_GBps_sent_per_rank": xgmi_gbps, "xgmi_frac": xgmi_frac,
+            "exchange_note": "exchange_ms = the all-to-alls of ONE direction of the three planes (half of a clip's), alone on the links; xgmi_frac = bytes this rank "
+                             "sent to the other ranks / exchange time / (7 links x 76.8 GB/s per direction); null with one rank (no exchange)",
             "max_abs_roundtrip_error_0_255": err,
             "parallelism": f"slab x{world}: 2 all-to-alls per plane roundtrip (RCCL), pipelined in {engs[0].P} row pieces"}
 
