@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "dct_spec.h"
+#ifndef DSP_STAMP
+#define DSP_STAMP(i) ((void)0)
+#endif
 #include "motion_filter.h"
 
 namespace dspfft {
@@ -41,9 +44,11 @@ __device__ __forceinline__ void col_roundtrip_body(unsigned char *lds, const typ
 	long long bin, bout;
 	S::base(af, blockIdx.x, bin, bout);
 	bool hit = false;
+	DSP_STAMP(0);
 	S::template prefetch<KIND_REDFT10>(af, bin, tid, st, hit);
 	S::template phase<KIND_REDFT10, 0>(af, buf, bout, tid, st);
 	__syncthreads();
+	DSP_STAMP(1);
 	// The empty asm statements make the thread index (and, below, the inverse plan's table pointers) opaque at each
 	// phase: otherwise index arithmetic and twiddle loads of LATER phases are hoisted to the top of the kernel and
 	// stay live across every barrier (measured: 176 VGPRs -> 1 workgroup per CU; with them: <= 128).
@@ -51,6 +56,7 @@ __device__ __forceinline__ void col_roundtrip_body(unsigned char *lds, const typ
 		int t = tid; asm volatile("" : "+v"(t));
 		S::template phase<KIND_REDFT10, ph>(af, buf, bout, t, st);
 		__syncthreads();
+		DSP_STAMP(1 + ph);
 	});
 	unsigned long long mine = 0;
 	int t = tid; asm volatile("" : "+v"(t));
@@ -61,16 +67,19 @@ __device__ __forceinline__ void col_roundtrip_body(unsigned char *lds, const typ
 		if ((tid & 63) == 0 && m) atomicAdd(&wg_coded, m);
 	}
 	__syncthreads();
+	DSP_STAMP(10);
 	if (coded && tid == 0 && wg_coded) atomicAdd(coded, (unsigned long long)wg_coded);
 	asm volatile("" : "+v"(t));
 	S::mid_write(buf, t, st);
 	__syncthreads();
+	DSP_STAMP(11);
 	typename S::PA a2 = ai;
 	asm volatile("" : "+s"(a2.W), "+s"(a2.T), "+s"(a2.out));
 	static_for<1, S::NPH>([&](auto ph) {
 		asm volatile("" : "+v"(t));
 		S::template phase<KIND_REDFT01, ph>(a2, buf, bout, t, st);
 		if constexpr (ph + 1 < S::NPH) __syncthreads();
+		DSP_STAMP(12 + ph);
 	});
 }
 

@@ -13,6 +13,11 @@
 
 namespace dspfft {
 
+// tools/kstamp.hip defines DSP_STAMP to record the clock behind the barriers of one kernel at a time (per-phase durations); nothing in the product
+#ifndef DSP_STAMP
+#define DSP_STAMP(i) ((void)0)
+#endif
+
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 template <class K>
@@ -367,7 +372,9 @@ __global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_kerne
 	typedef typename S::Re Re;
 	constexpr int NPRE = (int)(sizeof(st.pre) / sizeof(Re));
 	Re cur[NPRE], diff[NPRE];
+	DSP_STAMP(0);
 	static_for<0, NPRE>([&](auto i) { const Re p = st.pre[i], q = st2.pre[i]; cur[i] = p + q; diff[i] = p - q; });
+	DSP_STAMP(1);
 	// a real loop (not two copies of the phases) whose only loop-carried values are the waiting line's samples: the compiler
 	// otherwise hoists the second transform's index arithmetic and twiddle loads above the first, or carries the last stage's
 	// butterfly registers around the loop, and keeps them live across every barrier (133 / 115 VGPRs: a resident workgroup fewer)
@@ -382,6 +389,7 @@ __global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_kerne
 		static_for<0, S::NPH>([&](auto ph) {
 			S::template phase<KIND, ph, decltype(w), true>(a, planes, bout, t, w);
 			__syncthreads();
+			DSP_STAMP(2 + rep * 8 + ph);
 		});
 		static_for<0, NPRE>([&](auto i) { cur[i] = diff[i]; });
 	}
@@ -403,6 +411,7 @@ __global__ void __launch_bounds__(S::T, S::WPE) col_half_kernel(const typename S
 		if (tid == 0) a.zflags[tile] = 0;
 		return;
 	}
+	DSP_STAMP(0);
 	S::template prefetch<KIND>(a, bin, h, tid, st, hit);
 	if (a.zflags && a.mask) {
 		const int nz = __syncthreads_or(hit);
@@ -413,6 +422,7 @@ __global__ void __launch_bounds__(S::T, S::WPE) col_half_kernel(const typename S
 		if (!S::template skip_phase<KIND>(a, ph)) {           // see col_spec_kernel
 			S::template phase<KIND, ph>(a, buf, bout, h, tid, st);
 			if (S::template barrier_after<KIND>(a, ph)) __syncthreads();
+			DSP_STAMP(1 + ph);
 		}
 	});
 }
