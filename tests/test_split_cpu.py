@@ -48,6 +48,21 @@ def test_forced_split_forward_inverse_vs_oracle(forced, h, w):
     assert np.abs(out - x).max() < 5e-6 and np.array_equal(co, keep)
 
 
+def test_forced_split_on_8k_wide_lines(forced):
+    """7680 x 3 lines (BASELINE config 4's rows) as row pairs of a split plan: the 1024-thread pair kernel's phases on the emulation"""
+    h, w, c = 512, 7680, 3
+    x = ol.synth_f32(0xD5F0004, h * w * c).reshape(h, w, c)
+    fwd = Plan.image(h, w, c, REDFT10, lib=emul())
+    inv = Plan.image(h, w, c, REDFT01, lib=emul()).set_scale(1.0 / (4 * w * h))
+    assert "ROW*2 N=7680" in fwd.describe() and "ROW*2 N=7680" in inv.describe()
+    ref = ol.dct2d_interleaved(x.astype(np.float64), REDFT10, impl="port", threads=4)
+    d = x.copy()
+    fwd.execute(d.ctypes.data)
+    assert relerr(d, ref) < TOL
+    inv.execute(d.ctypes.data)
+    assert np.abs(d - x).max() < 5e-6
+
+
 def test_split_and_plain_agree_and_fallbacks(forced):
     h, w, c = 512, 512, 3
     x = ol.synth_f32(7, h * w * c).reshape(h, w, c)
