@@ -415,13 +415,24 @@ struct RowSpecG {
 				}
 			}
 			if constexpr (KIND == KIND_REDFT10) {
-				// pixel x -> reordered sample n; Re index inside the (padded) channel plane
+				// pixel x = tid + i T -> reordered sample n = x / 2 (x even) or N - 1 - (x - 1) / 2 (x odd); Re index inside the (padded) channel plane.
+				// T is a multiple of 4, so a thread's pixels all have ITS parity: n walks from n0 in steps of +-T/2 and keeps its low bit, and only the
+				// first round can hold pixel 0.  (Round 5: the general form -- a parity select, a signed division by the sub-block length and a select +
+				// multiply for in_scale0 on every sample -- was 184 of this phase's 197 vector instructions on 7680 x 3 lines, where the phases run at
+				// the vector issue rate: profiles/r05_isa_row_pair.txt.)
+				static_assert(T % 4 == 0, "a thread's pixels share a parity and a low bit");
+				const unsigned odd = (unsigned)tid & 1u, n0 = odd ? (unsigned)(N - 1) - ((unsigned)tid >> 1) : ((unsigned)tid >> 1), low = n0 & 1u;
+				const int dn = odd ? -(T / 2) : (T / 2);
 				static_for<0, PIX_ROUNDS>([&](auto i) {
 					const int x = tid + i * T;
 					if ((i + 1) * T <= N || x < N) {
-						const int n = makhoul_dst(x, N);
-						const int f = 2 * padded(n >> 1) + (n & 1);
-						static_for<0, C>([&](auto c) { const Re v = st.pre[i * C + c]; pf[c * (2 * PL) + f] = (x == 0) ? v * a.in_scale0 : v; });
+						const unsigned ph_ = (unsigned)((int)n0 + i * dn) >> 1;
+						const unsigned f = 2u * (ph_ + (ph_ / (unsigned)SB) * (unsigned)PADC) + low;
+						static_for<0, C>([&](auto c) {
+							Re v = st.pre[i * C + c];
+							if constexpr (i == 0) { if (x == 0) v *= a.in_scale0; }
+							pf[c * (2 * PL) + f] = v;
+						});
 					}
 				});
 			} else {
@@ -496,15 +507,19 @@ struct RowSpecG {
 						return;
 					}
 				}
-				auto value = [&](int x) {
-					const int n = makhoul_dst(x, N);
+				// output pixel x = tid + i T reads reordered sample n (see phase 0 of REDFT10: n = n0 + i dn, the low bit of n and the parity of x are
+				// the thread's own): its sign (-1)^n and the alternating output sign fold into ONE factor per thread, out_scale0 touches round 0 only
+				static_assert(T % 4 == 0, "a thread's pixels share a parity and a low bit");
+				const unsigned odd = (unsigned)tid & 1u, n0 = odd ? (unsigned)(N - 1) - ((unsigned)tid >> 1) : ((unsigned)tid >> 1);
+				const int dn = odd ? -(T / 2) : (T / 2);
+				Re sg = (n0 & 1u) ? -a.scale : a.scale;
+				if (a.alt_out && odd) sg = -sg;                  // dspfft_plan_set_output_alternate; folds away in the plain instantiation
+				auto value = [&](auto i, int x) {
+					const int n = (int)n0 + i * dn;
 					Pix<C, Re> o;
-					Re sc = (x == 0) ? a.scale * a.out_scale0 : a.scale;
-					if (a.alt_out && (x & 1)) sc = -sc;          // dspfft_plan_set_output_alternate; folds away in the plain instantiation
-					static_for<0, C>([&](auto c) {
-						const Re f = pf[c * (2 * PL) + n];
-						o.v[c] = ((n & 1) ? -f : f) * sc;
-					});
+					Re sc = sg;
+					if constexpr (i == 0) { if (x == 0) sc *= a.out_scale0; }
+					static_for<0, C>([&](auto c) { o.v[c] = pf[c * (2 * PL) + n] * sc; });
 					return o;
 				};
 				if (a.accumulate) {
@@ -518,13 +533,16 @@ struct RowSpecG {
 					static_for<0, PIX_ROUNDS>([&](auto i) {
 						const int x = tid + i * T;
 						if ((i + 1) * T <= N || x < N) {
-							Pix<C, Re> o = value(x);
+							Pix<C, Re> o = value(i, x);
 							static_for<0, C>([&](auto c) { o.v[c] += old[i].v[c]; });
 							store_pix<C, Re>(a.out + bout + (long long)x * GS, o);
 						}
 					});
 				} else {
-					tloop<N, T>(tid, [&](int x) { store_pix<C, Re>(a.out + bout + (long long)x * GS, value(x)); });
+					static_for<0, PIX_ROUNDS>([&](auto i) {
+						const int x = tid + i * T;
+						if ((i + 1) * T <= N || x < N) store_pix<C, Re>(a.out + bout + (long long)x * GS, value(i, x));
+					});
 				}
 			}
 		}
