@@ -525,6 +525,148 @@ __global__ void ab_combine2_kernel(float *out, const float *P, int cplx, int Kh,
 	}
 }
 
+// ---- small partial-sum blocks (-P 8x8, 16x16 ...: applybasis/applybasis.c:410-431) in ONE launch (round 5) ----
+// With blocks of P x P pixels the two products above have an inner dimension of P: the generic GEMM runs them on its register-staged K < 32
+// path, writes the intermediate [j][(hp, kh)][nh][(tp, kw, nw)], and a third kernel re-reads it to interleave the result -- the result's bytes
+// cross HBM three times (0.41 ms for a 403 MB result: 0.98 TB/s, profiles/r05_applybasis_blocks.json).  The arithmetic is nothing (0.9 GFLOP);
+// what matters is writing the result once, in runs.  One workgroup owns block row nh and a 16 x 16 tile of basis functions (kh, kw) and walks the
+// row in tiles of 16 blocks:
+//   stage   the tile's pixels, P rows x 16 P pixels, into LDS (whole rows of the image: coalesced)
+//   A       T[kw][sh][c] = sum_sw Fw[kw][nw P + sw] pix[nh P + sh][nw P + sw][j],  c = 3 nw + j: per block a (16 kw x P) . (P x 3 P) product on the matrix cores, into LDS
+//   B       out[kh][kw][nh][c] = sum_sh Fh[kh][nh P + sh] T[kw][sh][c] on the matrix cores: v_mfma_f32_16x16x4_f32 tiles of 16 kh x 16 c, K = P in steps
+//           of 4 (A operand: the lane's basis value, kept in a register for the whole row; B operand: one LDS word), four kw per wave;
+//           the accumulator's four registers are four kh rows x 16 consecutive c = 128 contiguous bytes per row of the complex result -- stored as
+//           (re, im) pairs straight from the accumulator, no intermediate, no combine pass.
+// Complex bases (dft / idft): T and the accumulators in two parts; the imaginary pass of complex pixels (a .coeff input) adds i x the result in place.
+typedef float ab_f4 __attribute__((ext_vector_type(4)));
+// khspan: the workgroup walks `khspan` tiles of kh for its (nh, kw tile), so that T is computed once for all of them (16 x 16 blocks: phase A is 768
+// multiply-adds and as many LDS reads per thread, as long as the 98 KB one kh tile stores)
+template <int P, bool CPLX>
+__global__ void __launch_bounds__(256) ab_blocks_kernel(float *out, const float *pix, const float *Fw, const float *Fh, int w, int h, int Kw, int Kh, int Nw, int Nh, int as_imag, int khspan)
+{
+	constexpr int NB = 16, CT = NB * 3, XW = NB * P * 3, NC = CPLX ? 2 : 1, KS = P / 4;
+	extern __shared__ __attribute__((aligned(16))) float ab_lds[];
+	float *pixs = ab_lds;                               // [P][XW + 4]
+	float *Ts = ab_lds + P * (XW + 4);                  // [NC][16][P][CT]
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int nh = blockIdx.x, kwb = blockIdx.y * 16;
+	// phase B's A operands: A[i = lane & 15][k = lane >> 4] of K-step s = Fh[khb + i][nh P + 4 s + k]
+	float ah[NC][KS];
+	auto load_ah = [&](int khb) {
+		const int kh = khb + (lane & 15);
+		for (int s_ = 0; s_ < KS; s_++)
+			for (int part = 0; part < NC; part++)
+				ah[part][s_] = kh < Kh ? Fh[((size_t)part * Kh + kh) * h + (size_t)nh * P + 4 * s_ + (lane >> 4)] : 0.f;
+	};
+	const int kh_first = (int)blockIdx.z * khspan * 16, kh_end = kh_first + khspan * 16 < Kh ? kh_first + khspan * 16 : Kh;
+	if (khspan == 1) load_ah(kh_first);
+	// phase A on the matrix cores as well: per block, T[kw][(sh, j)] = Fw_blk (16 kw x P) . Pix_blk (P x 3 P): 16 x 16 tiles over the 3 P columns (sh, j)
+	// (24 columns of an 8 x 8 block fill one tile and a half), K = P in steps of 4; a wave takes four of the tile's sixteen blocks.  The lane's
+	// Fw values (A operands) are fetched before the pixels are waited for.
+	constexpr int NTA = (3 * P + 15) / 16, XWP = XW + 4;      // pixel rows padded by four floats: the 16 columns of a tile then fall on 16 banks
+	for (int nwb = 0; nwb < Nw; nwb += NB) {
+		float af[NC][4][KS];
+		for (int b = 0; b < 4; b++) {
+			const int nw = nwb + wave * 4 + b, kw = kwb + (lane & 15);
+			for (int s_ = 0; s_ < KS; s_++)
+				for (int part = 0; part < NC; part++)
+					af[part][b][s_] = (kw < Kw && nw < Nw) ? Fw[((size_t)part * Kw + kw) * w + (size_t)nw * P + 4 * s_ + (lane >> 4)] : 0.f;
+		}
+		const int nx = (Nw - nwb < NB ? Nw - nwb : NB) * P * 3;          // floats of this tile's pixel rows that exist
+		for (int e = tid; e < P * XW; e += 256) {
+			const int sh = e / XW, xo = e - sh * XW;
+			pixs[sh * XWP + xo] = xo < nx ? pix[((size_t)(nh * P + sh) * w + (size_t)nwb * P) * 3 + xo] : 0.f;
+		}
+		__syncthreads();
+#pragma unroll
+		for (int b = 0; b < 4; b++) {
+			const int nw_l = wave * 4 + b;
+#pragma unroll
+			for (int nt = 0; nt < NTA; nt++) {
+				const int q = 16 * nt + (lane & 15), sh = q / 3, jj = q - 3 * sh;      // this lane's column (sh, j) of the block's 3 P
+				const bool col = q < 3 * P;
+				ab_f4 tr = {0.f, 0.f, 0.f, 0.f}, ti = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+				for (int s_ = 0; s_ < KS; s_++) {
+					const float bv = col ? pixs[sh * XWP + (nw_l * P + 4 * s_ + (lane >> 4)) * 3 + jj] : 0.f;
+					tr = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][b][s_], bv, tr, 0, 0, 0);
+					if constexpr (CPLX) ti = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][b][s_], bv, ti, 0, 0, 0);
+				}
+				if (col) {
+#pragma unroll
+					for (int r = 0; r < 4; r++) {
+						const int kw_l = 4 * (lane >> 4) + r;
+						Ts[((size_t)kw_l * P + sh) * CT + nw_l * 3 + jj] = tr[r];
+						if constexpr (CPLX) Ts[(((size_t)16 + kw_l) * P + sh) * CT + nw_l * 3 + jj] = ti[r];
+					}
+				}
+			}
+		}
+		__syncthreads();
+		for (int khb = kh_first; khb < kh_end; khb += 16) {
+		if (khspan > 1) load_ah(khb);
+		for (int q = 0; q < 4; q++) {
+			const int kw_l = wave * 4 + q, kw = kwb + kw_l;
+			if (kw >= Kw) break;                                 // (uniform per wave)
+			for (int nt = 0; nt < CT / 16; nt++) {
+				ab_f4 re = {0.f, 0.f, 0.f, 0.f}, im = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+				for (int s_ = 0; s_ < KS; s_++) {
+					const float br = Ts[((size_t)kw_l * P + 4 * s_ + (lane >> 4)) * CT + 16 * nt + (lane & 15)];
+					re = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[0][s_], br, re, 0, 0, 0);
+					if constexpr (CPLX) {
+						const float bi = Ts[(((size_t)16 + kw_l) * P + 4 * s_ + (lane >> 4)) * CT + 16 * nt + (lane & 15)];
+						re = __builtin_amdgcn_mfma_f32_16x16x4f32(-ah[1][s_], bi, re, 0, 0, 0);
+						im = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[0][s_], bi, im, 0, 0, 0);
+						im = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[1][s_], br, im, 0, 0, 0);
+					}
+				}
+				const int c = nwb * 3 + 16 * nt + (lane & 15);
+				if (c < Nw * 3) {
+#pragma unroll
+					for (int r = 0; r < 4; r++) {
+						const int kh = khb + 4 * (lane >> 4) + r;
+						if (kh < Kh) {
+							float2 *o = reinterpret_cast<float2 *>(out) + (((size_t)kh * Kw + kw) * Nh + nh) * (size_t)Nw * 3 + c;
+							float2 v;
+							if (as_imag) { v = *o; v.x -= im[r]; v.y += re[r]; }      // + i (re + i im): the imaginary part of complex pixels
+							else { v.x = re[r]; v.y = im[r]; }
+							*o = v;
+						}
+					}
+				}
+			}
+		}
+		}
+		__syncthreads();
+	}
+}
+template <int P, bool CPLX>
+static int launch_ab_blocks(float *out, const float *pix, const float *Fw, const float *Fh, int w, int h, int Kw, int Kh, int Nw, int Nh, int as_imag, hipStream_t s)
+{
+	const size_t lds = ((size_t)P * (16 * P * 3 + 4) + (size_t)(CPLX ? 2 : 1) * 16 * P * 48) * sizeof(float);
+	static thread_local bool attr[32] = {};
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
+	if (lds > 48 * 1024 && !attr[dev]) {
+		if (hipFuncSetAttribute(reinterpret_cast<const void *>(ab_blocks_kernel<P, CPLX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -4;
+		attr[dev] = true;
+	}
+	// kh tiles per workgroup: all of them for 16 x 16 blocks (phase A weighs as much as a kh tile's stores: 1024^2 image, 64 x 64 terms 0.62 ms with one tile
+	// per workgroup, 0.36 with two, 0.255 with all four -- also where that leaves fewer workgroups than CUs: 512^2 0.168 / 0.115 ms), one for smaller blocks
+	const int ktiles = (Kh + 15) / 16;
+	static const int span_env = getenv("DSPFFT_AB_KHSPAN") ? atoi(getenv("DSPFFT_AB_KHSPAN")) : 0;      // experiments
+	const int khspan = span_env > 0 ? (span_env < ktiles ? span_env : ktiles) : (P >= 16 ? ktiles : 1);
+	hipLaunchKernelGGL((ab_blocks_kernel<P, CPLX>), dim3(Nh, (Kw + 15) / 16, (ktiles + khspan - 1) / khspan), dim3(256), lds, s, out, pix, Fw, Fh, w, h, Kw, Kh, Nw, Nh, as_imag, khspan);
+	return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+// which block sizes the one-launch kernel takes (square, 4 / 8 / 16 pixels); DSPFFT_AB_BLOCKS=0: never (A/B runs)
+static bool ab_blocks_applies(int Pw, int Ph, int Kw, int Kh)
+{
+	static const int on = getenv("DSPFFT_AB_BLOCKS") ? atoi(getenv("DSPFFT_AB_BLOCKS")) : 1;
+	return on && Pw == Ph && (Pw == 4 || Pw == 8 || Pw == 16) && (Kw + 15) / 16 <= 65535 && (Kh + 15) / 16 <= 65535;
+}
+
 extern "C" size_t dspfft_applybasis_work_floats_ex(int w, int h, int Kw, int Kh, int Nw, int Nh, int func)
 {
 	const size_t C = func <= 1 ? 2 : 1;
@@ -545,9 +687,19 @@ static int applybasis_core(float *d_out, const float *d_pixels, int w, int h, in
 	float *Fw = planes + 3 * npix, *Fh = Fw + (size_t)C * Kw * w;               // [(part, k)][n]: imaginary rows stacked under the real ones
 	float *Tt = Fh + (size_t)C * Kh * h;                                         // [j][(part, kw)][nw][y]
 	float *P = Tt + (size_t)3 * C * Kw * Nw * h;                                 // [j][(hp, kh)][nh][(tp, kw, nw)]
-	hipLaunchKernelGGL(deinterleave3_kernel, dim3(1024), dim3(256), 0, s, planes, d_pixels, npix);
 	hipLaunchKernelGGL(ab_basis_kernel, dim3(512), dim3(256), 0, s, Fw, cplx ? Fw + (size_t)Kw * w : nullptr, func, ortho, (long long)Kw, kow, now, (unsigned long long)w);
 	hipLaunchKernelGGL(ab_basis_kernel, dim3(512), dim3(256), 0, s, Fh, cplx ? Fh + (size_t)Kh * h : nullptr, func, ortho, (long long)Kh, koh, noh, (unsigned long long)h);
+	if (ab_blocks_applies(Pw, Ph, Kw, Kh)) {             // small square blocks: the two products and the interleave in one launch, the result written once
+		switch (Pw * 2 + cplx) {
+		case 8: return launch_ab_blocks<4, false>(d_out, d_pixels, Fw, Fh, w, h, Kw, Kh, Nw, Nh, as_imag, s);
+		case 9: return launch_ab_blocks<4, true>(d_out, d_pixels, Fw, Fh, w, h, Kw, Kh, Nw, Nh, as_imag, s);
+		case 16: return launch_ab_blocks<8, false>(d_out, d_pixels, Fw, Fh, w, h, Kw, Kh, Nw, Nh, as_imag, s);
+		case 17: return launch_ab_blocks<8, true>(d_out, d_pixels, Fw, Fh, w, h, Kw, Kh, Nw, Nh, as_imag, s);
+		case 32: return launch_ab_blocks<16, false>(d_out, d_pixels, Fw, Fh, w, h, Kw, Kh, Nw, Nh, as_imag, s);
+		default: return launch_ab_blocks<16, true>(d_out, d_pixels, Fw, Fh, w, h, Kw, Kh, Nw, Nh, as_imag, s);
+		}
+	}
+	hipLaunchKernelGGL(deinterleave3_kernel, dim3(1024), dim3(256), 0, s, planes, d_pixels, npix);
 	int rc = gemm_nt_f32_batch2(Fw, planes, Tt, C * Kw, h, Pw, w, w, (long long)Nw * h,
 	                            Nw, Pw, Pw, h, 3, 0, (long long)npix, (long long)C * Kw * Nw * h, s);
 	if (rc) return rc;

@@ -55,6 +55,33 @@ def test_partsums_general_form(gpu, func, case):
     assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("P", [4, 8, 16])
+@pytest.mark.parametrize("func,case", [("dct2", "forward"), ("dft", "forward"), ("dst3", "ragged"), ("idft", "ragged"), ("dct3", "inverse_offset"), ("dht", "complex_pixels"),
+                                       ("dft", "complex_pixels")])
+def test_small_square_blocks_take_the_one_launch_kernel(gpu, monkeypatch, P, func, case):
+    """-P 4x4 / 8x8 / 16x16 (applybasis.c:410-431 with small partial-sum blocks: zoom_gemm.hip ab_blocks_kernel, matrix cores for the row sums, the complex
+    result written once) against the f64 restatement AND against the three-pass path it replaces (DSPFFT_AB_BLOCKS=0 in a fresh process is the A/B
+    switch; here the comparison runs through the general entry with a non-square block, which never takes the kernel): real and complex bases, basis
+    counts and block counts that are no multiples of 16, the --offset forms, complex pixels"""
+    from dspfun_amd import applybasis as ab
+    w, h = 20 * P, 7 * P
+    pre = (ol.synth_f32(21 + P, w * h * 3).reshape(h, w, 3) * 2 - 1).astype(np.float32)
+    pim, inverse, ortho = None, False, False
+    if case == "forward":
+        K, N, off = (32, 16), (w // P, h // P), (0, 0)
+    elif case == "ragged":                  # 21 x 37 basis functions, 17 x 5 blocks: tiles of 16 with tails in every direction, an --offset on the basis index
+        K, N, off = (21, 37), (17, 5), (3, -2)
+    elif case == "inverse_offset":          # --inverse: the offset moves the function's sample index (applybasis.c:372-378,416-420)
+        K, N, off, inverse = (w, h), (19, 6), (1, -1), True
+    else:                                    # a .coeff input: the imaginary pixels are a second pass that adds i x its result in place
+        pim = (ol.synth_f32(5 + P, w * h * 3).reshape(h, w, 3) - 0.5).astype(np.float32)
+        K, N, off, ortho = (24, 40), (w // P, h // P), (0, 0), True
+    dev = lambda a: gpu.from_numpy(a).cuda() if a is not None else None
+    got = ab.partsums_ex(gpu, dev(pre), dev(pim), func, ortho, K, N, (P, P), off, inverse).cpu().numpy()
+    ref = oracle_ex(pre, pim, func, ortho, K, N, (P, P), off, inverse)
+    assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+
+
 def test_forward_then_inverse_through_a_coeff_file_restores_the_image(gpu, tmp_path):
     """applybasis -f dct2 -u WxH -d x.coeff img; applybasis -f dct3 -I -u WxH x.coeff: the orthogonal DCT-II spectrum written as a
     .coeff file (byte-exact round trip of the file), read back as complex pixels, inverted with DCT-III x 4/(W H) ... = the image"""
