@@ -1465,10 +1465,14 @@ extern "C" int dspfft_transpose_f32(float *d_out, long long out_pitch, const flo
 }
 
 namespace {
+// spec_fused.h is_plain, for the host side: none of the fused scan step's or zoom's extras asked for
+bool is_plain_args(const PassArgs &a) { return !a.mask && !a.zflags && !a.accumulate && a.win_hi <= 0 && !a.alt_out && !a.in_mul && !a.in_rev; }
 // a planar row pass that can take / produce 8-bit samples itself
-bool pass_has_u8(const Pass &P)
+bool pass_has_u8(const dspfft_plan_s *pl, const Pass &P)
 {
 	if (P.type != Pass::ROW || P.pa.C != 1 || !P.hostloop.empty()) return false;
+	// the 8-bit kernels are plain instantiations (spec_kernels.h): a plan with zoom's window / modulation / alternating sign on this axis converts separately
+	if (pl->alt_axis == P.axis || (pl->win_axis == P.axis && P.first && pl->zpage)) return false;
 	return (P.has_spec && be_spec_has_u8(P.spec.id)) || (P.jit && P.jit_fn_u8);
 }
 
@@ -1582,14 +1586,14 @@ int roundtrip_core(dspfft_plan fwd, dspfft_plan inv, const float *d_in, float *d
 		long long ispan = 1;
 		for (int a = 0; a < fwd->rank; a++) ispan += (long long)(fwd->n[a] - 1) * fwd->axes[a].is;
 		for (const Dim &b : fwd->batches) ispan += (long long)(b.n - 1) * b.is;
-		if (d_out8 && !pass_has_u8(inv->passes[ni - 1])) {
+		if (d_out8 && !pass_has_u8(inv, inv->passes[ni - 1])) {
 			// the output conversion will be one sweep over the whole span, which must then hold nothing but samples
 			long long dense = 1;
 			for (int a = 0; a < fwd->rank; a++) dense *= fwd->n[a];
 			for (const Dim &b : fwd->batches) dense *= b.n;
 			if (dense != span) return fail(-2, "8-bit output without a planar specialised row pass needs a dense work layout");
 		}
-		if (d_in8 && !pass_has_u8(fwd->passes[0])) {
+		if (d_in8 && !pass_has_u8(fwd, fwd->passes[0])) {
 			if (ispan != span) return fail(-2, "8-bit input without a planar specialised row pass needs identical input and work layouts");
 			if (be_u8_to_f32(d_out, d_in8, (uint64_t)span, stream)) return fail(-4, "launch failed");
 			d_in = d_out; d_in8 = nullptr;
@@ -1610,10 +1614,12 @@ int roundtrip_core(dspfft_plan fwd, dspfft_plan inv, const float *d_in, float *d
 	const bool fusable = F.type == Pass::COL && I.type == Pass::COL && (listed || compiled) && F.spec_nwg == I.spec_nwg &&
 	                     F.hostloop.empty() && I.hostloop.empty() && (15u & ((uintptr_t)src | (uintptr_t)d_out)) == 0 &&
 	                     !(getenv("DSPFFT_NO_FUSED_ROUNDTRIP") && *getenv("DSPFFT_NO_FUSED_ROUNDTRIP") == '1');
+	PassArgs af, ai;
 	if (fusable) {
-		PassArgs af, ai;
 		fill_args(af, F.spa, fwd, F, src, d_out, fwd->scale, Fuse());
 		fill_args(ai, I.spa, inv, I, (const float *)d_out, d_out, ni == 1 ? inv->scale : 1.0, Fuse());
+	}
+	if (fusable && is_plain_args(af) && is_plain_args(ai)) {      // (the fused kernel is the plain instantiation of both passes)
 		if (compiled) {
 			// parameters: (PassArgs af, PassArgs ai, FilterOp filt, unsigned long long *coded); FilterOp is the MotionFilter, nothing else
 			void *args[4] = {&af, &ai, &mf, &d_coeffs_coded};
@@ -1626,7 +1632,7 @@ int roundtrip_core(dspfft_plan fwd, dspfft_plan inv, const float *d_in, float *d
 	}
 	for (size_t i = 1; i < ni; i++) {
 		const Pass &P = inv->passes[i];
-		if (i + 1 == ni && d_out8 && pass_has_u8(P)) {
+		if (i + 1 == ni && d_out8 && pass_has_u8(inv, P)) {
 			U8IO io; io.in = nullptr; io.out = d_out8; io.mul = mul8;
 			if (int rc = run_pass_u8(inv, P, d_out, d_out, true, io, stream)) return rc;
 			return 0;

@@ -46,8 +46,9 @@ __global__ void __launch_bounds__(S::T, S::WPE) jit_col(const typename S::PA a)
 
 // planar rows reading 8-bit samples (REDFT10) or writing quantised 8-bit samples (REDFT01): row_spec_u8_kernel's twin
 template <class S, int KIND>
-__global__ void __launch_bounds__(S::T, S::WPE) jit_row_u8(const typename S::PA a, const U8IO io)
+__global__ void __launch_bounds__(S::T, S::WPE) jit_row_u8(const typename S::PA a_, const U8IO io)
 {
+	const typename S::PA a = plain_args(a_);
 	__shared__ __attribute__((aligned(32))) unsigned char lds[S::LDS];
 	typename S::CX *planes = reinterpret_cast<typename S::CX *>(lds);
 	const int tid = threadIdx.x;

@@ -33,9 +33,22 @@ template <class S> constexpr int rt_waves_per_simd()
 
 // the body of the fused column roundtrip, shared by the listed kernels (spec_kernels.h, dynamic LDS) and the ones compiled at plan
 // time (jit_kernels.h, static LDS)
-template <class S>
-__device__ __forceinline__ void col_roundtrip_body(unsigned char *lds, const typename S::PA &af, const typename S::PA &ai, const FilterOp &filt, unsigned long long *coded)
+// the fused scan step's and zoom's fields pinned to "off" on a local copy of the arguments: every branch on them folds away after inlining
+template <class PA> __host__ __device__ inline PA plain_args(const PA &a_)
 {
+	PA a = a_;
+	a.mask = nullptr; a.zflags = nullptr; a.zranges = nullptr; a.accumulate = 0; a.win_lo = a.win_hi = 0; a.alt_out = 0; a.in_mul = nullptr; a.in_rev = 0;
+	// (lean_off stays a run-time value: DSPFFT_LEAN01=0 must reach the plain kernels too)
+	return a;
+}
+template <class PA> static inline bool is_plain(const PA &a) { return !a.mask && !a.zflags && !a.accumulate && a.win_hi <= 0 && !a.alt_out && !a.in_mul && !a.in_rev; }
+
+template <class S>
+__device__ __forceinline__ void col_roundtrip_body(unsigned char *lds, const typename S::PA &af_, const typename S::PA &ai_, const FilterOp &filt, unsigned long long *coded)
+{
+	// motion's roundtrip is a plain pair of passes: the fused scan step's mask / flags / accumulation and zoom's window / modulation / alternating
+	// sign are pinned off (launch_col_roundtrip refuses them), so their per-load selects and the masked variants of prefetch fold away
+	const typename S::PA af = plain_args(af_), ai = plain_args(ai_);
 	__shared__ unsigned int wg_coded;       // non-zero quantised coefficients of this tile (one global atomic per workgroup)
 	typename S::V *buf = reinterpret_cast<typename S::V *>(lds);
 	const int tid = threadIdx.x;

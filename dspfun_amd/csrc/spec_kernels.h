@@ -54,14 +54,7 @@ static inline int device_cus()
 // PLAIN: the instantiation a plain dspfft_execute runs -- no owner-id mask, no tile flags, no accumulation.  The fused scan step's
 // fields are pinned to "off" on a local copy of the arguments, so every branch on them folds away after inlining (the fused code is a
 // third of the kernel's text; two such kernels sharing the CUs ran 1.5 % faster without it: tools/sbench.hip vs -DUSELIB)
-template <class PA> __device__ inline PA plain_args(const PA &a_)
-{
-	PA a = a_;
-	a.mask = nullptr; a.zflags = nullptr; a.zranges = nullptr; a.accumulate = 0; a.win_lo = a.win_hi = 0; a.alt_out = 0; a.in_mul = nullptr; a.in_rev = 0;
-	// (lean_off stays a run-time value: DSPFFT_LEAN01=0 must reach the plain kernels too)
-	return a;
-}
-template <class PA> static inline bool is_plain(const PA &a) { return !a.mask && !a.zflags && !a.accumulate && a.win_hi <= 0 && !a.alt_out && !a.in_mul && !a.in_rev; }
+// (plain_args / is_plain: spec_fused.h, shared with the plan-time kernels)
 
 template <class S, int KIND, bool PLAIN>
 __global__ void __launch_bounds__(S::T, S::WPE) row_spec_kernel(const typename S::PA a_)
@@ -277,8 +270,11 @@ int launch_czt_spectrum(const CztArgs &a, cf *hspec, void *stream)
 
 // the same with 8-bit input (REDFT10) or quantised 8-bit output (REDFT01): planar rows only
 template <class S, int KIND>
-__global__ void __launch_bounds__(S::T, S::WPE) row_spec_u8_kernel(const typename S::PA a, const U8IO io_)
+__global__ void __launch_bounds__(S::T, S::WPE) row_spec_u8_kernel(const typename S::PA a_, const U8IO io_)
 {
+	// the 8-bit ends belong to motion's plain roundtrip: no owner-id mask, tile flags, accumulation, input window or modulation (launch_row_spec_u8 refuses
+	// them), so their per-load selects fold away as in the plain row kernels (round 5: they were a third of this kernel's first phase)
+	const typename S::PA a = plain_args(a_);
 	// this instantiation's 8-bit end is known: the phases' float alternatives (and what merging the two paths cost: a dynamically indexed
 	// copy of the line's samples in scratch behind a full wait for the loads) fold away
 	U8IO io = io_;
@@ -539,6 +535,7 @@ int launch_zoomx(const ZoomXArgs &a, int nsrc, bool clip, void *stream)
 template <class S, int KIND>
 int launch_row_spec_u8(const typename S::PA &a, const U8IO &io, int nwork, void *stream)
 {
+	if (!is_plain(a)) return -5;                 // (the kernel is the plain instantiation only)
 	static DevOnce once;
 	if (int lds_rc = allow_lds_dev(once, S::LDS, row_spec_u8_kernel<S, KIND>)) return lds_rc;
 	hipLaunchKernelGGL((row_spec_u8_kernel<S, KIND>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a, io);
@@ -548,6 +545,7 @@ int launch_row_spec_u8(const typename S::PA &a, const U8IO &io, int nwork, void 
 template <class S>
 int launch_col_roundtrip(const typename S::PA &af, const typename S::PA &ai, const MotionFilter &filt, unsigned long long *coded, int nwork, void *stream)
 {
+	if (!is_plain(af) || !is_plain(ai)) return -5;      // (col_roundtrip_body runs the plain instantiation of both passes)
 	static DevOnce once;
 	if (int lds_rc = allow_lds_dev(once, S::LDS, col_roundtrip_kernel<S>)) return lds_rc;
 	FilterOp f; f.p = filt;
