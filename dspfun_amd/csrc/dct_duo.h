@@ -145,8 +145,8 @@ struct ZoomXLeanT {
 	static_assert(NS >= 2 && NBL == T && T % 64 == 0, "one last-stage butterfly per thread");
 	static_assert(RL % 2 == 1, "odd last radix (conflict-free gather; the middle slot index pairs with itself)");
 	static constexpr int A_ROUNDS = (SB + T - 1) / T;
-	struct State { float hold[(C > 1 ? C - 1 : 1) * 2 * RL]; };      // pixel pairs of the channels before the last
-	struct Ex { float p[RL], s[RL]; };                                 // per store index i: the sample this thread keeps, the one its partner needs
+	struct State { float hold[(C > 1 ? C - 1 : 1) * 2 * RL]; };      // per store step, the two samples of the channels before the last
+	struct Ex { float p[RL], s[RL]; };                                 // per slot r: the samples of its two pixels, the lower pixel first
 
 	// source pixel q of slot s: k = min(s, L - s); q = 0: k, 1: L - k, 2: L + k, 3: N - k
 	static DSP_HD int src_pixel(int q, int s) { const int k = s < L - s ? s : L - s; return q == 0 ? k : q == 1 ? L - k : q == 2 ? L + k : N - k; }
@@ -181,47 +181,109 @@ struct ZoomXLeanT {
 			}
 		});
 	}
+	// The same with the line's pixels loaded WHOLE, once (NSRC == 1, one round: BASELINE config 3): a 12-byte load per slot serves the three channels,
+	// where phase_a issues a 4-byte load from the same pixel in each of them and waits for it again (round 5: phase A was the longest of a
+	// channel's three phases, 7.8K / 7.1K / 5.4K clocks of a workgroup's 52K, for 2K clocks of vector instructions: tools/kstamp zoomx)
+	static constexpr bool WHOLE = NSRC == 1 && A_ROUNDS == 1;
+	struct Pixels { Pix<C, float> p[R0]; };
+	static DSP_HD void load_pixels(const ZoomXArgs &a, long long bin, int tid, Pixels &px)
+	{
+		const float *line = a.in + bin;
+		const int m = tid < SB ? tid : SB - 1;                      // (threads beyond the butterflies load a valid pixel and drop it)
+		int mc = m * C;
+		DSP_PIN1(mc);                                               // (one per-thread element offset + a constant per slot, not a multiplication per load)
+		const int last = (a.cw - 1) * C;
+		static_for<0, R0>([&](auto r) {
+			// pixel of slot s = m + r SB: min(s, L - s), on which side of L/2 the slot lies known per r wherever SB divides L/2
+			int e;
+			if constexpr ((r + 1) * SB - 1 <= L / 2) e = mc + r * SB * C;
+			else if constexpr (r * SB >= L / 2) e = (L - r * SB) * C - mc;
+			else { const int s = m + r * SB; e = (s < L - s ? s : L - s) * C; }
+			e = e < last ? e : last;                                // beyond the window the multiplier is zero: any valid pixel will do
+			px.p[r] = load_pix<C, float>(at(line, e));
+		});
+	}
+	template <int CH>
+	static DSP_HD void phase_a_held(const ZoomXArgs &a, const PassArgs &w, V *buf, int tid, const Pixels &px)
+	{
+		const int m = tid;
+		if (m < SB) {
+			LC x[R0];
+			static_for<0, R0>([&](auto r) {
+				const LC t = B::l_get(*reinterpret_cast<const V *>(reinterpret_cast<const char *>(a.tab) + (unsigned)((m + r * SB) * (int)sizeof(V))));
+				const float f = px.p[r].v[CH];
+				x[r] = cmk<Pk2>(t.x * f, t.y * f);
+			});
+			Dft<R0>::run(x);
+			cf tw[R0];
+			tw[1] = w.W[m];
+			static_for<2, R0>([&](auto r) { if constexpr (r % 2 == 0) tw[r] = csqr(tw[r / 2]); else tw[r] = cmul(tw[r / 2], tw[r - r / 2]); });
+			static_for<1, R0>([&](auto r) { x[r] = B::lmul(x[r], tw[r]); });
+			static_for<0, R0>([&](auto r) { buf[m + r * (SB + B::PADC)] = B::l_put(x[r]); });
+		}
+	}
 	// phases B: stage I = 1 .. NS - 2
 	template <int I> static DSP_HD void phase_b(const PassArgs &w, V *buf, int tid) { B::template stage<I>(w, buf, tid); }
 
+	// element e of a line by a 32-bit BYTE offset from the (uniform) line base: the address needs no 64-bit vector arithmetic
+	static DSP_HD float *at(float *line, int e) { return reinterpret_cast<float *>(reinterpret_cast<char *>(line) + (unsigned)(e * 4)); }
+	static DSP_HD const float *at(const float *line, int e) { return reinterpret_cast<const float *>(reinterpret_cast<const char *>(line) + (unsigned)(e * 4)); }
 	// thread -> last-stage butterfly: partners kb, NBL - 1 - kb on mirror lanes of one wave
 	static DSP_HD int kb_of(int tid) { const int wv = tid >> 6, l = tid & 63; return l < 32 ? 32 * wv + l : NBL - 1 - (32 * wv + 63 - l); }
-	// phase C, first half: last butterfly from the plane, the two series combined; per store index i the kept sample p and the sample s
-	// the partner thread needs.  Lanes >= 32 run through their slots backwards (r = RL - 1 - i) so that partners meet at the same i.
+	// Output j = kb + NBL r of the last butterfly holds plane elements n = 2j (re), 2j + 1 (im): v[n] for even n, -v[n] for odd n.  Of the four
+	// pixels 4g .. 4g + 3 of group g, output j = g (j < L/2, `low`) holds 4g (re) and 4g + 2 (im), output j = L - 1 - g holds 4g + 3 (re) and
+	// 4g + 1 (im) -- of every channel, so a thread owns whole pixels and nothing needs to change hands.  `low` is known at compile time except
+	// for the middle slot (RL odd), where it is the half of the wave the lane sits in.
+	// (Round 4 traded im with the partner thread on the mirror lane so that each thread held the pixel PAIRS 4g, 4g + 1 / 4g + 2, 4g + 3, and ran
+	// lanes >= 32 through their slots backwards to make partners meet: 15 ds_bpermute and 75 selects per channel for nothing -- pixels are
+	// stored one 12-byte pixel per lane either way.)
+	static_assert(RL == 1 || L % (2 * NBL) == NBL, "the middle slot's outputs split between the low and the high half at kb = NBL / 2");
+	template <int R> static DSP_HD bool low_of(int tid) { if constexpr (2 * R + 1 < RL) return true; else if constexpr (2 * R + 1 > RL) return false; else return (tid & 63) < 32; }
+	// phase C, first half: last butterfly from the plane, the two series combined: per slot r its two pixels' samples in ascending order
+	// (p: 4g or 4g + 1, s: 4g + 2 or 4g + 3)
 	static DSP_HD void phase_c(const V *buf, int tid, Ex &e)
 	{
 		const int kb = kb_of(tid);
-		const bool up = (tid & 63) >= 32;
 		const V *p = buf + B::padded(B::last_blk(kb) * RL);
 		LC x[RL];
 		static_for<0, RL>([&](auto r) { x[r] = B::l_get(p[r]); });
 		Dft<RL>::run(x);
-		float ore[RL], oim[RL];
 		static_for<0, RL>([&](auto r) {
-			// output j = kb + NBL r holds plane elements n = 2j (re), 2j + 1 (im): v[n] for even n, -v[n] for odd n; samples x = 4j, 4j + 2 (even:
-			// cosine minus sine series) for j < L/2, odd samples (cosine plus sine) above
-			const int j = kb + NBL * r;
-			const float sg = 2 * j < L ? -1.f : 1.f;
-			ore[r] = x[r].x.x + sg * x[r].x.y;
-			oim[r] = -(x[r].y.x + sg * x[r].y.y);
-		});
-		static_for<0, RL>([&](auto i) {
-			e.p[i] = up ? ore[RL - 1 - i] : ore[i];
-			e.s[i] = up ? oim[RL - 1 - i] : oim[i];
+			// even samples: cosine minus sine series (j < L/2); odd samples: cosine plus sine
+			if constexpr (2 * r + 1 == RL) {
+				const float sg = low_of<r>(tid) ? -1.f : 1.f;
+				const float re = x[r].x.x + sg * x[r].x.y, im = -(x[r].y.x + sg * x[r].y.y);
+				e.p[r] = low_of<r>(tid) ? re : im; e.s[r] = low_of<r>(tid) ? im : re;
+			} else if constexpr (2 * r + 1 < RL) { e.p[r] = x[r].x.x - x[r].x.y; e.s[r] = -(x[r].y.x - x[r].y.y); }
+			else { e.s[r] = x[r].x.x + x[r].x.y; e.p[r] = -(x[r].y.x + x[r].y.y); }
 		});
 	}
-	// phase C, second half: recv[i] = the partner's s[i].  Channels before the last keep their pixel pairs; the last stores whole pixels
-	static DSP_HD void phase_c_emit(const ZoomXArgs &a, long long bout, int ch, int tid, const Ex &e, const float (&recv)[RL], State &st)
+	// Store step i: lanes < 32 bring their slot i, lanes >= 32 their slot RL - 1 - i -- the other two pixels of the same 32 groups, so that one
+	// store instruction of the wave writes 24 contiguous bytes of every 48 over one 1.5 KB stretch of the line (each half of the wave by its own
+	// slot order touches twice the cache lines per instruction: measured 2.1x the time of the closing phase).  x0: the pixel of y0; y1 goes to x0 + 2
+	template <int I> static DSP_HD void step_of(int tid, const Ex &e, float &y0, float &y1)
 	{
-		const int kb = kb_of(tid);
 		const bool up = (tid & 63) >= 32;
-		// slot of store index i: r = i (lanes < 32) or RL - 1 - i; low slot: pixels 4j (kept), 4j + 1 (received); high slot: 4j' + 2 (received),
-		// 4j' + 3 (kept), j' = L - 1 - j
+		y0 = up ? e.p[RL - 1 - I] : e.p[I]; y1 = up ? e.s[RL - 1 - I] : e.s[I];
+	}
+	// the pixels of the store steps: x0 of step I = (2 I + 1 <= RL ? lo + 4 NBL I : hi + 4 NBL (RL - 1 - I)), and x0 + 2.  Two per-thread bases, pinned
+	// in registers (left alone, the compiler rebuilds them from the thread index before every store: 8 instructions, one a quarter-rate multiply)
+	struct Bases { int lo, hi; };
+	static DSP_HD Bases bases_of(int tid)
+	{
+		const bool up = (tid & 63) >= 32;
+		const int kb = kb_of(tid), g0 = up ? NBL - 1 - kb : kb;
+		Bases b;
+		b.lo = 4 * g0 + (up ? 1 : 0); b.hi = 4 * (NBL - 1 - g0) + (up ? 0 : 1);
+		return b;
+	}
+	// phase C, second half.  Channels before the last keep their samples; the last stores whole pixels
+	static DSP_HD void phase_c_emit(const ZoomXArgs &a, long long bout, int ch, int tid, const Ex &e, State &st)
+	{
 		if (ch + 1 < C) {
 			static_for<0, RL>([&](auto i) {
-				const int j = kb + NBL * (up ? RL - 1 - i : i);
-				const bool low = 2 * j < L;
-				const float y0 = low ? e.p[i] : recv[i], y1 = low ? recv[i] : e.p[i];
+				float y0, y1;
+				step_of<i>(tid, e, y0, y1);
 				static_for<0, C - 1>([&](auto c) {
 					float &h0 = st.hold[(c * RL + i) * 2], &h1 = st.hold[(c * RL + i) * 2 + 1];
 					h0 = (ch == c) ? y0 : h0; h1 = (ch == c) ? y1 : h1;
@@ -230,17 +292,44 @@ struct ZoomXLeanT {
 			return;
 		}
 		float *line = a.out + bout;
+		const Bases b = bases_of(tid);
+		int elo = b.lo * C, ehi = b.hi * C;                  // element offsets; the clip test compares them with vw C
+		DSP_PIN1(elo); DSP_PIN1(ehi);
+		const int ve = a.vw * C;
 		static_for<0, RL>([&](auto i) {
-			const int j = kb + NBL * (up ? RL - 1 - i : i);
-			const bool low = 2 * j < L;
-			const float y0 = low ? e.p[i] : recv[i], y1 = low ? recv[i] : e.p[i];
-			const int x0 = low ? 4 * j : 4 * (L - 1 - j) + 2;
+			float y0, y1;
+			step_of<i>(tid, e, y0, y1);
+			const int e0 = 2 * i + 1 <= RL ? elo + 4 * NBL * i * C : ehi + 4 * NBL * (RL - 1 - i) * C;
 			Pix<C, float> o0, o1;
 			// (handed over one by one: read as a Pix straight from the array, the compiler uses a vector load that keeps the array in scratch)
 			static_for<0, C - 1>([&](auto c) { float v0 = st.hold[(c * RL + i) * 2], v1 = st.hold[(c * RL + i) * 2 + 1]; DSP_PIN1(v0); DSP_PIN1(v1); o0.v[c] = v0; o1.v[c] = v1; });
 			o0.v[C - 1] = y0; o1.v[C - 1] = y1;
-			if (!CLIP || x0 < a.vw) store_pix<C, float>(line + (unsigned)(x0 * C), o0);
-			if (!CLIP || x0 + 1 < a.vw) store_pix<C, float>(line + (unsigned)((x0 + 1) * C), o1);
+			if (!CLIP || e0 < ve) store_pix<C, float>(at(line, e0), o0);
+			if (!CLIP || e0 + 2 * C < ve) store_pix<C, float>(at(line, e0 + 2 * C), o1);
+		});
+	}
+	// the same with the channel known at compile time (WHOLE): no selects on the held samples
+	template <int CH>
+	static DSP_HD void phase_c_emit_ch(const ZoomXArgs &a, long long bout, int tid, const Ex &e, State &st)
+	{
+		float *line = a.out + bout;
+		int elo = 0, ehi = 0;
+		if constexpr (CH + 1 == C) { const Bases b = bases_of(tid); elo = b.lo * C; ehi = b.hi * C; DSP_PIN1(elo); DSP_PIN1(ehi); }
+		const int ve = a.vw * C;
+		static_for<0, RL>([&](auto i) {
+			float y0, y1;
+			step_of<i>(tid, e, y0, y1);
+			if constexpr (CH + 1 < C) {
+				DSP_PIN1(y0); DSP_PIN1(y1);            // (computed NOW: left alone, the compiler keeps the butterfly's inputs instead and sinks it to the stores)
+				st.hold[(CH * RL + i) * 2] = y0; st.hold[(CH * RL + i) * 2 + 1] = y1;
+			} else {
+				const int e0 = 2 * i + 1 <= RL ? elo + 4 * NBL * i * C : ehi + 4 * NBL * (RL - 1 - i) * C;
+				Pix<C, float> o0, o1;
+				static_for<0, C - 1>([&](auto c) { o0.v[c] = st.hold[(c * RL + i) * 2]; o1.v[c] = st.hold[(c * RL + i) * 2 + 1]; });
+				o0.v[C - 1] = y0; o1.v[C - 1] = y1;
+				if (!CLIP || e0 < ve) store_pix<C, float>(at(line, e0), o0);
+				if (!CLIP || e0 + 2 * C < ve) store_pix<C, float>(at(line, e0 + 2 * C), o1);
+			}
 		});
 	}
 };

@@ -198,21 +198,46 @@ __global__ void __launch_bounds__(S::T, WPE) zoomx_lean_kernel(const ZoomXArgs a
 	typename Z::State st;
 	// a real loop over the channels: unrolled, the compiler interleaves them and carries one channel's addresses and twiddles through the
 	// next (80 -> 176 -> 220 VGPRs for 1 -> 2 -> 3 unrolled channels of the first cut)
+	DSP_STAMP(0);
+	if constexpr (Z::WHOLE) {
+		typename Z::Pixels px;
+		Z::load_pixels(a, bin, tid, px);
+		static_for<0, C>([&](auto c) {
+			int t = tid; asm volatile("" : "+v"(t));
+			Z::template phase_a_held<c>(a, w, buf, t, px);
+			__syncthreads();
+			DSP_STAMP(1 + c * 4);
+			static_for<1, S::NS - 1>([&](auto I) {
+				Z::template phase_b<I>(w, buf, t);
+				__syncthreads();
+			});
+			DSP_STAMP(2 + c * 4);
+			typename Z::Ex e;
+			Z::phase_c(buf, t, e);
+			Z::template phase_c_emit_ch<c>(a, bout, t, e, st);
+			DSP_STAMP(3 + c * 4);
+			if constexpr (c + 1 < C) __syncthreads();
+			DSP_STAMP(4 + c * 4);
+		});
+		return;
+	}
 #pragma nounroll
 	for (int c = 0; c < C; c++) {
 		int t = tid; asm volatile("" : "+v"(t));
 		Z::phase_a(a, w, buf, bin, c, t);
 		__syncthreads();
+		DSP_STAMP(1 + c * 4);
 		static_for<1, S::NS - 1>([&](auto I) {
 			Z::template phase_b<I>(w, buf, t);
 			__syncthreads();
 		});
+		DSP_STAMP(2 + c * 4);
 		typename Z::Ex e;
 		Z::phase_c(buf, t, e);
-		float recv[Z::RL];
-		static_for<0, Z::RL>([&](auto i) { recv[i] = __shfl_xor(e.s[i], 63); });      // the partner slot's thread sits on the mirror lane
-		Z::phase_c_emit(a, bout, c, t, e, recv, st);
+		Z::phase_c_emit(a, bout, c, t, e, st);
+		DSP_STAMP(3 + c * 4);
 		if (c + 1 < C) __syncthreads();                      // the plane is the next channel's
+		DSP_STAMP(4 + c * 4);
 	}
 }
 

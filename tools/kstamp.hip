@@ -4,7 +4,7 @@
 // unstamped) -- read the phase SHARES, never compare a stamped kernel's total with an unstamped one's.
 //
 //   hipcc -std=c++17 -O3 -fno-slp-vectorize -ffp-contract=on --offload-arch=gfx950 -Idspfun_amd/csrc -Iinclude tools/kstamp.hip -o tools/kstamp
-//   tools/kstamp [pair|half|rt]
+//   tools/kstamp [pair|half|rt|zoomx]
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -65,7 +65,7 @@ template <class F> static void run(const char *what, int nwg, F &&launch)
 int main(int argc, char **argv)
 {
 	setvbuf(stdout, NULL, _IONBF, 0);
-	const char *which = argc > 1 ? argv[1] : "pair half rt";
+	const char *which = argc > 1 ? argv[1] : "pair half rt zoomx";
 	const int W8 = 7680, H8 = 4320;
 	const size_t n8 = (size_t)W8 * H8 * 3;
 	float *x;
@@ -115,6 +115,18 @@ int main(int argc, char **argv)
 		run("col_roundtrip 1080 K=16, quantiser (32 frames)", nwg, [&]() { hipLaunchKernelGGL((col_roundtrip_kernel<S>), dim3(nwg), dim3(S::T), S::LDS, 0, af, ai, f, (unsigned long long *)nullptr); });
 		f.p.enabled = 0;
 		run("col_roundtrip 1080 K=16, no filter", nwg, [&]() { hipLaunchKernelGGL((col_roundtrip_kernel<S>), dim3(nwg), dim3(S::T), S::LDS, 0, af, ai, f, (unsigned long long *)nullptr); });
+	}
+	if (strstr(which, "zoomx")) {
+		// zoom's x stage of BASELINE config 3: 2160 lines of 1920 pixels (3 floats) -> 7680 pixels; the table's values do not matter for time
+		typedef RowDuoT<7680, 256, 16, 16, 15> S;
+		const int cw = 1920, vw = 7680, lines = 2160;
+		std::vector<cf> tb((size_t)4 * S::L);
+		for (size_t i = 0; i < tb.size(); i++) tb[i] = cmk<float>(0.5f + (float)(i % 7) * 0.01f, -0.25f);
+		ZoomXArgs z = {};
+		float *out; CK(hipMalloc(&out, (size_t)vw * lines * 3 * 4));
+		z.in = x; z.out = out; z.tab = (const float *)upload(tb); z.W = tab_W(S::L); z.in_pitch = (long long)cw * 3; z.out_pitch = (long long)vw * 3; z.cw = cw; z.vw = vw; z.lines = lines;
+		CK(hipFuncSetAttribute(reinterpret_cast<const void *>(zoomx_lean_kernel<S, 3, 1, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS));
+		run("zoomx_lean 1920 -> 7680 x 3 (2160 lines)", lines, [&]() { hipLaunchKernelGGL((zoomx_lean_kernel<S, 3, 1, 2, false>), dim3(lines), dim3(S::T), S::LDS, 0, z); });
 	}
 	return 0;
 }
