@@ -115,10 +115,11 @@ DSP_HD ZoomXEntry zoomx_table_entry(int M, int cw, int k, int src, double theta,
 //      no LDS round trip in front of the first butterfly;
 //   B  the middle stages, in place (ColSpecT::stage);
 //   C  the last stage keeps its outputs in registers: thread kb holds FFT outputs j = kb + NBL r.  Output j carries samples x = 4j, 4j + 2
-//      (j < L/2) resp. 4j' + 3, 4j' + 1 (j' = L - 1 - j); the partner slot L - 1 - j = (NBL - 1 - kb) + NBL (RL - 1 - r) belongs to thread
-//      NBL - 1 - kb, which the lane map puts on the mirror lane (63 - lane) of the same wave: ONE cross-lane exchange per slot
-//      (ds_bpermute, no LDS round trip, no barrier) leaves every thread with pixel PAIRS (4j, 4j + 1) | (4j + 2, 4j + 3), and the wave's
-//      store of slot index i is one contiguous run of 32 x 48 bytes.
+//      (j < L/2) resp. 4j' + 3, 4j' + 1 (j' = L - 1 - j) -- of every channel, so the thread owns those pixels whole and keeps the earlier
+//      channels' samples in registers until the last channel stores 12-byte pixels.  The partner slot L - 1 - j = (NBL - 1 - kb) + NBL (RL - 1 - r)
+//      belongs to thread NBL - 1 - kb, which the lane map puts on the mirror lane (63 - lane) of the same wave: at store step i lanes < 32
+//      bring slot i and lanes >= 32 slot RL - 1 - i, so one store instruction writes 24 contiguous bytes of every 48 over one run of 32 x 48 bytes.
+//      (Round 4 exchanged im across the mirror lanes to hold pixel PAIRS: profiles/r05_isa_zoomx.txt.)
 // Needs T = NBL = L / RL threads (one last-stage butterfly each), T a multiple of 64.
 // item i < nsrc (M/4 + 1) of the per-slot table tab[q][s] (q < nsrc sources, s < M/2 slots, four floats each): the entries of slot pair
 // (k, L - k) for source q.  Every slot is written (slot L/2 by k = L/2, slot 0 by k = 0), so the table needs no clearing between frames.

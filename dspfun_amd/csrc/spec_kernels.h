@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(S::T, 1) row_sum2_kernel(const typename S::PA 
 
 // ---- zoom's x stage with the cosine and the sine part of a line as the two halves of a Pk2 (dct_duo.h ZoomXLeanT): the channels of a
 // line one after another through a 16-byte-slot plane, three phases each -- first stage fed from global memory, middle stages in the
-// plane, last stage to registers + one mirror-lane exchange per slot; pixel pairs wait in registers until the last channel stores ----
+// plane, last stage to registers; a thread's pixels wait in registers until the last channel stores them whole ----
 template <class S, int C, int NSRC, int WPE, bool CLIP>
 __global__ void __launch_bounds__(S::T, WPE) zoomx_lean_kernel(const ZoomXArgs a)
 {
