@@ -44,15 +44,20 @@ inline void motion_filter_set_divs(MotionFilter &p, int block_depth)
 // correctly rounded quotient (Markstein's theorem, for a correctly rounded reciprocal), so two steps give RN(v / q): 5 full-rate instructions
 // for the hardware sequence's 10 and its quarter-rate v_rcp_f32 (checked against the division on 2^26 values per quantiser, adversarial
 // significands included: tests/test_ref_motion.py).  rq == 0 (quantisers outside [1e-30, 1e30]): divide.
+// Most quotients are nowhere near a rounding boundary: t0 is within 1.5 x 2^-23 |t0| of RN(v / q), so unless its distance to the nearest
+// half-integer is within 4 x 2^-23 |t0| both round to the same integer, which is then not a tie either (round-to-even = roundf): 6 instructions
+// and a skipped branch instead of 12.  (|t0| >= 2^20 always takes the exact path.)
 DSP_HD float motion_quantise(float v, float q, float rq)
 {
-	float t;
-	if (rq != 0.f) {
-		const float t0 = v * rq;
+	if (rq == 0.f) return roundf(v / q) * q;
+	const float t0 = v * rq;
+	float r = rintf(t0);
+	const float d = t0 - r;                                                    // exact
+	if (fabsf(fabsf(d) - 0.5f) <= fabsf(t0) * 0x1p-21f) {
 		const float t1 = fmaf(fmaf(-t0, q, v), rq, t0);
-		t = fmaf(fmaf(-t1, q, v), rq, t1);
-	} else t = v / q;
-	return roundf(t) * q;
+		r = roundf(fmaf(fmaf(-t1, q, v), rq, t1));
+	}
+	return r * q;
 }
 
 // one coefficient at block position (z, y, x); `coded` counts the non-zero quantised coefficients (motion.c:743)
@@ -89,11 +94,13 @@ DSP_HD float4 motion_filter4(const MotionFilter &p, uint32_t e, float4 v, unsign
 {
 	if (p.quant_only) {
 		float r[4] = {v.x, v.y, v.z, v.w};
+		unsigned int nz = 0;
 		for (int q = 0; q < 4; q++) {
 			r[q] = motion_quantise(r[q], p.quantizer, p.rquant);                                       // motion.c:740-744
-			coded += (r[q] != 0.f);
+			nz += (r[q] != 0.f);
 			DSP_SCHED_FENCE();
 		}
+		coded += nz;
 		float4 o; o.x = r[0]; o.y = r[1]; o.z = r[2]; o.w = r[3];
 		return o;
 	}

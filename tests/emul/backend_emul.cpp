@@ -237,8 +237,8 @@ int launch_row_sum2(const typename S::PA &a, const typename S::PA &b, int nwork,
 	}
 	return 0;
 }
-// zoom's x stage on the duo row kernel (spec_kernels.h zoomx_lean_kernel): the cross-lane exchange (mirror lane of the same wave) is a
-// read of the partner thread's values between the two halves of phase C
+// zoom's x stage on the duo row kernel (spec_kernels.h zoomx_lean_kernel), the same two paths: the line's pixels loaded whole and the channels
+// unrolled (Z::WHOLE), or channel by channel
 template <class S, int C, int NSRC, bool CLIP>
 int emul_zoomx(const ZoomXArgs &a)
 {
@@ -251,15 +251,22 @@ int emul_zoomx(const ZoomXArgs &a)
 		const long long bin = (long long)line * a.in_pitch, bout = (long long)line * a.out_pitch;
 		std::vector<typename Z::State> st(S::T);
 		std::vector<typename Z::Ex> ex(S::T);
+		if constexpr (Z::WHOLE) {
+			std::vector<typename Z::Pixels> px(S::T);
+			for (int tid = 0; tid < S::T; tid++) Z::load_pixels(a, bin, tid, px[tid]);
+			static_for<0, C>([&](auto c) {
+				for (int tid = 0; tid < S::T; tid++) Z::template phase_a_held<c>(a, w, buf, tid, px[tid]);
+				static_for<1, S::NS - 1>([&](auto I) { for (int tid = 0; tid < S::T; tid++) Z::template phase_b<I>(w, buf, tid); });
+				for (int tid = 0; tid < S::T; tid++) Z::phase_c(buf, tid, ex[tid]);
+				for (int tid = 0; tid < S::T; tid++) Z::template phase_c_emit_ch<c>(a, bout, tid, ex[tid], st[tid]);
+			});
+			continue;
+		}
 		for (int c = 0; c < C; c++) {
 			for (int tid = 0; tid < S::T; tid++) Z::phase_a(a, w, buf, bin, c, tid);
 			static_for<1, S::NS - 1>([&](auto I) { for (int tid = 0; tid < S::T; tid++) Z::template phase_b<I>(w, buf, tid); });
 			for (int tid = 0; tid < S::T; tid++) Z::phase_c(buf, tid, ex[tid]);
-			for (int tid = 0; tid < S::T; tid++) {
-				float recv[Z::RL];
-				for (int i = 0; i < Z::RL; i++) recv[i] = ex[tid ^ 63].s[i];
-				Z::phase_c_emit(a, bout, c, tid, ex[tid], recv, st[tid]);
-			}
+			for (int tid = 0; tid < S::T; tid++) Z::phase_c_emit(a, bout, c, tid, ex[tid], st[tid]);
 		}
 	}
 	return 0;
