@@ -376,9 +376,11 @@ template <class S> constexpr int pair_waves_per_simd()
 	const int cap = (S::C == 1 && S::N >= 7680) ? DSP_PAIR_WPE_LONG : DSP_PAIR_WPE_MAX;
 	return w < 1 ? 1 : w > cap ? cap : w;
 }
-template <class S, int KIND>
-__global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_kernel(const typename S::PA a)
+// PLAIN: see row_spec_kernel (the 8K roundtrip's instantiation; the fused scan step of BASELINE config 4 runs the general one)
+template <class S, int KIND, bool PLAIN = false>
+__global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_kernel(const typename S::PA a_)
 {
+	const typename S::PA a = PLAIN ? plain_args(a_) : a_;
 	extern __shared__ __attribute__((aligned(32))) unsigned char lds[];
 	typename S::CX *planes = reinterpret_cast<typename S::CX *>(lds);
 	const int tid = threadIdx.x;
@@ -417,9 +419,10 @@ __global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_kerne
 }
 
 // COL side: one workgroup per half tile (N/2 rows x K floats)
-template <class S, int KIND>
-__global__ void __launch_bounds__(S::T, S::WPE) col_half_kernel(const typename S::PA a)
+template <class S, int KIND, bool PLAIN = false>
+__global__ void __launch_bounds__(S::T, S::WPE) col_half_kernel(const typename S::PA a_)
 {
+	const typename S::PA a = PLAIN ? plain_args(a_) : a_;
 	extern __shared__ __attribute__((aligned(32))) unsigned char lds[];
 	typename S::V *buf = reinterpret_cast<typename S::V *>(lds);
 	const int tid = threadIdx.x;
@@ -510,8 +513,9 @@ template <class S, int KIND>
 int launch_row_pair(const typename S::PA &a, int npairs, void *stream)
 {
 	static DevOnce once;
-	if (int lds_rc = allow_lds_dev(once, S::LDS, row_pair_kernel<S, KIND>)) return lds_rc;
-	hipLaunchKernelGGL((row_pair_kernel<S, KIND>), dim3(npairs), dim3(S::T), S::LDS, (hipStream_t)stream, a);
+	if (int lds_rc = allow_lds_dev(once, S::LDS, row_pair_kernel<S, KIND, false>, row_pair_kernel<S, KIND, true>)) return lds_rc;
+	if (is_plain(a)) hipLaunchKernelGGL((row_pair_kernel<S, KIND, true>), dim3(npairs), dim3(S::T), S::LDS, (hipStream_t)stream, a);
+	else hipLaunchKernelGGL((row_pair_kernel<S, KIND, false>), dim3(npairs), dim3(S::T), S::LDS, (hipStream_t)stream, a);
 	HIPCHK(hipGetLastError());
 	return 0;
 }
@@ -528,8 +532,9 @@ template <class S, int KIND>
 int launch_col_half(const typename S::PA &a, int nwork, void *stream)
 {
 	static DevOnce once;
-	if (int lds_rc = allow_lds_dev(once, S::LDS, col_half_kernel<S, KIND>)) return lds_rc;
-	hipLaunchKernelGGL((col_half_kernel<S, KIND>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a);
+	if (int lds_rc = allow_lds_dev(once, S::LDS, col_half_kernel<S, KIND, false>, col_half_kernel<S, KIND, true>)) return lds_rc;
+	if (is_plain(a)) hipLaunchKernelGGL((col_half_kernel<S, KIND, true>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a);
+	else hipLaunchKernelGGL((col_half_kernel<S, KIND, false>), dim3(nwork), dim3(S::T), S::LDS, (hipStream_t)stream, a);
 	HIPCHK(hipGetLastError());
 	return 0;
 }

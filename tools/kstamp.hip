@@ -82,10 +82,10 @@ int main(int argc, char **argv)
 		PassArgs a = {};
 		a.N = S::N; a.C = 3; a.nb0 = H8; a.nb1 = 1; a.sb0_in = a.sb0_out = (long long)W8 * 3; a.nlines = H8;
 		a.in = x; a.out = x; a.T = tab_T(S::N); a.W = tab_W(S::L); a.scale = 1.f; a.in_scale0 = a.out_scale0 = 1.f;
-		CK(hipFuncSetAttribute(reinterpret_cast<const void *>(row_pair_kernel<S, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS));
-		CK(hipFuncSetAttribute(reinterpret_cast<const void *>(row_pair_kernel<S, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS));
-		a.kind = 0; run("row_pair 7680x3 REDFT10 (2160 pairs)", H8 / 2, [&]() { hipLaunchKernelGGL((row_pair_kernel<S, 0>), dim3(H8 / 2), dim3(S::T), S::LDS, 0, a); });
-		a.kind = 1; run("row_pair 7680x3 REDFT01", H8 / 2, [&]() { hipLaunchKernelGGL((row_pair_kernel<S, 1>), dim3(H8 / 2), dim3(S::T), S::LDS, 0, a); });
+		CK(hipFuncSetAttribute(reinterpret_cast<const void *>(row_pair_kernel<S, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS));
+		CK(hipFuncSetAttribute(reinterpret_cast<const void *>(row_pair_kernel<S, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS));
+		a.kind = 0; run("row_pair 7680x3 REDFT10 (2160 pairs)", H8 / 2, [&]() { hipLaunchKernelGGL((row_pair_kernel<S, 0, true>), dim3(H8 / 2), dim3(S::T), S::LDS, 0, a); });
+		a.kind = 1; run("row_pair 7680x3 REDFT01", H8 / 2, [&]() { hipLaunchKernelGGL((row_pair_kernel<S, 1, true>), dim3(H8 / 2), dim3(S::T), S::LDS, 0, a); });
 	}
 	if (strstr(which, "half")) {
 		typedef ColHalfSpec<4320, 16, 1024, 12, 12, 15> S;
@@ -93,10 +93,10 @@ int main(int argc, char **argv)
 		a.N = S::N; a.K = 16; a.B = 8; a.ninner = W8 * 3; a.ntiles = W8 * 3 / 16; a.es_in = a.es_out = (long long)W8 * 3; a.nb0 = a.nb1 = 1;
 		a.in = x; a.out = x; a.T = tab_T(S::N); a.W = tab_W(S::M); a.H = tab_H(S::N); a.scale = 1.f; a.in_scale0 = a.out_scale0 = 1.f;
 		const int nwg = 2 * a.ntiles;
-		CK(hipFuncSetAttribute(reinterpret_cast<const void *>(col_half_kernel<S, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS));
-		CK(hipFuncSetAttribute(reinterpret_cast<const void *>(col_half_kernel<S, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS));
-		a.kind = 0; run("col_half 4320 K=16 REDFT10 (2880 half tiles)", nwg, [&]() { hipLaunchKernelGGL((col_half_kernel<S, 0>), dim3(nwg), dim3(S::T), S::LDS, 0, a); });
-		a.kind = 1; run("col_half 4320 K=16 REDFT01", nwg, [&]() { hipLaunchKernelGGL((col_half_kernel<S, 1>), dim3(nwg), dim3(S::T), S::LDS, 0, a); });
+		CK(hipFuncSetAttribute(reinterpret_cast<const void *>(col_half_kernel<S, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS));
+		CK(hipFuncSetAttribute(reinterpret_cast<const void *>(col_half_kernel<S, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS));
+		a.kind = 0; run("col_half 4320 K=16 REDFT10 (2880 half tiles)", nwg, [&]() { hipLaunchKernelGGL((col_half_kernel<S, 0, true>), dim3(nwg), dim3(S::T), S::LDS, 0, a); });
+		a.kind = 1; run("col_half 4320 K=16 REDFT01", nwg, [&]() { hipLaunchKernelGGL((col_half_kernel<S, 1, true>), dim3(nwg), dim3(S::T), S::LDS, 0, a); });
 	}
 	if (strstr(which, "rt")) {
 		typedef ColSpec<1080, 16, 512, 12, 10, 9> S;
