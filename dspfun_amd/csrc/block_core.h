@@ -135,7 +135,7 @@ DSP_HD void block_store_x(const BlockGeom &a, const TinyArgs &tx, float *out, ui
 			for (int j = 0; j < NX / 4; j++) {
 				uint32_t w4 = 0;
 #pragma unroll
-				for (int k = 0; k < 4; k++) w4 |= (uint32_t)quantise_u8((double)o[4 * j + k] * mul8) << (8 * k);
+				for (int k = 0; k < 4; k++) w4 |= quantise_u8_of(o[4 * j + k], mul8, (float)mul8) << (8 * k);
 				__builtin_memcpy(out8 + off + 4 * j, &w4, 4);
 			}
 		} else {

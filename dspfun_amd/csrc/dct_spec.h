@@ -59,7 +59,14 @@ DSP_HD void tloop(int tid, F &&f)
 	if constexpr (REM > 0) { if (tid < REM) f(tid + FULL * T); }
 }
 
-template <class Re> DSP_HD cx<Re> csqr(cx<Re> a) { return cmk<Re>(a.x * a.x - a.y * a.y, (Re)2 * a.x * a.y); }
+template <class Re> DSP_HD cx<Re> csqr(cx<Re> a)
+{
+#if defined(DSP_PK_CX)
+	if constexpr (std::is_same<Re, float>::value) return cmul(a, a);      // two packed issues for the four scalar ones
+	else
+#endif
+	return cmk<Re>(a.x * a.x - a.y * a.y, (Re)2 * a.x * a.y);
+}
 
 // x[r] *= w1^r, r = 1..R-1, powers built by a balanced product tree (depth log2 R) from ONE table
 // value, so a butterfly costs one twiddle load instead of R-1.
@@ -494,13 +501,14 @@ struct RowSpecG {
 			} else {
 				if constexpr (U8_OK) {
 					if (io && io->out) {      // four consecutive quantised pixels per dword store
+						const float mulf = (float)io->mul;
 						tloop<N / 4, T>(tid, [&](int g) {
 							uint32_t w4 = 0;
 							static_for<0, 4>([&](auto q) {
 								const int x = 4 * g + q, n = makhoul_dst(x, N);
 								const Re sc = (x == 0) ? a.scale * a.out_scale0 : a.scale;
 								const Re f = pf[n];
-								w4 |= (uint32_t)quantise_u8((double)(((n & 1) ? -f : f) * sc) * io->mul) << (8 * q);
+								w4 |= quantise_u8_of(((n & 1) ? -f : f) * sc, io->mul, mulf) << (8 * q);
 							});
 							__builtin_memcpy(io->out + bout + 4 * g, &w4, 4);
 						});

@@ -50,5 +50,18 @@ DSP_HD uint8_t quantise_u8(double pel)
 	if (pel < 0.0) return 0;
 	return (uint8_t)round(pel);
 }
+// quantise_u8((double)v * mul) for the kernels that store a quantised pixel per sample (rows' 8-bit end, block transforms): the float product
+// v * (float)mul is within 2^-23 |p| of the double one, so unless it lies within 2^-21 |p| of a half-integer both round to the same integer
+// (and clamp alike: 255.5 and -0.5 are such half-integers) -- six single-precision instructions, where the double path is a conversion, a
+// multiplication, three comparisons, two 64-bit selects, an addition and a conversion back; next to a boundary the double path decides.
+// NaN -> 0 and +-inf -> 255 / 0, as the double path's conversions give on the device.
+DSP_HD uint32_t quantise_u8_of(float v, double mul, float mulf)
+{
+	const float p = v * mulf;
+	const float r = rintf(p);
+	const float d = p - r;                                                     // exact
+	if (fabsf(fabsf(d) - 0.5f) <= fabsf(p) * 0x1p-21f) return quantise_u8((double)v * mul);
+	return (uint32_t)(int)fminf(fmaxf(r, 0.f), 255.f);
+}
 
 }  // namespace dspfft

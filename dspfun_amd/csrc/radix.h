@@ -61,6 +61,56 @@ template <class R> DSP_HD cx<R> cconj(cx<R> a) { return cmk<R>(a.x, -a.y); }
 template <class R> DSP_HD cx<R> cscale(cx<R> a, typename same_t<R>::type s) { return cmk<R>(a.x * s, a.y * s); }
 template <class R> DSP_HD cx<R> cmul_mi(cx<R> a) { return cmk<R>(a.y, -a.x); }   // a * (-i)
 template <class R> DSP_HD cx<R> cmul_pi(cx<R> a) { return cmk<R>(-a.y, a.x); }   // a * (+i)
+template <class R> DSP_HD cx<R> cadd_mi(cx<R> a, cx<R> b) { return cmk<R>(a.x + b.y, a.y - b.x); }   // a + (-i) b
+template <class R> DSP_HD cx<R> csub_mi(cx<R> a, cx<R> b) { return cmk<R>(a.x - b.y, a.y + b.x); }   // a - (-i) b
+
+// ---- cx<float> as ONE packed pair on the device (round 5) ----
+// The row kernels carry one signal per butterfly, (re, im) in a register pair; written component by component every complex add is two
+// v_add_f32 and every product four v_mul / v_fma.  The same operations on the pair as a 2 x float vector are v_pk_add_f32 (one issue) and
+// v_pk_mul_f32 + v_pk_fma_f32 with the operand halves picked by op_sel (two issues), and the kernels that run at the vector issue rate
+// (8K row pairs, motion's 8-bit row ends: profiles/r05_isa_*.txt) get through their butterflies in ~0.6 of the issues.  The results are the
+// same sums and products (one rounding per operation either way; which of a product pair is the FMA's addend is the compiler's choice in both).
+// Host (g++ emulation): the templates above.
+#if defined(__clang__) && defined(__HIP_DEVICE_COMPILE__) && !defined(DSP_NO_PK_CX)
+DSP_HD Pk2 pk_of(cf a) { return pk2(a.x, a.y); }
+DSP_HD cf cf_of(Pk2 v) { cf r; r.x = v.x; r.y = v.y; return r; }
+DSP_HD cf cadd(cf a, cf b) { return cf_of(pk_of(a) + pk_of(b)); }
+DSP_HD cf csub(cf a, cf b) { return cf_of(pk_of(a) - pk_of(b)); }
+DSP_HD cf cscale(cf a, float s) { return cf_of(pk_of(a) * pk2(s, s)); }
+// The products and the quarter-turn sums need one operand half negated: the instructions take that as a modifier (neg_lo / neg_hi), the compiler
+// spends a v_xor (and often a v_mov for the swapped halves) on it -- so these few are spelled out.  Plain asm, no side effects: scheduled and
+// allocated like any other instruction.  op_sel / op_sel_hi: which half of each source feeds the low / high result.
+// (a.x b.x - a.y b.y, a.x b.y + a.y b.x) = a.xx * b + a.yy * (-b.y, b.x)
+DSP_HD cf cmul(cf a, cf b)
+{
+	Pk2 t, r; const Pk2 va = pk_of(a), vb = pk_of(b);
+	asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(va), "v"(vb));
+	asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(va), "v"(vb), "v"(t));
+	return cf_of(r);
+}
+// a conj(b) = (a.x b.x + a.y b.y, a.y b.x - a.x b.y) = a * b.xx + a.yx * (b.y, -b.y)
+DSP_HD cf cmulc(cf a, cf b)
+{
+	Pk2 t, r; const Pk2 va = pk_of(a), vb = pk_of(b);
+	asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(va), "v"(vb));
+	asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(va), "v"(vb), "v"(t));
+	return cf_of(r);
+}
+// a + (-i) b = (a.x + b.y, a.y - b.x);  a - (-i) b = (a.x - b.y, a.y + b.x)
+DSP_HD cf cadd_mi(cf a, cf b)
+{
+	Pk2 r; const Pk2 va = pk_of(a), vb = pk_of(b);
+	asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(va), "v"(vb));
+	return cf_of(r);
+}
+DSP_HD cf csub_mi(cf a, cf b)
+{
+	Pk2 r; const Pk2 va = pk_of(a), vb = pk_of(b);
+	asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(va), "v"(vb));
+	return cf_of(r);
+}
+#define DSP_PK_CX 1
+#endif
 
 // ---- compile-time trigonometry: cos/sin(2 pi k / n), exact octant reduction on (k, n) ----
 namespace ct {
@@ -132,6 +182,10 @@ DSP_HD cx<Re> twmul(cx<Re> a) {
 	else if constexpr (4 * e == 3 * R) return cmul_pi(a);
 	else {
 		constexpr Re wr = (Re)TwHolder<R>::tab.re[e], wi = (Re)TwHolder<R>::tab.im[e];
+#if defined(DSP_PK_CX)
+		if constexpr (std::is_same<Re, float>::value) return cf_of(__builtin_elementwise_fma(pk2(a.y, a.x), pk2(-wi, wi), pk_of(a) * pk2(wr, wr)));
+		else
+#endif
 		return cmk<Re>(a.x * wr - a.y * wi, a.x * wi + a.y * wr);
 	}
 }
@@ -152,8 +206,8 @@ template <> struct Dft<2> {
 };
 template <> struct Dft<4> {
 	template <class C> static DSP_HD void run(C *x) {
-		C s0 = cadd(x[0], x[2]), s1 = csub(x[0], x[2]), s2 = cadd(x[1], x[3]), s3 = cmul_mi(csub(x[1], x[3]));
-		x[0] = cadd(s0, s2); x[1] = cadd(s1, s3); x[2] = csub(s0, s2); x[3] = csub(s1, s3);
+		C s0 = cadd(x[0], x[2]), s1 = csub(x[0], x[2]), s2 = cadd(x[1], x[3]), d = csub(x[1], x[3]);
+		x[0] = cadd(s0, s2); x[1] = cadd_mi(s1, d); x[2] = csub(s0, s2); x[3] = csub_mi(s1, d);
 	}
 };
 
@@ -169,6 +223,24 @@ struct DftOddPrime {
 		C sum = x0;
 		static_for<0, H>([&](auto q) { sum = cadd(sum, a[q]); });
 		x[0] = sum;
+#if defined(DSP_PK_CX)
+		if constexpr (std::is_same<C, cf>::value) {
+			static_for<1, H + 1>([&](auto r) {
+				Pk2 cc = pk_of(x0), ss = pk2(0.f, 0.f);
+				static_for<0, H>([&](auto q) {
+					constexpr int e = ((q + 1) * r) % P;
+					constexpr float c = (float)TwHolder<P>::tab.re[e];
+					constexpr float s = (float)-TwHolder<P>::tab.im[e];
+					cc = __builtin_elementwise_fma(pk_of(a[q]), pk2(c, c), cc);
+					ss = __builtin_elementwise_fma(pk_of(b[q]), pk2(s, s), ss);
+				});
+				// X[r] = C - i S ; X[P-r] = C + i S
+				x[r] = cadd_mi(cf_of(cc), cf_of(ss));
+				x[P - r] = csub_mi(cf_of(cc), cf_of(ss));
+			});
+			return;
+		}
+#endif
 		static_for<1, H + 1>([&](auto r) {
 			Re cr = x0.x, ci = x0.y, sr = 0, si = 0;
 			static_for<0, H>([&](auto q) {

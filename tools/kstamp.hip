@@ -62,6 +62,31 @@ template <class F> static void run(const char *what, int nwg, F &&launch)
 	report(what, nwg, us);
 }
 
+template <class S> static void rt_case(float *x, const char *what)
+{
+	const int w = 1920, h = 1080, frames = 256;               // config 5's luma clip (2.1 GB: nothing of it stays in the caches)
+	static float *clip = nullptr;
+	if (!clip) { CK(hipMalloc(&clip, (size_t)w * h * frames * 4)); for (int i = 0; i < frames; i += 32) CK(hipMemcpy(clip + (size_t)i * w * h, x, (size_t)w * h * 32 * 4, hipMemcpyDeviceToDevice)); }
+	x = clip;
+	PassArgs af = {};
+	af.N = S::N; af.K = S::K; af.B = S::K / 2; af.ninner = w; af.ntiles = w / S::K; af.es_in = af.es_out = w; af.nb0 = frames; af.nb1 = 1;
+	af.sb0_in = af.sb0_out = (long long)w * h;
+	af.in = x; af.out = x; af.T = tab_T(S::N); af.W = tab_W(S::N); af.scale = 1.f; af.in_scale0 = af.out_scale0 = 1.f; af.kind = 0;
+	PassArgs ai = af; ai.kind = 1; ai.scale = 1.f / (2.f * h);
+	MotionFilter mf = {};
+	mf.ad = 1; mf.ah = h; mf.aw = w; mf.mh = h; mf.mw = w; mf.b1d = 1; mf.b1h = h; mf.b1w = w; mf.damp = mf.boost = 1.f; mf.quantizer = 40.f; mf.enabled = 1;
+	motion_filter_set_divs(mf, 1);
+	FilterOp f; f.p = mf;
+	const int nwg = af.ntiles * frames;
+	char name[128];
+	CK(hipFuncSetAttribute(reinterpret_cast<const void *>(col_roundtrip_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS));
+	snprintf(name, sizeof name, "%s, quantiser (256 frames)", what);
+	run(name, nwg, [&]() { hipLaunchKernelGGL((col_roundtrip_kernel<S>), dim3(nwg), dim3(S::T), S::LDS, 0, af, ai, f, (unsigned long long *)nullptr); });
+	f.p.enabled = 0;
+	snprintf(name, sizeof name, "%s, no filter", what);
+	run(name, nwg, [&]() { hipLaunchKernelGGL((col_roundtrip_kernel<S>), dim3(nwg), dim3(S::T), S::LDS, 0, af, ai, f, (unsigned long long *)nullptr); });
+}
+
 int main(int argc, char **argv)
 {
 	setvbuf(stdout, NULL, _IONBF, 0);
@@ -99,22 +124,9 @@ int main(int argc, char **argv)
 		a.kind = 1; run("col_half 4320 K=16 REDFT01", nwg, [&]() { hipLaunchKernelGGL((col_half_kernel<S, 1, true>), dim3(nwg), dim3(S::T), S::LDS, 0, a); });
 	}
 	if (strstr(which, "rt")) {
-		typedef ColSpec<1080, 16, 512, 12, 10, 9> S;
-		const int w = 1920, h = 1080, frames = 32;                // an eighth of config 5's luma clip
-		PassArgs af = {};
-		af.N = S::N; af.K = 16; af.B = 8; af.ninner = w; af.ntiles = w / 16; af.es_in = af.es_out = w; af.nb0 = frames; af.nb1 = 1;
-		af.sb0_in = af.sb0_out = (long long)w * h;
-		af.in = x; af.out = x; af.T = tab_T(S::N); af.W = tab_W(S::N); af.scale = 1.f; af.in_scale0 = af.out_scale0 = 1.f; af.kind = 0;
-		PassArgs ai = af; ai.kind = 1; ai.scale = 1.f / (2.f * h);
-		MotionFilter mf = {};
-		mf.ad = 1; mf.ah = h; mf.aw = w; mf.mh = h; mf.mw = w; mf.b1d = 1; mf.b1h = h; mf.b1w = w; mf.damp = mf.boost = 1.f; mf.quantizer = 40.f; mf.enabled = 1;
-		motion_filter_set_divs(mf, 1);
-		FilterOp f; f.p = mf;
-		const int nwg = af.ntiles * frames;
-		CK(hipFuncSetAttribute(reinterpret_cast<const void *>(col_roundtrip_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS));
-		run("col_roundtrip 1080 K=16, quantiser (32 frames)", nwg, [&]() { hipLaunchKernelGGL((col_roundtrip_kernel<S>), dim3(nwg), dim3(S::T), S::LDS, 0, af, ai, f, (unsigned long long *)nullptr); });
-		f.p.enabled = 0;
-		run("col_roundtrip 1080 K=16, no filter", nwg, [&]() { hipLaunchKernelGGL((col_roundtrip_kernel<S>), dim3(nwg), dim3(S::T), S::LDS, 0, af, ai, f, (unsigned long long *)nullptr); });
+		rt_case<ColSpec<1080, 16, 512, 12, 10, 9>>(x, "col_roundtrip 1080 K=16 T=512");
+		rt_case<ColSpec<1080, 8, 256, 12, 10, 9>>(x, "col_roundtrip 1080 K=8 T=256");
+		rt_case<ColSpec<1080, 8, 512, 12, 10, 9>>(x, "col_roundtrip 1080 K=8 T=512");
 	}
 	if (strstr(which, "zoomx")) {
 		// zoom's x stage of BASELINE config 3: 2160 lines of 1920 pixels (3 floats) -> 7680 pixels; the table's values do not matter for time
