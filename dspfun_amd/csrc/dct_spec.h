@@ -409,14 +409,17 @@ struct RowSpecG {
 		if constexpr (PH == 0) {
 			if constexpr (KIND == KIND_REDFT10 && U8_OK) {
 				if (io && io->in) {       // the prefetch took four consecutive pixels per round
+					// pixels 4g, 4g + 2 are reordered samples 2g, 2g + 1 = slot g whole; 4g + 3, 4g + 1 are samples N - 2 - 2g, N - 1 - 2g = slot L - 1 - g
+					// whole: two 8-byte writes at a stride of one slot per lane.  (As four 4-byte writes at a stride of two floats every one of them
+					// was a two-way bank conflict: 40 % of this kernel's LDS cycles, profiles/r05_motion_sq.txt.)
 					static_for<0, U8_ROUNDS>([&](auto i) {
 						const int g = tid + i * T;
-						if ((i + 1) * T <= N / 4 || g < N / 4)
-							static_for<0, 4>([&](auto q) {
-								const int x = 4 * g + q, n = makhoul_dst(x, N);
-								const Re v = st.pre[i * 4 + q];
-								pf[2 * padded(n >> 1) + (n & 1)] = (x == 0) ? v * a.in_scale0 : v;
-							});
+						if ((i + 1) * T <= N / 4 || g < N / 4) {
+							Re v0 = st.pre[i * 4];
+							if constexpr (i == 0) { if (g == 0) v0 *= a.in_scale0; }
+							planes[padded(g)] = cmk<Re>(v0, st.pre[i * 4 + 2]);
+							planes[padded(L - 1 - g)] = cmk<Re>(st.pre[i * 4 + 3], st.pre[i * 4 + 1]);
+						}
 					});
 					return;
 				}
@@ -503,12 +506,13 @@ struct RowSpecG {
 					if (io && io->out) {      // four consecutive quantised pixels per dword store
 						const float mulf = (float)io->mul;
 						tloop<N / 4, T>(tid, [&](int g) {
+							// (the same two slots as REDFT10's phase 0 above, read whole; odd reordered samples carry the minus sign)
+							const CX lo = planes[g], hi = planes[L - 1 - g];
+							const Re f[4] = {lo.x, -hi.y, -lo.y, hi.x};
 							uint32_t w4 = 0;
 							static_for<0, 4>([&](auto q) {
-								const int x = 4 * g + q, n = makhoul_dst(x, N);
-								const Re sc = (x == 0) ? a.scale * a.out_scale0 : a.scale;
-								const Re f = pf[n];
-								w4 |= quantise_u8_of(((n & 1) ? -f : f) * sc, io->mul, mulf) << (8 * q);
+								const Re sc = (q == 0 && g == 0) ? a.scale * a.out_scale0 : a.scale;
+								w4 |= quantise_u8_of(f[q] * sc, io->mul, mulf) << (8 * q);
 							});
 							__builtin_memcpy(io->out + bout + 4 * g, &w4, 4);
 						});

@@ -294,8 +294,12 @@ int launch_czt_spectrum(const CztArgs &a, cf *hspec, void *stream)
 }
 
 // the same with 8-bit input (REDFT10) or quantised 8-bit output (REDFT01): planar rows only
+// Short lines (motion's 1920 / 960 sample rows: two waves a line, 8 KB of LDS) are asked to fit 64 registers so that eight waves share a SIMD: their phases are
+// a few hundred cycles of work each between barriers and global accesses, and only other workgroups fill the gaps (REDFT10 of config 5's luma clip,
+// kernel alone: 896 -> 813 us; 74 -> 64 VGPRs, no scratch).  Longer lines keep the allocator's choice (at 64 they spill).
+template <class S> constexpr int u8_waves_per_simd() { return S::N < 2048 ? 8 : S::WPE; }
 template <class S, int KIND>
-__global__ void __launch_bounds__(S::T, S::WPE) row_spec_u8_kernel(const typename S::PA a_, const U8IO io_)
+__global__ void __launch_bounds__(S::T, u8_waves_per_simd<S>()) row_spec_u8_kernel(const typename S::PA a_, const U8IO io_)
 {
 	// the 8-bit ends belong to motion's plain roundtrip: no owner-id mask, tile flags, accumulation, input window or modulation (launch_row_spec_u8 refuses
 	// them), so their per-load selects fold away as in the plain row kernels (round 5: they were a third of this kernel's first phase)
@@ -310,13 +314,16 @@ __global__ void __launch_bounds__(S::T, S::WPE) row_spec_u8_kernel(const typenam
 	typename S::template State<KIND> st;
 	long long bin, bout;
 	row_base(a, blockIdx.x, bin, bout);
+	DSP_STAMP(0);
 	S::template prefetch<KIND>(a, bin, tid, st, &io);
 	S::template phase<KIND, 0>(a, planes, bout, tid, st, &io);
 	__syncthreads();
+	DSP_STAMP(1);
 	static_for<1, S::NPH>([&](auto ph) {
 		{
 			S::template phase<KIND, ph>(a, planes, bout, tid, st, &io);
 			if constexpr (ph + 1 < S::NPH) __syncthreads();
+			DSP_STAMP(1 + ph);
 		}
 	});
 }

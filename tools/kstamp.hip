@@ -4,7 +4,7 @@
 // unstamped) -- read the phase SHARES, never compare a stamped kernel's total with an unstamped one's.
 //
 //   hipcc -std=c++17 -O3 -fno-slp-vectorize -ffp-contract=on --offload-arch=gfx950 -Idspfun_amd/csrc -Iinclude tools/kstamp.hip -o tools/kstamp
-//   tools/kstamp [pair|half|rt|zoomx]
+//   tools/kstamp [pair|half|rt|zoomx|u8]
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -90,7 +90,7 @@ template <class S> static void rt_case(float *x, const char *what)
 int main(int argc, char **argv)
 {
 	setvbuf(stdout, NULL, _IONBF, 0);
-	const char *which = argc > 1 ? argv[1] : "pair half rt zoomx";
+	const char *which = argc > 1 ? argv[1] : "pair half rt zoomx u8";
 	const int W8 = 7680, H8 = 4320;
 	const size_t n8 = (size_t)W8 * H8 * 3;
 	float *x;
@@ -101,7 +101,7 @@ int main(int argc, char **argv)
 		for (size_t i = 0; i < n8; i++) { s = s * 1664525u + 1013904223u; hx[i] = (s >> 8) * (1.0f / 16777216.0f); }
 		CK(hipMemcpy(x, hx.data(), n8 * 4, hipMemcpyHostToDevice));
 	}
-	CK(hipMalloc(&d_stamps, (size_t)65536 * 32 * 8));
+	CK(hipMalloc(&d_stamps, (size_t)300000 * 32 * 8));
 	if (strstr(which, "pair")) {
 		typedef RowSpec<7680, 3, 1024, 16, 15, 16> S;
 		PassArgs a = {};
@@ -127,6 +127,23 @@ int main(int argc, char **argv)
 		rt_case<ColSpec<1080, 16, 512, 12, 10, 9>>(x, "col_roundtrip 1080 K=16 T=512");
 		rt_case<ColSpec<1080, 8, 256, 12, 10, 9>>(x, "col_roundtrip 1080 K=8 T=256");
 		rt_case<ColSpec<1080, 8, 512, 12, 10, 9>>(x, "col_roundtrip 1080 K=8 T=512");
+	}
+	if (strstr(which, "u8")) {
+		// motion config 5's 8-bit row ends on the luma clip: 256 x 1080 lines of 1920 samples
+		typedef RowSpec<1920, 1, 128, 4, 16, 15> S;
+		const int w = 1920, lines = 1080 * 256;
+		uint8_t *p8; float *pf32;
+		CK(hipMalloc(&p8, (size_t)w * lines)); CK(hipMalloc(&pf32, (size_t)w * lines * 4));
+		CK(hipMemset(p8, 0x37, (size_t)w * lines));
+		for (int i = 0; i < 256; i += 32) CK(hipMemcpy(pf32 + (size_t)i * w * 1080, x, (size_t)w * 1080 * 32 * 4, hipMemcpyDeviceToDevice));
+		PassArgs a = {};
+		a.N = S::N; a.C = 1; a.nb0 = lines; a.nb1 = 1; a.sb0_in = a.sb0_out = w; a.nlines = lines;
+		a.in = pf32; a.out = pf32; a.T = tab_T(S::N); a.W = tab_W(S::L); a.scale = 1.f; a.in_scale0 = a.out_scale0 = 1.f;
+		U8IO io = {};
+		a.kind = 0; io.in = p8; io.out = nullptr; io.mul = 1.0;
+		run("row_spec_u8 1920 REDFT10 (u8 -> f32, 276480 lines)", lines, [&]() { hipLaunchKernelGGL((row_spec_u8_kernel<S, 0>), dim3(lines), dim3(S::T), S::LDS, 0, a, io); });
+		a.kind = 1; io.in = nullptr; io.out = p8; io.mul = 1.0 / 3840.0;
+		run("row_spec_u8 1920 REDFT01 (f32 -> u8)", lines, [&]() { hipLaunchKernelGGL((row_spec_u8_kernel<S, 1>), dim3(lines), dim3(S::T), S::LDS, 0, a, io); });
 	}
 	if (strstr(which, "zoomx")) {
 		// zoom's x stage of BASELINE config 3: 2160 lines of 1920 pixels (3 floats) -> 7680 pixels; the table's values do not matter for time
