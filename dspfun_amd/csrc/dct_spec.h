@@ -271,6 +271,10 @@ struct RowSpecG {
 	// 8-bit ends (U8IO, planar rows): a thread moves FOUR consecutive pixels as one dword, x = 4 (tid + i T) + q
 	static constexpr int U8_ROUNDS = (N / 4 + T - 1) / T;
 	static constexpr bool U8_OK = (C == 1) && (GS == 1) && (N % 4 == 0) && std::is_same<Re, float>::value;
+	// butterflies of stage I per thread, and where its twiddles start in State::stw
+	template <int I> static constexpr int stage_rounds() { return (C * (L / pack_get<I, Rs...>()) + T - 1) / T; }
+	template <int I> static constexpr int stw_off() { if constexpr (I <= 0) return 0; else return stw_off<I - 1>() + stage_rounds<I - 1>(); }
+	static constexpr int STW_N = stw_off<NS - 1>();
 	// per-thread registers that live across barriers: the last stage's butterflies and the
 	// line's global data, loaded before the first LDS phase
 	template <int KIND> struct State {
@@ -278,7 +282,22 @@ struct RowSpecG {
 		Re pre[(KIND == KIND_REDFT10 ? (U8_OK && 4 * U8_ROUNDS > PIX_ROUNDS ? 4 * U8_ROUNDS : PIX_ROUNDS) : 4 * K_ROUNDS) * C];
 		CX tw[K_ROUNDS];     // T[k] of this thread's (k, L - k) pairs, fetched with the line: a load at its point of use (REDFT01's phase 0,
 		                     // REDFT10's closing phase) is a full cache round trip in front of every line's arithmetic
+		CX stw[STW_N > 0 ? STW_N : 1];   // the stages' twiddles W[m TW] of this thread's butterflies (fetch_stage_twiddles), for the same reason
 	};
+	// Issue the loads of every stage's twiddles at the head of the kernel (round 5).  A stage used to load W[m TW] behind its barrier: a cache round
+	// trip in front of a few hundred cycles of butterflies, in each of the NS - 1 stage phases (motion's 1920-sample rows: the two stage phases
+	// took 5.2K + 5.7K of a workgroup's 26K clocks for 40 + 150 vector instructions; tools/kstamp u8).
+	template <class ST>
+	static DSP_HD void fetch_stage_twiddles(const PA &a, int tid, ST &st)
+	{
+		static_for<0, NS - 1>([&](auto I) {
+			constexpr int R = pack_get<I, Rs...>(), Lc = pack_lc<I, Rs...>(), M1 = Lc / R, NB = L / R, TW = L / Lc;
+			static_for<0, stage_rounds<I>()>([&](auto j) {
+				const int it = tid + j * T;
+				if ((j + 1) * T <= C * NB || it < C * NB) st.stw[stw_off<I>() + j] = a.W[((it % NB) % M1) * TW];
+			});
+		});
+	}
 
 	// issue the global loads of one line into registers (no LDS access, no waiting)
 	template <int KIND, class ST>
@@ -352,11 +371,14 @@ struct RowSpecG {
 	static DSP_HD int padded(int p) { return p + (p / SB) * PADC; }
 
 	// stages 0 .. NS-2 (in place, padded layout)
+	// stw: the thread's twiddles of this stage as fetch_stage_twiddles left them, or nullptr: load them here
 	template <int I, bool SEQTW = false>
-	static DSP_HD void stage(const PA &a, CX *planes, int tid)
+	static DSP_HD void stage(const PA &a, CX *planes, int tid, const CX *stw = nullptr)
 	{
 		constexpr int R = pack_get<I, Rs...>(), Lc = pack_lc<I, Rs...>(), M1 = Lc / R, NB = L / R, TW = L / Lc;
-		tloop<C * NB, T>(tid, [&](int it) {
+		static_for<0, stage_rounds<I>()>([&](auto j) {
+			const int it = tid + j * T;
+			if (!((j + 1) * T <= C * NB || it < C * NB)) return;
 			const int c = it / NB, q = it - c * NB;
 			const int blk = q / M1, m = q - blk * M1;
 			CX *p;
@@ -366,7 +388,10 @@ struct RowSpecG {
 			CX x[R];
 			static_for<0, R>([&](auto r) { x[r] = p[r * stride]; });
 			Dft<R>::run(x);
-			if constexpr (M1 > 1) { if constexpr (SEQTW) twiddle_chain_seq<R, CX>(x, a.W[m * TW]); else twiddle_chain<R, CX>(x, a.W[m * TW]); }
+			if constexpr (M1 > 1) {
+				const CX w1 = stw ? stw[stw_off<I>() + j] : a.W[m * TW];
+				if constexpr (SEQTW) twiddle_chain_seq<R, CX>(x, w1); else twiddle_chain<R, CX>(x, w1);
+			}
 			static_for<0, R>([&](auto r) { p[r * stride] = x[r]; });
 		});
 	}
@@ -402,7 +427,8 @@ struct RowSpecG {
 	}
 
 	// phase 0 consumes the prefetched registers; phases 1.. work on LDS; the last one stores to `bout`
-	template <int KIND, int PH, class ST, bool SEQTW = false>
+	// STW: st.stw holds the stages' twiddles (the caller ran fetch_stage_twiddles)
+	template <int KIND, int PH, class ST, bool SEQTW = false, bool STW = false>
 	static DSP_HD void phase(const PA &a, CX *planes, long long bout, int tid, ST &st, const U8IO *io = nullptr)
 	{
 		Re *pf = reinterpret_cast<Re *>(planes);
@@ -467,7 +493,7 @@ struct RowSpecG {
 				});
 			}
 		} else if constexpr (PH < NS) {
-			stage<PH - 1, SEQTW>(a, planes, tid);
+			if constexpr (STW) stage<PH - 1, SEQTW>(a, planes, tid, st.stw); else stage<PH - 1, SEQTW>(a, planes, tid);
 		} else if constexpr (PH == NS) {
 			last_read(planes, st, tid);
 		} else if constexpr (PH == NS + 1) {

@@ -69,11 +69,12 @@ __global__ void __launch_bounds__(S::T, S::WPE) row_spec_kernel(const typename S
 	// behind a masked column pass that skipped its empty tiles: this line's tile flags (PassGeom::zflags; one image: line = row)
 	const uint8_t *zf = a.zflags ? a.zflags + (blockIdx.x & 1) * a.zhalf : nullptr;
 	S::template prefetch<KIND>(a, bin, tid, st, nullptr, zf);
+	S::fetch_stage_twiddles(a, tid, st);
 	S::template phase<KIND, 0>(a, planes, bout, tid, st);
 	__syncthreads();
 	static_for<1, S::NPH>([&](auto ph) {
 		{
-			S::template phase<KIND, ph>(a, planes, bout, tid, st);
+			S::template phase<KIND, ph, decltype(st), false, true>(a, planes, bout, tid, st);
 			if constexpr (ph + 1 < S::NPH) __syncthreads();
 		}
 	});
@@ -316,12 +317,13 @@ __global__ void __launch_bounds__(S::T, u8_waves_per_simd<S>()) row_spec_u8_kern
 	row_base(a, blockIdx.x, bin, bout);
 	DSP_STAMP(0);
 	S::template prefetch<KIND>(a, bin, tid, st, &io);
+	S::fetch_stage_twiddles(a, tid, st);
 	S::template phase<KIND, 0>(a, planes, bout, tid, st, &io);
 	__syncthreads();
 	DSP_STAMP(1);
 	static_for<1, S::NPH>([&](auto ph) {
 		{
-			S::template phase<KIND, ph>(a, planes, bout, tid, st, &io);
+			S::template phase<KIND, ph, decltype(st), false, true>(a, planes, bout, tid, st, &io);
 			if constexpr (ph + 1 < S::NPH) __syncthreads();
 			DSP_STAMP(1 + ph);
 		}
