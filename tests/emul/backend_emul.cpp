@@ -419,6 +419,14 @@ int launch_col_roundtrip(const PassArgs &af, const PassArgs &ai, const MotionFil
 }
 #include "spec_registry.inc"
 
+// TEST-ONLY entry: the 8-bit quantiser of the fused stores (elementwise_core.h quantise_u8_of: single precision away from rounding boundaries,
+// the double path next to them) over n values, beside the double path itself
+extern "C" void emul_quantise_u8_of(const float *v, double mul, uint8_t *fast, uint8_t *exact, long long n)
+{
+	const float mulf = (float)mul;
+	for (long long i = 0; i < n; i++) { fast[i] = (uint8_t)quantise_u8_of(v[i], mul, mulf); exact[i] = quantise_u8((double)v[i] * mul); }
+}
+
 // TEST-ONLY entry: motion's filter (motion_filter.h motion_filter_at, the function the HIP kernels call per element) over one block, with the
 // arguments of dspfft_motion_filter (include/dspfft.h); returns the count of coded coefficients
 extern "C" unsigned long long emul_motion_filter(float *c, const int active[3], const int minbuf_hw[2], const int bb[3], const int be[3], float damp, float boost,

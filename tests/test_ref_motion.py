@@ -138,3 +138,29 @@ def test_quantiser_without_a_divider_is_the_float_division(q):
     coded = L.emul_motion_filter(got.ctypes.data, I3(1, 1, got.size), I2(1, got.size), I3(0, 0, 0), I3(1, 1, got.size), 1.0, 1.0, 0.0, 0.0, 0, 0.0, float(q32))
     assert np.array_equal(got, want), int((got != want).sum())
     assert coded == int((want != 0).sum())
+
+
+@pytest.mark.parametrize("mul", [1.0 / (8.0 * 1920 * 1080), 1.0 / 3840.0, 1.0, 0.3337, 255.0, 1.0 / (8.0 * 1920 * 1080 * 256)])
+def test_fused_8bit_store_is_the_double_path(mul):
+    """elementwise_core.h quantise_u8_of (what the rows' 8-bit end and the block kernels store): v * (float)mul rounded in single precision unless it
+    lies next to a rounding boundary, where motion.c:776's double expression decides -- the same byte as quantise_u8((double)v * mul) for every
+    value: 2^22 of them per multiplier, with pixel values at, just below and just above every half-integer of 0 ... 256, the clamps' neighbourhoods,
+    huge values, infinities and NaN"""
+    L = C.CDLL(emul()._name)
+    n = 1 << 22
+    rng = np.random.default_rng(int(np.float64(mul).view(np.uint64) % (1 << 32)))
+    pel = rng.uniform(-8.0, 264.0, n)
+    halves = rng.integers(-4, 520, n // 2) * 0.5                                             # k / 2: integers and halves
+    pel[: n // 2] = halves
+    v = (pel / mul).astype(np.float32)
+    v[: n // 6] = np.nextafter(v[: n // 6], np.float32(np.inf))
+    v[n // 6: n // 3] = np.nextafter(v[n // 6: n // 3], np.float32(-np.inf))
+    v[-8:] = np.array([np.inf, -np.inf, np.nan, 3e38, -3e38, 0.0, -0.0, 1e-45], dtype=np.float32)
+    fast = np.zeros(n, dtype=np.uint8); exact = np.zeros(n, dtype=np.uint8)
+    L.emul_quantise_u8_of.restype = None
+    L.emul_quantise_u8_of.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_longlong]
+    L.emul_quantise_u8_of(v.ctypes.data, mul, fast.ctypes.data, exact.ctypes.data, n)
+    ok = ~np.isnan(v)                                                                       # (NaN: the double path's conversion is the platform's; the device gives 0)
+    assert np.array_equal(fast[ok], exact[ok]), int((fast[ok] != exact[ok]).sum())
+    assert fast[np.isnan(v)].max() == 0
+    assert exact.min() == 0 and exact.max() == 255 and len(np.unique(exact)) == 256
