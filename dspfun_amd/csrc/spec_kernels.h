@@ -551,7 +551,7 @@ int launch_col_half(const typename S::PA &a, int nwork, void *stream)
 template <class S, int C>
 int launch_zoomx(const ZoomXArgs &a, int nsrc, bool clip, void *stream)
 {
-	// waves per SIMD to ask of the register allocator: what the plane's LDS lets onto a CU, at most two (256 VGPRs: the held pixel pairs + a
+	// waves per SIMD to ask of the register allocator: what the plane's LDS lets onto a CU, at most two (256 VGPRs: the held samples of two channels + a
 	// radix-16 butterfly over Pk2 need 214-244)
 	constexpr int WPE = (int)((160 * 1024) / S::LDS) * S::T / 256 >= 2 ? 2 : 1;
 	static DevOnce once;
