@@ -201,8 +201,9 @@ int dspfft_plan_many_r2r_ordered(dspfft_plan *plan, int rank, const int *n, int 
  * the default order, `inv` a REDFT01 plan created with first_axis_first = 1, in place on fwd's output layout; then
  * fwd's last pass and inv's first pass run along the same axis, and when both have a specialised column kernel
  * they execute as ONE launch: the tile stays in LDS through forward transform, filter and inverse transform
- * (8 B/sample of HBM traffic instead of 24 for that axis and the filter).  Otherwise the three steps run
- * separately.  filter == NULL skips the filter.  The filter is motion.c:683-744 (see dspfft_motion_filter below):
+ * (8 B/sample of HBM traffic instead of 24 for that axis and the filter).  Otherwise -- also when a plan carries
+ * an input window, modulation or alternating output sign on that axis (dspfft_plan_set_*: the fused kernel and the 8-bit
+ * row ends are plain instantiations) -- the three steps run separately.  filter == NULL skips the filter.  The filter is motion.c:683-744 (see dspfft_motion_filter below):
  * positions are taken inside blocks of block_depth planes of minbuf_hw[0] x minbuf_hw[1] elements (block_depth =
  * the embedding depth for one 3-D block, 1 when every frame is its own block, motion's default -b 0x0x1);
  * d_coeffs_coded (device, may be NULL) is incremented by the number of non-zero quantised coefficients.
