@@ -829,6 +829,45 @@ def test_roundtrip_u8_matches_float_path(gpu, case):
     assert np.abs(out.cpu().numpy().astype(np.float64) - np.clip(np.floor(u8 * mul + 0.5), 0, 255)).max() <= 6
 
 
+def test_roundtrip_of_a_plan_with_zooms_extras_runs_unfused(gpu):
+    """the fused column roundtrip and the 8-bit row ends are plain instantiations (round 5): an inverse plan that carries zoom's input window on the axis
+    the roundtrip fuses (its first pass), or the alternating output sign on the axis of the 8-bit end (its last pass), must take the separate passes
+    and give what executing the two plans one after the other gives -- not a failed launch"""
+    from dspfun_amd import Plan, _lib, REDFT10, REDFT01
+    L = _lib.load()
+    d, h, w = 3, 1080, 1920
+    n, dist = [h, w], h * w
+    nrm = 1.0 / (4.0 * h * w)
+    u8 = ol.synth_u8(33, d * h * w)
+    x = u8.astype(np.float32)
+    for extra in ("window", "alternate"):
+        fwd = Plan.many_r2r(n, [REDFT10] * 2, howmany=d, idist=dist, odist=dist)
+        inv = Plan.many_r2r(n, [REDFT01] * 2, howmany=d, idist=dist, odist=dist, first_axis_first=True).set_scale(nrm)
+        if extra == "window":
+            assert inv.set_input_window(0, 0, h // 3) is True           # coefficient rows from h / 3 up count as zero
+        else:
+            assert inv.set_output_alternate(1) is True
+        ref = dev(gpu, x)
+        fwd.execute(ref.data_ptr()); inv.execute(ref.data_ptr())
+        got = dev(gpu, x)
+        fwd.roundtrip(inv, got.data_ptr())
+        gpu.cuda.synchronize()
+        assert gpu.equal(got, ref)
+        r = ref.cpu().numpy().reshape(d, h, w)
+        if extra == "alternate":
+            assert np.abs(r * (1.0 - 2.0 * (np.arange(w) & 1)) - x.reshape(d, h, w)).max() < 2e-3       # the sign is there
+        else:
+            assert np.abs(r - x.reshape(d, h, w)).max() > 1.0                                            # ... and so is the window (a low-pass)
+        d8 = gpu.from_numpy(u8).to("cuda:0")
+        out = gpu.zeros(d * h * w, dtype=gpu.uint8, device="cuda:0")
+        work = gpu.empty(d * h * w, dtype=gpu.float32, device="cuda:0")
+        fwd.roundtrip_u8(inv, d8.data_ptr(), out.data_ptr(), work.data_ptr(), 1.0)
+        want = gpu.zeros(d * h * w, dtype=gpu.uint8, device="cuda:0")
+        assert L.dspfft_f32_to_u8(want.data_ptr(), ref.data_ptr(), 1.0, d * h * w, None) == 0
+        gpu.cuda.synchronize()
+        assert gpu.equal(out, want)
+
+
 @pytest.mark.parametrize("block", [(8, 8, 8), (16, 16, 4), (5, 12, 15), (4, 4, 4), (16, 16, 16), (16, 8, 8), (8, 16, 8), (4, 16, 16)])
 @pytest.mark.parametrize("dtype", ["f32", "f64"])
 def test_guru_blocks_of_a_volume(gpu, block, dtype):
