@@ -48,7 +48,8 @@
 	X(4320, 4, 512, 2, 12, 12, 15) \
 	X(540, 16, 256, 12, 5, 9) \
 	X(256, 16, 256, 4, 4, 16) \
-	X(4096, 8, 1024, 16, 16, 16)
+	X(4096, 8, 1024, 16, 16, 16) \
+	X(1080, 8, 256, 12, 10, 9) /* behind the K = 16 entry: taken only when a caller asks for it (be_find_spec's `prefer`): clip slices that the Infinity Cache holds */
 
 #define DSPFFT_COL_SPECS_B(X) \
 	X(4096, 4, 512, 16, 16, 16) \

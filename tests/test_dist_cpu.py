@@ -220,6 +220,65 @@ def test_scan_c4_bench_path_on_four_ranks():
     assert len({res[r]["ms_per_frame"] for r in range(world)}) == 1          # the MAX over ranks, agreed by all_reduce
 
 
+def _motion_c5_worker(rank, world, port, frames, planes_hw, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from emul_lib import emul
+        from bench_motion import motion_c5
+        q.put((rank, motion_c5(torch, dist, torch.device("cpu"), rank, world, reps_frames=4, reps_volume=2, frames=frames, planes_hw=planes_hw, lib=emul())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_motion_c5_bench_path_on_eight_ranks():
+    """tools/bench_motion.motion_c5 -- the function bench.py calls for its `motion_c5` object: frames_bench strong and weak, volume_bench and
+    SlabDCT3D.exchange_alone, with their barriers and the all_reduce of the time -- under eight gloo ranks with the emulation library on a clip
+    whose frame count and row counts do not divide by eight (motion/motion.c:535-552,591,613-615): the driver's first `bench.py --gpus 8` is then
+    not the first time this code runs with more than one rank.  The exchange figures are recomputed here from the object's own fields."""
+    world, frames, planes_hw = 8, 20, ((20, 24), (10, 12), (10, 12))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_motion_c5_worker, args=(r, world, port, frames, planes_hw, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    from dspfun_amd.dist import shard_range, block_range
+    # what one rank sends to the others in the all-to-alls of one direction (SlabDCT3D._buf / exchange_alone), recomputed from the geometry
+    sent = 0
+    for (h, w) in planes_hw:
+        dlp, hp = -(-frames // world), -(-h // world)
+        ch = -(-hp // min(4, hp))
+        pieces = -(-hp // ch)
+        sent += pieces * world * dlp * ch * w * 4 * (world - 1) // world
+    for rank in range(world):
+        o = res[rank]
+        s, wk, v = o["per_frame_strong"], o["per_frame_weak"], o["volume_3d"]
+        lo, hi = shard_range(frames, rank, world)
+        assert s["scaling"] == "strong" and s["frames_per_rank"] == hi - lo and s["ms_per_clip_round"] > 0 and 0 <= s["max_abs_u8_change"] < 256
+        assert wk["scaling"] == "weak" and wk["frames_per_rank"] == frames and wk["ms_per_clip_round"] > 0
+        assert "error" not in v, v
+        flo, fhi = block_range(frames, rank, world)
+        assert v["frames_per_rank"] == fhi - flo and v["ms_per_clip"] > 0 and v["exchanges_per_clip"] == 6
+        assert v["max_abs_roundtrip_error_0_255"] < 1e-3
+        assert v["exchange_ms"] is not None and v["exchange_ms"] > 0 and v["exchange_bytes_sent_per_rank"] == sent
+        frac = sent / (v["exchange_ms"] * 1e-3) / (7 * 76.8e9)
+        assert v["xgmi_frac"] is not None and abs(v["xgmi_frac"] - frac) <= 2e-3 * frac
+        assert abs(v["xgmi_GBps_sent_per_rank"] - sent / (v["exchange_ms"] * 1e-3) / 1e9) <= 2e-3 * v["xgmi_GBps_sent_per_rank"]
+    # the MAX over ranks, agreed by all_reduce
+    for key in (("per_frame_strong", "ms_per_clip_round"), ("per_frame_weak", "ms_per_clip_round"), ("volume_3d", "ms_per_clip"), ("volume_3d", "exchange_ms")):
+        assert len({res[r][key[0]][key[1]] for r in range(world)}) == 1, key
+    assert sum(res[r]["per_frame_strong"]["frames_per_rank"] for r in range(world)) == frames
+
+
 def test_x_pass_launches_per_piece():
     """one x-pass launch per piece for all full blocks (a third batch level of the row pass) + at most one for a short last block,
     whatever the number of ranks (round 3: one per rank)"""

@@ -545,7 +545,9 @@ def test_c3_zoom_4x_1080p(gpu):
     out = z.frame(4 * w, 4 * h, (4.0, 1.0), (4.0, 1.0))
     gpu.cuda.synchronize()
     sub = out[::4, ::4].cpu().numpy()
-    assert np.abs(sub - x).max() <= 2e-5
+    e_sub = np.abs(sub - x).max()
+    print(f"\nc3 dense product: max|out[::4, ::4] - in| = {e_sub:.3e} (max|in| = {np.abs(x).max():.4f})")
+    assert e_sub <= 1e-5 * np.abs(x).max()               # north_star: 1e-5 relative (whole frame: tests/test_zoom_c3_tolerance_gpu.py)
     # one full output row against the f64 restatement (row 1234 of 4320)
     L = ol.lib()
     cf = ol.dct2d_interleaved(x.astype(np.float64), ol.REDFT10, impl="port", threads=8)
@@ -557,7 +559,9 @@ def test_c3_zoom_4x_1080p(gpu):
     trow = cf[0] / 2 + np.tensordot(ybj, cf[1:], axes=(0, 0))              # (w, 3): sum over v
     XB = np.concatenate([np.full((4 * w, 1), 0.5), xb.reshape(4 * w, cw - 1)], axis=1)
     ref_row = (XB @ trow) / (w * h)
-    assert np.abs(out[j].cpu().numpy() - ref_row).max() <= 2e-5
+    e_row = np.abs(out[j].cpu().numpy() - ref_row).max()
+    print(f"c3 dense product: row {j} max|gpu - ref| = {e_row:.3e} (max|ref| = {np.abs(ref_row).max():.4f})")
+    assert e_row <= 1e-5 * np.abs(ref_row).max()
 
 
 def test_c5_motion_plane_full_size(gpu):

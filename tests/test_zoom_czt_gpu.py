@@ -114,7 +114,7 @@ def test_c3_size_centered_3p7(gpu):
     got = z.frame(*args, method="czt")
     dense = z.frame(*args, method="gemm")
     gpu.cuda.synchronize()
-    assert float((got - dense).abs().max()) <= 3e-5
+    assert float((got - dense).abs().max()) <= 1e-5 * float(dense.abs().max())     # north_star: 1e-5 relative (whole frame: tests/test_zoom_c3_tolerance_gpu.py)
     L = ol.lib()
     cf = ol.dct2d_interleaved(x.astype(np.float64), ol.REDFT10, impl="port", threads=8)
     cw = L.oracle_zoom_basis_f64(None, 1, 3.7, 1.0, 12.5, vw, w)
@@ -125,7 +125,7 @@ def test_c3_size_centered_3p7(gpu):
         ybj = np.cos(np.pi * (k + 0.5) * np.arange(1, h) / h)
         trow = cf[0] / 2 + np.tensordot(ybj, cf[1:], axes=(0, 0))
         ref_row = (XB @ trow[:cw]) / (w * h)
-        assert np.abs(got[j].cpu().numpy() - ref_row).max() <= 2e-5
+        assert np.abs(got[j].cpu().numpy() - ref_row).max() <= 1e-5 * np.abs(ref_row).max()
     for name in ("czt", "gemm"):
         for _ in range(30):
             z.frame(*args, method=name)

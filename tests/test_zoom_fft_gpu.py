@@ -103,9 +103,9 @@ def test_c3_zoom_4x_1080p_fft(gpu):
     z = Zoom(gpu, gpu.from_numpy(x).to("cuda:0"))
     out = z.frame(4 * w, 4 * h, (4.0, 1.0), (4.0, 1.0), method="fft")
     gpu.cuda.synchronize()
-    assert np.abs(out[::4, ::4].cpu().numpy() - x).max() <= 2e-5
+    assert np.abs(out[::4, ::4].cpu().numpy() - x).max() <= 1e-5 * np.abs(x).max()     # north_star: 1e-5 relative (whole frame: tests/test_zoom_c3_tolerance_gpu.py)
     dense = z.frame(4 * w, 4 * h, (4.0, 1.0), (4.0, 1.0), method="gemm")
-    assert float((out - dense).abs().max()) <= 3e-5
+    assert float((out - dense).abs().max()) <= 1e-5 * float(dense.abs().max())
     L = ol.lib()
     cf = ol.dct2d_interleaved(x.astype(np.float64), ol.REDFT10, impl="port", threads=8)
     cw = L.oracle_zoom_basis_f64(None, 0, 4.0, 1.0, 0.0, 4 * w, w)
@@ -115,7 +115,7 @@ def test_c3_zoom_4x_1080p_fft(gpu):
         trow = cf[0] / 2 + np.tensordot(ybj, cf[1:], axes=(0, 0))
         XB = np.concatenate([np.full((4 * w, 1), 0.5), xb.reshape(4 * w, cw - 1)], axis=1)
         ref_row = (XB @ trow) / (w * h)
-        assert np.abs(out[j].cpu().numpy() - ref_row).max() <= 2e-5
+        assert np.abs(out[j].cpu().numpy() - ref_row).max() <= 1e-5 * np.abs(ref_row).max()
     # timing (informative): events around 5 frames of each path
     for name in ("fft", "gemm"):
         a, b = gpu.cuda.Event(enable_timing=True), gpu.cuda.Event(enable_timing=True)

@@ -28,20 +28,26 @@ SAMPLES = FRAMES * sum(h * w for h, w in PLANES)
 XGMI_PEAK_PER_GPU = 7 * 76.8e9                                  # MI355X: seven xGMI links per GPU, 76.8 GB/s per direction each
 
 
-def _barrier(torch, dist):
-    torch.cuda.synchronize()
+def _on_gpu(torch, dev):
+    return torch.device(dev).type == "cuda"
+
+
+def _barrier(torch, dist, dev="cuda"):
+    if _on_gpu(torch, dev):
+        torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    if _on_gpu(torch, dev):
+        torch.cuda.synchronize()
 
 
 def _timed(torch, dist, dev, fn, reps):
     fn()
-    _barrier(torch, dist)
+    _barrier(torch, dist, dev)
     t0 = time.perf_counter()
     for _ in range(reps):
         fn()
-    _barrier(torch, dist)
+    _barrier(torch, dist, dev)
     dt = (time.perf_counter() - t0) / reps
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -50,10 +56,14 @@ def _timed(torch, dist, dev, fn, reps):
     return dt
 
 
-def frames_bench(torch, dist, dev, rank, world, weak, reps):
-    """per-frame blocks; weak: FRAMES frames per rank, strong: FRAMES frames over all ranks"""
+def frames_bench(torch, dist, dev, rank, world, weak, reps, frames=FRAMES, planes_hw=PLANES, lib=None):
+    """per-frame blocks; weak: `frames` frames per rank, strong: `frames` frames over all ranks.
+    frames, planes_hw, lib, dev = cpu: the CPU test of this very function (tests/test_dist_cpu.py: eight gloo ranks, a small clip, the emulation
+    library) -- bench.py and the script below use the defaults"""
     from dspfun_amd import Plan, REDFT10, REDFT01
     from dspfun_amd.dist import shard_range
+    FRAMES, PLANES = frames, planes_hw
+    SAMPLES = FRAMES * sum(h * w for h, w in PLANES)
     lo, hi = (0, FRAMES) if weak else shard_range(FRAMES, rank, world)
     nf = hi - lo
     r2 = math.sqrt(2.0)
@@ -62,8 +72,8 @@ def frames_bench(torch, dist, dev, rank, world, weak, reps):
         if not nf:
             continue
         # motion.c:644-647 with depth 1: 2 sqrt2 / sqrt2 (the z index is always 0), 1/sqrt2 more at x == 0 and at y == 0
-        fwd = Plan.many_r2r([h, w], [REDFT10] * 2, howmany=nf, idist=h * w, odist=h * w).set_scale(2.0)
-        inv = Plan.many_r2r([h, w], [REDFT01] * 2, howmany=nf, idist=h * w, odist=h * w, first_axis_first=True).set_scale(1.0 / 2.0 / (4.0 * h * w))
+        fwd = Plan.many_r2r([h, w], [REDFT10] * 2, howmany=nf, idist=h * w, odist=h * w, lib=lib).set_scale(2.0)
+        inv = Plan.many_r2r([h, w], [REDFT01] * 2, howmany=nf, idist=h * w, odist=h * w, first_axis_first=True, lib=lib).set_scale(1.0 / 2.0 / (4.0 * h * w))
         for a in range(2):
             fwd.set_axis_scale0(a, 1.0, 1.0 / r2); inv.set_axis_scale0(a, r2, 1.0)
         src = (torch.rand(nf, h, w, device=dev) * 255).to(torch.uint8)
@@ -71,7 +81,7 @@ def frames_bench(torch, dist, dev, rank, world, weak, reps):
                            flt=dict(active=(1, h, w), minbuf_hw=(h, w), block_depth=1, band_begin=(0, 0, 0), band_end=(1, h, w),
                                     quantizer=QUANT * 8 * math.sqrt(w * h))))     # motion.c:570
     coded = torch.zeros(1, dtype=torch.int64, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = torch.cuda.current_stream().cuda_stream if _on_gpu(torch, dev) else 0
 
     def clip():
         for p in planes:
@@ -87,13 +97,15 @@ def frames_bench(torch, dist, dev, rank, world, weak, reps):
             "max_abs_u8_change": err, "parallelism": f"frame-sharded x{world}, no collective"}
 
 
-def volume_bench(torch, dist, dev, rank, world, reps, chunks=None):
+def volume_bench(torch, dist, dev, rank, world, reps, chunks=None, frames=FRAMES, planes_hw=PLANES, lib=None):
     """one 3-D block per plane over the whole clip: SlabDCT3D forward + inverse (two RCCL all-to-alls per plane)"""
     from dspfun_amd.dist import SlabDCT3D
+    FRAMES, PLANES = frames, planes_hw
+    SAMPLES = FRAMES * sum(h * w for h, w in PLANES)
     chunks = int(os.environ.get("SLAB_CHUNKS", "4")) if chunks is None else chunks
     engs, vols = [], []
     for (h, w) in PLANES:
-        e = SlabDCT3D(FRAMES, h, w, chunks=chunks)
+        e = SlabDCT3D(FRAMES, h, w, chunks=chunks, lib=lib)
         engs.append(e)
         vols.append((torch.rand(e.dl, h, w, device=dev) * 255).floor())
     outs = []
@@ -114,39 +126,47 @@ def volume_bench(torch, dist, dev, rank, world, reps, chunks=None):
     # the exchange against the xGMI roofline.  The exchanges of ONE direction of the three planes (half of a roundtrip's), alone on
     # the links and each waited for: time, bytes that left this rank, and the fraction of 7 links x 76.8 GB/s per direction they ran at.  With
     # one rank there is no exchange: null.
-    exchange_ms = xgmi_gbps = xgmi_frac = None
+    exchange_ms = xgmi_gbps = xgmi_frac = exchange_bytes = None
     if world > 1:
         sent = [0]
 
         def exchanges():
             sent[0] = sum(e.exchange_alone(v) for e, v in zip(engs, vols))
         dtx = _timed(torch, dist, dev, exchanges, max(2, reps))
-        exchange_ms = round(dtx * 1e3, 3)
-        xgmi_gbps = round(sent[0] / dtx / 1e9, 1)
-        xgmi_frac = round(sent[0] / dtx / XGMI_PEAK_PER_GPU, 4)
+        exchange_ms = round(dtx * 1e3, 4)
+        exchange_bytes = int(sent[0])
+        xgmi_gbps = float(f"{sent[0] / dtx / 1e9:.6g}")
+        xgmi_frac = float(f"{sent[0] / dtx / XGMI_PEAK_PER_GPU:.6g}")
     return {"scaling": "strong", "frames_per_rank": engs[0].dl, "row_pieces": engs[0].P, "clips_timed": reps, "ms_per_clip": round(dt * 1e3, 3),
             "Msamples_per_s": round(SAMPLES / dt / 1e6), "algorithmic_GBps_per_gpu": round(SAMPLES * 16 / dt / 1e9 / world, 1),
             "alltoall_MB_sent_per_rank_per_exchange": round(a2a / 1e6, 1), "exchanges_per_clip": 2 * len(PLANES) if world > 1 else 0,
-            "exchange_ms": exchange_ms, "xgmi_GBps_sent_per_rank": xgmi_gbps, "xgmi_frac": xgmi_frac,
+            "exchange_ms": exchange_ms, "exchange_bytes_sent_per_rank": exchange_bytes, "xgmi_GBps_sent_per_rank": xgmi_gbps, "xgmi_frac": xgmi_frac,
             "exchange_note": "exchange_ms = the all-to-alls of ONE direction of the three planes (half of a clip's), alone on the links; xgmi_frac = bytes this rank "
                              "sent to the other ranks / exchange time / (7 links x 76.8 GB/s per direction); null with one rank (no exchange)",
             "max_abs_roundtrip_error_0_255": err,
             "parallelism": f"slab x{world}: 2 all-to-alls per plane roundtrip (RCCL), pipelined in {engs[0].P} row pieces"}
 
 
-def motion_c5(torch, dist, dev, rank, world, reps_frames=50, reps_volume=8):
-    """the object bench.py attaches to its JSON line (every rank must call it: the volume mode is collective)"""
-    out = {"workload": "motion on a 1920x1080x256 yuv420p clip (BASELINE configs[4]); per-frame blocks u8 -> u8 with --quant 20, and one 3-D "
+def motion_c5(torch, dist, dev, rank, world, reps_frames=50, reps_volume=8, frames=FRAMES, planes_hw=PLANES, lib=None):
+    """the object bench.py attaches to its JSON line (every rank must call it: the volume mode is collective).
+    frames, planes_hw, lib (and dev = cpu): see frames_bench"""
+    kw = dict(frames=frames, planes_hw=planes_hw, lib=lib)
+    h0, w0 = planes_hw[0]
+
+    def trim():
+        if _on_gpu(torch, dev):
+            torch.cuda.empty_cache()
+    out = {"workload": f"motion on a {w0}x{h0}x{frames} yuv420p clip (BASELINE configs[4]: 1920x1080x256); per-frame blocks u8 -> u8 with --quant 20, and one 3-D "
                        "block per plane (-b 0x0x0) float forward + inverse through SlabDCT3D",
-           "per_frame_strong": frames_bench(torch, dist, dev, rank, world, False, reps_frames)}
-    torch.cuda.empty_cache()
-    out["per_frame_weak"] = frames_bench(torch, dist, dev, rank, world, True, max(4, reps_frames // 4)) if world > 1 else "n_gpus = 1: same as per_frame_strong"
-    torch.cuda.empty_cache()
+           "per_frame_strong": frames_bench(torch, dist, dev, rank, world, False, reps_frames, **kw)}
+    trim()
+    out["per_frame_weak"] = frames_bench(torch, dist, dev, rank, world, True, max(4, reps_frames // 4), **kw) if world > 1 else "n_gpus = 1: same as per_frame_strong"
+    trim()
     try:
-        out["volume_3d"] = volume_bench(torch, dist, dev, rank, world, reps_volume)
+        out["volume_3d"] = volume_bench(torch, dist, dev, rank, world, reps_volume, **kw)
     except Exception as e:              # the collective path must not take the frame-sharded numbers down with it
         out["volume_3d"] = {"error": f"{type(e).__name__}: {e}"}
-    torch.cuda.empty_cache()
+    trim()
     return out
 
 
