@@ -28,7 +28,7 @@ SYMBOLS = [
     "dspfft_zoom_last_error", "dspfft_zoomfft_create", "dspfft_zoomfft_work_floats", "dspfft_zoomfft_execute", "dspfft_zoomfft_destroy", "dspfft_zoomfft_last_error", "dspfft_zoomczt_create", "dspfft_zoomczt_work_floats", "dspfft_zoomczt_execute", "dspfft_zoomczt_destroy",
     "dspfft_applybasis_work_floats", "dspfft_applybasis_partsums",
     "dspfft_applybasis_work_floats_ex", "dspfft_applybasis_partsums_ex", "dspfft_applybasis_render",
-    "dspfft_motion_load_u8", "dspfft_motion_store_u8", "dspfft_motion_topn_work_bytes", "dspfft_motion_topn", "dspfft_motion_last_error",
+    "dspfft_motion_load_u8", "dspfft_motion_store_u8", "dspfft_motion_load_f32", "dspfft_motion_store_f32", "dspfft_motion_topn_work_bytes", "dspfft_motion_topn", "dspfft_motion_last_error",
     "dspfft_spec_encode", "dspfft_ispec_decode", "dspfft_ispec_signmap", "dspfft_motion_filter", "dspfft_scan_pruned_accumulate", "dspfft_scan_pruned_work_floats", "dspfft_scan_pruned_accumulate_ws", "dspfft_pointwise_last_error",
 ]
 
@@ -154,6 +154,8 @@ def bind(lib):
         lib.dspfft_ispec_signmap.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]
         lib.dspfft_motion_load_u8.argtypes = [vp, vp, ip, ip, C.c_int, C.c_double, C.c_double, vp]
         lib.dspfft_motion_store_u8.argtypes = [vp, vp, ip, ip, C.c_int, C.c_double, C.c_double, C.c_double, vp]
+        lib.dspfft_motion_load_f32.argtypes = [vp, vp, ip, ip, C.c_int, C.c_double, C.c_double, vp]
+        lib.dspfft_motion_store_f32.argtypes = [vp, vp, ip, ip, C.c_int, C.c_double, C.c_double, C.c_double, vp]
         lib.dspfft_motion_topn_work_bytes.restype = C.c_size_t
         lib.dspfft_motion_topn_work_bytes.argtypes = [C.c_size_t]
         lib.dspfft_motion_topn.argtypes = [vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, vp]

@@ -67,7 +67,8 @@ inline bool chan_lines_enabled()
 	const int v = e ? atoi(e) : 1;
 	return v == 2 || (v != 0 && !g_chan_lines_suspended);
 }
-bool be_find_spec(int is_col, int N, int P, SpecInfo *info);
+// prefer_k > 0 (columns): the entry of that tile width first, where the list has one (slice plans of a clip: spec_list.h)
+bool be_find_spec(int is_col, int N, int P, SpecInfo *info, int prefer_k = 0);
 int be_launch_spec(int is_col, int id, const PassArgs &a, int nwg, void *stream);
 // the same for double samples (spec_list.h DSPFFT_*_SPECS_F64): plain passes only
 bool be_find_spec_f64(int is_col, int N, int P, SpecInfo *info);

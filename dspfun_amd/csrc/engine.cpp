@@ -210,6 +210,12 @@ struct dspfft_plan_s {
 	int alt_axis = -1;         // dspfft_plan_set_output_alternate
 	int mod_axis = -1, mod_rev = 0;          // dspfft_plan_set_input_modulation
 	const void *mod_table = nullptr;
+	bool first_axis_first = false;           // pass order (dspfft_plan_many_r2r_ordered): what a slice plan of this plan is built with
+	int col_kpref = 0;                       // column tile width asked of be_find_spec first (slice plans: the narrow tile, see RtSlices)
+	// dspfft_execute_roundtrip_u8 over a clip of frames: plans for a slice of the clip whose float intermediate the Infinity Cache holds
+	// (roundtrip_core), built on first use and owned by the forward plan
+	struct RtSlices { const dspfft_plan_s *inv_of = nullptr; int frames = 0; dspfft_plan_s *fwd = nullptr, *inv = nullptr, *fwd_rem = nullptr, *inv_rem = nullptr; void *side = nullptr, *ev_fork = nullptr, *ev_join = nullptr; };
+	std::vector<RtSlices> rt_slices;
 };
 
 namespace {
@@ -649,7 +655,7 @@ int build_pass(dspfft_plan_s *pl, int a, bool first, Pass &P)
 				// float4 tile rows: every stride that positions a tile must keep 16-B alignment
 				bool aligned = (ax.is % 4 == 0) && (ax.os % 4 == 0);
 				for (const Dim &d : rest) aligned = aligned && (d.is % 4 == 0) && (d.os % 4 == 0);
-				if (aligned && (pl->f64 ? be_find_spec_f64(1, N, inner.n, &P.spec) : be_find_spec(1, N, inner.n, &P.spec))) {
+				if (aligned && (pl->f64 ? be_find_spec_f64(1, N, inner.n, &P.spec) : be_find_spec(1, N, inner.n, &P.spec, pl->col_kpref))) {
 					P.has_spec = true; P.spa = pa;
 					P.spa.K = P.spec.P; P.spa.B = P.spec.P / 2; P.spa.ntiles = inner.n / P.spec.P;
 					P.spec_nwg = P.spa.ntiles * pa.nb0 * pa.nb1;
@@ -991,6 +997,7 @@ static int plan_finish(dspfft_plan_s *pl, dspfft_plan *plan, bool first_axis_fir
 	for (const Dim &b : pl->batches) { samples *= (size_t)b.n; pl->howmany *= b.n; }
 	for (int a = 0; a < pl->rank; a++) samples *= (size_t)pl->n[a];
 	pl->alg_bytes = samples * (pl->f64 ? 16 : 8);
+	pl->first_axis_first = first_axis_first;
 	bool first = true;
 	for (int i = 0; i < pl->rank; i++) {
 		const int a = first_axis_first ? i : pl->rank - 1 - i;
@@ -1490,9 +1497,101 @@ int run_pass_u8(const dspfft_plan_s *pl, const Pass &P, const float *in, float *
 	return 0;
 }
 
+int roundtrip_core(dspfft_plan fwd, dspfft_plan inv, const float *d_in, float *d_out, const uint8_t *d_in8, uint8_t *d_out8, double mul8,
+                   const dspfft_motion_filter_params *fp, unsigned long long *d_coeffs_coded, void *stream, bool may_slice = true);
+
+// ---- a clip of frames in slices (motion's per-frame blocks, motion/motion.c:591,613-615: the frames are independent) ----
+// The three launches of the 8-bit roundtrip move the clip's float intermediate through HBM four times (2.1 GB for config 5's luma plane).  Walked
+// in slices of S frames -- 8-bit rows -> fused column roundtrip -> 8-bit rows per slice, every slice through the SAME S frames of the work
+// buffer -- the intermediate stays in the 256 MB Infinity Cache and only the 8-bit ends touch HBM.  What that buys is bounded by the kernels,
+// which are issue- and latency-bound rather than HBM-bound (profiles/r06_motion_slices.txt): the column kernel gains 5-10 % on a resident slice
+// with the narrow K = 8 tile (four workgroups per CU; on the HBM-resident clip K = 16's 64-byte segments win), the row kernels lose a few per
+// cent to the launch tails of eleven launches instead of one.  Slices alternate between the caller's stream and one of the library's own with a
+// work area each, so that one slice's launch tails fill with the other's kernels.
+// Which plans: 2-D f32 per-frame plans with ONE batch level whose column pass has a narrow-tile entry (spec_list.h) and whose clip is larger
+// than two slices.  DSPFFT_RT_SLICE=frames forces a slice size (0: never), DSPFFT_RT_STREAMS=1 keeps every slice on the caller's stream.
+constexpr size_t kSliceBytes = 100u << 20;        // per work area (two areas in flight: 200 MB of the cache's 256)
+constexpr int kSliceTileK = 8;
+
+int slice_frames(const dspfft_plan_s *fwd, const dspfft_plan_s *inv, const dspfft_motion_filter_params *fp, int nstreams)
+{
+	static const int forced = []() { const char *e = getenv("DSPFFT_RT_SLICE"); return e ? atoi(e) : -1; }();
+	if (forced == 0 || fwd->rank != 2 || fwd->batches.size() != 1 || inv->batches.size() != 1 || fwd->passes.size() != 2 || inv->passes.size() != 2) return 0;
+	if (fwd->col_kpref || inv->col_kpref) return 0;                     // (a slice plan itself)
+	const Pass &F = fwd->passes[1], &I = inv->passes[0];
+	if (F.type != Pass::COL || I.type != Pass::COL || !F.has_spec || !I.has_spec || F.jit || I.jit) return 0;
+	SpecInfo narrow;
+	if (!be_find_spec(1, F.pa.N, F.pa.ninner, &narrow, kSliceTileK) || narrow.P != kSliceTileK || narrow.P == F.spec.P) return 0;
+	const Dim &b = fwd->batches[0];
+	const long long frame = b.os;                                       // floats between frames of the work layout
+	if (frame <= 0 || inv->batches[0].is != b.os || inv->batches[0].os != b.os) return 0;
+	long long S = forced > 0 ? forced : (long long)(kSliceBytes * (nstreams > 1 ? 1 : 2) / ((size_t)frame * sizeof(float)));
+	const int bd = fp ? fp->block_depth : 1;                            // the filter finds a frame's place in its block from its offset in the work area
+	if (bd > 1) S -= S % bd;
+	if (S < 1 || (forced <= 0 && b.n < 2 * S * nstreams)) return 0;     // nothing to gain on a clip of a slice or two
+	return (int)std::min<long long>(S, b.n);
+}
+
+dspfft_plan_s *slice_plan(const dspfft_plan_s *of, int frames)
+{
+	dspfft_plan_s *pl = new dspfft_plan_s();
+	pl->rank = of->rank; pl->scale = of->scale; pl->f64 = of->f64;
+	for (int a = 0; a < of->rank; a++) { pl->n[a] = of->n[a]; pl->kinds[a] = of->kinds[a]; pl->in0[a] = of->in0[a]; pl->out0[a] = of->out0[a]; pl->axes[a] = of->axes[a]; }
+	if (frames > 1) pl->batches.push_back(Dim{frames, of->batches[0].is, of->batches[0].os});
+	pl->col_kpref = kSliceTileK;
+	dspfft_plan out = nullptr;
+	return plan_finish(pl, &out, of->first_axis_first) ? nullptr : out;
+}
+
+// returns 1 when the clip was run in slices, 0 when this call does not qualify (the caller runs it whole), < 0 on error
+int roundtrip_sliced(dspfft_plan fwd, dspfft_plan inv, float *d_work, const uint8_t *d_in8, uint8_t *d_out8, double mul8,
+                     const dspfft_motion_filter_params *fp, unsigned long long *d_coeffs_coded, void *stream)
+{
+	static const int nstreams = []() { const char *e = getenv("DSPFFT_RT_STREAMS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v > 2 ? 2 : v; }();
+	const int S = slice_frames(fwd, inv, fp, nstreams);
+	if (!S) return 0;
+	dspfft_plan_s::RtSlices *r = nullptr;
+	for (dspfft_plan_s::RtSlices &c : fwd->rt_slices) if (c.inv_of == inv && c.frames == S) r = &c;
+	if (!r) {
+		dspfft_plan_s::RtSlices c;
+		const int total = fwd->batches[0].n, rem = total % S;
+		c.inv_of = inv; c.frames = S;
+		c.fwd = slice_plan(fwd, S); c.inv = slice_plan(inv, S);
+		if (rem) { c.fwd_rem = slice_plan(fwd, rem); c.inv_rem = slice_plan(inv, rem); }
+		if (nstreams > 1) { c.side = be_stream_create(); c.ev_fork = be_order_event_create(); c.ev_join = be_order_event_create(); }
+		const bool ok = c.fwd && c.inv && (!rem || (c.fwd_rem && c.inv_rem)) && (nstreams == 1 || (c.side && c.ev_fork && c.ev_join));
+		if (!ok) {
+			dspfft_destroy_plan(c.fwd); dspfft_destroy_plan(c.inv); dspfft_destroy_plan(c.fwd_rem); dspfft_destroy_plan(c.inv_rem);
+			if (c.side) be_stream_destroy(c.side);
+			if (c.ev_fork) be_event_destroy(c.ev_fork);
+			if (c.ev_join) be_event_destroy(c.ev_join);
+			return 0;
+		}
+		fwd->rt_slices.push_back(c);
+		r = &fwd->rt_slices.back();
+	}
+	// the parents' scales may have been set since (dspfft_plan_set_scale / _set_axis_scale0)
+	for (dspfft_plan_s *q : {r->fwd, r->fwd_rem}) if (q) { q->scale = fwd->scale; for (int a = 0; a < 2; a++) { q->in0[a] = fwd->in0[a]; q->out0[a] = fwd->out0[a]; } }
+	for (dspfft_plan_s *q : {r->inv, r->inv_rem}) if (q) { q->scale = inv->scale; for (int a = 0; a < 2; a++) { q->in0[a] = inv->in0[a]; q->out0[a] = inv->out0[a]; } }
+	const int total = fwd->batches[0].n;
+	const long long fin = fwd->batches[0].is, fwk = fwd->batches[0].os, fout = inv->batches[0].os;
+	const bool two = nstreams > 1 && r->side;
+	if (two && (be_event_record(r->ev_fork, stream) || be_stream_wait_event(r->side, r->ev_fork))) return fail(-4, "stream fork failed");
+	int k = 0;
+	for (int f0 = 0; f0 < total; f0 += S, k++) {
+		const bool last = total - f0 < S;
+		void *st = (two && (k & 1)) ? r->side : stream;
+		float *work = d_work + ((two && (k & 1)) ? (long long)S * fwk : 0);
+		if (int rc = roundtrip_core(last ? r->fwd_rem : r->fwd, last ? r->inv_rem : r->inv, nullptr, work, d_in8 + (long long)f0 * fin, d_out8 + (long long)f0 * fout, mul8,
+		                            fp, d_coeffs_coded, st, false)) return rc;
+	}
+	if (two && (be_event_record(r->ev_join, r->side) || be_stream_wait_event(stream, r->ev_join))) return fail(-4, "stream join failed");
+	return 1;
+}
+
 // d_in8 / d_out8 non-NULL: 8-bit samples at the two ends (dspfft_execute_roundtrip_u8), d_out is then the float work buffer
 int roundtrip_core(dspfft_plan fwd, dspfft_plan inv, const float *d_in, float *d_out, const uint8_t *d_in8, uint8_t *d_out8, double mul8,
-                   const dspfft_motion_filter_params *fp, unsigned long long *d_coeffs_coded, void *stream)
+                   const dspfft_motion_filter_params *fp, unsigned long long *d_coeffs_coded, void *stream, bool may_slice)
 {
 	if (!fwd || !inv || !(d_in || d_in8) || !d_out) return fail(-1, "null plan or buffer");
 	if (fwd->f64 || inv->f64) return fail(-1, "the fused roundtrip takes f32 plans");
@@ -1598,6 +1697,11 @@ int roundtrip_core(dspfft_plan fwd, dspfft_plan inv, const float *d_in, float *d
 			if (be_u8_to_f32(d_out, d_in8, (uint64_t)span, stream)) return fail(-4, "launch failed");
 			d_in = d_out; d_in8 = nullptr;
 		}
+	}
+	if (may_slice && d_in8 && d_out8 && pass_has_u8(fwd, fwd->passes[0]) && pass_has_u8(inv, inv->passes[ni - 1]) && F.axis == I.axis &&
+	    (15u & (uintptr_t)d_out) == 0 && !(getenv("DSPFFT_NO_FUSED_ROUNDTRIP") && *getenv("DSPFFT_NO_FUSED_ROUNDTRIP") == '1')) {
+		const int rc = roundtrip_sliced(fwd, inv, d_out, d_in8, d_out8, mul8, fp, d_coeffs_coded, stream);
+		if (rc) return rc < 0 ? rc : 0;
 	}
 	for (size_t i = 0; i + 1 < nf; i++) {
 		const Pass &P = fwd->passes[i];
@@ -1808,6 +1912,12 @@ extern "C" void dspfft_destroy_plan(dspfft_plan pl)
 	for (Pass &P : pl->passes) P.tab.release();
 	for (Pass &P : pl->split) P.tab.release();
 	be_free(pl->zflags); be_free(pl->zpage); be_free(pl->zranges); be_free(pl->eids);
+	for (dspfft_plan_s::RtSlices &r : pl->rt_slices) {
+		dspfft_destroy_plan(r.fwd); dspfft_destroy_plan(r.inv); dspfft_destroy_plan(r.fwd_rem); dspfft_destroy_plan(r.inv_rem);
+		if (r.side) be_stream_destroy(r.side);
+		if (r.ev_fork) be_event_destroy(r.ev_fork);
+		if (r.ev_join) be_event_destroy(r.ev_join);
+	}
 	delete pl;
 }
 
@@ -1819,6 +1929,11 @@ extern "C" int dspfft_plan_describe(dspfft_plan pl, char *buf, size_t buflen)
 	for (const Pass &P : pl->split) { s += P.desc; s += "\n"; }
 	if (pl->has_block) { s += pl->blk_desc; s += "\n"; }
 	for (const Pass &P : pl->passes) { if (!pl->split.empty() || pl->has_block) s += "plain "; s += P.desc; if (!P.hostloop.empty()) s += " +hostloop"; s += "\n"; }
+	for (const dspfft_plan_s::RtSlices &r : pl->rt_slices) {          // (present once dspfft_execute_roundtrip_u8 has walked a clip in slices)
+		char b[256];
+		snprintf(b, sizeof b, "roundtrip_u8 in slices of %d frames (last: %d) on %d stream(s): ", r.frames, r.fwd_rem ? r.fwd_rem->howmany : r.frames, r.side ? 2 : 1);
+		s += b; s += r.fwd->passes.back().desc; s += "\n";
+	}
 	snprintf(buf, buflen, "%s", s.c_str());
 	return 0;
 }

@@ -119,4 +119,29 @@ DSP_HD float4 motion_filter4(const MotionFilter &p, uint32_t e, float4 v, unsign
 	return o;
 }
 
+// ---- the two ends of motion's block loop as functions of one sample (motion_ops.hip's kernels; pinned to the reference's compiled lines through the
+// test-only emulation library: tests/test_ref_motion.py).  Scalar math in double (`intermediate` is long double in motion's build, motion/Makefile:2).
+enum { MOTION_MODE_NONE = 0, MOTION_MODE_ABS = 1, MOTION_MODE_SHIFT = 2, MOTION_MODE_FLAT = 3, MOTION_MODE_COPY = 4 };   // = DSPFFT_MOTION_* (include/dspfft.h)
+// motion.c:621-637: pel = the 8-bit sample, or the float sample * 255 (float_pixels, :623); the --ispec decode (:627-635); the value stored as a coefficient
+DSP_HD double motion_load_pel(double pel, int mode, double ic, double norm)
+{
+	switch (mode) {
+	case MOTION_MODE_SHIFT: return copysign(expm1(fabs((pel - 127.5) / ic)), pel - 127.5) / norm;
+	case MOTION_MODE_FLAT: return (pel - 127.5) * 2 / norm / norm;
+	case MOTION_MODE_COPY: return pel / norm / norm;
+	default: return pel;
+	}
+}
+// motion.c:759-771: the output pel of a coefficient before it is stored (8-bit: clamp + lround, :776; float_pixels: / 255, :774)
+DSP_HD double motion_store_pel(double c, int mode, double scalefactor, double norm, double cc)
+{
+	double pel = c * scalefactor * norm;
+	switch (mode) {
+	case MOTION_MODE_ABS: return cc * log1p(fabs(pel));
+	case MOTION_MODE_SHIFT: return cc * copysign(log1p(fabs(pel)), pel) + 127.5;
+	case MOTION_MODE_FLAT: return pel * norm / 2 + 127.5;
+	default: return pel * norm;
+	}
+}
+
 }  // namespace dspfft

@@ -11,6 +11,10 @@
 #include <stdio.h>
 
 #include "../../include/dspfft.h"
+#include "motion_filter.h"
+
+static_assert(dspfft::MOTION_MODE_NONE == DSPFFT_MOTION_NONE && dspfft::MOTION_MODE_ABS == DSPFFT_MOTION_ABS && dspfft::MOTION_MODE_SHIFT == DSPFFT_MOTION_SHIFT &&
+              dspfft::MOTION_MODE_FLAT == DSPFFT_MOTION_FLAT && dspfft::MOTION_MODE_COPY == DSPFFT_MOTION_COPY, "motion_filter.h's modes are dspfft.h's");
 
 namespace {
 
@@ -21,35 +25,28 @@ inline int mgrid(size_t n) { size_t b = (n + 255) / 256; return (int)(b < 1 ? 1 
 struct Reg { int n[3]; long long mh, mw; };
 __device__ inline size_t reg_off(const Reg &r, size_t i) { const size_t x = i % r.n[2], y = (i / r.n[2]) % r.n[1], z = i / ((size_t)r.n[2] * r.n[1]); return (z * r.mh + y) * r.mw + x; }
 
-__global__ void motion_load_kernel(float *c, const uint8_t *pix, Reg r, int mode, double ic, double norm)
+// PIX = uint8_t (the tool's default) or float (float_pixels: motion.c:623 reads sample * 255, :774 stores pel / 255)
+template <class PIX>
+__global__ void motion_load_kernel(float *c, const PIX *pix, Reg r, int mode, double ic, double norm)
 {
 	const size_t total = (size_t)r.n[0] * r.n[1] * r.n[2];
 	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
 		const size_t o = reg_off(r, i);
-		double pel = (double)pix[o];
-		switch (mode) {                                                                    // motion.c:626-634
-		case DSPFFT_MOTION_SHIFT: pel = copysign(expm1(fabs((pel - 127.5) / ic)), pel - 127.5) / norm; break;
-		case DSPFFT_MOTION_FLAT: pel = (pel - 127.5) * 2 / norm / norm; break;
-		case DSPFFT_MOTION_COPY: pel = pel / norm / norm; break;
-		default: break;
-		}
-		c[o] = (float)pel;
+		double pel;
+		if constexpr (sizeof(PIX) == 1) pel = (double)pix[o]; else pel = (double)(pix[o] * 255.0f) ;   // :623 float * int: a float product
+		c[o] = (float)dspfft::motion_load_pel(pel, mode, ic, norm);                                     // :627-637
 	}
 }
 
-__global__ void motion_store_kernel(uint8_t *pix, const float *c, Reg r, int mode, double scalefactor, double norm, double cc)
+template <class PIX>
+__global__ void motion_store_kernel(PIX *pix, const float *c, Reg r, int mode, double scalefactor, double norm, double cc)
 {
 	const size_t total = (size_t)r.n[0] * r.n[1] * r.n[2];
 	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
 		const size_t o = reg_off(r, i);
-		double pel = (double)c[o] * scalefactor * norm;                                     // motion.c:759
-		switch (mode) {                                                                     // :761-771
-		case DSPFFT_MOTION_ABS: pel = cc * log1p(fabs(pel)); break;
-		case DSPFFT_MOTION_SHIFT: pel = cc * copysign(log1p(fabs(pel)), pel) + 127.5; break;
-		case DSPFFT_MOTION_FLAT: pel = pel * norm / 2 + 127.5; break;
-		default: pel *= norm; break;
-		}
-		pix[o] = pel > 255 ? 255 : pel < 0 ? 0 : (uint8_t)lround(pel);                      // :776
+		const double pel = dspfft::motion_store_pel((double)c[o], mode, scalefactor, norm, cc);         // :759-771
+		if constexpr (sizeof(PIX) == 1) pix[o] = pel > 255 ? 255 : pel < 0 ? 0 : (uint8_t)lround(pel);  // :776
+		else pix[o] = (float)(pel / 255);                                                               // :774
 	}
 }
 
@@ -112,7 +109,16 @@ extern "C" int dspfft_motion_load_u8(float *d_coeffs, const uint8_t *d_pix, cons
 	if (!d_coeffs || !d_pix || !n || !minbuf_hw || n[0] < 1 || n[1] < 1 || n[2] < 1 || minbuf_hw[0] < n[1] || minbuf_hw[1] < n[2]) return mbad("bad arguments");
 	if (ispec_mode != DSPFFT_MOTION_NONE && ispec_mode != DSPFFT_MOTION_SHIFT && ispec_mode != DSPFFT_MOTION_FLAT && ispec_mode != DSPFFT_MOTION_COPY) return mbad("ispec mode: none, shift, flat or copy");
 	Reg r; r.n[0] = n[0]; r.n[1] = n[1]; r.n[2] = n[2]; r.mh = minbuf_hw[0]; r.mw = minbuf_hw[1];
-	hipLaunchKernelGGL(motion_load_kernel, dim3(mgrid((size_t)n[0] * n[1] * n[2])), dim3(256), 0, (hipStream_t)stream, d_coeffs, d_pix, r, ispec_mode, ic, normalization);
+	hipLaunchKernelGGL(motion_load_kernel<uint8_t>, dim3(mgrid((size_t)n[0] * n[1] * n[2])), dim3(256), 0, (hipStream_t)stream, d_coeffs, d_pix, r, ispec_mode, ic, normalization);
+	return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+extern "C" int dspfft_motion_load_f32(float *d_coeffs, const float *d_pix, const int n[3], const int minbuf_hw[2], int ispec_mode, double ic, double normalization, void *stream)
+{
+	if (!d_coeffs || !d_pix || !n || !minbuf_hw || n[0] < 1 || n[1] < 1 || n[2] < 1 || minbuf_hw[0] < n[1] || minbuf_hw[1] < n[2]) return mbad("bad arguments");
+	if (ispec_mode != DSPFFT_MOTION_NONE && ispec_mode != DSPFFT_MOTION_SHIFT && ispec_mode != DSPFFT_MOTION_FLAT && ispec_mode != DSPFFT_MOTION_COPY) return mbad("ispec mode: none, shift, flat or copy");
+	Reg r; r.n[0] = n[0]; r.n[1] = n[1]; r.n[2] = n[2]; r.mh = minbuf_hw[0]; r.mw = minbuf_hw[1];
+	hipLaunchKernelGGL(motion_load_kernel<float>, dim3(mgrid((size_t)n[0] * n[1] * n[2])), dim3(256), 0, (hipStream_t)stream, d_coeffs, d_pix, r, ispec_mode, ic, normalization);
 	return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
@@ -122,7 +128,17 @@ extern "C" int dspfft_motion_store_u8(uint8_t *d_pix, const float *d_coeffs, con
 	if (!d_coeffs || !d_pix || !n || !minbuf_hw || n[0] < 1 || n[1] < 1 || n[2] < 1 || minbuf_hw[0] < n[1] || minbuf_hw[1] < n[2]) return mbad("bad arguments");
 	if (spec_mode < DSPFFT_MOTION_NONE || spec_mode > DSPFFT_MOTION_COPY) return mbad("spec mode: none, abs, shift, flat or copy");
 	Reg r; r.n[0] = n[0]; r.n[1] = n[1]; r.n[2] = n[2]; r.mh = minbuf_hw[0]; r.mw = minbuf_hw[1];
-	hipLaunchKernelGGL(motion_store_kernel, dim3(mgrid((size_t)n[0] * n[1] * n[2])), dim3(256), 0, (hipStream_t)stream, d_pix, d_coeffs, r, spec_mode, scalefactor, normalization, c);
+	hipLaunchKernelGGL(motion_store_kernel<uint8_t>, dim3(mgrid((size_t)n[0] * n[1] * n[2])), dim3(256), 0, (hipStream_t)stream, d_pix, d_coeffs, r, spec_mode, scalefactor, normalization, c);
+	return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+extern "C" int dspfft_motion_store_f32(float *d_pix, const float *d_coeffs, const int n[3], const int minbuf_hw[2], int spec_mode,
+                                       double scalefactor, double normalization, double c, void *stream)
+{
+	if (!d_coeffs || !d_pix || !n || !minbuf_hw || n[0] < 1 || n[1] < 1 || n[2] < 1 || minbuf_hw[0] < n[1] || minbuf_hw[1] < n[2]) return mbad("bad arguments");
+	if (spec_mode < DSPFFT_MOTION_NONE || spec_mode > DSPFFT_MOTION_COPY) return mbad("spec mode: none, abs, shift, flat or copy");
+	Reg r; r.n[0] = n[0]; r.n[1] = n[1]; r.n[2] = n[2]; r.mh = minbuf_hw[0]; r.mw = minbuf_hw[1];
+	hipLaunchKernelGGL(motion_store_kernel<float>, dim3(mgrid((size_t)n[0] * n[1] * n[2])), dim3(256), 0, (hipStream_t)stream, d_pix, d_coeffs, r, spec_mode, scalefactor, normalization, c);
 	return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

@@ -328,6 +328,11 @@ int dspfft_motion_load_u8(float *d_coeffs, const uint8_t *d_pix, const int n[3],
  * or * normalization again (none / copy, :767), clamp and lround to 8 bits */
 int dspfft_motion_store_u8(uint8_t *d_pix, const float *d_coeffs, const int n[3], const int minbuf_hw[2], int spec_mode,
                            double scalefactor, double normalization, double c, void *hip_stream);
+/* the same two with float pixels (motion's float_pixels: planar float formats): the load reads sample * 255 (motion.c:623), the store writes
+ * pel / 255 unclamped (:774) */
+int dspfft_motion_load_f32(float *d_coeffs, const float *d_pix, const int n[3], const int minbuf_hw[2], int ispec_mode, double ic, double normalization, void *hip_stream);
+int dspfft_motion_store_f32(float *d_pix, const float *d_coeffs, const int n[3], const int minbuf_hw[2], int spec_mode,
+                            double scalefactor, double normalization, double c, void *hip_stream);
 /* motion.c:652-668 (--coeff-limit): keep the `keep` coefficients of largest magnitude among d_coeffs[0 .. count), zero the rest.
  * Radix select on the device (four histogram passes over the bits of |c|, no sort).  Ties at the threshold: the reference's choice
  * depends on qsort; here the earliest in buffer order are kept -- documented, deterministic. */

@@ -445,6 +445,26 @@ extern "C" unsigned long long emul_motion_filter(float *c, const int active[3], 
 	return coded;
 }
 
+// TEST-ONLY entries: the per-sample functions of motion_ops.hip's load / store kernels (motion_filter.h motion_load_pel / motion_store_pel) over a
+// {n[0], n[1], n[2]} corner of planes of minbuf_hw[0] x minbuf_hw[1], with the arguments of dspfft_motion_load_u8 / _f32 and dspfft_motion_store_u8 / _f32
+extern "C" void emul_motion_load(float *c, const void *pix, int float_pixels, const int n[3], const int minbuf_hw[2], int mode, double ic, double norm)
+{
+	for (int z = 0; z < n[0]; z++) for (int y = 0; y < n[1]; y++) for (int x = 0; x < n[2]; x++) {
+		const size_t o = ((size_t)z * minbuf_hw[0] + y) * minbuf_hw[1] + x;
+		const double pel = float_pixels ? (double)(((const float *)pix)[o] * 255.0f) : (double)((const uint8_t *)pix)[o];
+		c[o] = (float)motion_load_pel(pel, mode, ic, norm);
+	}
+}
+extern "C" void emul_motion_store(void *pix, int float_pixels, const float *c, const int n[3], const int minbuf_hw[2], int mode, double scalefactor, double norm, double cc)
+{
+	for (int z = 0; z < n[0]; z++) for (int y = 0; y < n[1]; y++) for (int x = 0; x < n[2]; x++) {
+		const size_t o = ((size_t)z * minbuf_hw[0] + y) * minbuf_hw[1] + x;
+		const double pel = motion_store_pel((double)c[o], mode, scalefactor, norm, cc);
+		if (float_pixels) ((float *)pix)[o] = (float)(pel / 255);
+		else ((uint8_t *)pix)[o] = pel > 255 ? 255 : pel < 0 ? 0 : (uint8_t)lround(pel);
+	}
+}
+
 int be_motion_filter(float *buf, const MotionFilter &filt, uint64_t span, unsigned long long *coded, void *)
 {
 	unsigned long long mine = 0;

@@ -24,6 +24,11 @@ direct-sum statement of the same transforms, and this script compiles that code 
                              motion/Makefile:1-2 builds; WITHOUT that Makefile's -ffast-math, under which the quantiser's division may become a
                              multiplication by a reciprocal -- what the compiler does then is not the reference's text)
 
+  spec/spec.h:18,22-69, spec/spec.c:66-139, spec/ispec.c:66-67,84-87,92-95,98-163   spec's own encode (DC, uniform range, gain presets incl. `reference`,
+                             range one / dc / dcs, log / linear, sign abs / shift / saturate / retain) and ispec's decode (with -p and the sign-map
+                             loop), COEFF_PRECISION=F, INTERMEDIATE_PRECISION=D  ->  tests/golden/ref_spec.npz
+  motion/motion.c:617-638,755-776 with every --ispec / --spec mode and float_pixels  ->  the io* arrays of tests/golden/ref_motion.npz
+
 The text of those line ranges is read from /root/reference at generation time into a temporary translation unit
 that includes the reference's include/precision.h (COEFF_PRECISION=L, INTERMEDIATE_PRECISION=L: the tightest build
 the reference offers) and is compiled with plain gcc -- no stand-in headers; no reference text is written to the
@@ -250,6 +255,198 @@ unsigned long long ref_motion_stages(int stages, float *coeffs_, unsigned char *
     return C.CDLL(so)
 
 
+def build_motion_io(tmp):
+    """motion.c's pixel load (:617-638, with the --ispec decodes and float_pixels) and its output stage (:755-776, with the --spec encodes,
+    the constant of `abs` from the block's DC (:755) and float_pixels), as they lie, around this script's own declarations (one component, i = 0)"""
+    tu = "#include <stdlib.h>\n#include <stdint.h>\n#include <stdbool.h>\n#include <string.h>\n#include <math.h>\n#include \"precision.h\"\n#include \"keyed_enum.h\"\n"
+    tu += lines("motion/motion.c", 18, 35) + lines("motion/motion.c", 58, 60)
+    decl = """
+	const int components = 1, i = 0;
+	coords minbuf = {{minbuf_[0], minbuf_[1], minbuf_[2]}}, scaled = {{scaled_[0], scaled_[1], scaled_[2]}}, block = {{block_[0], block_[1], block_[2]}};
+	intermediate threshold_min = 0, threshold_max = 0, quant = 0;
+	enum spectype spec = spec_;
+	enum ispectype ispec = ispec_;
+	bool float_pixels = float_pixels_, linear = false, dithering = false;
+	intermediate (*input_trc)(intermediate) = NULL, (*output_trc)(intermediate) = NULL;
+	coeff *coeffs = coeffs_;
+	void *pblock = pblock_;
+	size_t mincomponent = minbuf[0].w * minbuf[0].h * minbuf[0].d;
+"""
+    tu += """
+/* c_ic_out[0] = c[0], [1] = ic[0] (motion.c:568-569) */
+void ref_motion_load(float *coeffs_, void *pblock_, const uint64_t *minbuf_, const uint64_t *scaled_, const uint64_t *block_, int ispec_, int float_pixels_, long double *c_ic_out)
+{
+	const int spec_ = 0;
+""" + decl
+    tu += lines("motion/motion.c", 559, 573)
+    tu += lines("motion/motion.c", 617, 638)
+    tu += "\tc_ic_out[0] = c[0]; c_ic_out[1] = ic[0];\n\t(void)components; (void)linear; (void)dithering; (void)input_trc; (void)output_trc; (void)quantizer; (void)threshold; (void)scalefactor; (void)mincomponent;\n}\n"
+    tu += """
+/* dc_: the block's DC coefficient as :650 takes it before the filters */
+void ref_motion_store(float *coeffs_, void *pblock_, const uint64_t *minbuf_, const uint64_t *scaled_, const uint64_t *block_, int spec_, int float_pixels_, float dc_, long double *c_ic_out)
+{
+	const int ispec_ = 0;
+	coeff dc = dc_;
+""" + decl
+    tu += lines("motion/motion.c", 559, 573)
+    tu += "\tif(!spec) {}\n" + lines("motion/motion.c", 755, 776) + "\t\t\t\t\t\t}\n"
+    tu += "\tc_ic_out[0] = c[0]; c_ic_out[1] = ic[0];\n\t(void)components; (void)linear; (void)dithering; (void)input_trc; (void)output_trc; (void)quantizer; (void)threshold; (void)mincomponent; (void)ispec;\n}\n"
+    src = os.path.join(tmp, "motion_io.c")
+    so = os.path.join(tmp, "motion_io.so")
+    with open(src, "w") as f:
+        f.write(tu)
+    subprocess.check_call(["gcc", "-std=c11", "-D_GNU_SOURCE", "-DCOEFF_PRECISION=F", "-DINTERMEDIATE_PRECISION=L", "-O2", "-fPIC", "-shared", "-w",
+                           "-I" + os.path.join(REF, "include"), src, "-o", so, "-lm"])
+    return C.CDLL(so)
+
+
+ISPEC = {"none": 0, "shift": 1, "flat": 2, "copy": 3}             # enum ispectype (motion.c:24-27 through keyed_enum.h: none first)
+SPEC = {"none": 0, "abs": 1, "shift": 2, "flat": 3, "copy": 4}    # enum spectype (motion.c:18-22)
+
+
+def motion_io_fixtures(tmp, out):
+    """io{g}_*: the pixel load and the output stage for every --ispec / --spec mode, 8-bit and float pixels, on blocks embedded in a larger buffer"""
+    mo = build_motion_io(tmp)
+    vp = C.c_void_p
+    mo.ref_motion_load.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
+    mo.ref_motion_store.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp]
+    u64 = lambda *v: np.array(v, dtype=np.uint64)
+    geoms = [((2, 9, 16), (2, 12, 20)), ((1, 45, 80), (1, 48, 84))]        # (d, h, w) block = scaled inside minbuf (d, h, w)
+    out["io_geoms"] = np.array([[*a, *m] for a, m in geoms], dtype=np.int64)
+    for g, ((d, h, w), (md, mh, mw)) in enumerate(geoms):
+        n = md * mh * mw
+        MB, A = u64(mw, mh, md), u64(w, h, d)
+        pix8 = (splitmix64_stream(0xD5F1C00 + g, n) >> np.uint64(56)).astype(np.uint8)
+        pixf = synth_f32(0xD5F1D00 + g, n)
+        out[f"io{g}_pix_u8"] = pix8
+        out[f"io{g}_pix_f32"] = pixf
+        cic = np.zeros(2, dtype=np.longdouble)
+        for name, code in ISPEC.items():
+            for fpx, pix in ((0, pix8), (1, pixf)):
+                cbuf = np.full(n, np.float32(-77.0))                            # (:617 zeroes the whole buffer first)
+                p = pix.copy()
+                mo.ref_motion_load(cbuf.ctypes.data, p.ctypes.data, MB.ctypes.data, A.ctypes.data, A.ctypes.data, code, fpx, cic.ctypes.data)
+                out[f"io{g}_load_{name}_{'f32' if fpx else 'u8'}"] = cbuf
+                if name == "shift":
+                    out[f"io{g}_ic"] = np.array([float(cic[1])])
+        # coefficients of the size the uniform-range forward transform of 8-bit samples leaves (motion_fixtures), DC the largest
+        x = ((synth_f32(0xD5F1E00 + g, n) * 2 - 1) * np.float32(255.0 * np.sqrt(8.0 * w * h * d)) * (synth_f32(0xD5F1F00 + g, n) ** 6)).astype(np.float32)
+        x[0] = np.float32(127.0 * np.sqrt(8.0 * w * h * d))
+        out[f"io{g}_coeffs"] = x
+        for name, code in SPEC.items():
+            for fpx in (0, 1):
+                pb = np.zeros(n, dtype=np.float32 if fpx else np.uint8)
+                cb = x.copy()
+                mo.ref_motion_store(cb.ctypes.data, pb.ctypes.data, MB.ctypes.data, A.ctypes.data, A.ctypes.data, code, fpx, float(x[0]), cic.ctypes.data)
+                out[f"io{g}_store_{name}_{'f32' if fpx else 'u8'}"] = pb
+                if name in ("abs", "shift") and not fpx:
+                    out[f"io{g}_c_{name}"] = np.array([float(cic[0])])
+        print("motion io geometry", g, (d, h, w), (md, mh, mw))
+
+
+def build_spec(tmp):
+    """spec/spec.c:66-139 (DC, uniform range, gain, range, scale, sign) and spec/ispec.c:66-67,84-87,92-95,98-163 (the decode, with the sign-map
+    pixel loop but without the MagickWand calls that read the map image, :88-91,96-97) as they lie, around this script's own declarations;
+    enums and option structs from spec/spec.h:18,22-69 by line range (the header itself includes fftw3.h and MagickWand).
+    COEFF_PRECISION=F, INTERMEDIATE_PRECISION=D: the build whose types dspfft_spec_encode / dspfft_ispec_decode have (float samples, double scalars)."""
+    tu = "#include <stdlib.h>\n#include <stdint.h>\n#include <stdbool.h>\n#include <string.h>\n#include <math.h>\n#include \"precision.h\"\n#include \"keyed_enum.h\"\n"
+    tu += lines("spec/spec.h", 18, 18) + lines("spec/spec.h", 22, 69)
+    tu += """
+/* f_: w*h*d_ raw REDFT10^2 outputs (spec.c:64); normalised_: f after :78; DC_out: :66-68; gain_out: :81-87 */
+void ref_spec(float *f_, size_t w, size_t h, size_t d_, int scaletype, int signtype, int gaintype, int rangetype, double custom_gain, float *normalised_, double *DC_out, double *gain_out)
+{
+	struct specopts opts = {0};
+	opts.params = (struct specparams){scaletype, signtype, gaintype, rangetype};
+	opts.gain = custom_gain;
+	size_t l = w * h * d_, d = d_;
+	size_t i, y, z;
+	coeff *f = f_;
+"""
+    tu += lines("spec/spec.c", 66, 78)
+    tu += "\tmemcpy(normalised_, f, l * sizeof(coeff)); memcpy(DC_out, DC, d * sizeof(double));\n"
+    tu += lines("spec/spec.c", 81, 139)
+    tu += "\t*gain_out = gain;\n}\n"
+    tu += """
+/* f_: the spectrogram samples; DC_: the header's DC terms (overwritten from the map when map_ is given, ispec.c:92-93); map_: 8-bit sign map or NULL */
+void ref_ispec(float *f_, size_t w, size_t h, size_t d_, int scaletype, int signtype, int gaintype, int rangetype, double custom_gain, double *DC_, int preserve_dc_, unsigned char *map_, double *gain_out)
+{
+	struct specopts opts = {0};
+	opts.params = (struct specparams){scaletype, signtype, gaintype, rangetype};
+	opts.gain = custom_gain;
+	size_t l = w * h * d_, d = d_;
+	size_t i, y, z;
+	coeff *f = f_;
+	bool preserve_dc = preserve_dc_;
+	const char *signmap = map_ ? "map" : NULL;
+"""
+    tu += lines("spec/ispec.c", 66, 67)
+    tu += "\tmemcpy(DC, DC_, d * sizeof(double));\n"
+    tu += lines("spec/ispec.c", 84, 87) + "\t\t\tunsigned char* tmp = map_;\n" + lines("spec/ispec.c", 92, 95) + lines("spec/ispec.c", 98, 163)
+    tu += "\t*gain_out = gain; memcpy(DC_, DC, d * sizeof(double));\n}\n"
+    src = os.path.join(tmp, "spec.c")
+    so = os.path.join(tmp, "spec.so")
+    with open(src, "w") as f:
+        f.write(tu)
+    subprocess.check_call(["gcc", "-std=c11", "-D_GNU_SOURCE", "-DCOEFF_PRECISION=F", "-DINTERMEDIATE_PRECISION=D", "-O2", "-fPIC", "-shared", "-w",
+                           "-I" + os.path.join(REF, "include"), src, "-o", so, "-lm"])
+    return C.CDLL(so)
+
+
+# spec/spec.h:29-47 through keyed_enum.h (`none` first)
+SPEC_SIGN = {"abs": 1, "shift": 2, "saturate": 3, "retain": 4}
+SPEC_RANGE = {"one": 1, "dc": 2, "dcs": 3}
+SPEC_SCALE = {"linear": 1, "log": 2}
+SPEC_GAIN = {"native": 1, "reference": 2, "custom": 3}
+
+
+def spec_fixtures(tmp):
+    """tests/golden/ref_spec.npz: every range x scale x sign combination of spec's encode and ispec's decode (the three gain presets cycled over
+    them), one- and three-channel images; ispec additionally with -p (preserve DC) and with a sign map for the `abs` spectrograms"""
+    sp = build_spec(tmp)
+    vp, st = C.c_void_p, C.c_size_t
+    sp.ref_spec.argtypes = [vp, st, st, st, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, vp, vp, vp]
+    sp.ref_ispec.argtypes = [vp, st, st, st, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, vp, C.c_int, vp, vp]
+    out = {}
+    cases = []
+    k = 0
+    for (h, w, d) in ((9, 16, 3), (12, 10, 1)):
+        l = h * w * d
+        # raw REDFT10^2 outputs of an image in [0, 1): DC = 4 w h mean, the rest decays with frequency
+        img = synth_f32(0xD5F2000 + d, l).reshape(h, w, d).astype(np.float64)
+        yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+        raw = (rnd(0xD5F2100 + d, l).reshape(h, w, d) * (4.0 * w * h) / (1.0 + yy + xx)[..., None] ** 1.5)
+        raw[0, 0] = 4.0 * w * h * img.mean(axis=(0, 1)) * (1.0 + 0.2 * np.arange(d))
+        raw = raw.astype(np.float32)
+        for rname, rcode in SPEC_RANGE.items():
+            for sname, scode in SPEC_SCALE.items():
+                for gname, gcode in SPEC_SIGN.items():
+                    gain_name = list(SPEC_GAIN)[k % 3]
+                    custom = 96.0 + k
+                    f = raw.copy().ravel()
+                    normalised = np.zeros(l, dtype=np.float32)
+                    DC = np.zeros(d); gain = np.zeros(1)
+                    sp.ref_spec(f.ctypes.data, w, h, d, scode, gcode, SPEC_GAIN[gain_name], rcode, custom, normalised.ctypes.data, DC.ctypes.data, gain.ctypes.data)
+                    out[f"s{k}_raw"] = raw.ravel().copy(); out[f"s{k}_normalised"] = normalised; out[f"s{k}_encoded"] = f.copy(); out[f"s{k}_dc"] = DC.copy()
+                    for pdc in (0, 1):
+                        g2 = f.copy(); DC2 = DC.copy(); gain2 = np.zeros(1)
+                        sp.ref_ispec(g2.ctypes.data, w, h, d, scode, gcode, SPEC_GAIN[gain_name], rcode, custom, DC2.ctypes.data, pdc, None, gain2.ctypes.data)
+                        out[f"s{k}_decoded_p{pdc}"] = g2
+                        assert gain2[0] == gain[0]
+                    if gname == "abs":
+                        # the sign map spec -t sign writes: 8-bit samples of the `saturate` spectrogram (1 -> 255, 0 -> 0), first pixel = the DC terms
+                        smap = np.where(normalised >= 0, 255, 0).astype(np.uint8)
+                        smap[:d] = np.clip(np.round(DC * 255), 0, 255).astype(np.uint8)
+                        g3 = f.copy(); DC3 = DC.copy(); gain3 = np.zeros(1)
+                        sp.ref_ispec(g3.ctypes.data, w, h, d, scode, gcode, SPEC_GAIN[gain_name], rcode, custom, DC3.ctypes.data, 1, smap.ctypes.data, gain3.ctypes.data)
+                        out[f"s{k}_signmap"] = smap; out[f"s{k}_decoded_signmap"] = g3; out[f"s{k}_dc_signmap"] = DC3.copy()
+                    cases.append([h, w, d, rcode, scode, gcode, SPEC_GAIN[gain_name], custom, gain[0]])
+                    k += 1
+    out["cases"] = np.array(cases, dtype=np.float64)
+    path = os.path.join(HERE, "ref_spec.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), len(cases), "cases")
+
+
 def motion_fixtures(tmp):
     """inputs and outputs of motion's elementwise stages on blocks embedded in a larger buffer; every stage alone and the whole chain"""
     mo = build_motion(tmp)
@@ -299,6 +496,7 @@ def motion_fixtures(tmp):
         out[f"m{ci}_store_in"] = cb
         out[f"m{ci}_store_u8"] = pb.copy()
         print("motion case", ci, a, m)
+    motion_io_fixtures(tmp, out)
     path = os.path.join(HERE, "ref_motion.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path))
@@ -422,7 +620,9 @@ def main():
             scan_fixtures(tmp)
         if len(sys.argv) < 2 or sys.argv[1] == "motion":
             motion_fixtures(tmp)
-        if len(sys.argv) > 1 and sys.argv[1] in ("scan", "motion"):
+        if len(sys.argv) < 2 or sys.argv[1] == "spec":
+            spec_fixtures(tmp)
+        if len(sys.argv) > 1 and sys.argv[1] in ("scan", "motion", "spec"):
             return
         sz = build_scan_zoom(tmp)
         ab = build_applybasis(tmp)

@@ -164,3 +164,82 @@ def test_fused_8bit_store_is_the_double_path(mul):
     assert np.array_equal(fast[ok], exact[ok]), int((fast[ok] != exact[ok]).sum())
     assert fast[np.isnan(v)].max() == 0
     assert exact.min() == 0 and exact.max() == 255 and len(np.unique(exact)) == 256
+
+
+# ---- the pixel load (motion.c:617-638) and the output stage (:755-776) with every --ispec / --spec mode, 8-bit and float pixels ----
+IO_GEOMS = [tuple(int(v) for v in r) for r in FIX["io_geoms"]]
+ISPEC_MODES = {"none": 0, "shift": 2, "flat": 3, "copy": 4}                 # DSPFFT_MOTION_* (include/dspfft.h)
+SPEC_MODES = {"none": 0, "abs": 1, "shift": 2, "flat": 3, "copy": 4}
+
+
+def io_consts(g):
+    """scalefactor, normalization (motion.c:566-567; block == scaled in the fixtures) and the constants :568-569,755 as the reference computed them"""
+    d, h, w = IO_GEOMS[g][:3]
+    return 1.0, float(1 / np.sqrt(np.longdouble(w * h * d * 8))), {"shift": float(FIX[f"io{g}_c_shift"][0]), "abs": float(FIX[f"io{g}_c_abs"][0])}, float(FIX[f"io{g}_ic"][0])
+
+
+def corner(a, g):
+    d, h, w, md, mh, mw = IO_GEOMS[g]
+    return a.reshape(md, mh, mw)[:d, :h, :w]
+
+
+def check_load(got, g, name, px):
+    """coefficients are `coeff` (float) values of long double expressions in the reference, of double ones here: the same float but for the rare
+    value whose two roundings straddle; outside the block the reference's buffer is zero (:617) and the load writes nothing there"""
+    ref = corner(FIX[f"io{g}_load_{name}_{px}"], g).astype(np.float64)
+    err = np.abs(corner(got, g).astype(np.float64) - ref)
+    assert (err <= np.spacing(np.abs(ref).astype(np.float32)).astype(np.float64)).all(), (g, name, px, err.max())
+    assert (err > 0).mean() <= 0.01
+
+
+def check_store(got, g, name, px):
+    ref = corner(FIX[f"io{g}_store_{name}_{px}"], g)
+    out = corner(got, g)
+    if px == "u8":
+        diff = np.abs(out.astype(int) - ref.astype(int))
+        assert diff.max() <= 1 and (diff > 0).mean() <= 0.002, (g, name, diff.max(), (diff > 0).mean())      # (a pel within 1e-16 of a half rounds either way)
+    else:
+        err = np.abs(out.astype(np.float64) - ref.astype(np.float64))
+        assert (err <= np.spacing(np.abs(ref))).all() and (err > 0).mean() <= 0.01, (g, name, err.max())
+
+
+@pytest.mark.parametrize("g", range(len(IO_GEOMS)))
+@pytest.mark.parametrize("px", ["u8", "f32"])
+@pytest.mark.parametrize("name", list(ISPEC_MODES))
+def test_load_functions_of_the_kernels_are_the_references(g, px, name):
+    d, h, w, md, mh, mw = IO_GEOMS[g]
+    _, norm, _, ic = io_consts(g)
+    E = emul()
+    E.emul_motion_load.restype = None
+    E.emul_motion_load.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double]
+    pix = FIX[f"io{g}_pix_{px}"].copy()
+    c = np.zeros(md * mh * mw, dtype=np.float32)
+    E.emul_motion_load(c.ctypes.data, pix.ctypes.data, int(px == "f32"), I3(d, h, w), I2(mh, mw), ISPEC_MODES[name], ic, norm)
+    check_load(c, g, name, px)
+    assert not corner(c, g)[..., :0].size and c.reshape(md, mh, mw)[:, h:, :].max(initial=0) == 0 and c.reshape(md, mh, mw)[:, :, w:].max(initial=0) == 0
+
+
+@pytest.mark.parametrize("g", range(len(IO_GEOMS)))
+@pytest.mark.parametrize("px", ["u8", "f32"])
+@pytest.mark.parametrize("name", list(SPEC_MODES))
+def test_store_functions_of_the_kernels_are_the_references(g, px, name):
+    d, h, w, md, mh, mw = IO_GEOMS[g]
+    sf, norm, cc, _ = io_consts(g)
+    E = emul()
+    E.emul_motion_store.restype = None
+    E.emul_motion_store.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double]
+    out = np.zeros(md * mh * mw, dtype=np.float32 if px == "f32" else np.uint8)
+    coeffs = FIX[f"io{g}_coeffs"]                 # (kept alive across the call: the archive hands out a new array per access)
+    E.emul_motion_store(out.ctypes.data, int(px == "f32"), coeffs.ctypes.data, I3(d, h, w), I2(mh, mw), SPEC_MODES[name], sf, norm, cc.get(name, 0.0))
+    check_store(out, g, name, px)
+
+
+def test_spectrogram_constants_are_the_references():
+    """c of --spec shift / ic of --ispec shift (motion.c:568-569) and c of --spec abs from the block's DC (:755), as tests/motion_ref.py restates them"""
+    for g in range(len(IO_GEOMS)):
+        d, h, w = IO_GEOMS[g][:3]
+        sf, norm, cc, ic = io_consts(g)
+        want = 127.5 / np.log1p(w * h * d * norm * 255 * 8)
+        assert abs(cc["shift"] - want) <= 1e-12 * want and abs(ic - want) <= 1e-12 * want
+        dc = float(FIX[f"io{g}_coeffs"][0])
+        assert abs(cc["abs"] - 255.0 / np.log1p(abs(dc * sf * norm))) <= 1e-12 * cc["abs"]
