@@ -250,6 +250,7 @@ struct RowSpecG {
 	typedef cx<Re_> CX;
 	typedef PassArgsT<Re_> PA;
 	static constexpr int N = N_, C = C_, GS = GS_, T = T_, L = N_ / 2, NS = (int)sizeof...(Rs), NPH = NS + 3;
+	template <int T2> using with_threads = RowSpecG<Re_, N_, C_, GS_, T2, Rs...>;      // the same line on another workgroup size
 	static_assert(GS_ == C_ || C_ == 1, "channel lines hold one channel");
 	// min waves per SIMD asked of the register allocator.  double: as many workgroups as the line's LDS allows, capped at 4 (128 VGPRs);
 	// left alone the allocator spends 140+ on the double kernels and a second workgroup no longer fits a CU
@@ -583,6 +584,82 @@ struct RowSpecG {
 					});
 				}
 			}
+		}
+	}
+
+	// ---- a plain line's outputs as VALUES (row_pair_pipe_kernel: the pair's butterfly moved to the output side) ----
+	// The closing phase of a plain pass (phase<KIND, NS + 2> without 8-bit ends, accumulation or alternating sign) with its stores replaced by
+	// f(slot, offset of the pixel within the line in samples, pixel): `slot` is a compile-time index < OUT_SLOTS that names the same pixel in every line
+	// of this thread, called for the pixels this thread owns only.
+	template <int KIND> static constexpr int out_slots() { return KIND == KIND_REDFT10 ? 4 * K_ROUNDS : PIX_ROUNDS; }
+	template <int KIND> struct OutHold { Pix<C, Re> v[out_slots<KIND>()]; };
+	template <int KIND, class ST, class F>
+	static DSP_HD void final_each(const PA &a, const CX *planes, int tid, const ST &st, F &&f)
+	{
+		if constexpr (KIND == KIND_REDFT10) {
+			static_for<0, K_ROUNDS>([&](auto ri) {
+				const int k = tid + ri * T;
+				if (!((ri + 1) * T <= L / 2 + 1 || k <= L / 2)) return;
+				const int km = k ? L - k : 0;
+				const CX tk = st.tw[ri];
+				const CX tlk = cmul(cconj(tk), cmk<Re>((Re)0.70710678118654752440, (Re)-0.70710678118654752440));
+				const CX t1 = csqr(csqr(tk));
+				Pix<C, Re> o0, o1, o2, o3;
+				static_for<0, C>([&](auto c) {
+					const CX zk = planes[c * PL + k];
+					const CX zm = cconj(planes[c * PL + km]);
+					const CX E = cadd(zk, zm);
+					const CX D = cmul_mi(csub(zk, zm));
+					const CX P = cmul(t1, D);
+					const CX wk = cmul(tk, cadd(E, P));
+					const CX wm = cmul(tlk, cconj(csub(E, P)));
+					const Re sc = a.scale;
+					o0.v[c] = wk.x * (k == 0 ? sc * a.out_scale0 : sc);
+					o1.v[c] = -wk.y * sc;
+					o2.v[c] = wm.x * sc;
+					o3.v[c] = -wm.y * sc;
+				});
+				f(std::integral_constant<int, ri * 4 + 0>(), (long long)k * GS, o0);
+				if (k > 0) f(std::integral_constant<int, ri * 4 + 1>(), (long long)(N - k) * GS, o1);
+				if (L - k != k) f(std::integral_constant<int, ri * 4 + 2>(), (long long)(L - k) * GS, o2);
+				if (k > 0 && L + k != N - k) f(std::integral_constant<int, ri * 4 + 3>(), (long long)(L + k) * GS, o3);
+			});
+		} else {
+			const Re *pf = reinterpret_cast<const Re *>(planes);
+			static_assert(T % 4 == 0, "a thread's pixels share a parity and a low bit");
+			const unsigned odd = (unsigned)tid & 1u, n0 = odd ? (unsigned)(N - 1) - ((unsigned)tid >> 1) : ((unsigned)tid >> 1);
+			const int dn = odd ? -(T / 2) : (T / 2);
+			const Re sg = (n0 & 1u) ? -a.scale : a.scale;
+			static_for<0, PIX_ROUNDS>([&](auto i) {
+				const int x = tid + i * T;
+				if (!((i + 1) * T <= N || x < N)) return;
+				const int n = (int)n0 + i * dn;
+				Pix<C, Re> o;
+				Re sc = sg;
+				if constexpr (i == 0) { if (x == 0) sc *= a.out_scale0; }
+				static_for<0, C>([&](auto c) { o.v[c] = pf[c * (2 * PL) + n] * sc; });
+				f(std::integral_constant<int, i>(), (long long)x * GS, o);
+			});
+		}
+	}
+	// the pixels final_each hands out, by slot: g(slot, offset within the line) for the slots this thread owns (the stores of a held line)
+	template <int KIND, class G>
+	static DSP_HD void out_each(int tid, G &&g)
+	{
+		if constexpr (KIND == KIND_REDFT10) {
+			static_for<0, K_ROUNDS>([&](auto ri) {
+				const int k = tid + ri * T;
+				if (!((ri + 1) * T <= L / 2 + 1 || k <= L / 2)) return;
+				g(std::integral_constant<int, ri * 4 + 0>(), (long long)k * GS);
+				if (k > 0) g(std::integral_constant<int, ri * 4 + 1>(), (long long)(N - k) * GS);
+				if (L - k != k) g(std::integral_constant<int, ri * 4 + 2>(), (long long)(L - k) * GS);
+				if (k > 0 && L + k != N - k) g(std::integral_constant<int, ri * 4 + 3>(), (long long)(L + k) * GS);
+			});
+		} else {
+			static_for<0, PIX_ROUNDS>([&](auto i) {
+				const int x = tid + i * T;
+				if ((i + 1) * T <= N || x < N) g(std::integral_constant<int, i>(), (long long)x * GS);
+			});
 		}
 	}
 

@@ -427,6 +427,105 @@ __global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_kerne
 	}
 }
 
+// ---- row pairs of lines that fill a CU's LDS on their own (7680 x 3 floats: 92 KB, ONE workgroup per CU), software-pipelined (round 6) ----
+// row_pair_kernel loads both lines, waits, and transforms (r1 + r2) and (r1 - r2): with a single resident workgroup nothing overlaps the load wait or the
+// workgroup's turnover (tools/kstamp: 3.6K of a pair's 41K stamped clocks wait for the loads).  The transform is linear, so the pair's butterfly can sit
+// on the OUTPUT side instead: out1 = T(r1) + T(r2), out2 = T(r1) - T(r2).  Then the lines are needed one at a time, and a persistent workgroup (one per
+// CU walks the pairs) fetches every line ONE TRANSFORM AHEAD into the registers that phase 0 of the previous line has just emptied -- the same 24
+// registers per thread the waiting line occupies today, no LDS: T(r1)'s outputs wait in registers (as the difference line does today) while r2 is
+// transformed, and the pair's two output lines are stored after phase 0 of the NEXT line, so that no store sits between a line's loads and their use
+// (vmcnt is in-order) and the stores drain under the next line's stages.  The stage twiddles W and T[k] live in LDS (45 KB beside the 92 KB plane:
+// a vector-memory load between a prefetch and its use would wait for it, see row_persist_kernel).  Plain passes only (the fused scan step's masked /
+// accumulating pair pass keeps row_pair_kernel).
+#ifndef DSP_PAIR_PIPE_T
+#define DSP_PAIR_PIPE_T 768
+#endif
+// `v` holds nothing worth keeping from here on: every register of it is (re)defined by an empty asm statement, which costs no instruction and ends
+// the old values' live ranges.  State that is written under per-thread conditions (the last, partly filled round of a phase) otherwise stays alive
+// around a persistent kernel's whole loop as far as the register allocator can tell.
+template <int I, int N> __device__ __forceinline__ void forget_regs(float *p)
+{
+	if constexpr (I < N) { float f; asm volatile("" : "=v"(f)); p[I] = f; forget_regs<I + 1, N>(p); }
+}
+template <class V> __device__ __forceinline__ void forget(V &v)
+{
+	static_assert(sizeof(V) % 4 == 0, "registers");
+	forget_regs<0, (int)(sizeof(V) / 4)>(reinterpret_cast<float *>(&v));
+}
+template <class S> constexpr size_t pair_pipe_lds() { return S::LDS + sizeof(typename S::CX) * (size_t)(S::L + S::L / 2 + 1); }
+template <class S> constexpr bool pair_pipe_ok() { return S::C > 1 && S::LDS > 80 * 1024 && pair_pipe_lds<S>() <= 160 * 1024; }
+template <class S, int KIND>
+__global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_pipe_kernel(const typename S::PA a_, int nwork)
+{
+	typedef typename S::CX CX;
+	typedef typename S::Re Re;
+	extern __shared__ __attribute__((aligned(32))) unsigned char lds[];
+	CX *planes = reinterpret_cast<CX *>(lds);
+	CX *wtab = reinterpret_cast<CX *>(lds + S::LDS), *ttab = wtab + S::L;
+	const int tid = threadIdx.x;
+	for (int i = tid; i < S::L; i += S::T) wtab[i] = a_.W[i];
+	for (int i = tid; i <= S::L / 2; i += S::T) ttab[i] = a_.T[i];
+	typename S::PA a = plain_args(a_);
+	a.W = wtab; a.T = ttab;
+	const int pairs = a.nb0 >> 1;
+	// element offset of line `second` (0: y1 = 2n, 1: y2 = nb0 - 1 - 2n) of pair `work`
+	auto line_in = [&](int work, int second) { const int i1 = work / pairs, n = work - i1 * pairs; return (long long)(second ? a.nb0 - 1 - 2 * n : 2 * n) * a.sb0_in + (long long)i1 * a.sb1_in; };
+	auto line_out = [&](int work, int second) { const int i1 = work / pairs, n = work - i1 * pairs; return (long long)(second ? a.nb0 - 1 - 2 * n : 2 * n) * a.sb0_out + (long long)i1 * a.sb1_out; };
+	typename S::template State<KIND> st;
+	typename S::template OutHold<KIND> h1, h2;     // h1: T(r1)'s outputs, then out1; h2: out2
+	__syncthreads();                                 // the tables are in place
+	int work = blockIdx.x, pending = 0;
+	long long pb1 = 0, pb2 = 0;
+	if (work < nwork) S::template prefetch<KIND>(a, line_in(work, 0), tid, st, nullptr, nullptr);
+	// one pair per iteration, its two lines spelled out (SECOND is a compile-time constant): with ONE copy of the phases and a run-time "second" the
+	// compiler must assume out2 alive around the whole loop -- 24 registers more across every stage, 133-159 spilled
+	auto line = [&](auto SECOND, int next_work) __attribute__((always_inline)) {
+		// (the thread index is re-made opaque for every line: see row_persist_kernel)
+		int t = tid; asm volatile("" : "+v"(t));
+		forget(st.x);
+		S::template phase<KIND, 0, decltype(st), true>(a, planes, 0, t, st);
+		if constexpr (!SECOND) {
+			if (pending) {                           // the previous pair's two lines: their loads are long done, the plane already holds this line
+				S::template out_each<KIND>(t, [&](auto slot, long long off) {
+					store_pix<S::C, Re>(a.out + pb1 + off, h1.v[slot]);
+					store_pix<S::C, Re>(a.out + pb2 + off, h2.v[slot]);
+				});
+			}
+		}
+		if constexpr (!SECOND) { forget(h1); forget(h2); }
+		forget(st.pre);
+		if (next_work < nwork) S::template prefetch<KIND>(a, line_in(next_work, SECOND ? 0 : 1), t, st, nullptr, nullptr);      // lands behind this line's stages
+		__syncthreads();
+		static_for<1, S::NS + 2>([&](auto ph) {
+			int u = t; asm volatile("" : "+v"(u));
+			S::template phase<KIND, ph, decltype(st), true>(a, planes, 0, u, st);
+			__syncthreads();
+		});
+		int u = t; asm volatile("" : "+v"(u));
+		if constexpr (!SECOND) {
+			S::template final_each<KIND>(a, planes, u, st, [&](auto slot, long long, Pix<S::C, Re> v) { h1.v[slot] = v; });
+		} else {
+			forget(h2);
+			S::template final_each<KIND>(a, planes, u, st, [&](auto slot, long long, Pix<S::C, Re> v) {
+				const Pix<S::C, Re> p = h1.v[slot];
+				static_for<0, S::C>([&](auto c) { h1.v[slot].v[c] = p.v[c] + v.v[c]; h2.v[slot].v[c] = p.v[c] - v.v[c]; });
+			});
+		}
+		__syncthreads();                             // the plane is the next line's
+	};
+	while (work < nwork) {
+		line(std::integral_constant<bool, false>(), work);
+		line(std::integral_constant<bool, true>(), work + (int)gridDim.x);
+		pending = 1; pb1 = line_out(work, 0); pb2 = line_out(work, 1);
+		work += (int)gridDim.x;
+	}
+	if (pending)
+		S::template out_each<KIND>(tid, [&](auto slot, long long off) {
+			store_pix<S::C, Re>(a.out + pb1 + off, h1.v[slot]);
+			store_pix<S::C, Re>(a.out + pb2 + off, h2.v[slot]);
+		});
+}
+
 // COL side: one workgroup per half tile (N/2 rows x K floats)
 template <class S, int KIND, bool PLAIN = false>
 __global__ void __launch_bounds__(S::T, S::WPE) col_half_kernel(const typename S::PA a_)
@@ -523,6 +622,23 @@ int launch_row_pair(const typename S::PA &a, int npairs, void *stream)
 {
 	static DevOnce once;
 	if (int lds_rc = allow_lds_dev(once, S::LDS, row_pair_kernel<S, KIND, false>, row_pair_kernel<S, KIND, true>)) return lds_rc;
+	if constexpr (pair_pipe_ok<S>()) {
+		// DSPFFT_PAIR_PIPE=0 keeps one workgroup per pair, =1024 runs the pipelined kernel on 1024 threads (A/B runs)
+		static const int on = []() { const char *e = getenv("DSPFFT_PAIR_PIPE"); return e ? atoi(e) : 1; }();
+		const int cus = device_cus();
+		if (on && is_plain(a) && npairs > cus) {
+			// on DSP_PAIR_PIPE_T threads: the held output lines, the line in flight and the closing phase's arithmetic together need more than the
+			// 128 registers that 1024 threads leave each; 768 threads have 168 and fill the radix-16 / radix-15 stages' rounds better (720 and 768
+			// butterflies)
+			typedef typename S::template with_threads<DSP_PAIR_PIPE_T> SP;
+			static DevOnce ponce;
+			if (int p_rc = allow_lds_dev(ponce, pair_pipe_lds<SP>(), row_pair_pipe_kernel<SP, KIND>, row_pair_pipe_kernel<S, KIND>)) return p_rc;
+			if (on == 1024) hipLaunchKernelGGL((row_pair_pipe_kernel<S, KIND>), dim3(cus), dim3(S::T), pair_pipe_lds<S>(), (hipStream_t)stream, a, npairs);
+			else hipLaunchKernelGGL((row_pair_pipe_kernel<SP, KIND>), dim3(cus), dim3(SP::T), pair_pipe_lds<SP>(), (hipStream_t)stream, a, npairs);
+			HIPCHK(hipGetLastError());
+			return 0;
+		}
+	}
 	if (is_plain(a)) hipLaunchKernelGGL((row_pair_kernel<S, KIND, true>), dim3(npairs), dim3(S::T), S::LDS, (hipStream_t)stream, a);
 	else hipLaunchKernelGGL((row_pair_kernel<S, KIND, false>), dim3(npairs), dim3(S::T), S::LDS, (hipStream_t)stream, a);
 	HIPCHK(hipGetLastError());
