@@ -589,8 +589,8 @@ struct RowSpecG {
 
 	// ---- a plain line's outputs as VALUES (row_pair_pipe_kernel: the pair's butterfly moved to the output side) ----
 	// The closing phase of a plain pass (phase<KIND, NS + 2> without 8-bit ends, accumulation or alternating sign) with its stores replaced by
-	// f(slot, offset of the pixel within the line in samples, pixel): `slot` is a compile-time index < OUT_SLOTS that names the same pixel in every line
-	// of this thread, called for the pixels this thread owns only.
+	// f(slot, offset of the pixel within the line in samples, pixel): `slot` is a compile-time index < out_slots() that names the same pixel in every
+	// line of this thread, called for the pixels this thread owns only.
 	template <int KIND> static constexpr int out_slots() { return KIND == KIND_REDFT10 ? 4 * K_ROUNDS : PIX_ROUNDS; }
 	template <int KIND> struct OutHold { Pix<C, Re> v[out_slots<KIND>()]; };
 	template <int KIND, class ST, class F>
@@ -604,6 +604,7 @@ struct RowSpecG {
 				const CX tk = st.tw[ri];
 				const CX tlk = cmul(cconj(tk), cmk<Re>((Re)0.70710678118654752440, (Re)-0.70710678118654752440));
 				const CX t1 = csqr(csqr(tk));
+				const Re sc = a.scale, s0 = (k == 0) ? sc * a.out_scale0 : sc;
 				Pix<C, Re> o0, o1, o2, o3;
 				static_for<0, C>([&](auto c) {
 					const CX zk = planes[c * PL + k];
@@ -613,11 +614,7 @@ struct RowSpecG {
 					const CX P = cmul(t1, D);
 					const CX wk = cmul(tk, cadd(E, P));
 					const CX wm = cmul(tlk, cconj(csub(E, P)));
-					const Re sc = a.scale;
-					o0.v[c] = wk.x * (k == 0 ? sc * a.out_scale0 : sc);
-					o1.v[c] = -wk.y * sc;
-					o2.v[c] = wm.x * sc;
-					o3.v[c] = -wm.y * sc;
+					o0.v[c] = wk.x * s0; o1.v[c] = -wk.y * sc; o2.v[c] = wm.x * sc; o3.v[c] = -wm.y * sc;
 				});
 				f(std::integral_constant<int, ri * 4 + 0>(), (long long)k * GS, o0);
 				if (k > 0) f(std::integral_constant<int, ri * 4 + 1>(), (long long)(N - k) * GS, o1);
@@ -634,35 +631,14 @@ struct RowSpecG {
 				const int x = tid + i * T;
 				if (!((i + 1) * T <= N || x < N)) return;
 				const int n = (int)n0 + i * dn;
-				Pix<C, Re> o;
 				Re sc = sg;
 				if constexpr (i == 0) { if (x == 0) sc *= a.out_scale0; }
+				Pix<C, Re> o;
 				static_for<0, C>([&](auto c) { o.v[c] = pf[c * (2 * PL) + n] * sc; });
 				f(std::integral_constant<int, i>(), (long long)x * GS, o);
 			});
 		}
 	}
-	// the pixels final_each hands out, by slot: g(slot, offset within the line) for the slots this thread owns (the stores of a held line)
-	template <int KIND, class G>
-	static DSP_HD void out_each(int tid, G &&g)
-	{
-		if constexpr (KIND == KIND_REDFT10) {
-			static_for<0, K_ROUNDS>([&](auto ri) {
-				const int k = tid + ri * T;
-				if (!((ri + 1) * T <= L / 2 + 1 || k <= L / 2)) return;
-				g(std::integral_constant<int, ri * 4 + 0>(), (long long)k * GS);
-				if (k > 0) g(std::integral_constant<int, ri * 4 + 1>(), (long long)(N - k) * GS);
-				if (L - k != k) g(std::integral_constant<int, ri * 4 + 2>(), (long long)(L - k) * GS);
-				if (k > 0 && L + k != N - k) g(std::integral_constant<int, ri * 4 + 3>(), (long long)(L + k) * GS);
-			});
-		} else {
-			static_for<0, PIX_ROUNDS>([&](auto i) {
-				const int x = tid + i * T;
-				if ((i + 1) * T <= N || x < N) g(std::integral_constant<int, i>(), (long long)x * GS);
-			});
-		}
-	}
-
 	// ---- two REDFT01 transforms summed into one output line (row_sum2_kernel: out = A(in_a) + B(in_b)) ----
 	// the first transform's output line waits in registers (N C / T values per thread) while the second runs through the same LDS
 	struct Hold { Pix<C, Re> v[PIX_ROUNDS]; };

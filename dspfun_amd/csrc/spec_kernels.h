@@ -427,16 +427,17 @@ __global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_kerne
 	}
 }
 
-// ---- row pairs of lines that fill a CU's LDS on their own (7680 x 3 floats: 92 KB, ONE workgroup per CU), software-pipelined (round 6) ----
-// row_pair_kernel loads both lines, waits, and transforms (r1 + r2) and (r1 - r2): with a single resident workgroup nothing overlaps the load wait or the
-// workgroup's turnover (tools/kstamp: 3.6K of a pair's 41K stamped clocks wait for the loads).  The transform is linear, so the pair's butterfly can sit
-// on the OUTPUT side instead: out1 = T(r1) + T(r2), out2 = T(r1) - T(r2).  Then the lines are needed one at a time, and a persistent workgroup (one per
-// CU walks the pairs) fetches every line ONE TRANSFORM AHEAD into the registers that phase 0 of the previous line has just emptied -- the same 24
-// registers per thread the waiting line occupies today, no LDS: T(r1)'s outputs wait in registers (as the difference line does today) while r2 is
-// transformed, and the pair's two output lines are stored after phase 0 of the NEXT line, so that no store sits between a line's loads and their use
-// (vmcnt is in-order) and the stores drain under the next line's stages.  The stage twiddles W and T[k] live in LDS (45 KB beside the 92 KB plane:
-// a vector-memory load between a prefetch and its use would wait for it, see row_persist_kernel).  Plain passes only (the fused scan step's masked /
-// accumulating pair pass keeps row_pair_kernel).
+// ---- row pairs of lines that fill a CU's LDS on their own (7680 x 3 floats: 92 KB, ONE workgroup per CU), the second line fetched ahead (round 6) ----
+// row_pair_kernel loads both lines, waits, and transforms (r1 + r2) and (r1 - r2).  With a single resident workgroup nothing overlaps that wait, and it
+// is a third of a pair's life: 184 KB through a CU's in-order memory pipe behind the previous pair's 184 KB of stores (tools/kstamp: wave 0 waits 5.5K
+// clocks, the slowest wave 11K more, of 50K).  The transform is linear, so the pair's butterfly can sit on the OUTPUT side: out1 = T(r1) + T(r2),
+// out2 = T(r1) - T(r2).  Then the lines are needed one at a time: a persistent workgroup (one per CU walks the pairs) waits for r1 only, fetches r2
+// right behind phase 0 of r1 into the registers that phase has just emptied -- it lands under r1's stages -- keeps T(r1)'s outputs in registers (as
+// the difference line waits today) and stores both output lines from r2's closing phase.  The next pair's r1 is requested behind those stores.
+// The stage twiddles W and T[k] live in LDS (45 KB beside the 92 KB plane): vmcnt is in-order, a vector-memory load between the prefetch and its use
+// would wait for it (see row_persist_kernel).  Plain passes only (the fused scan step's masked / accumulating pair pass keeps row_pair_kernel).
+// (Fetching BOTH lines one transform ahead and storing the pair behind the next line's phase 0 was built first: the held output line costs 24 more
+// registers through every phase, and 184 KB of stores in one burst block the issuing waves for 15-18K clocks: 236 / 232 us, profiles/r06_8k_pair_pipe.txt.)
 #ifndef DSP_PAIR_PIPE_T
 #define DSP_PAIR_PIPE_T 768
 #endif
@@ -454,7 +455,7 @@ template <class V> __device__ __forceinline__ void forget(V &v)
 }
 template <class S> constexpr size_t pair_pipe_lds() { return S::LDS + sizeof(typename S::CX) * (size_t)(S::L + S::L / 2 + 1); }
 template <class S> constexpr bool pair_pipe_ok() { return S::C > 1 && S::LDS > 80 * 1024 && pair_pipe_lds<S>() <= 160 * 1024; }
-template <class S, int KIND>
+template <class S, int KIND, bool EARLY = false>
 __global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_pipe_kernel(const typename S::PA a_, int nwork)
 {
 	typedef typename S::CX CX;
@@ -472,58 +473,57 @@ __global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_pipe_
 	auto line_in = [&](int work, int second) { const int i1 = work / pairs, n = work - i1 * pairs; return (long long)(second ? a.nb0 - 1 - 2 * n : 2 * n) * a.sb0_in + (long long)i1 * a.sb1_in; };
 	auto line_out = [&](int work, int second) { const int i1 = work / pairs, n = work - i1 * pairs; return (long long)(second ? a.nb0 - 1 - 2 * n : 2 * n) * a.sb0_out + (long long)i1 * a.sb1_out; };
 	typename S::template State<KIND> st;
-	typename S::template OutHold<KIND> h1, h2;     // h1: T(r1)'s outputs, then out1; h2: out2
+	typename S::template OutHold<KIND> h1;           // T(r1)'s outputs
 	__syncthreads();                                 // the tables are in place
-	int work = blockIdx.x, pending = 0;
-	long long pb1 = 0, pb2 = 0;
-	if (work < nwork) S::template prefetch<KIND>(a, line_in(work, 0), tid, st, nullptr, nullptr);
-	// one pair per iteration, its two lines spelled out (SECOND is a compile-time constant): with ONE copy of the phases and a run-time "second" the
-	// compiler must assume out2 alive around the whole loop -- 24 registers more across every stage, 133-159 spilled
-	auto line = [&](auto SECOND, int next_work) __attribute__((always_inline)) {
+	// one pair per iteration, its two lines spelled out (SECOND is a compile-time constant)
+	auto line = [&](auto SECOND, long long in_next, bool has_next, long long pb1, long long pb2) __attribute__((always_inline)) {
 		// (the thread index is re-made opaque for every line: see row_persist_kernel)
 		int t = tid; asm volatile("" : "+v"(t));
 		forget(st.x);
+		DSP_STAMP(SECOND ? 10 : 0);
 		S::template phase<KIND, 0, decltype(st), true>(a, planes, 0, t, st);
-		if constexpr (!SECOND) {
-			if (pending) {                           // the previous pair's two lines: their loads are long done, the plane already holds this line
-				S::template out_each<KIND>(t, [&](auto slot, long long off) {
-					store_pix<S::C, Re>(a.out + pb1 + off, h1.v[slot]);
-					store_pix<S::C, Re>(a.out + pb2 + off, h2.v[slot]);
-				});
-			}
+		DSP_STAMP(SECOND ? 11 : 1);
+		if constexpr (!SECOND) {                     // r2: lands behind r1's stages
+			forget(h1); forget(st.pre);
+			S::template prefetch<KIND>(a, in_next, t, st, nullptr, nullptr);
+		} else if constexpr (EARLY) {                // the next pair's r1 behind r2's stages, IN FRONT of this pair's stores
+			forget(st.pre);
+			if (has_next) S::template prefetch<KIND>(a, in_next, t, st, nullptr, nullptr);
 		}
-		if constexpr (!SECOND) { forget(h1); forget(h2); }
-		forget(st.pre);
-		if (next_work < nwork) S::template prefetch<KIND>(a, line_in(next_work, SECOND ? 0 : 1), t, st, nullptr, nullptr);      // lands behind this line's stages
 		__syncthreads();
+		DSP_STAMP(SECOND ? 12 : 2);
 		static_for<1, S::NS + 2>([&](auto ph) {
 			int u = t; asm volatile("" : "+v"(u));
 			S::template phase<KIND, ph, decltype(st), true>(a, planes, 0, u, st);
 			__syncthreads();
+			DSP_STAMP((SECOND ? 12 : 2) + ph);
 		});
 		int u = t; asm volatile("" : "+v"(u));
 		if constexpr (!SECOND) {
 			S::template final_each<KIND>(a, planes, u, st, [&](auto slot, long long, Pix<S::C, Re> v) { h1.v[slot] = v; });
 		} else {
-			forget(h2);
-			S::template final_each<KIND>(a, planes, u, st, [&](auto slot, long long, Pix<S::C, Re> v) {
-				const Pix<S::C, Re> p = h1.v[slot];
-				static_for<0, S::C>([&](auto c) { h1.v[slot].v[c] = p.v[c] + v.v[c]; h2.v[slot].v[c] = p.v[c] - v.v[c]; });
+			S::template final_each<KIND>(a, planes, u, st, [&](auto slot, long long off, Pix<S::C, Re> v) {
+				Pix<S::C, Re> o1, o2;
+				static_for<0, S::C>([&](auto c) { o1.v[c] = h1.v[slot].v[c] + v.v[c]; o2.v[c] = h1.v[slot].v[c] - v.v[c]; });
+				store_pix<S::C, Re>(a.out + pb1 + off, o1);
+				store_pix<S::C, Re>(a.out + pb2 + off, o2);
 			});
+			if constexpr (!EARLY) {
+				forget(st.pre);
+				if (has_next) S::template prefetch<KIND>(a, in_next, u, st, nullptr, nullptr);     // the next pair's r1, behind this pair's stores
+			}
 		}
 		__syncthreads();                             // the plane is the next line's
+		DSP_STAMP(SECOND ? 19 : 9);
 	};
+	int work = blockIdx.x;
+	if (work < nwork) S::template prefetch<KIND>(a, line_in(work, 0), tid, st, nullptr, nullptr);
 	while (work < nwork) {
-		line(std::integral_constant<bool, false>(), work);
-		line(std::integral_constant<bool, true>(), work + (int)gridDim.x);
-		pending = 1; pb1 = line_out(work, 0); pb2 = line_out(work, 1);
-		work += (int)gridDim.x;
+		const int next = work + (int)gridDim.x;
+		line(std::integral_constant<bool, false>(), line_in(work, 1), true, 0, 0);
+		line(std::integral_constant<bool, true>(), next < nwork ? line_in(next, 0) : 0, next < nwork, line_out(work, 0), line_out(work, 1));
+		work = next;
 	}
-	if (pending)
-		S::template out_each<KIND>(tid, [&](auto slot, long long off) {
-			store_pix<S::C, Re>(a.out + pb1 + off, h1.v[slot]);
-			store_pix<S::C, Re>(a.out + pb2 + off, h2.v[slot]);
-		});
 }
 
 // COL side: one workgroup per half tile (N/2 rows x K floats)
@@ -623,18 +623,21 @@ int launch_row_pair(const typename S::PA &a, int npairs, void *stream)
 	static DevOnce once;
 	if (int lds_rc = allow_lds_dev(once, S::LDS, row_pair_kernel<S, KIND, false>, row_pair_kernel<S, KIND, true>)) return lds_rc;
 	if constexpr (pair_pipe_ok<S>()) {
-		// DSPFFT_PAIR_PIPE=0 keeps one workgroup per pair, =1024 runs the pipelined kernel on 1024 threads (A/B runs)
+		// DSPFFT_PAIR_PIPE=0 keeps one workgroup per pair (A/B runs)
 		static const int on = []() { const char *e = getenv("DSPFFT_PAIR_PIPE"); return e ? atoi(e) : 1; }();
 		const int cus = device_cus();
 		if (on && is_plain(a) && npairs > cus) {
-			// on DSP_PAIR_PIPE_T threads: the held output lines, the line in flight and the closing phase's arithmetic together need more than the
-			// 128 registers that 1024 threads leave each; 768 threads have 168 and fill the radix-16 / radix-15 stages' rounds better (720 and 768
-			// butterflies)
+			// on DSP_PAIR_PIPE_T = 768 threads: the held output line, the line in flight and the closing phase's arithmetic need more than the 128
+			// registers that 1024 threads leave each, and 768 fill the radix-16 / radix-15 stages' rounds better (720 and 768 butterflies); measured
+			// 195.7 / 196.8 us against 221 / 220 on 1024 threads and 204.5 / 212 for row_pair_kernel (profiles/r06_8k_pair_pipe.txt).
+			// REDFT01 requests the next pair's first line in FRONT of this pair's stores (its twenty stores per thread are unconditional: the compiler
+			// counts them and waits for the loads alone); REDFT10's stores sit under per-lane conditions, the wait behind them would be for the whole
+			// queue, so its request goes out behind them (198.0 in front, 195.7 behind).
 			typedef typename S::template with_threads<DSP_PAIR_PIPE_T> SP;
+			constexpr bool EARLY = KIND == KIND_REDFT01;
 			static DevOnce ponce;
-			if (int p_rc = allow_lds_dev(ponce, pair_pipe_lds<SP>(), row_pair_pipe_kernel<SP, KIND>, row_pair_pipe_kernel<S, KIND>)) return p_rc;
-			if (on == 1024) hipLaunchKernelGGL((row_pair_pipe_kernel<S, KIND>), dim3(cus), dim3(S::T), pair_pipe_lds<S>(), (hipStream_t)stream, a, npairs);
-			else hipLaunchKernelGGL((row_pair_pipe_kernel<SP, KIND>), dim3(cus), dim3(SP::T), pair_pipe_lds<SP>(), (hipStream_t)stream, a, npairs);
+			if (int p_rc = allow_lds_dev(ponce, pair_pipe_lds<SP>(), row_pair_pipe_kernel<SP, KIND, EARLY>)) return p_rc;
+			hipLaunchKernelGGL((row_pair_pipe_kernel<SP, KIND, EARLY>), dim3(cus), dim3(SP::T), pair_pipe_lds<SP>(), (hipStream_t)stream, a, npairs);
 			HIPCHK(hipGetLastError());
 			return 0;
 		}

@@ -343,9 +343,58 @@ int launch_row_spec_u8(const PassArgs &a, const U8IO &io, int nwork, void *)
 	}
 	return 0;
 }
+static inline bool is_plain_pass(const PassArgs &a) { return !a.mask && !a.zflags && !a.accumulate && a.win_hi <= 0 && !a.alt_out && !a.in_mul && !a.in_rev; }
+// the pipelined pair kernel's order of work (spec_kernels.h row_pair_pipe_kernel): the pair's butterfly on the OUTPUT side -- T(r1) kept as values
+// (RowSpecG::final_each), T(r2) added / subtracted and both lines stored -- on the workgroup size the HIP launcher uses.  EMUL_PAIR_PIPE=1 sends every
+// plain interleaved pair pass through it (the HIP launcher takes it for lines that fill a CU's LDS only), =0 none.
+template <class S, int KIND>
+int launch_row_pair_pipe(const PassArgs &a_, int npairs)
+{
+	std::vector<unsigned char> lds(S::LDS + 16);
+	cf *planes = (cf *)lds.data();
+	const PassArgs &a = a_;                          // (plain: launch_row_pair checks)
+	const int pairs = a.nb0 >> 1;
+	typedef typename S::template State<KIND> ST;
+	typedef typename S::template OutHold<KIND> OH;
+	for (int wg = 0; wg < npairs; wg++) {
+		const int i1 = wg / pairs, n = wg - i1 * pairs;
+		const int y[2] = {2 * n, a.nb0 - 1 - 2 * n};
+		const long long b1 = y[0] * a.sb0_out + i1 * a.sb1_out, b2 = y[1] * a.sb0_out + i1 * a.sb1_out;
+		std::vector<ST> st(S::T), st2(S::T);
+		std::vector<OH> h1(S::T);
+		// (both lines are read before anything is stored, as in the kernel: in place is safe)
+		for (int tid = 0; tid < S::T; tid++) {
+			S::template prefetch<KIND>(a, y[0] * a.sb0_in + i1 * a.sb1_in, tid, st[tid], nullptr, nullptr);
+			S::template prefetch<KIND>(a, y[1] * a.sb0_in + i1 * a.sb1_in, tid, st2[tid], nullptr, nullptr);
+		}
+		for (int second = 0; second < 2; second++) {
+			std::vector<ST> &cur = second ? st2 : st;
+			static_for<0, S::NS + 2>([&](auto ph) { for (int tid = 0; tid < S::T; tid++) S::template phase<KIND, ph, ST, true>(a, planes, 0, tid, cur[tid]); });
+			for (int tid = 0; tid < S::T; tid++) {
+				if (!second) S::template final_each<KIND>(a, planes, tid, cur[tid], [&](auto slot, long long, Pix<S::C, float> v) { h1[tid].v[slot] = v; });
+				else S::template final_each<KIND>(a, planes, tid, cur[tid], [&](auto slot, long long off, Pix<S::C, float> v) {
+					Pix<S::C, float> o1, o2;
+					for (int c = 0; c < S::C; c++) { o1.v[c] = h1[tid].v[slot].v[c] + v.v[c]; o2.v[c] = h1[tid].v[slot].v[c] - v.v[c]; }
+					store_pix<S::C, float>(a.out + b1 + off, o1);
+					store_pix<S::C, float>(a.out + b2 + off, o2);
+				});
+			}
+		}
+	}
+	return 0;
+}
 template <class S, int KIND>
 int launch_row_pair(const PassArgs &a, int npairs, void *)
 {
+	{
+		const char *e = getenv("EMUL_PAIR_PIPE");
+		const int mode = e ? atoi(e) : -1;
+		constexpr bool fills_a_cu = S::C > 1 && S::LDS > 80 * 1024;
+		if (is_plain_pass(a) && S::C > 1 && (mode == 1 || (mode != 0 && fills_a_cu))) {
+			if constexpr (fills_a_cu) return launch_row_pair_pipe<typename S::template with_threads<768>, KIND>(a, npairs);
+			else if constexpr (S::C > 1) return launch_row_pair_pipe<S, KIND>(a, npairs);
+		}
+	}
 	std::vector<unsigned char> lds(S::LDS + 16);
 	cf *planes = (cf *)lds.data();
 	const int pairs = a.nb0 >> 1;

@@ -24,8 +24,10 @@ def relerr(got, ref):
     return np.abs(got.astype(np.float64) - ref).max() / np.abs(ref).max()
 
 
+@pytest.mark.parametrize("pipe", ["0", "1"])       # the pair's butterfly on the input side (row_pair_kernel) / on the output side (row_pair_pipe_kernel's order of work)
 @pytest.mark.parametrize("h,w", [(512, 512), (1080, 1920)])
-def test_forced_split_forward_inverse_vs_oracle(forced, h, w):
+def test_forced_split_forward_inverse_vs_oracle(forced, h, w, pipe, monkeypatch):
+    monkeypatch.setenv("EMUL_PAIR_PIPE", pipe)
     c = 3
     x = ol.synth_f32(0xD5F0002, h * w * c).reshape(h, w, c)
     fwd = Plan.image(h, w, c, REDFT10, lib=emul())
@@ -48,8 +50,13 @@ def test_forced_split_forward_inverse_vs_oracle(forced, h, w):
     assert np.abs(out - x).max() < 5e-6 and np.array_equal(co, keep)
 
 
-def test_forced_split_on_8k_wide_lines(forced):
-    """7680 x 3 lines (BASELINE config 4's rows) as row pairs of a split plan: the 1024-thread pair kernel's phases on the emulation"""
+@pytest.mark.parametrize("pipe", ["0", None])
+def test_forced_split_on_8k_wide_lines(forced, pipe, monkeypatch):
+    """7680 x 3 lines (BASELINE config 4's rows) as row pairs of a split plan: the 1024-thread pair kernel's phases on the emulation, and (default, as the
+    HIP launcher chooses for plain passes) the pipelined pair kernel's order of work on its 768 threads: T(r1) held as values, T(r2) added and
+    subtracted in the closing phase (RowSpecG::final_each)"""
+    if pipe is not None:
+        monkeypatch.setenv("EMUL_PAIR_PIPE", pipe)
     h, w, c = 512, 7680, 3
     x = ol.synth_f32(0xD5F0004, h * w * c).reshape(h, w, c)
     fwd = Plan.image(h, w, c, REDFT10, lib=emul())

@@ -112,6 +112,19 @@ int main(int argc, char **argv)
 		a.kind = 0; run("row_pair 7680x3 REDFT10 (2160 pairs)", H8 / 2, [&]() { hipLaunchKernelGGL((row_pair_kernel<S, 0, true>), dim3(H8 / 2), dim3(S::T), S::LDS, 0, a); });
 		a.kind = 1; run("row_pair 7680x3 REDFT01", H8 / 2, [&]() { hipLaunchKernelGGL((row_pair_kernel<S, 1, true>), dim3(H8 / 2), dim3(S::T), S::LDS, 0, a); });
 	}
+	if (strstr(which, "pipe")) {
+		// round 6's pipelined pair kernel (one workgroup per CU; the stamps are the LAST pair's of each workgroup): [1] phase 0 of r1 (its wait for the line
+		// included), [2] r2 requested + barrier (the slowest wave's wait for r1), [3..6] stages and last stage, [9] closing phase to registers; [10..16] the
+		// same for r2, [19] closing phase + the pair's stores (+ the next pair's r1 requested)
+		typedef RowSpec<7680, 3, 768, 16, 15, 16> S;
+		PassArgs a = {};
+		a.N = S::N; a.C = 3; a.nb0 = H8; a.nb1 = 1; a.sb0_in = a.sb0_out = (long long)W8 * 3; a.nlines = H8;
+		a.in = x; a.out = x; a.T = tab_T(S::N); a.W = tab_W(S::L); a.scale = 1.f; a.in_scale0 = a.out_scale0 = 1.f;
+		CK(hipFuncSetAttribute(reinterpret_cast<const void *>(row_pair_pipe_kernel<S, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_pipe_lds<S>()));
+		CK(hipFuncSetAttribute(reinterpret_cast<const void *>(row_pair_pipe_kernel<S, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_pipe_lds<S>()));
+		a.kind = 0; run("row_pair_pipe 7680x3 REDFT10 (768 threads, 256 workgroups)", 256, [&]() { hipLaunchKernelGGL((row_pair_pipe_kernel<S, 0>), dim3(256), dim3(S::T), pair_pipe_lds<S>(), 0, a, H8 / 2); });
+		a.kind = 1; run("row_pair_pipe 7680x3 REDFT01 (next pair requested in front of the stores)", 256, [&]() { hipLaunchKernelGGL((row_pair_pipe_kernel<S, 1, true>), dim3(256), dim3(S::T), pair_pipe_lds<S>(), 0, a, H8 / 2); });
+	}
 	if (strstr(which, "half")) {
 		typedef ColHalfSpec<4320, 16, 1024, 12, 12, 15> S;
 		PassArgs a = {};
