@@ -51,42 +51,71 @@ def synth_frames(torch, nframes, device):
     return out
 
 
+def physical_core_cpus():
+    """one logical CPU per physical core that this process may run on, grouped by socket (package) in ascending order: [cpu, ...], {package: count}.
+    From /sys/devices/system/cpu/cpuN/topology; falls back to the affinity mask as it is."""
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    seen, cpus, per_pkg = set(), [], {}
+    for cpu in allowed:
+        base = f"/sys/devices/system/cpu/cpu{cpu}/topology/"
+        try:
+            with open(base + "core_id") as f:
+                core = int(f.read())
+            with open(base + "physical_package_id") as f:
+                pkg = int(f.read())
+        except (OSError, ValueError):
+            core, pkg = cpu, 0
+        if (pkg, core) in seen:
+            continue
+        seen.add((pkg, core))
+        cpus.append((pkg, cpu))
+        per_pkg[pkg] = per_pkg.get(pkg, 0) + 1
+    cpus.sort()
+    return [c for _, c in cpus], per_pkg
+
+
 def cpu_baseline(max_seconds=30.0):
-    """Oracle CPU port (f32) on full 3840x2160x3 roundtrips: ONE thread and ALL host cores (SURVEY.md 8d asks for both), each repeated
-    while its share of the budget allows.  Only this leg of bench.py touches oracle/."""
+    """Oracle CPU port (f32) on full 3840x2160x3 roundtrips: ONE thread and ALL physical cores (SURVEY.md 8d asks for both).  Only this leg of
+    bench.py touches oracle/.  The all-core figure runs oracle/cpu_port_impl.h's bench entry (round 5's all-core number was
+    2.2x the single-thread one -- a frame first touched by the caller's thread, plans rebuilt and thread teams restarted in every pass): one
+    thread team for the whole run, each thread pinned to its own physical core, the frame first touched by the threads that transform its
+    rows, static row / column-block ranges, plans built before the clock starts (as FFTW's are).  Never called FFTW."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as ol
-    threads = max(1, min(ol.lib().cpu_port_max_threads(), os.cpu_count() or 1))
-    x = ol.synth_f32(SEED, H * W * C)
-    n, kinds2, kinds3 = [H, W], [ol.REDFT10] * 2, [ol.REDFT01] * 2
-
-    # straight into the C entry point on preallocated arrays: ol.r2r_many copies its 100 MB input and output on one host thread, which at
-    # 128 threads cost more than the transforms themselves (round 2's 24.5 Mpix/s was mostly those copies)
     import ctypes as C_
     L = ol.lib()
-    ia = lambda v: (C_.c_int * len(v))(*v)
-    f = np.empty_like(x); b = np.empty_like(x)
-    fn = L.cpu_port_r2r_many_f32
+    x = ol.synth_f32(SEED, H * W * C)
+    cpus, per_pkg = physical_core_cpus()
+    cpus = cpus[:max(1, min(len(cpus), L.cpu_port_max_threads()))]
+    fn = L.cpu_port_roundtrip_bench_f32
+    fn.restype = C_.c_int
+    fn.argtypes = [C_.c_int, C_.c_int, C_.c_int, C_.c_void_p, C_.c_int, C_.c_void_p, C_.c_int, C_.POINTER(C_.c_double), C_.POINTER(C_.c_double)]
 
     def run(nthr, budget):
-        reps, t0 = 0, time.perf_counter()
-        while True:
-            rc = fn(2, ia(n), C, x.ctypes.data, None, C, 1, f.ctypes.data, None, C, 1, ia(kinds2), nthr)
-            rc |= fn(2, ia(n), C, f.ctypes.data, None, C, 1, b.ctypes.data, None, C, 1, ia(kinds3), nthr)
-            assert rc == 0
-            reps += 1
-            el = time.perf_counter() - t0
-            if el * (reps + 1) / reps > budget or reps >= 64:
-                break
-        return reps, el, float(np.abs(b / np.float32(4.0 * W * H) - x).max())
+        """a probe of one roundtrip sizes the timed run to the budget"""
+        pin = (C_.c_int * nthr)(*cpus[:nthr]) if nthr > 1 else None
+        sec, err = C_.c_double(0), C_.c_double(0)
+        rc = fn(H, W, C, x.ctypes.data, nthr, pin, 1, C_.byref(sec), C_.byref(err))
+        pinned = rc == 0
+        if rc == -3:                         # affinity refused (a container's cpuset): unpinned
+            pin = None
+            rc = fn(H, W, C, x.ctypes.data, nthr, pin, 1, C_.byref(sec), C_.byref(err))
+        assert rc == 0, rc
+        reps = int(max(1, min(256, (budget - 2 * sec.value) / max(sec.value, 1e-4))))
+        rc = fn(H, W, C, x.ctypes.data, nthr, pin, reps, C_.byref(sec), C_.byref(err))
+        assert rc == 0, rc
+        return reps, sec.value, err.value, pinned and pin is not None
 
-    r1, e1, err1 = run(1, max_seconds * 0.4)
-    ra, ea, erra = run(threads, max_seconds * 0.4)
-    return {"value": round(ra * H * W / 1e6 / ea, 3), "unit": "Mpixels/s", "cores": threads, "kind": "port",
-            "single_thread_value": round(r1 * H * W / 1e6 / e1, 3),
-            "sample": f"{ra} roundtrip(s) of one 3840x2160x3 f32 frame with {threads} OpenMP threads and {r1} with one thread, oracle/cpu_port.c "
-                      f"(columns transformed in transposed blocks of 16; roundtrip max abs err {max(err1, erra):.1e})"}
+    r1, e1, err1, _ = run(1, max_seconds * 0.4)
+    ra, ea, erra, pinned = run(len(cpus), max_seconds * 0.4)
+    return {"value": round(ra * H * W / 1e6 / ea, 3), "unit": "Mpixels/s", "cores": len(cpus), "kind": "port",
+            "single_thread_value": round(r1 * H * W / 1e6 / e1, 3), "all_core_over_single_thread": round((ra / ea) / (r1 / e1), 1),
+            "sample": f"{ra} in-place roundtrip(s) of one 3840x2160x3 f32 frame on {len(cpus)} OpenMP threads, "
+                      f"{'each pinned to its own physical core' if pinned else 'unpinned (affinity not settable here)'} "
+                      f"({', '.join(f'socket {k}: {v} cores' for k, v in sorted(per_pkg.items()))}; {os.cpu_count()} logical CPUs), frame first touched by the threads that own its rows, "
+                      f"static row / 16-column-block ranges, one thread team, plans built before the clock starts; {r1} roundtrip(s) with one thread; "
+                      f"oracle/cpu_port_impl.h cpu_port_roundtrip_bench (roundtrip max abs err {max(err1, erra):.1e})"}
 
 
 def scipy_cpu_baseline(max_seconds=10.0):

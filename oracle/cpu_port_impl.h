@@ -14,6 +14,7 @@
 
 typedef struct { REAL re, im; } FN(cpx);
 #define CPX FN(cpx)
+static double FN(now_seconds)(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
 typedef struct {
 	int n;            /* complex length */
@@ -326,6 +327,88 @@ int FN(cpu_port_r2r_many)(int rank, const int *n, int howmany,
 		first = 0;
 	}
 	return 0;
+}
+
+/*
+ * bench.py's all-core CPU leg (`cpu_baseline`; nothing else calls it): `reps` in-place roundtrips REDFT10^2 -> REDFT01^2 / (4wh) of one interleaved
+ * h x w x c frame -- the arithmetic of spec.c:63-64 + ispec.c:165-166 through the port's own dct2_1d / dct3_1d -- laid out for many cores:
+ *   one thread team for the whole run (plans and scratch per thread, built before the clock starts, as FFTW plans are);
+ *   each thread pinned to cpus[t] when a list is given (one logical CPU per physical core) and the frame FIRST TOUCHED by the thread that owns its
+ *   rows in the row passes, so that a two-socket box does not serve every thread from the node the caller's thread happens to sit on;
+ *   static row ranges / static ranges of 16-column blocks, a barrier between passes.
+ * The timed region is the `reps` roundtrips (threads already running, frame resident and touched).  Returns 0; *seconds = wall time of the
+ * timed region, *max_err = max |frame - x| after the last roundtrip.
+ */
+int FN(cpu_port_roundtrip_bench)(int h, int w, int c, const REAL *x, int threads, const int *cpus, int reps, double *seconds, double *max_err)
+{
+	if (h < 2 || w < 2 || c < 1 || threads < 1 || reps < 1) return -1;
+	const size_t len = (size_t)h * w * c;
+	REAL *f = malloc(sizeof(REAL) * len);            /* untouched pages: the threads below touch them */
+	if (!f) return -2;
+	enum { BL = 16 };
+	const long row_len = (long)w * c, nblk = (row_len + BL - 1) / BL;
+	const REAL scale = (REAL)(1.0 / (4.0 * w * h));
+	double t_start = 0, t_end = 0, err = 0;
+	int bad = 0;
+	#pragma omp parallel num_threads(threads) reduction(max : err) reduction(+ : bad)
+	{
+#ifdef _OPENMP
+		const int t = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+		const int t = 0, nt = 1;
+#endif
+#if defined(__linux__) && defined(_GNU_SOURCE)
+		if (cpus) { cpu_set_t set; CPU_ZERO(&set); CPU_SET(cpus[t], &set); if (sched_setaffinity(0, sizeof set, &set)) bad++; }
+#endif
+		const long y0 = (long)h * t / nt, y1 = (long)h * (t + 1) / nt;          /* my rows */
+		const long b0 = nblk * t / nt, b1 = nblk * (t + 1) / nt;                /* my column blocks */
+		for (long y = y0; y < y1; y++) memcpy(f + (size_t)y * row_len, x + (size_t)y * row_len, sizeof(REAL) * (size_t)row_len);
+		DCTPLAN PW, PH;
+		FN(dct_plan_init)(&PW, w); FN(dct_plan_init)(&PH, h);
+		const int nmax = w > h ? w : h;
+		REAL *tin = malloc(sizeof(REAL) * (size_t)nmax * 2 * BL), *tout = tin + (size_t)nmax * BL;
+		if (!tin) bad++;
+		#pragma omp barrier
+		if (t == 0) t_start = FN(now_seconds)();
+		for (int rep = 0; rep < reps && tin; rep++) {
+			for (int dir = 0; dir < 2; dir++) {
+				/* forward: rows then columns (FFTW's last-axis-first order does not matter for the result); inverse: columns then rows */
+				for (int pass = 0; pass < 2; pass++) {
+					const int rows = (pass == 0) == (dir == 0);
+					if (rows) {
+						for (long y = y0; y < y1; y++) {
+							REAL *line = f + (size_t)y * row_len;
+							for (int ch = 0; ch < c; ch++) {
+								if (dir == 0) FN(dct2_1d)(&PW, line + ch, c, tout, 1); else FN(dct3_1d)(&PW, line + ch, c, tout, 1);
+								if (dir == 1) for (int k = 0; k < w; k++) line[(size_t)k * c + ch] = tout[k] * scale;
+								else for (int k = 0; k < w; k++) line[(size_t)k * c + ch] = tout[k];
+							}
+						}
+					} else {
+						for (long blk = b0; blk < b1; blk++) {
+							const long j0 = blk * BL;
+							const int nb = (int)(row_len - j0 < BL ? row_len - j0 : BL);
+							REAL *col = f + j0;
+							for (int k = 0; k < h; k++) { const REAL *xr = col + (size_t)k * row_len; for (int b = 0; b < nb; b++) tin[(size_t)b * h + k] = xr[b]; }
+							for (int b = 0; b < nb; b++) {
+								if (dir == 0) FN(dct2_1d)(&PH, tin + (size_t)b * h, 1, tout + (size_t)b * h, 1);
+								else FN(dct3_1d)(&PH, tin + (size_t)b * h, 1, tout + (size_t)b * h, 1);
+							}
+							for (int k = 0; k < h; k++) { REAL *yr = col + (size_t)k * row_len; for (int b = 0; b < nb; b++) yr[b] = tout[(size_t)b * h + k]; }
+						}
+					}
+					#pragma omp barrier
+				}
+			}
+		}
+		if (t == 0) t_end = FN(now_seconds)();
+		for (long y = y0; y < y1; y++)
+			for (long i = 0; i < row_len; i++) { const double d = fabs((double)f[(size_t)y * row_len + i] - (double)x[(size_t)y * row_len + i]); if (d > err) err = d; }
+		free(tin); FN(dct_plan_free)(&PW); FN(dct_plan_free)(&PH);
+	}
+	free(f);
+	*seconds = t_end - t_start; *max_err = err;
+	return bad ? -3 : 0;
 }
 
 #undef CPX
