@@ -87,11 +87,19 @@ def _coeff_dtype(precision):
     return dt
 
 
-def write_coeff(path, parts_np, precision="L"):
-    """parts_np: complex [k_h][k_w][n_h][n_w][3] (the partial sums in loop order); precision: the INTERMEDIATE_PRECISION of the build that will read it"""
+def write_coeff(path, parts_np, precision=None):
+    """parts_np: complex [k_h][k_w][n_h][n_w][3] (the partial sums in loop order); precision: the INTERMEDIATE_PRECISION of the build that will read
+    it.  None (default): "L", what the reference's default build reads (applybasis/Makefile:1-2) -- round 4 and before wrote "D"; on a platform whose
+    long double is not the 16-byte x87 format (aarch64, MSVC) no "L" file can be written and the default falls back to "D" with a warning."""
+    import warnings
     import numpy as np
     kh, kw, nh, nw, c = parts_np.shape
     assert c == 3
+    if precision is None:
+        precision = "L"
+        if np.dtype(np.clongdouble).itemsize != 32:
+            warnings.warn("long double is not the 16-byte x87 format here: writing a COEFF file for an INTERMEDIATE_PRECISION=D build of applybasis")
+            precision = "D"
     with open(path, "wb") as f:
         np.array([nw * kw, nh * kh], dtype=np.uint64).tofile(f)          # dumpsize = {N.w K.w, N.h K.h}
         np.ascontiguousarray(parts_np).astype(_coeff_dtype(precision)).tofile(f)
@@ -104,9 +112,11 @@ def read_coeff(path, precision=None):
     with open(path, "rb") as f:
         w, h = (int(v) for v in np.fromfile(f, dtype=np.uint64, count=2))
         n = w * h * 3
+        if n == 0:                                   # an empty frame: nothing to tell the precision by, nothing to read
+            return np.zeros((h, w, 3), dtype=np.complex128)
         if precision is None:
             body = os.path.getsize(path) - 16
-            precision = {32 * n: "L", 16 * n: "D", 8 * n: "F"}.get(body) if n else None
+            precision = {32 * n: "L", 16 * n: "D", 8 * n: "F"}.get(body)
             if precision is None:
                 raise ValueError(f".coeff file of {w} x {h} values with a body of {body} bytes: no build of the reference writes that")
         data = np.fromfile(f, dtype=_coeff_dtype(precision), count=n)

@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <complex>
 #include <dlfcn.h>
 #include <string>
@@ -79,9 +80,11 @@ FastDiv make_div(uint32_t d)
 	FastDiv f; f.d = d; f.mul = d >= 2 ? (uint32_t)((((uint64_t)1 << 32) + d - 1) / d) : 0; return f;
 }
 
-// Tuning overrides for experiments and A/B runs (0 / unset = the built-in choice).  A plan reads the environment ONCE: plan_finish() takes a
-// snapshot of every planner switch (EnvScope) and the planner consults only that, so a plan is made under one consistent set of values
-// whatever other threads do meanwhile.  (The snapshot lives in the planning thread; execute-time switches are read where they act.)
+// Tuning overrides for experiments and A/B runs (0 / unset = the built-in choice).  plan_finish() takes a snapshot of the planner switches listed
+// here (EnvScope) and everything it calls -- build_pass, build_split, build_block -- consults only that, so the passes of a plan are made under one
+// consistent set of values whatever other threads do meanwhile.  What acts OUTSIDE plan_finish reads the environment where it acts: the execute-time
+// switches (DSPFFT_LEAN01, DSPFFT_NO_FUSED_ROUNDTRIP, DSPFFT_ROW_CHAN, DSPFFT_RT_SLICE ...), dspfft_plan_scan_prepare (DSPFFT_SCAN_EIDS, DSPFFT_ZSKIP)
+// and the plan options set after creation.
 const char *const kPlanEnv[] = {"DSPFFT_JIT", "DSPFFT_JIT_TUNE", "DSPFFT_NO_TINY", "DSPFFT_ROW_LPW", "DSPFFT_ROW_THREADS", "DSPFFT_COL_K", "DSPFFT_COL_THREADS",
                                 "DSPFFT_DENSE_STAGED", "DSPFFT_NO_SPLIT", "DSPFFT_FORCE_SPLIT", "DSPFFT_NO_BLOCK", "DSPFFT_BLOCK_G", "DSPFFT_NO_BLUESTEIN"};
 constexpr int kNPlanEnv = (int)(sizeof kPlanEnv / sizeof kPlanEnv[0]);
@@ -367,9 +370,13 @@ std::string library_dir()
 }
 // DSPFFT_JIT=1 forces it on, =2 off; otherwise the planning effort the caller asked for decides (dspfft_set_plan_effort: the FFTW
 // shim passes FFTW_MEASURE / PATIENT / EXHAUSTIVE on as "this plan will be executed many times", FFTW_ESTIMATE as "plan fast")
-// planning effort of the plans THIS THREAD makes next (dspfft_set_plan_effort): thread-local, so that the FFTW shim's set / plan / restore around one
-// fftw(plan_many_r2r) call (fftw_shim.hip make_plan) cannot leak into a plan another thread is making
-thread_local int g_plan_effort = 0;
+// planning effort of the plans made next: a PROCESS-WIDE value (dspfft_set_plan_effort: what one thread sets, plans made on any thread see -- worker
+// pools, Python threads) that a thread may override for itself (dspfft_set_thread_plan_effort; < 0: no override).  The FFTW shim's set / plan /
+// restore around one fftw(plan_many_r2r) call (fftw_shim.hip make_plan) uses the thread's override, so it cannot leak into a plan another thread
+// is making.  (Round 5 made the one setter thread-local, which silently dropped plans created on other threads to effort 0: ADVICE r05.)
+std::atomic<int> g_plan_effort_default{0};
+thread_local int t_plan_effort = -1;
+#define g_plan_effort (t_plan_effort >= 0 ? t_plan_effort : g_plan_effort_default.load(std::memory_order_relaxed))
 bool jit_enabled()
 {
 	const int e = env_int("DSPFFT_JIT");
@@ -1939,8 +1946,11 @@ extern "C" int dspfft_plan_describe(dspfft_plan pl, char *buf, size_t buflen)
 }
 
 extern "C" size_t dspfft_plan_algorithmic_bytes(dspfft_plan pl) { return pl ? pl->alg_bytes : 0; }
-extern "C" void dspfft_set_plan_effort(int effort) { g_plan_effort = effort; }
-extern "C" int dspfft_get_plan_effort(void) { return g_plan_effort; }
+#undef g_plan_effort
+extern "C" void dspfft_set_plan_effort(int effort) { g_plan_effort_default.store(effort < 0 ? 0 : effort, std::memory_order_relaxed); }
+extern "C" int dspfft_get_plan_effort(void) { return t_plan_effort >= 0 ? t_plan_effort : g_plan_effort_default.load(std::memory_order_relaxed); }
+extern "C" void dspfft_set_thread_plan_effort(int effort) { t_plan_effort = effort < 0 ? -1 : effort; }
+extern "C" int dspfft_get_thread_plan_effort(void) { return t_plan_effort; }
 
 extern "C" int dspfft_scan_zigzag(uint32_t *d_lin, uint32_t w, uint32_t h, uint64_t first, uint64_t count, void *s)
 {

@@ -70,14 +70,14 @@ Shim *make_plan(int rank, const int *n, int howmany, void *in, const int *inembe
 	Shim *s = new Shim();
 	s->es = f64 ? sizeof(double) : sizeof(float); s->h_in = in; s->h_out = out;
 	// FFTW_ESTIMATE = plan fast; FFTW_MEASURE / PATIENT / EXHAUSTIVE (scan.c:359, motion.c:93-103) = this plan will run many times:
-	// frame sizes without a listed specialised kernel get one compiled now (dspfft_set_plan_effort: the effort is the calling thread's own state,
-	// set and restored around this one plan -- concurrent planning from other threads is not affected)
-	const int effort_before = dspfft_get_plan_effort();
-	dspfft_set_plan_effort((flags & FFTW_ESTIMATE) ? 0 : (flags & (FFTW_PATIENT | FFTW_EXHAUSTIVE)) ? 2 : 1);
+	// frame sizes without a listed specialised kernel get one compiled now (dspfft_set_thread_plan_effort: the calling thread's own override of the
+	// process-wide effort, set and restored around this one plan -- concurrent planning from other threads is not affected)
+	const int effort_before = dspfft_get_thread_plan_effort();
+	dspfft_set_thread_plan_effort((flags & FFTW_ESTIMATE) ? 0 : (flags & (FFTW_PATIENT | FFTW_EXHAUSTIVE)) ? 2 : 1);
 	// fftw_ (double) plans compute in double on the device, as the reference's default build does on the CPU
 	const int rc = f64 ? dspfft_plan_many_r2r_f64(&s->plan, rank, n, howmany, inembed, istride, idist, onembed, ostride, odist, kinds)
 	                   : dspfft_plan_many_r2r(&s->plan, rank, n, howmany, inembed, istride, idist, onembed, ostride, odist, kinds);
-	dspfft_set_plan_effort(effort_before);
+	dspfft_set_thread_plan_effort(effort_before);
 	if (rc) {
 		fprintf(stderr, "dspfft: plan_many_r2r failed: %s\n", dspfft_last_error());
 		delete s; return nullptr;

@@ -71,7 +71,10 @@ template <class R> DSP_HD cx<R> csub_mi(cx<R> a, cx<R> b) { return cmk<R>(a.x - 
 // (8K row pairs, motion's 8-bit row ends: profiles/r05_isa_*.txt) get through their butterflies in ~0.6 of the issues.  The results are the
 // same sums and products (one rounding per operation either way; which of a product pair is the FMA's addend is the compiler's choice in both).
 // Host (g++ emulation): the templates above.
-#if defined(__clang__) && defined(__HIP_DEVICE_COMPILE__) && !defined(DSP_NO_PK_CX)
+// (only where the ISA has packed FP32 in VOP3P: gfx90a and the gfx94x / gfx950 family.  The library builds for gfx950 alone; the guard keeps an ARCH
+// override of the Makefile or a plan-time compile for another device on the scalar templates instead of failing in the assembler.)
+#if defined(__clang__) && defined(__HIP_DEVICE_COMPILE__) && !defined(DSP_NO_PK_CX) && \
+    (defined(__gfx90a__) || defined(__gfx940__) || defined(__gfx941__) || defined(__gfx942__) || defined(__gfx950__))
 DSP_HD Pk2 pk_of(cf a) { return pk2(a.x, a.y); }
 DSP_HD cf cf_of(Pk2 v) { cf r; r.x = v.x; r.y = v.y; return r; }
 DSP_HD cf cadd(cf a, cf b) { return cf_of(pk_of(a) + pk_of(b)); }

@@ -177,7 +177,9 @@ int dspfft_execute_masked_accumulate_f64(dspfft_plan plan, const double *d_in, d
  * {D/8,8HW,8HW},{H/8,8W,8W},{W/8,8,8}.  rank 1..3, howmany_rank 0..6; f64 != 0 selects double samples.  Lengths up to
  * 32 run one line per thread in registers. */
 typedef struct { int n; int is; int os; } dspfft_iodim;
-/* Planning effort for the plans the CALLING THREAD creates after the call (thread-local; plans already made keep theirs).
+/* Planning effort for the plans created after the call, on ANY thread of the process (plans already made keep theirs); a thread may override it for
+ * the plans it makes itself with dspfft_set_thread_plan_effort (effort < 0 removes the override; dspfft_get_thread_plan_effort: -1 when none), which is
+ * what the FFTW shim does around each fftw(plan_many_r2r).  dspfft_get_plan_effort returns the value in force for the calling thread.
  * 0 (default): a frame size without a compile-time-specialised kernel (spec_list.h) runs on the runtime-geometry kernels.
  * > 0: such sizes get RowSpecT / ColSpecT kernels COMPILED AT PLAN TIME (hiprtc: about a second per new size, then cached in
  * $DSPFFT_JIT_CACHE or ~/.cache/dspfft-jit) and run 1.3-1.8x faster from then on.
@@ -187,6 +189,8 @@ typedef struct { int n; int is; int os; } dspfft_iodim;
  * DSPFFT_JIT_TUNE=1 / 2 the timed search. */
 void dspfft_set_plan_effort(int effort);
 int dspfft_get_plan_effort(void);
+void dspfft_set_thread_plan_effort(int effort);
+int dspfft_get_thread_plan_effort(void);
 int dspfft_plan_guru_r2r(dspfft_plan *plan, int rank, const dspfft_iodim *dims, int howmany_rank, const dspfft_iodim *howmany_dims,
                          const int *kinds, int f64);
 

@@ -87,10 +87,11 @@ def test_bench_gpus_n_launches_its_own_ranks():
 
 
 
-def test_planning_effort_is_the_calling_threads_own_and_two_threads_plan_and_execute_side_by_side():
-    """dspfft_set_plan_effort is thread-local state (the FFTW shim sets and restores it around each fftw(plan_many_r2r)): what one thread sets
-    another never sees, and two threads that plan and execute at the same time -- one of them flipping its effort all the while -- both get
-    the transform.  On the test-only emulation library (the engine's planner and pass logic are the product's; ctypes releases the GIL for the calls)."""
+def test_planning_effort_override_is_the_calling_threads_own_and_two_threads_plan_and_execute_side_by_side():
+    """dspfft_set_plan_effort is process-wide (a plan made on any thread sees it: worker pools, Python threads -- ADVICE r05); the override
+    dspfft_set_thread_plan_effort is the calling thread's own (the FFTW shim sets and restores it around each fftw(plan_many_r2r)): what one thread
+    overrides another never sees, and two threads that plan and execute at the same time -- one of them flipping its override all the while -- both
+    get the transform.  On the test-only emulation library (the engine's planner and pass logic are the product's; ctypes releases the GIL for the calls)."""
     import threading
     import numpy as np
     import oracle_lib as ol
@@ -98,17 +99,20 @@ def test_planning_effort_is_the_calling_threads_own_and_two_threads_plan_and_exe
     from dspfun_amd.engine import Plan, REDFT10, REDFT01
     L = emul()
     L.dspfft_set_plan_effort.restype = None
-    L.dspfft_set_plan_effort(0)
+    L.dspfft_set_thread_plan_effort.restype = None
+    L.dspfft_set_plan_effort(3)
+    assert L.dspfft_get_plan_effort() == 3 and L.dspfft_get_thread_plan_effort() == -1
     seen, errors = {}, []
     start = threading.Barrier(2)
 
     def worker(name, effort, h, w):
         try:
+            assert L.dspfft_get_plan_effort() == 3 and L.dspfft_get_thread_plan_effort() == -1      # the process-wide value reaches a new thread
             start.wait()
             x = ol.synth_f32(hash(name) & 0xffff, h * w * 3).reshape(h, w, 3)
             ref = ol.dct2d_interleaved(x.astype(np.float64), REDFT10, impl="port", threads=1)
             for it in range(12):
-                L.dspfft_set_plan_effort(effort if it % 2 == 0 else effort + 1)
+                L.dspfft_set_thread_plan_effort(effort if it % 2 == 0 else effort + 1)
                 fwd = Plan.image(h, w, 3, REDFT10, lib=L)
                 inv = Plan.image(h, w, 3, REDFT01, lib=L).set_scale(1.0 / (4 * w * h))
                 assert L.dspfft_get_plan_effort() == (effort if it % 2 == 0 else effort + 1)       # nobody else touched it
@@ -118,6 +122,8 @@ def test_planning_effort_is_the_calling_threads_own_and_two_threads_plan_and_exe
                 inv.execute(d.ctypes.data)
                 assert np.abs(d - x).max() < 5e-6
             seen[name] = L.dspfft_get_plan_effort()
+            L.dspfft_set_thread_plan_effort(-1)
+            assert L.dspfft_get_plan_effort() == 3
         except Exception as e:              # (an assertion in a thread would otherwise vanish)
             errors.append((name, repr(e)))
 
@@ -126,6 +132,7 @@ def test_planning_effort_is_the_calling_threads_own_and_two_threads_plan_and_exe
         t.start()
     for t in ts:
         t.join()
+    L.dspfft_set_plan_effort(0)
     assert not errors, errors
     assert seen == {"a": 1, "b": 5}
-    assert L.dspfft_get_plan_effort() == 0          # ... and the main thread's is still what it set
+    assert L.dspfft_get_plan_effort() == 0 and L.dspfft_get_thread_plan_effort() == -1      # ... and the main thread never had an override
