@@ -74,6 +74,26 @@ def physical_core_cpus():
     return [c for _, c in cpus], per_pkg
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited.  The GPU boxes' containers see 256 logical
+    CPUs and are held to 16 by the CFS quota: threads beyond it are throttled, not run (profiles/r06_cpu_scale.txt: 16 threads 178-188 Mpix/s,
+    128 threads 54-62)."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = float(f.read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(max_seconds=30.0):
     """Oracle CPU port (f32) on full 3840x2160x3 roundtrips: ONE thread and ALL physical cores (SURVEY.md 8d asks for both).  Only this leg of
     bench.py touches oracle/.  The all-core figure runs oracle/cpu_port_impl.h's bench entry (round 5's all-core number was
@@ -87,7 +107,9 @@ def cpu_baseline(max_seconds=30.0):
     L = ol.lib()
     x = ol.synth_f32(SEED, H * W * C)
     cpus, per_pkg = physical_core_cpus()
-    cpus = cpus[:max(1, min(len(cpus), L.cpu_port_max_threads()))]
+    quota = cpu_quota()
+    usable = len(cpus) if quota is None else max(1, min(len(cpus), int(quota + 0.5)))      # "all cores" = all the container is given time on
+    cpus = cpus[:max(1, min(usable, L.cpu_port_max_threads()))]
     fn = L.cpu_port_roundtrip_bench_f32
     fn.restype = C_.c_int
     fn.argtypes = [C_.c_int, C_.c_int, C_.c_int, C_.c_void_p, C_.c_int, C_.c_void_p, C_.c_int, C_.POINTER(C_.c_double), C_.POINTER(C_.c_double)]
@@ -111,11 +133,13 @@ def cpu_baseline(max_seconds=30.0):
     ra, ea, erra, pinned = run(len(cpus), max_seconds * 0.4)
     return {"value": round(ra * H * W / 1e6 / ea, 3), "unit": "Mpixels/s", "cores": len(cpus), "kind": "port",
             "single_thread_value": round(r1 * H * W / 1e6 / e1, 3), "all_core_over_single_thread": round((ra / ea) / (r1 / e1), 1),
-            "sample": f"{ra} in-place roundtrip(s) of one 3840x2160x3 f32 frame on {len(cpus)} OpenMP threads, "
+            "cpu_quota": quota, "physical_cores": sum(per_pkg.values()),
+            "sample": f"{ra} consecutive in-place roundtrip(s) of one 3840x2160x3 f32 frame on {len(cpus)} OpenMP threads, "
                       f"{'each pinned to its own physical core' if pinned else 'unpinned (affinity not settable here)'} "
-                      f"({', '.join(f'socket {k}: {v} cores' for k, v in sorted(per_pkg.items()))}; {os.cpu_count()} logical CPUs), frame first touched by the threads that own its rows, "
-                      f"static row / 16-column-block ranges, one thread team, plans built before the clock starts; {r1} roundtrip(s) with one thread; "
-                      f"oracle/cpu_port_impl.h cpu_port_roundtrip_bench (roundtrip max abs err {max(err1, erra):.1e})"}
+                      f"(the box: {', '.join(f'socket {k}: {v} cores' for k, v in sorted(per_pkg.items()))}, {os.cpu_count()} logical CPUs; "
+                      f"{'no CPU quota' if quota is None else f'the container is held to {quota:g} CPUs of time by its cgroup quota, so that many threads: more are throttled, not run'}), "
+                      f"frame first touched by the threads that own its rows, static row / 16-column-block ranges, one thread team, plans built before the clock starts; "
+                      f"{r1} roundtrip(s) with one thread; oracle/cpu_port_impl.h cpu_port_roundtrip_bench (max abs err after the last roundtrip {max(err1, erra):.1e})"}
 
 
 def scipy_cpu_baseline(max_seconds=10.0):
