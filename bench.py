@@ -565,8 +565,11 @@ def main():
             # north_star asks for >= 70 % of the HBM roofline on this roundtrip.  A plane is 200 times what a CU holds and the row -> column exchange
             # crosses XCDs, so each direction is two passes over memory: four passes per roundtrip at the no-arithmetic floors of their access shapes
             # (37.5 + 34.5 + 34.5 + 29.5 us, profiles/r02_membench2.csv) are 0.366 of the 48 B/pixel roofline -- the declared cap of this design
-            "target": {"roundtrip_frac_of_hbm_roofline": 0.70, "declared_cap": 0.366, "frac_of_declared_cap": round(value * 1e6 * ALG_BYTES_PER_PIXEL / (HBM_PEAK * world) / 0.366, 3),
-                       "why": "two memory passes per direction are forced (no plane fits on chip); four passes at the copy floors of their access shapes = 0.366"},
+            # (the TARGET is north_star's 0.70 and is not met; `builders_model_of_this_design` is the builder's own estimate of what a two-pass-per-direction
+            # design can reach, reported for context: not a goal post -- ADVICE r05)
+            "target": {"roundtrip_frac_of_hbm_roofline": 0.70, "met": bool(value * 1e6 * ALG_BYTES_PER_PIXEL / (HBM_PEAK * world) >= 0.70),
+                       "builders_model_of_this_design": {"cap": 0.366, "frac_of_it": round(value * 1e6 * ALG_BYTES_PER_PIXEL / (HBM_PEAK * world) / 0.366, 3),
+                                                         "why": "two memory passes per direction are forced (no plane fits on chip); four passes at the copy floors of their access shapes = 0.366"}},
             "single_stream_value": single_stream_value,
             "frame_latency_ms": frame_latency,
             "forward_check": {"dc_rel_err": fwd_dc_err, "energy_rel_err": fwd_energy_err,
