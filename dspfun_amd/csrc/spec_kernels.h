@@ -440,9 +440,6 @@ __global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_kerne
 // would wait for it (see row_persist_kernel).  Plain passes only (the fused scan step's masked / accumulating pair pass keeps row_pair_kernel).
 // (Fetching BOTH lines one transform ahead and storing the pair behind the next line's phase 0 was built first: the held output line costs 24 more
 // registers through every phase, and 184 KB of stores in one burst block the issuing waves for 15-18K clocks: 236 / 232 us, profiles/r06_8k_pair_pipe.txt.)
-#ifndef DSP_PAIR_PIPE_EARLY10
-#define DSP_PAIR_PIPE_EARLY10 0
-#endif
 #ifndef DSP_PAIR_PIPE_T
 #define DSP_PAIR_PIPE_T 768
 #endif
@@ -639,7 +636,7 @@ int launch_row_pair(const typename S::PA &a, int npairs, void *stream)
 			// counts them and waits for the loads alone); REDFT10's stores sit under per-lane conditions, the wait behind them would be for the whole
 			// queue, so its request goes out behind them (198.0 in front, 195.7 behind).
 			typedef typename S::template with_threads<DSP_PAIR_PIPE_T> SP;
-			constexpr bool EARLY = KIND == KIND_REDFT01 || DSP_PAIR_PIPE_EARLY10;
+			constexpr bool EARLY = KIND == KIND_REDFT01;
 			static DevOnce ponce;
 			if (int p_rc = allow_lds_dev(ponce, pair_pipe_lds<SP>(), row_pair_pipe_kernel<SP, KIND, EARLY>)) return p_rc;
 			hipLaunchKernelGGL((row_pair_pipe_kernel<SP, KIND, EARLY>), dim3(cus), dim3(SP::T), pair_pipe_lds<SP>(), (hipStream_t)stream, a, npairs);
