@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <atomic>
 #include <complex>
+#include <mutex>
 #include <dlfcn.h>
 #include <string>
 #include <type_traits>
@@ -219,6 +220,8 @@ struct dspfft_plan_s {
 	// (roundtrip_core), built on first use and owned by the forward plan
 	struct RtSlices { const dspfft_plan_s *inv_of = nullptr; int frames = 0; dspfft_plan_s *fwd = nullptr, *inv = nullptr, *fwd_rem = nullptr, *inv_rem = nullptr; void *side = nullptr, *ev_fork = nullptr, *ev_join = nullptr; };
 	std::vector<RtSlices> rt_slices;
+	std::mutex rt_mutex;                     // two host threads may run the same plan pair on their own buffers and streams: the slice plans are made once, and
+	                                         // a call's fork / slices / join are enqueued as one piece (the library stream and its two events are shared)
 };
 
 namespace {
@@ -1557,6 +1560,7 @@ int roundtrip_sliced(dspfft_plan fwd, dspfft_plan inv, float *d_work, const uint
 	static const int nstreams = []() { const char *e = getenv("DSPFFT_RT_STREAMS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v > 2 ? 2 : v; }();
 	const int S = slice_frames(fwd, inv, fp, nstreams);
 	if (!S) return 0;
+	std::lock_guard<std::mutex> lock(fwd->rt_mutex);
 	dspfft_plan_s::RtSlices *r = nullptr;
 	for (dspfft_plan_s::RtSlices &c : fwd->rt_slices) if (c.inv_of == inv && c.frames == S) r = &c;
 	if (!r) {
