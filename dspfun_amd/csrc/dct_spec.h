@@ -369,6 +369,47 @@ struct RowSpecG {
 		}
 	}
 
+	// ---- REDFT01 loads behind a masked column pass, with the tile flags of THIS THREAD's samples precomputed (row_pair_pipe_kernel's scan form) ----
+	// The flags are per column tile (zf[(offset in the line) >> zshift]): which of a thread's samples lie in skipped tiles is the same for every line of a pass.
+	// A persistent workgroup therefore looks the flags up ONCE -- bit (ri * 4 + j) * C + c of the result: sample c of pixel j (k, N - k, L - k, L + k) of round
+	// ri is to be read -- where prefetch_m's FLAGGED form spends two flag loads, three shifts and a handful of selects on every pixel of every line (about 300
+	// of a line's 1100 vector instructions on 7680 x 3 lines).  zf == nullptr: everything is read.
+	static_assert(4 * K_ROUNDS * C <= 64 || C > 4, "one bit per sample of a REDFT01 line's loads");
+	static DSP_HD int pixel01(int k, int j) { return j == 0 ? k : j == 1 ? (k ? N - k : 0) : j == 2 ? L - k : L + k; }
+	static DSP_HD unsigned long long flag_bits01(const uint8_t *zf, int zshift, int tid)
+	{
+		unsigned long long m = 0;
+		static_for<0, K_ROUNDS>([&](auto ri) {
+			const int k = tid + ri * T;
+			if (!((ri + 1) * T <= L / 2 + 1 || k <= L / 2)) return;
+			static_for<0, 4>([&](auto j) {
+				const int o = pixel01(k, j) * GS;
+				static_for<0, C>([&](auto c) { if (!zf || zf[(o + c) >> zshift]) m |= 1ull << ((ri * 4 + j) * C + c); });
+			});
+		});
+		return m;
+	}
+	template <class ST>
+	static DSP_HD void prefetch01_bits(const PA &a, long long bin, int tid, ST &st, unsigned long long bits)
+	{
+		static_for<0, K_ROUNDS>([&](auto i) {
+			const int k = tid + i * T;
+			if ((i + 1) * T <= L / 2 + 1 || k <= L / 2) st.tw[i] = a.T[k];
+		});
+		static_for<0, K_ROUNDS>([&](auto i) {
+			const int k = tid + i * T;
+			if ((i + 1) * T <= L / 2 + 1 || k <= L / 2) {
+				static_for<0, 4>([&](auto j) {
+					const unsigned b = (unsigned)(bits >> ((i * 4 + j) * C)) & ((1u << C) - 1u);
+					// (no branch around the load, see load_pix_m: a pixel nobody wrote loads from the page of zeros)
+					const Re *p = b ? a.in + bin + (long long)pixel01(k, j) * GS : reinterpret_cast<const Re *>(a.zpage);
+					const Pix<C, Re> v = load_pix<C, Re>(p);
+					static_for<0, C>([&](auto c) { st.pre[(i * 4 + j) * C + c] = ((b >> c) & 1u) ? v.v[c] : (Re)0; });
+				});
+			}
+		});
+	}
+
 	static DSP_HD int padded(int p) { return p + (p / SB) * PADC; }
 
 	// stages 0 .. NS-2 (in place, padded layout)

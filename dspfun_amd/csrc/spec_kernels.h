@@ -457,7 +457,22 @@ template <class V> __device__ __forceinline__ void forget(V &v)
 }
 template <class S> constexpr size_t pair_pipe_lds() { return S::LDS + sizeof(typename S::CX) * (size_t)(S::L + S::L / 2 + 1); }
 template <class S> constexpr bool pair_pipe_ok() { return S::C > 1 && S::LDS > 80 * 1024 && pair_pipe_lds<S>() <= 160 * 1024; }
-template <class S, int KIND, bool EARLY = false>
+// SCAN: the pair pass of the fused scan step (scan/scan.c:446-459, REDFT01 behind the masked half-tile pass, work buffer -> running sum).  Its lines are read with
+// that pass's tile flags (PassGeom::zflags; copied into LDS, kPairPipeFlagBytes behind the tables: a flag fetched from memory in front of every pixel load would
+// have the load wait for everything the pipe holds) and are mostly zeros (a frame keeps 1/32 of the coefficients), so there is little to hide on the input side;
+// what row_pair_kernel waits for is `sum += image`: the old values of an output line are loaded in its closing phase, right before they are added -- twice per
+// pair, 1.19 GB per frame at 4.3 TB/s.  Here the old values of the first output line are requested behind phase 0 of r2 (30 registers that hold nothing else
+// then: the next pair's r1 goes out behind the stores, as in REDFT10's plain form) and have landed when r2's closing phase adds them; the second line's go out
+// at the head of that phase and land while the first line is stored.
+constexpr int kPairPipeFlagBytes = 4096;
+template <class PA> __host__ __device__ inline PA scan_pair_args(const PA &a_)
+{
+	PA a = a_;
+	a.mask = nullptr; a.zranges = nullptr; a.win_lo = a.win_hi = 0; a.alt_out = 0; a.in_mul = nullptr; a.in_rev = 0;
+	return a;
+}
+template <class PA> static inline bool is_scan_pair(const PA &a) { return !a.mask && a.win_hi <= 0 && !a.alt_out && !a.in_mul && !a.in_rev && (!a.zflags || 2 * a.zhalf <= kPairPipeFlagBytes); }
+template <class S, int KIND, bool EARLY = false, bool SCAN = false>
 __global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_pipe_kernel(const typename S::PA a_, int nwork)
 {
 	typedef typename S::CX CX;
@@ -468,15 +483,27 @@ __global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_pipe_
 	const int tid = threadIdx.x;
 	for (int i = tid; i < S::L; i += S::T) wtab[i] = a_.W[i];
 	for (int i = tid; i <= S::L / 2; i += S::T) ttab[i] = a_.T[i];
-	typename S::PA a = plain_args(a_);
+	typename S::PA a = SCAN ? scan_pair_args(a_) : plain_args(a_);
 	a.W = wtab; a.T = ttab;
+	// the tile flags of the two halves (even rows: r1's, odd rows: r2's), or null
+	uint8_t *ftab = reinterpret_cast<uint8_t *>(ttab + S::L / 2 + 1);
+	if constexpr (SCAN) { if (a.zflags) for (int i = tid; i < 2 * a.zhalf; i += S::T) ftab[i] = a.zflags[i]; }
+	const uint8_t *zf1 = (SCAN && a.zflags) ? ftab : nullptr, *zf2 = (SCAN && a.zflags) ? ftab + a.zhalf : nullptr;
+	unsigned long long bits1 = ~0ull, bits2 = ~0ull;     // SCAN: which of this thread's samples of an even / odd line are to be read (RowSpecG::flag_bits01)
 	const int pairs = a.nb0 >> 1;
 	// element offset of line `second` (0: y1 = 2n, 1: y2 = nb0 - 1 - 2n) of pair `work`
 	auto line_in = [&](int work, int second) { const int i1 = work / pairs, n = work - i1 * pairs; return (long long)(second ? a.nb0 - 1 - 2 * n : 2 * n) * a.sb0_in + (long long)i1 * a.sb1_in; };
 	auto line_out = [&](int work, int second) { const int i1 = work / pairs, n = work - i1 * pairs; return (long long)(second ? a.nb0 - 1 - 2 * n : 2 * n) * a.sb0_out + (long long)i1 * a.sb1_out; };
 	typename S::template State<KIND> st;
 	typename S::template OutHold<KIND> h1;           // T(r1)'s outputs
+	typename S::template OutHold<KIND> old1, old2;   // SCAN: the running sum's old values of the pair's two output lines (dead otherwise)
 	__syncthreads();                                 // the tables are in place
+	if constexpr (SCAN && KIND == KIND_REDFT01) { if (a.zflags) { bits1 = S::flag_bits01(zf1, a.zshift, tid); bits2 = S::flag_bits01(zf2, a.zshift, tid); } }
+	// the loads of a line: plain, or (SCAN) with this thread's precomputed flags
+	auto fetch = [&](long long bin, int t, auto SECOND_LINE) __attribute__((always_inline)) {
+		if constexpr (SCAN && KIND == KIND_REDFT01) S::prefetch01_bits(a, bin, t, st, SECOND_LINE ? bits2 : bits1);
+		else S::template prefetch<KIND>(a, bin, t, st, nullptr, nullptr);
+	};
 	// one pair per iteration, its two lines spelled out (SECOND is a compile-time constant)
 	auto line = [&](auto SECOND, long long in_next, bool has_next, long long pb1, long long pb2) __attribute__((always_inline)) {
 		// (the thread index is re-made opaque for every line: see row_persist_kernel)
@@ -487,10 +514,18 @@ __global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_pipe_
 		DSP_STAMP(SECOND ? 11 : 1);
 		if constexpr (!SECOND) {                     // r2: lands behind r1's stages
 			forget(h1); forget(st.pre);
-			S::template prefetch<KIND>(a, in_next, t, st, nullptr, nullptr);
+			fetch(in_next, t, std::integral_constant<bool, true>());
 		} else if constexpr (EARLY) {                // the next pair's r1 behind r2's stages, IN FRONT of this pair's stores
 			forget(st.pre);
-			if (has_next) S::template prefetch<KIND>(a, in_next, t, st, nullptr, nullptr);
+			if (has_next) fetch(in_next, t, std::integral_constant<bool, false>());
+		} else if constexpr (SCAN && KIND == KIND_REDFT01) {
+			if (a.accumulate) {                      // sum += image (scan.c:451-459): the first line's old values, landing behind r2's stages
+				forget(old1);
+				static_for<0, S::PIX_ROUNDS>([&](auto i) {
+					const int x = t + i * S::T;
+					if ((i + 1) * S::T <= S::N || x < S::N) old1.v[i] = load_pix<S::C, Re>(a.out + pb1 + (long long)x * S::GS);
+				});
+			}
 		}
 		__syncthreads();
 		DSP_STAMP(SECOND ? 12 : 2);
@@ -504,22 +539,46 @@ __global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_pipe_
 		if constexpr (!SECOND) {
 			S::template final_each<KIND>(a, planes, u, st, [&](auto slot, long long, Pix<S::C, Re> v) { h1.v[slot] = v; });
 		} else {
-			S::template final_each<KIND>(a, planes, u, st, [&](auto slot, long long off, Pix<S::C, Re> v) {
-				Pix<S::C, Re> o1, o2;
-				static_for<0, S::C>([&](auto c) { o1.v[c] = h1.v[slot].v[c] + v.v[c]; o2.v[c] = h1.v[slot].v[c] - v.v[c]; });
-				store_pix<S::C, Re>(a.out + pb1 + off, o1);
-				store_pix<S::C, Re>(a.out + pb2 + off, o2);
-			});
+			bool done = false;
+			if constexpr (SCAN && KIND == KIND_REDFT01) {
+				if (a.accumulate) {
+					// the second line's old values go out now and land while the first line is added and stored (two sweeps over the plane: REDFT01's closing
+					// phase is one LDS read and a product per sample; both lines' old values held through r2's stages would be 30 registers too many: 56 spilled)
+					forget(old2);
+					static_for<0, S::PIX_ROUNDS>([&](auto i) {
+						const int x = u + i * S::T;
+						if ((i + 1) * S::T <= S::N || x < S::N) old2.v[i] = load_pix<S::C, Re>(a.out + pb2 + (long long)x * S::GS);
+					});
+					S::template final_each<KIND>(a, planes, u, st, [&](auto slot, long long off, Pix<S::C, Re> v) {
+						Pix<S::C, Re> o;
+						static_for<0, S::C>([&](auto c) { o.v[c] = (h1.v[slot].v[c] + v.v[c]) + old1.v[slot].v[c]; });
+						store_pix<S::C, Re>(a.out + pb1 + off, o);
+					});
+					S::template final_each<KIND>(a, planes, u, st, [&](auto slot, long long off, Pix<S::C, Re> v) {
+						Pix<S::C, Re> o;
+						static_for<0, S::C>([&](auto c) { o.v[c] = (h1.v[slot].v[c] - v.v[c]) + old2.v[slot].v[c]; });
+						store_pix<S::C, Re>(a.out + pb2 + off, o);
+					});
+					done = true;
+				}
+			}
+			if (!done)
+				S::template final_each<KIND>(a, planes, u, st, [&](auto slot, long long off, Pix<S::C, Re> v) {
+					Pix<S::C, Re> o1, o2;
+					static_for<0, S::C>([&](auto c) { o1.v[c] = h1.v[slot].v[c] + v.v[c]; o2.v[c] = h1.v[slot].v[c] - v.v[c]; });
+					store_pix<S::C, Re>(a.out + pb1 + off, o1);
+					store_pix<S::C, Re>(a.out + pb2 + off, o2);
+				});
 			if constexpr (!EARLY) {
 				forget(st.pre);
-				if (has_next) S::template prefetch<KIND>(a, in_next, u, st, nullptr, nullptr);     // the next pair's r1, behind this pair's stores
+				if (has_next) fetch(in_next, u, std::integral_constant<bool, false>());     // the next pair's r1, behind this pair's stores
 			}
 		}
 		__syncthreads();                             // the plane is the next line's
 		DSP_STAMP(SECOND ? 19 : 9);
 	};
 	int work = blockIdx.x;
-	if (work < nwork) S::template prefetch<KIND>(a, line_in(work, 0), tid, st, nullptr, nullptr);
+	if (work < nwork) fetch(line_in(work, 0), tid, std::integral_constant<bool, false>());
 	while (work < nwork) {
 		const int next = work + (int)gridDim.x;
 		line(std::integral_constant<bool, false>(), line_in(work, 1), true, 0, 0);
@@ -628,6 +687,19 @@ int launch_row_pair(const typename S::PA &a, int npairs, void *stream)
 		// DSPFFT_PAIR_PIPE=0 keeps one workgroup per pair (A/B runs)
 		static const int on = []() { const char *e = getenv("DSPFFT_PAIR_PIPE"); return e ? atoi(e) : 1; }();
 		const int cus = device_cus();
+		if constexpr (KIND == KIND_REDFT01) {
+			// the fused scan step's accumulating pair pass (BASELINE config 4): DSPFFT_PAIR_PIPE_SCAN=0 keeps row_pair_kernel
+			static const int scan_on = []() { const char *e = getenv("DSPFFT_PAIR_PIPE_SCAN"); return e ? atoi(e) : 1; }();
+			if (on && scan_on && !is_plain(a) && is_scan_pair(a) && a.in != a.out && npairs > cus) {
+				typedef typename S::template with_threads<DSP_PAIR_PIPE_T> SP;
+				static DevOnce sonce;
+				const size_t bytes = pair_pipe_lds<SP>() + kPairPipeFlagBytes;
+				if (int p_rc = allow_lds_dev(sonce, bytes, row_pair_pipe_kernel<SP, KIND, false, true>)) return p_rc;
+				hipLaunchKernelGGL((row_pair_pipe_kernel<SP, KIND, false, true>), dim3(cus), dim3(SP::T), bytes, (hipStream_t)stream, a, npairs);
+				HIPCHK(hipGetLastError());
+				return 0;
+			}
+		}
 		if (on && is_plain(a) && npairs > cus) {
 			// on DSP_PAIR_PIPE_T = 768 threads: the held output line, the line in flight and the closing phase's arithmetic need more than the 128
 			// registers that 1024 threads leave each, and 768 fill the radix-16 / radix-15 stages' rounds better (720 and 768 butterflies); measured

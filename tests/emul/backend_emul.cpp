@@ -352,7 +352,7 @@ int launch_row_pair_pipe(const PassArgs &a_, int npairs)
 {
 	std::vector<unsigned char> lds(S::LDS + 16);
 	cf *planes = (cf *)lds.data();
-	const PassArgs &a = a_;                          // (plain: launch_row_pair checks)
+	const PassArgs &a = a_;                          // (plain, or the scan step's pair pass: launch_row_pair checks)
 	const int pairs = a.nb0 >> 1;
 	typedef typename S::template State<KIND> ST;
 	typedef typename S::template OutHold<KIND> OH;
@@ -363,7 +363,16 @@ int launch_row_pair_pipe(const PassArgs &a_, int npairs)
 		std::vector<ST> st(S::T), st2(S::T);
 		std::vector<OH> h1(S::T);
 		// (both lines are read before anything is stored, as in the kernel: in place is safe)
+		// the scan form (REDFT01 behind the masked half-tile pass): the loads go by this thread's precomputed tile flags -- even rows' flags for r1, odd rows' for r2
+		const bool scan = KIND == KIND_REDFT01 && !is_plain_pass(a);
 		for (int tid = 0; tid < S::T; tid++) {
+			if constexpr (KIND == KIND_REDFT01) {
+				if (scan) {
+					S::prefetch01_bits(a, y[0] * a.sb0_in + i1 * a.sb1_in, tid, st[tid], S::flag_bits01(a.zflags, a.zshift, tid));
+					S::prefetch01_bits(a, y[1] * a.sb0_in + i1 * a.sb1_in, tid, st2[tid], S::flag_bits01(a.zflags ? a.zflags + a.zhalf : nullptr, a.zshift, tid));
+					continue;
+				}
+			}
 			S::template prefetch<KIND>(a, y[0] * a.sb0_in + i1 * a.sb1_in, tid, st[tid], nullptr, nullptr);
 			S::template prefetch<KIND>(a, y[1] * a.sb0_in + i1 * a.sb1_in, tid, st2[tid], nullptr, nullptr);
 		}
@@ -375,6 +384,10 @@ int launch_row_pair_pipe(const PassArgs &a_, int npairs)
 				else S::template final_each<KIND>(a, planes, tid, cur[tid], [&](auto slot, long long off, Pix<S::C, float> v) {
 					Pix<S::C, float> o1, o2;
 					for (int c = 0; c < S::C; c++) { o1.v[c] = h1[tid].v[slot].v[c] + v.v[c]; o2.v[c] = h1[tid].v[slot].v[c] - v.v[c]; }
+					if (a.accumulate) {               // sum += image (scan.c:451-459)
+						const Pix<S::C, float> q1 = load_pix<S::C, float>(a.out + b1 + off), q2 = load_pix<S::C, float>(a.out + b2 + off);
+						for (int c = 0; c < S::C; c++) { o1.v[c] += q1.v[c]; o2.v[c] += q2.v[c]; }
+					}
 					store_pix<S::C, float>(a.out + b1 + off, o1);
 					store_pix<S::C, float>(a.out + b2 + off, o2);
 				});
@@ -390,7 +403,9 @@ int launch_row_pair(const PassArgs &a, int npairs, void *)
 		const char *e = getenv("EMUL_PAIR_PIPE");
 		const int mode = e ? atoi(e) : -1;
 		constexpr bool fills_a_cu = S::C > 1 && S::LDS > 80 * 1024;
-		if (is_plain_pass(a) && S::C > 1 && (mode == 1 || (mode != 0 && fills_a_cu))) {
+		// plain passes, and REDFT01 pair passes of the fused scan step (tile flags + accumulation, out of place), as the HIP launcher chooses
+		const bool scan_pair = KIND == KIND_REDFT01 && !a.mask && a.win_hi <= 0 && !a.alt_out && !a.in_mul && !a.in_rev && a.in != a.out;
+		if ((is_plain_pass(a) || scan_pair) && S::C > 1 && (mode == 1 || (mode != 0 && fills_a_cu))) {
 			if constexpr (fills_a_cu) return launch_row_pair_pipe<typename S::template with_threads<768>, KIND>(a, npairs);
 			else if constexpr (S::C > 1) return launch_row_pair_pipe<S, KIND>(a, npairs);
 		}

@@ -110,9 +110,11 @@ def test_split_is_not_used_where_it_does_not_apply():
     assert d.splitlines()[1].startswith("axis 0: COL*/2 N=4320 as 2 x 2160, K=16")
 
 
-def test_forced_split_carries_the_fused_scan_step(forced):
+@pytest.mark.parametrize("pipe", ["0", "1"])       # row_pair_kernel's order of work / the pipelined pair kernel's scan form (loads by precomputed tile flags, accumulation in r2's closing phase)
+def test_forced_split_carries_the_fused_scan_step(forced, pipe, monkeypatch):
     """scan/scan.c:429-459 through the split passes: mask on the half-tile column pass's loads, accumulation in the row-pair pass's
     stores -- the same sums as the plain passes and as the f64 restatement"""
+    monkeypatch.setenv("EMUL_PAIR_PIPE", pipe)
     h, w, c = 512, 512, 3
     x = ol.synth_f32(0xD5F0004, h * w * c).reshape(h, w, c)
     fwd = Plan.image(h, w, c, REDFT10, lib=emul()).set_scale(1.0 / (4 * w * h))
@@ -149,6 +151,7 @@ def test_masked_accumulate_skips_empty_tiles(force_split, dtype, monkeypatch):
         pytest.skip("double plans have no column split")
     if force_split:
         monkeypatch.setenv("DSPFFT_FORCE_SPLIT", "1")
+        monkeypatch.setenv("EMUL_PAIR_PIPE", "1")     # the pair pass in the pipelined kernel's scan form: the skipped tiles through RowSpecG::flag_bits01 / prefetch01_bits
     else:
         monkeypatch.setenv("DSPFFT_ZSKIP", "1")       # plain plans take part on request only
     L = emul()
