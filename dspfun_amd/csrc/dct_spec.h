@@ -185,7 +185,7 @@ template <bool MASKED, class Re> DSP_HD typename sig_of<Re>::type loadv_m(const 
 // are then one 4- or 8-byte load next to its neighbours' (a wave: 256 or 512 contiguous bytes), where the owner-id array itself costs one
 // 128-byte line per tile ROW for 22 bytes of it: 6.8 M L2 requests per 8K frame, every one a miss in the vector L1 -- the 8K column pass
 // spent 155 of its 200 us on them, whatever the order of the loads and whichever XCD the neighbours ran on (profiles/r04_scan_mask.txt).
-// Two steps: all ids of a thread's items, then all coefficients, an item nobody selected from the page of zeros (no branch between loads).
+// Two steps: all ids of a thread's items, then all coefficients (an item nobody selected is not loaded).
 // EB = bytes per id; ids that do not fit (and the DC pixel's "no frame") are stored as all ones and match no frame the table is used for.
 template <int EB, class Re> struct MaskIds { uint32_t v[EB == 1 ? 1 : 2 * sig_of<Re>::NCS * EB / 4]; };
 template <int EB, class Re> DSP_HD void mask_fetch_ids(const PassArgsT<Re> &a, long long eoff, MaskIds<EB, Re> &m)
@@ -207,7 +207,11 @@ template <int EB, class Re> DSP_HD typename sig_of<Re>::type mask_select_load(co
 		any = any || sel[c];
 	});
 	hit = hit || any;
-	V v = *(any ? reinterpret_cast<const V *>(a.in + off) : reinterpret_cast<const V *>(a.zpage));
+	// an item nobody selected is not loaded at all: the lanes that selected one load under the execution mask, a wave without any skips the instruction
+	// (round 6; until then it loaded from the page of zeros: scan step 329.8 -> 327.4 us)
+	V v;
+	static_for<0, NCS>([&](auto i) { v.s[i].x = v.s[i].y = (Re)0; });
+	if (any) v = *reinterpret_cast<const V *>(a.in + off);
 	static_for<0, NCS>([&](auto i) { if (!sel[2 * i]) v.s[i].x = (Re)0; if (!sel[2 * i + 1]) v.s[i].y = (Re)0; });
 	return v;
 }
@@ -401,9 +405,11 @@ struct RowSpecG {
 			if ((i + 1) * T <= L / 2 + 1 || k <= L / 2) {
 				static_for<0, 4>([&](auto j) {
 					const unsigned b = (unsigned)(bits >> ((i * 4 + j) * C)) & ((1u << C) - 1u);
-					// (no branch around the load, see load_pix_m: a pixel nobody wrote loads from the page of zeros)
-					const Re *p = b ? a.in + bin + (long long)pixel01(k, j) * GS : reinterpret_cast<const Re *>(a.zpage);
-					const Pix<C, Re> v = load_pix<C, Re>(p);
+					// a pixel of skipped tiles is not loaded at all (the lanes that need it load under the execution mask; a wave none of whose lanes
+					// does skips the instruction): against a load from the page of zeros, as load_pix_z does it, the scan step 337.5 -> 329.5 us
+					Pix<C, Re> v;
+					static_for<0, C>([&](auto c) { v.v[c] = (Re)0; });
+					if (b) v = load_pix<C, Re>(a.in + bin + (long long)pixel01(k, j) * GS);
 					static_for<0, C>([&](auto c) { st.pre[(i * 4 + j) * C + c] = ((b >> c) & 1u) ? v.v[c] : (Re)0; });
 				});
 			}
