@@ -642,13 +642,19 @@ struct RowSpecG {
 	// line of this thread, called for the pixels this thread owns only.
 	template <int KIND> static constexpr int out_slots() { return KIND == KIND_REDFT10 ? 4 * K_ROUNDS : PIX_ROUNDS; }
 	template <int KIND> struct OutHold { Pix<C, Re> v[out_slots<KIND>()]; };
-	template <int KIND, class ST, class F>
+	// UNCOND (REDFT10): f is called for EVERY slot of every thread, so that the caller's stores are unconditional and the compiler can count them (a wait for
+	// loads issued in front of them is then vmcnt(number of stores), not vmcnt(0)).  A thread beyond the last item recomputes item L/2, and the slots that have
+	// no pixel of their own (k = 0: N - k and L + k; k = L/2: L - k and L + k) repeat a sibling slot's pixel -- the same value to the same address, harmless.
+	// The twiddle of a clamped item must be item L/2's: the caller loads st.tw through tw_index().
+	template <bool UNCOND> static DSP_HD int tw_index(int k) { return UNCOND && k > L / 2 ? L / 2 : k; }
+	template <int KIND, bool UNCOND = false, class ST, class F>
 	static DSP_HD void final_each(const PA &a, const CX *planes, int tid, const ST &st, F &&f)
 	{
 		if constexpr (KIND == KIND_REDFT10) {
 			static_for<0, K_ROUNDS>([&](auto ri) {
-				const int k = tid + ri * T;
-				if (!((ri + 1) * T <= L / 2 + 1 || k <= L / 2)) return;
+				const int k0 = tid + ri * T;
+				if constexpr (!UNCOND) { if (!((ri + 1) * T <= L / 2 + 1 || k0 <= L / 2)) return; }
+				const int k = tw_index<UNCOND>(k0);
 				const int km = k ? L - k : 0;
 				const CX tk = st.tw[ri];
 				const CX tlk = cmul(cconj(tk), cmk<Re>((Re)0.70710678118654752440, (Re)-0.70710678118654752440));
@@ -665,6 +671,21 @@ struct RowSpecG {
 					const CX wm = cmul(tlk, cconj(csub(E, P)));
 					o0.v[c] = wk.x * s0; o1.v[c] = -wk.y * sc; o2.v[c] = wm.x * sc; o3.v[c] = -wm.y * sc;
 				});
+				if constexpr (UNCOND) {
+					const bool first = k == 0, mid = 2 * k == L;
+					const int e0 = k * GS, e1 = first ? e0 : (N - k) * GS, e2 = mid ? e0 : (L - k) * GS, e3 = first ? e2 : mid ? e1 : (L + k) * GS;
+					Pix<C, Re> q1, q2, q3;
+					static_for<0, C>([&](auto c) {
+						q1.v[c] = first ? o0.v[c] : o1.v[c];
+						q2.v[c] = mid ? o0.v[c] : o2.v[c];
+						q3.v[c] = first ? q2.v[c] : mid ? q1.v[c] : o3.v[c];
+					});
+					f(std::integral_constant<int, ri * 4 + 0>(), (long long)e0, o0);
+					f(std::integral_constant<int, ri * 4 + 1>(), (long long)e1, q1);
+					f(std::integral_constant<int, ri * 4 + 2>(), (long long)e2, q2);
+					f(std::integral_constant<int, ri * 4 + 3>(), (long long)e3, q3);
+					return;
+				}
 				f(std::integral_constant<int, ri * 4 + 0>(), (long long)k * GS, o0);
 				if (k > 0) f(std::integral_constant<int, ri * 4 + 1>(), (long long)(N - k) * GS, o1);
 				if (L - k != k) f(std::integral_constant<int, ri * 4 + 2>(), (long long)(L - k) * GS, o2);

@@ -498,6 +498,9 @@ __global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_pipe_
 	typename S::template OutHold<KIND> h1;           // T(r1)'s outputs
 	typename S::template OutHold<KIND> old1, old2;   // SCAN: the running sum's old values of the pair's two output lines (dead otherwise)
 	__syncthreads();                                 // the tables are in place
+	// REDFT10 with its next pair requested in FRONT of the pair's stores: every store unconditional (RowSpecG::final_each UNCOND), the closing phase's twiddles
+	// read from the LDS table where they are used (item L/2's for a thread beyond the last item; kept in registers across the loop they cost a spill among the stores)
+	constexpr bool UNC = KIND == KIND_REDFT10 && EARLY;
 	if constexpr (SCAN && KIND == KIND_REDFT01) { if (a.zflags) { bits1 = S::flag_bits01(zf1, a.zshift, tid); bits2 = S::flag_bits01(zf2, a.zshift, tid); } }
 	// the loads of a line: plain, or (SCAN) with this thread's precomputed flags
 	auto fetch = [&](long long bin, int t, auto SECOND_LINE) __attribute__((always_inline)) {
@@ -536,8 +539,10 @@ __global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_pipe_
 			DSP_STAMP((SECOND ? 12 : 2) + ph);
 		});
 		int u = t; asm volatile("" : "+v"(u));
+		if constexpr (UNC) static_for<0, S::K_ROUNDS>([&](auto ri) { st.tw[ri] = ttab[S::template tw_index<true>(u + ri * S::T)]; });
+		auto each = [&](auto &&f) __attribute__((always_inline)) { S::template final_each<KIND, UNC>(a, planes, u, st, f); };
 		if constexpr (!SECOND) {
-			S::template final_each<KIND>(a, planes, u, st, [&](auto slot, long long, Pix<S::C, Re> v) { h1.v[slot] = v; });
+			each([&](auto slot, long long, Pix<S::C, Re> v) { h1.v[slot] = v; });
 		} else {
 			bool done = false;
 			if constexpr (SCAN && KIND == KIND_REDFT01) {
@@ -563,7 +568,7 @@ __global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_pipe_
 				}
 			}
 			if (!done)
-				S::template final_each<KIND>(a, planes, u, st, [&](auto slot, long long off, Pix<S::C, Re> v) {
+				each([&](auto slot, long long off, Pix<S::C, Re> v) {
 					Pix<S::C, Re> o1, o2;
 					static_for<0, S::C>([&](auto c) { o1.v[c] = h1.v[slot].v[c] + v.v[c]; o2.v[c] = h1.v[slot].v[c] - v.v[c]; });
 					store_pix<S::C, Re>(a.out + pb1 + off, o1);
@@ -704,11 +709,12 @@ int launch_row_pair(const typename S::PA &a, int npairs, void *stream)
 			// on DSP_PAIR_PIPE_T = 768 threads: the held output line, the line in flight and the closing phase's arithmetic need more than the 128
 			// registers that 1024 threads leave each, and 768 fill the radix-16 / radix-15 stages' rounds better (720 and 768 butterflies); measured
 			// 195.7 / 196.8 us against 221 / 220 on 1024 threads and 204.5 / 212 for row_pair_kernel (profiles/r06_8k_pair_pipe.txt).
-			// REDFT01 requests the next pair's first line in FRONT of this pair's stores (its twenty stores per thread are unconditional: the compiler
-			// counts them and waits for the loads alone); REDFT10's stores sit under per-lane conditions, the wait behind them would be for the whole
-			// queue, so its request goes out behind them (198.0 in front, 195.7 behind).
+			// Both kinds request the next pair's first line in FRONT of this pair's stores, which are unconditional so that the compiler counts them and the
+			// wait at the next phase 0 is for the loads alone: REDFT01's twenty stores per thread are; REDFT10's sit under per-lane conditions (k > 0,
+			// k != L/2, the ragged last round) and are made unconditional by RowSpecG::final_each's UNCOND form -- ROW10 198.0 us with the request in front of
+			// conditional stores, 195.7 behind them, 185.1 in front of unconditional ones.
 			typedef typename S::template with_threads<DSP_PAIR_PIPE_T> SP;
-			constexpr bool EARLY = KIND == KIND_REDFT01;
+			constexpr bool EARLY = true;
 			static DevOnce ponce;
 			if (int p_rc = allow_lds_dev(ponce, pair_pipe_lds<SP>(), row_pair_pipe_kernel<SP, KIND, EARLY>)) return p_rc;
 			hipLaunchKernelGGL((row_pair_pipe_kernel<SP, KIND, EARLY>), dim3(cus), dim3(SP::T), pair_pipe_lds<SP>(), (hipStream_t)stream, a, npairs);

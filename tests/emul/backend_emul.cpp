@@ -379,9 +379,12 @@ int launch_row_pair_pipe(const PassArgs &a_, int npairs)
 		for (int second = 0; second < 2; second++) {
 			std::vector<ST> &cur = second ? st2 : st;
 			static_for<0, S::NS + 2>([&](auto ph) { for (int tid = 0; tid < S::T; tid++) S::template phase<KIND, ph, ST, true>(a, planes, 0, tid, cur[tid]); });
+			// REDFT10 as the kernel runs it: every slot of every thread (final_each UNCOND: clamped items, repeated pixels), this thread's twiddles through tw_index
+			constexpr bool UNC = KIND == KIND_REDFT10;
 			for (int tid = 0; tid < S::T; tid++) {
-				if (!second) S::template final_each<KIND>(a, planes, tid, cur[tid], [&](auto slot, long long, Pix<S::C, float> v) { h1[tid].v[slot] = v; });
-				else S::template final_each<KIND>(a, planes, tid, cur[tid], [&](auto slot, long long off, Pix<S::C, float> v) {
+				if constexpr (UNC) for (int ri = 0; ri < S::K_ROUNDS; ri++) cur[tid].tw[ri] = a.T[S::template tw_index<true>(tid + ri * S::T)];
+				if (!second) S::template final_each<KIND, UNC>(a, planes, tid, cur[tid], [&](auto slot, long long, Pix<S::C, float> v) { h1[tid].v[slot] = v; });
+				else S::template final_each<KIND, UNC>(a, planes, tid, cur[tid], [&](auto slot, long long off, Pix<S::C, float> v) {
 					Pix<S::C, float> o1, o2;
 					for (int c = 0; c < S::C; c++) { o1.v[c] = h1[tid].v[slot].v[c] + v.v[c]; o2.v[c] = h1[tid].v[slot].v[c] - v.v[c]; }
 					if (a.accumulate) {               // sum += image (scan.c:451-459)

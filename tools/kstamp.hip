@@ -120,9 +120,9 @@ int main(int argc, char **argv)
 		PassArgs a = {};
 		a.N = S::N; a.C = 3; a.nb0 = H8; a.nb1 = 1; a.sb0_in = a.sb0_out = (long long)W8 * 3; a.nlines = H8;
 		a.in = x; a.out = x; a.T = tab_T(S::N); a.W = tab_W(S::L); a.scale = 1.f; a.in_scale0 = a.out_scale0 = 1.f;
-		CK(hipFuncSetAttribute(reinterpret_cast<const void *>(row_pair_pipe_kernel<S, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_pipe_lds<S>()));
+		CK(hipFuncSetAttribute(reinterpret_cast<const void *>(row_pair_pipe_kernel<S, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_pipe_lds<S>()));
 		CK(hipFuncSetAttribute(reinterpret_cast<const void *>(row_pair_pipe_kernel<S, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_pipe_lds<S>()));
-		a.kind = 0; run("row_pair_pipe 7680x3 REDFT10 (768 threads, 256 workgroups)", 256, [&]() { hipLaunchKernelGGL((row_pair_pipe_kernel<S, 0>), dim3(256), dim3(S::T), pair_pipe_lds<S>(), 0, a, H8 / 2); });
+		a.kind = 0; run("row_pair_pipe 7680x3 REDFT10 (768 threads, 256 workgroups)", 256, [&]() { hipLaunchKernelGGL((row_pair_pipe_kernel<S, 0, true>), dim3(256), dim3(S::T), pair_pipe_lds<S>(), 0, a, H8 / 2); });
 		a.kind = 1; run("row_pair_pipe 7680x3 REDFT01 (next pair requested in front of the stores)", 256, [&]() { hipLaunchKernelGGL((row_pair_pipe_kernel<S, 1, true>), dim3(256), dim3(S::T), pair_pipe_lds<S>(), 0, a, H8 / 2); });
 	}
 	if (strstr(which, "half")) {
