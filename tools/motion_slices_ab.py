@@ -10,7 +10,7 @@ import sys
 import zlib
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-FRAMES, QUANT = 256, 20.0
+FRAMES, QUANT = int(os.environ.get("FRAMES", "256")), 20.0
 PLANES = ((1080, 1920), (540, 960), (540, 960))
 
 
