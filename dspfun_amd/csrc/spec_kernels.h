@@ -503,18 +503,44 @@ __global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_pipe_
 	constexpr bool UNC = KIND == KIND_REDFT10 && EARLY;
 	if constexpr (SCAN && KIND == KIND_REDFT01) { if (a.zflags) { bits1 = S::flag_bits01(zf1, a.zshift, tid); bits2 = S::flag_bits01(zf2, a.zshift, tid); } }
 	// the loads of a line: plain, or (SCAN) with this thread's precomputed flags
+	typedef Re PixV __attribute__((ext_vector_type(S::C == 3 ? 3 : S::C == 2 ? 2 : S::C == 4 ? 4 : 1)));
+	constexpr bool FLY = KIND == KIND_REDFT01 && !SCAN;
+	PixV fly[FLY ? 4 * S::K_ROUNDS : 1];             // REDFT01's line in flight
 	auto fetch = [&](long long bin, int t, auto SECOND_LINE) __attribute__((always_inline)) {
 		if constexpr (SCAN && KIND == KIND_REDFT01) S::prefetch01_bits(a, bin, t, st, SECOND_LINE ? bits2 : bits1);
-		else S::template prefetch<KIND>(a, bin, t, st, nullptr, nullptr);
+		else if constexpr (FLY) {
+			// RowSpecG::prefetch's loads with the item index CLAMPED instead of tested: under `if (k <= L/2)` the ragged last round's loads end in a join at
+			// which the compiler waits for them -- and, vmcnt being in order, for every load of the line issued before them: the prefetch was waited for
+			// where it was issued.  A thread beyond the last item loads item L/2's pixels again and phase 0 ignores them.
+			// The pixels land in `fly`, whole 12-byte vectors as the load instruction writes them, and are taken apart where the line is consumed (head): written
+			// straight into State::pre's scalars the allocator could not keep ten of the twelve vectors where they landed and copied them -- behind a wait -- at once.
+			static_for<0, S::K_ROUNDS>([&](auto i) {
+				const int k0 = t + i * S::T, k = k0 <= S::L / 2 ? k0 : S::L / 2;
+				st.tw[i] = a.T[k];
+				const Re *p = a.in + bin;
+				__builtin_memcpy(&fly[i * 4 + 0], p + (long long)k * S::GS, S::C * sizeof(Re));
+				__builtin_memcpy(&fly[i * 4 + 1], p + (long long)(k ? S::N - k : 0) * S::GS, S::C * sizeof(Re));
+				__builtin_memcpy(&fly[i * 4 + 2], p + (long long)(S::L - k) * S::GS, S::C * sizeof(Re));
+				__builtin_memcpy(&fly[i * 4 + 3], p + (long long)(S::L + k) * S::GS, S::C * sizeof(Re));
+			});
+		} else S::template prefetch<KIND>(a, bin, t, st, nullptr, nullptr);
 	};
 	// one pair per iteration, its two lines spelled out (SECOND is a compile-time constant)
-	auto line = [&](auto SECOND, long long in_next, bool has_next, long long pb1, long long pb2) __attribute__((always_inline)) {
+	// `head`: phase 0 of a line (consumes the line's loads); `rest`: everything behind it.  The loop below is ROTATED -- r1's head of the next pair closes the
+	// iteration instead of opening it -- so that the wait in front of it lies on ONE path, behind this pair's stores, and the compiler writes it as
+	// vmcnt(stores behind the loads): at the top of the loop it would merge with the path from the first prefetch (nothing behind the loads) into vmcnt(0)
+	// = the whole store queue.
+	auto head = [&](auto SECOND) __attribute__((always_inline)) {
 		// (the thread index is re-made opaque for every line: see row_persist_kernel)
 		int t = tid; asm volatile("" : "+v"(t));
 		forget(st.x);
 		DSP_STAMP(SECOND ? 10 : 0);
+		if constexpr (FLY) static_for<0, 4 * S::K_ROUNDS>([&](auto n) { static_for<0, S::C>([&](auto c) { st.pre[n * S::C + c] = fly[n][(int)decltype(c)::value]; }); });
 		S::template phase<KIND, 0, decltype(st), true>(a, planes, 0, t, st);
 		DSP_STAMP(SECOND ? 11 : 1);
+	};
+	auto rest = [&](auto SECOND, long long in_next, bool has_next, long long pb1, long long pb2) __attribute__((always_inline)) {
+		int t = tid; asm volatile("" : "+v"(t));
 		if constexpr (!SECOND) {                     // r2: lands behind r1's stages
 			forget(h1); forget(st.pre);
 			fetch(in_next, t, std::integral_constant<bool, true>());
@@ -583,12 +609,29 @@ __global__ void __launch_bounds__(S::T, pair_waves_per_simd<S>()) row_pair_pipe_
 		DSP_STAMP(SECOND ? 19 : 9);
 	};
 	int work = blockIdx.x;
-	if (work < nwork) fetch(line_in(work, 0), tid, std::integral_constant<bool, false>());
-	while (work < nwork) {
-		const int next = work + (int)gridDim.x;
-		line(std::integral_constant<bool, false>(), line_in(work, 1), true, 0, 0);
-		line(std::integral_constant<bool, true>(), next < nwork ? line_in(next, 0) : 0, next < nwork, line_out(work, 0), line_out(work, 1));
-		work = next;
+	const std::integral_constant<bool, false> FIRST;
+	const std::integral_constant<bool, true> SECOND_;
+	if constexpr (EARLY) {
+		if (work < nwork) { fetch(line_in(work, 0), tid, FIRST); head(FIRST); }
+		while (work < nwork) {
+			const int next = work + (int)gridDim.x;
+			rest(FIRST, line_in(work, 1), true, 0, 0);
+			head(SECOND_);
+			rest(SECOND_, next < nwork ? line_in(next, 0) : 0, next < nwork, line_out(work, 0), line_out(work, 1));
+			work = next;
+			if (work < nwork) head(FIRST);
+		}
+	} else {
+		// (the next pair's r1 is requested BEHIND the stores: its wait is for the whole queue on any path, and the rotated loop costs the scan form 36 spilled registers)
+		if (work < nwork) fetch(line_in(work, 0), tid, FIRST);
+		while (work < nwork) {
+			const int next = work + (int)gridDim.x;
+			head(FIRST);
+			rest(FIRST, line_in(work, 1), true, 0, 0);
+			head(SECOND_);
+			rest(SECOND_, next < nwork ? line_in(next, 0) : 0, next < nwork, line_out(work, 0), line_out(work, 1));
+			work = next;
+		}
 	}
 }
 
