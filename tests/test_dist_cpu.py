@@ -216,6 +216,7 @@ def test_scan_c4_bench_path_on_four_ranks():
         o = res[rank]
         assert o["frames"] == -(-40 * 24 // 97) and o["planes_per_rank"] == [1, 1, 1, 0] and o["ranks_with_a_plane"] == 3
         assert o["scaling_efficiency_ceiling"] == 0.75 and o["max_abs_final_sum_minus_input"] < 5e-6 and o["ms_per_frame"] > 0
+        assert o["ms_per_frame_second_scan"] > 0
         assert "planar" in o["layout"]
     assert len({res[r]["ms_per_frame"] for r in range(world)}) == 1          # the MAX over ranks, agreed by all_reduce
 

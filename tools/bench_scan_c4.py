@@ -22,7 +22,6 @@ def scan_c4(torch, dist, dev, rank, world, size=(W, H), step=STEP, lib=None):
     W, H = size
     g = torch.Generator(device=dev); g.manual_seed(0xD5F0004)
     img = torch.rand((H, W, C), device=dev, generator=g)
-    eng = ChannelShardedScan(img, step, lib=lib)
     on_gpu = torch.device(dev).type == "cuda"
 
     def barrier():
@@ -33,23 +32,32 @@ def scan_c4(torch, dist, dev, rank, world, size=(W, H), step=STEP, lib=None):
         if on_gpu:
             torch.cuda.synchronize()
 
-    eng.warm(); eng.warm()          # untimed: the step's kernels loaded (a frame id nobody owns adds zeros)
-    barrier()
-    t0 = time.perf_counter()
-    while eng.next_frame():
-        pass
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def one_scan():
+        eng = ChannelShardedScan(img, step, lib=lib)
+        eng.warm(); eng.warm()          # untimed: the step's kernels loaded (a frame id nobody owns adds zeros)
+        barrier()
+        t0 = time.perf_counter()
+        while eng.next_frame():
+            pass
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return eng, dt
+
+    # the whole scan twice, each on fresh running sums.  The first is what one `scan` invocation sees: its 32 frames are ~12 ms of GPU time behind an idle
+    # device, and the clocks are still rising through them (r06: 0.358-0.365 ms per frame; 0.348 behind 128 untimed steps).  The second follows it directly.
+    eng, dt = one_scan()
+    eng, dt_again = one_scan()
     err = float((eng.gather() - img).abs().max())
     busy = min(C, world)
     samples = W * H * C
     ms = dt / eng.nframes * 1e3
     return {"workload": f"scan zigzag progressive reconstruct of {W}x{H} RGB, step {step} (BASELINE configs[3]: 7680x4320, 2^20), colour planes over the ranks",
-            "frames": eng.nframes, "untimed_warm_steps": 2, "ms_per_frame": round(ms, 4), "frames_per_s": round(eng.nframes / dt, 1),
+            "frames": eng.nframes, "untimed_warm_steps": 2, "ms_per_frame": round(ms, 4),
+            "ms_per_frame_second_scan": round(dt_again / eng.nframes * 1e3, 4), "frames_per_s": round(eng.nframes / dt, 1),
             "algorithmic_GBps_total": round(samples * 12 / ms / 1e6, 1), "frac_of_8TBps_per_busy_gpu": round(samples * 12 / ms / 1e6 / 8000 / busy, 4),
             "planes_per_rank": [len([z for z in range(C) if z % world == r]) for r in range(world)], "ranks_with_a_plane": busy,
             # the busiest rank owns ceil(3 / N) planes: speed-up over one GPU is at most 3 / ceil(3 / N), i.e. efficiency 3 / (N ceil(3 / N))
