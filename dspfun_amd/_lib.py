@@ -19,7 +19,7 @@ SYMBOLS = [
     "dspfft_plan_many_r2r_ordered", "dspfft_plan_guru_r2r", "dspfft_execute_roundtrip", "dspfft_execute_roundtrip_u8",
     "dspfft_execute", "dspfft_plan_num_passes", "dspfft_execute_pass", "dspfft_destroy_plan", "dspfft_plan_describe", "dspfft_plan_algorithmic_bytes",
     "dspfft_execute_many", "dspfft_execute_many_repeat", "dspfft_execute_sum2", "dspfft_cosrows_create", "dspfft_cosrows_execute", "dspfft_cosrows_destroy", "dspfft_cztrows_create", "dspfft_cztrows_execute", "dspfft_cztrows_length", "dspfft_cztrows_destroy", "dspfft_transpose_f32", "dspfft_plan_set_input_modulation", "dspfft_stream_create", "dspfft_stream_destroy", "dspfft_stream_synchronize", "dspfft_event_create", "dspfft_event_destroy", "dspfft_event_synchronize", "dspfft_event_elapsed_ms",
-    "dspfft_last_error", "dspfft_version", "dspfft_set_thread_plan_effort", "dspfft_get_thread_plan_effort",
+    "dspfft_last_error", "dspfft_version", "dspfft_set_thread_plan_effort", "dspfft_get_thread_plan_effort", "dspfft_fftw_sparse_uploads",
     "dspfft_scan_zigzag", "dspfft_scan_zigzag_frame_ids", "dspfft_execute_masked_accumulate", "dspfft_scan_scatter", "dspfft_accumulate", "dspfft_broadcast_dc",
     "dspfft_scan_limit", "dspfft_scan_max_interval", "dspfft_scan_coord_slots", "dspfft_scan_owner_index", "dspfft_scan_frame_ids", "dspfft_scan_coords", "dspfft_scan_stamp",
     "dspfft_scan_index_to_frame_ids", "dspfft_scan_magnitude_work_bytes", "dspfft_scan_magnitude_index",

@@ -11,8 +11,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <unordered_set>
+#include <vector>
 
 #include "../../include/dspfft.h"
 #include "../../include/fftw3.h"
@@ -53,7 +56,53 @@ size_t span(int rank, const int *n, const int *embed, int stride, int dist, int 
 	return idx * (size_t)stride + (size_t)(howmany - 1) * (size_t)dist + 1;
 }
 
+// ---- sparse upload -------------------------------------------------------------------------------------------------------------------
+// scan/scan.c:429-447 clears `reconstruction` and sets one step's coefficients (<= 3 % of an 8K frame) before every fftw_execute: the dense upload moves
+// 398 MB over a 57 GB/s link for 12-30 MB of data.  Host threads read memory 3-4x faster than the link carries it (1.7 ms for those 398 MB on 12-16 threads,
+// 7.0 ms by hipMemcpy), so execute() looks first: 4 KB blocks that hold anything but zero bits are packed into a pinned staging buffer and put in place on the
+// device by one small kernel behind a hipMemsetAsync.  -0.0f has a bit set and travels; what arrives is byte for byte what the dense copy delivers.
+constexpr size_t kUpBlock = 4096;                 // bytes per block = one 256-thread workgroup x 16 B
+constexpr size_t kUpChunk = 256;                  // blocks a thread takes at a time (1 MB): ranges interleave so that a dense corner spreads over all threads
+constexpr size_t kUpMinBytes = (size_t)32 << 20;  // below this the dense copy takes < 0.6 ms
+constexpr int kUpFillPct = 25;                    // denser than this (per thread): plain hipMemcpyAsync
+
+__global__ __launch_bounds__(256) void scatter_blocks_kernel(const uint4 *__restrict__ stage, const uint32_t *__restrict__ index, uint4 *__restrict__ dst)
+{
+	const uint32_t b = index[blockIdx.x];
+	if (b == 0xFFFFFFFFu) return;                 // unused tail of a thread's share
+	dst[(size_t)b * (kUpBlock / 16) + threadIdx.x] = stage[(size_t)blockIdx.x * (kUpBlock / 16) + threadIdx.x];
+}
+
+int upload_threads()
+{
+	// DSPFFT_UPLOAD_THREADS is read at every execute (0 = always the dense copy); the default is found once
+	if (const char *e = getenv("DSPFFT_UPLOAD_THREADS")) { const int t = atoi(e); return t > 64 ? 64 : t; }
+	static const int n = [] {
+		int t = (int)std::thread::hardware_concurrency();
+		// a container's CPU quota, not the machine's core count, is what the threads get (cgroup v2: "<quota> <period>" or "max <period>")
+		if (FILE *fp = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+			long long q = 0, per = 0;
+			if (fscanf(fp, "%lld %lld", &q, &per) == 2 && q > 0 && per > 0 && (int)(q / per) < t) t = (int)(q / per);
+			fclose(fp);
+		}
+		return t > 12 ? 12 : t;          // 12 threads read a pinned array as fast as 16 or 24 (profiles/r06_scan_gpu_8k.txt)
+	}();
+	return n;
+}
+
+std::atomic<unsigned long long> g_sparse_uploads{0};
+
+struct SparseUp {
+	int threads = 0;
+	size_t nblk = 0, share = 0;                   // whole blocks of the array; staging blocks per thread
+	char *h_stage = nullptr, *d_stage = nullptr;
+	uint32_t *h_index = nullptr, *d_index = nullptr;
+	unsigned skip = 0, dense_streak = 0;          // dense inputs: look again only after 1, 2, 4 ... 64 executes
+	~SparseUp() { (void)hipHostFree(h_stage); (void)hipHostFree(h_index); (void)hipFree(d_stage); (void)hipFree(d_index); }
+};
+
 struct Shim {
+	SparseUp *up = nullptr;
 	dspfft_plan plan = nullptr;
 	void *h_in = nullptr, *h_out = nullptr;
 	size_t in_len = 0, out_len = 0;          // elements
@@ -61,6 +110,7 @@ struct Shim {
 	size_t es = 4;                           // bytes per element: 4 (fftwf_) or 8 (fftw_)
 	void *d_in = nullptr, *d_out = nullptr;  // d_out == d_in when in-place
 	hipStream_t stream = nullptr;
+	int device = 0;                          // the device current at plan time: the stream's
 };
 
 Shim *make_plan(int rank, const int *n, int howmany, void *in, const int *inembed, int istride, int idist,
@@ -92,7 +142,7 @@ Shim *make_plan(int rank, const int *n, int howmany, void *in, const int *inembe
 	bool ok = hipMalloc(&s->d_in, s->in_len * s->es) == hipSuccess;
 	if (in == out) s->d_out = s->d_in;
 	else ok = ok && hipMalloc(&s->d_out, s->out_len * s->es) == hipSuccess;
-	ok = ok && hipStreamCreate(&s->stream) == hipSuccess;
+	ok = ok && hipStreamCreate(&s->stream) == hipSuccess && hipGetDevice(&s->device) == hipSuccess;
 	if (!ok) {
 		fprintf(stderr, "dspfft: device allocation failed (%zu + %zu elements)\n", s->in_len, s->out_len);
 		dspfft_destroy_plan(s->plan); (void)hipFree(s->d_in); if (s->d_out != s->d_in) (void)hipFree(s->d_out);
@@ -101,10 +151,94 @@ Shim *make_plan(int rank, const int *n, int howmany, void *in, const int *inembe
 	return s;
 }
 
+// h_in -> d_in.  Returns false on a HIP error.
+bool upload_in(Shim *s)
+{
+	const size_t bytes = s->in_len * s->es;
+	const auto dense = [&] { return hipMemcpyAsync(s->d_in, s->h_in, bytes, hipMemcpyHostToDevice, s->stream) == hipSuccess; };
+	int T = upload_threads();
+	if (bytes < kUpMinBytes || T < 4 || ((uintptr_t)s->h_in & 15)) return dense();     // < 4 threads read no faster than the link
+	if (s->up && s->up->threads) T = s->up->threads;                                    // the staging buffers are laid out for the first execute's team
+	if (!s->up) {
+		SparseUp *u = new SparseUp();
+		u->threads = T; u->nblk = bytes / kUpBlock;
+		const size_t mine = (u->nblk + T - 1) / T;                                      // blocks a thread looks at, at most (+ one chunk of imbalance)
+		u->share = (mine + kUpChunk) * kUpFillPct / 100 + 1;
+		const size_t cap = u->share * T;
+		if (hipHostMalloc((void **)&u->h_stage, cap * kUpBlock, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **)&u->h_index, cap * 4, hipHostMallocDefault) != hipSuccess ||
+		    hipMalloc((void **)&u->d_stage, cap * kUpBlock) != hipSuccess || hipMalloc((void **)&u->d_index, cap * 4) != hipSuccess) {
+			(void)hipGetLastError(); delete u; u = new SparseUp();                      // no room for the staging buffers: dense from now on
+			u->skip = ~0u;
+		}
+		s->up = u;
+	}
+	SparseUp *u = s->up;
+	if (u->skip) { if (u->skip != ~0u) u->skip--; return dense(); }
+	// the device side clears while the host looks (a dense frame overwrites it all the same)
+	bool ok = hipMemsetAsync(s->d_in, 0, u->nblk * kUpBlock, s->stream) == hipSuccess;
+	std::atomic<bool> full{false}, failed{false};
+	std::vector<size_t> used(T, 0);
+	const auto look = [&](int t) {
+		(void)hipSetDevice(s->device);
+		const size_t at = (size_t)t * u->share;
+		char *stage = u->h_stage + at * kUpBlock;
+		uint32_t *index = u->h_index + at;
+		size_t n = 0, sent = 0;
+		// what is packed goes up while the rest is still being read: a copy per half megabyte, enqueued by the thread that packed it
+		const auto send = [&] {
+			if (n > sent && hipMemcpyAsync(u->d_stage + (at + sent) * kUpBlock, stage + sent * kUpBlock, (n - sent) * kUpBlock, hipMemcpyHostToDevice, s->stream) != hipSuccess)
+				failed.store(true, std::memory_order_relaxed);
+			sent = n;
+		};
+		for (size_t c = (size_t)t * kUpChunk; c < u->nblk && !full.load(std::memory_order_relaxed); c += (size_t)T * kUpChunk) {
+			const size_t end = c + kUpChunk < u->nblk ? c + kUpChunk : u->nblk;
+			for (size_t b = c; b < end; b++) {
+				const uint64_t *q = (const uint64_t *)((const char *)s->h_in + b * kUpBlock);
+				uint64_t any = 0;
+				for (size_t i = 0; i < kUpBlock / 8; i++) any |= q[i];
+				if (!any) continue;
+				if (n == u->share) { full.store(true, std::memory_order_relaxed); return; }
+				memcpy(stage + n * kUpBlock, q, kUpBlock);
+				index[n++] = (uint32_t)b;
+			}
+			if (n - sent >= 128) send();
+		}
+		send();
+		used[t] = n;
+		for (size_t i = n; i < u->share; i++) index[i] = 0xFFFFFFFFu;
+	};
+	{
+		std::vector<std::thread> team;
+		for (int t = 1; t < T; t++) team.emplace_back(look, t);
+		look(0);
+		for (auto &th : team) th.join();
+	}
+	if (failed.load()) return false;
+	if (full.load()) {
+		// (staged blocks already on their way are never put in place: the scatter kernel is not launched)
+		u->skip = 1u << (u->dense_streak < 6 ? u->dense_streak : 6);
+		u->dense_streak++;
+		return dense();
+	}
+	u->dense_streak = 0;
+	g_sparse_uploads++;
+	size_t top = 0;                                                                      // staging blocks up to the last share in use
+	for (int t = 0; t < T; t++) if (used[t]) top = ((size_t)t + 1) * u->share;
+	if (top && ok) {
+		ok = hipMemcpyAsync(u->d_index, u->h_index, top * 4, hipMemcpyHostToDevice, s->stream) == hipSuccess;
+		hipLaunchKernelGGL(scatter_blocks_kernel, dim3((unsigned)top), dim3(256), 0, s->stream, (const uint4 *)u->d_stage, (const uint32_t *)u->d_index, (uint4 *)s->d_in);
+		ok = ok && hipGetLastError() == hipSuccess;
+	}
+	// what does not fill a block: as it is
+	if (const size_t tail = bytes - u->nblk * kUpBlock)
+		ok = ok && hipMemcpyAsync((char *)s->d_in + u->nblk * kUpBlock, (const char *)s->h_in + u->nblk * kUpBlock, tail, hipMemcpyHostToDevice, s->stream) == hipSuccess;
+	return ok;
+}
+
 void run(Shim *s)
 {
 	if (!s) { fprintf(stderr, "dspfft: execute on a NULL plan\n"); return; }
-	bool ok = hipMemcpyAsync(s->d_in, s->h_in, s->in_len * s->es, hipMemcpyHostToDevice, s->stream) == hipSuccess;
+	bool ok = upload_in(s);
 	// out-of-place with embedding gaps: elements the transform does not write must survive in `out`, so the host's `out` goes up
 	// first.  A dense output (scan's per-frame plan, scan/scan.c:359,447) is overwritten whole: two transfers per execute, not three.
 	if (s->d_out != s->d_in && !s->out_dense) ok = ok && hipMemcpyAsync(s->d_out, s->h_out, s->out_len * s->es, hipMemcpyHostToDevice, s->stream) == hipSuccess;
@@ -130,12 +264,15 @@ void destroy(Shim *s)
 	if (s->d_out != s->d_in) (void)hipFree(s->d_out);
 	(void)hipFree(s->d_in);
 	if (s->stream) (void)hipStreamDestroy(s->stream);
+	delete s->up;
 	delete s;
 }
 
 }  // namespace
 
 extern "C" {
+
+unsigned long long dspfft_fftw_sparse_uploads(void) { return g_sparse_uploads.load(); }
 
 float *fftwf_alloc_real(size_t n) { return (float *)pinned_alloc(n * sizeof(float)); }
 void fftwf_free(void *p) { pinned_free(p); }

@@ -191,6 +191,11 @@ void dspfft_set_plan_effort(int effort);
 int dspfft_get_plan_effort(void);
 void dspfft_set_thread_plan_effort(int effort);
 int dspfft_get_thread_plan_effort(void);
+/* Diagnostic for the FFTW shim (include/fftw3.h): how many fftw(execute) calls of this process carried their input up as packed non-zero 4 KB blocks
+ * instead of one dense copy.  Arrays of 32 MB and more are read by host threads first (DSPFFT_UPLOAD_THREADS, default = the CPU quota, at most 12;
+ * 0 = never); an array more than a quarter non-zero goes up dense and is looked at again only after 1, 2, 4 ... 64 further executes.  What arrives on the
+ * device is the same bytes either way (scan/scan.c:429-447: <= 3 % of `reconstruction` is set per output frame). */
+unsigned long long dspfft_fftw_sparse_uploads(void);
 int dspfft_plan_guru_r2r(dspfft_plan *plan, int rank, const dspfft_iodim *dims, int howmany_rank, const dspfft_iodim *howmany_dims,
                          const int *kinds, int f64);
 

@@ -479,3 +479,63 @@ def test_zoom_harness(tmp_path, btype, xs, ys, pos, view, method, how):
         assert (" by " + how).encode() in r.stderr, r.stderr
     ref = _zoom_oracle(x, btype, xs, ys, pos[0], pos[1], vw, vh)
     assert np.abs(frames[0] - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def _band(h, w, c, frame, nframes, rng):
+    """what scan/scan.c:429-445 leaves in `reconstruction` for one output frame of a zigzag scan: zeros but for an anti-diagonal band"""
+    a = np.zeros((h, w, c), np.float32)
+    y, x = np.mgrid[0:h, 0:w]
+    d = (y * w // h + x)
+    lo, hi = (2 * w) * frame // nframes, (2 * w) * (frame + 1) // nframes
+    m = (d >= lo) & (d < hi)
+    a[m] = rng.standard_normal((int(m.sum()), c)).astype(np.float32)
+    return a
+
+
+@pytest.mark.parametrize("h,w,c,inplace", [(1021, 3001, 3, False), (1024, 3072, 3, True)])
+def test_sparse_upload_delivers_the_bytes_of_the_dense_copy(fftw, monkeypatch, h, w, c, inplace):
+    """scan/scan.c:429-447: `reconstruction` is mostly zeros at every execute.  Arrays of >= 32 MB go up as packed non-zero 4 KB blocks; the output must be
+    bit for bit what the dense copy gives -- frame after frame through ONE plan (nothing of the previous frame may linger), with a -0.0f that is the only
+    thing in its block, an array whose byte count is not a multiple of the block, a dense frame in between (dense copy, then the look-ahead backs off)."""
+    fftw.dspfft_fftw_sparse_uploads.restype = C.c_ulonglong
+    n = h * w * c
+    assert n * 4 >= 32 << 20 and (inplace or (n * 4) % 4096)
+    pin = fftw.fftwf_alloc_real(n)
+    pout = pin if inplace else fftw.fftwf_alloc_real(n)
+    a, b = _host_array(pin, n, np.float32), _host_array(pout, n, np.float32)
+    a[:] = 0
+    plan = fftw.fftwf_plan_many_r2r(2, _ia([h, w]), c, pin, None, c, 1, pout, None, c, 1, _ia([4, 4]), 1 << 6)
+    assert plan
+    rng = np.random.default_rng(h)
+    frames = [_band(h, w, c, f, 48, rng).ravel() for f in (0, 23, 47)]       # a band is 1/24 of every row it crosses: <= 2 of its 9 blocks
+    frames[1][-1] = 1.5                                             # the tail that does not fill a block
+    lone = np.zeros(n, np.float32); lone[n // 2] = -0.0; lone[7] = 2.0        # a block whose only set bit is a sign
+    dense = rng.standard_normal(n).astype(np.float32)
+    order = [frames[0], frames[1], lone, dense, frames[2], frames[0]]
+
+    def run_all():
+        outs = []
+        for x in order:
+            a[:] = x
+            fftw.fftwf_execute(plan)
+            outs.append(b.copy())
+        return outs
+    monkeypatch.setenv("DSPFFT_UPLOAD_THREADS", "0")
+    before = fftw.dspfft_fftw_sparse_uploads()
+    want = run_all()
+    assert fftw.dspfft_fftw_sparse_uploads() == before              # 0 threads: the dense copy, always
+    monkeypatch.setenv("DSPFFT_UPLOAD_THREADS", "6")
+    got = run_all()
+    # frames 0, 1, lone go up sparse; `dense` fills a thread's share and goes up whole; the next execute is not looked at (back-off 1); the last is
+    assert fftw.dspfft_fftw_sparse_uploads() == before + 4
+    for g, w_ in zip(got, want):
+        assert np.array_equal(g.view(np.uint32), w_.view(np.uint32))
+    # and against the oracle, once
+    a[:] = frames[1]
+    fftw.fftwf_execute(plan)
+    ref = ol.dct2d_interleaved(frames[1].reshape(h, w, c).astype(np.float64), ol.REDFT01, impl="port")
+    assert np.abs(b.reshape(h, w, c) - ref).max() <= 1e-5 * np.abs(ref).max()
+    fftw.fftwf_destroy_plan(plan)
+    fftw.fftwf_free(pin)
+    if not inplace:
+        fftw.fftwf_free(pout)
