@@ -174,6 +174,18 @@ bool upload_in(Shim *s)
 	}
 	SparseUp *u = s->up;
 	if (u->skip) { if (u->skip != ~0u) u->skip--; return dense(); }
+	const auto back_off = [&] { u->skip = 1u << (u->dense_streak < 6 ? u->dense_streak : 6); u->dense_streak++; };
+	{
+		// 128 blocks across the array first (microseconds): an image or a spectrum has something in most of them and is not worth a team
+		size_t set = 0;
+		for (size_t k = 0; k < 128; k++) {
+			const uint64_t *q = (const uint64_t *)((const char *)s->h_in + (u->nblk * k / 128) * kUpBlock);
+			uint64_t any = 0;
+			for (size_t i = 0; i < kUpBlock / 8; i++) any |= q[i];
+			set += any != 0;
+		}
+		if (set > 64) { back_off(); return dense(); }
+	}
 	// the device side clears while the host looks (a dense frame overwrites it all the same)
 	bool ok = hipMemsetAsync(s->d_in, 0, u->nblk * kUpBlock, s->stream) == hipSuccess;
 	std::atomic<bool> full{false}, failed{false};
@@ -216,8 +228,7 @@ bool upload_in(Shim *s)
 	if (failed.load()) return false;
 	if (full.load()) {
 		// (staged blocks already on their way are never put in place: the scatter kernel is not launched)
-		u->skip = 1u << (u->dense_streak < 6 ? u->dense_streak : 6);
-		u->dense_streak++;
+		back_off();
 		return dense();
 	}
 	u->dense_streak = 0;
