@@ -65,6 +65,7 @@ constexpr size_t kUpBlock = 4096;                 // bytes per block = one 256-t
 constexpr size_t kUpChunk = 256;                  // blocks a thread takes at a time (1 MB): ranges interleave so that a dense corner spreads over all threads
 constexpr size_t kUpMinBytes = (size_t)32 << 20;  // below this the dense copy takes < 0.6 ms
 constexpr int kUpFillPct = 25;                    // denser than this (per thread): plain hipMemcpyAsync
+constexpr size_t kUpMaxStage = (size_t)1 << 30;   // pinned + device staging per plan, at most
 
 __global__ __launch_bounds__(256) void scatter_blocks_kernel(const uint4 *__restrict__ stage, const uint32_t *__restrict__ index, uint4 *__restrict__ dst)
 {
@@ -164,6 +165,7 @@ bool upload_in(Shim *s)
 		u->threads = T; u->nblk = bytes / kUpBlock;
 		const size_t mine = (u->nblk + T - 1) / T;                                      // blocks a thread looks at, at most (+ one chunk of imbalance)
 		u->share = (mine + kUpChunk) * kUpFillPct / 100 + 1;
+		if (u->share * T * kUpBlock > kUpMaxStage) u->share = kUpMaxStage / kUpBlock / T;   // (a larger array counts as dense at a lower fill)
 		const size_t cap = u->share * T;
 		if (hipHostMalloc((void **)&u->h_stage, cap * kUpBlock, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **)&u->h_index, cap * 4, hipHostMallocDefault) != hipSuccess ||
 		    hipMalloc((void **)&u->d_stage, cap * kUpBlock) != hipSuccess || hipMalloc((void **)&u->d_index, cap * 4) != hipSuccess) {
