@@ -92,6 +92,8 @@ int upload_threads()
 }
 
 std::atomic<unsigned long long> g_sparse_uploads{0};
+// DSPFFT_UPLOAD_DEBUG=1: one line per large execute on stderr (which way the input went up, and why)
+bool upload_debug() { static const bool on = [] { const char *e = getenv("DSPFFT_UPLOAD_DEBUG"); return e && *e == '1'; }(); return on; }
 
 struct SparseUp {
 	int threads = 0;
@@ -175,18 +177,23 @@ bool upload_in(Shim *s)
 		s->up = u;
 	}
 	SparseUp *u = s->up;
-	if (u->skip) { if (u->skip != ~0u) u->skip--; return dense(); }
+	if (u->skip) { if (upload_debug()) fprintf(stderr, "dspfft: upload dense: not looked at (%u more)\n", u->skip - 1); if (u->skip != ~0u) u->skip--; return dense(); }
 	const auto back_off = [&] { u->skip = 1u << (u->dense_streak < 6 ? u->dense_streak : 6); u->dense_streak++; };
 	{
-		// 128 blocks across the array first (microseconds): an image or a spectrum has something in most of them and is not worth a team
+		// 128 blocks across the array first (microseconds): an image or a spectrum has something in most of them and is not worth a team.
+		// One block from each 128th of the array, at a scrambled place in it: evenly spaced samples walk a diagonal of the frame, and a zigzag
+		// scan's band IS a diagonal (511 rows: 127 of 128 even samples fell into a band that covers a twenty-fourth of the frame)
 		size_t set = 0;
+		uint32_t lcg = 12345u;
 		for (size_t k = 0; k < 128; k++) {
-			const uint64_t *q = (const uint64_t *)((const char *)s->h_in + (u->nblk * k / 128) * kUpBlock);
+			lcg = lcg * 1664525u + 1013904223u;
+			const size_t lo = u->nblk * k / 128, hi = u->nblk * (k + 1) / 128;
+			const uint64_t *q = (const uint64_t *)((const char *)s->h_in + (lo + (hi > lo ? (lcg >> 8) % (hi - lo) : 0)) * kUpBlock);
 			uint64_t any = 0;
 			for (size_t i = 0; i < kUpBlock / 8; i++) any |= q[i];
 			set += any != 0;
 		}
-		if (set > 64) { back_off(); return dense(); }
+		if (set > 64) { if (upload_debug()) fprintf(stderr, "dspfft: upload dense: %zu of 128 sampled blocks are set\n", set); back_off(); return dense(); }
 	}
 	// the device side clears while the host looks (a dense frame overwrites it all the same)
 	bool ok = hipMemsetAsync(s->d_in, 0, u->nblk * kUpBlock, s->stream) == hipSuccess;
@@ -230,9 +237,11 @@ bool upload_in(Shim *s)
 	if (failed.load()) return false;
 	if (full.load()) {
 		// (staged blocks already on their way are never put in place: the scatter kernel is not launched)
+		if (upload_debug()) fprintf(stderr, "dspfft: upload dense: a thread found more than %zu of its blocks set\n", u->share);
 		back_off();
 		return dense();
 	}
+	if (upload_debug()) { size_t n = 0; for (size_t v : used) n += v; fprintf(stderr, "dspfft: upload sparse: %zu of %zu blocks on %d threads\n", n, u->nblk, T); }
 	u->dense_streak = 0;
 	g_sparse_uploads++;
 	size_t top = 0;                                                                      // staging blocks up to the last share in use

@@ -492,32 +492,37 @@ def _band(h, w, c, frame, nframes, rng):
     return a
 
 
-@pytest.mark.parametrize("h,w,c,inplace", [(1021, 3001, 3, False), (1024, 3072, 3, True)])
-def test_sparse_upload_delivers_the_bytes_of_the_dense_copy(fftw, monkeypatch, h, w, c, inplace):
+@pytest.mark.parametrize("h,w,c,inplace,dtype", [(1021, 3001, 3, False, np.float32), (1024, 3072, 3, True, np.float32), (511, 3071, 3, False, np.float64)])
+def test_sparse_upload_delivers_the_bytes_of_the_dense_copy(fftw, monkeypatch, h, w, c, inplace, dtype):
     """scan/scan.c:429-447: `reconstruction` is mostly zeros at every execute.  Arrays of >= 32 MB go up as packed non-zero 4 KB blocks; the output must be
     bit for bit what the dense copy gives -- frame after frame through ONE plan (nothing of the previous frame may linger), with a -0.0f that is the only
     thing in its block, an array whose byte count is not a multiple of the block, a dense frame in between (dense copy, then the look-ahead backs off)."""
     fftw.dspfft_fftw_sparse_uploads.restype = C.c_ulonglong
     n = h * w * c
-    assert n * 4 >= 32 << 20 and (inplace or (n * 4) % 4096)
-    pin = fftw.fftwf_alloc_real(n)
-    pout = pin if inplace else fftw.fftwf_alloc_real(n)
-    a, b = _host_array(pin, n, np.float32), _host_array(pout, n, np.float32)
+    es = np.dtype(dtype).itemsize
+    f64 = dtype == np.float64
+    alloc, mkplan, execute, destroy, free = ((fftw.fftw_alloc_real, fftw.fftw_plan_many_r2r, fftw.fftw_execute, fftw.fftw_destroy_plan, fftw.fftw_free) if f64 else
+                                             (fftw.fftwf_alloc_real, fftw.fftwf_plan_many_r2r, fftw.fftwf_execute, fftw.fftwf_destroy_plan, fftw.fftwf_free))
+    bits = np.uint64 if f64 else np.uint32
+    assert n * es >= 32 << 20 and (inplace or (n * es) % 4096)
+    pin = alloc(n)
+    pout = pin if inplace else alloc(n)
+    a, b = _host_array(pin, n, dtype), _host_array(pout, n, dtype)
     a[:] = 0
-    plan = fftw.fftwf_plan_many_r2r(2, _ia([h, w]), c, pin, None, c, 1, pout, None, c, 1, _ia([4, 4]), 1 << 6)
+    plan = mkplan(2, _ia([h, w]), c, pin, None, c, 1, pout, None, c, 1, _ia([4, 4]), 1 << 6)
     assert plan
     rng = np.random.default_rng(h)
-    frames = [_band(h, w, c, f, 48, rng).ravel() for f in (0, 23, 47)]       # a band is 1/24 of every row it crosses: <= 2 of its 9 blocks
+    frames = [_band(h, w, c, f, 48, rng).ravel().astype(dtype) for f in (0, 23, 47)]       # a band is 1/24 of every row it crosses: <= 2 of its 9 blocks
     frames[1][-1] = 1.5                                             # the tail that does not fill a block
-    lone = np.zeros(n, np.float32); lone[n // 2] = -0.0; lone[7] = 2.0        # a block whose only set bit is a sign
-    dense = rng.standard_normal(n).astype(np.float32)
+    lone = np.zeros(n, dtype); lone[n // 2] = -0.0; lone[7] = 2.0        # a block whose only set bit is a sign
+    dense = rng.standard_normal(n).astype(dtype)
     order = [frames[0], frames[1], lone, dense, frames[2], frames[0]]
 
     def run_all():
         outs = []
         for x in order:
             a[:] = x
-            fftw.fftwf_execute(plan)
+            execute(plan)
             outs.append(b.copy())
         return outs
     monkeypatch.setenv("DSPFFT_UPLOAD_THREADS", "0")
@@ -529,13 +534,13 @@ def test_sparse_upload_delivers_the_bytes_of_the_dense_copy(fftw, monkeypatch, h
     # frames 0, 1, lone go up sparse; `dense` fills a thread's share and goes up whole; the next execute is not looked at (back-off 1); the last is
     assert fftw.dspfft_fftw_sparse_uploads() == before + 4
     for g, w_ in zip(got, want):
-        assert np.array_equal(g.view(np.uint32), w_.view(np.uint32))
+        assert np.array_equal(g.view(bits), w_.view(bits))
     # and against the oracle, once
     a[:] = frames[1]
-    fftw.fftwf_execute(plan)
+    execute(plan)
     ref = ol.dct2d_interleaved(frames[1].reshape(h, w, c).astype(np.float64), ol.REDFT01, impl="port")
-    assert np.abs(b.reshape(h, w, c) - ref).max() <= 1e-5 * np.abs(ref).max()
-    fftw.fftwf_destroy_plan(plan)
-    fftw.fftwf_free(pin)
+    assert np.abs(b.reshape(h, w, c) - ref).max() <= (1e-12 if f64 else 1e-5) * np.abs(ref).max()
+    destroy(plan)
+    free(pin)
     if not inplace:
-        fftw.fftwf_free(pout)
+        free(pout)
