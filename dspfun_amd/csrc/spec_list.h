@@ -47,7 +47,10 @@
 	X(4320, 8, 1024, 2, 12, 12, 15) \
 	X(4320, 4, 512, 2, 12, 12, 15) \
 	X(540, 16, 256, 12, 5, 9) \
-	X(256, 16, 256, 4, 4, 16) \
+	X(256, 32, 128, 16, 16) /* round 6: motion's z axis (config 5 as ONE 3-D block: 256 frames a frame apart).  128-byte segments and two stages of one radix-16
+	                           butterfly per thread: luma clip u8 -> u8 5.73 -> 4.55 ms, forward + inverse 5.40 -> 4.83 ms (K = 16 / 64 threads, 16 / 128 (8, 8, 4),
+	                           64 / 256, 32 / 256 (8, 8, 4), 64 / 512, 32 / 64 measured beside it: tools/bench_motion_3d.py, profiles/r06_motion_3d.txt) */ \
+	X(256, 16, 256, 4, 4, 16) /* inner extents that are no multiple of 32 */ \
 	X(4096, 8, 1024, 16, 16, 16) \
 	X(1080, 8, 256, 12, 10, 9) /* behind the K = 16 entry: taken only when a caller asks for it (be_find_spec's `prefer`): clip slices that the Infinity Cache holds */
 

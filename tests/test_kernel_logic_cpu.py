@@ -427,7 +427,7 @@ def test_fused_roundtrip_matches_unfused_and_oracle(case):
     L = emul()
     r2 = float(np.sqrt(2.0))
     if case.startswith("volume"):
-        d, h, w = 256, 4, 8                       # one 3-D block: z is the fused axis (COL* N=256 K=16, inner = h*w = 32)
+        d, h, w = 256, 4, 8                       # one 3-D block: z is the fused axis (COL* N=256 K=32, inner = h*w = 32: one tile)
         n, howmany, dist, bd = [d, h, w], 1, 0, d
         active, frames = (d, h, w), 1
     else:
@@ -443,6 +443,8 @@ def test_fused_roundtrip_matches_unfused_and_oracle(case):
     for a in range(rank):
         fwd.set_axis_scale0(a, 1.0, 1.0 / r2); inv.set_axis_scale0(a, r2, 1.0); ref_inv.set_axis_scale0(a, r2, 1.0)
     assert "COL*" in fwd.describe().splitlines()[-1] and "COL*" in inv.describe().splitlines()[1]
+    if case.startswith("volume"):
+        assert "N=256 K=32" in fwd.describe().splitlines()[-1]       # round 6: the 128-byte z tile where the inner extent is a multiple of 32
     flt = None
     if case == "volume":
         flt = dict(active=active, minbuf_hw=(h, w), block_depth=bd, band_begin=(0, 1, 2), band_end=(100, 4, 7), damp=0.25, boost=1.5, preserve_dc=1)

@@ -108,10 +108,14 @@ def volume_bench(torch, dist, dev, rank, world, reps, chunks=None, frames=FRAMES
         e = SlabDCT3D(FRAMES, h, w, chunks=chunks, lib=lib)
         engs.append(e)
         vols.append((torch.rand(e.dl, h, w, device=dev) * 255).floor())
-    outs = []
+    # forward() overwrites its input, so every roundtrip transforms the frames the one before returned (round 6; before that each clip paid for a
+    # clone of its 3.2 GB of frames inside the timed region: 1.4 of 9.5 ms).  The error below is the drift after ALL of them.
+    outs = [v.clone() for v in vols]
+    nround = [0]
 
     def clip3d():
-        outs[:] = [e.inverse(e.forward(v.clone())) for e, v in zip(engs, vols)]
+        outs[:] = [e.inverse(e.forward(o)) for e, o in zip(engs, outs)]
+        nround[0] += 1
 
     # two timed regions, the faster one reported: the first region of this path was seen 50 % slow on some runs (9.9 vs 15.2 ms per clip,
     # same binary; the caching allocator still carving its blocks), the second never
@@ -143,7 +147,7 @@ def volume_bench(torch, dist, dev, rank, world, reps, chunks=None, frames=FRAMES
             "exchange_ms": exchange_ms, "exchange_bytes_sent_per_rank": exchange_bytes, "xgmi_GBps_sent_per_rank": xgmi_gbps, "xgmi_frac": xgmi_frac,
             "exchange_note": "exchange_ms = the all-to-alls of ONE direction of the three planes (half of a clip's), alone on the links; xgmi_frac = bytes this rank "
                              "sent to the other ranks / exchange time / (7 links x 76.8 GB/s per direction); null with one rank (no exchange)",
-            "max_abs_roundtrip_error_0_255": err,
+            "max_abs_roundtrip_error_0_255": err, "roundtrips_behind_that_error": nround[0],
             "parallelism": f"slab x{world}: 2 all-to-alls per plane roundtrip (RCCL), pipelined in {engs[0].P} row pieces"}
 
 
