@@ -11,8 +11,8 @@
 	X(7680, 3, 1024, 16, 15, 16)        \
 	X(960, 3, 192, 2, 16, 15)          \
 	X(256, 3, 192, 8, 16)              \
-	X(1920, 1, 128, 4, 16, 15)         \
-	X(960, 1, 64, 2, 16, 15)           \
+	X(1920, 1, 128, 8, 8, 15)          /* round 6: (4, 16, 15) left 60 of the 128 threads busy in its radix-16 stage; motion's clip (Y + U + V) 4.05 -> 3.97 ms with this and */ \
+	X(960, 1, 64, 4, 8, 15)            /* (2, 16, 15) -> (4, 8, 15) for the chroma lines; (8, 10, 12), (10, 12, 8), (6, 10, 16) / (8, 4, 15), (8, 6, 10) measured beside them */ \
 	X(4096, 3, 512, 8, 16, 16)         \
 	X(2560, 3, 512, 8, 10, 16)         \
 	X(2048, 3, 256, 4, 16, 16)         \

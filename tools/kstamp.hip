@@ -143,7 +143,7 @@ int main(int argc, char **argv)
 	}
 	if (strstr(which, "u8")) {
 		// motion config 5's 8-bit row ends on the luma clip: 256 x 1080 lines of 1920 samples
-		typedef RowSpec<1920, 1, 128, 4, 16, 15> S;
+		typedef RowSpec<1920, 1, 128, 8, 8, 15> S;
 		const int w = 1920, lines = 1080 * 256;
 		uint8_t *p8; float *pf32;
 		CK(hipMalloc(&p8, (size_t)w * lines)); CK(hipMalloc(&pf32, (size_t)w * lines * 4));
