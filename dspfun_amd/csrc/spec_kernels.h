@@ -297,10 +297,10 @@ int launch_czt_spectrum(const CztArgs &a, cf *hspec, void *stream)
 // the same with 8-bit input (REDFT10) or quantised 8-bit output (REDFT01): planar rows only
 // Short lines (motion's 1920 / 960 sample rows: two waves a line, 8 KB of LDS) are asked to fit 64 registers so that eight waves share a SIMD: their phases are
 // a few hundred cycles of work each between barriers and global accesses, and only other workgroups fill the gaps (REDFT10 of config 5's luma clip,
-// kernel alone: 896 -> 813 us; 74 -> 64 VGPRs, no scratch).  Asked per (line, kind) where the kernel FITS 64 registers: 960-sample REDFT10 lines (config 5's
-// chroma rows, one wave a line, 15 samples a thread beside a radix-16 butterfly) spilled 2 registers = 12 bytes of scratch per lane there (at seven waves too) and get
-// six waves (80 registers); longer lines keep the allocator's choice (at 64 they spill).  `make -C dspfun_amd/csrc check-scratch` fails on scratch in these kernels.
-template <class S, int KIND> constexpr int u8_waves_per_simd() { return S::N >= 2048 ? S::WPE : (S::N == 960 && KIND == KIND_REDFT10) ? 6 : 8; }
+// kernel alone: 896 -> 813 us; 74 -> 64 VGPRs, no scratch).  Asked where the kernel FITS 64 registers: longer lines keep the allocator's choice (at 64 they spill), and
+// `make -C dspfun_amd/csrc check-scratch` fails on scratch in these kernels.  (960-sample REDFT10 lines spilled 12 bytes a lane beside the radix-16 butterfly of their
+// round-5 radices (2, 16, 15) and ran at six waves; with (4, 8, 15) they fit -- six or eight waves measure the same, 3.91-3.94 ms per clip.)
+template <class S, int KIND> constexpr int u8_waves_per_simd() { return S::N >= 2048 ? S::WPE : 8; }
 template <class S, int KIND>
 __global__ void __launch_bounds__(S::T, (u8_waves_per_simd<S, KIND>())) row_spec_u8_kernel(const typename S::PA a_, const U8IO io_)
 {
